@@ -1,0 +1,119 @@
+/* include/uvol_codec.h — C ABI of the MI355X-native UVOL codec (libuvolcodec.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of EtherealEngine/Universal-Volumetric:
+ * the per-frame geometry + texture encode that scripts/Encoder.py performs by spawning two
+ * external processes,
+ *     draco_encoder -i f.obj -o f.drc -qp 11 -qt 10 -qn 8 -qg 8 -cl 7      (scripts/Encoder.py:260-262)
+ *     basisu -ktx2 -tex_type video -multifile_printf P -multifile_num B -multifile_first i -y_flip
+ *            -output_file texture_%07u.ktx2                                  (scripts/Encoder.py:290-292)
+ * Every entry point below replaces one of those process boundaries with an in-process call that
+ * runs hand-written HIP kernels on gfx950.  Conventions follow the reference's own in-repo C-ABI
+ * precedent (deprecated/encoder_legacy/codec/corto_codec.h:41-43): opaque handle, caller-owned
+ * buffers, int status, no exceptions, no torch types.
+ *
+ * Threading: a ctx is bound to one GPU and one HIP stream; it is NOT thread-safe.  Different
+ * ctxs may be used from different threads / processes (one process per GPU in bench.py).
+ * There is NO CPU fallback: uvol_ctx_create fails with UVOL_E_NODEVICE when no gfx950 GPU is present.
+ */
+#ifndef UVOL_CODEC_H
+#define UVOL_CODEC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVOL_ABI_VERSION 1
+
+enum {
+  UVOL_OK = 0,
+  UVOL_E_INVALID = -1,     /* bad argument */
+  UVOL_E_NODEVICE = -2,    /* no usable HIP device (fails loudly, never falls back to CPU) */
+  UVOL_E_HIP = -3,         /* HIP runtime error, see uvol_last_error */
+  UVOL_E_NOSPACE = -4,     /* caller output buffer too small (out_len holds the required size) */
+  UVOL_E_ENCODE = -5,      /* per-frame encode failure (bad indices, empty mesh, ...) */
+  UVOL_E_UNSUPPORTED = -6
+};
+
+/* Mirrors the numeric project-config.json fields consumed on the hot path
+ * (scripts/Encoder.py:171-179 template, :260 and :290 use sites; defaults identical). */
+typedef struct uvol_params {
+  int32_t q_position_attr;          /* Q_POSITION_ATTR,         default 11 */
+  int32_t q_texture_attr;           /* Q_TEXTURE_ATTR,          default 10 */
+  int32_t q_normal_attr;            /* Q_NORMAL_ATTR,           default 8  */
+  int32_t q_generic_attr;           /* Q_GENERIC_ATTR,          default 8 (accepted, unused: no generic attribute on this ABI) */
+  int32_t draco_compression_level;  /* DRACO_COMPRESSION_LEVEL, default 7 (only the cl 7 tool-set is implemented) */
+  int32_t ktx2_batch_size;          /* KTX2_BATCH_SIZE (mandatory in the reference) = layers per .ktx2 */
+  int32_t etc1s_quality;            /* basisu -q equivalent, 1..255, default 128 (Encoder.py passes none) */
+  int32_t y_flip;                   /* basisu -y_flip (Encoder.py:290 always passes it), default 1 */
+  int32_t max_batch;                /* frames in flight per geometry batch, default 32 */
+  int32_t reserved[7];
+} uvol_params;
+
+void uvol_params_default(uvol_params *p);
+
+typedef struct uvol_ctx uvol_ctx;
+
+int  uvol_abi_version(void);
+int  uvol_device_count(void);
+/* device = HIP ordinal. Returns UVOL_OK and *out on success. */
+int  uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out);
+void uvol_ctx_destroy(uvol_ctx *ctx);
+const char *uvol_last_error(const uvol_ctx *ctx);
+int  uvol_sync(uvol_ctx *ctx);
+
+/* One frame of OBJ-shaped geometry: separate value arrays + per-corner index triplets
+ * (what draco_encoder parses out of `v/vt/vn/f` lines).  uv / nrm (and their index arrays) may be
+ * NULL.  Pointers are HOST pointers for uvol_encode_mesh* and DEVICE pointers for *_dev. */
+typedef struct uvol_mesh {
+  const float    *pos;      uint32_t n_pos;    /* n_pos * 3 */
+  const float    *uv;       uint32_t n_uv;     /* n_uv  * 2 */
+  const float    *nrm;      uint32_t n_nrm;    /* n_nrm * 3 */
+  const uint32_t *idx_pos;                     /* 3 * n_faces */
+  const uint32_t *idx_uv;                      /* 3 * n_faces or NULL */
+  const uint32_t *idx_nrm;                     /* 3 * n_faces or NULL */
+  uint32_t        n_faces;
+} uvol_mesh;
+
+/* Upper bound of the .drc size for a mesh (use to size `out`). */
+size_t uvol_mesh_bound(const uvol_mesh *m);
+
+/* Replaces one `draco_encoder` process (scripts/Encoder.py:260-262): OBJ arrays -> .drc bytes. */
+int uvol_encode_mesh(uvol_ctx *ctx, const uvol_mesh *mesh, uint8_t *out, size_t cap, size_t *out_len);
+
+/* Batched form of HOT LOOP 1 (scripts/Encoder.py:256-267): n independent frames, all in flight on
+ * the GPU at once (one serial connectivity walker per frame, parallel kernels batched over frames).
+ * status[i] is the per-frame result; a failed frame does not poison the batch. */
+int uvol_encode_mesh_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
+                           uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+/* Same with inputs already resident in HBM (device pointers inside `meshes`; `meshes` itself is a host array). */
+int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
+                               uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+
+/* Replaces one `basisu -ktx2 -tex_type video` process (scripts/Encoder.py:290-292):
+ * n_layers RGBA8 images (width*height*4 bytes each, top row first as a PNG decoder yields them)
+ * -> one ETC1S/BasisLZ .ktx2 with n_layers array layers (layer 0 I-frame, others P-frames). */
+size_t uvol_texture_bound(uint32_t width, uint32_t height, int n_layers);
+int uvol_encode_texture_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers,
+                                uint32_t width, uint32_t height,
+                                uint8_t *out, size_t cap, size_t *out_len);
+/* Same with the layers already resident in HBM (array of device pointers). */
+int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_layers,
+                                    uint32_t width, uint32_t height,
+                                    uint8_t *out, size_t cap, size_t *out_len);
+
+/* ---- measurement hooks (bench.py / rocprof cross-check) ---- */
+/* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
+int uvol_profile_enable(uvol_ctx *ctx, int on);
+int uvol_profile_reset(uvol_ctx *ctx);
+/* Number of distinct kernel groups recorded so far. */
+int uvol_profile_count(uvol_ctx *ctx);
+/* name/launch-count/total-ms/algorithmic-bytes of group i. */
+int uvol_profile_get(uvol_ctx *ctx, int i, char *name, size_t name_cap,
+                     uint64_t *launches, double *total_ms, uint64_t *algo_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVOL_CODEC_H */

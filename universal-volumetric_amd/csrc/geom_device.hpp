@@ -1,0 +1,170 @@
+// geom_device.hpp — device-side data model + small device helpers of the geometry (.drc) pipeline.
+//
+// Replaces the arithmetic of one `draco_encoder -qp -qt -qn -cl 7` process (scripts/Encoder.py:260)
+// with a batch of frames resident in HBM.  Bitstream layout: SURVEY.md Appendix A (Draco 2.2,
+// edgebreaker + valence traversal); encoder-side rules: SURVEY.md A.10.
+//
+// Data layout in HBM: one GeoJob per frame; every per-corner array is a flat SoA int32/uint8
+// array of 3*F entries so that consecutive lanes touch consecutive addresses in the parallel
+// kernels (dedup, corner table, fans, seams, quantise, predictors, histograms, gather).  The three
+// inherently serial walkers (edgebreaker, attribute DFS, rANS/rabs state machines) run one frame /
+// stream per workgroup, so a batch of N frames keeps N (or 9N / 5N) CUs busy at once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#define GEO_NSTREAM 9     // rANS streams: 6 valence contexts, position, uv, normal
+#define GEO_NRABS 5       // rabs streams: start faces, seam uv, seam normal, uv orientations, normal flips
+#define GEO_MAXPIECES 64
+
+struct RansStream {
+  const uint32_t *syms;   // symbols (device)
+  uint32_t n;             // number of symbols
+  uint32_t *freq;         // [alpha_cap] histogram (zeroed per batch)
+  uint32_t *probs;        // [alpha_cap]
+  uint32_t *cum;          // [alpha_cap]
+  uint32_t *scratch;      // counting-sort scratch [(1<<20)+alpha_cap] shared per job
+  uint32_t alpha_cap;
+  uint32_t max_sym;       // atomicMax target
+  uint32_t prec_bits;
+  uint8_t *head;  uint32_t head_len;      // scheme, bl, varint(ns), table
+  uint8_t *pay;   uint32_t pay_cap;       // [8 bytes reserved for varint(len)] payload
+  uint32_t pay_off, pay_len;              // piece = pay + pay_off, length pay_len (varint + payload)
+};
+
+struct RabsStream {
+  const uint8_t *bits; uint32_t n; uint32_t zeros;
+  uint8_t *buf; uint32_t cap; uint32_t off, len;   // piece = buf + off
+};
+
+struct GeoJob {
+  // ---- inputs (device pointers) ----
+  const float *pos, *uv, *nrm;
+  const uint32_t *ipos, *iuv, *inrm;
+  uint32_t n_pos, n_uv, n_nrm, nf_in;
+  int32_t has_uv, has_nrm, nad;
+  int32_t qp, qt, qn;
+  // ---- state ----
+  int32_t status;
+  uint32_t nf, nc, nverts;
+  int32_t nsym, nsplit, nev, nstart, ninit;
+  uint32_t interior_seams[2];
+  int32_t att_kind[2];          // 0 uv, 1 normal, per attribute-data slot
+  uint32_t n_elig;              // seam-bit count
+  uint32_t ne[3];               // entries: base, att0, att1 (att uses base when no interior seams)
+  uint32_t n_ori, ne_uv, ne_nrm;
+  uint32_t pos_min_u[3], pos_max_u[3], uv_min_u[2], uv_max_u[2];   // orderable-float encodings
+  int32_t wrap_lo[2], wrap_hi[2];                                  // [0]=pos, [1]=uv
+  uint32_t out_len;
+  // ---- workspace ----
+  uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3];
+  uint64_t *e_key; uint32_t *e_val; uint32_t e_cap;
+  uint8_t *keep; uint32_t *bsum;      // scan scratch (max(nf_in, nc)/256 + 1)
+  int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
+  int32_t *opp, *vert, *ring; uint8_t *vopen;
+  uint8_t *fvis, *vvis; int32_t *vval, *c2vm, *f2split, *proc, *initc, *stack;
+  int32_t *ev_src, *ev_spl; uint8_t *ev_edge;
+  uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
+  uint8_t *start_bits;
+  int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert; uint8_t *bopen;
+  uint8_t *seam[2]; uint8_t *elig; uint8_t *seam_bits[2];
+  int32_t *avert[2]; uint8_t *aopen[2];
+  int32_t *order[3], *v2d[3]; uint8_t *t_fvis[3], *t_vvis[3]; int32_t *t_stack[3];
+  int32_t *P, *U, *O;
+  uint32_t *sym_pos, *sym_uv, *sym_nrm;
+  uint8_t *has_ori, *ori_val, *ori_c, *ori_bits, *flips;
+  RansStream rs[GEO_NSTREAM];
+  RabsStream rb[GEO_NRABS];
+  uint8_t *arena; uint32_t arena_cap;
+  const uint8_t *piece_ptr[GEO_MAXPIECES]; uint32_t piece_len[GEO_MAXPIECES], piece_off[GEO_MAXPIECES]; uint32_t n_pieces;
+  uint8_t *out; uint32_t out_cap;
+};
+
+#define GEO_INV (-1)
+__device__ __host__ __forceinline__ uint32_t uvol_blocks_dev(uint32_t n) { return (n + 255u) / 256u; }
+__device__ __host__ __forceinline__ int g_nxt(int c) { return (c % 3 == 2) ? c - 2 : c + 1; }
+__device__ __host__ __forceinline__ int g_prv(int c) { return (c % 3 == 0) ? c + 2 : c - 1; }
+
+__device__ __forceinline__ uint64_t g_mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
+}
+__device__ __forceinline__ uint32_t g_float_order(float f) {
+  uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __host__ __forceinline__ float g_float_unorder(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &u, 4); return f;
+}
+
+// seam-masked corner-table view
+struct GTab { const int32_t *opp; const uint8_t *seam; };
+__device__ __forceinline__ int gt_opp(const GTab &t, int c) { if (c < 0) return GEO_INV; if (t.seam && t.seam[c]) return GEO_INV; return t.opp[c]; }
+__device__ __forceinline__ int gt_swl(const GTab &t, int c) { int o = gt_opp(t, g_nxt(c)); return o < 0 ? GEO_INV : g_nxt(o); }
+__device__ __forceinline__ int gt_swr(const GTab &t, int c) { int o = gt_opp(t, g_prv(c)); return o < 0 ? GEO_INV : g_prv(o); }
+
+// exact floor(sqrt(n)) for n < 2^63 (draco IntSqrt contract)
+__device__ __forceinline__ uint64_t g_isqrt(uint64_t n) {
+  if (n == 0) return 0;
+  uint64_t r = (uint64_t)sqrt((double)n);
+  while (r * r > n) r--;
+  while ((r + 1) * (r + 1) <= n) r++;
+  return r;
+}
+
+// ---- octahedral toolbox ----
+struct GOct { int MAXQ, MAXV, CEN; };
+__device__ __forceinline__ GOct g_oct(int q) { GOct t; t.MAXQ = (1 << q) - 1; t.MAXV = t.MAXQ - 1; t.CEN = t.MAXV / 2; return t; }
+__device__ __forceinline__ int g_iabs(int x) { return x < 0 ? -x : x; }
+__device__ __forceinline__ long long g_labs(long long x) { return x < 0 ? -x : x; }
+__device__ inline void g_oct_canon(const GOct &t, int &s, int &tt) {
+  if ((s == 0 && tt == 0) || (s == 0 && tt == t.MAXV) || (s == t.MAXV && tt == 0)) { s = t.MAXV; tt = t.MAXV; return; }
+  if (s == 0 && tt > t.CEN) tt = t.CEN - (tt - t.CEN);
+  else if (s == t.MAXV && tt < t.CEN) tt = t.CEN + (t.CEN - tt);
+  else if (tt == t.MAXV && s < t.CEN) s = t.CEN + (t.CEN - s);
+  else if (tt == 0 && s > t.CEN) s = t.CEN - (s - t.CEN);
+}
+__device__ inline void g_vec_to_oct(const GOct &t, const int v[3], int &s, int &tt) {
+  if (v[0] >= 0) { s = v[1] + t.CEN; tt = v[2] + t.CEN; }
+  else { s = v[1] < 0 ? g_iabs(v[2]) : t.MAXV - g_iabs(v[2]); tt = v[2] < 0 ? g_iabs(v[1]) : t.MAXV - g_iabs(v[1]); }
+  g_oct_canon(t, s, tt);
+}
+__device__ inline void g_invert_diamond(const GOct &t, int &s, int &tt) {
+  int ss, st;
+  if (s >= 0 && tt >= 0) { ss = 1; st = 1; } else if (s <= 0 && tt <= 0) { ss = -1; st = -1; } else { ss = s > 0 ? 1 : -1; st = tt > 0 ? 1 : -1; }
+  int cs = ss * t.CEN, ct = st * t.CEN, us = 2 * s - cs, ut = 2 * tt - ct;
+  if (ss * st >= 0) { int tmp = us; us = -ut; ut = -tmp; } else { int tmp = us; us = ut; ut = tmp; }
+  us += cs; ut += ct; s = us / 2; tt = ut / 2;
+}
+__device__ __forceinline__ int g_rot_count(int x, int y) {
+  if (x == 0) return y == 0 ? 0 : (y > 0 ? 3 : 1);
+  if (x > 0) return y >= 0 ? 2 : 1;
+  return y <= 0 ? 0 : 3;
+}
+__device__ __forceinline__ void g_rot(int &x, int &y, int c) {
+  int X = x, Y = y;
+  if (c == 1) { x = Y; y = -X; } else if (c == 2) { x = -X; y = -Y; } else if (c == 3) { x = -Y; y = X; }
+}
+__device__ __forceinline__ int g_modmax(const GOct &t, int x) { if (x > t.CEN) return x - t.MAXQ; if (x < -t.CEN) return x + t.MAXQ; return x; }
+__device__ inline void g_oct_corr(const GOct &t, const int orig[2], const int pred[2], int corr[2]) {
+  int os = orig[0] - t.CEN, ot = orig[1] - t.CEN, ps = pred[0] - t.CEN, pt = pred[1] - t.CEN;
+  if (g_iabs(ps) + g_iabs(pt) > t.CEN) { g_invert_diamond(t, os, ot); g_invert_diamond(t, ps, pt); }
+  bool bl = (ps == 0 && pt == 0) || (ps < 0 && pt <= 0);
+  if (!bl) { int rc = g_rot_count(ps, pt); g_rot(os, ot, rc); g_rot(ps, pt, rc); }
+  corr[0] = os - ps; corr[1] = ot - pt;
+  if (corr[0] < 0) corr[0] += t.MAXQ;
+  if (corr[1] < 0) corr[1] += t.MAXQ;
+}
+
+__device__ __forceinline__ uint32_t g_sym_of(int v) { return v >= 0 ? ((uint32_t)v << 1) : ((((uint32_t)(-(v + 1))) << 1) | 1u); }
+__device__ __forceinline__ int g_wrap_corr(int lo, int hi, int orig, long long pred) {
+  int max_dif = 1 + hi - lo, max_corr = max_dif / 2, min_corr = -max_corr;
+  if ((max_dif & 1) == 0) max_corr -= 1;
+  int p = pred < lo ? lo : (pred > hi ? hi : (int)pred);
+  int c = orig - p;
+  if (c < min_corr) c += max_dif; else if (c > max_corr) c -= max_dif;
+  return c;
+}
+
+__device__ __forceinline__ uint32_t g_put_varint(uint8_t *p, uint64_t v) {
+  uint32_t n = 0; while (v >= 0x80) { p[n++] = (uint8_t)(v | 0x80); v >>= 7; } p[n++] = (uint8_t)v; return n;
+}
+__device__ __forceinline__ uint32_t g_varint_len(uint64_t v) { uint32_t n = 1; while (v >= 0x80) { n++; v >>= 7; } return n; }

@@ -1,0 +1,124 @@
+// uvol_api.cpp — the extern "C" surface declared in include/uvol_codec.h.
+// Each entry point replaces a process boundary of scripts/Encoder.py (:260-262 draco_encoder,
+// :290-292 basisu); see the header for the mapping.  No CPU fallback: without a HIP device
+// uvol_ctx_create returns UVOL_E_NODEVICE.
+#include "uvol_common.hpp"
+#include <new>
+
+extern "C" {
+
+void uvol_params_default(uvol_params *p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->q_position_attr = 11; p->q_texture_attr = 10; p->q_normal_attr = 8; p->q_generic_attr = 8;
+  p->draco_compression_level = 7; p->ktx2_batch_size = 5; p->etc1s_quality = 128; p->y_flip = 1; p->max_batch = 32;
+}
+
+int uvol_abi_version(void) { return UVOL_ABI_VERSION; }
+
+int uvol_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
+  if (!out) return UVOL_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UVOL_E_NODEVICE;
+  if (device < 0 || device >= n) return UVOL_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return UVOL_E_HIP;
+  uvol_ctx *ctx = new (std::nothrow) uvol_ctx();
+  if (!ctx) return UVOL_E_HIP;
+  ctx->device = device;
+  if (params) ctx->prm = *params; else uvol_params_default(&ctx->prm);
+  if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
+  if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
+  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
+  *out = ctx;
+  return UVOL_OK;
+}
+
+void uvol_ctx_destroy(uvol_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->resolve_profile();
+  geo_destroy(ctx); tex_destroy(ctx);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *uvol_last_error(const uvol_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int uvol_sync(uvol_ctx *ctx) {
+  if (!ctx) return UVOL_E_INVALID;
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->resolve_profile();
+  return UVOL_OK;
+}
+
+static int encode_batch_common(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool dev,
+                               uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  if (!ctx || !meshes || n < 0 || !outs || !caps || !out_lens) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  const int mb = ctx->prm.max_batch;
+  for (int b0 = 0; b0 < n; b0 += mb) {
+    const int nb = n - b0 < mb ? n - b0 : mb;
+    int rc = geo_encode_batch(ctx, meshes + b0, nb, dev, outs + b0, caps + b0, out_lens + b0, status ? status + b0 : nullptr);
+    if (rc != UVOL_OK) return rc;
+  }
+  return UVOL_OK;
+}
+
+int uvol_encode_mesh(uvol_ctx *ctx, const uvol_mesh *mesh, uint8_t *out, size_t cap, size_t *out_len) {
+  if (!ctx || !mesh || !out || !out_len) return UVOL_E_INVALID;
+  int st = 0;
+  int rc = encode_batch_common(ctx, mesh, 1, false, &out, &cap, out_len, &st);
+  return rc != UVOL_OK ? rc : st;
+}
+
+int uvol_encode_mesh_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps,
+                           size_t *out_lens, int *status) {
+  return encode_batch_common(ctx, meshes, n, false, outs, caps, out_lens, status);
+}
+
+int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps,
+                               size_t *out_lens, int *status) {
+  return encode_batch_common(ctx, meshes, n, true, outs, caps, out_lens, status);
+}
+
+int uvol_encode_texture_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t width, uint32_t height,
+                                uint8_t *out, size_t cap, size_t *out_len) {
+  if (!ctx || !rgba || n_layers <= 0 || !out || !out_len || width == 0 || height == 0) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_encode_segment(ctx, rgba, n_layers, width, height, false, out, cap, out_len);
+}
+
+int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_layers, uint32_t width, uint32_t height,
+                                    uint8_t *out, size_t cap, size_t *out_len) {
+  if (!ctx || !rgba_dev || n_layers <= 0 || !out || !out_len || width == 0 || height == 0) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_encode_segment(ctx, rgba_dev, n_layers, width, height, true, out, cap, out_len);
+}
+
+int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; ctx->profiling = on != 0; return UVOL_OK; }
+int uvol_profile_reset(uvol_ctx *ctx) {
+  if (!ctx) return UVOL_E_INVALID;
+  (void)hipStreamSynchronize(ctx->stream); ctx->resolve_profile(); ctx->prof.clear(); return UVOL_OK;
+}
+int uvol_profile_count(uvol_ctx *ctx) { if (!ctx) return 0; ctx->resolve_profile(); return (int)ctx->prof.size(); }
+int uvol_profile_get(uvol_ctx *ctx, int i, char *name, size_t name_cap, uint64_t *launches, double *total_ms, uint64_t *algo_bytes) {
+  if (!ctx || i < 0 || i >= (int)ctx->prof.size()) return UVOL_E_INVALID;
+  const uvol_prof_entry &e = ctx->prof[i];
+  if (name && name_cap) { strncpy(name, e.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (launches) *launches = e.launches;
+  if (total_ms) *total_ms = e.total_ms;
+  if (algo_bytes) *algo_bytes = e.algo_bytes;
+  return UVOL_OK;
+}
+
+}  // extern "C"

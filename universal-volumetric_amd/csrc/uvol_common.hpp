@@ -1,0 +1,105 @@
+// uvol_common.hpp — shared host-side plumbing of libuvolcodec (ctx, error handling, device arena,
+// per-kernel-group hipEvent profiling).  gfx950 only; no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/uvol_codec.h"
+
+#define UVOL_BLOCK 256
+
+#define UVOL_HIP_CHECK(ctx, expr)                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return UVOL_E_HIP;                                                                           \
+    }                                                                                              \
+  } while (0)
+
+struct uvol_prof_entry {
+  std::string name;
+  uint64_t launches = 0;
+  double total_ms = 0;
+  uint64_t algo_bytes = 0;
+};
+struct uvol_prof_pending { int idx; hipEvent_t a, b; };
+
+// A growable device allocation that is re-used across calls (no hipMalloc in the steady state).
+struct uvol_devbuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct GeoState;   // geometry pipeline state (geom_encode.hip)
+struct TexState;   // texture pipeline state (tex_encode.hip)
+
+struct uvol_ctx {
+  int device = 0;
+  uvol_params prm{};
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  bool profiling = false;
+  std::vector<uvol_prof_entry> prof;
+  std::vector<uvol_prof_pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  GeoState *geo = nullptr;
+  TexState *tex = nullptr;
+
+  void set_error(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(err, sizeof(err), fmt, ap); va_end(ap);
+  }
+  int prof_index(const char *name) {
+    for (size_t i = 0; i < prof.size(); i++) if (prof[i].name == name) return (int)i;
+    prof.push_back({name, 0, 0.0, 0});
+    return (int)prof.size() - 1;
+  }
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return e;
+  }
+  // bracket a kernel group; resolved lazily at the next sync
+  struct Scope {
+    uvol_ctx *c; int idx; hipEvent_t a = nullptr, b = nullptr;
+    Scope(uvol_ctx *ctx, const char *name, uint64_t algo_bytes) : c(ctx), idx(-1) {
+      if (!c->profiling) return;
+      idx = c->prof_index(name); c->prof[idx].launches++; c->prof[idx].algo_bytes += algo_bytes;
+      a = c->get_event(); b = c->get_event();
+      if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~Scope() { if (idx >= 0 && a && b) { (void)hipEventRecord(b, c->stream); c->pending.push_back({idx, a, b}); } }
+  };
+  void resolve_profile() {
+    for (auto &p : pending) {
+      float ms = 0;
+      if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) prof[p.idx].total_ms += ms;
+      event_pool.push_back(p.a); event_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+static inline int uvol_ensure(uvol_ctx *ctx, uvol_devbuf &b, size_t bytes) {
+  if (bytes <= b.cap) return UVOL_OK;
+  if (b.p) { UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); UVOL_HIP_CHECK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + bytes / 8 + 4096;
+  UVOL_HIP_CHECK(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return UVOL_OK;
+}
+
+static inline unsigned uvol_blocks(size_t n, unsigned bs = UVOL_BLOCK) { return (unsigned)((n + bs - 1) / bs); }
+
+// pipeline entry points implemented in the .hip translation units
+int geo_create(uvol_ctx *ctx);
+void geo_destroy(uvol_ctx *ctx);
+int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_on_device,
+                     uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+int tex_create(uvol_ctx *ctx);
+void tex_destroy(uvol_ctx *ctx);
+int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t w, uint32_t h,
+                       bool inputs_on_device, uint8_t *out, size_t cap, size_t *out_len);

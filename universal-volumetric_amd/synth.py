@@ -1,0 +1,184 @@
+"""synth.py — seeded synthetic UVOL frames: OBJ-shaped meshes and RGBA8 textures.
+
+Geometry: displaced UV-sphere "body" in millimetres (bbox ~0.6 x 1.8 x 0.5 m like the reference
+fixture, example/src/VolumetricPlayer.tsx:180 scales by 0.001), closed manifold, UV atlas cut into
+rectangular charts (so UV seams exist), per-vertex normals plus one hard crease ring (so the normal
+attribute has a few seams, like the fixtures' 25 seam corners).
+Texture: multi-octave value noise over ~70 % of the image, flat black background, frame-to-frame
+change confined to ~30 % of the 4x4 blocks.
+"""
+import numpy as np
+
+
+def sphere_mesh(n_seg=400, n_ring=251, frame=0, charts=(40, 25), seed=0, crease=True):
+    """Closed UV-sphere: V = n_seg*(n_ring-1)+2, F = 2*n_seg*(n_ring-1).
+    Defaults give V=100,002 / F=200,000 (BASELINE config); (283,177) -> ~50k verts."""
+    rng = np.random.default_rng(seed)
+    nr = n_ring - 1                                   # interior rings
+    th = (np.arange(n_seg) / n_seg) * 2 * np.pi       # longitude
+    ph = (np.arange(1, n_ring) / n_ring) * np.pi      # colatitude, poles excluded
+    T, Pp = np.meshgrid(th, ph)                       # (nr, n_seg)
+    t = frame * 0.07
+    rad = 1.0 + 0.08 * np.sin(3 * T + t) * np.sin(2 * Pp) + 0.05 * np.cos(5 * Pp - 2 * t) + 0.02 * np.sin(9 * T + 7 * Pp + 3 * t)
+    x = 300.0 * rad * np.sin(Pp) * np.cos(T)
+    y = 900.0 + 880.0 * rad * np.cos(Pp)
+    z = -300.0 + 250.0 * rad * np.sin(Pp) * np.sin(T)
+    body = np.stack([x, y, z], -1).reshape(-1, 3)
+    jitter = rng.standard_normal(body.shape).astype(np.float32) * 0.15
+    top = np.array([[0.0, 900.0 + 880.0 * (1.0 + 0.05 * np.cos(-2 * t)), -300.0]])
+    bot = np.array([[0.0, 900.0 - 880.0 * (1.0 + 0.05 * np.cos(5 * np.pi - 2 * t)), -300.0]])
+    pos = np.concatenate([body + jitter, top, bot]).astype(np.float32)
+    i_top, i_bot = nr * n_seg, nr * n_seg + 1
+
+    def vid(r, s):
+        return r * n_seg + (s % n_seg)
+
+    faces = []
+    r = np.arange(nr - 1)[:, None]; s = np.arange(n_seg)[None, :]
+    a = vid(r, s); b = vid(r, s + 1); c = vid(r + 1, s); d = vid(r + 1, s + 1)
+    quads1 = np.stack([a, c, b], -1).reshape(-1, 3)
+    quads2 = np.stack([b, c, d], -1).reshape(-1, 3)
+    body_f = np.empty((quads1.shape[0] * 2, 3), dtype=np.int64)
+    body_f[0::2] = quads1; body_f[1::2] = quads2
+    s1 = np.arange(n_seg)
+    cap_top = np.stack([np.full(n_seg, i_top), vid(0, s1), vid(0, s1 + 1)], -1)
+    cap_bot = np.stack([np.full(n_seg, i_bot), vid(nr - 1, s1 + 1), vid(nr - 1, s1)], -1)
+    idx_pos = np.concatenate([cap_top, body_f, cap_bot]).astype(np.uint32)
+    nf = len(idx_pos)
+
+    # ---- UV atlas: charts over (segment, ring) space; every face gets the chart of its low corner ----
+    cs, cr = charts
+    seg_per = max(1, n_seg // cs); ring_per = max(1, nr // cr)
+    # face -> (r0, s0) lattice cell
+    fr = np.concatenate([np.zeros(n_seg, int), np.repeat(np.arange(nr - 1), 2 * n_seg), np.full(n_seg, nr - 1)])
+    fs = np.concatenate([s1, np.repeat(np.tile(s1, nr - 1), 2).reshape(nr - 1, n_seg, 2).reshape(-1) if False else np.tile(np.repeat(s1, 2), nr - 1), s1])
+    chart_s = np.minimum(fs // seg_per, cs - 1); chart_r = np.minimum(fr // ring_per, cr - 1)
+    chart = chart_r * cs + chart_s
+    # per-corner lattice coordinates (unwrapped in s so a chart never straddles the 2*pi seam)
+    pr = np.where(idx_pos >= nr * n_seg, -1, idx_pos // n_seg).astype(np.int64)
+    ps = (idx_pos % n_seg).astype(np.int64)
+    ps = np.where((ps < fs[:, None]) & (idx_pos < nr * n_seg), ps + n_seg, ps)        # wrap-around column
+    pole_top = idx_pos == i_top; pole_bot = idx_pos == i_bot
+    pr = np.where(pole_top, -1, np.where(pole_bot, nr, pr)); ps = np.where(pole_top | pole_bot, fs[:, None], ps)
+    cell_w, cell_h = 1.0 / cs, 1.0 / cr
+    u = (chart_s[:, None] + 0.04 + 0.92 * (ps - chart_s[:, None] * seg_per) / (seg_per + (n_seg - cs * seg_per) + 1)) * cell_w
+    v = (chart_r[:, None] + 0.04 + 0.92 * (pr + 1 - chart_r[:, None] * ring_per) / (ring_per + (nr - cr * ring_per) + 2)) * cell_h
+    key = (chart[:, None].astype(np.int64) << 40) | ((pr + 1).astype(np.int64) << 20) | ps.astype(np.int64)
+    uniq, inv = np.unique(key.reshape(-1), return_inverse=True)
+    uv = np.zeros((len(uniq), 2), dtype=np.float32)
+    uv[inv, 0] = u.reshape(-1); uv[inv, 1] = v.reshape(-1)
+    idx_uv = inv.reshape(nf, 3).astype(np.uint32)
+
+    # ---- normals: area-weighted per vertex + noise; optional hard crease along the middle ring ----
+    P = pos.astype(np.float64)
+    fn = np.cross(P[idx_pos[:, 1]] - P[idx_pos[:, 0]], P[idx_pos[:, 2]] - P[idx_pos[:, 0]])
+    vn = np.zeros_like(P)
+    for k in range(3):
+        np.add.at(vn, idx_pos[:, k], fn)
+    vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-12)
+    vn += rng.standard_normal(vn.shape) * 0.02
+    vn /= np.linalg.norm(vn, axis=1, keepdims=True)
+    nrm = vn.astype(np.float32)
+    idx_nrm = idx_pos.copy()
+    if crease:
+        rc = nr // 2                                  # faces below ring rc use a second normal set on that ring
+        ring_ids = vid(rc, s1)
+        extra = nrm[ring_ids] * np.float32(0.7) + np.array([0, -0.7, 0], dtype=np.float32)
+        extra /= np.linalg.norm(extra, axis=1, keepdims=True)
+        base = len(nrm); nrm = np.concatenate([nrm, extra.astype(np.float32)])
+        remap = np.full(len(pos), -1, dtype=np.int64); remap[ring_ids] = base + np.arange(n_seg)
+        below = fr >= rc
+        sel = below[:, None] & (remap[idx_pos] >= 0)
+        idx_nrm = np.where(sel, remap[idx_pos], idx_pos).astype(np.uint32)
+    return dict(pos=pos, idx_pos=idx_pos.reshape(-1), uv=uv, idx_uv=idx_uv.reshape(-1), nrm=nrm, idx_nrm=idx_nrm.reshape(-1).astype(np.uint32))
+
+
+def grid_mesh(nx=24, ny=16, seed=1, holes=True):
+    """Open height-field patch with a boundary (and optionally a punched hole): exercises L/R/E starts and boundary fans."""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.arange(nx), np.arange(ny))
+    pos = np.stack([xs * 10.0, ys * 10.0, 15.0 * np.sin(xs * 0.4) * np.cos(ys * 0.3)], -1).reshape(-1, 3).astype(np.float32)
+    pos += rng.standard_normal(pos.shape).astype(np.float32) * 0.3
+    f = []
+    for j in range(ny - 1):
+        for i in range(nx - 1):
+            if holes and 5 <= i < 9 and 4 <= j < 8:
+                continue
+            a, b, c, d = j * nx + i, j * nx + i + 1, (j + 1) * nx + i, (j + 1) * nx + i + 1
+            f += [(a, b, c), (b, d, c)]
+    idx = np.array(f, dtype=np.uint32)
+    uv = (pos[:, :2] / np.array([nx * 10.0, ny * 10.0], dtype=np.float32)).astype(np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (len(pos), 1))
+    nrm[:, 0] = -0.3 * np.cos(xs.reshape(-1) * 0.4); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return dict(pos=pos, idx_pos=idx.reshape(-1), uv=uv, idx_uv=idx.reshape(-1).copy(), nrm=nrm.astype(np.float32), idx_nrm=idx.reshape(-1).copy())
+
+
+def torus_mesh(n_major=48, n_minor=20, seed=2):
+    """Genus-1 closed mesh: forces topology-split events (handles) in the edgebreaker traversal."""
+    rng = np.random.default_rng(seed)
+    a = np.arange(n_major) / n_major * 2 * np.pi; b = np.arange(n_minor) / n_minor * 2 * np.pi
+    A, B = np.meshgrid(a, b, indexing="ij")
+    pos = np.stack([(100 + 35 * np.cos(B)) * np.cos(A), (100 + 35 * np.cos(B)) * np.sin(A), 35 * np.sin(B)], -1).reshape(-1, 3).astype(np.float32)
+    pos += rng.standard_normal(pos.shape).astype(np.float32) * 0.2
+    f = []
+    for i in range(n_major):
+        for j in range(n_minor):
+            p00 = i * n_minor + j; p01 = i * n_minor + (j + 1) % n_minor
+            p10 = ((i + 1) % n_major) * n_minor + j; p11 = ((i + 1) % n_major) * n_minor + (j + 1) % n_minor
+            f += [(p00, p10, p01), (p01, p10, p11)]
+    idx = np.array(f, dtype=np.uint32)
+    # uv per corner with wrap seams
+    fi = np.repeat(np.arange(n_major), n_minor * 2); fj = np.tile(np.repeat(np.arange(n_minor), 2), n_major)
+    ci = (idx // n_minor).astype(np.int64); cj = (idx % n_minor).astype(np.int64)
+    ci = np.where(ci < fi[:, None], ci + n_major, ci); cj = np.where(cj < fj[:, None], cj + n_minor, cj)
+    key = ci * 4096 + cj
+    uniq, inv = np.unique(key.reshape(-1), return_inverse=True)
+    uv = np.stack([(uniq // 4096) / (n_major + 1.0), (uniq % 4096) / (n_minor + 1.0)], -1).astype(np.float32)
+    P = pos.astype(np.float64)
+    fn = np.cross(P[idx[:, 1]] - P[idx[:, 0]], P[idx[:, 2]] - P[idx[:, 0]])
+    vn = np.zeros_like(P)
+    for k in range(3):
+        np.add.at(vn, idx[:, k], fn)
+    vn /= np.linalg.norm(vn, axis=1, keepdims=True)
+    return dict(pos=pos, idx_pos=idx.reshape(-1), uv=uv, idx_uv=inv.astype(np.uint32), nrm=vn.astype(np.float32), idx_nrm=idx.reshape(-1).copy())
+
+
+def _value_noise(h, w, cells, rng):
+    g = rng.random((cells + 2, cells + 2)).astype(np.float32)
+    ys = np.linspace(0, cells, h, endpoint=False); xs = np.linspace(0, cells, w, endpoint=False)
+    y0 = ys.astype(int); x0 = xs.astype(int); fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    fy = fy * fy * (3 - 2 * fy); fx = fx * fx * (3 - 2 * fx)
+    a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+    return a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx
+
+
+def texture_sequence(n_frames, size=2048, seed=0, change_frac=0.30, bg_frac=0.30):
+    """List of HxWx4 uint8 frames (alpha 255). ~bg_frac black background, ~change_frac of blocks change per frame."""
+    rng = np.random.default_rng(seed)
+    h = w = size
+    base = np.zeros((h, w, 3), dtype=np.float32)
+    for ch in range(3):
+        acc = np.zeros((h, w), dtype=np.float32)
+        for o, amp in ((4, 0.5), (16, 0.25), (64, 0.15), (256, 0.10)):
+            acc += amp * _value_noise(h, w, min(o, size // 4), rng)
+        base[..., ch] = acc
+    base = (base - base.min()) / (base.max() - base.min())
+    base[..., 0] = 0.25 + 0.7 * base[..., 0]; base[..., 1] = 0.15 + 0.6 * base[..., 1]; base[..., 2] = 0.1 + 0.5 * base[..., 2]
+    yy, xx = np.mgrid[0:h, 0:w]
+    fg = ((xx / w - 0.5) ** 2 / 0.21 + (yy / h - 0.5) ** 2 / 0.235) < 1.0        # ellipse ~70 % of the area
+    if bg_frac <= 0:
+        fg[:] = True
+    mov = _value_noise(h // 4, w // 4, 12, rng)
+    thr = np.quantile(mov, 1.0 - change_frac)
+    moving_blocks = np.kron(mov > thr, np.ones((4, 4), dtype=bool))[:h, :w]
+    frames = []
+    for f in range(n_frames):
+        img = base.copy()
+        if f > 0:
+            wob = 0.06 * np.sin(0.9 * f + xx / 37.0) * np.cos(0.7 * f + yy / 29.0)
+            img += (wob * moving_blocks)[..., None]
+        img = np.clip(img, 0, 1) * fg[..., None]
+        rgba = np.empty((h, w, 4), dtype=np.uint8)
+        rgba[..., :3] = (img * 255.0 + 0.5).astype(np.uint8); rgba[..., 3] = 255
+        frames.append(rgba)
+    return frames

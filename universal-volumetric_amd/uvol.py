@@ -1,0 +1,192 @@
+"""uvol.py — thin ctypes mirror of include/uvol_codec.h (libuvolcodec.so, HIP/gfx950).
+
+Host-side counterpart of the two process boundaries of the reference driver
+(scripts/Encoder.py:260-262 `draco_encoder`, :290-292 `basisu`).  There is no CPU fallback: if the
+HIP library or a GPU is missing, `Codec()` raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libuvolcodec.so")
+
+UVOL_OK, UVOL_E_INVALID, UVOL_E_NODEVICE, UVOL_E_HIP, UVOL_E_NOSPACE, UVOL_E_ENCODE, UVOL_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+
+
+class Params(C.Structure):
+    """project-config.json numeric fields used on the hot path (scripts/Encoder.py:171-179)."""
+    _fields_ = [("Q_POSITION_ATTR", C.c_int32), ("Q_TEXTURE_ATTR", C.c_int32), ("Q_NORMAL_ATTR", C.c_int32),
+                ("Q_GENERIC_ATTR", C.c_int32), ("DRACO_COMPRESSION_LEVEL", C.c_int32), ("KTX2_BATCH_SIZE", C.c_int32),
+                ("etc1s_quality", C.c_int32), ("y_flip", C.c_int32), ("max_batch", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("n_pos", C.c_uint32), ("uv", C.c_void_p), ("n_uv", C.c_uint32),
+                ("nrm", C.c_void_p), ("n_nrm", C.c_uint32), ("idx_pos", C.c_void_p), ("idx_uv", C.c_void_p),
+                ("idx_nrm", C.c_void_p), ("n_faces", C.c_uint32)]
+
+
+EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
+           "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_encode_mesh", "uvol_encode_mesh_batch",
+           "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
+           "uvol_encode_texture_segment_dev", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_profile_get"]
+
+
+def load(path=None):
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950); no CPU fallback exists")
+    L = C.CDLL(path)
+    L.uvol_params_default.argtypes = [C.POINTER(Params)]
+    L.uvol_ctx_create.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]
+    L.uvol_ctx_destroy.argtypes = [C.c_void_p]
+    L.uvol_last_error.argtypes = [C.c_void_p]; L.uvol_last_error.restype = C.c_char_p
+    L.uvol_sync.argtypes = [C.c_void_p]
+    L.uvol_mesh_bound.argtypes = [C.POINTER(Mesh)]; L.uvol_mesh_bound.restype = C.c_size_t
+    L.uvol_encode_mesh.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    for nm in ("uvol_encode_mesh_batch", "uvol_encode_mesh_batch_dev"):
+        getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    L.uvol_texture_bound.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.uvol_texture_bound.restype = C.c_size_t
+    for nm in ("uvol_encode_texture_segment", "uvol_encode_texture_segment_dev"):
+        getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
+                                   C.c_size_t, C.POINTER(C.c_size_t)]
+    L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.uvol_profile_reset.argtypes = [C.c_void_p]
+    L.uvol_profile_count.argtypes = [C.c_void_p]
+    L.uvol_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    return L
+
+
+class UvolError(RuntimeError):
+    pass
+
+
+def _f32(a, cols):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(-1, cols)
+
+
+def _u32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint32).reshape(-1)
+
+
+class Codec:
+    """One codec context = one GPU + one HIP stream.  Field names follow project-config.json."""
+
+    def __init__(self, device=0, lib_path=None, **config):
+        self.L = load(lib_path)
+        p = Params()
+        self.L.uvol_params_default(C.byref(p))
+        for k, v in config.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, int(v))
+        self.params = p
+        h = C.c_void_p()
+        rc = self.L.uvol_ctx_create(device, C.byref(p), C.byref(h))
+        if rc != UVOL_OK:
+            raise UvolError(f"uvol_ctx_create(device={device}) failed rc={rc} (no CPU fallback; a gfx950 GPU is required)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.uvol_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def error(self):
+        return self.L.uvol_last_error(self.h).decode()
+
+    # ---- geometry ----
+    @staticmethod
+    def _mesh_host(pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None):
+        pos = _f32(pos, 3); uv = _f32(uv, 2); nrm = _f32(nrm, 3)
+        idx_pos = _u32(idx_pos); idx_uv = _u32(idx_uv); idx_nrm = _u32(idx_nrm)
+        m = Mesh()
+        m.pos = pos.ctypes.data; m.n_pos = len(pos)
+        m.idx_pos = idx_pos.ctypes.data; m.n_faces = len(idx_pos) // 3
+        if uv is not None and idx_uv is not None:
+            m.uv = uv.ctypes.data; m.n_uv = len(uv); m.idx_uv = idx_uv.ctypes.data
+        if nrm is not None and idx_nrm is not None:
+            m.nrm = nrm.ctypes.data; m.n_nrm = len(nrm); m.idx_nrm = idx_nrm.ctypes.data
+        return m, (pos, uv, nrm, idx_pos, idx_uv, idx_nrm)
+
+    def encode_mesh(self, pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None) -> bytes:
+        return self.encode_mesh_batch([dict(pos=pos, idx_pos=idx_pos, uv=uv, idx_uv=idx_uv, nrm=nrm, idx_nrm=idx_nrm)])[0]
+
+    def encode_mesh_batch(self, frames, raise_on_error=True):
+        """frames: list of dicts(pos, idx_pos[, uv, idx_uv, nrm, idx_nrm]) of host arrays -> list of .drc bytes."""
+        n = len(frames)
+        meshes = (Mesh * n)(); keep = []
+        for i, f in enumerate(frames):
+            m, k = self._mesh_host(**f); meshes[i] = m; keep.append(k)
+        return self._run_batch(self.L.uvol_encode_mesh_batch, meshes, n, raise_on_error)
+
+    def encode_mesh_batch_dev(self, meshes, raise_on_error=True):
+        """meshes: ctypes array of Mesh holding DEVICE pointers (inputs resident in HBM)."""
+        return self._run_batch(self.L.uvol_encode_mesh_batch_dev, meshes, len(meshes), raise_on_error)
+
+    def _run_batch(self, fn, meshes, n, raise_on_error):
+        caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)()
+        bufs = []
+        for i in range(n):
+            cap = self.L.uvol_mesh_bound(C.byref(meshes[i]))
+            b = np.empty(cap, dtype=np.uint8); bufs.append(b)
+            caps[i] = cap; outs[i] = b.ctypes.data
+        rc = fn(self.h, meshes, n, outs, caps, lens, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_mesh_batch rc={rc}: {self.error()}")
+        res = []
+        for i in range(n):
+            if st[i] != UVOL_OK:
+                if raise_on_error:
+                    raise UvolError(f"frame {i} failed status={st[i]}: {self.error()}")
+                res.append(None)
+            else:
+                res.append(bufs[i][:lens[i]].tobytes())
+        return res
+
+    # ---- texture ----
+    def encode_texture_segment(self, layers) -> bytes:
+        """layers: list of HxWx4 uint8 arrays (top row first) -> one .ktx2 (ETC1S/BasisLZ, len(layers) array layers)."""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in layers]
+        h, w = arrs[0].shape[:2]
+        for a in arrs:
+            if a.shape != (h, w, 4):
+                raise ValueError("all layers must be HxWx4 uint8 of one size")
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        return self._run_tex(self.L.uvol_encode_texture_segment, ptrs, n, w, h)
+
+    def encode_texture_segment_dev(self, dev_ptrs, width, height) -> bytes:
+        n = len(dev_ptrs)
+        ptrs = (C.c_void_p * n)(*[int(p) for p in dev_ptrs])
+        return self._run_tex(self.L.uvol_encode_texture_segment_dev, ptrs, n, width, height)
+
+    def _run_tex(self, fn, ptrs, n, w, h):
+        cap = self.L.uvol_texture_bound(w, h, n)
+        out = np.empty(cap, dtype=np.uint8); ln = C.c_size_t()
+        rc = fn(self.h, ptrs, n, w, h, out.ctypes.data, cap, C.byref(ln))
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_texture_segment rc={rc}: {self.error()}")
+        return out[:ln.value].tobytes()
+
+    # ---- measurement ----
+    def profile(self, on=True):
+        self.L.uvol_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self):
+        self.L.uvol_profile_reset(self.h)
+
+    def profile_report(self):
+        self.L.uvol_sync(self.h)
+        out = []
+        for i in range(self.L.uvol_profile_count(self.h)):
+            name = C.create_string_buffer(128); la = C.c_uint64(); ms = C.c_double(); ab = C.c_uint64()
+            self.L.uvol_profile_get(self.h, i, name, 128, C.byref(la), C.byref(ms), C.byref(ab))
+            out.append(dict(name=name.value.decode(), launches=la.value, total_ms=ms.value, algo_bytes=ab.value))
+        return out
