@@ -35,14 +35,14 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
 
 // scan selectors
 enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2 };
-__device__ inline void scan_src(const GeoJob &J, int sel, const uint8_t *&flags, uint32_t &n) {
-  if (sel == SCAN_KEEP) { flags = J.keep; n = J.nf_in; }
-  else if (sel == SCAN_ELIG) { flags = J.elig; n = J.nc; }
-  else { flags = J.has_ori; n = J.has_uv ? J.ne_uv : 0; }
-}
+// NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
+// an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
+// register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.keep : (sel == SCAN_ELIG ? J.elig : J.has_ori); }
+__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u)); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
-  const uint8_t *flags; uint32_t n; scan_src(J, sel, flags, n);
+  const uint8_t *flags = scan_flags(J, sel); const uint32_t n = scan_count(J, sel);
   if (blockIdx.x >= uvol_blocks_dev(n)) return;       // block-uniform exit
   uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   uint32_t v = (J.status == 0 && i < n) ? flags[i] : 0, tot;
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int se
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_sums(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
-  const uint8_t *flags; uint32_t nn; scan_src(J, sel, flags, nn);
+  const uint32_t nn = scan_count(J, sel);
   const uint32_t nblocks = uvol_blocks_dev(nn);
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -176,10 +176,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
   JOB_OR_RETURN;
   uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (c >= J.nc) return;
-  GTab T; int32_t *vert; uint8_t *vopen; int32_t *ring = nullptr;
-  if (which == 0) { T.opp = J.opp; T.seam = nullptr; vert = J.vert; vopen = J.vopen; ring = J.ring; }
-  else if (which == 1) { T.opp = J.nopp; T.seam = nullptr; vert = J.bvert; vopen = J.bopen; }
-  else { int i = which - 2; if (i >= J.nad || !J.interior_seams[i]) return; T.opp = J.nopp; T.seam = J.seam[i]; vert = J.avert[i]; vopen = J.aopen[i]; }
+  // value-returning selects only (see the miscompile note at scan_flags)
+  const int ai = which >= 2 ? which - 2 : 0;
+  if (which >= 2 && (ai >= J.nad || !J.interior_seams[ai])) return;
+  GTab T;
+  T.opp = which == 0 ? J.opp : J.nopp;
+  T.seam = which >= 2 ? J.seam[ai] : nullptr;
+  int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
+  uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
+  int32_t *ring = which == 0 ? J.ring : nullptr;
   int l = (int)c; bool closed = false; uint32_t guard = 0;
   for (;;) { int nl = gt_swl(T, l); if (nl < 0) break; if (nl == (int)c) { closed = true; break; } l = nl; if (++guard > J.nc) { J.status = -22; return; } }
   if (closed) {
@@ -359,9 +364,10 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
   if (threadIdx.x != 0 || J.status != 0) return;
-  GTab T; const int32_t *vert; const uint8_t *vopen;
-  if (t == 0) { T.opp = J.nopp; T.seam = nullptr; vert = J.bvert; vopen = J.bopen; }
-  else { int i = t - 1; if (i >= J.nad || !J.interior_seams[i]) return; T.opp = J.nopp; T.seam = J.seam[i]; vert = J.avert[i]; vopen = J.aopen[i]; }
+  const int ai = t > 0 ? t - 1 : 0;
+  if (t > 0 && (ai >= J.nad || !J.interior_seams[ai])) return;
+  GTab T; T.opp = J.nopp; T.seam = t > 0 ? J.seam[ai] : nullptr;
+  const int32_t *vert = t > 0 ? J.avert[ai] : J.bvert; const uint8_t *vopen = t > 0 ? J.aopen[ai] : J.bopen;
   const int nf = (int)J.nf;
   uint8_t *fv = J.t_fvis[t], *vv = J.t_vvis[t]; int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
   int n = 0;
@@ -940,7 +946,14 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
   return 4096 + (size_t)m->n_faces * 3 * 24;
 }
 
-#define LAUNCH(k, grid, block, ...) hipLaunchKernelGGL(k, grid, block, 0, ctx->stream, __VA_ARGS__)
+#define LAUNCH(k, grid, block, ...)                                                              \
+  do {                                                                                           \
+    if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s\n", #k); fflush(stderr); }              \
+    hipLaunchKernelGGL(k, grid, block, 0, ctx->stream, __VA_ARGS__);                             \
+    if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } \
+      GeoJob dbg_; (void)hipMemcpy(&dbg_, dj, sizeof(GeoJob), hipMemcpyDeviceToHost); \
+      fprintf(stderr, "[uvol]   job0 status %d nf %u nverts %u ne %u %u %u ne_uv %u has_ori %p bsum %p elig %p n_ori %u\n", dbg_.status, dbg_.nf, dbg_.nverts, dbg_.ne[0], dbg_.ne[1], dbg_.ne[2], dbg_.ne_uv, (void*)dbg_.has_ori, (void*)dbg_.bsum, (void*)dbg_.elig, dbg_.n_ori); fflush(stderr); } \
+  } while (0)
 
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -92,6 +93,7 @@ static inline int uvol_ensure(uvol_ctx *ctx, uvol_devbuf &b, size_t bytes) {
   return UVOL_OK;
 }
 
+static inline bool uvol_debug() { static int d = -1; if (d < 0) { const char *e = getenv("UVOL_DEBUG"); d = (e && *e && *e != '0') ? 1 : 0; } return d == 1; }
 static inline unsigned uvol_blocks(size_t n, unsigned bs = UVOL_BLOCK) { return (unsigned)((n + bs - 1) / bs); }
 
 // pipeline entry points implemented in the .hip translation units
