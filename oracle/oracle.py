@@ -192,3 +192,112 @@ def drc_encode(pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None, qp=11
     if rc:
         raise ValueError(f"drc_encode rc={rc}")
     return _take(buf)
+
+
+# ------------------------------------------------------------------------------------------------
+# KTX2 / BasisLZ ETC1S
+# ------------------------------------------------------------------------------------------------
+KTX2_MAX_LAYERS = 64
+
+
+class Ktx2File(C.Structure):
+    _fields_ = [("vk_format", C.c_uint32), ("type_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("depth", C.c_uint32), ("layers", C.c_uint32), ("faces", C.c_uint32), ("levels", C.c_uint32), ("supercomp", C.c_uint32),
+                ("dfd_off", C.c_uint32), ("dfd_len", C.c_uint32), ("kvd_off", C.c_uint32), ("kvd_len", C.c_uint32),
+                ("sgd_off", C.c_uint64), ("sgd_len", C.c_uint64), ("level_off", C.c_uint64), ("level_len", C.c_uint64), ("level_ulen", C.c_uint64),
+                ("dfd_model", C.c_uint32), ("dfd_transfer", C.c_uint32), ("dfd_primaries", C.c_uint32),
+                ("n_endpoints", C.c_uint32), ("n_selectors", C.c_uint32), ("endpoints_len", C.c_uint32), ("selectors_len", C.c_uint32),
+                ("tables_len", C.c_uint32), ("extended_len", C.c_uint32), ("bx", C.c_uint32), ("by", C.c_uint32),
+                ("endpoints", C.POINTER(C.c_uint8)), ("selectors", C.POINTER(C.c_uint32)), ("hist_size", C.c_uint32),
+                ("ep_bits_used", C.c_uint32), ("sel_bits_used", C.c_uint32), ("tab_bits_used", C.c_uint32), ("n_slices", C.c_int),
+                ("slice_flags", C.c_uint32 * KTX2_MAX_LAYERS), ("slice_off", C.c_uint32 * KTX2_MAX_LAYERS), ("slice_len", C.c_uint32 * KTX2_MAX_LAYERS),
+                ("slice_bits_used", C.c_uint64 * KTX2_MAX_LAYERS), ("slice_skip", C.c_uint32 * KTX2_MAX_LAYERS),
+                ("block_ei", C.POINTER(C.c_uint16)), ("block_si", C.POINTER(C.c_uint16)),
+                ("writer", C.c_char * 64), ("anim_duration", C.c_uint32), ("anim_timescale", C.c_uint32), ("anim_loops", C.c_uint32), ("has_anim", C.c_int)]
+
+
+class Ktx2EncParams(C.Structure):
+    _fields_ = [("quality", C.c_int), ("y_flip", C.c_int)]
+
+
+def _ktx2_setup():
+    L = lib()
+    if getattr(L, "_ktx2_ready", False):
+        return L
+    L.ktx2_decode.restype = C.c_int
+    L.ktx2_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Ktx2File)]
+    L.ktx2_free.argtypes = [C.POINTER(Ktx2File)]
+    L.ktx2_layer_rgba.argtypes = [C.POINTER(Ktx2File), C.c_int, C.c_void_p]
+    if hasattr(L, "ktx2_encode"):
+        L.ktx2_encode.restype = C.c_int
+        L.ktx2_encode.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Ktx2EncParams), C.POINTER(OrcBuf)]
+    L._ktx2_ready = True
+    return L
+
+
+class DecodedKtx2:
+    def __init__(self, f, images=True):
+        for k in ("vk_format", "type_size", "width", "height", "depth", "layers", "faces", "levels", "supercomp", "dfd_off", "dfd_len",
+                  "kvd_off", "kvd_len", "sgd_off", "sgd_len", "level_off", "level_len", "level_ulen", "dfd_model", "dfd_transfer",
+                  "dfd_primaries", "n_endpoints", "n_selectors", "endpoints_len", "selectors_len", "tables_len", "extended_len",
+                  "bx", "by", "hist_size", "ep_bits_used", "sel_bits_used", "tab_bits_used", "n_slices", "has_anim",
+                  "anim_duration", "anim_timescale", "anim_loops"):
+            setattr(self, k, getattr(f, k))
+        self.writer = f.writer.decode(errors="replace")
+        n = f.n_slices
+        self.slice_flags = list(f.slice_flags[:n]); self.slice_off = list(f.slice_off[:n]); self.slice_len = list(f.slice_len[:n])
+        self.slice_bits_used = list(f.slice_bits_used[:n]); self.slice_skip = list(f.slice_skip[:n])
+        self.endpoints = np.ctypeslib.as_array(f.endpoints, (f.n_endpoints, 4)).copy()
+        self.selectors = np.ctypeslib.as_array(f.selectors, (f.n_selectors,)).copy()
+        nb = f.bx * f.by
+        self.block_ei = np.ctypeslib.as_array(f.block_ei, (n, nb)).copy()
+        self.block_si = np.ctypeslib.as_array(f.block_si, (n, nb)).copy()
+        self.images = []
+        if images:
+            for l in range(n):
+                img = np.zeros((f.height, f.width, 4), dtype=np.uint8)
+                lib().ktx2_layer_rgba(C.byref(f), l, img.ctypes.data)
+                self.images.append(img)
+
+
+def ktx2_decode(data: bytes, images=True) -> DecodedKtx2:
+    L = _ktx2_setup()
+    f = Ktx2File()
+    rc = L.ktx2_decode(data, len(data), C.byref(f))
+    if rc:
+        raise ValueError(f"ktx2_decode rc={rc}")
+    try:
+        return DecodedKtx2(f, images)
+    finally:
+        L.ktx2_free(C.byref(f))
+
+
+def ktx2_goldens(data: bytes) -> dict:
+    d = ktx2_decode(data)
+    return dict(size=len(data), width=d.width, height=d.height, layers=d.layers, supercomp=d.supercomp, dfd_model=d.dfd_model,
+                sgd_off=d.sgd_off, sgd_len=d.sgd_len, level_off=d.level_off, level_len=d.level_len,
+                n_endpoints=d.n_endpoints, n_selectors=d.n_selectors, endpoints_len=d.endpoints_len, selectors_len=d.selectors_len,
+                tables_len=d.tables_len, hist_size=d.hist_size, ep_bits=d.ep_bits_used, sel_bits=d.sel_bits_used, tab_bits=d.tab_bits_used,
+                slice_flags=d.slice_flags, slice_off=d.slice_off, slice_len=d.slice_len, slice_bits=d.slice_bits_used, slice_skip=d.slice_skip,
+                writer=d.writer, first_endpoints=d.endpoints[:3].tolist(),
+                crc_ei="%08x" % crc32(d.block_ei), crc_si="%08x" % crc32(d.block_si),
+                crc_img=["%08x" % crc32(im) for im in d.images])
+
+
+def ktx2_encode(layers, quality=128, y_flip=1) -> bytes:
+    L = _ktx2_setup()
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in layers]
+    h, w = arrs[0].shape[:2]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    prm = Ktx2EncParams(quality, y_flip)
+    buf = OrcBuf()
+    rc = L.ktx2_encode(ptrs, len(arrs), w, h, C.byref(prm), C.byref(buf))
+    if rc:
+        raise ValueError(f"ktx2_encode rc={rc}")
+    return _take(buf)
+
+
+def psnr(a, b):
+    a = np.asarray(a, dtype=np.float64)[..., :3]; b = np.asarray(b, dtype=np.float64)[..., :3]
+    mse = ((a - b) ** 2).mean()
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
