@@ -35,6 +35,8 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned X = 1, unsigned Y = 1, unsigned Z = 1) : x(X), y(Y), z(Z) {} };
 struct hipemu_uint3 { unsigned x, y, z; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
 extern thread_local hipemu_uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 extern thread_local char *hipemu_dyn_smem;

@@ -1,0 +1,89 @@
+"""CPU oracle vs the reference's .ktx2 fixtures + oracle ETC1S encoder round trips."""
+import json
+import os
+import struct
+import numpy as np
+import pytest
+from conftest import GOLDEN, REF_OUT
+
+GOLD = json.load(open(os.path.join(GOLDEN, "ktx2_goldens.json")))
+TEXDIR = os.path.join(REF_OUT, "texture_ktx2-fps30-1k_baseColor_default")
+
+
+def test_survey_appendix_values():
+    f0 = GOLD["files"]["00000.ktx2"]
+    assert (f0["size"], f0["width"], f0["height"], f0["layers"], f0["supercomp"], f0["dfd_model"]) == (232441, 1024, 1024, 5, 1, 163)
+    assert (f0["sgd_off"], f0["sgd_len"], f0["level_off"], f0["level_len"]) == (216, 5422, 5638, 226803)
+    assert (f0["n_endpoints"], f0["n_selectors"], f0["endpoints_len"], f0["selectors_len"], f0["tables_len"], f0["hist_size"]) == (1506, 734, 2789, 1598, 915, 64)
+    assert (f0["ep_bits"], f0["sel_bits"], f0["tab_bits"]) == (22309, 12780, 7318)
+    assert f0["slice_flags"] == [0, 2, 2, 2, 2] and f0["slice_len"] == [81805, 37466, 36123, 35947, 35462]
+    assert f0["slice_bits"] == [654434, 299722, 288981, 287570, 283690] and f0["slice_skip"] == [0, 43794, 44830, 44968, 45073]
+    assert f0["first_endpoints"] == [[0, 0, 0, 0], [10, 10, 9, 6], [19, 15, 14, 0]] and f0["writer"] == "Basis Universal 1.16"
+    fs = GOLD["files"]
+    assert GOLD["n_files"] == 50 and sum(sum(v["slice_skip"]) for v in fs.values()) == 8984009
+    assert (min(v["n_endpoints"] for v in fs.values()), max(v["n_endpoints"] for v in fs.values())) == (1489, 1532)
+    assert (min(v["n_selectors"] for v in fs.values()), max(v["n_selectors"] for v in fs.values())) == (728, 744)
+    assert all(v["slice_flags"] == [0, 2, 2, 2, 2] for v in fs.values())
+    assert max(8 * l - b for v in fs.values() for l, b in zip(v["slice_len"], v["slice_bits"])) <= 7
+
+
+def test_decoder_on_committed_fixture(oracle):
+    g = oracle.ktx2_goldens(open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read())
+    assert g == GOLD["files"]["00000.ktx2"]
+
+
+@pytest.mark.skipif(not os.path.isdir(TEXDIR), reason="/root/reference only exists in the build container")
+def test_decoder_on_all_50_reference_fixtures(oracle):
+    for name, g in sorted(GOLD["files"].items()):
+        assert oracle.ktx2_goldens(open(os.path.join(TEXDIR, name), "rb").read()) == g, name
+
+
+def _check_container(k, w, h, layers):
+    """Header / DFD / KVD layout per SURVEY B.0 (what src/lib/KTX2Loader.js:297-301 and ktx-parse read)."""
+    assert k[:12] == bytes([0xAB]) + b"KTX 20" + bytes([0xBB]) + b"\r\n\x1a\n"
+    vk, ts, pw, ph, pd, lc, fc, lv, sc = struct.unpack_from("<9I", k, 12)
+    assert (vk, ts, pw, ph, pd, lc, fc, lv, sc) == (0, 1, w, h, 0, layers, 1, 1, 1)
+    dfd_off, dfd_len, kvd_off, kvd_len = struct.unpack_from("<4I", k, 48)
+    sgd_off, sgd_len, lvl_off, lvl_len, lvl_ulen = struct.unpack_from("<5Q", k, 64)
+    assert (dfd_off, dfd_len, kvd_off) == (104, 44, 148) and sgd_off % 8 == 0 and lvl_off == sgd_off + sgd_len and lvl_off + lvl_len == len(k) and lvl_ulen == 0
+    ref_dfd = bytes.fromhex("2c000000" "00000000" "02002800" "a3010200" "03030000" "0000000000000000" "00003f00" "00000000" "00000000" "ffffffff")
+    assert k[104:148] == ref_dfd
+    assert k[152:164] == b"KTXanimData\0" and struct.unpack_from("<3I", k, 164) == (1, 15, 0)
+    assert lc >= 2 or layers == 1      # the stock player needs an array texture
+
+
+@pytest.mark.parametrize("size,n,seed", [(64, 2, 1), (128, 3, 2), (100, 2, 3)])
+def test_encoder_roundtrip(oracle, size, n, seed):
+    import synth
+    tex = synth.texture_sequence(n, size=size, seed=seed)
+    k = oracle.ktx2_encode(tex)
+    _check_container(k, size, size, n)
+    d = oracle.ktx2_decode(k)
+    assert d.slice_flags == [0] + [2] * (n - 1) and d.hist_size == 64
+    assert all(8 * l - b <= 7 for l, b in zip(d.slice_len, d.slice_bits_used))
+    assert d.slice_skip[0] == 0 and all(s > 0 for s in d.slice_skip[1:])
+    for l in range(n):
+        assert oracle.psnr(d.images[l], tex[l][::-1]) > 30.0      # stored rows are bottom-up (-y_flip)
+
+
+def test_encoder_on_reference_texture(oracle):
+    """Real captured content: re-encode the decoded reference segment; bpp and codebook sizes land at the
+    fixture's operating point (Basis Universal 1.16 defaults: 0.355 bpp, 1506/734 entries)."""
+    ref = open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read()
+    d = oracle.ktx2_decode(ref)
+    src = [im[::-1].copy() for im in d.images]
+    k = oracle.ktx2_encode(src)
+    e = oracle.ktx2_decode(k)
+    assert 0.8 * len(ref) < len(k) < 1.1 * len(ref)
+    assert 1200 <= e.n_endpoints <= 1536 and 600 <= e.n_selectors <= 768
+    assert min(oracle.psnr(e.images[l], d.images[l]) for l in range(5)) > 38.0
+    assert all(40000 < s < 60000 for s in e.slice_skip[1:])
+
+
+def test_encoder_flat_and_single_layer(oracle):
+    flat = [np.full((16, 16, 4), 255, np.uint8)]
+    flat[0][..., :3] = (12, 200, 77)
+    k = oracle.ktx2_encode(flat)
+    d = oracle.ktx2_decode(k)
+    assert d.n_endpoints == 1 and d.n_selectors == 1
+    assert np.abs(d.images[0][..., :3].astype(int) - flat[0][..., :3].astype(int)).max() <= 8

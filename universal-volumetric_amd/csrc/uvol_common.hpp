@@ -13,6 +13,13 @@
 
 #define UVOL_BLOCK 256
 
+// dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
+#ifdef HIPEMU
+#define UVOL_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu_dyn_smem)
+#else
+#define UVOL_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[]; T *name = reinterpret_cast<T *>(name##_raw_)
+#endif
+
 #define UVOL_HIP_CHECK(ctx, expr)                                                                  \
   do {                                                                                             \
     hipError_t e_ = (expr);                                                                        \
