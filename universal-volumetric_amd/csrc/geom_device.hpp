@@ -64,6 +64,7 @@ struct GeoJob {
   int32_t *opp, *vert, *ring; uint8_t *vopen;
   uint8_t *fvis, *vvis; int32_t *vval, *c2vm, *f2split, *proc, *initc, *stack;
   int32_t *ev_src, *ev_spl; uint8_t *ev_edge;
+  int32_t *rec[4]; uint8_t *symb, *ctx_of; int32_t *face_time;
   uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
   uint8_t *start_bits;
   int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert; uint8_t *bopen;

@@ -34,12 +34,12 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
 }
 
 // scan selectors
-enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2 };
+enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3 };
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
 // register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
-__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.keep : (sel == SCAN_ELIG ? J.elig : J.has_ori); }
-__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u)); }
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return (sel == SCAN_KEEP || sel == SCAN_EVENTS) ? J.keep : (sel == SCAN_ELIG ? J.elig : J.has_ori); }
+__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
   const uint8_t *flags = scan_flags(J, sel); const uint32_t n = scan_count(J, sel);
@@ -202,110 +202,219 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: valence edgebreaker traversal — inherently serial per frame; one workgroup (lane 0) per frame.
-// (MeshEdgebreakerEncoderImpl::EncodeConnectivity + MeshEdgebreakerTraversalValenceEncoder)
+// K4: valence edgebreaker — split into
+//   k_pack_faces   (parallel)  32-byte per-face records {opp[3], (vertex<<1|open)[3]} so a walker needs ONE load per face
+//   k_eb_walk      (serial)    MeshEdgebreakerEncoderImpl::EncodeConnectivity traversal only: symbols, processed corners,
+//                              face encode times; visited faces / vertices are bitmaps in LDS
+//   k_eb_events    (parallel)  topology-split events from (symbol, neighbour symbol) pairs, order-preserving compaction
+//   k_eb_valence   (serial)    MeshEdgebreakerTraversalValenceEncoder bookkeeping replayed over the known symbol
+//                              sequence (all addresses known in advance -> lanes prefetch a chunk of 64 symbols)
+//   k_eb_ctx       (1 wave)    ballot-ordered scatter of the symbols into the 6 valence-context streams
+// (SURVEY A.3 / A.10).  The serial kernels run one frame per workgroup; a batch keeps that many CUs busy.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_edgebreaker(GeoJob *jobs) {
+// which: 0 old base table (edgebreaker), 1 new base, 2/3 attribute tables (DFS)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which) {
+  JOB_OR_RETURN;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (f >= J.nf) return;
+  const int ai = which >= 2 ? which - 2 : 0;
+  if (which >= 2 && (ai >= J.nad || !J.interior_seams[ai])) return;
+  const int32_t *opp = which == 0 ? J.opp : J.nopp;
+  const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
+  const int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
+  const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
+  int32_t *rec = J.rec[which] + 8 * (size_t)f;
+  int r[8];
+  for (int k = 0; k < 3; k++) {
+    const int c = 3 * (int)f + k;
+    r[k] = (seam && seam[c]) ? GEO_INV : opp[c];
+    const int v = vert[c];
+    r[3 + k] = (v << 1) | (vopen[v] ? 1 : 0);
+  }
+  r[6] = 0; r[7] = 0;
+  int4 *dst = reinterpret_cast<int4 *>(rec);
+  dst[0] = make_int4(r[0], r[1], r[2], r[3]); dst[1] = make_int4(r[4], r[5], r[6], r[7]);
+}
+
+struct FaceRec { int o[3]; int v[3]; };
+__device__ __forceinline__ FaceRec load_rec(const int32_t *rec, int f) {
+  const int4 *p = reinterpret_cast<const int4 *>(rec + 8 * (size_t)f);
+  const int4 a = p[0], b = p[1];
+  FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
+}
+__device__ __forceinline__ int sel3(const int a[3], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : a[2]); }
+__device__ __forceinline__ bool bit_get(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+__device__ __forceinline__ void bit_set(uint32_t *w, int i) { w[i >> 5] |= 1u << (i & 31); }
+
+template <bool LDS>
+__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
-  if (threadIdx.x != 0 || J.status != 0) return;
+  UVOL_DYN_SMEM(uint32_t, lds);
   const int nf = (int)J.nf, nc = (int)J.nc;
-  const int32_t *opp = J.opp, *vert = J.vert; const uint8_t *vopen = J.vopen;
-  uint8_t *fvis = J.fvis, *vvis = J.vvis; int32_t *vval = J.vval, *c2vm = J.c2vm, *f2split = J.f2split;
-  for (int i = 0; i < nc; i++) { vval[i] = J.ring[i]; c2vm[i] = vert[i]; }
-  int nvval = nc, nproc = 0, ninit = 0, nstart = 0, nev = 0, last_sym = -1, nsplit = 0, prev_symbol = -1;
-  uint32_t ctxn[6] = {0, 0, 0, 0, 0, 0};
+  const bool ok = J.status == 0;
+  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = ((uint32_t)nc + 31) / 32;
+  uint32_t *fbits = LDS ? lds : reinterpret_cast<uint32_t *>(J.fvis);
+  uint32_t *vbits = LDS ? lds + fw : reinterpret_cast<uint32_t *>(J.vvis);
+  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + vw; k += 64) lds[k] = 0; __syncthreads(); }
+  if (threadIdx.x != 0 || !ok) return;
+  const int32_t *rec = J.rec[0];
+  int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
+  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
-  auto encode_symbol = [&](int symbol, int lc) {
-    const int nx = g_nxt(lc), pv = g_prv(lc);
-    const int active_valence = vval[c2vm[nx]];
-    switch (symbol) {
-      case T_C: case T_S:
-        vval[c2vm[nx]] -= 1; vval[c2vm[pv]] -= 1;
-        if (symbol == T_S) {
-          int nleft = 0, a = opp[pv];
-          while (a >= 0) { if (fvis[a / 3]) break; nleft++; a = opp[g_nxt(a)]; }
-          vval[c2vm[lc]] = nleft + 1;
-          const int newv = nvval; int nright = 0; a = opp[nx];
-          while (a >= 0) { if (fvis[a / 3]) break; nright++; c2vm[g_nxt(a)] = newv; a = opp[g_prv(a)]; }
-          vval[nvval++] = nright + 1;
-        }
-        break;
-      case T_R: vval[c2vm[lc]] -= 1; vval[c2vm[nx]] -= 1; vval[c2vm[pv]] -= 2; break;
-      case T_L: vval[c2vm[lc]] -= 1; vval[c2vm[nx]] -= 2; vval[c2vm[pv]] -= 1; break;
-      default:  vval[c2vm[lc]] -= 2; vval[c2vm[nx]] -= 2; vval[c2vm[pv]] -= 2; break;
-    }
-    if (prev_symbol != -1) {
-      int cv = active_valence < 2 ? 2 : (active_valence > 7 ? 7 : active_valence);
-      const int id = prev_symbol == T_C ? 0 : prev_symbol == T_S ? 1 : prev_symbol == T_L ? 2 : prev_symbol == T_R ? 3 : 4;
-      J.ctx_sym[cv - 2][ctxn[cv - 2]++] = (uint32_t)id;
-    }
-    prev_symbol = symbol;
-  };
-  auto check_split = [&](int src_edge, int nb_face) {
-    int sid = f2split[nb_face] - 1;
-    if (sid >= 0) { J.ev_src[nev] = last_sym; J.ev_spl[nev] = sid; J.ev_edge[nev] = (uint8_t)src_edge; nev++; }
-  };
-  int32_t *stack = J.stack;
   for (int f0 = 0; f0 < nf; f0++) {
-    if (fvis[f0]) continue;
-    int ci = 3 * f0, interior = 1, start_corner = ci;
-    for (int i = 0; i < 3; i++) {
-      if (opp[ci] < 0) { interior = 0; start_corner = ci; break; }
-      if (vopen[vert[ci]]) {
-        int rc = ci;
-        while (rc >= 0) { ci = rc; int o = opp[g_prv(rc)]; rc = o < 0 ? -1 : g_prv(o); }
+    if (bit_get(fbits, f0)) continue;
+    const FaceRec r0 = load_rec(rec, f0);
+    int interior = 1, start_corner = 3 * f0;
+    for (int k = 0; k < 3; k++) {
+      if (r0.o[k] < 0) { interior = 0; start_corner = 3 * f0 + k; break; }
+      if (r0.v[k] & 1) {              // boundary vertex: swing right to the boundary edge
+        int ci = 3 * f0 + k, rc = ci;
+        while (rc >= 0) { ci = rc; const FaceRec rr = load_rec(rec, rc / 3); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
         interior = 0; start_corner = g_prv(ci); break;
       }
-      ci = g_nxt(ci);
     }
     J.start_bits[nstart++] = (uint8_t)interior;
     int from;
     if (interior) {
-      ci = 3 * f0;
-      vvis[vert[ci]] = 1; vvis[vert[ci + 1]] = 1; vvis[vert[ci + 2]] = 1;
-      fvis[f0] = 1;
-      J.initc[ninit++] = ci + 1;
-      from = opp[ci + 1];
-      if (from < 0 || fvis[from / 3]) continue;
+      bit_set(vbits, r0.v[0] >> 1); bit_set(vbits, r0.v[1] >> 1); bit_set(vbits, r0.v[2] >> 1);
+      bit_set(fbits, f0); ftime[f0] = -1;
+      J.initc[ninit++] = 3 * f0 + 1;
+      from = r0.o[1];
+      if (from < 0 || bit_get(fbits, from / 3)) continue;
     } else from = start_corner;
     int sp = 0; stack[sp++] = from;
     while (sp > 0) {
       int corner = stack[sp - 1];
-      if (corner < 0 || fvis[corner / 3]) { sp--; continue; }
+      if (corner < 0 || bit_get(fbits, corner / 3)) { sp--; continue; }
       for (;;) {
-        last_sym++;
-        const int face = corner / 3; fvis[face] = 1;
-        J.proc[nproc++] = corner;
-        const int v = vert[corner]; const bool on_b = vopen[v] != 0;
-        if (!vvis[v]) {
-          vvis[v] = 1;
-          if (!on_b) { encode_symbol(T_C, corner); corner = opp[g_nxt(corner)]; continue; }
-        }
-        const int rcn = opp[g_nxt(corner)], lcn = opp[g_prv(corner)];
-        const bool rvis = rcn < 0 ? true : fvis[rcn / 3] != 0, lvis = lcn < 0 ? true : fvis[lcn / 3] != 0;
-        if (rvis) {
-          if (rcn >= 0) check_split(1, rcn / 3);
-          if (lvis) { if (lcn >= 0) check_split(0, lcn / 3); encode_symbol(T_E, corner); sp--; break; }
-          else { encode_symbol(T_R, corner); corner = lcn; }
-        } else {
-          if (lvis) { if (lcn >= 0) check_split(0, lcn / 3); encode_symbol(T_L, corner); corner = rcn; }
-          else {
-            encode_symbol(T_S, corner); nsplit++;
-            f2split[face] = last_sym + 1;
-            stack[sp - 1] = lcn; stack[sp++] = rcn;
-            break;
-          }
-        }
+        const int face = corner / 3, k = corner - 3 * face;
+        const FaceRec r = load_rec(rec, face);
+        bit_set(fbits, face);
+        const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
+        proc[nproc] = corner; ftime[face] = nproc;
+        int sym;
+        const int v = vi >> 1;
+        bool fresh_interior = false;
+        if (!bit_get(vbits, v)) { bit_set(vbits, v); fresh_interior = !(vi & 1); }
+        if (fresh_interior) { symb[nproc++] = T_C; corner = rcn; continue; }
+        const bool rvis = rcn < 0 ? true : bit_get(fbits, rcn / 3), lvis = lcn < 0 ? true : bit_get(fbits, lcn / 3);
+        if (rvis) { if (lvis) { sym = T_E; } else { sym = T_R; } } else { sym = lvis ? T_L : T_S; }
+        symb[nproc++] = (uint8_t)sym;
+        if (sym == T_E) { sp--; break; }
+        if (sym == T_R) { corner = lcn; continue; }
+        if (sym == T_L) { corner = rcn; continue; }
+        nsplit++; stack[sp - 1] = lcn; stack[sp++] = rcn; break;
       }
     }
   }
-  J.nsym = last_sym + 1; J.nsplit = nsplit; J.nev = nev; J.nstart = nstart; J.ninit = ninit;
-  for (int i = 0; i < 6; i++) { J.ctx_n[i] = ctxn[i]; J.rs[i].n = ctxn[i]; }
+  J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
   if (nproc + ninit != nf) J.status = -10;
-  // rabs stream 0: start-face configuration bits
   J.rb[0].n = (uint32_t)nstart;
   uint32_t z = 0; for (int i = 0; i < nstart; i++) z += J.start_bits[i] == 0;
   J.rb[0].zeros = z;
+}
+
+// topology-split events (CheckAndStoreTopologySplitEvent): symbol i contributes an event for each already-encoded
+// right / left neighbour whose own symbol is S.  flag[i] = number of events (0..2), compacted in symbol order.
+__device__ inline int eb_events_of(const GeoJob &J, uint32_t i, int ev_spl[2], int ev_edge[2]) {
+  const int sym = J.symb[i]; int n = 0;
+  if (sym != 5 && sym != 3 && sym != 7) return 0;
+  const int c = J.proc[i];
+  const int rcn = J.opp[g_nxt(c)], lcn = J.opp[g_prv(c)];
+  if ((sym == 5 || sym == 7) && rcn >= 0) { const int t = J.face_time[rcn / 3]; if (t >= 0 && J.symb[t] == 1) { ev_spl[n] = t; ev_edge[n] = 1; n++; } }
+  if ((sym == 3 || sym == 7) && lcn >= 0) { const int t = J.face_time[lcn / 3]; if (t >= 0 && J.symb[t] == 1) { ev_spl[n] = t; ev_edge[n] = 0; n++; } }
+  return n;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_flags(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (i >= J.nf) return;
+  int a[2], b[2];
+  J.keep[i] = i < (uint32_t)J.nsym ? (uint8_t)eb_events_of(J, i, a, b) : 0;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && i < J.nf;
+  uint32_t v = live ? J.keep[i] : 0, tot;
+  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum[blockIdx.x] : 0);
+  if (live && v) {
+    int a[2], b[2]; const int n = eb_events_of(J, i, a, b);
+    for (int k = 0; k < n; k++) { J.ev_src[pos + k] = (int)i; J.ev_spl[pos + k] = a[k]; J.ev_edge[pos + k] = (uint8_t)b[k]; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nev = (int)J.bsum[uvol_blocks_dev(J.nf)];
+}
+
+// valence bookkeeping replay: ctx_of[i] = context (0..5) under which symbol i-1 is coded (i >= 1)
+__global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  const bool ok = J.status == 0;
+  const int nsym = ok ? J.nsym : 0, nc = (int)J.nc;
+  const int32_t *opp = J.opp, *proc = J.proc, *ftime = J.face_time; const uint8_t *symb = J.symb;
+  int32_t *vval = J.vval, *c2vm = J.c2vm;
+  // initial valences / corner->vertex replica (parallel over lanes)
+  for (int i = (int)lane; i < (ok ? nc : 0); i += 64) { vval[i] = J.ring[i]; c2vm[i] = J.vert[i]; }
+  __syncthreads();
+  int nvval = nc;
+  for (int base = 0; base < nsym; base += 64) {
+    const int mi = base + (int)lane;
+    // lane-parallel gather of the chunk's corners, symbols and vertex ids (valid until an S re-maps corners)
+    int c_ = 0, s_ = 0, va_ = 0, vn_ = 0, vp_ = 0;
+    if (mi < nsym) { c_ = proc[mi]; s_ = symb[mi]; va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
+    const int cnt = nsym - base < 64 ? nsym - base : 64;
+    for (int j = 0; j < cnt; j++) {
+      const int i = base + j;
+      const int lc = (int)UVOL_READLANE(c_, j), sym = (int)UVOL_READLANE(s_, j);
+      int ia = (int)UVOL_READLANE(va_, j), in_ = (int)UVOL_READLANE(vn_, j), ip = (int)UVOL_READLANE(vp_, j);
+      bool remapped = false;
+      if (lane == 0) {
+        const int nx = g_nxt(lc), pv = g_prv(lc);
+        const int active_valence = vval[in_];
+        if (sym == 0 || sym == 1) {
+          vval[in_] -= 1; vval[ip] -= 1;
+          if (sym == 1) {
+            int nleft = 0, a = opp[pv];
+            while (a >= 0) { if (ftime[a / 3] <= i) break; nleft++; a = opp[g_nxt(a)]; }
+            vval[ia] = nleft + 1;
+            const int newv = nvval; int nright = 0; a = opp[nx];
+            while (a >= 0) { if (ftime[a / 3] <= i) break; nright++; c2vm[g_nxt(a)] = newv; a = opp[g_prv(a)]; }
+            vval[nvval] = nright + 1;
+          }
+        } else if (sym == 5) { vval[ia] -= 1; vval[in_] -= 1; vval[ip] -= 2; }
+        else if (sym == 3) { vval[ia] -= 1; vval[in_] -= 2; vval[ip] -= 1; }
+        else { vval[ia] -= 2; vval[in_] -= 2; vval[ip] -= 2; }
+        if (i > 0) { const int cv = active_valence < 2 ? 2 : (active_valence > 7 ? 7 : active_valence); J.ctx_of[i] = (uint8_t)(cv - 2); }
+      }
+      if (sym == 1) { nvval++; remapped = true; }
+      if (remapped) {               // wave-uniform: refresh the not-yet-consumed vertex ids of this chunk
+        __threadfence_block();
+        if (mi < nsym && (int)lane > j) { va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
+      }
+    }
+  }
+}
+
+// symbols -> the six valence-context streams, in symbol order (wave ballots give each symbol its slot)
+__global__ void __launch_bounds__(64) k_eb_ctx(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  const int nsym = J.status == 0 ? J.nsym : 0;
+  uint32_t base_c[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int base = 1; base < nsym; base += 64) {
+    const int i = base + (int)lane;
+    const bool in = i < nsym;
+    const int cx = in ? J.ctx_of[i] : 7;
+    const int ps = in ? J.symb[i - 1] : 0;
+    const uint32_t id = ps == 0 ? 0u : (ps == 1 ? 1u : (ps == 3 ? 2u : (ps == 5 ? 3u : 4u)));
+    for (int c = 0; c < 6; c++) {
+      const unsigned long long m = __ballot(in && cx == c);
+      if (in && cx == c) J.ctx_sym[c][base_c[c] + (uint32_t)__popcll(m & lt)] = id;
+      base_c[c] += (uint32_t)__popcll(m);
+    }
+  }
+  if (lane == 0 && J.status == 0) for (int c = 0; c < 6; c++) { J.ctx_n[c] = base_c[c]; J.rs[c].n = base_c[c]; }
 }
 
 // renumber into decoder order (decoder corner 3f+k <-> rot^k(processed corner f))
@@ -359,38 +468,46 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 
 // ------------------------------------------------------------------------------------------------
 // K5: DepthFirstTraverser — serial per (table, frame).  t=0 base table, t=1,2 attribute tables.
+// One 32-byte record load per face; visited faces / vertices are bitmaps in LDS.
 // ------------------------------------------------------------------------------------------------
+template <bool LDS>
 __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
-  if (threadIdx.x != 0 || J.status != 0) return;
+  UVOL_DYN_SMEM(uint32_t, lds);
   const int ai = t > 0 ? t - 1 : 0;
-  if (t > 0 && (ai >= J.nad || !J.interior_seams[ai])) return;
-  GTab T; T.opp = J.nopp; T.seam = t > 0 ? J.seam[ai] : nullptr;
-  const int32_t *vert = t > 0 ? J.avert[ai] : J.bvert; const uint8_t *vopen = t > 0 ? J.aopen[ai] : J.bopen;
-  const int nf = (int)J.nf;
-  uint8_t *fv = J.t_fvis[t], *vv = J.t_vvis[t]; int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
+  const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
+  const int nf = (int)J.nf, nc = (int)J.nc;
+  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = ((uint32_t)nc + 31) / 32;
+  uint32_t *fbits = LDS ? lds : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
+  uint32_t *vbits = LDS ? lds + fw : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
+  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + vw; k += 64) lds[k] = 0; __syncthreads(); }
+  if (threadIdx.x != 0 || !ok) return;
+  const int32_t *rec = J.rec[1 + t];
+  int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
   int n = 0;
-#define T_VISIT(v, c) do { vv[v] = 1; v2d[v] = n; order[n++] = (c); } while (0)
-#define T_FVIS(c) ((c) < 0 ? true : fv[(c) / 3] != 0)
+#define T_VISIT(vid, c) do { bit_set(vbits, (vid)); v2d[(vid)] = n; order[n++] = (c); } while (0)
+#define T_FVIS(c) ((c) < 0 ? true : bit_get(fbits, (c) / 3))
   for (int f = 0; f < nf; f++) {
-    if (fv[f]) continue;
+    if (bit_get(fbits, f)) continue;
     int cid = 3 * f, sp = 0;
     stack[sp++] = cid;
-    { int vn = vert[cid + 1], vp = vert[cid + 2];
-      if (!vv[vn]) T_VISIT(vn, cid + 1);
-      if (!vv[vp]) T_VISIT(vp, cid + 2); }
+    { const FaceRec r0 = load_rec(rec, f); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
+      if (!bit_get(vbits, vn)) T_VISIT(vn, cid + 1);
+      if (!bit_get(vbits, vp)) T_VISIT(vp, cid + 2); }
     while (sp > 0) {
       cid = stack[sp - 1];
-      if (cid < 0 || fv[cid / 3]) { sp--; continue; }
+      if (cid < 0 || bit_get(fbits, cid / 3)) { sp--; continue; }
       for (;;) {
-        fv[cid / 3] = 1;
-        const int v = vert[cid];
-        if (!vv[v]) {
+        const int face = cid / 3, k = cid - 3 * face;
+        const FaceRec r = load_rec(rec, face);
+        bit_set(fbits, face);
+        const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
+        const int v = vi >> 1;
+        if (!bit_get(vbits, v)) {
           T_VISIT(v, cid);
-          if (!vopen[v]) { cid = gt_opp(T, g_nxt(cid)); continue; }
+          if (!(vi & 1)) { cid = rc; continue; }
         }
-        const int rc = gt_opp(T, g_nxt(cid)), lc = gt_opp(T, g_prv(cid));
         if (T_FVIS(rc)) { if (T_FVIS(lc)) { sp--; break; } cid = lc; }
         else { if (T_FVIS(lc)) cid = rc; else { stack[sp - 1] = lc; stack[sp++] = rc; break; } }
       }
@@ -855,9 +972,24 @@ struct GeoState {
   uvol_devbuf outs;       // output buffers
   std::vector<GeoJob> hjobs;
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
+  size_t max_lds = 64 * 1024;
 };
 
-int geo_create(uvol_ctx *ctx) { ctx->geo = new GeoState(); return UVOL_OK; }
+int geo_create(uvol_ctx *ctx) {
+  ctx->geo = new GeoState();
+#ifndef HIPEMU
+  // the serial walkers keep their visited bitmaps in LDS: allow the full 160 KiB of a gfx950 CU
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->geo->max_lds = (size_t)v;
+  const size_t want = ctx->geo->max_lds;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipGetLastError();
+#else
+  ctx->geo->max_lds = 160 * 1024;
+#endif
+  return UVOL_OK;
+}
 void geo_destroy(uvol_ctx *ctx) {
   if (!ctx->geo) return;
   GeoState *g = ctx->geo;
@@ -878,7 +1010,7 @@ inline uint32_t pow2_at_least(uint64_t v) { uint32_t c = 16; while (c < v) c <<=
 
 // Lays out one job's workspace. With base == nullptr only the sizes are computed.
 // zero_bytes = size of the leading region that must be zeroed before each batch.
-size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes) {
+size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_bytes) {
   Carver C;
   const size_t nfi = J.nf_in, nc = 3 * nfi;
   const uint32_t maxq = (uint32_t)std::max(J.qp, std::max(J.qt, J.qn));
@@ -892,13 +1024,16 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes) {
   }
   J.e_cap = pow2_at_least(2ull * nc + 2);
   CARVE(J.e_key, uint64_t, J.e_cap); CARVE(J.e_val, uint32_t, J.e_cap);
-  CARVE(J.fvis, uint8_t, nfi + 1); CARVE(J.vvis, uint8_t, nc + 1); CARVE(J.f2split, int32_t, nfi + 1);
-  for (int t = 0; t < 3; t++) { CARVE(J.t_fvis[t], uint8_t, nfi + 1); CARVE(J.t_vvis[t], uint8_t, nc + 1); }
+  CARVE(J.fvis, uint8_t, nfi + 64); CARVE(J.vvis, uint8_t, nc + 64); CARVE(J.f2split, int32_t, 4);
+  for (int t = 0; t < 3; t++) { CARVE(J.t_fvis[t], uint8_t, nfi + 64); CARVE(J.t_vvis[t], uint8_t, nc + 64); }
   for (int s = 0; s < GEO_NSTREAM; s++) {
     J.rs[s].alpha_cap = s < 6 ? 8 : alpha_big;
     CARVE(J.rs[s].freq, uint32_t, J.rs[s].alpha_cap);
   }
   *zero_bytes = (C.off + 255) & ~(size_t)255;
+  // ---- 0x7f-filled region (face encode times start at +inf) ----
+  CARVE(J.face_time, int32_t, nfi + 1);
+  *fill7f_bytes = ((C.off + 255) & ~(size_t)255) - *zero_bytes;
   // ---- the rest ----
   CARVE(J.canon[0], uint32_t, J.n_pos + 1); CARVE(J.canon[1], uint32_t, J.n_uv + 1); CARVE(J.canon[2], uint32_t, J.n_nrm + 1);
   CARVE(J.keep, uint8_t, nfi + 1); CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8);
@@ -906,6 +1041,8 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes) {
   CARVE(J.opp, int32_t, nc + 3); CARVE(J.vert, int32_t, nc + 3); CARVE(J.ring, int32_t, nc + 3); CARVE(J.vopen, uint8_t, nc + 3);
   CARVE(J.vval, int32_t, nc + nfi + 3); CARVE(J.c2vm, int32_t, nc + 3);
   CARVE(J.proc, int32_t, nfi + 1); CARVE(J.initc, int32_t, nfi + 1); CARVE(J.stack, int32_t, nfi + 2);
+  for (int w = 0; w < 4; w++) CARVE(J.rec[w], int32_t, 8 * (nfi + 1));
+  CARVE(J.symb, uint8_t, nfi + 64); CARVE(J.ctx_of, uint8_t, nfi + 64);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2); CARVE(J.ev_spl, int32_t, 2 * nfi + 2); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1);
   CARVE(J.start_bits, uint8_t, nfi + 1);
@@ -955,6 +1092,13 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
       fprintf(stderr, "[uvol]   job0 status %d nf %u nverts %u ne %u %u %u ne_uv %u has_ori %p bsum %p elig %p n_ori %u\n", dbg_.status, dbg_.nf, dbg_.nverts, dbg_.ne[0], dbg_.ne[1], dbg_.ne[2], dbg_.ne_uv, (void*)dbg_.has_ori, (void*)dbg_.bsum, (void*)dbg_.elig, dbg_.n_ori); fflush(stderr); } \
   } while (0)
 
+#define LAUNCH_SM(k, grid, block, shmem, ...)                                                    \
+  do {                                                                                           \
+    if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s (lds %zu)\n", #k, (size_t)(shmem)); fflush(stderr); } \
+    hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, __VA_ARGS__);                         \
+    if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
+  } while (0)
+
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   GeoState *G = ctx->geo;
@@ -975,7 +1119,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
     { int k = 0; if (J.has_uv) J.att_kind[k++] = 0; if (J.has_nrm) J.att_kind[k++] = 1; for (; k < 2; k++) J.att_kind[k] = -1; }
-    size_t zb; size_t sz = layout_job(J, nullptr, &zb);
+    size_t zb, f7; size_t sz = layout_job(J, nullptr, &zb, &f7);
     ws_off[i] = ws_total; ws_total += sz; zero_sz[i] = zb;
     const size_t in_sz = ((size_t)m.n_pos * 12 + 255) / 256 * 256 + ((size_t)J.n_uv * 8 + 255) / 256 * 256 + ((size_t)J.n_nrm * 12 + 255) / 256 * 256 +
                          (size_t)(1 + J.has_uv + J.has_nrm) * (((size_t)m.n_faces * 12 + 255) / 256 * 256);
@@ -993,8 +1137,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     uint8_t *base = (uint8_t *)G->slab.p + ws_off[i];
-    size_t zb; layout_job(J, base, &zb);
+    size_t zb, f7; layout_job(J, base, &zb, &f7);
     UVOL_HIP_CHECK(ctx, hipMemsetAsync(base, 0, zero_sz[i], ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipMemsetAsync(base + zb, 0x7f, f7, ctx->stream));
     J.out = (uint8_t *)G->outs.p + out_off[i];
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
     else {
@@ -1039,7 +1184,22 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
-  { uvol_ctx::Scope sc(ctx, "geo.k4_edgebreaker", 0); LAUNCH(k_edgebreaker, dim3(N), dim3(64), dj); }
+  const size_t walk_lds = (((size_t)max_nfi + 31) / 32 + ((size_t)3 * max_nfi + 31) / 32) * 4;
+  const bool use_lds = walk_lds <= G->max_lds;
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
+    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
+    if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj); else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj);
+  }
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence_ctx", 0);
+    LAUNCH(k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
+    LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
+    LAUNCH(k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_eb_valence, dim3(N), dim3(64), dj);
+    LAUNCH(k_eb_ctx, dim3(N), dim3(64), dj);
+  }
   {
     uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
@@ -1052,7 +1212,13 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 2);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 3);
   }
-  { uvol_ctx::Scope sc(ctx, "geo.k5_traverse", 0); LAUNCH(k_traverse, dim3(3, N), dim3(64), dj); }
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
+    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 1);
+    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 2);
+    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 3);
+    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj); else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj);
+  }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
     LAUNCH(k_minmax, dim3(bv, N), dim3(UVOL_BLOCK), dj);

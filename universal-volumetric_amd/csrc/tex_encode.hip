@@ -165,9 +165,42 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force)
   const uint32_t nl = V.nl, ncap = nl < (uint32_t)LCAP ? nl : (uint32_t)LCAP, stride = 1 + 2 * DIM;
   for (uint32_t k = threadIdx.x; k < ncap * stride; k += UVOL_BLOCK) lds[k] = 0;
   __syncthreads();
-  for (uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x; i < V.n_items; i += gridDim.x * UVOL_BLOCK) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    bool todo = i < V.n_items;
+    const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
+    if (DIM == 16) {
+      // Unit-weight selector vectors: while the wave's items sit in few leaves (the contended early
+      // rounds) count with ballots — c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 —
+      // and let 33 lanes post one add each; whatever is left after 4 leaders takes the atomic path.
+      const uint32_t sw = todo ? J.bsel[J.item[i]] : 0;
+      unsigned long long rem = __ballot(todo);
+      for (int rounds = 0; rounds < 4 && rem; rounds++) {
+        const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
+        const uint32_t ll = UVOL_READLANE(l, leader);
+        const bool inm = todo && l == ll;
+        const unsigned long long m = __ballot(inm);
+        uint32_t myv = 0;
+        for (int d = 0; d < 16; d++) {
+          const uint32_t xv = (sw >> (2 * d)) & 3u;
+          const uint32_t c1 = (uint32_t)__popcll(__ballot(inm && xv == 1)), c2 = (uint32_t)__popcll(__ballot(inm && xv == 2)), c3 = (uint32_t)__popcll(__ballot(inm && xv == 3));
+          if (lane == (uint32_t)(1 + d)) myv = c1 + 2 * c2 + 3 * c3;
+          if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
+        }
+        if (lane == 0) myv = (uint32_t)__popcll(m);
+        if (lane < 33 && myv) {
+          if (ll < ncap) atomicAdd(&lds[(size_t)ll * stride + lane], (CT)myv);
+          else if (lane == 0) atomicAdd(&V.stW[ll], (unsigned long long)myv);
+          else if (lane <= 16) atomicAdd(&V.stS[(size_t)ll * DIM + (lane - 1)], (unsigned long long)myv);
+          else atomicAdd(&V.stQ[(size_t)ll * DIM + (lane - 17)], (unsigned long long)myv);
+        }
+        rem &= ~m;
+        if (inm) todo = false;
+      }
+    }
+    if (!todo) continue;
     int x[DIM]; unsigned long long w; vq_item<DIM>(J, i, x, w);
-    const uint32_t l = V.leaf[i];
     if (l < ncap) {
       CT *p = lds + (size_t)l * stride;
       atomicAdd(&p[0], (CT)w);
@@ -449,6 +482,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_preds(TexJob *job) {
 #define TOK(kind, sym, extra) ((unsigned long long)(kind) | ((unsigned long long)(sym) << 8) | ((unsigned long long)(extra) << 32))
 #define TOK_NOP 255ull
 
+// One wave per slice.  Lane k keeps selector-history entry k in a register (search = ballot, swap = two
+// lane reads); the four symbol histograms live in LDS and are owned by lane 0 (plain increments, flushed
+// once at the end); block fields are loaded 64 at a time, one block per lane, a chunk ahead of their use.
+template <bool LDS_HIST>
 __global__ void __launch_bounds__(64) k_symbolize(TexJob *job) {
   TexJob &J = *job;
   const uint32_t l = blockIdx.x, lane = threadIdx.x;
@@ -457,43 +494,54 @@ __global__ void __launch_bounds__(64) k_symbolize(TexJob *job) {
   const size_t o = (size_t)l * J.nb;
   const uint16_t *ei = J.bei + o, *si = J.bsi + o; const uint8_t *sk = J.skip + o, *pr = J.pred + o;
   unsigned long long *T = J.tok + 3 * o;
+  UVOL_DYN_SMEM(uint32_t, lh);
+  const uint32_t o_ep = 0, o_de = 257, o_sel = 257 + J.Kmax_e, o_rle = o_sel + J.Kmax_s + TEX_HS + 1, n_lh = o_rle + 64;
+  if (LDS_HIST) { for (uint32_t k = lane; k < n_lh; k += 64) lh[k] = 0; __syncthreads(); }
   uint32_t *f_ep = J.hm[0].freq, *f_de = J.hm[1].freq, *f_sel = J.hm[2].freq, *f_rle = J.hm[3].freq;
+#define CNT(arr, off, idx) do { if (LDS_HIST) lh[(off) + (idx)]++; else atomicAdd(&arr[idx], 1u); } while (0)
   const bool is_p = l > 0;
   uint32_t hist = lane;                         // lane k holds history entry k
   uint32_t rover = TEX_HS / 2, prev_sym = 0, prev_ei = 0;
   uint32_t ep_count = 0, ep_s1 = 0, ep_s2 = 0, sel_count = 0, sel_s1 = 0, sel_s2 = 0;
   const uint32_t SEL_RLE = ns + TEX_HS;
-  // lane 0 performs the stores; every lane runs the same (wave-uniform) control flow
-#define FIN_EP() do { if (lane == 0) { if (ep_count >= 3) { T[ep_s1] = TOK(1, 256, ep_count - 3); atomicAdd(&f_ep[256], 1u); } \
-      else { if (ep_count >= 1) { T[ep_s1] = TOK(0, prev_sym, 0); atomicAdd(&f_ep[prev_sym], 1u); } if (ep_count == 2) { T[ep_s2] = TOK(0, prev_sym, 0); atomicAdd(&f_ep[prev_sym], 1u); } } } ep_count = 0; } while (0)
-#define FIN_SEL() do { if (lane == 0) { if (sel_count >= 3) { const uint32_t rs_ = sel_count - 3 < 63 ? sel_count - 3 : 63; T[sel_s1] = TOK(4, rs_, rs_ == 63 ? sel_count - 3 : 0); atomicAdd(&f_sel[SEL_RLE], 1u); atomicAdd(&f_rle[rs_], 1u); } \
-      else { if (sel_count >= 1) { T[sel_s1] = TOK(3, ns, 0); atomicAdd(&f_sel[ns], 1u); } if (sel_count == 2) { T[sel_s2] = TOK(3, ns, 0); atomicAdd(&f_sel[ns], 1u); } } } sel_count = 0; } while (0)
-  for (uint32_t base = 0; base < nb; base += 64) {
-    const uint32_t mb = base + lane; const bool in = mb < nb;
-    // coalesced per-lane loads of 64 consecutive blocks, then a wave-uniform walk over them
-    uint32_t v_ei = in ? ei[mb] : 0, v_si = in ? si[mb] : 0, v_sk = in ? sk[mb] : 0, v_pr = in ? pr[mb] : 0, v_ms = 0;
-    if (in) {
+#define FIN_EP() do { if (lane == 0) { if (ep_count >= 3) { T[ep_s1] = TOK(1, 256, ep_count - 3); CNT(f_ep, o_ep, 256); } \
+      else { if (ep_count >= 1) { T[ep_s1] = TOK(0, prev_sym, 0); CNT(f_ep, o_ep, prev_sym); } if (ep_count == 2) { T[ep_s2] = TOK(0, prev_sym, 0); CNT(f_ep, o_ep, prev_sym); } } } ep_count = 0; } while (0)
+#define FIN_SEL() do { if (lane == 0) { if (sel_count >= 3) { const uint32_t rs_ = sel_count - 3 < 63 ? sel_count - 3 : 63; T[sel_s1] = TOK(4, rs_, rs_ == 63 ? sel_count - 3 : 0); CNT(f_sel, o_sel, SEL_RLE); CNT(f_rle, o_rle, rs_); } \
+      else { if (sel_count >= 1) { T[sel_s1] = TOK(3, ns, 0); CNT(f_sel, o_sel, ns); } if (sel_count == 2) { T[sel_s2] = TOK(3, ns, 0); CNT(f_sel, o_sel, ns); } } } sel_count = 0; } while (0)
+  // per-lane fields of block (base+lane): A = ei | si<<16 ; B = pred | skip<<2 | origin<<3 | macro_symbol<<8
+  auto load_chunk = [&](uint32_t base, uint32_t &A, uint32_t &Bf) {
+    const uint32_t mb = base + lane; A = 0; Bf = 0;
+    if (mb < nb) {
+      A = (uint32_t)ei[mb] | ((uint32_t)si[mb] << 16);
+      const uint32_t p0 = pr[mb]; Bf = p0 | ((uint32_t)sk[mb] << 2);
       const uint32_t x = mb % bx, y = mb / bx;
       if (!(x & 1) && !(y & 1)) {
-        v_ms = v_pr;
-        if (x + 1 < bx) v_ms |= (uint32_t)pr[mb + 1] << 2;
-        if (y + 1 < by) { v_ms |= (uint32_t)pr[mb + bx] << 4; if (x + 1 < bx) v_ms |= (uint32_t)pr[mb + bx + 1] << 6; }
-        v_ms |= 0x100u;                           // origin marker
+        uint32_t ms = p0;
+        if (x + 1 < bx) ms |= (uint32_t)pr[mb + 1] << 2;
+        if (y + 1 < by) { ms |= (uint32_t)pr[mb + bx] << 4; if (x + 1 < bx) ms |= (uint32_t)pr[mb + bx + 1] << 6; }
+        Bf |= 8u | (ms << 8);
       }
+      T[3 * (size_t)mb] = TOK_NOP; T[3 * (size_t)mb + 1] = TOK_NOP; T[3 * (size_t)mb + 2] = TOK_NOP;
     }
-    if (in && lane < 64) { T[3 * mb] = TOK_NOP; T[3 * mb + 1] = TOK_NOP; T[3 * mb + 2] = TOK_NOP; }
+  };
+  uint32_t nA = 0, nB = 0;
+  if (nb) load_chunk(0, nA, nB);
+  for (uint32_t base = 0; base < nb; base += 64) {
+    const uint32_t cA = nA, cB = nB;
+    if (base + 64 < nb) load_chunk(base + 64, nA, nB);      // prefetch the next 64 blocks
     const uint32_t cnt = nb - base < 64 ? nb - base : 64;
     for (uint32_t j = 0; j < cnt; j++) {
       const uint32_t b = base + j;
-      const uint32_t c_ei = __shfl(v_ei, (int)j), c_si = __shfl(v_si, (int)j), c_sk = __shfl(v_sk, (int)j), c_pr = __shfl(v_pr, (int)j), c_ms = __shfl(v_ms, (int)j);
-      if (c_ms & 0x100u) {
-        const uint32_t ms = c_ms & 0xffu;
+      const uint32_t a = UVOL_READLANE(cA, j), f = UVOL_READLANE(cB, j);
+      const uint32_t c_ei = a & 0xffffu, c_si = a >> 16, c_pr = f & 3u, c_sk = (f >> 2) & 1u;
+      if (f & 8u) {
+        const uint32_t ms = (f >> 8) & 0xffu;
         if (ms == prev_sym) { ep_count++; if (ep_count == 1) ep_s1 = 3 * b; else if (ep_count == 2) ep_s2 = 3 * b; }
-        else { FIN_EP(); if (lane == 0) { T[3 * b] = TOK(0, ms, 0); atomicAdd(&f_ep[ms], 1u); } prev_sym = ms; }
+        else { FIN_EP(); if (lane == 0) { T[3 * (size_t)b] = TOK(0, ms, 0); CNT(f_ep, o_ep, ms); } prev_sym = ms; }
       }
       if (c_pr == 3) {
         const uint32_t d = c_ei >= prev_ei ? c_ei - prev_ei : c_ei + ne - prev_ei;
-        if (lane == 0) { T[3 * b + 1] = TOK(2, d, 0); atomicAdd(&f_de[d], 1u); }
+        if (lane == 0) { T[3 * (size_t)b + 1] = TOK(2, d, 0); CNT(f_de, o_de, d); }
       }
       prev_ei = c_ei;
       if (!(is_p && c_sk)) {
@@ -503,11 +551,11 @@ __global__ void __launch_bounds__(64) k_symbolize(TexJob *job) {
         else {
           FIN_SEL();
           if (h < TEX_HS) {
-            if (lane == 0) { T[3 * b + 2] = TOK(3, ns + h, 0); atomicAdd(&f_sel[ns + h], 1u); }
-            const uint32_t a = __shfl(hist, (int)h), c = __shfl(hist, (int)(h / 2));
-            if (lane == h) hist = c; else if (lane == h / 2) hist = a;
+            if (lane == 0) { T[3 * (size_t)b + 2] = TOK(3, ns + h, 0); CNT(f_sel, o_sel, ns + h); }
+            const uint32_t va = UVOL_READLANE(hist, h), vc = UVOL_READLANE(hist, h / 2);
+            if (lane == h) hist = vc; else if (lane == h / 2) hist = va;
           } else {
-            if (lane == 0) { T[3 * b + 2] = TOK(3, c_si, 0); atomicAdd(&f_sel[c_si], 1u); }
+            if (lane == 0) { T[3 * (size_t)b + 2] = TOK(3, c_si, 0); CNT(f_sel, o_sel, c_si); }
             if (lane == rover) hist = c_si;
             rover++; if (rover == TEX_HS) rover = TEX_HS / 2;
           }
@@ -516,8 +564,16 @@ __global__ void __launch_bounds__(64) k_symbolize(TexJob *job) {
     }
   }
   if (ok) { FIN_SEL(); FIN_EP(); }
+  if (LDS_HIST) {
+    __syncthreads();
+    if (ok) for (uint32_t k = lane; k < n_lh; k += 64) {
+      const uint32_t v = lh[k]; if (!v) continue;
+      if (k < o_de) atomicAdd(&f_ep[k], v); else if (k < o_sel) atomicAdd(&f_de[k - o_de], v); else if (k < o_rle) atomicAdd(&f_sel[k - o_sel], v); else atomicAdd(&f_rle[k - o_rle], v);
+    }
+  }
 #undef FIN_EP
 #undef FIN_SEL
+#undef CNT
 }
 
 // ---- cooperative (one workgroup) Huffman construction; mirrors the CPU restatement exactly ----
@@ -912,7 +968,9 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
   {
     uvol_ctx::Scope sc(ctx, "tex.k12_symbolize", (uint64_t)J.NB * 6);
     TLAUNCH(k_preds, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
-    TLAUNCH(k_symbolize, dim3(J.L), dim3(64), 0, dj);
+    const size_t lh_bytes = (size_t)(257 + J.Kmax_e + J.Kmax_s + TEX_HS + 1 + 64) * 4;
+    if (lh_bytes <= 60 * 1024) TLAUNCH((k_symbolize<true>), dim3(J.L), dim3(64), lh_bytes, dj);
+    else TLAUNCH((k_symbolize<false>), dim3(J.L), dim3(64), 0, dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "tex.k12_huffman_pack", (uint64_t)J.NB * 24);

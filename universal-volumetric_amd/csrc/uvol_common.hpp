@@ -13,6 +13,13 @@
 
 #define UVOL_BLOCK 256
 
+// wave-uniform lane read (v_readlane on the GPU, a shuffle in the shim)
+#ifdef HIPEMU
+#define UVOL_READLANE(v, l) ((uint32_t)__shfl((uint32_t)(v), (int)(l)))
+#else
+#define UVOL_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
+#endif
+
 // dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
 #ifdef HIPEMU
 #define UVOL_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu_dyn_smem)
