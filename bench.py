@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
+    ap.add_argument("--tex-streams", type=int, default=2, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,19 +86,24 @@ def main():
 
     cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
     geo = uvol.Codec(device=local_rank, **cfg)
-    tex = uvol.Codec(device=local_rank, **cfg)
+    texs = [uvol.Codec(device=local_rank, **cfg) for _ in range(max(1, args.tex_streams))]
     batch = (uvol.Mesh * F)(*[dev_meshes[i % args.distinct] for i in range(F)])
     out = {}
 
     def run_geo():
         out["drc"] = geo.encode_mesh_batch_dev(batch)
 
-    def run_tex():
-        out["ktx2"] = [tex.encode_texture_segment_dev(tex_ptrs, args.tex_size, args.tex_size) for _ in range(nseg)]
+    def run_tex(ti):
+        out["ktx2_%d" % ti] = [texs[ti].encode_texture_segment_dev(tex_ptrs, args.tex_size, args.tex_size)
+                               for _ in range(ti, nseg, len(texs))]
 
     def step():
-        a = threading.Thread(target=run_geo); b = threading.Thread(target=run_tex)
-        a.start(); b.start(); a.join(); b.join()
+        th = [threading.Thread(target=run_geo)] + [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        out["ktx2"] = [k for ti in range(len(texs)) for k in out["ktx2_%d" % ti]]
 
     def barrier():
         if world > 1:
@@ -106,7 +112,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    geo.profile(True); tex.profile(True); geo.profile_reset(); tex.profile_reset()
+    geo.profile(True); geo.profile_reset()
+    for t in texs:
+        t.profile(True); t.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -131,7 +139,13 @@ def main():
         drc_len = sum(len(x) for x in out["drc"]) / F
         ktx_len = sum(len(x) for x in out["ktx2"]) / F
         algo_per_frame = 32.0 * V + 12.0 * Fc + 4.0 * args.tex_size ** 2 + drc_len + ktx_len
-        groups = geo.profile_report() + tex.profile_report()
+        groups = geo.profile_report()
+        tg = {}
+        for t in texs:
+            for g in t.profile_report():
+                a = tg.setdefault(g["name"], dict(name=g["name"], launches=0, total_ms=0.0, algo_bytes=0))
+                a["launches"] += g["launches"]; a["total_ms"] += g["total_ms"]; a["algo_bytes"] += g["algo_bytes"]
+        groups += list(tg.values())
         groups.sort(key=lambda g: -g["total_ms"])
         dom = groups[0]
         units = F if dom["name"].startswith("geo.") else B                      # frames one launch of that group processes
@@ -144,7 +158,7 @@ def main():
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
                                    "%d frames per step, qp11/qt10/qn8/cl7" % (V, Fc, args.tex_size, args.tex_size, B, F),
-                       "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU, geometry+texture on 2 streams",
+                       "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU 1 geometry stream + %d texture streams" % len(texs),
                        "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "units_per_launch": units,
@@ -155,7 +169,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
         print(json.dumps(res))
-    geo.close(); tex.close()
+    geo.close()
+    for t in texs:
+        t.close()
     if world > 1:
         dist.destroy_process_group()
 

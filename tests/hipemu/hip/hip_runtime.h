@@ -37,6 +37,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned X = 1, unsigned Y = 1, unsigned Z 
 struct hipemu_uint3 { unsigned x, y, z; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) int4 { int x, y, z, w; };
 inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 extern thread_local hipemu_uint3 threadIdx, blockIdx;

@@ -820,56 +820,97 @@ __global__ void __launch_bounds__(64) k_rans_tables(GeoJob *jobs) {
   S.head_len = o;
 }
 
-__global__ void __launch_bounds__(64) k_rans_encode(GeoJob *jobs) {
+// rANS (blockIdx.x < GEO_NSTREAM) and rabs (blockIdx.x >= GEO_NSTREAM) state machines, one wave per stream, all
+// streams of all frames in ONE launch.  Symbols / bits are prefetched 64 at a time (one per lane, read back with
+// v_readlane), the {prob, cum} table sits in LDS, and output bytes are staged one per lane and stored 64 at a time.
+#define RANS_LDS_ENTRIES 6144
+__global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
-  RansStream &S = J.rs[blockIdx.x];
-  if (threadIdx.x != 0 || J.status != 0 || S.n == 0) return;
-  const uint32_t prec_bits = S.prec_bits, prec = 1u << prec_bits, L = prec * 4;
-  const uint32_t *probs = S.probs, *cum = S.cum, *syms = S.syms;
-  uint8_t *pay = S.pay + 8; uint32_t w = 0; const uint32_t cap = S.pay_cap - 16;
-  uint32_t st = L;
-  for (long long i = (long long)S.n - 1; i >= 0; i--) {
-    const uint32_t s = syms[i], p = probs[s];
-    const unsigned long long lim = (unsigned long long)(L >> prec_bits) * 256ull * p;
-    while (st >= lim) { if (w < cap) pay[w] = (uint8_t)(st & 255); w++; st >>= 8; }
-    st = (st / p) * prec + st % p + cum[s];
+  UVOL_DYN_SMEM(uint2, tab);
+  const uint32_t lane = threadIdx.x;
+  const bool ok = J.status == 0;
+  uint32_t stage = 0, w = 0;
+  if (blockIdx.x < GEO_NSTREAM) {
+    RansStream &S = J.rs[blockIdx.x];
+    const uint32_t n = ok ? S.n : 0;
+    const uint32_t ns = S.max_sym + 1;
+    const bool in_lds = ns <= RANS_LDS_ENTRIES;
+    if (n && in_lds) for (uint32_t k = lane; k < ns; k += 64) tab[k] = make_uint2(S.probs[k], S.cum[k]);
+    __syncthreads();
+    if (!n) return;
+    const uint32_t prec_bits = S.prec_bits, prec = 1u << prec_bits, L = prec * 4;
+    const uint32_t *syms = S.syms;
+    uint8_t *pay = S.pay + 8; const uint32_t cap = S.pay_cap - 80;
+    uint32_t st = L;
+    for (uint32_t hi = n; hi > 0;) {
+      const uint32_t cnt = hi < 64 ? hi : 64;
+      const uint32_t sy = lane < cnt ? syms[hi - 1 - lane] : 0;      // lane j = j-th symbol from the end of the remaining range
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t sv = UVOL_READLANE(sy, j);
+        uint2 e; if (in_lds) e = tab[sv]; else e = make_uint2(S.probs[sv], S.cum[sv]);
+        const uint32_t p = e.x, lim = 1024u * p;
+        while (st >= lim) {
+          if (lane == (w & 63)) stage = st & 255;
+          w++; st >>= 8;
+          if ((w & 63) == 0 && w <= cap) pay[w - 64 + lane] = (uint8_t)stage;
+        }
+        const uint32_t q = st / p;
+        st = q * prec + (st - q * p) + e.y;
+      }
+      hi -= cnt;
+    }
+    if (w + 4 > cap) { if (lane == 0) J.status = -32; return; }
+    if (lane < (w & 63)) pay[(w & ~63u) + lane] = (uint8_t)stage;
+    __threadfence_block();
+    if (lane == 0) {
+      st -= L;
+      if (st < (1u << 6)) pay[w++] = (uint8_t)st;
+      else if (st < (1u << 14)) { const uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
+      else if (st < (1u << 22)) { const uint32_t v = (2u << 22) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; }
+      else { const uint32_t v = (3u << 30) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; pay[w++] = (v >> 24) & 255; }
+      const uint32_t vl = g_varint_len(w);
+      g_put_varint(S.pay + 8 - vl, w);
+      S.pay_off = 8 - vl; S.pay_len = vl + w;
+    }
+  } else {
+    RabsStream &B = J.rb[blockIdx.x - GEO_NSTREAM];
+    __syncthreads();
+    if (!ok) return;
+    const uint32_t n = B.n; const uint64_t total = n ? n : 1;
+    const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
+    uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
+    const uint32_t p = 256 - p0;
+    uint8_t *pay = B.buf + 8; const uint32_t cap = B.cap - 80;
+    uint32_t st = 4096;
+    for (uint32_t hi = n; hi > 0;) {
+      const uint32_t cnt = hi < 64 ? hi : 64;
+      const unsigned long long bm = __ballot(lane < cnt && B.bits[hi - 1 - lane] != 0);     // bit j = j-th bit from the end
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t bit = (uint32_t)((bm >> j) & 1ull), ls = bit ? p : p0;
+        if (st >= 4096u * ls) {
+          if (lane == (w & 63)) stage = st & 255;
+          w++; st >>= 8;
+          if ((w & 63) == 0 && w <= cap) pay[w - 64 + lane] = (uint8_t)stage;
+        }
+        const uint32_t q = st / ls;
+        st = q * 256 + (st - q * ls) + (bit ? 0u : p);
+      }
+      hi -= cnt;
+    }
+    if (w + 3 > cap) { if (lane == 0) J.status = -33; return; }
+    if (lane < (w & 63)) pay[(w & ~63u) + lane] = (uint8_t)stage;
+    __threadfence_block();
+    if (lane == 0) {
+      st -= 4096;
+      if (st < (1u << 6)) pay[w++] = (uint8_t)st;
+      else if (st < (1u << 14)) { const uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
+      else { const uint32_t v = (2u << 22) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; }
+      const uint32_t vl = g_varint_len(w);
+      g_put_varint(B.buf + 8 - vl, w);
+      B.buf[8 - vl - 1] = (uint8_t)p0;
+      B.off = 8 - vl - 1; B.len = 1 + vl + w;
+    }
   }
-  if (w + 4 > cap) { J.status = -32; return; }
-  st -= L;
-  if (st < (1u << 6)) pay[w++] = (uint8_t)st;
-  else if (st < (1u << 14)) { uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
-  else if (st < (1u << 22)) { uint32_t v = (2u << 22) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; }
-  else { uint32_t v = (3u << 30) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; pay[w++] = (v >> 24) & 255; }
-  const uint32_t vl = g_varint_len(w);
-  g_put_varint(S.pay + 8 - vl, w);
-  S.pay_off = 8 - vl; S.pay_len = vl + w;
-}
-
-// RAnsBitEncoder (rabs), one lane per stream
-__global__ void __launch_bounds__(64) k_rabs_encode(GeoJob *jobs) {
-  GeoJob &J = jobs[blockIdx.y];
-  RabsStream &B = J.rb[blockIdx.x];
-  if (threadIdx.x != 0 || J.status != 0) return;
-  const uint32_t n = B.n; const uint64_t total = n ? n : 1;
-  const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
-  uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
-  const uint32_t p = 256 - p0;
-  uint8_t *pay = B.buf + 8; uint32_t w = 0, st = 4096; const uint32_t cap = B.cap - 16;
-  for (long long i = (long long)n - 1; i >= 0; i--) {
-    const int bit = B.bits[i]; const uint32_t ls = bit ? p : p0;
-    if (st >= 16u * 256u * ls) { if (w < cap) pay[w] = (uint8_t)(st & 255); w++; st >>= 8; }
-    const uint32_t q = st / ls, r = st % ls;
-    st = q * 256 + r + (bit ? 0 : p);
-  }
-  if (w + 3 > cap) { J.status = -33; return; }
-  st -= 4096;
-  if (st < (1u << 6)) pay[w++] = (uint8_t)st;
-  else if (st < (1u << 14)) { uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
-  else { uint32_t v = (2u << 22) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; }
-  const uint32_t vl = g_varint_len(w);
-  g_put_varint(B.buf + 8 - vl, w);
-  B.buf[8 - vl - 1] = (uint8_t)p0;
-  B.off = 8 - vl - 1; B.len = 1 + vl + w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1060,7 +1101,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
     const size_t nsym = s < 6 ? nfi : (s == 6 ? 3 * nc : 2 * nc);
     CARVE(S.probs, uint32_t, S.alpha_cap); CARVE(S.cum, uint32_t, S.alpha_cap);
     CARVE(S.head, uint8_t, 3 * (size_t)S.alpha_cap + 32);
-    S.pay_cap = (uint32_t)(3 * nsym + 64); CARVE(S.pay, uint8_t, S.pay_cap);
+    S.pay_cap = (uint32_t)(3 * nsym + 256); CARVE(S.pay, uint8_t, S.pay_cap);
     S.syms = nullptr; S.n = 0; S.max_sym = 0; S.head_len = 0; S.pay_len = 0; S.pay_off = 0; S.prec_bits = 12;
   }
   // each big stream needs its own counting-sort scratch (k_rans_tables runs the 9 streams concurrently)
@@ -1069,7 +1110,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
   for (int b = 0; b < GEO_NRABS; b++) {
     RabsStream &B = J.rb[b];
     const size_t nb = b == 0 ? nfi : nc;
-    B.cap = (uint32_t)(nb / 4 + nb / 8 + 64); CARVE(B.buf, uint8_t, B.cap);
+    B.cap = (uint32_t)(nb / 4 + nb / 8 + 256); CARVE(B.buf, uint8_t, B.cap);
     B.bits = nullptr; B.n = 0; B.zeros = 0; B.off = 0; B.len = 0;
   }
   J.arena_cap = (uint32_t)(20 * nfi + 1024); CARVE(J.arena, uint8_t, J.arena_cap);
@@ -1239,8 +1280,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     uvol_ctx::Scope sc(ctx, "geo.k7_entropy", 0);
     LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_rans_tables, dim3(GEO_NSTREAM, N), dim3(64), dj);
-    LAUNCH(k_rans_encode, dim3(GEO_NSTREAM, N), dim3(64), dj);
-    LAUNCH(k_rabs_encode, dim3(GEO_NRABS, N), dim3(64), dj);
+    LAUNCH_SM(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), (size_t)RANS_LDS_ENTRIES * sizeof(uint2), dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k8_layout_gather", 0);

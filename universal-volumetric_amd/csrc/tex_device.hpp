@@ -44,6 +44,8 @@ struct TexJob {
   uint32_t n_items; uint32_t *item;             // coded (non-skipped) blocks, ascending
   uint32_t *scb; uint8_t *sused; uint32_t *scu; uint32_t ns; uint32_t *smap;
   uint8_t *pred;            // [NB]
+  uint32_t *clist; uint32_t ncoded[TEX_MAX_LAYERS];   // coded (non-skipped) blocks per slice, raster order
+  uint8_t *msym; uint32_t *gid, *gstart, *gsize;       // macroblock symbols and their equal-value groups
   unsigned long long *tok;  // [NB*3]  kind | sym<<8 | extra<<32
   TexHuff hm[TEX_NMODEL];
   uint32_t *hscratch;       // Huffman build scratch

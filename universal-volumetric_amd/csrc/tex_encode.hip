@@ -482,98 +482,174 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_preds(TexJob *job) {
 #define TOK(kind, sym, extra) ((unsigned long long)(kind) | ((unsigned long long)(sym) << 8) | ((unsigned long long)(extra) << 32))
 #define TOK_NOP 255ull
 
-// One wave per slice.  Lane k keeps selector-history entry k in a register (search = ballot, swap = two
-// lane reads); the four symbol histograms live in LDS and are owned by lane 0 (plain increments, flushed
-// once at the end); block fields are loaded 64 at a time, one block per lane, a chunk ahead of their use.
-template <bool LDS_HIST>
-__global__ void __launch_bounds__(64) k_symbolize(TexJob *job) {
+// ---- per-slice scans: flags at J.flag[l*stride + i], block sums at J.bsum[l*(nblk+1) + blk] ----
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sscan_a(TexJob *job, uint32_t n, uint32_t stride) {
+  TexJob &J = *job;
+  const uint32_t l = blockIdx.y, i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  uint32_t v = (J.status == 0 && i < n) ? J.flag[(size_t)l * stride + i] : 0, tot;
+  t_block_excl_scan(v, &tot);
+  if (threadIdx.x == 0) J.bsum[(size_t)l * (gridDim.x + 1) + blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sscan_b(TexJob *job, uint32_t nblocks) {
+  TexJob &J = *job;
+  uint32_t *bs = J.bsum + (size_t)blockIdx.x * (nblocks + 1);
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += UVOL_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < nblocks ? bs[i] : 0, tot;
+    const uint32_t ex = t_block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    if (i < nblocks) bs[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bs[nblocks] = carry;
+}
+
+// delta-endpoint tokens + slot initialisation + "coded block" flags (parallel; prev_ei is simply the raster predecessor)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tok_delta(TexJob *job) {
+  TJOB_OR_RETURN;
+  const uint32_t b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (b >= J.NB) return;
+  const uint32_t l = b / J.nb, r = b % J.nb;
+  const uint32_t e = J.bei[b], pe = r ? J.bei[b - 1] : 0u;
+  unsigned long long *T = J.tok + 3 * (size_t)b;
+  T[0] = TOK_NOP; T[2] = TOK_NOP;
+  T[1] = J.pred[b] == 3 ? TOK(2, e >= pe ? e - pe : e + J.ne - pe, 0) : TOK_NOP;
+  J.flag[b] = (l > 0 && J.skip[b]) ? 0 : 1;
+}
+// coded blocks of each slice, in raster order
+__global__ void __launch_bounds__(UVOL_BLOCK) k_coded_list(TexJob *job) {
+  TexJob &J = *job;
+  const uint32_t l = blockIdx.y, i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && i < J.nb;
+  uint32_t v = live ? J.flag[(size_t)l * J.nb + i] : 0, tot;
+  const uint32_t pos = t_block_excl_scan(v, &tot) + J.bsum[(size_t)l * (gridDim.x + 1) + blockIdx.x];
+  if (live && v) J.clist[(size_t)l * J.nb + pos] = i;
+  if (blockIdx.x == 0 && threadIdx.x == 0) J.ncoded[l] = J.status == 0 ? J.bsum[(size_t)l * (gridDim.x + 1) + gridDim.x] : 0;
+}
+// macroblock symbols (2x2 blocks, 2 bits each) and equal-value group boundaries
+__device__ __forceinline__ uint32_t t_macro_sym(const TexJob &J, uint32_t l, uint32_t k) {
+  const uint32_t mbx = (J.bx + 1) / 2, x = 2 * (k % mbx), y = 2 * (k / mbx);
+  const uint8_t *pr = J.pred + (size_t)l * J.nb; const uint32_t b = y * J.bx + x;
+  uint32_t ms = pr[b];
+  if (x + 1 < J.bx) ms |= (uint32_t)pr[b + 1] << 2;
+  if (y + 1 < J.by) { ms |= (uint32_t)pr[b + J.bx] << 4; if (x + 1 < J.bx) ms |= (uint32_t)pr[b + J.bx + 1] << 6; }
+  return ms;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_mb_flags(TexJob *job, uint32_t nm) {
+  TJOB_OR_RETURN;
+  const uint32_t l = blockIdx.y, k = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (k >= nm) return;
+  const uint32_t ms = t_macro_sym(J, l, k), pm = k ? t_macro_sym(J, l, k - 1) : 0u;
+  J.msym[(size_t)l * nm + k] = (uint8_t)ms;
+  J.flag[(size_t)l * nm + k] = ms != pm ? 1 : 0;          // group boundary (the decoder's prev_sym starts at 0)
+  J.gsize[(size_t)l * nm + k] = 0;
+}
+// gid = number of boundaries up to and including k (0 = the leading group that continues prev_sym = 0)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_mb_groups(TexJob *job, uint32_t nm) {
+  TexJob &J = *job;
+  const uint32_t l = blockIdx.y, k = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && k < nm;
+  uint32_t v = live ? J.flag[(size_t)l * nm + k] : 0, tot;
+  const uint32_t ex = t_block_excl_scan(v, &tot) + J.bsum[(size_t)l * (gridDim.x + 1) + blockIdx.x];
+  if (!live) return;
+  const uint32_t g = ex + v;
+  J.gid[(size_t)l * nm + k] = g;
+  if (v || k == 0) J.gstart[(size_t)l * nm + g] = k;
+  atomicAdd(&J.gsize[(size_t)l * nm + g], 1u);
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_mb_tokens(TexJob *job, uint32_t nm) {
+  TJOB_OR_RETURN;
+  const uint32_t l = blockIdx.y, k = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (k >= nm) return;
+  const size_t o = (size_t)l * nm;
+  const uint32_t g = J.gid[o + k], st = J.gstart[o + g], sz = J.gsize[o + g], ms = J.msym[o + k];
+  const uint32_t lit = g > 0 ? 1u : 0u;                    // groups > 0 open with a literal symbol
+  const uint32_t run_first = st + lit, run_len = sz - lit;
+  const uint32_t mbx = (J.bx + 1) / 2, b = (2 * (k / mbx)) * J.bx + 2 * (k % mbx);
+  unsigned long long tk = TOK_NOP;
+  if (lit && k == st) tk = TOK(0, ms, 0);
+  else if (run_len >= 3) { if (k == run_first) tk = TOK(1, 256, run_len - 3); }
+  else tk = TOK(0, ms, 0);
+  J.tok[3 * ((size_t)l * J.nb + b)] = tk;
+}
+
+// selector tokens: the 64-entry history (move-towards-front by index halving, rover insertion) is inherently
+// sequential.  One wave per slice; lane k keeps history entry k in a register (search = ballot + ffs, swap = two
+// lane reads); the coded blocks are prefetched 64 at a time; tokens are collected per lane and stored coalesced.
+__global__ void __launch_bounds__(64) k_sel_tokens(TexJob *job) {
   TexJob &J = *job;
   const uint32_t l = blockIdx.x, lane = threadIdx.x;
   const bool ok = J.status == 0;
-  const uint32_t nb = ok ? J.nb : 0, bx = J.bx, by = J.by, ne = J.ne, ns = J.ns;
+  const uint32_t n = ok ? J.ncoded[l] : 0, ns = J.ns;
   const size_t o = (size_t)l * J.nb;
-  const uint16_t *ei = J.bei + o, *si = J.bsi + o; const uint8_t *sk = J.skip + o, *pr = J.pred + o;
+  const uint32_t *cl = J.clist + o; const uint16_t *si = J.bsi + o;
   unsigned long long *T = J.tok + 3 * o;
-  UVOL_DYN_SMEM(uint32_t, lh);
-  const uint32_t o_ep = 0, o_de = 257, o_sel = 257 + J.Kmax_e, o_rle = o_sel + J.Kmax_s + TEX_HS + 1, n_lh = o_rle + 64;
-  if (LDS_HIST) { for (uint32_t k = lane; k < n_lh; k += 64) lh[k] = 0; __syncthreads(); }
-  uint32_t *f_ep = J.hm[0].freq, *f_de = J.hm[1].freq, *f_sel = J.hm[2].freq, *f_rle = J.hm[3].freq;
-#define CNT(arr, off, idx) do { if (LDS_HIST) lh[(off) + (idx)]++; else atomicAdd(&arr[idx], 1u); } while (0)
-  const bool is_p = l > 0;
-  uint32_t hist = lane;                         // lane k holds history entry k
-  uint32_t rover = TEX_HS / 2, prev_sym = 0, prev_ei = 0;
-  uint32_t ep_count = 0, ep_s1 = 0, ep_s2 = 0, sel_count = 0, sel_s1 = 0, sel_s2 = 0;
-  const uint32_t SEL_RLE = ns + TEX_HS;
-#define FIN_EP() do { if (lane == 0) { if (ep_count >= 3) { T[ep_s1] = TOK(1, 256, ep_count - 3); CNT(f_ep, o_ep, 256); } \
-      else { if (ep_count >= 1) { T[ep_s1] = TOK(0, prev_sym, 0); CNT(f_ep, o_ep, prev_sym); } if (ep_count == 2) { T[ep_s2] = TOK(0, prev_sym, 0); CNT(f_ep, o_ep, prev_sym); } } } ep_count = 0; } while (0)
-#define FIN_SEL() do { if (lane == 0) { if (sel_count >= 3) { const uint32_t rs_ = sel_count - 3 < 63 ? sel_count - 3 : 63; T[sel_s1] = TOK(4, rs_, rs_ == 63 ? sel_count - 3 : 0); CNT(f_sel, o_sel, SEL_RLE); CNT(f_rle, o_rle, rs_); } \
-      else { if (sel_count >= 1) { T[sel_s1] = TOK(3, ns, 0); CNT(f_sel, o_sel, ns); } if (sel_count == 2) { T[sel_s2] = TOK(3, ns, 0); CNT(f_sel, o_sel, ns); } } } sel_count = 0; } while (0)
-  // per-lane fields of block (base+lane): A = ei | si<<16 ; B = pred | skip<<2 | origin<<3 | macro_symbol<<8
-  auto load_chunk = [&](uint32_t base, uint32_t &A, uint32_t &Bf) {
-    const uint32_t mb = base + lane; A = 0; Bf = 0;
-    if (mb < nb) {
-      A = (uint32_t)ei[mb] | ((uint32_t)si[mb] << 16);
-      const uint32_t p0 = pr[mb]; Bf = p0 | ((uint32_t)sk[mb] << 2);
-      const uint32_t x = mb % bx, y = mb / bx;
-      if (!(x & 1) && !(y & 1)) {
-        uint32_t ms = p0;
-        if (x + 1 < bx) ms |= (uint32_t)pr[mb + 1] << 2;
-        if (y + 1 < by) { ms |= (uint32_t)pr[mb + bx] << 4; if (x + 1 < bx) ms |= (uint32_t)pr[mb + bx + 1] << 6; }
-        Bf |= 8u | (ms << 8);
-      }
-      T[3 * (size_t)mb] = TOK_NOP; T[3 * (size_t)mb + 1] = TOK_NOP; T[3 * (size_t)mb + 2] = TOK_NOP;
-    }
-  };
-  uint32_t nA = 0, nB = 0;
-  if (nb) load_chunk(0, nA, nB);
-  for (uint32_t base = 0; base < nb; base += 64) {
-    const uint32_t cA = nA, cB = nB;
-    if (base + 64 < nb) load_chunk(base + 64, nA, nB);      // prefetch the next 64 blocks
-    const uint32_t cnt = nb - base < 64 ? nb - base : 64;
+  uint32_t hist = lane, rover = TEX_HS / 2;
+  uint32_t run = 0, run_e1 = 0, run_e2 = 0;            // pending history[0] run: length and element indices of its first two members
+  auto load_chunk = [&](uint32_t base, uint32_t &B, uint32_t &S) { const uint32_t e = base + lane; B = 0; S = 0; if (e < n) { B = cl[e]; S = si[B]; } };
+  uint32_t nB = 0, nS = 0;
+  if (n) load_chunk(0, nB, nS);
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t cB = nB, cS = nS;
+    if (base + 64 < n) load_chunk(base + 64, nB, nS);
+    unsigned long long mytok = TOK_NOP;
+    const uint32_t cnt = n - base < 64 ? n - base : 64;
+    // finalise a pending run; its members may sit in this chunk (lane registers) or in an earlier one (direct store)
+#define PUT_TOK(e, tk) do { if ((e) >= base) { if (lane == (e) - base) mytok = (tk); } else if (lane == 0) T[3 * (size_t)cl[(e)] + 2] = (tk); } while (0)
+#define FIN_RUN() do { if (run >= 3) { const uint32_t rs_ = run - 3 < 63 ? run - 3 : 63; PUT_TOK(run_e1, TOK(4, rs_, rs_ == 63 ? run - 3 : 0)); } \
+      else { if (run >= 1) PUT_TOK(run_e1, TOK(3, ns, 0)); if (run == 2) PUT_TOK(run_e2, TOK(3, ns, 0)); } run = 0; } while (0)
     for (uint32_t j = 0; j < cnt; j++) {
-      const uint32_t b = base + j;
-      const uint32_t a = UVOL_READLANE(cA, j), f = UVOL_READLANE(cB, j);
-      const uint32_t c_ei = a & 0xffffu, c_si = a >> 16, c_pr = f & 3u, c_sk = (f >> 2) & 1u;
-      if (f & 8u) {
-        const uint32_t ms = (f >> 8) & 0xffu;
-        if (ms == prev_sym) { ep_count++; if (ep_count == 1) ep_s1 = 3 * b; else if (ep_count == 2) ep_s2 = 3 * b; }
-        else { FIN_EP(); if (lane == 0) { T[3 * (size_t)b] = TOK(0, ms, 0); CNT(f_ep, o_ep, ms); } prev_sym = ms; }
-      }
-      if (c_pr == 3) {
-        const uint32_t d = c_ei >= prev_ei ? c_ei - prev_ei : c_ei + ne - prev_ei;
-        if (lane == 0) { T[3 * (size_t)b + 1] = TOK(2, d, 0); CNT(f_de, o_de, d); }
-      }
-      prev_ei = c_ei;
-      if (!(is_p && c_sk)) {
-        const unsigned long long hit = __ballot(hist == c_si);
-        const uint32_t h = hit ? (uint32_t)(__ffsll((long long)hit) - 1) : TEX_HS;
-        if (h == 0) { sel_count++; if (sel_count == 1) sel_s1 = 3 * b + 2; else if (sel_count == 2) sel_s2 = 3 * b + 2; }
-        else {
-          FIN_SEL();
-          if (h < TEX_HS) {
-            if (lane == 0) { T[3 * (size_t)b + 2] = TOK(3, ns + h, 0); CNT(f_sel, o_sel, ns + h); }
-            const uint32_t va = UVOL_READLANE(hist, h), vc = UVOL_READLANE(hist, h / 2);
-            if (lane == h) hist = vc; else if (lane == h / 2) hist = va;
-          } else {
-            if (lane == 0) { T[3 * (size_t)b + 2] = TOK(3, c_si, 0); CNT(f_sel, o_sel, c_si); }
-            if (lane == rover) hist = c_si;
-            rover++; if (rover == TEX_HS) rover = TEX_HS / 2;
-          }
-        }
+      const uint32_t s = UVOL_READLANE(cS, j);
+      const unsigned long long hit = __ballot(hist == s);
+      if (hit & 1ull) { run++; if (run == 1) run_e1 = base + j; else if (run == 2) run_e2 = base + j; continue; }
+      FIN_RUN();
+      if (hit) {
+        const uint32_t h = (uint32_t)(__ffsll((long long)hit) - 1);
+        if (lane == j) mytok = TOK(3, ns + h, 0);
+        const uint32_t va = UVOL_READLANE(hist, h), vc = UVOL_READLANE(hist, h / 2);
+        if (lane == h) hist = vc; else if (lane == h / 2) hist = va;
+      } else {
+        if (lane == j) mytok = TOK(3, s, 0);
+        if (lane == rover) hist = s;
+        rover++; if (rover == TEX_HS) rover = TEX_HS / 2;
       }
     }
+    if (base + 64 >= n) FIN_RUN();
+    if (lane < cnt) T[3 * (size_t)cB + 2] = mytok;
+    // a run that stays open across the chunk boundary keeps NOPs in this chunk; its head is patched by a direct store later
   }
-  if (ok) { FIN_SEL(); FIN_EP(); }
-  if (LDS_HIST) {
-    __syncthreads();
-    if (ok) for (uint32_t k = lane; k < n_lh; k += 64) {
-      const uint32_t v = lh[k]; if (!v) continue;
-      if (k < o_de) atomicAdd(&f_ep[k], v); else if (k < o_sel) atomicAdd(&f_de[k - o_de], v); else if (k < o_rle) atomicAdd(&f_sel[k - o_sel], v); else atomicAdd(&f_rle[k - o_rle], v);
-    }
+#undef PUT_TOK
+#undef FIN_RUN
+}
+
+// symbol histograms of the four slice models from the finished token slots (LDS-privatised)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tok_hist(TexJob *job) {
+  TJOB_OR_RETURN;
+  UVOL_DYN_SMEM(uint32_t, lh);
+  const uint32_t o_de = 257, o_sel = 257 + J.Kmax_e, o_rle = o_sel + J.Kmax_s + TEX_HS + 1, n_lh = o_rle + 64;
+  for (uint32_t k = threadIdx.x; k < n_lh; k += UVOL_BLOCK) lh[k] = 0;
+  __syncthreads();
+  const size_t n = 3 * (size_t)J.NB;
+  for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * UVOL_BLOCK) {
+    const unsigned long long tk = J.tok[i];
+    const uint32_t kind = (uint32_t)(tk & 255), sym = (uint32_t)((tk >> 8) & 0xffffff);
+    if (kind == 255) continue;
+    if (kind <= 1) atomicAdd(&lh[kind == 1 ? 256u : sym], 1u);
+    else if (kind == 2) atomicAdd(&lh[o_de + sym], 1u);
+    else if (kind == 3) atomicAdd(&lh[o_sel + sym], 1u);
+    else { atomicAdd(&lh[o_sel + J.ns + TEX_HS], 1u); atomicAdd(&lh[o_rle + sym], 1u); }
   }
-#undef FIN_EP
-#undef FIN_SEL
-#undef CNT
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n_lh; k += UVOL_BLOCK) {
+    const uint32_t v = lh[k]; if (!v) continue;
+    if (k < o_de) atomicAdd(&J.hm[0].freq[k], v); else if (k < o_sel) atomicAdd(&J.hm[1].freq[k - o_de], v);
+    else if (k < o_rle) atomicAdd(&J.hm[2].freq[k - o_sel], v); else atomicAdd(&J.hm[3].freq[k - o_rle], v);
+  }
 }
 
 // ---- cooperative (one workgroup) Huffman construction; mirrors the CPU restatement exactly ----
@@ -860,6 +936,7 @@ size_t tex_layout(TexJob &J, uint8_t *base, size_t *zero_bytes) {
   TCARVE(J.item, uint32_t, NB + 8);
   TCARVE(J.sused, uint8_t, KC + 8); TCARVE(J.scu, uint32_t, KC + 8); TCARVE(J.smap, uint32_t, KC + 8);
   TCARVE(J.pred, uint8_t, NB + 8);
+  TCARVE(J.clist, uint32_t, NB + 8); TCARVE(J.msym, uint8_t, NB + 8); TCARVE(J.gid, uint32_t, NB + 8); TCARVE(J.gstart, uint32_t, NB + 8); TCARVE(J.gsize, uint32_t, NB + 8);
   TCARVE(J.tok, unsigned long long, 3 * NB + 8);
   for (int m = 0; m < TEX_NMODEL; m++) { TCARVE(J.hm[m].size, uint8_t, TEX_MODEL_CAP); TCARVE(J.hm[m].code, uint16_t, TEX_MODEL_CAP); }
   TCARVE(J.hscratch, uint32_t, (size_t)7 * 10 * (TEX_MODEL_CAP + 8));
@@ -968,9 +1045,20 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
   {
     uvol_ctx::Scope sc(ctx, "tex.k12_symbolize", (uint64_t)J.NB * 6);
     TLAUNCH(k_preds, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH(k_tok_delta, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH(k_sscan_a, dim3(bnb, J.L), dim3(UVOL_BLOCK), 0, dj, J.nb, J.nb);
+    TLAUNCH(k_sscan_b, dim3(J.L), dim3(UVOL_BLOCK), 0, dj, bnb);
+    TLAUNCH(k_coded_list, dim3(bnb, J.L), dim3(UVOL_BLOCK), 0, dj);
+    const uint32_t nm = ((J.bx + 1) / 2) * ((J.by + 1) / 2); const unsigned bnm = uvol_blocks(nm);
+    TLAUNCH(k_mb_flags, dim3(bnm, J.L), dim3(UVOL_BLOCK), 0, dj, nm);
+    TLAUNCH(k_sscan_a, dim3(bnm, J.L), dim3(UVOL_BLOCK), 0, dj, nm, nm);
+    TLAUNCH(k_sscan_b, dim3(J.L), dim3(UVOL_BLOCK), 0, dj, bnm);
+    TLAUNCH(k_mb_groups, dim3(bnm, J.L), dim3(UVOL_BLOCK), 0, dj, nm);
+    TLAUNCH(k_mb_tokens, dim3(bnm, J.L), dim3(UVOL_BLOCK), 0, dj, nm);
+    TLAUNCH(k_sel_tokens, dim3(J.L), dim3(64), 0, dj);
     const size_t lh_bytes = (size_t)(257 + J.Kmax_e + J.Kmax_s + TEX_HS + 1 + 64) * 4;
-    if (lh_bytes <= 60 * 1024) TLAUNCH((k_symbolize<true>), dim3(J.L), dim3(64), lh_bytes, dj);
-    else TLAUNCH((k_symbolize<false>), dim3(J.L), dim3(64), 0, dj);
+    if (lh_bytes > 60 * 1024) { ctx->set_error("etc1s_quality too high for the LDS histogram (codebooks > 60 KiB)"); return UVOL_E_UNSUPPORTED; }
+    TLAUNCH(k_tok_hist, dim3(std::min<unsigned>(uvol_blocks((size_t)3 * J.NB), 1024u)), dim3(UVOL_BLOCK), lh_bytes, dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "tex.k12_huffman_pack", (uint64_t)J.NB * 24);
