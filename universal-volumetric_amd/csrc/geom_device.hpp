@@ -59,7 +59,7 @@ struct GeoJob {
   // ---- workspace ----
   uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3];
   uint64_t *e_key; uint32_t *e_val; uint32_t e_cap;
-  uint8_t *keep; uint32_t *bsum;      // scan scratch (max(nf_in, nc)/256 + 1)
+  uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
   int32_t *opp, *vert, *ring; uint8_t *vopen;
   uint8_t *fvis, *vvis; int32_t *vval, *c2vm, *f2split, *proc, *initc, *stack;

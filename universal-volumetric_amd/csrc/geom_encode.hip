@@ -47,26 +47,27 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int se
   uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   uint32_t v = (J.status == 0 && i < n) ? flags[i] : 0, tot;
   block_excl_scan(v, &tot);
-  if (threadIdx.x == 0) J.bsum[blockIdx.x] = tot;
+  if (threadIdx.x == 0) (sel == SCAN_EVENTS ? J.bsum2 : J.bsum)[blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_sums(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
   const uint32_t nn = scan_count(J, sel);
   const uint32_t nblocks = uvol_blocks_dev(nn);
+  uint32_t *bsum = sel == SCAN_EVENTS ? J.bsum2 : J.bsum;     // the event scan runs on the auxiliary stream
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   for (uint32_t b0 = 0; b0 < nblocks; b0 += UVOL_BLOCK) {
     uint32_t i = b0 + threadIdx.x;
-    uint32_t v = i < nblocks ? J.bsum[i] : 0, tot;
+    uint32_t v = i < nblocks ? bsum[i] : 0, tot;
     uint32_t ex = block_excl_scan(v, &tot);
     uint32_t c = carry;
-    if (i < nblocks) J.bsum[i] = c + ex;
+    if (i < nblocks) bsum[i] = c + ex;
     __syncthreads();
     if (threadIdx.x == 0) carry = c + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) J.bsum[nblocks] = carry;
+  if (threadIdx.x == 0) bsum[nblocks] = carry;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -337,12 +338,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const bool live = J.status == 0 && i < J.nf;
   uint32_t v = live ? J.keep[i] : 0, tot;
-  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum[blockIdx.x] : 0);
+  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum2[blockIdx.x] : 0);
   if (live && v) {
     int a[2], b[2]; const int n = eb_events_of(J, i, a, b);
     for (int k = 0; k < n; k++) { J.ev_src[pos + k] = (int)i; J.ev_spl[pos + k] = a[k]; J.ev_edge[pos + k] = (uint8_t)b[k]; }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nev = (int)J.bsum[uvol_blocks_dev(J.nf)];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nev = (int)J.bsum2[uvol_blocks_dev(J.nf)];
 }
 
 // valence bookkeeping replay: ctx_of[i] = context (0..5) under which symbol i-1 is coded (i >= 1)
@@ -370,9 +371,12 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
       bool remapped = false;
       if (lane == 0) {
         const int nx = g_nxt(lc), pv = g_prv(lc);
-        const int active_valence = vval[in_];
+        // the three corners of a face are three distinct vertex instances: issue the three loads together
+        // (one memory round trip per symbol instead of three serialised read-modify-writes)
+        const int val_n = vval[in_], val_p = vval[ip], val_a = vval[ia];
+        const int active_valence = val_n;
         if (sym == 0 || sym == 1) {
-          vval[in_] -= 1; vval[ip] -= 1;
+          vval[in_] = val_n - 1; vval[ip] = val_p - 1;
           if (sym == 1) {
             int nleft = 0, a = opp[pv];
             while (a >= 0) { if (ftime[a / 3] <= i) break; nleft++; a = opp[g_nxt(a)]; }
@@ -381,9 +385,9 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
             while (a >= 0) { if (ftime[a / 3] <= i) break; nright++; c2vm[g_nxt(a)] = newv; a = opp[g_prv(a)]; }
             vval[nvval] = nright + 1;
           }
-        } else if (sym == 5) { vval[ia] -= 1; vval[in_] -= 1; vval[ip] -= 2; }
-        else if (sym == 3) { vval[ia] -= 1; vval[in_] -= 2; vval[ip] -= 1; }
-        else { vval[ia] -= 2; vval[in_] -= 2; vval[ip] -= 2; }
+        } else if (sym == 5) { vval[ia] = val_a - 1; vval[in_] = val_n - 1; vval[ip] = val_p - 2; }
+        else if (sym == 3) { vval[ia] = val_a - 1; vval[in_] = val_n - 2; vval[ip] = val_p - 1; }
+        else { vval[ia] = val_a - 2; vval[in_] = val_n - 2; vval[ip] = val_p - 2; }
         if (i > 0) { const int cv = active_valence < 2 ? 2 : (active_valence > 7 ? 7 : active_valence); J.ctx_of[i] = (uint8_t)(cv - 2); }
       }
       if (sym == 1) { nvval++; remapped = true; }
@@ -1014,10 +1018,13 @@ struct GeoState {
   std::vector<GeoJob> hjobs;
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
   size_t max_lds = 64 * 1024;
+  hipStream_t aux = nullptr;           // second stream: valence replay runs beside renumber/seams/DFS
+  hipEvent_t ev_walk = nullptr, ev_val = nullptr;
 };
 
 int geo_create(uvol_ctx *ctx) {
   ctx->geo = new GeoState();
+  if (hipStreamCreateWithFlags(&ctx->geo->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->geo->ev_walk) != hipSuccess || hipEventCreate(&ctx->geo->ev_val) != hipSuccess) return UVOL_E_HIP;
 #ifndef HIPEMU
   // the serial walkers keep their visited bitmaps in LDS: allow the full 160 KiB of a gfx950 CU
   int v = 0;
@@ -1039,6 +1046,9 @@ void geo_destroy(uvol_ctx *ctx) {
   if (g->jobs.p) (void)hipFree(g->jobs.p);
   if (g->outs.p) (void)hipFree(g->outs.p);
   if (g->pinned) (void)hipHostFree(g->pinned);
+  if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
+  if (g->ev_walk) (void)hipEventDestroy(g->ev_walk);
+  if (g->ev_val) (void)hipEventDestroy(g->ev_val);
   delete g; ctx->geo = nullptr;
 }
 
@@ -1077,7 +1087,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
   *fill7f_bytes = ((C.off + 255) & ~(size_t)255) - *zero_bytes;
   // ---- the rest ----
   CARVE(J.canon[0], uint32_t, J.n_pos + 1); CARVE(J.canon[1], uint32_t, J.n_uv + 1); CARVE(J.canon[2], uint32_t, J.n_nrm + 1);
-  CARVE(J.keep, uint8_t, nfi + 1); CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8);
+  CARVE(J.keep, uint8_t, nfi + 1); CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8); CARVE(J.bsum2, uint32_t, nc / UVOL_BLOCK + 8);
   CARVE(J.cp, int32_t, nc + 3); CARVE(J.cu, int32_t, nc + 3); CARVE(J.cn, int32_t, nc + 3);
   CARVE(J.opp, int32_t, nc + 3); CARVE(J.vert, int32_t, nc + 3); CARVE(J.ring, int32_t, nc + 3); CARVE(J.vopen, uint8_t, nc + 3);
   CARVE(J.vval, int32_t, nc + nfi + 3); CARVE(J.c2vm, int32_t, nc + 3);
@@ -1133,6 +1143,12 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
       fprintf(stderr, "[uvol]   job0 status %d nf %u nverts %u ne %u %u %u ne_uv %u has_ori %p bsum %p elig %p n_ori %u\n", dbg_.status, dbg_.nf, dbg_.nverts, dbg_.ne[0], dbg_.ne[1], dbg_.ne[2], dbg_.ne_uv, (void*)dbg_.has_ori, (void*)dbg_.bsum, (void*)dbg_.elig, dbg_.n_ori); fflush(stderr); } \
   } while (0)
 
+#define LAUNCH_ON(stream_, k, grid, block, ...)                                                  \
+  do {                                                                                           \
+    if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s (aux)\n", #k); fflush(stderr); }        \
+    hipLaunchKernelGGL(k, grid, block, 0, stream_, __VA_ARGS__);                                 \
+    if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(stream_); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
+  } while (0)
 #define LAUNCH_SM(k, grid, block, shmem, ...)                                                    \
   do {                                                                                           \
     if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s (lds %zu)\n", #k, (size_t)(shmem)); fflush(stderr); } \
@@ -1232,15 +1248,20 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
     if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj); else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj);
   }
+  // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
+  // renumber / seams / fans / DFS traversal on the main stream; joined again before the entropy stage.
+  UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_walk, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(G->aux, G->ev_walk, 0));
   {
-    uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence_ctx", 0);
-    LAUNCH(k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
-    LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
-    LAUNCH(k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_eb_valence, dim3(N), dim3(64), dj);
-    LAUNCH(k_eb_ctx, dim3(N), dim3(64), dj);
+    uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence_ctx", 0, G->aux);
+    LAUNCH_ON(G->aux, k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH_ON(G->aux, k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
+    LAUNCH_ON(G->aux, k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
+    LAUNCH_ON(G->aux, k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH_ON(G->aux, k_eb_valence, dim3(N), dim3(64), dj);
+    LAUNCH_ON(G->aux, k_eb_ctx, dim3(N), dim3(64), dj);
   }
+  UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_val, G->aux));
   {
     uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
@@ -1276,6 +1297,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_ori_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_pred_nrm, dim3(bc, N), dim3(UVOL_BLOCK), dj);
   }
+  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
     uvol_ctx::Scope sc(ctx, "geo.k7_entropy", 0);
     LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);

@@ -79,14 +79,14 @@ struct uvol_ctx {
   }
   // bracket a kernel group; resolved lazily at the next sync
   struct Scope {
-    uvol_ctx *c; int idx; hipEvent_t a = nullptr, b = nullptr;
-    Scope(uvol_ctx *ctx, const char *name, uint64_t algo_bytes) : c(ctx), idx(-1) {
+    uvol_ctx *c; int idx; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    Scope(uvol_ctx *ctx, const char *name, uint64_t algo_bytes, hipStream_t on = nullptr) : c(ctx), idx(-1), st(on ? on : ctx->stream) {
       if (!c->profiling) return;
       idx = c->prof_index(name); c->prof[idx].launches++; c->prof[idx].algo_bytes += algo_bytes;
       a = c->get_event(); b = c->get_event();
-      if (a) (void)hipEventRecord(a, c->stream);
+      if (a) (void)hipEventRecord(a, st);
     }
-    ~Scope() { if (idx >= 0 && a && b) { (void)hipEventRecord(b, c->stream); c->pending.push_back({idx, a, b}); } }
+    ~Scope() { if (idx >= 0 && a && b) { (void)hipEventRecord(b, st); c->pending.push_back({idx, a, b}); } }
   };
   void resolve_profile() {
     for (auto &p : pending) {
