@@ -1,0 +1,35 @@
+"""Shared by the CLI tests: write a tiny OBJ + PNG sequence and a project-config.json (with // comments)."""
+import json
+import os
+import numpy as np
+
+
+def write_obj(path, m):
+    with open(path, "w") as f:
+        for v in m["pos"]: f.write("v %r %r %r\n" % tuple(float(x) for x in v))
+        for v in m["uv"]: f.write("vt %r %r\n" % tuple(float(x) for x in v))
+        for v in m["nrm"]: f.write("vn %r %r %r\n" % tuple(float(x) for x in v))
+        ip, iu, inn = (m[k].reshape(-1, 3) + 1 for k in ("idx_pos", "idx_uv", "idx_nrm"))
+        for a, b, c in zip(ip, iu, inn):
+            f.write("f " + " ".join("%d/%d/%d" % (a[k], b[k], c[k]) for k in range(3)) + "\n")
+
+
+def make_sequence(root, n_frames=10, tex=64, batch=5, comments=True):
+    import synth
+    from PIL import Image
+    os.makedirs(os.path.join(root, "OBJ")); os.makedirs(os.path.join(root, "PNG"))
+    meshes = [synth.sphere_mesh(16, 9, charts=(2, 2), frame=k, seed=k) for k in range(n_frames)]
+    for k, m in enumerate(meshes):
+        write_obj(os.path.join(root, "OBJ", "frame_%05d.obj" % k), m)
+    texs = synth.texture_sequence(n_frames, size=tex, seed=3)
+    for k, t in enumerate(texs):
+        Image.fromarray(t, "RGBA").save(os.path.join(root, "PNG", "export_%05d.png" % k))
+    cfg = {"name": "test", "OBJFilesPath": os.path.join(root, "OBJ", "frame_#####.obj"), "ImagesPath": os.path.join(root, "PNG", "export_#####.png"),
+           "KTX2_FIRST_FILE": 0, "KTX2_FILE_COUNT": n_frames, "KTX2_BATCH_SIZE": batch, "GEOMETRY_FRAME_RATE": 30, "TEXTURE_FRAME_RATE": 30,
+           "OutputDirectory": os.path.join(root, "out"), "Q_POSITION_ATTR": 11}
+    text = json.dumps(cfg, indent=1)
+    if comments:
+        text = text.replace('"Q_POSITION_ATTR": 11', '"Q_POSITION_ATTR": 11 // quantization bits for the position attribute, default=11.')
+    p = os.path.join(root, "project-config.json")
+    open(p, "w").write(text)
+    return p, cfg, meshes, texs

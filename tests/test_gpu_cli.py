@@ -1,0 +1,51 @@
+"""End-to-end on a real GPU: `uvolenc project-config.json` (the Encoder.py-equivalent host driver) and the two argv shims."""
+import json
+import os
+import shlex
+import subprocess
+import pytest
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "universal-volumetric_amd", "bin")
+
+
+def test_uvolenc_end_to_end(oracle, tmp_path):
+    import cli_helpers
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "universal-volumetric_amd"), "all"])
+    cfgp, cfg, meshes, texs = cli_helpers.make_sequence(str(tmp_path), n_frames=12, tex=64, batch=5)
+    r = subprocess.run([os.path.join(BIN, "uvolenc"), cfgp, "--encoder-py-manifest"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = cfg["OutputDirectory"]
+    drc = sorted(os.listdir(os.path.join(out, "geometry_draco"))); ktx = sorted(os.listdir(os.path.join(out, "texture_ktx2_baseColor_default")))
+    assert drc == ["%05d.drc" % k for k in range(12)] and ktx == ["00000.ktx2", "00001.ktx2", "00002.ktx2"]
+    for k, m in enumerate(meshes):
+        got = open(os.path.join(out, "geometry_draco", drc[k]), "rb").read()
+        assert got == oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"])
+    for s in range(3):
+        got = open(os.path.join(out, "texture_ktx2_baseColor_default", ktx[s]), "rb").read()
+        assert got == oracle.ktx2_encode(texs[5 * s:5 * s + 5])
+    man = json.load(open(os.path.join(out, "uvol.json")))
+    assert man["geometry"]["targets"]["draco"]["frameCount"] == 12
+    t = man["texture"]["targets"]["ktx2"]
+    assert (t["sequenceCount"], t["sequenceSize"], t["resolution"]) == (3, 5, [64, 64])
+    assert "Frames and frame rates are compatible" in r.stdout
+    assert json.load(open(os.path.join(out, "uvol.encoderpy.json")))["geometry"]["frameCount"] == 12
+
+
+def test_argv_shims_with_reference_command_lines(oracle, tmp_path):
+    """The exact command strings scripts/Encoder.py:260 and :290 build, run through shlex like the reference does."""
+    import cli_helpers
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "universal-volumetric_amd"), "all"])
+    cfgp, cfg, meshes, texs = cli_helpers.make_sequence(str(tmp_path), n_frames=5, tex=64, batch=5)
+    obj = os.path.join(str(tmp_path), "OBJ", "frame_00002.obj"); drc = os.path.join(str(tmp_path), "f.drc")
+    cmd = f'{os.path.join(BIN, "draco_encoder")} -i "{obj}" -o "{drc}" -qp 11 -qt 10 -qn 8 -qg 8 -cl 7'
+    assert subprocess.call(shlex.split(cmd), stdout=subprocess.DEVNULL) == 0
+    m = meshes[2]
+    assert open(drc, "rb").read() == oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"])
+    pat = os.path.join(str(tmp_path), "PNG", "export_%05u.png"); ktx = os.path.join(str(tmp_path), "texture_0000000.ktx2")
+    cmd = f'{os.path.join(BIN, "basisu")} -ktx2 -tex_type video -multifile_printf "{pat}" -multifile_num 5 -multifile_first 0 -y_flip -output_file "{ktx}"'
+    assert subprocess.call(shlex.split(cmd), stdout=subprocess.DEVNULL) == 0
+    assert open(ktx, "rb").read() == oracle.ktx2_encode(texs)
+    # failure = non-zero exit code, as scripts/Encoder.py:263 expects
+    assert subprocess.call([os.path.join(BIN, "draco_encoder"), "-i", "/nonexistent.obj", "-o", drc], stderr=subprocess.DEVNULL) != 0

@@ -1,0 +1,383 @@
+// uvol_host.cpp — see uvol_host.hpp.  Mirrors scripts/Encoder.py (file:line cited per function).
+#include "uvol_host.hpp"
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
+#include <zlib.h>
+
+namespace uvolh {
+
+// ------------------------------------------------------------------ JSON
+namespace {
+struct P {
+  const std::string &s; size_t i = 0; std::string err;
+  explicit P(const std::string &t) : s(t) {}
+  void ws() {
+    for (;;) {
+      while (i < s.size() && std::isspace((unsigned char)s[i])) i++;
+      if (i + 1 < s.size() && s[i] == '/' && s[i + 1] == '/') { while (i < s.size() && s[i] != '\n') i++; continue; }
+      if (i + 1 < s.size() && s[i] == '/' && s[i + 1] == '*') { i += 2; while (i + 1 < s.size() && !(s[i] == '*' && s[i + 1] == '/')) i++; i += 2; continue; }
+      if (i < s.size() && s[i] == '#') { while (i < s.size() && s[i] != '\n') i++; continue; }
+      break;
+    }
+  }
+  bool fail(const char *m) { if (err.empty()) { err = m; err += " at offset " + std::to_string(i); } return false; }
+  bool str(std::string &o) {
+    if (s[i] != '"') return fail("expected string");
+    i++; o.clear();
+    while (i < s.size() && s[i] != '"') {
+      char c = s[i++];
+      if (c == '\\' && i < s.size()) {
+        char e = s[i++];
+        switch (e) { case 'n': o += '\n'; break; case 't': o += '\t'; break; case 'r': o += '\r'; break; case 'b': o += '\b'; break; case 'f': o += '\f'; break;
+          case 'u': { unsigned v = 0; for (int k = 0; k < 4 && i < s.size(); k++) v = v * 16 + (unsigned)(std::isdigit((unsigned char)s[i]) ? s[i] - '0' : (std::tolower(s[i]) - 'a' + 10)), i++;
+            if (v < 0x80) o += (char)v; else if (v < 0x800) { o += (char)(0xC0 | (v >> 6)); o += (char)(0x80 | (v & 63)); } else { o += (char)(0xE0 | (v >> 12)); o += (char)(0x80 | ((v >> 6) & 63)); o += (char)(0x80 | (v & 63)); } break; }
+          default: o += e; }
+      } else o += c;
+    }
+    if (i >= s.size()) return fail("unterminated string");
+    i++; return true;
+  }
+  bool val(Json &j) {
+    ws(); if (i >= s.size()) return fail("unexpected end");
+    char c = s[i];
+    if (c == '{') {
+      i++; j.type = Json::Obj; ws();
+      if (i < s.size() && s[i] == '}') { i++; return true; }
+      for (;;) {
+        ws(); if (i < s.size() && s[i] == '}') { i++; return true; }          // trailing comma
+        std::string k; if (!str(k)) return false; ws();
+        if (i >= s.size() || s[i] != ':') return fail("expected ':'");
+        i++;
+        Json v; if (!val(v)) return false; j.set(k, std::move(v)); ws();
+        if (i < s.size() && s[i] == ',') { i++; continue; }
+        if (i < s.size() && s[i] == '}') { i++; return true; }
+        return fail("expected ',' or '}'");
+      }
+    }
+    if (c == '[') {
+      i++; j.type = Json::Arr; ws();
+      if (i < s.size() && s[i] == ']') { i++; return true; }
+      for (;;) {
+        ws(); if (i < s.size() && s[i] == ']') { i++; return true; }
+        Json v; if (!val(v)) return false; j.arr.push_back(std::move(v)); ws();
+        if (i < s.size() && s[i] == ',') { i++; continue; }
+        if (i < s.size() && s[i] == ']') { i++; return true; }
+        return fail("expected ',' or ']'");
+      }
+    }
+    if (c == '"') { j.type = Json::Str; return str(j.str); }
+    if (!s.compare(i, 4, "true")) { i += 4; j.type = Json::Bool; j.b = true; return true; }
+    if (!s.compare(i, 5, "false")) { i += 5; j.type = Json::Bool; j.b = false; return true; }
+    if (!s.compare(i, 4, "null")) { i += 4; j.type = Json::Null; return true; }
+    size_t st = i; bool isint = true;
+    if (i < s.size() && (s[i] == '-' || s[i] == '+')) i++;
+    while (i < s.size() && (std::isdigit((unsigned char)s[i]) || s[i] == '.' || s[i] == 'e' || s[i] == 'E' || s[i] == '-' || s[i] == '+')) { if (!std::isdigit((unsigned char)s[i])) isint = false; i++; }
+    if (i == st) return fail("unexpected character");
+    j.type = Json::Num; j.num = std::strtod(s.substr(st, i - st).c_str(), nullptr); j.is_int = isint; return true;
+  }
+};
+void dump(const Json &j, std::string &o) {
+  switch (j.type) {
+    case Json::Null: o += "null"; break;
+    case Json::Bool: o += j.b ? "true" : "false"; break;
+    case Json::Num: { char b[64]; if (j.is_int || j.num == std::floor(j.num)) std::snprintf(b, sizeof b, "%lld", (long long)j.num); else std::snprintf(b, sizeof b, "%.17g", j.num); o += b; break; }
+    case Json::Str: o += '"'; for (char c : j.str) { if (c == '"' || c == '\\') { o += '\\'; o += c; } else if (c == '\n') o += "\\n"; else if (c == '\t') o += "\\t"; else o += c; } o += '"'; break;
+    case Json::Arr: o += '['; for (size_t k = 0; k < j.arr.size(); k++) { if (k) o += ", "; dump(j.arr[k], o); } o += ']'; break;
+    case Json::Obj: o += '{'; for (size_t k = 0; k < j.obj.size(); k++) { if (k) o += ", "; o += '"'; o += j.obj[k].first; o += "\": "; dump(j.obj[k].second, o); } o += '}'; break;
+  }
+}
+}  // namespace
+bool json_parse(const std::string &text, Json &out, std::string &err) { P p(text); out = Json(); if (!p.val(out)) { err = p.err; return false; } p.ws(); if (p.i != text.size()) { err = "trailing characters"; return false; } return true; }
+std::string json_dump(const Json &j) { std::string o; dump(j, o); return o; }
+
+// ------------------------------------------------------------------ patterns
+std::string convert_pounds_to_c_style(const std::string &s) {       // scripts/Encoder.py:16-19
+  size_t n = std::count(s.begin(), s.end(), '#');
+  if (!n) { std::string o = "%00u"; for (char c : s) { o += c; o += "%00u"; } return o; }   // python: s.replace('', '%00u')
+  std::string run(n, '#'), rep = "%0" + std::to_string(n) + "u", out = s;
+  for (size_t p = out.find(run); p != std::string::npos; p = out.find(run, p + rep.size())) out.replace(p, n, rep);
+  return out;
+}
+bool match_pattern(const std::string &pattern, const std::string &fn) {   // scripts/Encoder.py:87-100
+  const size_t pad = std::count(pattern.begin(), pattern.end(), '#');
+  const std::string run(pad, '#');
+  size_t pi = pattern.find(run);                          // python str.find(''): 0
+  if (pi == std::string::npos) {                          // python find() == -1: slices with -1
+    // pattern[:-1] == file_name[:-1] and pattern[-1+pad:] == file_name[-1+pad:] and file_name[-1:-1+pad].isdigit()
+    auto sl = [](const std::string &t, long a, long b) { long n = (long)t.size(); if (a < 0) a += n; if (b < 0) b += n; a = std::max(0L, std::min(a, n)); b = std::max(0L, std::min(b, n)); return a < b ? t.substr((size_t)a, (size_t)(b - a)) : std::string(); };
+    auto from = [](const std::string &t, long a) { long n = (long)t.size(); if (a < 0) a += n; a = std::max(0L, std::min(a, n)); return t.substr((size_t)a); };
+    std::string mid = sl(fn, -1, -1 + (long)pad);
+    bool dig = !mid.empty() && std::all_of(mid.begin(), mid.end(), [](char c) { return std::isdigit((unsigned char)c); });
+    return sl(pattern, 0, -1) == sl(fn, 0, -1) && from(pattern, -1 + (long)pad) == from(fn, -1 + (long)pad) && dig;
+  }
+  auto sub = [](const std::string &t, size_t a, size_t b) { a = std::min(a, t.size()); b = std::min(b, t.size()); return a < b ? t.substr(a, b - a) : std::string(); };
+  std::string mid = sub(fn, pi, pi + pad);
+  bool dig = !mid.empty() && std::all_of(mid.begin(), mid.end(), [](char c) { return std::isdigit((unsigned char)c); });
+  return sub(pattern, 0, pi) == sub(fn, 0, pi) && sub(pattern, pi + pad, std::string::npos) == sub(fn, pi + pad, std::string::npos) && dig;
+}
+static std::string strip_brackets(const std::string &pattern) {
+  const size_t pad = std::count(pattern.begin(), pattern.end(), '#');
+  if (!pad) return pattern;
+  const std::string br = "[" + std::string(pad, '#') + "]";
+  size_t p = pattern.find(br);
+  if (p == std::string::npos) return pattern;
+  std::string o = pattern; o.replace(p, br.size(), std::string(pad, '#')); return o;
+}
+bool match_pattern_lenient(const std::string &pattern, const std::string &fn) { return match_pattern(pattern, fn) || match_pattern(strip_brackets(pattern), fn); }
+std::string format_index(const std::string &pattern, unsigned index) {
+  std::string p = strip_brackets(pattern);
+  const size_t pad = std::count(p.begin(), p.end(), '#');
+  if (!pad) return p;
+  char buf[64]; std::snprintf(buf, sizeof buf, "%0*u", (int)pad, index);
+  size_t at = p.find(std::string(pad, '#'));
+  if (at == std::string::npos) return p;
+  p.replace(at, pad, buf); return p;
+}
+
+// ------------------------------------------------------------------ config
+std::string check_all_fields(const Json &cfg) {                       // scripts/Encoder.py:45-84
+  static const char *mand[] = { "name", "GEOMETRY_FRAME_RATE", "TEXTURE_FRAME_RATE", "OutputDirectory", "KTX2_BATCH_SIZE" };
+  std::string missing;
+  for (const char *k : mand) { const Json *v = cfg.get(k); if (!v || v->type == Json::Null) { if (!missing.empty()) missing += ", "; missing += std::string("'") + k + "'"; } }
+  if (!missing.empty()) return "Missing mandatory fields:  [" + missing + "]";
+  auto truthy = [&](const char *k) { const Json *v = cfg.get(k); return v && v->truthy(); };
+  if (!(truthy("ABCFilePath") || truthy("OBJFilesPath") || truthy("DRACOFilesPath"))) return "Path to Geometry data is not specified";
+  if (truthy("ImagesPath")) {
+    const Json *a = cfg.get("KTX2_FIRST_FILE"), *b = cfg.get("KTX2_FILE_COUNT");
+    auto is_int = [](const Json *v) { return v && ((v->type == Json::Num && v->is_int) || v->type == Json::Bool); };   // isinstance(True, int) is True in python
+    if (!(is_int(a) && is_int(b))) return "When ImagesPath is given, you must specify `KTX2_FIRST_FILE` and `KTX2_FILE_COUNT`";
+  } else if (!truthy("KTX2FilesPath")) return "Path to Texture data is not specified";
+  return "";
+}
+bool load_config(const std::string &text, Config &c, std::string &err) {
+  if (!json_parse(text, c.raw, err)) return false;
+  if (c.raw.type != Json::Obj) { err = "config is not a JSON object"; return false; }
+  err = check_all_fields(c.raw);
+  if (!err.empty()) return false;
+  auto S = [&](const char *k) { const Json *v = c.raw.get(k); return v && v->type == Json::Str ? v->str : std::string(); };
+  auto N = [&](const char *k, double d) { const Json *v = c.raw.get(k); return v && v->type == Json::Num ? v->num : d; };
+  c.name = S("name"); c.obj_files_path = S("OBJFilesPath"); c.draco_files_path = S("DRACOFilesPath"); c.images_path = S("ImagesPath");
+  c.ktx2_files_path = S("KTX2FilesPath"); c.output_directory = S("OutputDirectory"); c.audio_url = S("AudioURL"); c.abc_file_path = S("ABCFilePath");
+  c.q_position = (int)N("Q_POSITION_ATTR", 11); c.q_texture = (int)N("Q_TEXTURE_ATTR", 10); c.q_normal = (int)N("Q_NORMAL_ATTR", 8);
+  c.q_generic = (int)N("Q_GENERIC_ATTR", 8); c.compression_level = (int)N("DRACO_COMPRESSION_LEVEL", 7);
+  c.ktx2_first_file = (int)N("KTX2_FIRST_FILE", 0); c.ktx2_file_count = (int)N("KTX2_FILE_COUNT", 0); c.ktx2_batch_size = (int)N("KTX2_BATCH_SIZE", 0);
+  c.geometry_frame_rate = N("GEOMETRY_FRAME_RATE", 0); c.texture_frame_rate = N("TEXTURE_FRAME_RATE", 0);
+  if (c.ktx2_batch_size <= 0) { err = "KTX2_BATCH_SIZE must be a positive integer"; return false; }
+  return true;
+}
+std::string config_template() {                                          // scripts/Encoder.py:163-186 (same fields, same defaults)
+  return "{\n  \"name\": \"\",\n  \"draco_encoder\": \"\", // unused by uvolenc (in-process HIP codec)\n  \"basisu\": \"\", // unused by uvolenc (in-process HIP codec)\n"
+         "  \"ABCFilePath\": \"\",\n  \"OBJFilesPath\": \"\", // pattern with hashes. eg: OBJ/frame_[#####].obj\n  \"DRACOFilesPath\": \"\", // pattern with hashes\n"
+         "  \"Q_POSITION_ATTR\": 11, // quantization bits for the position attribute, default=11.\n  \"Q_TEXTURE_ATTR\": 10, // quantization bits for the texture coordinate attribute, default=10.\n"
+         "  \"Q_NORMAL_ATTR\": 8, // quantization bits for the normal vector attribute, default=8.\n  \"Q_GENERIC_ATTR\": 8, // quantization bits for any generic attribute, default=8.\n"
+         "  \"DRACO_COMPRESSION_LEVEL\": 7, // compression level [0-10], most=10, least=0, default=7.\n  \"ImagesPath\": \"\", // pattern with hashes.\n"
+         "  \"KTX2_FIRST_FILE\": 0, // The index of the first file in above pattern. Eg: If PNG/frame_001.png is first texture, this field should be 1\n"
+         "  \"KTX2_FILE_COUNT\": 0,\n  \"KTX2_BATCH_SIZE\": 7,\n  \"KTX2FilesPath\": \"\",\n  \"GEOMETRY_FRAME_RATE\": 30,\n  \"TEXTURE_FRAME_RATE\": 30,\n  \"OutputDirectory\": \"\"\n}\n";
+}
+
+// ------------------------------------------------------------------ files
+bool write_file(const std::string &path, const void *data, size_t n) { FILE *f = std::fopen(path.c_str(), "wb"); if (!f) return false; bool ok = std::fwrite(data, 1, n, f) == n; std::fclose(f); return ok; }
+bool read_file(const std::string &path, std::vector<uint8_t> &d) {
+  FILE *f = std::fopen(path.c_str(), "rb"); if (!f) return false;
+  std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+  d.resize(n > 0 ? (size_t)n : 0); bool ok = n >= 0 && std::fread(d.data(), 1, d.size(), f) == d.size(); std::fclose(f); return ok;
+}
+std::vector<std::string> list_dir(const std::string &dir) {
+  std::vector<std::string> v; DIR *d = opendir(dir.empty() ? "." : dir.c_str()); if (!d) return v;
+  while (dirent *e = readdir(d)) { std::string n = e->d_name; if (n != "." && n != "..") v.push_back(n); }
+  closedir(d); std::sort(v.begin(), v.end()); return v;
+}
+bool make_dirs(const std::string &dir) {
+  if (dir.empty()) return true;
+  std::string cur;
+  for (size_t i = 0; i <= dir.size(); i++) {
+    if (i == dir.size() || dir[i] == '/') { if (!cur.empty() && cur != "/") { if (mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return false; } }
+    if (i < dir.size()) cur += dir[i];
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ OBJ (what draco_encoder's OBJ front end extracts: v / vt / vn / f, polygons fanned)
+bool read_obj(const std::string &path, ObjMesh &m, std::string &err) {
+  std::vector<uint8_t> d; if (!read_file(path, d)) { err = "cannot read " + path; return false; }
+  m = ObjMesh();
+  const char *p = (const char *)d.data(), *e = p + d.size();
+  bool has_uv = true, has_n = true; long nfaces = 0;
+  std::vector<long> fv, ft, fn;
+  auto skip_sp = [&](const char *&q) { while (q < e && (*q == ' ' || *q == '\t' || *q == '\r')) q++; };
+  auto num = [&](const char *&q, float &o) { skip_sp(q); char *end; o = std::strtof(q, &end); bool ok = end != q; q = end; return ok; };
+  while (p < e) {
+    const char *ln = p; while (p < e && *p != '\n') p++;
+    const char *le = p; if (p < e) p++;
+    const char *q = ln; skip_sp(q);
+    if (q + 1 < le && q[0] == 'v' && (q[1] == ' ' || q[1] == '\t')) { q += 1; float x, y, z; if (num(q, x) && num(q, y) && num(q, z)) { m.pos.push_back(x); m.pos.push_back(y); m.pos.push_back(z); } }
+    else if (q + 2 < le && q[0] == 'v' && q[1] == 't' && (q[2] == ' ' || q[2] == '\t')) { q += 2; float u = 0, v = 0; num(q, u); num(q, v); m.uv.push_back(u); m.uv.push_back(v); }
+    else if (q + 2 < le && q[0] == 'v' && q[1] == 'n' && (q[2] == ' ' || q[2] == '\t')) { q += 2; float x = 0, y = 0, z = 0; num(q, x); num(q, y); num(q, z); m.nrm.push_back(x); m.nrm.push_back(y); m.nrm.push_back(z); }
+    else if (q + 1 < le && q[0] == 'f' && (q[1] == ' ' || q[1] == '\t')) {
+      q += 1; fv.clear(); ft.clear(); fn.clear();
+      for (;;) {
+        skip_sp(q); if (q >= le) break;
+        char *end; long a = std::strtol(q, &end, 10); if (end == q) break; q = end;
+        long b = 0, c = 0; bool hb = false, hc = false;
+        if (q < le && *q == '/') { q++; if (q < le && *q != '/') { b = std::strtol(q, &end, 10); hb = end != q; q = end; } if (q < le && *q == '/') { q++; c = std::strtol(q, &end, 10); hc = end != q; q = end; } }
+        const long np = (long)m.pos.size() / 3, nt = (long)m.uv.size() / 2, nn = (long)m.nrm.size() / 3;
+        fv.push_back(a < 0 ? np + a : a - 1);
+        ft.push_back(hb ? (b < 0 ? nt + b : b - 1) : -1);
+        fn.push_back(hc ? (c < 0 ? nn + c : c - 1) : -1);
+      }
+      for (size_t k = 1; k + 1 < fv.size(); k++) {
+        const size_t tri[3] = { 0, k, k + 1 };
+        for (size_t t : tri) {
+          if (fv[t] < 0 || fv[t] >= (long)m.pos.size() / 3) { err = path + ": face references a missing vertex"; return false; }
+          m.idx_pos.push_back((uint32_t)fv[t]);
+          if (ft[t] < 0 || ft[t] >= (long)m.uv.size() / 2) has_uv = false;
+          m.idx_uv.push_back(ft[t] < 0 ? 0u : (uint32_t)ft[t]);
+          if (fn[t] < 0 || fn[t] >= (long)m.nrm.size() / 3) has_n = false;
+          m.idx_nrm.push_back(fn[t] < 0 ? 0u : (uint32_t)fn[t]);
+        }
+        nfaces++;
+      }
+    }
+  }
+  if (!nfaces || m.pos.empty()) { err = path + ": no faces"; return false; }
+  if (!has_uv || m.uv.empty()) { m.uv.clear(); m.idx_uv.clear(); }
+  if (!has_n || m.nrm.empty()) { m.nrm.clear(); m.idx_nrm.clear(); }
+  return true;
+}
+
+// ------------------------------------------------------------------ PNG (8/16-bit, colour types 0/2/3/4/6, non-interlaced) via zlib
+bool read_png(const std::string &path, Image &img, std::string &err) {
+  std::vector<uint8_t> d; if (!read_file(path, d)) { err = "cannot read " + path; return false; }
+  static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
+  if (d.size() < 33 || std::memcmp(d.data(), sig, 8)) { err = path + ": not a PNG"; return false; }
+  auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
+  uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0; std::vector<uint8_t> idat, plte, trns;
+  for (size_t o = 8; o + 12 <= d.size();) {
+    uint32_t len = be32(o); if (o + 12 + len > d.size()) break;
+    const char *t = (const char *)&d[o + 4]; const uint8_t *body = &d[o + 8];
+    if (!std::memcmp(t, "IHDR", 4) && len >= 13) { w = be32(o + 8); h = be32(o + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+    else if (!std::memcmp(t, "PLTE", 4)) plte.assign(body, body + len);
+    else if (!std::memcmp(t, "tRNS", 4)) trns.assign(body, body + len);
+    else if (!std::memcmp(t, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+    else if (!std::memcmp(t, "IEND", 4)) break;
+    o += 12 + len;
+  }
+  if (!w || !h || interlace || (depth != 8 && depth != 16) || (ctype != 0 && ctype != 2 && ctype != 3 && ctype != 4 && ctype != 6) || (ctype == 3 && depth != 8)) { err = path + ": unsupported PNG variant"; return false; }
+  const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4, bpp = ch * depth / 8;
+  const size_t stride = (size_t)w * bpp;
+  std::vector<uint8_t> raw((stride + 1) * h);
+  uLongf outl = (uLongf)raw.size();
+  if (uncompress(raw.data(), &outl, idat.data(), (uLong)idat.size()) != Z_OK || outl != raw.size()) { err = path + ": zlib inflate failed"; return false; }
+  std::vector<uint8_t> cur(stride), prev(stride, 0);
+  img.w = w; img.h = h; img.rgba.assign((size_t)w * h * 4, 255);
+  for (uint32_t y = 0; y < h; y++) {
+    const uint8_t *r = &raw[(stride + 1) * y]; const int ft = r[0]; r++;
+    for (size_t x = 0; x < stride; x++) {
+      const int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= (size_t)bpp ? prev[x - bpp] : 0; int v = r[x];
+      switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
+        case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; } default: break; }
+      cur[x] = (uint8_t)v;
+    }
+    uint8_t *o = &img.rgba[(size_t)y * w * 4]; const int s = depth / 8;
+    for (uint32_t x = 0; x < w; x++) {
+      const uint8_t *px = &cur[(size_t)x * bpp];
+      switch (ctype) {
+        case 0: o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = px[0]; break;
+        case 2: o[4 * x] = px[0]; o[4 * x + 1] = px[s]; o[4 * x + 2] = px[2 * s]; break;
+        case 3: { const size_t k = px[0]; if (3 * k + 2 < plte.size()) { o[4 * x] = plte[3 * k]; o[4 * x + 1] = plte[3 * k + 1]; o[4 * x + 2] = plte[3 * k + 2]; } if (k < trns.size()) o[4 * x + 3] = trns[k]; break; }
+        case 4: o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = px[0]; o[4 * x + 3] = px[s]; break;
+        default: o[4 * x] = px[0]; o[4 * x + 1] = px[s]; o[4 * x + 2] = px[2 * s]; o[4 * x + 3] = px[3 * s]; break;
+      }
+    }
+    prev.swap(cur);
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ frame accounting (scripts/Encoder.py:103-154)
+static void split_path(const std::string &p, std::string &dir, std::string &base) { size_t k = p.find_last_of('/'); if (k == std::string::npos) { dir = ""; base = p; } else { dir = p.substr(0, k); base = p.substr(k + 1); } }
+bool check_total_frames(const std::string &drc_pat, const std::string &ktx2_pat, int batch, double geo_rate, double tex_rate, FrameCounts &out, std::string &err) {
+  std::string dd, dp, kd, kp; split_path(drc_pat, dd, dp); split_path(ktx2_pat, kd, kp);
+  out = FrameCounts();
+  for (auto &f : list_dir(dd)) if (match_pattern_lenient(dp, f)) out.geometry_frames++;
+  std::vector<std::string> segs; for (auto &f : list_dir(kd)) if (match_pattern_lenient(kp, f)) segs.push_back(f);
+  if (segs.empty()) { err = "no texture segments match " + ktx2_pat; return false; }
+  out.texture_segments = (long)segs.size();
+  std::vector<uint8_t> last; if (!read_file((kd.empty() ? "" : kd + "/") + segs.back(), last) || last.size() < 36) { err = "cannot read last texture segment"; return false; }
+  uint32_t layers; std::memcpy(&layers, &last[32], 4);                 // KTX2 layerCount (scripts/Encoder.py:128-130)
+  out.texture_frames = (out.texture_segments - 1) * batch + (long)layers;
+  out.compatible = (double)out.geometry_frames * tex_rate == (double)out.texture_frames * geo_rate;     // :135-137
+  out.geometry_duration = out.geometry_frames / geo_rate; out.texture_duration = out.texture_frames / tex_rate;
+  return true;
+}
+
+// ------------------------------------------------------------------ manifests
+Json manifest_player(const Config &c, long geo_frames, long tex_segments, uint32_t tw, uint32_t th, int pad) {
+  const std::string hashes = "[" + std::string((size_t)pad, '#') + "]";
+  Json m = Json::object();
+  m.set("version", Json::string("v2"));
+  if (!c.audio_url.empty()) { Json a = Json::object(); a.set("path", Json::string(c.audio_url)); a.set("format", Json::string("mp3")); m.set("audio", a); }
+  Json g = Json::object(), gt = Json::object(), gd = Json::object();
+  gd.set("format", Json::string("draco")); gd.set("frameRate", Json::number(c.geometry_frame_rate)); gd.set("frameCount", Json::number((double)geo_frames, true));
+  gt.set("draco", gd); g.set("targets", gt); g.set("path", Json::string("geometry_[target]/" + hashes + "[ext]")); m.set("geometry", g);
+  Json t = Json::object(), tt = Json::object(), td = Json::object(), res = Json::array();
+  res.arr.push_back(Json::number(tw, true)); res.arr.push_back(Json::number(th, true));
+  td.set("format", Json::string("ktx2")); td.set("resolution", res); td.set("type", Json::string("baseColor")); td.set("tag", Json::string("default"));
+  td.set("sequenceSize", Json::number(c.ktx2_batch_size, true)); td.set("sequenceCount", Json::number((double)tex_segments, true)); td.set("frameRate", Json::number(c.texture_frame_rate));
+  tt.set("ktx2", td); t.set("targets", tt); t.set("path", Json::string("texture_[target]_[type]_[tag]/" + hashes + "[ext]")); m.set("texture", t);
+  return m;
+}
+Json manifest_encoder_py(const Config &c, long geo_frames, long tex_segments, const std::string &drc_rel, const std::string &ktx2_rel) {   // scripts/Encoder.py:311-328
+  Json m = Json::object(); m.set("version", Json::string("v2"));
+  Json g = Json::object(); g.set("format", Json::string("draco")); g.set("frameRate", Json::number(c.geometry_frame_rate)); g.set("frameCount", Json::number((double)geo_frames, true)); g.set("path", Json::string(drc_rel)); m.set("geometry", g);
+  Json t = Json::object(), arr = Json::array(), e = Json::object();
+  e.set("format", Json::string("ktx2")); e.set("frameRate", Json::number(c.texture_frame_rate)); e.set("sequenceCount", Json::number((double)tex_segments, true)); e.set("sequenceSize", Json::number(c.ktx2_batch_size, true)); e.set("path", Json::string(ktx2_rel));
+  arr.arr.push_back(e); t.set("targets", arr); m.set("texture", t);
+  if (!c.audio_url.empty()) { Json a = Json::object(); a.set("format", Json::string("mp3")); a.set("path", Json::string(c.audio_url)); m.set("audio", a); }
+  return m;
+}
+
+}  // namespace uvolh
+
+// ------------------------------------------------------------------ tiny C surface for the CPU-side tests (no HIP)
+extern "C" {
+static thread_local std::string g_ret;
+const char *uvolh_convert_pounds(const char *s) { g_ret = uvolh::convert_pounds_to_c_style(s); return g_ret.c_str(); }
+int uvolh_match_pattern(const char *p, const char *f) { return uvolh::match_pattern(p, f) ? 1 : 0; }
+int uvolh_match_pattern_lenient(const char *p, const char *f) { return uvolh::match_pattern_lenient(p, f) ? 1 : 0; }
+const char *uvolh_format_index(const char *p, unsigned i) { g_ret = uvolh::format_index(p, i); return g_ret.c_str(); }
+const char *uvolh_check_config(const char *json_text) {
+  uvolh::Json j; std::string err;
+  if (!uvolh::json_parse(json_text, j, err)) { g_ret = "parse error: " + err; return g_ret.c_str(); }
+  g_ret = uvolh::check_all_fields(j); return g_ret.c_str();
+}
+const char *uvolh_check_total_frames(const char *drc_pat, const char *ktx2_pat, int batch, double gr, double tr) {
+  uvolh::FrameCounts fc; std::string err;
+  if (!uvolh::check_total_frames(drc_pat, ktx2_pat, batch, gr, tr, fc, err)) { g_ret = "error: " + err; return g_ret.c_str(); }
+  char b[256]; std::snprintf(b, sizeof b, "{\"geometry\": %.17g, \"texture\": %.17g, \"geometry_frames\": %ld, \"texture_frames\": %ld, \"segments\": %ld, \"compatible\": %s}",
+                             fc.geometry_duration, fc.texture_duration, fc.geometry_frames, fc.texture_frames, fc.texture_segments, fc.compatible ? "true" : "false");
+  g_ret = b; return g_ret.c_str();
+}
+const char *uvolh_manifest(const char *config_json, long geo_frames, long segments, unsigned w, unsigned h, int pad, int encoder_py_shape, const char *drc_rel, const char *ktx2_rel) {
+  uvolh::Config c; std::string err;
+  if (!uvolh::load_config(config_json, c, err)) { g_ret = "error: " + err; return g_ret.c_str(); }
+  g_ret = uvolh::json_dump(encoder_py_shape ? uvolh::manifest_encoder_py(c, geo_frames, segments, drc_rel, ktx2_rel) : uvolh::manifest_player(c, geo_frames, segments, w, h, pad));
+  return g_ret.c_str();
+}
+const char *uvolh_template(void) { g_ret = uvolh::config_template(); return g_ret.c_str(); }
+int uvolh_read_obj_counts(const char *path, unsigned *out6) {
+  uvolh::ObjMesh m; std::string err; if (!uvolh::read_obj(path, m, err)) return -1;
+  out6[0] = (unsigned)m.pos.size() / 3; out6[1] = (unsigned)m.uv.size() / 2; out6[2] = (unsigned)m.nrm.size() / 3; out6[3] = (unsigned)m.idx_pos.size() / 3; out6[4] = (unsigned)m.idx_uv.size() / 3; out6[5] = (unsigned)m.idx_nrm.size() / 3; return 0;
+}
+int uvolh_read_png(const char *path, unsigned *wh, unsigned char *rgba, size_t cap) {
+  uvolh::Image im; std::string err; if (!uvolh::read_png(path, im, err)) return -1;
+  wh[0] = im.w; wh[1] = im.h; if (rgba && cap >= im.rgba.size()) std::memcpy(rgba, im.rgba.data(), im.rgba.size()); return 0;
+}
+}

@@ -1,0 +1,69 @@
+// uvol_host.hpp — host-side mirror of the reference driver scripts/Encoder.py (the caller of the hot path).
+// Same project-config.json fields, same validation rules and error behaviour, same frame accounting, and the
+// V2 manifest the stock player (src/V2/player.ts) reads.  C++17, no HIP in this header.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace uvolh {
+
+// ---- minimal JSON (commentjson-compatible input: // and /* */ comments, trailing commas) ----
+struct Json {
+  enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+  bool b = false; double num = 0; bool is_int = false; std::string str;
+  std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
+  const Json *get(const std::string &k) const { for (auto &kv : obj) if (kv.first == k) return &kv.second; return nullptr; }
+  Json &set(const std::string &k, Json v) { for (auto &kv : obj) if (kv.first == k) { kv.second = std::move(v); return kv.second; } obj.emplace_back(k, std::move(v)); type = Obj; return obj.back().second; }
+  static Json object() { Json j; j.type = Obj; return j; }
+  static Json array() { Json j; j.type = Arr; return j; }
+  static Json string(const std::string &s) { Json j; j.type = Str; j.str = s; return j; }
+  static Json number(double v, bool integer = false) { Json j; j.type = Num; j.num = v; j.is_int = integer; return j; }
+  // python truthiness, as used by `config.get(k)` tests in Encoder.py
+  bool truthy() const { switch (type) { case Null: return false; case Bool: return b; case Num: return num != 0; case Str: return !str.empty(); case Arr: return !arr.empty(); default: return !obj.empty(); } }
+};
+bool json_parse(const std::string &text, Json &out, std::string &err);
+std::string json_dump(const Json &j);
+
+// ---- patterns (scripts/Encoder.py:16-19, :87-100; SURVEY I2: bracketed and bare forms are both accepted) ----
+std::string convert_pounds_to_c_style(const std::string &s);          // export_#####.png -> export_%05u.png
+bool match_pattern(const std::string &pattern, const std::string &file_name);   // exact Encoder.py semantics
+bool match_pattern_lenient(const std::string &pattern, const std::string &file_name);   // also frame_[#####].obj vs frame_00001.obj
+std::string format_index(const std::string &pattern, unsigned index);  // replaces the (bracketed or bare) # run
+
+// ---- config ----
+struct Config {
+  Json raw;
+  std::string name, obj_files_path, draco_files_path, images_path, ktx2_files_path, output_directory, audio_url, abc_file_path;
+  int q_position = 11, q_texture = 10, q_normal = 8, q_generic = 8, compression_level = 7;
+  int ktx2_first_file = 0, ktx2_file_count = 0, ktx2_batch_size = 0;
+  double geometry_frame_rate = 0, texture_frame_rate = 0;
+};
+// check_all_fields (scripts/Encoder.py:45-84): returns "" when valid, else the reference's message
+std::string check_all_fields(const Json &cfg);
+bool load_config(const std::string &json_text, Config &c, std::string &err);
+std::string config_template();                                          // `create-template` (scripts/Encoder.py:163-186)
+
+// ---- ingest ----
+struct ObjMesh { std::vector<float> pos, uv, nrm; std::vector<uint32_t> idx_pos, idx_uv, idx_nrm; };
+bool read_obj(const std::string &path, ObjMesh &m, std::string &err);
+struct Image { uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; };
+bool read_png(const std::string &path, Image &img, std::string &err);
+bool write_file(const std::string &path, const void *data, size_t n);
+bool read_file(const std::string &path, std::vector<uint8_t> &data);
+std::vector<std::string> list_dir(const std::string &dir);
+bool make_dirs(const std::string &dir);
+
+// ---- frame accounting (scripts/Encoder.py:103-154) ----
+struct FrameCounts { long geometry_frames = 0, texture_frames = 0, texture_segments = 0; double geometry_duration = 0, texture_duration = 0; bool compatible = false; };
+bool check_total_frames(const std::string &drc_path_pattern, const std::string &ktx2_path_pattern, int batch, double geo_rate, double tex_rate, FrameCounts &out, std::string &err);
+
+// ---- manifests ----
+// The shape src/V2/player.ts reads (src/Interfaces.ts:75-132): targets are objects keyed by target name.
+Json manifest_player(const Config &c, long geometry_frames, long texture_segments, uint32_t tex_w, uint32_t tex_h, int pad_width);
+// The literal dict scripts/Encoder.py:311-328 writes (kept behind --encoder-py-manifest).
+Json manifest_encoder_py(const Config &c, long geometry_frames, long texture_segments, const std::string &drc_rel, const std::string &ktx2_rel);
+
+}  // namespace uvolh
