@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one batch of synthetic frames resident in HBM:
 FRAMES_PER_STEP geometry frames (one `uvol_encode_mesh_batch_dev` call = what FRAMES_PER_STEP
 `draco_encoder` processes do, scripts/Encoder.py:256-267) and FRAMES_PER_STEP / KTX2_BATCH_SIZE
-texture segments (one `uvol_encode_texture_segment_dev` call each = one `basisu` process,
+texture segments (one batched `uvol_encode_texture_segments_dev` call = that many `basisu` processes,
 scripts/Encoder.py:279-298), geometry and texture on two HIP streams of the same GPU.  The timed
 region ends when every .drc / .ktx2 byte is in host memory.
 
@@ -33,13 +33,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=40)
+    ap.add_argument("--frames-per-step", type=int, default=80)
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
-    ap.add_argument("--tex-streams", type=int, default=2, help="texture contexts (HIP streams) fed by host threads")
+    ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,8 +94,8 @@ def main():
         out["drc"] = geo.encode_mesh_batch_dev(batch)
 
     def run_tex(ti):
-        out["ktx2_%d" % ti] = [texs[ti].encode_texture_segment_dev(tex_ptrs, args.tex_size, args.tex_size)
-                               for _ in range(ti, nseg, len(texs))]
+        mine = len(range(ti, nseg, len(texs)))            # segments of this step handled by texture context ti, ONE batched call
+        out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
 
     def step():
         th = [threading.Thread(target=run_geo)] + [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs))]
@@ -148,7 +148,7 @@ def main():
         groups += list(tg.values())
         groups.sort(key=lambda g: -g["total_ms"])
         dom = groups[0]
-        units = F if dom["name"].startswith("geo.") else B                      # frames one launch of that group processes
+        units = F if dom["name"].startswith("geo.") else F // len(texs)          # frames one launch of that group processes
         avg_ms = dom["total_ms"] / max(1, dom["launches"])
         achieved = algo_per_frame * units / (avg_ms * 1e-3) / 1e9
         res = {

@@ -103,6 +103,15 @@ int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_de
                                     uint32_t width, uint32_t height,
                                     uint8_t *out, size_t cap, size_t *out_len);
 
+/* Batched form of HOT LOOP 2 (scripts/Encoder.py:279-298): n_segments independent segments of n_layers layers each
+ * (rgba[s * n_layers + l]), all of one size, encoded with ONE kernel launch per pipeline stage. */
+int uvol_encode_texture_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers,
+                                 uint32_t width, uint32_t height,
+                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens);
+int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers,
+                                     uint32_t width, uint32_t height,
+                                     uint8_t *const *outs, const size_t *caps, size_t *out_lens);
+
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int uvol_profile_enable(uvol_ctx *ctx, int on);

@@ -43,3 +43,13 @@ def test_gpu_full_size_segment(oracle, gpu_codec):
     assert all(0.5 * nb < s < 0.9 * nb for s in d.slice_skip[1:])
     assert min(oracle.psnr(d.images[l], tex[l][::-1]) for l in range(5)) > 30.0
     assert k == oracle.ktx2_encode(tex)
+
+
+def test_gpu_batched_segments_equal_single_calls(oracle, gpu_codec):
+    """uvol_encode_texture_segments (one launch per stage for the whole batch) == per-segment calls == oracle."""
+    import synth
+    segs = [synth.texture_sequence(3, size=128, seed=s) for s in (1, 2, 3, 4)]
+    segs.append([np.full((128, 128, 4), v, np.uint8) for v in (10, 10, 200)])
+    res = gpu_codec.encode_texture_segments(segs)
+    for seg, r in zip(segs, res):
+        assert r == oracle.ktx2_encode(seg)

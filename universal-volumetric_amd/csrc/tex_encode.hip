@@ -13,7 +13,7 @@
 #include "tex_device.hpp"
 #include <algorithm>
 
-#define TJOB_OR_RETURN TexJob &J = *job; if (J.status != 0) return
+#define TJOB_OR_RETURN TexJob &J = job[blockIdx.z]; if (J.status != 0) return
 
 // ------------------------------------------------------------------------------------------------
 // scans (block-level exclusive scan shared with nothing else in this TU)
@@ -33,7 +33,7 @@ __device__ inline uint32_t t_block_excl_scan(uint32_t v, uint32_t *total) {
 }
 // phase 1: per-block sums of flag[0..n)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_tscan_a(TexJob *job, uint32_t n) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   uint32_t v = (J.status == 0 && i < n) ? J.flag[i] : 0, tot;
   t_block_excl_scan(v, &tot);
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tscan_a(TexJob *job, uint32_t n)
 }
 // phase 2: exclusive scan of the block sums (single workgroup); bsum[nblocks] = grand total
 __global__ void __launch_bounds__(UVOL_BLOCK) k_tscan_b(TexJob *job, uint32_t nblocks) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_cell_flags(TexJob *job) {
   if (c < (1u << 18)) J.flag[c] = J.hist[c] ? 1 : 0;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_cell_compact(TexJob *job) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const bool live = J.status == 0 && c < (1u << 18);
   uint32_t v = live ? J.flag[c] : 0, tot;
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_block_assign(TexJob *job) {
   J.bsel[b] = sel;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_item_compact(TexJob *job) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const bool live = J.status == 0 && b < J.NB;
   uint32_t v = live ? J.flag[b] : 0, tot;
@@ -484,14 +484,14 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_preds(TexJob *job) {
 
 // ---- per-slice scans: flags at J.flag[l*stride + i], block sums at J.bsum[l*(nblk+1) + blk] ----
 __global__ void __launch_bounds__(UVOL_BLOCK) k_sscan_a(TexJob *job, uint32_t n, uint32_t stride) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.y, i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   uint32_t v = (J.status == 0 && i < n) ? J.flag[(size_t)l * stride + i] : 0, tot;
   t_block_excl_scan(v, &tot);
   if (threadIdx.x == 0) J.bsum[(size_t)l * (gridDim.x + 1) + blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_sscan_b(TexJob *job, uint32_t nblocks) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   uint32_t *bs = J.bsum + (size_t)blockIdx.x * (nblocks + 1);
   __shared__ uint32_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tok_delta(TexJob *job) {
 }
 // coded blocks of each slice, in raster order
 __global__ void __launch_bounds__(UVOL_BLOCK) k_coded_list(TexJob *job) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.y, i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const bool live = J.status == 0 && i < J.nb;
   uint32_t v = live ? J.flag[(size_t)l * J.nb + i] : 0, tot;
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_mb_flags(TexJob *job, uint32_t n
 }
 // gid = number of boundaries up to and including k (0 = the leading group that continues prev_sym = 0)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_mb_groups(TexJob *job, uint32_t nm) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.y, k = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const bool live = J.status == 0 && k < nm;
   uint32_t v = live ? J.flag[(size_t)l * nm + k] : 0, tot;
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_mb_tokens(TexJob *job, uint32_t 
 // sequential.  One wave per slice; lane k keeps history entry k in a register (search = ballot + ffs, swap = two
 // lane reads); the coded blocks are prefetched 64 at a time; tokens are collected per lane and stored coalesced.
 __global__ void __launch_bounds__(64) k_sel_tokens(TexJob *job) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.x, lane = threadIdx.x;
   const bool ok = J.status == 0;
   const uint32_t n = ok ? J.ncoded[l] : 0, ns = J.ns;
@@ -836,7 +836,7 @@ __device__ __forceinline__ void t_tok_bits(const TexJob &J, unsigned long long t
 }
 // grid (blocks over 3*nb slots, L): per-block bit totals
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_a(TexJob *job) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.y, i = blockIdx.x * UVOL_BLOCK + threadIdx.x, n = 3 * J.nb;
   unsigned long long bits; uint32_t len = 0;
   if (J.status == 0 && i < n) t_tok_bits(J, J.tok[3 * (size_t)l * J.nb + i], bits, len);
@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_a(TexJob *job) {
 }
 // one workgroup per slice: exclusive scan of the block totals (64-bit safe: totals < 2^32 bits per slice is asserted)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_b(TexJob *job, uint32_t nblocks) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.x;
   uint32_t *bs = J.bsum + (size_t)l * (nblocks + 1);
   __shared__ uint32_t carry;
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_b(TexJob *job, uint32_t nbl
   }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_c(TexJob *job) {
-  TexJob &J = *job;
+  TexJob &J = job[blockIdx.z];
   const uint32_t l = blockIdx.y, i = blockIdx.x * UVOL_BLOCK + threadIdx.x, n = 3 * J.nb;
   unsigned long long bits = 0; uint32_t len = 0;
   const bool ok = J.status == 0;
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_c(TexJob *job) {
 // ================================================================================================
 struct TexState {
   uvol_devbuf slab, layers, job;
-  std::vector<uint8_t> stage;
+  std::vector<TexJob> hjobs;
 };
 int tex_create(uvol_ctx *ctx) { ctx->tex = new TexState(); return UVOL_OK; }
 void tex_destroy(uvol_ctx *ctx) {
@@ -952,12 +952,13 @@ inline void put16(uint8_t *&p, uint16_t v) { memcpy(p, &v, 2); p += 2; }
 #define TLAUNCH(k, grid, block, shmem, ...)                                                      \
   do {                                                                                           \
     if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s\n", #k); fflush(stderr); }              \
-    hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, __VA_ARGS__);                         \
+    dim3 g3_ = grid; g3_.z = NSEG;                                                               \
+    hipLaunchKernelGGL(k, g3_, block, shmem, ctx->stream, __VA_ARGS__);                          \
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
   } while (0)
 
 template <int DIM, int LCAP, typename CT>
-static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks) {
+static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG) {
   const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   const unsigned kb = uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM);
   const unsigned sb = std::min<unsigned>(item_blocks, 512u);
@@ -970,39 +971,49 @@ static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks) {
   }
 }
 template <int DIM, int LCAP, typename CT>
-static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks) {
+static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG) {
   const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   TLAUNCH((k_vq_zero<DIM>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM)), dim3(UVOL_BLOCK), 0, dj, 1);
   TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1);
 }
 
-int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t W, uint32_t H,
-                       bool on_device, uint8_t *out, size_t cap, size_t *out_len) {
+// n_seg segments of n_layers layers each (rgba[s * n_layers + l]), all of one size: ONE launch per stage for the whole batch
+int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
+                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
   TexState *T = ctx->tex;
-  if (n_layers > TEX_MAX_LAYERS || W > 16384 || H > 16384) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }
-  TexJob J; memset(&J, 0, sizeof(J));
-  J.W = W; J.H = H; J.L = (uint32_t)n_layers; J.bx = (W + 3) / 4; J.by = (H + 3) / 4; J.nb = J.bx * J.by; J.NB = J.nb * J.L;
-  J.yflip = ctx->prm.y_flip ? 1 : 0;
+  if (n_seg <= 0) return UVOL_OK;
+  if (n_layers > TEX_MAX_LAYERS || W > 16384 || H > 16384 || n_seg > 65535) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }
+  const unsigned NSEG = (unsigned)n_seg;
+  TexJob J0; memset(&J0, 0, sizeof(J0));
+  J0.W = W; J0.H = H; J0.L = (uint32_t)n_layers; J0.bx = (W + 3) / 4; J0.by = (H + 3) / 4; J0.nb = J0.bx * J0.by; J0.NB = J0.nb * J0.L;
+  J0.yflip = ctx->prm.y_flip ? 1 : 0;
   const int q = std::min(255, std::max(1, ctx->prm.etc1s_quality));
-  J.Kmax_e = (uint32_t)std::min(TEX_MAX_CODEBOOK, std::max(32, q * 12)); J.Kmax_s = (uint32_t)std::min(TEX_MAX_CODEBOOK, std::max(32, q * 6));
-  J.T_skip = (uint32_t)((255 - q) * 3 / 2);
-  J.slice_cap = (uint32_t)((size_t)J.nb * 8 + 64);
-  size_t zero_bytes = 0; const size_t ws = tex_layout(J, nullptr, &zero_bytes);
+  J0.Kmax_e = (uint32_t)std::min(TEX_MAX_CODEBOOK, std::max(32, q * 12)); J0.Kmax_s = (uint32_t)std::min(TEX_MAX_CODEBOOK, std::max(32, q * 6));
+  J0.T_skip = (uint32_t)((255 - q) * 3 / 2);
+  J0.slice_cap = (uint32_t)((size_t)J0.nb * 8 + 64);
+  size_t zero_bytes = 0; const size_t ws = tex_layout(J0, nullptr, &zero_bytes);
   const size_t lbytes = (size_t)W * H * 4;
   int rc;
-  if ((rc = uvol_ensure(ctx, T->slab, ws))) return rc;
-  if ((rc = uvol_ensure(ctx, T->job, sizeof(TexJob)))) return rc;
-  if (!on_device && (rc = uvol_ensure(ctx, T->layers, lbytes * (size_t)n_layers))) return rc;
-  tex_layout(J, (uint8_t *)T->slab.p, &zero_bytes);
-  UVOL_HIP_CHECK(ctx, hipMemsetAsync(T->slab.p, 0, zero_bytes, ctx->stream));
-  for (int l = 0; l < n_layers; l++) {
-    if (on_device) J.layer[l] = rgba[l];
-    else { uint8_t *d = (uint8_t *)T->layers.p + lbytes * (size_t)l; UVOL_HIP_CHECK(ctx, hipMemcpyAsync(d, rgba[l], lbytes, hipMemcpyHostToDevice, ctx->stream)); J.layer[l] = d; }
+  if ((rc = uvol_ensure(ctx, T->slab, ws * (size_t)n_seg))) return rc;
+  if ((rc = uvol_ensure(ctx, T->job, sizeof(TexJob) * (size_t)n_seg))) return rc;
+  if (!on_device && (rc = uvol_ensure(ctx, T->layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
+  T->hjobs.assign((size_t)n_seg, J0);
+  for (int s = 0; s < n_seg; s++) {
+    TexJob &J = T->hjobs[s];
+    uint8_t *base = (uint8_t *)T->slab.p + ws * (size_t)s;
+    tex_layout(J, base, &zero_bytes);
+    UVOL_HIP_CHECK(ctx, hipMemsetAsync(base, 0, zero_bytes, ctx->stream));
+    for (int l = 0; l < n_layers; l++) {
+      const uint8_t *src = rgba[(size_t)s * n_layers + l];
+      if (on_device) J.layer[l] = src;
+      else { uint8_t *d = (uint8_t *)T->layers.p + lbytes * ((size_t)s * n_layers + l); UVOL_HIP_CHECK(ctx, hipMemcpyAsync(d, src, lbytes, hipMemcpyHostToDevice, ctx->stream)); J.layer[l] = d; }
+    }
   }
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->job.p, &J, sizeof(TexJob), hipMemcpyHostToDevice, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->job.p, T->hjobs.data(), sizeof(TexJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
   TexJob *dj = (TexJob *)T->job.p;
+  const TexJob &J = J0;
   const unsigned bnb = uvol_blocks(J.nb), bNB = uvol_blocks(J.NB), bcell = (1u << 18) / UVOL_BLOCK, bK = uvol_blocks(TEX_MAX_CODEBOOK);
-  const uint64_t src_bytes = (uint64_t)lbytes * n_layers;
+  const uint64_t src_bytes = (uint64_t)lbytes * n_layers * (uint64_t)n_seg;
   { uvol_ctx::Scope sc(ctx, "tex.k11_skip", src_bytes); TLAUNCH(k_tex_skip, dim3(bnb), dim3(UVOL_BLOCK), 0, dj); }
   { uvol_ctx::Scope sc(ctx, "tex.k9_endpoint_fit", src_bytes); TLAUNCH(k_tex_fit, dim3(bNB), dim3(UVOL_BLOCK), 0, dj); }
   {
@@ -1012,9 +1023,9 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
     TLAUNCH(k_tscan_b, dim3(1), dim3(UVOL_BLOCK), 0, dj, bcell);
     TLAUNCH(k_cell_compact, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_cell_leaf_init, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
-    run_vq_rounds<4, 800, unsigned long long>(ctx, dj, bcell);
+    run_vq_rounds<4, 800, unsigned long long>(ctx, dj, bcell, NSEG);
     for (int it = 0; it <= 2; it++) {
-      run_vq_stats<4, 800, unsigned long long>(ctx, dj, bcell);
+      run_vq_stats<4, 800, unsigned long long>(ctx, dj, bcell, NSEG);
       TLAUNCH(k_ep_entries, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
       if (it < 2) TLAUNCH(k_ep_assign, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
     }
@@ -1029,9 +1040,9 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
   }
   {
     uvol_ctx::Scope sc(ctx, "tex.k10_selector_codebook", src_bytes * 2);
-    run_vq_rounds<16, 480, unsigned int>(ctx, dj, bNB);
+    run_vq_rounds<16, 480, unsigned int>(ctx, dj, bNB, NSEG);
     for (int it = 0; it < 2; it++) {
-      run_vq_stats<16, 480, unsigned int>(ctx, dj, bNB);
+      run_vq_stats<16, 480, unsigned int>(ctx, dj, bNB, NSEG);
       TLAUNCH(k_sel_centroids, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
       TLAUNCH(k_sel_assign, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
     }
@@ -1043,7 +1054,7 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
   }
   const unsigned bslots = uvol_blocks((size_t)3 * J.nb);
   {
-    uvol_ctx::Scope sc(ctx, "tex.k12_symbolize", (uint64_t)J.NB * 6);
+    uvol_ctx::Scope sc(ctx, "tex.k12_symbolize", (uint64_t)J.NB * 6 * n_seg);
     TLAUNCH(k_preds, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_tok_delta, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_sscan_a, dim3(bnb, J.L), dim3(UVOL_BLOCK), 0, dj, J.nb, J.nb);
@@ -1061,7 +1072,7 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
     TLAUNCH(k_tok_hist, dim3(std::min<unsigned>(uvol_blocks((size_t)3 * J.NB), 1024u)), dim3(UVOL_BLOCK), lh_bytes, dj);
   }
   {
-    uvol_ctx::Scope sc(ctx, "tex.k12_huffman_pack", (uint64_t)J.NB * 24);
+    uvol_ctx::Scope sc(ctx, "tex.k12_huffman_pack", (uint64_t)J.NB * 24 * n_seg);
     TLAUNCH(k_huff_models, dim3(4), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_sections, dim3(3), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_pack_a, dim3(bslots, J.L), dim3(UVOL_BLOCK), 0, dj);
@@ -1069,12 +1080,10 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
     TLAUNCH(k_pack_c, dim3(bslots, J.L), dim3(UVOL_BLOCK), 0, dj);
   }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
-  TexJob R;
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(&R, dj, sizeof(TexJob), hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexJob) * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
-  if (R.status != 0) { ctx->set_error("texture segment: device status %d", R.status); return UVOL_E_ENCODE; }
-  // ---- K13: KTX2 container ----
+  // ---- K13: KTX2 containers ----
   static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
   static const char writer[] = "uvol-mi355x etc1s 0.1";
   uint8_t kvd[128]; uint8_t *kp = kvd;
@@ -1083,26 +1092,36 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
   while ((kp - kvd) & 3) *kp++ = 0;
   const uint32_t dfd_off = 80 + 24, dfd_len = 44, kvd_off = dfd_off + dfd_len, kvd_len = (uint32_t)(kp - kvd);
   const uint64_t sgd_off = ((uint64_t)kvd_off + kvd_len + 7) & ~7ull;
-  const uint64_t sgd_len = 20 + 20 * (uint64_t)n_layers + R.sec_len[0] + R.sec_len[1] + R.sec_len[2];
-  uint64_t lvl_len = 0; for (int l = 0; l < n_layers; l++) lvl_len += R.slice_len[l];
-  const uint64_t lvl_off = sgd_off + sgd_len, total = lvl_off + lvl_len;
-  *out_len = (size_t)total;
-  if (total > cap) { ctx->set_error("texture segment: output buffer too small (%llu > %llu)", (unsigned long long)total, (unsigned long long)cap); return UVOL_E_NOSPACE; }
-  uint8_t *p = out;
-  memcpy(p, ident, 12); p += 12;
-  put32(p, 0); put32(p, 1); put32(p, W); put32(p, H); put32(p, 0); put32(p, (uint32_t)n_layers); put32(p, 1); put32(p, 1); put32(p, 1);
-  put32(p, dfd_off); put32(p, dfd_len); put32(p, kvd_off); put32(p, kvd_len); put64(p, sgd_off); put64(p, sgd_len);
-  put64(p, lvl_off); put64(p, lvl_len); put64(p, 0);
-  put32(p, 44); put32(p, 0); put16(p, 2); put16(p, 40);
-  *p++ = 163; *p++ = 1; *p++ = 2; *p++ = 0; *p++ = 3; *p++ = 3; *p++ = 0; *p++ = 0;
-  for (int i = 0; i < 8; i++) *p++ = 0;
-  put16(p, 0); *p++ = 63; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; put32(p, 0); put32(p, 0xFFFFFFFFu);
-  memcpy(p, kvd, kvd_len); p += kvd_len;
-  while ((uint64_t)(p - out) < sgd_off) *p++ = 0;
-  put16(p, (uint16_t)R.ne); put16(p, (uint16_t)R.ns); put32(p, R.sec_len[0]); put32(p, R.sec_len[1]); put32(p, R.sec_len[2]); put32(p, 0);
-  { uint32_t off = 0; for (int l = 0; l < n_layers; l++) { put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, R.slice_len[l]); put32(p, 0); put32(p, 0); off += R.slice_len[l]; } }
-  for (int s = 0; s < 3; s++) { UVOL_HIP_CHECK(ctx, hipMemcpyAsync(p, R.sec[s], R.sec_len[s], hipMemcpyDeviceToHost, ctx->stream)); p += R.sec_len[s]; }
-  for (int l = 0; l < n_layers; l++) { UVOL_HIP_CHECK(ctx, hipMemcpyAsync(p, R.slice[l], R.slice_len[l], hipMemcpyDeviceToHost, ctx->stream)); p += R.slice_len[l]; }
+  int worst = UVOL_OK;
+  for (int s = 0; s < n_seg; s++) {
+    const TexJob &R = T->hjobs[s];
+    if (R.status != 0) { ctx->set_error("texture segment %d: device status %d", s, R.status); worst = UVOL_E_ENCODE; out_lens[s] = 0; continue; }
+    const uint64_t sgd_len = 20 + 20 * (uint64_t)n_layers + R.sec_len[0] + R.sec_len[1] + R.sec_len[2];
+    uint64_t lvl_len = 0; for (int l = 0; l < n_layers; l++) lvl_len += R.slice_len[l];
+    const uint64_t lvl_off = sgd_off + sgd_len, total = lvl_off + lvl_len;
+    out_lens[s] = (size_t)total;
+    if (total > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%llu > %llu)", s, (unsigned long long)total, (unsigned long long)caps[s]); worst = UVOL_E_NOSPACE; continue; }
+    uint8_t *out = outs[s], *p = out;
+    memcpy(p, ident, 12); p += 12;
+    put32(p, 0); put32(p, 1); put32(p, W); put32(p, H); put32(p, 0); put32(p, (uint32_t)n_layers); put32(p, 1); put32(p, 1); put32(p, 1);
+    put32(p, dfd_off); put32(p, dfd_len); put32(p, kvd_off); put32(p, kvd_len); put64(p, sgd_off); put64(p, sgd_len);
+    put64(p, lvl_off); put64(p, lvl_len); put64(p, 0);
+    put32(p, 44); put32(p, 0); put16(p, 2); put16(p, 40);
+    *p++ = 163; *p++ = 1; *p++ = 2; *p++ = 0; *p++ = 3; *p++ = 3; *p++ = 0; *p++ = 0;
+    for (int i = 0; i < 8; i++) *p++ = 0;
+    put16(p, 0); *p++ = 63; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; put32(p, 0); put32(p, 0xFFFFFFFFu);
+    memcpy(p, kvd, kvd_len); p += kvd_len;
+    while ((uint64_t)(p - out) < sgd_off) *p++ = 0;
+    put16(p, (uint16_t)R.ne); put16(p, (uint16_t)R.ns); put32(p, R.sec_len[0]); put32(p, R.sec_len[1]); put32(p, R.sec_len[2]); put32(p, 0);
+    { uint32_t off = 0; for (int l = 0; l < n_layers; l++) { put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, R.slice_len[l]); put32(p, 0); put32(p, 0); off += R.slice_len[l]; } }
+    for (int k = 0; k < 3; k++) { UVOL_HIP_CHECK(ctx, hipMemcpyAsync(p, R.sec[k], R.sec_len[k], hipMemcpyDeviceToHost, ctx->stream)); p += R.sec_len[k]; }
+    for (int l = 0; l < n_layers; l++) { UVOL_HIP_CHECK(ctx, hipMemcpyAsync(p, R.slice[l], R.slice_len[l], hipMemcpyDeviceToHost, ctx->stream)); p += R.slice_len[l]; }
+  }
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return UVOL_OK;
+  return worst;
+}
+
+int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t W, uint32_t H,
+                       bool on_device, uint8_t *out, size_t cap, size_t *out_len) {
+  return tex_encode_segments(ctx, rgba, 1, n_layers, W, H, on_device, &out, &cap, out_len);
 }

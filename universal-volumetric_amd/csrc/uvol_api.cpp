@@ -105,6 +105,19 @@ int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_de
   return tex_encode_segment(ctx, rgba_dev, n_layers, width, height, true, out, cap, out_len);
 }
 
+int uvol_encode_texture_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height,
+                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  if (!ctx || !rgba || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_encode_segments(ctx, rgba, n_segments, n_layers, width, height, false, outs, caps, out_lens);
+}
+int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers, uint32_t width, uint32_t height,
+                                     uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  if (!ctx || !rgba_dev || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_encode_segments(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
+}
+
 int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; ctx->profiling = on != 0; return UVOL_OK; }
 int uvol_profile_reset(uvol_ctx *ctx) {
   if (!ctx) return UVOL_E_INVALID;

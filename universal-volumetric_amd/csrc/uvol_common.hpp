@@ -117,5 +117,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
 int tex_create(uvol_ctx *ctx);
 void tex_destroy(uvol_ctx *ctx);
+int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
+                        bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens);
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t w, uint32_t h,
                        bool inputs_on_device, uint8_t *out, size_t cap, size_t *out_len);

@@ -30,7 +30,7 @@ class Mesh(C.Structure):
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
-           "uvol_encode_texture_segment_dev", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
 
 
@@ -53,6 +53,9 @@ def load(path=None):
     for nm in ("uvol_encode_texture_segment", "uvol_encode_texture_segment_dev"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_size_t)]
+    for nm in ("uvol_encode_texture_segments", "uvol_encode_texture_segments_dev"):
+        getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.uvol_profile_reset.argtypes = [C.c_void_p]
     L.uvol_profile_count.argtypes = [C.c_void_p]
@@ -166,6 +169,30 @@ class Codec:
         n = len(dev_ptrs)
         ptrs = (C.c_void_p * n)(*[int(p) for p in dev_ptrs])
         return self._run_tex(self.L.uvol_encode_texture_segment_dev, ptrs, n, width, height)
+
+    def encode_texture_segments(self, segments):
+        """segments: list of lists of HxWx4 uint8 arrays (same size, same layer count) -> list of .ktx2 bytes (one batched call)."""
+        arrs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in seg] for seg in segments]
+        h, w = arrs[0][0].shape[:2]; nl = len(arrs[0])
+        flat = [a for seg in arrs for a in seg]
+        if any(len(seg) != nl for seg in arrs) or any(a.shape != (h, w, 4) for a in flat):
+            raise ValueError("all segments must have the same layer count and HxWx4 size")
+        ptrs = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
+        return self._run_tex_batch(self.L.uvol_encode_texture_segments, ptrs, len(arrs), nl, w, h)
+
+    def encode_texture_segments_dev(self, dev_ptrs, n_layers, width, height):
+        """dev_ptrs: flat list of n_segments*n_layers device pointers."""
+        ptrs = (C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs])
+        return self._run_tex_batch(self.L.uvol_encode_texture_segments_dev, ptrs, len(dev_ptrs) // n_layers, n_layers, width, height)
+
+    def _run_tex_batch(self, fn, ptrs, nseg, nl, w, h):
+        cap = self.L.uvol_texture_bound(w, h, nl)
+        bufs = [np.empty(cap, dtype=np.uint8) for _ in range(nseg)]
+        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
+        rc = fn(self.h, ptrs, nseg, nl, w, h, outs, caps, lens)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_texture_segments rc={rc}: {self.error()}")
+        return [bufs[i][:lens[i]].tobytes() for i in range(nseg)]
 
     def _run_tex(self, fn, ptrs, n, w, h):
         cap = self.L.uvol_texture_bound(w, h, n)
