@@ -34,12 +34,12 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
 }
 
 // scan selectors
-enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3 };
+enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3, SCAN_DENSE = 4 };
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
 // register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
-__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return (sel == SCAN_KEEP || sel == SCAN_EVENTS) ? J.keep : (sel == SCAN_ELIG ? J.elig : J.has_ori); }
-__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return (sel == SCAN_KEEP || sel == SCAN_EVENTS) ? J.keep : (sel == SCAN_ELIG ? J.elig : (sel == SCAN_DENSE ? J.dflag : J.has_ori)); }
+__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : ((sel == SCAN_ELIG || sel == SCAN_DENSE) ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
   const uint8_t *flags = scan_flags(J, sel); const uint32_t n = scan_count(J, sel);
@@ -213,6 +213,38 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 //   k_eb_ctx       (1 wave)    ballot-ordered scatter of the symbols into the 6 valence-context streams
 // (SURVEY A.3 / A.10).  The serial kernels run one frame per workgroup; a batch keeps that many CUs busy.
 // ------------------------------------------------------------------------------------------------
+// dense vertex ids per table (so the walkers' vertex-visited bitmap is nverts bits, not 3*nf): canonical corners are
+// numbered by an order-preserving scan and the table's corner->vertex array is rewritten in place.
+__device__ __forceinline__ bool dense_table_live(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return !(which >= 2 && (ai >= J.nad || !J.interior_seams[ai])); }
+__device__ __forceinline__ int32_t *dense_vert(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]); }
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense_flags(GeoJob *jobs, int which) {
+  JOB_OR_RETURN;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c >= J.nc) return;
+  J.dflag[c] = (dense_table_live(J, which) && dense_vert(J, which)[c] == (int32_t)c) ? 1 : 0;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense_assign(GeoJob *jobs, int which) {
+  GeoJob &J = jobs[blockIdx.y];
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && c < J.nc;
+  uint32_t v = live ? J.dflag[c] : 0, tot;
+  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsum[blockIdx.x] : 0);
+  if (live && v) {
+    const int ai = which >= 2 ? which - 2 : 0;
+    const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
+    J.dtmp[c] = (int32_t)pos; J.vopen_d[which][pos] = vopen[c];
+    if (which == 0) J.ring_d[pos] = J.ring[c];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nverts_t[which] = J.bsum[uvol_blocks_dev(J.nc)];
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense_apply(GeoJob *jobs, int which) {
+  JOB_OR_RETURN;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c >= J.nc || !dense_table_live(J, which)) return;
+  int32_t *vert = dense_vert(J, which);
+  vert[c] = J.dtmp[vert[c]];
+}
+
 // which: 0 old base table (edgebreaker), 1 new base, 2/3 attribute tables (DFS)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which) {
   JOB_OR_RETURN;
@@ -223,7 +255,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
   const int32_t *opp = which == 0 ? J.opp : J.nopp;
   const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
   const int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
-  const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
+  const uint8_t *vopen = J.vopen_d[which];
   int32_t *rec = J.rec[which] + 8 * (size_t)f;
   int r[8];
   for (int k = 0; k < 3; k++) {
@@ -253,11 +285,15 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   UVOL_DYN_SMEM(uint32_t, lds);
   const int nf = (int)J.nf, nc = (int)J.nc;
   const bool ok = J.status == 0;
-  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = ((uint32_t)nc + 31) / 32;
+  // LDS holds nf face bits + up to nf vertex bits (vertices are densely numbered; a table with more vertices than
+  // faces keeps its vertex bitmap in global memory instead)
+  const uint32_t fw = ((uint32_t)nf + 31) / 32, vcap = fw, vw = (J.nverts_t[0] + 31) / 32;
+  const bool v_in_lds = LDS && vw <= vcap;
   uint32_t *fbits = LDS ? lds : reinterpret_cast<uint32_t *>(J.fvis);
-  uint32_t *vbits = LDS ? lds + fw : reinterpret_cast<uint32_t *>(J.vvis);
-  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + vw; k += 64) lds[k] = 0; __syncthreads(); }
+  uint32_t *vbits = v_in_lds ? lds + fw : reinterpret_cast<uint32_t *>(J.vvis);
+  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + (v_in_lds ? vw : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (threadIdx.x != 0 || !ok) return;
+  (void)nc;
   const int32_t *rec = J.rec[0];
   int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
@@ -355,9 +391,11 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
   const int32_t *opp = J.opp, *proc = J.proc, *ftime = J.face_time; const uint8_t *symb = J.symb;
   int32_t *vval = J.vval, *c2vm = J.c2vm;
   // initial valences / corner->vertex replica (parallel over lanes)
-  for (int i = (int)lane; i < (ok ? nc : 0); i += 64) { vval[i] = J.ring[i]; c2vm[i] = J.vert[i]; }
+  const int nv0 = ok ? (int)J.nverts_t[0] : 0;
+  for (int i = (int)lane; i < (ok ? nc : 0); i += 64) c2vm[i] = J.vert[i];
+  for (int i = (int)lane; i < nv0; i += 64) vval[i] = J.ring_d[i];
   __syncthreads();
-  int nvval = nc;
+  int nvval = nv0;
   for (int base = 0; base < nsym; base += 64) {
     const int mi = base + (int)lane;
     // lane-parallel gather of the chunk's corners, symbols and vertex ids (valid until an S re-maps corners)
@@ -482,10 +520,12 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   const int ai = t > 0 ? t - 1 : 0;
   const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
   const int nf = (int)J.nf, nc = (int)J.nc;
-  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = ((uint32_t)nc + 31) / 32;
+  const uint32_t fw = ((uint32_t)nf + 31) / 32, vcap = fw, vw = (J.nverts_t[1 + t] + 31) / 32;
+  const bool v_in_lds = LDS && vw <= vcap;
   uint32_t *fbits = LDS ? lds : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
-  uint32_t *vbits = LDS ? lds + fw : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
-  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + vw; k += 64) lds[k] = 0; __syncthreads(); }
+  uint32_t *vbits = v_in_lds ? lds + fw : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
+  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + (v_in_lds ? vw : 0); k += 64) lds[k] = 0; __syncthreads(); }
+  (void)nc;
   if (threadIdx.x != 0 || !ok) return;
   const int32_t *rec = J.rec[1 + t];
   int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
@@ -750,15 +790,31 @@ __global__ void __launch_bounds__(64) k_stream_setup(GeoJob *jobs) {
 // ------------------------------------------------------------------------------------------------
 // K7: rANS (RAW scheme) — histogram (parallel), table build (serial, tiny), encode (serial per stream)
 // ------------------------------------------------------------------------------------------------
+// grid (blocks, stream, frame).  Alphabets that fit (<= HIST_LDS entries) are counted in LDS first: the six
+// valence-context streams have 5 symbols, so global atomics would serialise on 5 addresses per frame.
+#define HIST_LDS 8192
 __global__ void __launch_bounds__(UVOL_BLOCK) k_hist(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.z];
-  if (J.status != 0) return;
+  __shared__ uint32_t lh[HIST_LDS];
+  const bool ok = J.status == 0;
   RansStream &S = J.rs[blockIdx.y];
-  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const uint32_t n = ok ? S.n : 0;
+  const bool in_lds = S.alpha_cap <= HIST_LDS;
+  const uint32_t per_block = 16 * UVOL_BLOCK, b0 = blockIdx.x * per_block;
+  if (b0 >= n) return;                                   // block-uniform
+  if (in_lds) { for (uint32_t k = threadIdx.x; k < S.alpha_cap; k += UVOL_BLOCK) lh[k] = 0; }
+  __syncthreads();
   uint32_t mx = 0;
-  if (i < S.n) { uint32_t s = S.syms[i]; if (s < S.alpha_cap) atomicAdd(&S.freq[s], 1u); else J.status = -30; mx = s; }
+  for (uint32_t i = b0 + threadIdx.x; i < n && i < b0 + per_block; i += UVOL_BLOCK) {
+    const uint32_t s = S.syms[i];
+    if (s >= S.alpha_cap) { J.status = -30; continue; }
+    if (in_lds) atomicAdd(&lh[s], 1u); else atomicAdd(&S.freq[s], 1u);
+    mx = s > mx ? s : mx;
+  }
   for (int d = 32; d >= 1; d >>= 1) { uint32_t m2 = __shfl_xor(mx, d); mx = m2 > mx ? m2 : mx; }
   if ((threadIdx.x & 63) == 0 && mx) atomicMax(&S.max_sym, mx);
+  __syncthreads();
+  if (in_lds) for (uint32_t k = threadIdx.x; k < S.alpha_cap; k += UVOL_BLOCK) { const uint32_t v = lh[k]; if (v) atomicAdd(&S.freq[k], v); }
 }
 
 // RAnsSymbolEncoder::Create + table serialisation, one lane per stream
@@ -1092,7 +1148,8 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
   CARVE(J.opp, int32_t, nc + 3); CARVE(J.vert, int32_t, nc + 3); CARVE(J.ring, int32_t, nc + 3); CARVE(J.vopen, uint8_t, nc + 3);
   CARVE(J.vval, int32_t, nc + nfi + 3); CARVE(J.c2vm, int32_t, nc + 3);
   CARVE(J.proc, int32_t, nfi + 1); CARVE(J.initc, int32_t, nfi + 1); CARVE(J.stack, int32_t, nfi + 2);
-  for (int w = 0; w < 4; w++) CARVE(J.rec[w], int32_t, 8 * (nfi + 1));
+  for (int w = 0; w < 4; w++) { CARVE(J.rec[w], int32_t, 8 * (nfi + 1)); CARVE(J.vopen_d[w], uint8_t, nc + 3); }
+  CARVE(J.dflag, uint8_t, nc + 3); CARVE(J.dtmp, int32_t, nc + 3); CARVE(J.ring_d, int32_t, nc + 3);
   CARVE(J.symb, uint8_t, nfi + 64); CARVE(J.ctx_of, uint8_t, nfi + 64);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2); CARVE(J.ev_spl, int32_t, 2 * nfi + 2); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1);
@@ -1154,6 +1211,15 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s (lds %zu)\n", #k, (size_t)(shmem)); fflush(stderr); } \
     hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, __VA_ARGS__);                         \
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
+  } while (0)
+
+#define DENSE_TABLE(w)                                                               \
+  do {                                                                               \
+    LAUNCH(k_dense_flags, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));              \
+    LAUNCH(k_scan_blocks, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)SCAN_DENSE);       \
+    LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_DENSE);          \
+    LAUNCH(k_dense_assign, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));             \
+    LAUNCH(k_dense_apply, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));              \
   } while (0)
 
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
@@ -1241,11 +1307,12 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
-  const size_t walk_lds = (((size_t)max_nfi + 31) / 32 + ((size_t)3 * max_nfi + 31) / 32) * 4;
+  const size_t walk_lds = 2 * (((size_t)max_nfi + 31) / 32) * 4;      // nf face bits + nf vertex bits
   const bool use_lds = walk_lds <= G->max_lds;
   {
-    uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
+    DENSE_TABLE(0);
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
+    uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj); else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
@@ -1253,12 +1320,11 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_walk, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(G->aux, G->ev_walk, 0));
   {
-    uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence_ctx", 0, G->aux);
     LAUNCH_ON(G->aux, k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH_ON(G->aux, k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
     LAUNCH_ON(G->aux, k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
     LAUNCH_ON(G->aux, k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH_ON(G->aux, k_eb_valence, dim3(N), dim3(64), dj);
+    { uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence", 0, G->aux); LAUNCH_ON(G->aux, k_eb_valence, dim3(N), dim3(64), dj); }
     LAUNCH_ON(G->aux, k_eb_ctx, dim3(N), dim3(64), dj);
   }
   UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_val, G->aux));
@@ -1275,10 +1341,8 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 3);
   }
   {
+    for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 1);
-    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 2);
-    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 3);
     if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj); else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj);
   }
   {
@@ -1299,9 +1363,12 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   }
   UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
-    uvol_ctx::Scope sc(ctx, "geo.k7_entropy", 0);
-    LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
+    uvol_ctx::Scope sc0(ctx, "geo.k7_hist_tables", 0);
+    LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi, 16 * UVOL_BLOCK), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_rans_tables, dim3(GEO_NSTREAM, N), dim3(64), dj);
+  }
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k7_entropy_encode", 0);
     LAUNCH_SM(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), (size_t)RANS_LDS_ENTRIES * sizeof(uint2), dj);
   }
   {

@@ -1066,7 +1066,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     TLAUNCH(k_sscan_b, dim3(J.L), dim3(UVOL_BLOCK), 0, dj, bnm);
     TLAUNCH(k_mb_groups, dim3(bnm, J.L), dim3(UVOL_BLOCK), 0, dj, nm);
     TLAUNCH(k_mb_tokens, dim3(bnm, J.L), dim3(UVOL_BLOCK), 0, dj, nm);
-    TLAUNCH(k_sel_tokens, dim3(J.L), dim3(64), 0, dj);
+    { uvol_ctx::Scope sc2(ctx, "tex.k12_sel_tokens", (uint64_t)J.NB * 6 * n_seg); TLAUNCH(k_sel_tokens, dim3(J.L), dim3(64), 0, dj); }
     const size_t lh_bytes = (size_t)(257 + J.Kmax_e + J.Kmax_s + TEX_HS + 1 + 64) * 4;
     if (lh_bytes > 60 * 1024) { ctx->set_error("etc1s_quality too high for the LDS histogram (codebooks > 60 KiB)"); return UVOL_E_UNSUPPORTED; }
     TLAUNCH(k_tok_hist, dim3(std::min<unsigned>(uvol_blocks((size_t)3 * J.NB), 1024u)), dim3(UVOL_BLOCK), lh_bytes, dj);
