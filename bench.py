@@ -120,14 +120,11 @@ def main():
     for _ in range(args.steps):
         step()
     # manifest gather: {frames, segments, layers in last segment, bytes} per rank
+    import shard
     nbytes = sum(len(x) for x in out["drc"]) + sum(len(x) for x in out["ktx2"])
-    mine = torch.tensor([F * args.steps, nseg * args.steps, B, nbytes], dtype=torch.int64, device=dev)
-    if world > 1:
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        total_frames = int(sum(int(x[0]) for x in allr))
-    else:
-        total_frames = int(mine[0])
+    table = shard.gather_counts(F * args.steps, nseg * args.steps, B, nbytes, device=dev)      # RCCL all_gather when world > 1
+    total_frames, total_segs, total_tex_frames, _ = shard.totals(table, B)
+    assert total_frames == total_tex_frames                                                   # check_total_frames (Encoder.py:135)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

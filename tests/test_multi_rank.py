@@ -1,0 +1,44 @@
+"""N>1 path on CPU: world size 2 over gloo — shard plan, the manifest all_gather, and rank 0's accounting."""
+import os
+import sys
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from conftest import ROOT
+
+
+def _worker(rank, world, port, n_frames, batch, q):
+    sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
+    import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f0, nf, s0, ns = shard.plan(n_frames, batch, world, rank)
+    last_layers = min(batch, n_frames - (s0 + ns - 1) * batch) if ns else 0
+    table = shard.gather_counts(nf, ns, last_layers, 1000 * nf, device=None)
+    if rank == 0:
+        q.put((table.tolist(), shard.totals(table, batch)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(1200, 5), (23, 5), (7, 7)])
+def test_two_rank_gather_and_accounting(n_frames, batch):
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = 29500 + (n_frames % 200)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, batch, q)) for r in range(2)]
+    [p.start() for p in ps]; table, tot = q.get(timeout=120); [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    n_seg = (n_frames + batch - 1) // batch
+    assert tot[0] == n_frames and tot[1] == n_seg and tot[2] == n_frames          # geometry frames == texture frames
+    assert sum(r[0] for r in table) == n_frames and all(r[0] <= r[1] * batch for r in table)
+
+
+def test_plan_is_segment_aligned_and_contiguous():
+    sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
+    import shard
+    for n, b, w in [(1200, 5, 8), (300, 5, 4), (13, 5, 8), (10, 7, 3)]:
+        nxt = 0; segs = 0
+        for r in range(w):
+            f0, nf, s0, ns = shard.plan(n, b, w, r)
+            assert f0 == nxt and f0 % b == 0 or nf == 0
+            nxt = f0 + nf if nf else nxt; segs += ns
+        assert nxt == n and segs == (n + b - 1) // b
