@@ -279,71 +279,115 @@ __device__ __forceinline__ int sel3(const int a[3], int k) { return k == 0 ? a[0
 __device__ __forceinline__ bool bit_get(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(uint32_t *w, int i) { w[i >> 5] |= 1u << (i & 31); }
 
+// Walker LDS layout: [face bits fw words][vertex bits fw words][WALK_LINES tags][pad][WALK_LINES x 64 records of 32 B].
+// The record cache is direct-mapped on groups of 64 consecutive faces; a miss is filled by the WHOLE wave with one
+// coalesced 2 KiB read (lane k fetches face 64*g + k), so the otherwise idle 63 lanes turn the walker's dependent
+// 32-byte HBM reads into LDS hits whenever the traversal stays inside recently touched face neighbourhoods.
+#define WALK_LINES 32
+struct WalkLds { uint32_t *fbits, *vbits, *gtag; int4 *cdata; };
+__device__ __forceinline__ size_t walk_lds_words(uint32_t fw) { return ((size_t)2 * fw + WALK_LINES + 3) & ~(size_t)3; }
+__device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw) {
+  WalkLds w; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + 2 * fw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw)); return w;
+}
+template <bool LDS>
+__device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, const WalkLds &W, uint32_t lane) {
+  if (!LDS) return load_rec(rec, f);
+  const uint32_t g = (uint32_t)f >> 6, line = g & (WALK_LINES - 1);
+  if (UVOL_READLANE(W.gtag[line], 0) != g + 1) {    // wave-uniform miss (lane 0's view of the tag): every lane fetches one record of the group
+    const int ff = (int)(g << 6) + (int)lane;
+    if (ff < nf) { const int4 *p = reinterpret_cast<const int4 *>(rec + 8 * (size_t)ff); const int4 a = p[0], b = p[1]; W.cdata[(line * 64 + lane) * 2] = a; W.cdata[(line * 64 + lane) * 2 + 1] = b; }
+    if (lane == 0) W.gtag[line] = g + 1;
+    __syncthreads();
+  }
+  const int4 a = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2], b = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2 + 1];
+  FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
+}
+// Lane 0 is the only reader/writer of the visited bitmaps and of the cache tags; its view is broadcast with v_readlane
+// so that all 64 lanes follow the same control flow without relying on lock-step LDS read-modify-write races.
+__device__ __forceinline__ bool ubit_get(const uint32_t *w, int i) { return UVOL_READLANE((uint32_t)bit_get(w, i), 0) != 0; }
+__device__ __forceinline__ void ubit_set(uint32_t *w, int i, uint32_t lane) { if (lane == 0) bit_set(w, i); }
+// lane 0 owns the explicit DFS stack in global memory; values are broadcast so that control flow stays wave-uniform
+__device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
+
 template <bool LDS>
 __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_DYN_SMEM(uint32_t, lds);
-  const int nf = (int)J.nf, nc = (int)J.nc;
+  const uint32_t lane = threadIdx.x;
+  const int nf = (int)J.nf;
   const bool ok = J.status == 0;
   // LDS holds nf face bits + up to nf vertex bits (vertices are densely numbered; a table with more vertices than
-  // faces keeps its vertex bitmap in global memory instead)
-  const uint32_t fw = ((uint32_t)nf + 31) / 32, vcap = fw, vw = (J.nverts_t[0] + 31) / 32;
-  const bool v_in_lds = LDS && vw <= vcap;
-  uint32_t *fbits = LDS ? lds : reinterpret_cast<uint32_t *>(J.fvis);
-  uint32_t *vbits = v_in_lds ? lds + fw : reinterpret_cast<uint32_t *>(J.vvis);
-  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + (v_in_lds ? vw : 0); k += 64) lds[k] = 0; __syncthreads(); }
-  if (threadIdx.x != 0 || !ok) return;
-  (void)nc;
+  // faces keeps its vertex bitmap in global memory instead) + the record cache
+  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32;
+  const bool v_in_lds = LDS && vw <= fw;
+  WalkLds W = walk_lds_carve(lds, fw);
+  uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.fvis);
+  uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
+  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + WALK_LINES; k += 64) lds[k] = 0; __syncthreads(); }
+  if (!ok) return;
   const int32_t *rec = J.rec[0];
   int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
+  // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
   for (int f0 = 0; f0 < nf; f0++) {
-    if (bit_get(fbits, f0)) continue;
-    const FaceRec r0 = load_rec(rec, f0);
+    if (ubit_get(fbits, f0)) continue;
+    const FaceRec r0 = walk_rec<LDS>(rec, f0, nf, W, lane);
     int interior = 1, start_corner = 3 * f0;
     for (int k = 0; k < 3; k++) {
       if (r0.o[k] < 0) { interior = 0; start_corner = 3 * f0 + k; break; }
       if (r0.v[k] & 1) {              // boundary vertex: swing right to the boundary edge
         int ci = 3 * f0 + k, rc = ci;
-        while (rc >= 0) { ci = rc; const FaceRec rr = load_rec(rec, rc / 3); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
+        while (rc >= 0) { ci = rc; const FaceRec rr = walk_rec<LDS>(rec, rc / 3, nf, W, lane); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
         interior = 0; start_corner = g_prv(ci); break;
       }
     }
-    J.start_bits[nstart++] = (uint8_t)interior;
+    if (lane == 0) J.start_bits[nstart] = (uint8_t)interior;
+    nstart++;
     int from;
     if (interior) {
-      bit_set(vbits, r0.v[0] >> 1); bit_set(vbits, r0.v[1] >> 1); bit_set(vbits, r0.v[2] >> 1);
-      bit_set(fbits, f0); ftime[f0] = -1;
-      J.initc[ninit++] = 3 * f0 + 1;
+      ubit_set(vbits, r0.v[0] >> 1, lane); ubit_set(vbits, r0.v[1] >> 1, lane); ubit_set(vbits, r0.v[2] >> 1, lane);
+      ubit_set(fbits, f0, lane);
+      if (lane == 0) { ftime[f0] = -1; J.initc[ninit] = 3 * f0 + 1; }
+      ninit++;
       from = r0.o[1];
-      if (from < 0 || bit_get(fbits, from / 3)) continue;
+      if (from < 0 || ubit_get(fbits, from / 3)) continue;
     } else from = start_corner;
-    int sp = 0; stack[sp++] = from;
+    int sp = 0;
+    if (lane == 0) stack[sp] = from;
+    sp++;
+    int top = from;                                   // value at stack[sp-1] when known without a load
+    bool top_known = true;
     while (sp > 0) {
-      int corner = stack[sp - 1];
-      if (corner < 0 || bit_get(fbits, corner / 3)) { sp--; continue; }
+      int corner = top_known ? top : walk_stack_top(stack, sp, lane);
+      top_known = false;
+      if (corner < 0 || ubit_get(fbits, corner / 3)) { sp--; continue; }
       for (;;) {
         const int face = corner / 3, k = corner - 3 * face;
-        const FaceRec r = load_rec(rec, face);
-        bit_set(fbits, face);
+        const FaceRec r = walk_rec<LDS>(rec, face, nf, W, lane);
+        ubit_set(fbits, face, lane);
         const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
-        proc[nproc] = corner; ftime[face] = nproc;
+        if (lane == 0) { proc[nproc] = corner; ftime[face] = nproc; }
         int sym;
         const int v = vi >> 1;
         bool fresh_interior = false;
-        if (!bit_get(vbits, v)) { bit_set(vbits, v); fresh_interior = !(vi & 1); }
-        if (fresh_interior) { symb[nproc++] = T_C; corner = rcn; continue; }
-        const bool rvis = rcn < 0 ? true : bit_get(fbits, rcn / 3), lvis = lcn < 0 ? true : bit_get(fbits, lcn / 3);
+        if (!ubit_get(vbits, v)) { ubit_set(vbits, v, lane); fresh_interior = !(vi & 1); }
+        if (fresh_interior) { if (lane == 0) symb[nproc] = T_C; nproc++; corner = rcn; continue; }
+        const bool rvis = rcn < 0 ? true : ubit_get(fbits, rcn / 3), lvis = lcn < 0 ? true : ubit_get(fbits, lcn / 3);
         if (rvis) { if (lvis) { sym = T_E; } else { sym = T_R; } } else { sym = lvis ? T_L : T_S; }
-        symb[nproc++] = (uint8_t)sym;
+        if (lane == 0) symb[nproc] = (uint8_t)sym;
+        nproc++;
         if (sym == T_E) { sp--; break; }
         if (sym == T_R) { corner = lcn; continue; }
         if (sym == T_L) { corner = rcn; continue; }
-        nsplit++; stack[sp - 1] = lcn; stack[sp++] = rcn; break;
+        nsplit++;
+        if (lane == 0) { stack[sp - 1] = lcn; stack[sp] = rcn; }
+        sp++; top = rcn; top_known = true;
+        break;
       }
     }
   }
+  if (lane != 0) return;
   J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
   if (nproc + ninit != nf) J.status = -10;
   J.rb[0].n = (uint32_t)nstart;
@@ -517,48 +561,53 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
   UVOL_DYN_SMEM(uint32_t, lds);
+  const uint32_t lane = threadIdx.x;
   const int ai = t > 0 ? t - 1 : 0;
   const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
-  const int nf = (int)J.nf, nc = (int)J.nc;
-  const uint32_t fw = ((uint32_t)nf + 31) / 32, vcap = fw, vw = (J.nverts_t[1 + t] + 31) / 32;
-  const bool v_in_lds = LDS && vw <= vcap;
-  uint32_t *fbits = LDS ? lds : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
-  uint32_t *vbits = v_in_lds ? lds + fw : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
-  if (LDS) { if (ok) for (uint32_t k = threadIdx.x; k < fw + (v_in_lds ? vw : 0); k += 64) lds[k] = 0; __syncthreads(); }
-  (void)nc;
-  if (threadIdx.x != 0 || !ok) return;
+  const int nf = (int)J.nf;
+  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32;
+  const bool v_in_lds = LDS && vw <= fw;
+  WalkLds W = walk_lds_carve(lds, fw);
+  uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
+  uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
+  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + WALK_LINES; k += 64) lds[k] = 0; __syncthreads(); }
+  if (!ok) return;
   const int32_t *rec = J.rec[1 + t];
   int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
   int n = 0;
-#define T_VISIT(vid, c) do { bit_set(vbits, (vid)); v2d[(vid)] = n; order[n++] = (c); } while (0)
-#define T_FVIS(c) ((c) < 0 ? true : bit_get(fbits, (c) / 3))
+#define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) { v2d[(vid)] = n; order[n] = (c); } n++; } while (0)
+#define T_FVIS(c) ((c) < 0 ? true : ubit_get(fbits, (c) / 3))
   for (int f = 0; f < nf; f++) {
-    if (bit_get(fbits, f)) continue;
+    if (ubit_get(fbits, f)) continue;
     int cid = 3 * f, sp = 0;
-    stack[sp++] = cid;
-    { const FaceRec r0 = load_rec(rec, f); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
-      if (!bit_get(vbits, vn)) T_VISIT(vn, cid + 1);
-      if (!bit_get(vbits, vp)) T_VISIT(vp, cid + 2); }
+    if (lane == 0) stack[sp] = cid;
+    sp++;
+    int top = cid; bool top_known = true;
+    { const FaceRec r0 = walk_rec<LDS>(rec, f, nf, W, lane); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
+      if (!ubit_get(vbits, vn)) T_VISIT(vn, cid + 1);
+      if (!ubit_get(vbits, vp)) T_VISIT(vp, cid + 2); }
     while (sp > 0) {
-      cid = stack[sp - 1];
-      if (cid < 0 || bit_get(fbits, cid / 3)) { sp--; continue; }
+      cid = top_known ? top : walk_stack_top(stack, sp, lane);
+      top_known = false;
+      if (cid < 0 || ubit_get(fbits, cid / 3)) { sp--; continue; }
       for (;;) {
         const int face = cid / 3, k = cid - 3 * face;
-        const FaceRec r = load_rec(rec, face);
-        bit_set(fbits, face);
+        const FaceRec r = walk_rec<LDS>(rec, face, nf, W, lane);
+        ubit_set(fbits, face, lane);
         const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
         const int v = vi >> 1;
-        if (!bit_get(vbits, v)) {
+        if (!ubit_get(vbits, v)) {
           T_VISIT(v, cid);
           if (!(vi & 1)) { cid = rc; continue; }
         }
         if (T_FVIS(rc)) { if (T_FVIS(lc)) { sp--; break; } cid = lc; }
-        else { if (T_FVIS(lc)) cid = rc; else { stack[sp - 1] = lc; stack[sp++] = rc; break; } }
+        else { if (T_FVIS(lc)) cid = rc; else { if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; } sp++; top = rc; top_known = true; break; } }
       }
     }
   }
 #undef T_VISIT
 #undef T_FVIS
+  if (lane != 0) return;
   J.ne[t] = (uint32_t)n;
   if (t == 0 && (uint32_t)n != J.nverts) J.status = -11;
 }
@@ -1307,7 +1356,8 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
-  const size_t walk_lds = 2 * (((size_t)max_nfi + 31) / 32) * 4;      // nf face bits + nf vertex bits
+  const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
+  const size_t walk_lds = (((size_t)2 * walk_fw + WALK_LINES + 3) & ~(size_t)3) * 4 + (size_t)WALK_LINES * 64 * 32;      // bitmaps + tags + record cache
   const bool use_lds = walk_lds <= G->max_lds;
   {
     DENSE_TABLE(0);
