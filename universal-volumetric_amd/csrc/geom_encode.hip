@@ -289,9 +289,9 @@ __device__ __forceinline__ size_t walk_lds_words(uint32_t fw) { return ((size_t)
 __device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw) {
   WalkLds w; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + 2 * fw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw)); return w;
 }
-template <bool LDS>
+template <bool CACHE>
 __device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, const WalkLds &W, uint32_t lane) {
-  if (!LDS) return load_rec(rec, f);
+  if (!CACHE) return load_rec(rec, f);
   const uint32_t g = (uint32_t)f >> 6, line = g & (WALK_LINES - 1);
   if (UVOL_READLANE(W.gtag[line], 0) != g + 1) {    // wave-uniform miss (lane 0's view of the tag): every lane fetches one record of the group
     const int ff = (int)(g << 6) + (int)lane;
@@ -309,9 +309,10 @@ __device__ __forceinline__ void ubit_set(uint32_t *w, int i, uint32_t lane) { if
 // lane 0 owns the explicit DFS stack in global memory; values are broadcast so that control flow stays wave-uniform
 __device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
 
-template <bool LDS>
+template <bool LDS, bool CACHE>
 __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
+  UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
   const uint32_t lane = threadIdx.x;
   const int nf = (int)J.nf;
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   WalkLds W = walk_lds_carve(lds, fw);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.fvis);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
-  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + WALK_LINES; k += 64) lds[k] = 0; __syncthreads(); }
+  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok) return;
   const int32_t *rec = J.rec[0];
   int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
@@ -332,13 +333,13 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
   for (int f0 = 0; f0 < nf; f0++) {
     if (ubit_get(fbits, f0)) continue;
-    const FaceRec r0 = walk_rec<LDS>(rec, f0, nf, W, lane);
+    const FaceRec r0 = walk_rec<CACHE>(rec, f0, nf, W, lane);
     int interior = 1, start_corner = 3 * f0;
     for (int k = 0; k < 3; k++) {
       if (r0.o[k] < 0) { interior = 0; start_corner = 3 * f0 + k; break; }
       if (r0.v[k] & 1) {              // boundary vertex: swing right to the boundary edge
         int ci = 3 * f0 + k, rc = ci;
-        while (rc >= 0) { ci = rc; const FaceRec rr = walk_rec<LDS>(rec, rc / 3, nf, W, lane); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
+        while (rc >= 0) { ci = rc; const FaceRec rr = walk_rec<CACHE>(rec, rc / 3, nf, W, lane); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
         interior = 0; start_corner = g_prv(ci); break;
       }
     }
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
       if (corner < 0 || ubit_get(fbits, corner / 3)) { sp--; continue; }
       for (;;) {
         const int face = corner / 3, k = corner - 3 * face;
-        const FaceRec r = walk_rec<LDS>(rec, face, nf, W, lane);
+        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
         ubit_set(fbits, face, lane);
         const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
         if (lane == 0) { proc[nproc] = corner; ftime[face] = nproc; }
@@ -429,6 +430,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
 // valence bookkeeping replay: ctx_of[i] = context (0..5) under which symbol i-1 is coded (i >= 1)
 __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
+  UVOL_SERIAL_PRIO();
   const uint32_t lane = threadIdx.x;
   const bool ok = J.status == 0;
   const int nsym = ok ? J.nsym : 0, nc = (int)J.nc;
@@ -484,6 +486,7 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
 // symbols -> the six valence-context streams, in symbol order (wave ballots give each symbol its slot)
 __global__ void __launch_bounds__(64) k_eb_ctx(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
+  UVOL_SERIAL_PRIO();
   const uint32_t lane = threadIdx.x;
   const int nsym = J.status == 0 ? J.nsym : 0;
   uint32_t base_c[6] = {0, 0, 0, 0, 0, 0};
@@ -556,10 +559,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 // K5: DepthFirstTraverser — serial per (table, frame).  t=0 base table, t=1,2 attribute tables.
 // One 32-byte record load per face; visited faces / vertices are bitmaps in LDS.
 // ------------------------------------------------------------------------------------------------
-template <bool LDS>
+template <bool LDS, bool CACHE>
 __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
+  UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
   const uint32_t lane = threadIdx.x;
   const int ai = t > 0 ? t - 1 : 0;
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   WalkLds W = walk_lds_carve(lds, fw);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
-  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + WALK_LINES; k += 64) lds[k] = 0; __syncthreads(); }
+  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok) return;
   const int32_t *rec = J.rec[1 + t];
   int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
@@ -583,7 +587,7 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
     if (lane == 0) stack[sp] = cid;
     sp++;
     int top = cid; bool top_known = true;
-    { const FaceRec r0 = walk_rec<LDS>(rec, f, nf, W, lane); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
+    { const FaceRec r0 = walk_rec<CACHE>(rec, f, nf, W, lane); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
       if (!ubit_get(vbits, vn)) T_VISIT(vn, cid + 1);
       if (!ubit_get(vbits, vp)) T_VISIT(vp, cid + 2); }
     while (sp > 0) {
@@ -592,7 +596,7 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
       if (cid < 0 || ubit_get(fbits, cid / 3)) { sp--; continue; }
       for (;;) {
         const int face = cid / 3, k = cid - 3 * face;
-        const FaceRec r = walk_rec<LDS>(rec, face, nf, W, lane);
+        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
         ubit_set(fbits, face, lane);
         const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
         const int v = vi >> 1;
@@ -869,6 +873,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_hist(GeoJob *jobs) {
 // RAnsSymbolEncoder::Create + table serialisation, one lane per stream
 __global__ void __launch_bounds__(64) k_rans_tables(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
+  UVOL_SERIAL_PRIO();
   RansStream &S = J.rs[blockIdx.x];
   if (threadIdx.x != 0 || J.status != 0 || S.n == 0) return;
   const uint32_t ns = S.max_sym + 1;
@@ -935,6 +940,7 @@ __global__ void __launch_bounds__(64) k_rans_tables(GeoJob *jobs) {
 #define RANS_LDS_ENTRIES 6144
 __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
+  UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint2, tab);
   const uint32_t lane = threadIdx.x;
   const bool ok = J.status == 0;
@@ -1135,8 +1141,10 @@ int geo_create(uvol_ctx *ctx) {
   int v = 0;
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->geo->max_lds = (size_t)v;
   const size_t want = ctx->geo->max_lds;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   (void)hipGetLastError();
 #else
   ctx->geo->max_lds = 160 * 1024;
@@ -1357,13 +1365,19 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
   const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
-  const size_t walk_lds = (((size_t)2 * walk_fw + WALK_LINES + 3) & ~(size_t)3) * 4 + (size_t)WALK_LINES * 64 * 32;      // bitmaps + tags + record cache
+  const size_t walk_lds = (((size_t)2 * walk_fw + WALK_LINES + 3) & ~(size_t)3) * 4;          // bitmaps (+ tag words)
+  const size_t walk_lds_c = walk_lds + (size_t)WALK_LINES * 64 * 32;                              // + record cache
   const bool use_lds = walk_lds <= G->max_lds;
+  // the record cache costs 64 KiB of LDS per walker: only worth it while every walker can still have a CU of its own
+  static const int cache_env = [] { const char *e = getenv("UVOL_WALK_CACHE"); return e ? atoi(e) : -1; }();
+  const bool use_cache = walk_lds_c <= G->max_lds && (cache_env >= 0 ? cache_env != 0 : 3 * n <= 256);
   {
     DENSE_TABLE(0);
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj); else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj);
+    if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj);
+    else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj);
+    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
   // renumber / seams / fans / DFS traversal on the main stream; joined again before the entropy stage.
@@ -1393,7 +1407,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj); else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj);
+    if (use_cache) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj);
+    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj);
+    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);

@@ -583,6 +583,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_mb_tokens(TexJob *job, uint32_t 
 // lane reads); the coded blocks are prefetched 64 at a time; tokens are collected per lane and stored coalesced.
 __global__ void __launch_bounds__(64) k_sel_tokens(TexJob *job) {
   TexJob &J = job[blockIdx.z];
+  UVOL_SERIAL_PRIO();
   const uint32_t l = blockIdx.x, lane = threadIdx.x;
   const bool ok = J.status == 0;
   const uint32_t n = ok ? J.ncoded[l] : 0, ns = J.ns;

@@ -20,6 +20,13 @@
 #define UVOL_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
 #endif
 
+// the one-wave serial walkers are latency-bound: give them issue priority over co-resident throughput kernels
+#ifdef HIPEMU
+#define UVOL_SERIAL_PRIO() do { } while (0)
+#else
+#define UVOL_SERIAL_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 // dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
 #ifdef HIPEMU
 #define UVOL_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu_dyn_smem)
