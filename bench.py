@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=80)
+    ap.add_argument("--frames-per-step", type=int, default=240)
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,12 +91,17 @@ def main():
     batch = (uvol.Mesh * F)(*[dev_meshes[i % args.distinct] for i in range(F)])
     out = {}
 
+    host_frames = [meshes_h[i % args.distinct] for i in range(F)]
+
     def run_geo():
-        out["drc"] = geo.encode_mesh_batch_dev(batch)
+        out["drc"] = geo.encode_mesh_batch(host_frames) if args.host_inputs else geo.encode_mesh_batch_dev(batch)
 
     def run_tex(ti):
         mine = len(range(ti, nseg, len(texs)))            # segments of this step handled by texture context ti, ONE batched call
-        out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
+        if args.host_inputs:
+            out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([tex_h] * mine) if mine else []
+        else:
+            out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
 
     def step():
         th = [threading.Thread(target=run_geo)] + [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs))]
@@ -152,13 +158,13 @@ def main():
             "metric": "frames/s encode, 100k-vert mesh + 2048^2 texture",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic",
+            "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
                                    "%d frames per step, qp11/qt10/qn8/cl7" % (V, Fc, args.tex_size, args.tex_size, B, F),
                        "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU 1 geometry stream + %d texture streams" % len(texs),
                        "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "units_per_launch": units,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], units), "avg_launch_ms": avg_ms, "units_per_launch": units,
                          "algorithmic_bytes_per_frame": algo_per_frame,
                          "end_to_end_achieved": algo_per_frame * total_frames / world / dt / 1e9},
             "kernel_groups_ms_per_step": {g["name"]: g["total_ms"] / args.steps for g in groups},
@@ -171,6 +177,17 @@ def main():
         t.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(group, units):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are
+    collected in their own runs, profiles/r01_pmc_traffic.json records the per-frame figure and how it was corrected)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        e = t["kernels"].get(group)
+        return None if e is None else e["hbm_bytes_per_frame"] * units
+    except Exception:
+        return None
 
 
 def cpu_baseline(mesh, tex, B):

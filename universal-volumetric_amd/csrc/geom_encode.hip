@@ -304,10 +304,11 @@ __device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, c
 }
 // Lane 0 is the only reader/writer of the visited bitmaps and of the cache tags; its view is broadcast with v_readlane
 // so that all 64 lanes follow the same control flow without relying on lock-step LDS read-modify-write races.
-__device__ __forceinline__ bool ubit_get(const uint32_t *w, int i) { return UVOL_READLANE((uint32_t)bit_get(w, i), 0) != 0; }
+// (UNI = false: only lane 0 is alive — the plain lane-0 walker used when the record cache is off)
+template <bool UNI> __device__ __forceinline__ bool ubit_get(const uint32_t *w, int i) { if (!UNI) return bit_get(w, i); return UVOL_READLANE((uint32_t)bit_get(w, i), 0) != 0; }
 __device__ __forceinline__ void ubit_set(uint32_t *w, int i, uint32_t lane) { if (lane == 0) bit_set(w, i); }
 // lane 0 owns the explicit DFS stack in global memory; values are broadcast so that control flow stays wave-uniform
-__device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
+template <bool UNI> __device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { if (!UNI) return stack[sp - 1]; int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
 
 template <bool LDS, bool CACHE>
 __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
@@ -325,14 +326,14 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.fvis);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
   if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
-  if (!ok) return;
+  if (!ok || (!CACHE && lane != 0)) return;       // without the cache the 63 helper lanes have nothing to do
   const int32_t *rec = J.rec[0];
   int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
   for (int f0 = 0; f0 < nf; f0++) {
-    if (ubit_get(fbits, f0)) continue;
+    if (ubit_get<CACHE>(fbits, f0)) continue;
     const FaceRec r0 = walk_rec<CACHE>(rec, f0, nf, W, lane);
     int interior = 1, start_corner = 3 * f0;
     for (int k = 0; k < 3; k++) {
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
       if (lane == 0) { ftime[f0] = -1; J.initc[ninit] = 3 * f0 + 1; }
       ninit++;
       from = r0.o[1];
-      if (from < 0 || ubit_get(fbits, from / 3)) continue;
+      if (from < 0 || ubit_get<CACHE>(fbits, from / 3)) continue;
     } else from = start_corner;
     int sp = 0;
     if (lane == 0) stack[sp] = from;
@@ -360,9 +361,9 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
     int top = from;                                   // value at stack[sp-1] when known without a load
     bool top_known = true;
     while (sp > 0) {
-      int corner = top_known ? top : walk_stack_top(stack, sp, lane);
+      int corner = top_known ? top : walk_stack_top<CACHE>(stack, sp, lane);
       top_known = false;
-      if (corner < 0 || ubit_get(fbits, corner / 3)) { sp--; continue; }
+      if (corner < 0 || ubit_get<CACHE>(fbits, corner / 3)) { sp--; continue; }
       for (;;) {
         const int face = corner / 3, k = corner - 3 * face;
         const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
@@ -372,9 +373,9 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
         int sym;
         const int v = vi >> 1;
         bool fresh_interior = false;
-        if (!ubit_get(vbits, v)) { ubit_set(vbits, v, lane); fresh_interior = !(vi & 1); }
+        if (!ubit_get<CACHE>(vbits, v)) { ubit_set(vbits, v, lane); fresh_interior = !(vi & 1); }
         if (fresh_interior) { if (lane == 0) symb[nproc] = T_C; nproc++; corner = rcn; continue; }
-        const bool rvis = rcn < 0 ? true : ubit_get(fbits, rcn / 3), lvis = lcn < 0 ? true : ubit_get(fbits, lcn / 3);
+        const bool rvis = rcn < 0 ? true : ubit_get<CACHE>(fbits, rcn / 3), lvis = lcn < 0 ? true : ubit_get<CACHE>(fbits, lcn / 3);
         if (rvis) { if (lvis) { sym = T_E; } else { sym = T_R; } } else { sym = lvis ? T_L : T_S; }
         if (lane == 0) symb[nproc] = (uint8_t)sym;
         nproc++;
@@ -575,32 +576,32 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
   if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
-  if (!ok) return;
+  if (!ok || (!CACHE && lane != 0)) return;
   const int32_t *rec = J.rec[1 + t];
   int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
   int n = 0;
 #define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) { v2d[(vid)] = n; order[n] = (c); } n++; } while (0)
-#define T_FVIS(c) ((c) < 0 ? true : ubit_get(fbits, (c) / 3))
+#define T_FVIS(c) ((c) < 0 ? true : ubit_get<CACHE>(fbits, (c) / 3))
   for (int f = 0; f < nf; f++) {
-    if (ubit_get(fbits, f)) continue;
+    if (ubit_get<CACHE>(fbits, f)) continue;
     int cid = 3 * f, sp = 0;
     if (lane == 0) stack[sp] = cid;
     sp++;
     int top = cid; bool top_known = true;
     { const FaceRec r0 = walk_rec<CACHE>(rec, f, nf, W, lane); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
-      if (!ubit_get(vbits, vn)) T_VISIT(vn, cid + 1);
-      if (!ubit_get(vbits, vp)) T_VISIT(vp, cid + 2); }
+      if (!ubit_get<CACHE>(vbits, vn)) T_VISIT(vn, cid + 1);
+      if (!ubit_get<CACHE>(vbits, vp)) T_VISIT(vp, cid + 2); }
     while (sp > 0) {
-      cid = top_known ? top : walk_stack_top(stack, sp, lane);
+      cid = top_known ? top : walk_stack_top<CACHE>(stack, sp, lane);
       top_known = false;
-      if (cid < 0 || ubit_get(fbits, cid / 3)) { sp--; continue; }
+      if (cid < 0 || ubit_get<CACHE>(fbits, cid / 3)) { sp--; continue; }
       for (;;) {
         const int face = cid / 3, k = cid - 3 * face;
         const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
         ubit_set(fbits, face, lane);
         const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
         const int v = vi >> 1;
-        if (!ubit_get(vbits, v)) {
+        if (!ubit_get<CACHE>(vbits, v)) {
           T_VISIT(v, cid);
           if (!(vi & 1)) { cid = rc; continue; }
         }
