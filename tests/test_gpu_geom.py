@@ -69,3 +69,27 @@ def test_gpu_error_isolation(gpu_codec):
     bad = dict(pos=pos, idx_pos=np.array([0, 1, 7], np.uint32))
     res = gpu_codec.encode_mesh_batch([bad, good], raise_on_error=False)
     assert res[0] is None and res[1] is not None and res[1][:5] == b"DRACO"
+
+
+def test_gpu_edge_cases_and_quantisation_bits(oracle, gpu_codec):
+    import synth, uvol
+    cases = list(synth.edge_case_meshes().values())
+    for f, r in zip(cases, gpu_codec.encode_mesh_batch(cases)):
+        assert r == _oracle_bytes(oracle, f)
+    m = synth.torus_mesh(16, 8)
+    for qp, qt, qn in [(14, 12, 10), (8, 8, 6), (16, 16, 12)]:
+        c2 = uvol.Codec(device=0, Q_POSITION_ATTR=qp, Q_TEXTURE_ATTR=qt, Q_NORMAL_ATTR=qn)
+        assert c2.encode_mesh(**m) == oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=qp, qt=qt, qn=qn)
+        c2.close()
+
+
+def test_gpu_both_walker_variants(oracle, monkeypatch):
+    """The serial walkers have two forms (64 lanes + LDS record cache / lane 0 only); both must be bit-exact."""
+    import synth, uvol
+    frames = [synth.torus_mesh(16, 8), synth.sphere_mesh(120, 61, charts=(12, 6), frame=3), synth.grid_mesh()]
+    for v in ("1", "0"):
+        monkeypatch.setenv("UVOL_WALK_CACHE", v)
+        c = uvol.Codec(device=0)
+        for f, r in zip(frames, c.encode_mesh_batch(frames)):
+            assert r == _oracle_bytes(oracle, f)
+        c.close()

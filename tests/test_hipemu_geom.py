@@ -39,3 +39,17 @@ def test_hipemu_error_paths(hipemu_lib):
     with pytest.raises(uvol.UvolError):
         uvol.Codec(lib_path=hipemu_lib, DRACO_COMPRESSION_LEVEL=3).encode_mesh(**good)
     cd.close()
+
+
+def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    cases = list(synth.edge_case_meshes().values())
+    for f, r in zip(cases, cd.encode_mesh_batch(cases)):
+        assert r == oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"))
+    cd.close()
+    m = synth.torus_mesh(16, 8)
+    for qp, qt, qn in [(14, 12, 10), (8, 8, 6)]:
+        c2 = uvol.Codec(lib_path=hipemu_lib, Q_POSITION_ATTR=qp, Q_TEXTURE_ATTR=qt, Q_NORMAL_ATTR=qn)
+        assert c2.encode_mesh(**m) == oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=qp, qt=qt, qn=qn)
+        c2.close()

@@ -126,3 +126,20 @@ def test_encoder_on_reference_geometry(oracle, name):
     d = check_roundtrip(oracle, mesh, e)
     assert (d.nf, d.nev) == (m.nf, m.nev)
     assert abs(len(e) - len(b)) < 0.01 * len(b)
+
+
+def test_encoder_edge_case_meshes(oracle):
+    """Non-manifold edges / vertices, flipped and duplicate faces, several components, open boundary: valid streams that decode to the input."""
+    import synth
+    for name, m in synth.edge_case_meshes().items():
+        e = oracle.drc_encode(m["pos"], m["idx_pos"], m.get("uv"), m.get("idx_uv"), m.get("nrm"), m.get("idx_nrm"))
+        check_roundtrip(oracle, m, e)
+
+
+@pytest.mark.parametrize("qp,qt,qn", [(14, 12, 10), (8, 8, 6), (16, 16, 12)])
+def test_encoder_other_quantisation_bits(oracle, qp, qt, qn):
+    import synth
+    m = synth.torus_mesh(16, 8)
+    e = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=qp, qt=qt, qn=qn)
+    d = check_roundtrip(oracle, m, e, qp=qp, qt=qt)
+    assert [a["qbits"] for a in d.atts] == [qp, qt, qn]

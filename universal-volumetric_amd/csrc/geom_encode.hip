@@ -478,6 +478,7 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
       if (sym == 1) { nvval++; remapped = true; }
       if (remapped) {               // wave-uniform: refresh the not-yet-consumed vertex ids of this chunk
         __threadfence_block();
+        UVOL_WAVE_SYNC();
         if (mi < nsym && (int)lane > j) { va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
       }
     }

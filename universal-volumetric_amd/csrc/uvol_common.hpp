@@ -20,6 +20,14 @@
 #define UVOL_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
 #endif
 
+// intra-wave ordering point between lane 0's stores and the other lanes' loads: lock-step on the GPU (plus a
+// compiler barrier); a real rendezvous in the shim, where lanes are fibers that run ahead of each other
+#ifdef HIPEMU
+#define UVOL_WAVE_SYNC() do { (void)__shfl(0, 0); } while (0)
+#else
+#define UVOL_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 // the one-wave serial walkers are latency-bound: give them issue priority over co-resident throughput kernels
 #ifdef HIPEMU
 #define UVOL_SERIAL_PRIO() do { } while (0)

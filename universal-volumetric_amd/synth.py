@@ -182,3 +182,21 @@ def texture_sequence(n_frames, size=2048, seed=0, change_frac=0.30, bg_frac=0.30
         rgba[..., :3] = (img * 255.0 + 0.5).astype(np.uint8); rgba[..., 3] = 255
         frames.append(rgba)
     return frames
+
+
+def edge_case_meshes():
+    """Small meshes that exercise the non-manifold / boundary / multi-component rules of the corner table
+    (extra faces on an edge become boundaries, one fan per vertex instance, inconsistent orientation, duplicate faces)."""
+    def mk(pos, faces):
+        return dict(pos=np.array(pos, np.float32), idx_pos=np.array(faces, np.uint32).reshape(-1))
+    c = {}
+    c["fin"] = mk([[0, 0, 0], [1, 0, 0], [0.5, 1, 0], [0.5, -1, 0], [0.5, 0, 1]], [[0, 1, 2], [1, 0, 3], [0, 1, 4]])
+    c["bowtie"] = mk([[0, 0, 0], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, -1, 0]], [[0, 1, 2], [0, 3, 4]])
+    c["flipped"] = mk([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], [[0, 1, 2], [1, 2, 3]])
+    c["dupface"] = mk([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], [[0, 1, 2], [0, 1, 2], [2, 1, 3]])
+    t = torus_mesh(10, 6); s = sphere_mesh(12, 7, charts=(2, 2))
+    c["two_components"] = dict(pos=np.concatenate([t["pos"], s["pos"] + 500]), idx_pos=np.concatenate([t["idx_pos"], s["idx_pos"] + len(t["pos"])]))
+    c["small_torus_handles"] = torus_mesh(16, 8)
+    g = grid_mesh(7, 5, holes=False)
+    c["open_grid"] = g
+    return c
