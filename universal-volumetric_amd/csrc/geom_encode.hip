@@ -302,6 +302,21 @@ __device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, c
   const int4 a = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2], b = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2 + 1];
   FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
 }
+// Lane-0 walker without the cache: as soon as a face's record is known, the records of BOTH neighbours it can step
+// to (right / left) are requested, so the next step's dependent HBM read overlaps this step's LDS bitmap work.
+struct RecPrefetch { int fa, fb; FaceRec ra, rb; };
+__device__ __forceinline__ void prefetch_init(RecPrefetch &P) { P.fa = -1; P.fb = -1; }
+__device__ __forceinline__ FaceRec prefetch_take(const RecPrefetch &P, const int32_t *rec, int f) {
+  if (f == P.fa) return P.ra;
+  if (f == P.fb) return P.rb;
+  return load_rec(rec, f);
+}
+__device__ __forceinline__ void prefetch_issue(RecPrefetch &P, const int32_t *rec, int ca, int cb) {
+  P.fa = ca >= 0 ? ca / 3 : -1; P.fb = cb >= 0 ? cb / 3 : -1;
+  if (P.fa >= 0) P.ra = load_rec(rec, P.fa);
+  if (P.fb >= 0 && P.fb != P.fa) P.rb = load_rec(rec, P.fb); else P.fb = -1;
+}
+
 // Lane 0 is the only reader/writer of the visited bitmaps and of the cache tags; its view is broadcast with v_readlane
 // so that all 64 lanes follow the same control flow without relying on lock-step LDS read-modify-write races.
 // (UNI = false: only lane 0 is alive — the plain lane-0 walker used when the record cache is off)
@@ -330,6 +345,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   const int32_t *rec = J.rec[0];
   int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
+  RecPrefetch PF; prefetch_init(PF);
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
   for (int f0 = 0; f0 < nf; f0++) {
@@ -366,9 +382,10 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
       if (corner < 0 || ubit_get<CACHE>(fbits, corner / 3)) { sp--; continue; }
       for (;;) {
         const int face = corner / 3, k = corner - 3 * face;
-        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
-        ubit_set(fbits, face, lane);
+        const FaceRec r = CACHE ? walk_rec<CACHE>(rec, face, nf, W, lane) : prefetch_take(PF, rec, face);
         const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
+        if (!CACHE) prefetch_issue(PF, rec, rcn, lcn);
+        ubit_set(fbits, face, lane);
         if (lane == 0) { proc[nproc] = corner; ftime[face] = nproc; }
         int sym;
         const int v = vi >> 1;
@@ -581,6 +598,7 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   const int32_t *rec = J.rec[1 + t];
   int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
   int n = 0;
+  RecPrefetch PF; prefetch_init(PF);
 #define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) { v2d[(vid)] = n; order[n] = (c); } n++; } while (0)
 #define T_FVIS(c) ((c) < 0 ? true : ubit_get<CACHE>(fbits, (c) / 3))
   for (int f = 0; f < nf; f++) {
@@ -598,9 +616,10 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
       if (cid < 0 || ubit_get<CACHE>(fbits, cid / 3)) { sp--; continue; }
       for (;;) {
         const int face = cid / 3, k = cid - 3 * face;
-        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
-        ubit_set(fbits, face, lane);
+        const FaceRec r = CACHE ? walk_rec<CACHE>(rec, face, nf, W, lane) : prefetch_take(PF, rec, face);
         const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
+        if (!CACHE) prefetch_issue(PF, rec, rc, lc);
+        ubit_set(fbits, face, lane);
         const int v = vi >> 1;
         if (!ubit_get<CACHE>(vbits, v)) {
           T_VISIT(v, cid);
