@@ -39,8 +39,10 @@ def main():
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
+    ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cu-split", type=int, default=0, help="1: partition CUs between the geometry and texture streams")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     args = ap.parse_args()
 
@@ -86,15 +88,22 @@ def main():
     torch.cuda.synchronize()
 
     cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
-    geo = uvol.Codec(device=local_rank, **cfg)
-    texs = [uvol.Codec(device=local_rank, **cfg) for _ in range(max(1, args.tex_streams))]
-    batch = (uvol.Mesh * F)(*[dev_meshes[i % args.distinct] for i in range(F)])
+    gcfg, tcfg = dict(cfg), dict(cfg)
+    if args.cu_split:          # geometry on 3 of every 4 CUs, texture on the 4th (hipExtStreamCreateWithCUMask)
+        gcfg.update(cu_mod=4, cu_residues=0b0111); tcfg.update(cu_mod=4, cu_residues=0b1000)
+    GS = max(1, args.geo_streams)
+    geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]
+    texs = [uvol.Codec(device=local_rank, **tcfg) for _ in range(max(1, args.tex_streams))]
     out = {}
 
     host_frames = [meshes_h[i % args.distinct] for i in range(F)]
 
-    def run_geo():
-        out["drc"] = geo.encode_mesh_batch(host_frames) if args.host_inputs else geo.encode_mesh_batch_dev(batch)
+    gsl = [(gi * F // GS, (gi + 1) * F // GS) for gi in range(GS)]
+    gbatches = [(uvol.Mesh * (b - a))(*[dev_meshes[i % args.distinct] for i in range(a, b)]) for a, b in gsl]
+
+    def run_geo(gi):
+        a, b = gsl[gi]
+        out["drc_%d" % gi] = geos[gi].encode_mesh_batch(host_frames[a:b]) if args.host_inputs else geos[gi].encode_mesh_batch_dev(gbatches[gi])
 
     def run_tex(ti):
         mine = len(range(ti, nseg, len(texs)))            # segments of this step handled by texture context ti, ONE batched call
@@ -104,12 +113,13 @@ def main():
             out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
 
     def step():
-        th = [threading.Thread(target=run_geo)] + [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs))]
+        th = [threading.Thread(target=run_geo, args=(gi,)) for gi in range(GS)] + [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs))]
         for t in th:
             t.start()
         for t in th:
             t.join()
         out["ktx2"] = [k for ti in range(len(texs)) for k in out["ktx2_%d" % ti]]
+        out["drc"] = [k for gi in range(GS) for k in out["drc_%d" % gi]]
 
     def barrier():
         if world > 1:
@@ -118,7 +128,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    geo.profile(True); geo.profile_reset()
+    for g in geos:
+        g.profile(True); g.profile_reset()
     for t in texs:
         t.profile(True); t.profile_reset()
     barrier()
@@ -142,16 +153,16 @@ def main():
         drc_len = sum(len(x) for x in out["drc"]) / F
         ktx_len = sum(len(x) for x in out["ktx2"]) / F
         algo_per_frame = 32.0 * V + 12.0 * Fc + 4.0 * args.tex_size ** 2 + drc_len + ktx_len
-        groups = geo.profile_report()
+        groups = []
         tg = {}
-        for t in texs:
+        for t in geos + texs:
             for g in t.profile_report():
                 a = tg.setdefault(g["name"], dict(name=g["name"], launches=0, total_ms=0.0, algo_bytes=0))
                 a["launches"] += g["launches"]; a["total_ms"] += g["total_ms"]; a["algo_bytes"] += g["algo_bytes"]
         groups += list(tg.values())
         groups.sort(key=lambda g: -g["total_ms"])
         dom = groups[0]
-        units = F if dom["name"].startswith("geo.") else F // len(texs)          # frames one launch of that group processes
+        units = F // GS if dom["name"].startswith("geo.") else F // len(texs)          # frames one launch of that group processes
         avg_ms = dom["total_ms"] / max(1, dom["launches"])
         achieved = algo_per_frame * units / (avg_ms * 1e-3) / 1e9
         res = {
@@ -161,7 +172,7 @@ def main():
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
                                    "%d frames per step, qp11/qt10/qn8/cl7" % (V, Fc, args.tex_size, args.tex_size, B, F),
-                       "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU 1 geometry stream + %d texture streams" % len(texs),
+                       "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
                        "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], units), "avg_launch_ms": avg_ms, "units_per_launch": units,
@@ -172,7 +183,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
         print(json.dumps(res))
-    geo.close()
+    for g in geos:
+        g.close()
     for t in texs:
         t.close()
     if world > 1:

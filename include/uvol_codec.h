@@ -48,7 +48,9 @@ typedef struct uvol_params {
   int32_t etc1s_quality;            /* basisu -q equivalent, 1..255, default 128 (Encoder.py passes none) */
   int32_t y_flip;                   /* basisu -y_flip (Encoder.py:290 always passes it), default 1 */
   int32_t max_batch;                /* frames in flight per geometry batch, default 32 */
-  int32_t reserved[7];
+  int32_t cu_mod;                   /* optional CU partition: stream runs only on CUs with (index % cu_mod) in cu_residues; 0 = all CUs */
+  int32_t cu_residues;              /* bit r set = residue r allowed */
+  int32_t reserved[5];
 } uvol_params;
 
 void uvol_params_default(uvol_params *p);

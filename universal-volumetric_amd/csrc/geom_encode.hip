@@ -284,15 +284,15 @@ __device__ __forceinline__ void bit_set(uint32_t *w, int i) { w[i >> 5] |= 1u <<
 // coalesced 2 KiB read (lane k fetches face 64*g + k), so the otherwise idle 63 lanes turn the walker's dependent
 // 32-byte HBM reads into LDS hits whenever the traversal stays inside recently touched face neighbourhoods.
 #define WALK_LINES 32
-struct WalkLds { uint32_t *fbits, *vbits, *gtag; int4 *cdata; };
+struct WalkLds { uint32_t *fbits, *vbits, *gtag; int4 *cdata; uint32_t lmask; };
 __device__ __forceinline__ size_t walk_lds_words(uint32_t fw) { return ((size_t)2 * fw + WALK_LINES + 3) & ~(size_t)3; }
-__device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw) {
-  WalkLds w; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + 2 * fw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw)); return w;
+__device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw, int lines) {
+  WalkLds w; w.lmask = (uint32_t)lines - 1u; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + 2 * fw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw)); return w;
 }
 template <bool CACHE>
 __device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, const WalkLds &W, uint32_t lane) {
   if (!CACHE) return load_rec(rec, f);
-  const uint32_t g = (uint32_t)f >> 6, line = g & (WALK_LINES - 1);
+  const uint32_t g = (uint32_t)f >> 6, line = g & W.lmask;
   if (UVOL_READLANE(W.gtag[line], 0) != g + 1) {    // wave-uniform miss (lane 0's view of the tag): every lane fetches one record of the group
     const int ff = (int)(g << 6) + (int)lane;
     if (ff < nf) { const int4 *p = reinterpret_cast<const int4 *>(rec + 8 * (size_t)ff); const int4 a = p[0], b = p[1]; W.cdata[(line * 64 + lane) * 2] = a; W.cdata[(line * 64 + lane) * 2 + 1] = b; }
@@ -302,21 +302,6 @@ __device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, c
   const int4 a = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2], b = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2 + 1];
   FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
 }
-// Lane-0 walker without the cache: as soon as a face's record is known, the records of BOTH neighbours it can step
-// to (right / left) are requested, so the next step's dependent HBM read overlaps this step's LDS bitmap work.
-struct RecPrefetch { int fa, fb; FaceRec ra, rb; };
-__device__ __forceinline__ void prefetch_init(RecPrefetch &P) { P.fa = -1; P.fb = -1; }
-__device__ __forceinline__ FaceRec prefetch_take(const RecPrefetch &P, const int32_t *rec, int f) {
-  if (f == P.fa) return P.ra;
-  if (f == P.fb) return P.rb;
-  return load_rec(rec, f);
-}
-__device__ __forceinline__ void prefetch_issue(RecPrefetch &P, const int32_t *rec, int ca, int cb) {
-  P.fa = ca >= 0 ? ca / 3 : -1; P.fb = cb >= 0 ? cb / 3 : -1;
-  if (P.fa >= 0) P.ra = load_rec(rec, P.fa);
-  if (P.fb >= 0 && P.fb != P.fa) P.rb = load_rec(rec, P.fb); else P.fb = -1;
-}
-
 // Lane 0 is the only reader/writer of the visited bitmaps and of the cache tags; its view is broadcast with v_readlane
 // so that all 64 lanes follow the same control flow without relying on lock-step LDS read-modify-write races.
 // (UNI = false: only lane 0 is alive — the plain lane-0 walker used when the record cache is off)
@@ -326,7 +311,7 @@ __device__ __forceinline__ void ubit_set(uint32_t *w, int i, uint32_t lane) { if
 template <bool UNI> __device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { if (!UNI) return stack[sp - 1]; int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
 
 template <bool LDS, bool CACHE>
-__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
+__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
@@ -337,7 +322,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   // faces keeps its vertex bitmap in global memory instead) + the record cache
   const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32;
   const bool v_in_lds = LDS && vw <= fw;
-  WalkLds W = walk_lds_carve(lds, fw);
+  WalkLds W = walk_lds_carve(lds, fw, lines);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.fvis);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
   if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
@@ -345,7 +330,6 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
   const int32_t *rec = J.rec[0];
   int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
-  RecPrefetch PF; prefetch_init(PF);
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
   for (int f0 = 0; f0 < nf; f0++) {
@@ -382,10 +366,9 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs) {
       if (corner < 0 || ubit_get<CACHE>(fbits, corner / 3)) { sp--; continue; }
       for (;;) {
         const int face = corner / 3, k = corner - 3 * face;
-        const FaceRec r = CACHE ? walk_rec<CACHE>(rec, face, nf, W, lane) : prefetch_take(PF, rec, face);
-        const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
-        if (!CACHE) prefetch_issue(PF, rec, rcn, lcn);
+        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
         ubit_set(fbits, face, lane);
+        const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
         if (lane == 0) { proc[nproc] = corner; ftime[face] = nproc; }
         int sym;
         const int v = vi >> 1;
@@ -579,7 +562,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 // One 32-byte record load per face; visited faces / vertices are bitmaps in LDS.
 // ------------------------------------------------------------------------------------------------
 template <bool LDS, bool CACHE>
-__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
+__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
   UVOL_SERIAL_PRIO();
@@ -590,7 +573,7 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   const int nf = (int)J.nf;
   const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32;
   const bool v_in_lds = LDS && vw <= fw;
-  WalkLds W = walk_lds_carve(lds, fw);
+  WalkLds W = walk_lds_carve(lds, fw, lines);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
   if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
@@ -598,7 +581,6 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
   const int32_t *rec = J.rec[1 + t];
   int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
   int n = 0;
-  RecPrefetch PF; prefetch_init(PF);
 #define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) { v2d[(vid)] = n; order[n] = (c); } n++; } while (0)
 #define T_FVIS(c) ((c) < 0 ? true : ubit_get<CACHE>(fbits, (c) / 3))
   for (int f = 0; f < nf; f++) {
@@ -616,10 +598,9 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs) {
       if (cid < 0 || ubit_get<CACHE>(fbits, cid / 3)) { sp--; continue; }
       for (;;) {
         const int face = cid / 3, k = cid - 3 * face;
-        const FaceRec r = CACHE ? walk_rec<CACHE>(rec, face, nf, W, lane) : prefetch_take(PF, rec, face);
-        const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
-        if (!CACHE) prefetch_issue(PF, rec, rc, lc);
+        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
         ubit_set(fbits, face, lane);
+        const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
         const int v = vi >> 1;
         if (!ubit_get<CACHE>(vbits, v)) {
           T_VISIT(v, cid);
@@ -1150,18 +1131,20 @@ struct GeoState {
   std::vector<GeoJob> hjobs;
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
   size_t max_lds = 64 * 1024;
+  int num_cu = 256;                    // CUs this context's streams may run on
   hipStream_t aux = nullptr;           // second stream: valence replay runs beside renumber/seams/DFS
   hipEvent_t ev_walk = nullptr, ev_val = nullptr;
 };
 
 int geo_create(uvol_ctx *ctx) {
   ctx->geo = new GeoState();
-  if (hipStreamCreateWithFlags(&ctx->geo->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->geo->ev_walk) != hipSuccess || hipEventCreate(&ctx->geo->ev_val) != hipSuccess) return UVOL_E_HIP;
+  if (uvol_make_stream(ctx, &ctx->geo->aux) != hipSuccess || hipEventCreate(&ctx->geo->ev_walk) != hipSuccess || hipEventCreate(&ctx->geo->ev_val) != hipSuccess) return UVOL_E_HIP;
 #ifndef HIPEMU
   // the serial walkers keep their visited bitmaps in LDS: allow the full 160 KiB of a gfx950 CU
   int v = 0;
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->geo->max_lds = (size_t)v;
   const size_t want = ctx->geo->max_lds;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ctx->geo->num_cu = v;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
@@ -1387,18 +1370,22 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   }
   const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
   const size_t walk_lds = (((size_t)2 * walk_fw + WALK_LINES + 3) & ~(size_t)3) * 4;          // bitmaps (+ tag words)
-  const size_t walk_lds_c = walk_lds + (size_t)WALK_LINES * 64 * 32;                              // + record cache
+  static const int walk_lines = [] { const char *e = getenv("UVOL_WALK_LINES"); int v = e ? atoi(e) : WALK_LINES; int p2 = 1; while (p2 * 2 <= v && p2 * 2 <= WALK_LINES) p2 *= 2; return p2; }();
+  const size_t walk_lds_c = walk_lds + (size_t)walk_lines * 64 * 32;                              // + record cache
   const bool use_lds = walk_lds <= G->max_lds;
   // the record cache costs 64 KiB of LDS per walker: only worth it while every walker can still have a CU of its own
+  // (n edgebreaker walkers, 3n attribute traversers).  UVOL_WALK_CACHE overrides: bit 0 = walker, bit 1 = traversers.
   static const int cache_env = [] { const char *e = getenv("UVOL_WALK_CACHE"); return e ? atoi(e) : -1; }();
-  const bool use_cache = walk_lds_c <= G->max_lds && (cache_env >= 0 ? cache_env != 0 : 3 * n <= 256);
+  const bool cache_fits = walk_lds_c <= G->max_lds;
+  const bool use_cache = cache_fits && (cache_env >= 0 ? (cache_env & 1) != 0 : 3 * n <= G->num_cu);
+  const bool use_cache_t = cache_fits && (cache_env >= 0 ? (cache_env & 2) != 0 : 3 * n <= G->num_cu);
   {
     DENSE_TABLE(0);
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj);
-    else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj);
-    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj);
+    if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj, walk_lines);
+    else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, 1);
+    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 1);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
   // renumber / seams / fans / DFS traversal on the main stream; joined again before the entropy stage.
@@ -1428,9 +1415,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    if (use_cache) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj);
-    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj);
-    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj);
+    if (use_cache_t) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj, walk_lines);
+    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, 1);
+    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 1);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);

@@ -5,6 +5,24 @@
 #include "uvol_common.hpp"
 #include <new>
 
+// Optional CU partition (params.cu_mod / cu_residues): the context's streams only run on CUs whose index modulo
+// cu_mod has its bit set in cu_residues.  bench.py --cu-split gives geometry 3 of every 4 CUs and texture the 4th,
+// so the latency-bound one-wave walkers never share a CU's memory pipeline with the streaming texture kernels.
+hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
+#ifndef HIPEMU
+  if (ctx->prm.cu_mod > 1 && ctx->prm.cu_mod <= 32 && ctx->prm.cu_residues != 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) {
+      const int ncu = prop.multiProcessorCount; std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu; i++) if ((ctx->prm.cu_residues >> (i % ctx->prm.cu_mod)) & 1) mask[(size_t)i / 32] |= 1u << (i % 32);
+      if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+  }
+#endif
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 extern "C" {
 
 void uvol_params_default(uvol_params *p) {
@@ -35,7 +53,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
   if (params) ctx->prm = *params; else uvol_params_default(&ctx->prm);
   if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
   if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
+  if (uvol_make_stream(ctx, &ctx->stream) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
   if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
   *out = ctx;
   return UVOL_OK;

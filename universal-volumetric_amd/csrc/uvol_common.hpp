@@ -126,6 +126,7 @@ static inline bool uvol_debug() { static int d = -1; if (d < 0) { const char *e 
 static inline unsigned uvol_blocks(size_t n, unsigned bs = UVOL_BLOCK) { return (unsigned)((n + bs - 1) / bs); }
 
 // pipeline entry points implemented in the .hip translation units
+hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out);
 int geo_create(uvol_ctx *ctx);
 void geo_destroy(uvol_ctx *ctx);
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_on_device,
