@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cu-split", type=int, default=0, help="1: partition CUs between the geometry and texture streams")
+    ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
+    ap.add_argument("--cu-split", type=int, default=0, help="16*G+T: CU residue masks (mod 4) for the geometry / texture streams, e.g. 0x7*16+0x8 = 120")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     args = ap.parse_args()
 
@@ -89,8 +90,8 @@ def main():
 
     cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
     gcfg, tcfg = dict(cfg), dict(cfg)
-    if args.cu_split:          # geometry on 3 of every 4 CUs, texture on the 4th (hipExtStreamCreateWithCUMask)
-        gcfg.update(cu_mod=4, cu_residues=0b0111); tcfg.update(cu_mod=4, cu_residues=0b1000)
+    if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)
+        gcfg.update(cu_mod=4, cu_residues=int(args.cu_split) // 16); tcfg.update(cu_mod=4, cu_residues=int(args.cu_split) % 16)
     GS = max(1, args.geo_streams)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]
     texs = [uvol.Codec(device=local_rank, **tcfg) for _ in range(max(1, args.tex_streams))]
@@ -113,13 +114,14 @@ def main():
             out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
 
     def step():
-        th = [threading.Thread(target=run_geo, args=(gi,)) for gi in range(GS)] + [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs))]
+        th = [threading.Thread(target=run_geo, args=(gi,)) for gi in range(GS) if args.only != "tex"] + \
+             [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs)) if args.only != "geo"]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        out["ktx2"] = [k for ti in range(len(texs)) for k in out["ktx2_%d" % ti]]
-        out["drc"] = [k for gi in range(GS) for k in out["drc_%d" % gi]]
+        out["ktx2"] = [k for ti in range(len(texs)) for k in out.get("ktx2_%d" % ti, [])]
+        out["drc"] = [k for gi in range(GS) for k in out.get("drc_%d" % gi, [])]
 
     def barrier():
         if world > 1:
@@ -141,7 +143,7 @@ def main():
     nbytes = sum(len(x) for x in out["drc"]) + sum(len(x) for x in out["ktx2"])
     table = shard.gather_counts(F * args.steps, nseg * args.steps, B, nbytes, device=dev)      # RCCL all_gather when world > 1
     total_frames, total_segs, total_tex_frames, _ = shard.totals(table, B)
-    assert total_frames == total_tex_frames                                                   # check_total_frames (Encoder.py:135)
+    assert total_frames == total_tex_frames or args.only                                                   # check_total_frames (Encoder.py:135)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -169,7 +171,7 @@ def main():
             "metric": "frames/s encode, 100k-vert mesh + 2048^2 texture",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else ""),
+            "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else "") + (" DIAGNOSTIC %s only" % args.only if args.only else ""),
             "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
                                    "%d frames per step, qp11/qt10/qn8/cl7" % (V, Fc, args.tex_size, args.tex_size, B, F),
                        "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU %d geometry + %d texture streams" % (GS, len(texs)),

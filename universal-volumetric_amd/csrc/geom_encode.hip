@@ -937,13 +937,40 @@ __global__ void __launch_bounds__(64) k_rans_tables(GeoJob *jobs) {
 }
 
 // rANS (blockIdx.x < GEO_NSTREAM) and rabs (blockIdx.x >= GEO_NSTREAM) state machines, one wave per stream, all
-// streams of all frames in ONE launch.  Symbols / bits are prefetched 64 at a time (one per lane, read back with
-// v_readlane), the {prob, cum} table sits in LDS, and output bytes are staged one per lane and stored 64 at a time.
-#define RANS_LDS_ENTRIES 6144
-__global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs) {
+// streams of all frames in ONE launch.  The state recurrence x' = (x / p) * prec + x % p + cum is the only serial part,
+// so everything else is hoisted out of it: 64 symbols are fetched at a time (one per lane), every lane looks its own
+// {prob, cum} up in the LDS table and derives an exact reciprocal of prob in parallel; the serial loop then only reads
+// those back with v_readlane and runs on the scalar unit (s_mul_hi instead of a ~35-instruction integer division, no
+// LDS access in the dependent chain).  Output bytes are staged one per lane and stored 64 at a time.
+// Reciprocal (Alverson): for 2 <= d < 2^31, s = ceil(log2 d), m = ceil(2^(31+s) / d):  floor(x / d) = (x * m) >> (31 + s)
+// for every x < 2^31 (error term x*e/(d*2^(31+s)) < 2^-s <= 1/d).  States here stay below 2^30 (Draco: x < 1024 * p).
+__device__ __forceinline__ uint2 g_recip(uint32_t d) {          // {m, s - 1}; d == 1 yields x - 1 (callers compensate)
+  if (d < 2) return make_uint2(0xffffffffu, 0u);               // (x * (2^32 - 1)) >> 32 = x - 1 for x >= 1
+  const uint32_t sh = 32u - (uint32_t)__clz((int)(d - 1));
+  const unsigned long long m = ((1ull << (31 + sh)) + d - 1) / d;
+  return make_uint2((uint32_t)m, sh - 1);
+}
+// The table only needs to be close, not in the dependent chain: 2048 entries (16 KiB, static) keep every stream of every
+// frame resident at once (14 one-wave workgroups per frame); larger alphabets read {prob, cum} from global memory / L2.
+#define RANS_LDS_ENTRIES 2048
+// one rabs step with the constants of one bit value (LIM = 4096 * ls, MULT = 256 - ls)
+#define RABS_STEP(LIM, M, SH, ADD, MULT)                                                                        \
+  {                                                                                                             \
+    if (st >= (LIM)) {                                                                                          \
+      if (lane == (w & 63)) stage = st & 255;                                                                   \
+      w++; st >>= 8;                                                                                            \
+      if ((w & 63) == 0 && w <= cap) pay[w - 64 + lane] = (uint8_t)stage;                                       \
+    }                                                                                                           \
+    const uint32_t q_ = (uint32_t)(((unsigned long long)st * (M)) >> 32) >> (SH);                               \
+    st = st + (ADD) + q_ * (MULT);                                                                              \
+  }
+__global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
   GeoJob &J = jobs[blockIdx.y];
+#ifndef HIPEMU
+  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
+#endif
   UVOL_SERIAL_PRIO();
-  UVOL_DYN_SMEM(uint2, tab);
+  __shared__ uint2 tab[RANS_LDS_ENTRIES];
   const uint32_t lane = threadIdx.x;
   const bool ok = J.status == 0;
   uint32_t stage = 0, w = 0;
@@ -959,23 +986,48 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs) {
     const uint32_t *syms = S.syms;
     uint8_t *pay = S.pay + 8; const uint32_t cap = S.pay_cap - 80;
     uint32_t st = L;
-    for (uint32_t hi = n; hi > 0;) {
+    // software pipeline over chunks of 64 symbols (lane j = j-th symbol from the end of the remaining range):
+    // symbols are fetched two chunks ahead, their table entries one chunk ahead, both overlapping the serial loop
+#define RANS_LOAD_SY(H) (lane < (H) ? syms[(H) - 1 - lane] : 0u)
+#define RANS_LOOKUP(SY) (in_lds ? tab[SY] : make_uint2(S.probs[SY], S.cum[SY]))
+    uint32_t hi = n;
+    uint32_t sy_nxt = RANS_LOAD_SY(hi);
+    uint2 e_nxt = RANS_LOOKUP(sy_nxt);
+    sy_nxt = RANS_LOAD_SY(hi > 64 ? hi - 64 : 0u);
+    while (hi > 0) {
       const uint32_t cnt = hi < 64 ? hi : 64;
-      const uint32_t sy = lane < cnt ? syms[hi - 1 - lane] : 0;      // lane j = j-th symbol from the end of the remaining range
-      for (uint32_t j = 0; j < cnt; j++) {
-        const uint32_t sv = UVOL_READLANE(sy, j);
-        uint2 e; if (in_lds) e = tab[sv]; else e = make_uint2(S.probs[sv], S.cum[sv]);
-        const uint32_t p = e.x, lim = 1024u * p;
-        while (st >= lim) {
-          if (lane == (w & 63)) stage = st & 255;
-          w++; st >>= 8;
-          if ((w & 63) == 0 && w <= cap) pay[w - 64 + lane] = (uint8_t)stage;
-        }
-        const uint32_t q = st / p;
-        st = q * prec + (st - q * p) + e.y;
-      }
+      const uint2 e = e_nxt;
       hi -= cnt;
+      e_nxt = RANS_LOOKUP(sy_nxt);
+      sy_nxt = RANS_LOAD_SY(hi > 64 ? hi - 64 : 0u);
+      const uint2 rc = g_recip(e.x);
+      const uint32_t ps = e.x | (rc.y << 24);                        // prob < 2^21, shift - 1 < 32
+      const uint32_t cs = e.y + (e.x == 1 ? prec - 1 : 0);            // prob 1: the reciprocal yields x - 1, made up for here
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t pj = UVOL_READLANE(ps, j), p = pj & 0xffffffu, lim = 1024u * p;
+        const uint32_t m = UVOL_READLANE(rc.x, j), cj = UVOL_READLANE(cs, j);
+        if (st >= lim) {                                              // renormalise: k = bytes to emit (x < 2^30, lim >= 1024: at most 3)
+          uint32_t k = 3u; k = (st >> 16) < lim ? 2u : k; k = (st >> 8) < lim ? 1u : k;
+          const uint32_t pos = w & 63;
+          if (__builtin_expect(pos + k >= 64, 0)) {                   // staging buffer wraps: byte by byte, flushing in between
+            for (uint32_t i = 0; i < k; i++) {
+              if (lane == (w & 63)) stage = st & 255;
+              w++; st >>= 8;
+              if ((w & 63) == 0 && w <= cap) pay[w - 64 + lane] = (uint8_t)stage;
+            }
+          } else {
+            const uint32_t d = (lane - pos) & 63;
+            if (d < k) stage = (st >> (8 * d)) & 255;
+            w += k; st >>= 8 * k;
+          }
+        }
+        const uint32_t q = (uint32_t)(((unsigned long long)st * m) >> 32) >> (pj >> 24);
+        st = st + cj + q * (prec - p);                                // = q * prec + (st - q * p) + cum
+      }
     }
+#ifndef HIPEMU
+    if (dbg && blockIdx.y == 0 && lane == 0) printf("[entropy] rans stream %d: n=%u alphabet=%u bytes=%u  %.3f ms\n", (int)blockIdx.x, n, ns, w, (double)(wall_clock64() - t_begin) * 1e-5);
+#endif
     if (w + 4 > cap) { if (lane == 0) J.status = -32; return; }
     if (lane < (w & 63)) pay[(w & ~63u) + lane] = (uint8_t)stage;
     __threadfence_block();
@@ -996,24 +1048,32 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs) {
     const uint32_t n = B.n; const uint64_t total = n ? n : 1;
     const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
     uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
+    p0 = UVOL_READLANE(p0, 0);
     const uint32_t p = 256 - p0;
     uint8_t *pay = B.buf + 8; const uint32_t cap = B.cap - 80;
     uint32_t st = 4096;
+    // x' = (x / ls) * 256 + x % ls + add  =  x + add + q * (256 - ls);  ls == 1: q comes out as x - 1, compensated by 255
+    const uint2 r1 = g_recip(p), r0 = g_recip(p0);
+    const uint32_t m1 = UVOL_READLANE(r1.x, 0), s1 = UVOL_READLANE(r1.y, 0), m0 = UVOL_READLANE(r0.x, 0), s0 = UVOL_READLANE(r0.y, 0);
+    const uint32_t a1 = (p == 1 ? 255u : 0u), a0 = p + (p0 == 1 ? 255u : 0u);
+    const uint32_t lim1 = 4096u * p, lim0 = 4096u * p0, mu1 = 256u - p, mu0 = 256u - p0;
+    uint32_t nxt = (lane < n && B.bits[n - 1 - lane] != 0) ? 1u : 0u;
     for (uint32_t hi = n; hi > 0;) {
       const uint32_t cnt = hi < 64 ? hi : 64;
-      const unsigned long long bm = __ballot(lane < cnt && B.bits[hi - 1 - lane] != 0);     // bit j = j-th bit from the end
-      for (uint32_t j = 0; j < cnt; j++) {
-        const uint32_t bit = (uint32_t)((bm >> j) & 1ull), ls = bit ? p : p0;
-        if (st >= 4096u * ls) {
-          if (lane == (w & 63)) stage = st & 255;
-          w++; st >>= 8;
-          if ((w & 63) == 0 && w <= cap) pay[w - 64 + lane] = (uint8_t)stage;
-        }
-        const uint32_t q = st / ls;
-        st = q * 256 + (st - q * ls) + (bit ? 0u : p);
-      }
+      const unsigned long long bm = __ballot(nxt != 0);                // bit j = j-th bit from the end
       hi -= cnt;
+      nxt = (lane < hi && B.bits[hi - 1 - lane] != 0) ? 1u : 0u;        // next chunk's read overlaps this chunk's serial loop
+      for (uint32_t j = 0; j < cnt;) {                                  // runs of zeros in a tight loop with constant operands
+        const unsigned long long rest = bm >> j;
+        uint32_t run = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : 64u; if (run > cnt - j) run = cnt - j;
+        for (uint32_t r = 0; r < run; r++) RABS_STEP(lim0, m0, s0, a0, mu0);
+        j += run;
+        if (j < cnt) { RABS_STEP(lim1, m1, s1, a1, mu1); j++; }
+      }
     }
+#ifndef HIPEMU
+    if (dbg && blockIdx.y == 0 && lane == 0) printf("[entropy] rabs stream %d: n=%u bytes=%u  %.3f ms\n", (int)blockIdx.x - GEO_NSTREAM, n, w, (double)(wall_clock64() - t_begin) * 1e-5);
+#endif
     if (w + 3 > cap) { if (lane == 0) J.status = -33; return; }
     if (lane < (w & 63)) pay[(w & ~63u) + lane] = (uint8_t)stage;
     __threadfence_block();
@@ -1443,7 +1503,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k7_entropy_encode", 0);
-    LAUNCH_SM(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), (size_t)RANS_LDS_ENTRIES * sizeof(uint2), dj);
+    LAUNCH(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), dj, uvol_debug() ? 1 : 0);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k8_layout_gather", 0);

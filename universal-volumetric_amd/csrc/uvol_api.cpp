@@ -15,7 +15,9 @@ hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) {
       const int ncu = prop.multiProcessorCount; std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int i = 0; i < ncu; i++) if ((ctx->prm.cu_residues >> (i % ctx->prm.cu_mod)) & 1) mask[(size_t)i / 32] |= 1u << (i % 32);
-      if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+      const hipError_t e = hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+      if (uvol_debug()) fprintf(stderr, "[uvol] CU-masked stream: %d CUs, mod %d residues 0x%x -> %s\n", ncu, ctx->prm.cu_mod, ctx->prm.cu_residues, hipGetErrorString(e));
+      if (e == hipSuccess) return hipSuccess;
       (void)hipGetLastError();
     }
   }
