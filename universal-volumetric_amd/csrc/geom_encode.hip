@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
   r[6] = 0; r[7] = 0;
   int4 *dst = reinterpret_cast<int4 *>(rec);
   dst[0] = make_int4(r[0], r[1], r[2], r[3]); dst[1] = make_int4(r[4], r[5], r[6], r[7]);
+  if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
 
 struct FaceRec { int o[3]; int v[3]; };
@@ -275,6 +276,18 @@ __device__ __forceinline__ FaceRec load_rec(const int32_t *rec, int f) {
   const int4 a = p[0], b = p[1];
   FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
 }
+// typed-pointer variants for the lane-0 walkers (P = UVOL_G / UVOL_L pointer)
+#ifdef HIPEMU
+typedef int4 uvol_i4;
+#else
+typedef int uvol_i4 __attribute__((ext_vector_type(4)));      // loadable through an address-space-qualified pointer
+#endif
+template <typename P> __device__ __forceinline__ FaceRec load_rec_p(P rec4, int f) {
+  const uvol_i4 a = rec4[2 * (size_t)f], b = rec4[2 * (size_t)f + 1];
+  FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
+}
+template <typename P> __device__ __forceinline__ bool pbit_get(P w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+template <typename P> __device__ __forceinline__ void pbit_set(P w, int i) { UVOL_OR_NORET(&w[i >> 5], 1u << (i & 31)); }   // fire and forget
 __device__ __forceinline__ int sel3(const int a[3], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : a[2]); }
 __device__ __forceinline__ bool bit_get(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(uint32_t *w, int i) { w[i >> 5] |= 1u << (i & 31); }
@@ -310,6 +323,85 @@ __device__ __forceinline__ void ubit_set(uint32_t *w, int i, uint32_t lane) { if
 // lane 0 owns the explicit DFS stack in global memory; values are broadcast so that control flow stays wave-uniform
 template <bool UNI> __device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { if (!UNI) return stack[sp - 1]; int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
 
+// Lane-0 edgebreaker walk (the variant without the record cache): one lane, typed pointers, no scatter stores —
+// face_time is rebuilt from proc[] by k_face_time afterwards.  Per face: one 32-byte record read from HBM, one
+// sequential proc/symb store pair, a fire-and-forget ds_or for the face bit and LDS reads for the vertex / neighbour bits.
+template <typename FB, typename VB>
+__device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
+  const int nf = (int)J.nf;
+  UVOL_G(const uvol_i4) rec = UVOL_TO_G(const uvol_i4, reinterpret_cast<const uvol_i4 *>(J.rec[0]));
+  UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack);
+  UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
+  UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
+  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
+  enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
+  for (int f0 = 0; f0 < nf; f0++) {
+    if (pbit_get(fbits, f0)) continue;
+    const FaceRec r0 = load_rec_p(rec, f0);
+    int interior = 1, start_corner = 3 * f0;
+    for (int k = 0; k < 3; k++) {
+      if (r0.o[k] < 0) { interior = 0; start_corner = 3 * f0 + k; break; }
+      if (r0.v[k] & 1) {              // boundary vertex: swing right to the boundary edge
+        int ci = 3 * f0 + k, rc = ci;
+        while (rc >= 0) { ci = rc; const FaceRec rr = load_rec_p(rec, rc / 3); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
+        interior = 0; start_corner = g_prv(ci); break;
+      }
+    }
+    start_bits[nstart] = (uint8_t)interior;
+    nstart++;
+    int from;
+    if (interior) {
+      pbit_set(vbits, r0.v[0] >> 1); pbit_set(vbits, r0.v[1] >> 1); pbit_set(vbits, r0.v[2] >> 1);
+      pbit_set(fbits, f0);
+      initc[ninit] = 3 * f0 + 1;
+      ninit++;
+      from = r0.o[1];
+      if (from < 0 || pbit_get(fbits, from / 3)) continue;
+    } else from = start_corner;
+    int sp = 0;
+    stack[sp] = from;
+    sp++;
+    int top = from;                                   // value at stack[sp-1] when known without a load
+    bool top_known = true;
+    while (sp > 0) {
+      int corner = top_known ? top : stack[sp - 1];
+      top_known = false;
+      if (corner < 0 || pbit_get(fbits, corner / 3)) { sp--; continue; }
+      for (;;) {
+        const int face = corner / 3, k = corner - 3 * face;
+        const FaceRec r = load_rec_p(rec, face);
+        proc[nproc] = corner;
+        pbit_set(fbits, face);
+        const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
+        const int v = vi >> 1;
+        // the three bitmap words this step can need, read together (one LDS round trip)
+        const uint32_t vw_ = vbits[v >> 5];
+        const uint32_t rw_ = rcn < 0 ? 0xffffffffu : fbits[(rcn / 3) >> 5], lw_ = lcn < 0 ? 0xffffffffu : fbits[(lcn / 3) >> 5];
+        int sym;
+        bool fresh_interior = false;
+        if (!((vw_ >> (v & 31)) & 1u)) { pbit_set(vbits, v); fresh_interior = !(vi & 1); }
+        if (fresh_interior) { symb[nproc] = T_C; nproc++; corner = rcn; continue; }
+        const bool rvis = rcn < 0 ? true : ((rw_ >> ((rcn / 3) & 31)) & 1u) != 0, lvis = lcn < 0 ? true : ((lw_ >> ((lcn / 3) & 31)) & 1u) != 0;
+        if (rvis) { if (lvis) { sym = T_E; } else { sym = T_R; } } else { sym = lvis ? T_L : T_S; }
+        symb[nproc] = (uint8_t)sym;
+        nproc++;
+        if (sym == T_E) { sp--; break; }
+        if (sym == T_R) { corner = lcn; continue; }
+        if (sym == T_L) { corner = rcn; continue; }
+        nsplit++;
+        stack[sp - 1] = lcn; stack[sp] = rcn;
+        sp++; top = rcn; top_known = true;
+        break;
+      }
+    }
+  }
+  J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
+  if (nproc + ninit != nf) J.status = -10;
+  J.rb[0].n = (uint32_t)nstart;
+  uint32_t z = 0; for (int i = 0; i < nstart; i++) z += J.start_bits[i] == 0;
+  J.rb[0].zeros = z;
+}
+
 template <bool LDS, bool CACHE>
 __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
   GeoJob &J = jobs[blockIdx.x];
@@ -327,8 +419,15 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
   if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok || (!CACHE && lane != 0)) return;       // without the cache the 63 helper lanes have nothing to do
+  if (!CACHE) {                                   // lane-0 walker: typed pointers per (face bits, vertex bits) placement
+    if (LDS) {
+      if (v_in_lds) eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+      else eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+    } else eb_walk_lane0(J, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis)), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+    return;
+  }
   const int32_t *rec = J.rec[0];
-  int32_t *proc = J.proc, *stack = J.stack, *ftime = J.face_time; uint8_t *symb = J.symb;
+  int32_t *proc = J.proc, *stack = J.stack; uint8_t *symb = J.symb;
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
@@ -350,7 +449,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
     if (interior) {
       ubit_set(vbits, r0.v[0] >> 1, lane); ubit_set(vbits, r0.v[1] >> 1, lane); ubit_set(vbits, r0.v[2] >> 1, lane);
       ubit_set(fbits, f0, lane);
-      if (lane == 0) { ftime[f0] = -1; J.initc[ninit] = 3 * f0 + 1; }
+      if (lane == 0) J.initc[ninit] = 3 * f0 + 1;
       ninit++;
       from = r0.o[1];
       if (from < 0 || ubit_get<CACHE>(fbits, from / 3)) continue;
@@ -369,7 +468,7 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
         const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
         ubit_set(fbits, face, lane);
         const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
-        if (lane == 0) { proc[nproc] = corner; ftime[face] = nproc; }
+        if (lane == 0) proc[nproc] = corner;
         int sym;
         const int v = vi >> 1;
         bool fresh_interior = false;
@@ -395,6 +494,24 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
   J.rb[0].n = (uint32_t)nstart;
   uint32_t z = 0; for (int i = 0; i < nstart; i++) z += J.start_bits[i] == 0;
   J.rb[0].zeros = z;
+}
+
+// face_time[f] = index of the symbol that encoded face f (-1 for the faces that only start a component): the inverse
+// of proc[], built in parallel so that the serial walker has no scatter store in its loop
+__global__ void __launch_bounds__(UVOL_BLOCK) k_face_time(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (i < (uint32_t)J.nsym) J.face_time[J.proc[i] / 3] = (int32_t)i;
+}
+// v2d[t][vertex] = position of the vertex in the coding order of table t: the inverse of order[t][] (same reason)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const int t = blockIdx.z;
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (i >= J.ne[t]) return;
+  if (t > 0 && (t - 1 >= J.nad || !J.interior_seams[t - 1])) return;
+  const int c = J.order[t][i];
+  J.v2d[t][J.rec[1 + t][8 * (size_t)(c / 3) + 3 + c % 3] >> 1] = (int32_t)i;
 }
 
 // topology-split events (CheckAndStoreTopologySplitEvent): symbol i contributes an event for each already-encoded
@@ -561,6 +678,50 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 // K5: DepthFirstTraverser — serial per (table, frame).  t=0 base table, t=1,2 attribute tables.
 // One 32-byte record load per face; visited faces / vertices are bitmaps in LDS.
 // ------------------------------------------------------------------------------------------------
+// Lane-0 DepthFirstTraverser (variant without the record cache): typed pointers, order[] is the only output stream —
+// v2d[] (its inverse) is rebuilt by k_v2d afterwards.
+template <typename FB, typename VB>
+__device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vbits) {
+  const int nf = (int)J.nf;
+  UVOL_G(const uvol_i4) rec = UVOL_TO_G(const uvol_i4, reinterpret_cast<const uvol_i4 *>(J.rec[1 + t]));
+  UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  int n = 0;
+  for (int f = 0; f < nf; f++) {
+    if (pbit_get(fbits, f)) continue;
+    int cid = 3 * f, sp = 0;
+    stack[sp] = cid;
+    sp++;
+    int top = cid; bool top_known = true;
+    { const FaceRec r0 = load_rec_p(rec, f); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
+      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); order[n] = cid + 1; n++; }
+      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); order[n] = cid + 2; n++; } }
+    while (sp > 0) {
+      cid = top_known ? top : stack[sp - 1];
+      top_known = false;
+      if (cid < 0 || pbit_get(fbits, cid / 3)) { sp--; continue; }
+      for (;;) {
+        const int face = cid / 3, k = cid - 3 * face;
+        const FaceRec r = load_rec_p(rec, face);
+        pbit_set(fbits, face);
+        const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
+        const int v = vi >> 1;
+        // the three bitmap words this step can need, read together (one LDS round trip)
+        const uint32_t vw_ = vbits[v >> 5];
+        const uint32_t rw_ = rc < 0 ? 0xffffffffu : fbits[(rc / 3) >> 5], lw_ = lc < 0 ? 0xffffffffu : fbits[(lc / 3) >> 5];
+        if (!((vw_ >> (v & 31)) & 1u)) {
+          pbit_set(vbits, v); order[n] = cid; n++;
+          if (!(vi & 1)) { cid = rc; continue; }
+        }
+        const bool rvis = rc < 0 ? true : ((rw_ >> ((rc / 3) & 31)) & 1u) != 0, lvis = lc < 0 ? true : ((lw_ >> ((lc / 3) & 31)) & 1u) != 0;
+        if (rvis) { if (lvis) { sp--; break; } cid = lc; }
+        else { if (lvis) cid = rc; else { stack[sp - 1] = lc; stack[sp] = rc; sp++; top = rc; top_known = true; break; } }
+      }
+    }
+  }
+  J.ne[t] = (uint32_t)n;
+  if (t == 0 && (uint32_t)n != J.nverts) J.status = -11;
+}
+
 template <bool LDS, bool CACHE>
 __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines) {
   GeoJob &J = jobs[blockIdx.y];
@@ -573,15 +734,29 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines) {
   const int nf = (int)J.nf;
   const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32;
   const bool v_in_lds = LDS && vw <= fw;
-  WalkLds W = walk_lds_carve(lds, fw, lines);
+  WalkLds W = walk_lds_carve(lds, fw, lines & 0xff);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
   if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok || (!CACHE && lane != 0)) return;
+#ifndef HIPEMU
+  const unsigned long long t_begin = (lines & 0x100) ? wall_clock64() : 0ull;
+#define TRAVERSE_DBG() if ((lines & 0x100) && blockIdx.y == 0 && lane == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5)
+#else
+#define TRAVERSE_DBG()
+#endif
+  if (!CACHE) {
+    if (LDS) {
+      if (v_in_lds) traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+      else traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+    } else traverse_lane0(J, t, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t])), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+    TRAVERSE_DBG();
+    return;
+  }
   const int32_t *rec = J.rec[1 + t];
-  int32_t *stack = J.t_stack[t], *order = J.order[t], *v2d = J.v2d[t];
+  int32_t *stack = J.t_stack[t], *order = J.order[t];
   int n = 0;
-#define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) { v2d[(vid)] = n; order[n] = (c); } n++; } while (0)
+#define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) order[n] = (c); n++; } while (0)
 #define T_FVIS(c) ((c) < 0 ? true : ubit_get<CACHE>(fbits, (c) / 3))
   for (int f = 0; f < nf; f++) {
     if (ubit_get<CACHE>(fbits, f)) continue;
@@ -1446,6 +1621,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj, walk_lines);
     else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, 1);
     else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 1);
+    LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
   // renumber / seams / fans / DFS traversal on the main stream; joined again before the entropy stage.
@@ -1476,8 +1652,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     if (use_cache_t) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj, walk_lines);
-    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, 1);
+    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, 1 | (uvol_debug() ? 0x100 : 0));
     else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 1);
+    LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);

@@ -35,6 +35,24 @@
 #define UVOL_SERIAL_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 
+// Address-space-qualified pointers for the serial walkers.  A pointer read out of a job struct is "generic", so the
+// compiler has to use flat_* instructions, which count in BOTH vmcnt and lgkmcnt: every LDS bitmap test then also
+// waits for the global stores issued just before it (a full memory round trip per face).  Casting to the global /
+// LDS address spaces yields global_* / ds_* instructions with independent, exactly counted waits.
+#ifdef HIPEMU
+#define UVOL_G(T) T *
+#define UVOL_L(T) T *
+#define UVOL_TO_G(T, p) (p)
+#define UVOL_TO_L(T, p) (p)
+#define UVOL_OR_NORET(p, v) ((void)(*(p) |= (v)))
+#else
+#define UVOL_G(T) __attribute__((address_space(1))) T *
+#define UVOL_L(T) __attribute__((address_space(3))) T *
+#define UVOL_TO_G(T, p) ((__attribute__((address_space(1))) T *)(p))
+#define UVOL_TO_L(T, p) ((__attribute__((address_space(3))) T *)(p))
+#define UVOL_OR_NORET(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#endif
+
 // dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
 #ifdef HIPEMU
 #define UVOL_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu_dyn_smem)
