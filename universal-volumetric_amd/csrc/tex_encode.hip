@@ -219,6 +219,88 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force)
     else atomicAdd(&V.stQ[(size_t)l * DIM + (f - 1 - DIM)], v);
   }
 }
+// Selector-vector statistics (DIM 16, unit weights).  The host bounds the items one workgroup visits by SEL_STATS_ITEMS,
+// so every per-workgroup partial sum fits 16 bits (count <= 6144, S <= 3 * 6144, Q <= 9 * 6144 = 55296): two counters
+// share an LDS word, 17 words per leaf {W|S0, S1|S2, ... , Q15|-}, and lcap = min(Kmax_s, 960) leaves (<= 64 KiB) are
+// privatised — at the default quality (768 leaves) no selector statistic ever touches a global atomic in the item loop.
+// field f: 0 = W, 1..16 = S[f-1], 17..32 = Q[f-17];  word = f >> 1, half = f & 1.
+#define SEL_STATS_ITEMS 6144
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force, uint32_t lcap) {
+  TJOB_OR_RETURN;
+  TexVQ &V = J.vq[1];
+  if (V.done && !force) return;
+  UVOL_DYN_SMEM(uint32_t, lds);                 // [lcap * 17]
+  const uint32_t nl = V.nl, ncap = nl < lcap ? nl : lcap;
+  for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) lds[k] = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    bool todo = i < V.n_items;
+    const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
+    // while the wave's items sit in few leaves (always in the early rounds, mostly later: neighbouring blocks look
+    // alike) count with ballots — c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 — and let 33 lanes
+    // post one add each; whatever is left after 4 leaders takes the per-item path.
+    const uint32_t sw = todo ? J.bsel[J.item[i]] : 0;
+    unsigned long long rem = __ballot(todo);
+    for (int rounds = 0; rounds < 4 && rem; rounds++) {
+      const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
+      const uint32_t ll = UVOL_READLANE(l, leader);
+      const bool inm = todo && l == ll;
+      const unsigned long long m = __ballot(inm);
+      uint32_t myv = 0;
+      for (int d = 0; d < 16; d++) {
+        const uint32_t xv = (sw >> (2 * d)) & 3u;
+        const uint32_t c1 = (uint32_t)__popcll(__ballot(inm && xv == 1)), c2 = (uint32_t)__popcll(__ballot(inm && xv == 2)), c3 = (uint32_t)__popcll(__ballot(inm && xv == 3));
+        if (lane == (uint32_t)(1 + d)) myv = c1 + 2 * c2 + 3 * c3;
+        if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
+      }
+      if (lane == 0) myv = (uint32_t)__popcll(m);
+      if (lane < 33 && myv) {
+        if (ll < ncap) atomicAdd(&lds[ll * 17 + (lane >> 1)], myv << ((lane & 1) * 16));
+        else if (lane == 0) atomicAdd(&V.stW[ll], (unsigned long long)myv);
+        else if (lane <= 16) atomicAdd(&V.stS[(size_t)ll * 16 + (lane - 1)], (unsigned long long)myv);
+        else atomicAdd(&V.stQ[(size_t)ll * 16 + (lane - 17)], (unsigned long long)myv);
+      }
+      rem &= ~m;
+      if (inm) todo = false;
+    }
+    if (!todo) continue;
+    if (l < ncap) {
+      uint32_t *p = lds + (size_t)l * 17;
+      uint32_t prev = 1;                                                   // field 0: W += 1
+      for (int d = 0; d < 16; d++) {                                       // fields 1..16: S
+        const uint32_t xv = (sw >> (2 * d)) & 3u;
+        if (d & 1) prev = xv; else { const uint32_t v = prev | (xv << 16); if (v) atomicAdd(&p[d >> 1], v); }
+      }
+      // fields 16 (S15) | 17 (Q0), then Q1|Q2 ... Q13|Q14, then Q15 alone
+      { const uint32_t q0 = (sw & 3u) * (sw & 3u), v = prev | (q0 << 16); if (v) atomicAdd(&p[8], v); }
+      for (int d = 1; d < 15; d += 2) {
+        const uint32_t a = (sw >> (2 * d)) & 3u, b = (sw >> (2 * d + 2)) & 3u, v = (a * a) | ((b * b) << 16);
+        if (v) atomicAdd(&p[9 + (d >> 1)], v);
+      }
+      { const uint32_t a = (sw >> 30) & 3u; if (a) atomicAdd(&p[16], a * a); }
+    } else {
+      atomicAdd(&V.stW[l], 1ull);
+      for (int d = 0; d < 16; d++) {
+        const unsigned long long xv = (sw >> (2 * d)) & 3u;
+        if (xv) { atomicAdd(&V.stS[(size_t)l * 16 + d], xv); atomicAdd(&V.stQ[(size_t)l * 16 + d], xv * xv); }
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) {
+    const uint32_t v = lds[k]; if (!v) continue;
+    const uint32_t l = k / 17, w = k % 17;
+    for (int h = 0; h < 2; h++) {
+      const unsigned long long part = h ? (v >> 16) : (v & 0xffffu); if (!part) continue;
+      const uint32_t f = 2 * w + (uint32_t)h;
+      if (f == 0) atomicAdd(&V.stW[l], part);
+      else if (f <= 16) atomicAdd(&V.stS[(size_t)l * 16 + (f - 1)], part);
+      else atomicAdd(&V.stQ[(size_t)l * 16 + (f - 17)], part);
+    }
+  }
+}
 // split decision — one workgroup
 template <int DIM>
 __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job) {
@@ -978,6 +1060,23 @@ static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsign
   TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1);
 }
 
+// selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
+static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < 960u ? J.Kmax_s : 960u; }
+static inline unsigned sel_stat_blocks(const TexJob &J) { return std::max<unsigned>(512u, (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }
+static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force) {
+  const uint32_t lcap = sel_lcap(J);
+  TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
+  TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap);
+}
+static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
+  for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
+    run_sel_stats(ctx, dj, J, NSEG, 0);
+    TLAUNCH((k_vq_decide<16>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH((k_vq_apply<16>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH((k_vq_advance<16>), dim3(1), dim3(64), 0, dj);
+  }
+}
+
 // n_seg segments of n_layers layers each (rgba[s * n_layers + l]), all of one size: ONE launch per stage for the whole batch
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
                         bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
@@ -1041,9 +1140,9 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   }
   {
     uvol_ctx::Scope sc(ctx, "tex.k10_selector_codebook", src_bytes * 2);
-    run_vq_rounds<16, 480, unsigned int>(ctx, dj, bNB, NSEG);
+    run_sel_rounds(ctx, dj, J, bNB, NSEG);
     for (int it = 0; it < 2; it++) {
-      run_vq_stats<16, 480, unsigned int>(ctx, dj, bNB, NSEG);
+      run_sel_stats(ctx, dj, J, NSEG, 1);
       TLAUNCH(k_sel_centroids, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
       TLAUNCH(k_sel_assign, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
     }
