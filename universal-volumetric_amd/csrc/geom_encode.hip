@@ -292,15 +292,17 @@ __device__ __forceinline__ int sel3(const int a[3], int k) { return k == 0 ? a[0
 __device__ __forceinline__ bool bit_get(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(uint32_t *w, int i) { w[i >> 5] |= 1u << (i & 31); }
 
-// Walker LDS layout: [face bits fw words][vertex bits fw words][WALK_LINES tags][pad][WALK_LINES x 64 records of 32 B].
+// Walker LDS layout: [face bits fw words][vertex bits vcw words][WALK_LINES tags][pad][WALK_LINES x 64 records of 32 B].
+// vcw is sized by the host from the input attribute counts (a table with more vertices keeps its vertex bitmap in
+// global memory): ~37 KiB instead of 50 KiB per walker for a 200k-face / 100k-vertex mesh, i.e. 4 walkers per CU.
 // The record cache is direct-mapped on groups of 64 consecutive faces; a miss is filled by the WHOLE wave with one
 // coalesced 2 KiB read (lane k fetches face 64*g + k), so the otherwise idle 63 lanes turn the walker's dependent
 // 32-byte HBM reads into LDS hits whenever the traversal stays inside recently touched face neighbourhoods.
 #define WALK_LINES 32
 struct WalkLds { uint32_t *fbits, *vbits, *gtag; int4 *cdata; uint32_t lmask; };
-__device__ __forceinline__ size_t walk_lds_words(uint32_t fw) { return ((size_t)2 * fw + WALK_LINES + 3) & ~(size_t)3; }
-__device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw, int lines) {
-  WalkLds w; w.lmask = (uint32_t)lines - 1u; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + 2 * fw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw)); return w;
+__device__ __forceinline__ size_t walk_lds_words(uint32_t fw, uint32_t vcw) { return ((size_t)fw + vcw + WALK_LINES + 3) & ~(size_t)3; }
+__device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw, uint32_t vcw, int lines) {
+  WalkLds w; w.lmask = (uint32_t)lines - 1u; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + fw + vcw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw, vcw)); return w;
 }
 template <bool CACHE>
 __device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, const WalkLds &W, uint32_t lane) {
@@ -403,7 +405,7 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
 }
 
 template <bool LDS, bool CACHE>
-__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
+__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines, int vcap_words) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
@@ -413,11 +415,12 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines) {
   // LDS holds nf face bits + up to nf vertex bits (vertices are densely numbered; a table with more vertices than
   // faces keeps its vertex bitmap in global memory instead) + the record cache
   const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32;
-  const bool v_in_lds = LDS && vw <= fw;
-  WalkLds W = walk_lds_carve(lds, fw, lines);
+  const uint32_t vcw = (uint32_t)vcap_words;
+  const bool v_in_lds = LDS && vw <= vcw;
+  WalkLds W = walk_lds_carve(lds, fw, vcw, lines);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.fvis);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
-  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
+  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok || (!CACHE && lane != 0)) return;       // without the cache the 63 helper lanes have nothing to do
   if (!CACHE) {                                   // lane-0 walker: typed pointers per (face bits, vertex bits) placement
     if (LDS) {
@@ -723,7 +726,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
 }
 
 template <bool LDS, bool CACHE>
-__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines) {
+__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines, int vcap_words) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
   UVOL_SERIAL_PRIO();
@@ -733,11 +736,12 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines) {
   const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
   const int nf = (int)J.nf;
   const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32;
-  const bool v_in_lds = LDS && vw <= fw;
-  WalkLds W = walk_lds_carve(lds, fw, lines & 0xff);
+  const uint32_t vcw = (uint32_t)vcap_words;
+  const bool v_in_lds = LDS && vw <= vcw;
+  WalkLds W = walk_lds_carve(lds, fw, vcw, lines & 0xff);
   uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
   uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
-  if (LDS) { if (ok) for (uint32_t k = lane; k < 2 * fw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
+  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok || (!CACHE && lane != 0)) return;
 #ifndef HIPEMU
   const unsigned long long t_begin = (lines & 0x100) ? wall_clock64() : 0ull;
@@ -1604,7 +1608,15 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
   const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
-  const size_t walk_lds = (((size_t)2 * walk_fw + WALK_LINES + 3) & ~(size_t)3) * 4;          // bitmaps (+ tag words)
+  // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
+  // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
+  // whatever fits the same number of walkers per CU, so the slack of the LDS slot is not wasted.
+  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4, tag_bytes = (size_t)WALK_LINES * 4;
+  const size_t v_min_bytes = std::min<size_t>((((size_t)max_vals + max_vals / 16 + 31) / 32 + 2) * 4, ((3 * (size_t)max_nfi + 31) / 32) * 4);
+  size_t per_cu = lds_cu / (fw_bytes + v_min_bytes + tag_bytes); if (per_cu < 1) per_cu = 1;
+  const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
+  const size_t walk_vcw = slot > fw_bytes + tag_bytes + v_min_bytes ? (slot - fw_bytes - tag_bytes) / 4 : v_min_bytes / 4;
+  const size_t walk_lds = ((walk_fw + walk_vcw + WALK_LINES + 3) & ~(size_t)3) * 4;                 // bitmaps (+ tag words)
   static const int walk_lines = [] { const char *e = getenv("UVOL_WALK_LINES"); int v = e ? atoi(e) : WALK_LINES; int p2 = 1; while (p2 * 2 <= v && p2 * 2 <= WALK_LINES) p2 *= 2; return p2; }();
   const size_t walk_lds_c = walk_lds + (size_t)walk_lines * 64 * 32;                              // + record cache
   const bool use_lds = walk_lds <= G->max_lds;
@@ -1618,9 +1630,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     DENSE_TABLE(0);
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj, walk_lines);
-    else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, 1);
-    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 1);
+    if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj, walk_lines, (int)walk_vcw);
+    else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, 1, (int)walk_vcw);
+    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 1, 0);
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
@@ -1651,9 +1663,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    if (use_cache_t) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj, walk_lines);
-    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, 1 | (uvol_debug() ? 0x100 : 0));
-    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 1);
+    if (use_cache_t) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj, walk_lines, (int)walk_vcw);
+    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, 1 | (uvol_debug() ? 0x100 : 0), (int)walk_vcw);
+    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 1, 0);
     LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
   }
   {
