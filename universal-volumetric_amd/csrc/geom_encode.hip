@@ -548,7 +548,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nev = (int)J.bsum2[uvol_blocks_dev(J.nf)];
 }
 
-// valence bookkeeping replay: ctx_of[i] = context (0..5) under which symbol i-1 is coded (i >= 1)
+// valence bookkeeping replay: ctx_of[i] = context (0..5) under which symbol i-1 is coded (i >= 1).
+// The context of symbol i is the clamped valence of the vertex at next(corner_i) just before i updates it.  Between two
+// split symbols valences only receive fixed decrements (C: n-1 p-1; R: a-1 n-1 p-2; L: a-1 n-2 p-1; E: a-2 n-2 p-2), so
+// a run of up to 64 symbols is resolved by the whole wave at once: lane j reads the run-start valence of its vertex
+// and subtracts what lanes k < j apply to that same vertex (one pass of v_readlane broadcasts), then every lane posts
+// its three decrements with atomic adds.  Only an S symbol (vertex split: ring walks + corner re-mapping) is serial.
 __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
@@ -561,6 +566,7 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
   const int nv0 = ok ? (int)J.nverts_t[0] : 0;
   for (int i = (int)lane; i < (ok ? nc : 0); i += 64) c2vm[i] = J.vert[i];
   for (int i = (int)lane; i < nv0; i += 64) vval[i] = J.ring_d[i];
+  __threadfence();
   __syncthreads();
   int nvval = nv0;
   for (int base = 0; base < nsym; base += 64) {
@@ -569,38 +575,55 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
     int c_ = 0, s_ = 0, va_ = 0, vn_ = 0, vp_ = 0;
     if (mi < nsym) { c_ = proc[mi]; s_ = symb[mi]; va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
     const int cnt = nsym - base < 64 ? nsym - base : 64;
-    for (int j = 0; j < cnt; j++) {
-      const int i = base + j;
-      const int lc = (int)UVOL_READLANE(c_, j), sym = (int)UVOL_READLANE(s_, j);
-      int ia = (int)UVOL_READLANE(va_, j), in_ = (int)UVOL_READLANE(vn_, j), ip = (int)UVOL_READLANE(vp_, j);
-      bool remapped = false;
-      if (lane == 0) {
-        const int nx = g_nxt(lc), pv = g_prv(lc);
-        // the three corners of a face are three distinct vertex instances: issue the three loads together
-        // (one memory round trip per symbol instead of three serialised read-modify-writes)
-        const int val_n = vval[in_], val_p = vval[ip], val_a = vval[ia];
-        const int active_valence = val_n;
-        if (sym == 0 || sym == 1) {
-          vval[in_] = val_n - 1; vval[ip] = val_p - 1;
-          if (sym == 1) {
-            int nleft = 0, a = opp[pv];
-            while (a >= 0) { if (ftime[a / 3] <= i) break; nleft++; a = opp[g_nxt(a)]; }
-            vval[ia] = nleft + 1;
-            const int newv = nvval; int nright = 0; a = opp[nx];
-            while (a >= 0) { if (ftime[a / 3] <= i) break; nright++; c2vm[g_nxt(a)] = newv; a = opp[g_prv(a)]; }
-            vval[nvval] = nright + 1;
-          }
-        } else if (sym == 5) { vval[ia] = val_a - 1; vval[in_] = val_n - 1; vval[ip] = val_p - 2; }
-        else if (sym == 3) { vval[ia] = val_a - 1; vval[in_] = val_n - 2; vval[ip] = val_p - 1; }
-        else { vval[ia] = val_a - 2; vval[in_] = val_n - 2; vval[ip] = val_p - 2; }
-        if (i > 0) { const int cv = active_valence < 2 ? 2 : (active_valence > 7 ? 7 : active_valence); J.ctx_of[i] = (uint8_t)(cv - 2); }
-      }
-      if (sym == 1) { nvval++; remapped = true; }
-      if (remapped) {               // wave-uniform: refresh the not-yet-consumed vertex ids of this chunk
-        __threadfence_block();
+    // decrements of this lane's symbol, packed a | n << 2 | p << 4
+    const uint32_t dpk = s_ == 0 ? 0x14u : (s_ == 5 ? 0x25u : (s_ == 3 ? 0x19u : 0x2au));
+    int start = 0;
+    while (start < cnt) {
+      const unsigned long long smask = __ballot((int)lane >= start && (int)lane < cnt && s_ == 1);
+      const int e = smask ? (int)(__ffsll((long long)smask) - 1) : cnt;          // first split symbol of [start, cnt)
+      if (e > start) {                                                          // run [start, e) without a split
+        const bool act = (int)lane >= start && (int)lane < e;
+        const int v_start = act ? UVOL_ALOAD(&vval[vn_]) : 0;
+        int acc = 0;
+        for (int k = start; k + 1 < e; k++) {
+          const int ka = (int)UVOL_READLANE(va_, k), kn = (int)UVOL_READLANE(vn_, k), kp = (int)UVOL_READLANE(vp_, k);
+          const uint32_t kd = UVOL_READLANE(dpk, k);
+          const int hit = (vn_ == ka ? (int)(kd & 3u) : 0) + (vn_ == kn ? (int)((kd >> 2) & 3u) : 0) + (vn_ == kp ? (int)(kd >> 4) : 0);
+          acc += (int)lane > k ? hit : 0;
+        }
+        if (act) {
+          const int av = v_start - acc;
+          if (mi > 0) { const int cv = av < 2 ? 2 : (av > 7 ? 7 : av); J.ctx_of[mi] = (uint8_t)(cv - 2); }
+          if (dpk & 3u) UVOL_AADD(&vval[va_], -(int)(dpk & 3u));
+          UVOL_AADD(&vval[vn_], -(int)((dpk >> 2) & 3u));
+          UVOL_AADD(&vval[vp_], -(int)(dpk >> 4));
+        }
+        __threadfence();
         UVOL_WAVE_SYNC();
-        if (mi < nsym && (int)lane > j) { va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
       }
+      if (e < cnt) {                                                            // the split symbol: serial, lane 0
+        const int i = base + e;
+        const int lc = (int)UVOL_READLANE(c_, e);
+        const int ia = (int)UVOL_READLANE(va_, e), in_ = (int)UVOL_READLANE(vn_, e), ip = (int)UVOL_READLANE(vp_, e);
+        if (lane == 0) {
+          const int nx = g_nxt(lc), pv = g_prv(lc);
+          const int val_n = UVOL_ALOAD(&vval[in_]), val_p = UVOL_ALOAD(&vval[ip]);
+          UVOL_ASTORE(&vval[in_], val_n - 1); UVOL_ASTORE(&vval[ip], val_p - 1);
+          int nleft = 0, a = opp[pv];
+          while (a >= 0) { if (ftime[a / 3] <= i) break; nleft++; a = opp[g_nxt(a)]; }
+          UVOL_ASTORE(&vval[ia], nleft + 1);
+          const int newv = nvval; int nright = 0; a = opp[nx];
+          while (a >= 0) { if (ftime[a / 3] <= i) break; nright++; c2vm[g_nxt(a)] = newv; a = opp[g_prv(a)]; }
+          UVOL_ASTORE(&vval[nvval], nright + 1);
+          if (i > 0) { const int cv = val_n < 2 ? 2 : (val_n > 7 ? 7 : val_n); J.ctx_of[i] = (uint8_t)(cv - 2); }
+        }
+        nvval++;
+        // refresh the not-yet-consumed vertex ids of this chunk (corners right of the split now map to the new vertex)
+        __threadfence();
+        UVOL_WAVE_SYNC();
+        if (mi < nsym && (int)lane > e) { va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
+      }
+      start = e + 1;
     }
   }
 }

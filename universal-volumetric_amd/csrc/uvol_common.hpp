@@ -53,6 +53,18 @@
 #define UVOL_OR_NORET(p, v) ((void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #endif
 
+// device-scope relaxed atomics on global words (L2-coherent: loads bypass the per-CU L1) for data that lanes of one wave
+// update with atomic adds and read back later; plain operations in the shim (one OS thread runs a whole workgroup)
+#ifdef HIPEMU
+#define UVOL_ALOAD(p) (*(p))
+#define UVOL_ASTORE(p, v) ((void)(*(p) = (v)))
+#define UVOL_AADD(p, v) ((void)(*(p) += (v)))
+#else
+#define UVOL_ALOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define UVOL_ASTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define UVOL_AADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#endif
+
 // dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
 #ifdef HIPEMU
 #define UVOL_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu_dyn_smem)
