@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
+    ap.add_argument("--geo-stagger-ms", type=float, default=0.0, help="one-time start delay of geometry stream g: g * this")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
     ap.add_argument("--cu-split", type=int, default=0, help="16*G+T: CU residue masks (mod 4) for the geometry / texture streams, e.g. 0x7*16+0x8 = 120")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
@@ -113,31 +115,47 @@ def main():
         else:
             out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
 
-    def step():
-        th = [threading.Thread(target=run_geo, args=(gi,)) for gi in range(GS) if args.only != "tex"] + \
-             [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs)) if args.only != "geo"]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        out["ktx2"] = [k for ti in range(len(texs)) for k in out.get("ktx2_%d" % ti, [])]
-        out["drc"] = [k for gi in range(GS) for k in out.get("drc_%d" % gi, [])]
+    def steps(k):
+        """k passes over the batch.  Every stream (geometry sub-batch / texture share) runs its k passes back to back on its
+        own host thread; with --lockstep all streams meet at a barrier after every pass instead.  --geo-stagger-ms delays
+        geometry stream g by g * that much once, so that the streams' serial phases interleave instead of colliding."""
+        def loop(fn, arg, delay):
+            if delay > 0:
+                time.sleep(delay)
+            for _ in range(k):
+                fn(arg)
+        if args.lockstep:
+            for _ in range(k):
+                th = [threading.Thread(target=run_geo, args=(gi,)) for gi in range(GS) if args.only != "tex"] + \
+                     [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs)) if args.only != "geo"]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+        else:
+            th = [threading.Thread(target=loop, args=(run_geo, gi, gi * args.geo_stagger_ms * 1e-3)) for gi in range(GS) if args.only != "tex"] + \
+                 [threading.Thread(target=loop, args=(run_tex, ti, 0.0)) for ti in range(len(texs)) if args.only != "geo"]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        out["ktx2"] = [k_ for ti in range(len(texs)) for k_ in out.get("ktx2_%d" % ti, [])]
+        out["drc"] = [k_ for gi in range(GS) for k_ in out.get("drc_%d" % gi, [])]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        steps(args.warmup)
     for g in geos:
         g.profile(True); g.profile_reset()
     for t in texs:
         t.profile(True); t.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     # manifest gather (SURVEY §8e): {frames, segments, layers in last segment, bytes} per rank
     import shard
     nbytes = sum(len(x) for x in out["drc"]) + sum(len(x) for x in out["ktx2"])

@@ -40,6 +40,7 @@ struct alignas(8) uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) int4 { int x, y, z, w; };
 inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 extern thread_local hipemu_uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 extern thread_local char *hipemu_dyn_smem;

@@ -78,8 +78,10 @@ struct GeoJob {
   RansStream rs[GEO_NSTREAM];
   RabsStream rb[GEO_NRABS];
   uint8_t *arena; uint32_t arena_cap;
+  uint8_t *ws_base; uint64_t ws_zero;          // zero-initialised head of this job's workspace (k_job_clear)
   const uint8_t *piece_ptr[GEO_MAXPIECES]; uint32_t piece_len[GEO_MAXPIECES], piece_off[GEO_MAXPIECES]; uint32_t n_pieces;
   uint8_t *out; uint32_t out_cap;
+  uint8_t *out_pack; uint64_t out_pack_off;     // packed output area of the batch + this frame's offset in it (k_out_offsets)
 };
 
 #define GEO_INV (-1)

@@ -1373,12 +1373,18 @@ __global__ void __launch_bounds__(64) k_layout(GeoJob *jobs) {
   J.out_len = total;
   if (total > J.out_cap) J.status = UVOL_E_NOSPACE;
 }
+// the frames' bitstreams are gathered back to back (16-byte aligned) so that the host fetches the whole batch with ONE copy
+__global__ void __launch_bounds__(64) k_out_offsets(GeoJob *jobs, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t off = 0;
+  for (int i = 0; i < n; i++) { jobs[i].out_pack_off = off; if (jobs[i].status == 0) off += ((uint64_t)jobs[i].out_len + 15) & ~(uint64_t)15; }
+}
 __global__ void __launch_bounds__(UVOL_BLOCK) k_gather(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.z];
   if (J.status != 0) return;
   const uint32_t pc = blockIdx.y;
   if (pc >= J.n_pieces) return;
-  const uint8_t *src = J.piece_ptr[pc]; uint8_t *dst = J.out + J.piece_off[pc]; const uint32_t len = J.piece_len[pc];
+  const uint8_t *src = J.piece_ptr[pc]; uint8_t *dst = J.out_pack + J.out_pack_off + J.piece_off[pc]; const uint32_t len = J.piece_len[pc];
   for (uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x; i < len; i += gridDim.x * UVOL_BLOCK) dst[i] = src[i];
 }
 
@@ -1461,7 +1467,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
     CARVE(J.rs[s].freq, uint32_t, J.rs[s].alpha_cap);
   }
   *zero_bytes = (C.off + 255) & ~(size_t)255;
-  // ---- 0x7f-filled region (face encode times start at +inf) ----
+  // ---- face encode times (preset to -1 by k_pack_faces, filled by k_face_time) ----
   CARVE(J.face_time, int32_t, nfi + 1);
   *fill7f_bytes = ((C.off + 255) & ~(size_t)255) - *zero_bytes;
   // ---- the rest ----
@@ -1545,6 +1551,14 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     LAUNCH(k_dense_apply, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));              \
   } while (0)
 
+// zero the hash tables / visited maps / histograms at the head of every job's workspace
+__global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  uint4 *p = reinterpret_cast<uint4 *>(J.ws_base);
+  const size_t n16 = (size_t)(J.ws_zero / 16);
+  for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * UVOL_BLOCK) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   GeoState *G = ctx->geo;
@@ -1584,9 +1598,8 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     uint8_t *base = (uint8_t *)G->slab.p + ws_off[i];
     size_t zb, f7; layout_job(J, base, &zb, &f7);
-    UVOL_HIP_CHECK(ctx, hipMemsetAsync(base, 0, zero_sz[i], ctx->stream));
-    UVOL_HIP_CHECK(ctx, hipMemsetAsync(base + zb, 0x7f, f7, ctx->stream));
-    J.out = (uint8_t *)G->outs.p + out_off[i];
+    J.ws_base = base; J.ws_zero = zero_sz[i];          // cleared by ONE k_job_clear launch for the whole batch (was 2 memsets per frame)
+    J.out = (uint8_t *)G->outs.p + out_off[i]; J.out_pack = (uint8_t *)G->outs.p;
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
     else {
       uint8_t *ib = (uint8_t *)G->inputs.p + in_off[i]; size_t o = 0;
@@ -1610,6 +1623,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->jobs.p, G->hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   GeoJob *dj = (GeoJob *)G->jobs.p;
   const unsigned N = (unsigned)n;
+  LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals);
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
@@ -1720,21 +1734,35 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     uvol_ctx::Scope sc(ctx, "geo.k8_layout_gather", 0);
     LAUNCH(k_layout, dim3(N), dim3(64), dj);
+    LAUNCH(k_out_offsets, dim3(1), dim3(64), dj, n);
     LAUNCH(k_gather, dim3(64, GEO_MAXPIECES, N), dim3(UVOL_BLOCK), dj);
   }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->hjobs.data(), dj, sizeof(GeoJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   int worst = UVOL_OK;
+  // one device-to-host copy of the packed bitstreams into pinned staging, then plain memcpy into the caller's buffers
+  size_t packed = 0;
+  for (int i = 0; i < n; i++) { const GeoJob &J = G->hjobs[i]; if (J.status == 0) packed = std::max<size_t>(packed, (size_t)J.out_pack_off + J.out_len); }
+  if (packed > G->pinned_cap) {
+    if (G->pinned) (void)hipHostFree(G->pinned);
+    G->pinned = nullptr; G->pinned_cap = 0;
+    const size_t want = packed + packed / 4 + (1u << 20);
+    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&G->pinned, want, hipHostMallocDefault));
+    G->pinned_cap = want;
+  }
+  if (packed) {
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->pinned, G->outs.p, packed, hipMemcpyDeviceToHost, ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   for (int i = 0; i < n; i++) {
     const GeoJob &J = G->hjobs[i];
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
     out_lens[i] = J.out_len;
-    if (st == UVOL_OK) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(outs[i], J.out, J.out_len, hipMemcpyDeviceToHost, ctx->stream));
+    if (st == UVOL_OK) memcpy(outs[i], G->pinned + J.out_pack_off, J.out_len);
     else { ctx->set_error("mesh %d: encode failed (device status %d)", i, J.status); worst = st; }
     if (status) status[i] = st;
   }
-  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
   return status ? UVOL_OK : worst;
 }

@@ -136,11 +136,15 @@ class Codec:
 
     def _run_batch(self, fn, meshes, n, raise_on_error):
         caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)()
-        bufs = []
+        bufs = getattr(self, "_obufs", [])          # output buffers are kept between calls (no fresh pages to fault in per batch)
+        while len(bufs) < n:
+            bufs.append(np.empty(0, dtype=np.uint8))
         for i in range(n):
             cap = self.L.uvol_mesh_bound(C.byref(meshes[i]))
-            b = np.empty(cap, dtype=np.uint8); bufs.append(b)
-            caps[i] = cap; outs[i] = b.ctypes.data
+            if bufs[i].size < cap:
+                bufs[i] = np.empty(cap, dtype=np.uint8)
+            caps[i] = cap; outs[i] = bufs[i].ctypes.data
+        self._obufs = bufs
         rc = fn(self.h, meshes, n, outs, caps, lens, st)
         if rc != UVOL_OK:
             raise UvolError(f"encode_mesh_batch rc={rc}: {self.error()}")
