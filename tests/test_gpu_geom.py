@@ -2,7 +2,7 @@
 import os
 import numpy as np
 import pytest
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from helpers import check_roundtrip
 
 pytestmark = pytest.mark.gpu
@@ -83,13 +83,21 @@ def test_gpu_edge_cases_and_quantisation_bits(oracle, gpu_codec):
         c2.close()
 
 
-def test_gpu_both_walker_variants(oracle, monkeypatch):
-    """The serial walkers have two forms (64 lanes + LDS record cache / lane 0 only); both must be bit-exact."""
-    import synth, uvol
-    frames = [synth.torus_mesh(16, 8), synth.sphere_mesh(120, 61, charts=(12, 6), frame=3), synth.grid_mesh()]
-    for v in ("1", "0"):
-        monkeypatch.setenv("UVOL_WALK_CACHE", v)
-        c = uvol.Codec(device=0)
-        for f, r in zip(frames, c.encode_mesh_batch(frames)):
-            assert r == _oracle_bytes(oracle, f)
-        c.close()
+def test_gpu_walker_bitmap_placements(oracle):
+    """The serial walkers keep their visited bitmaps in LDS, fall back to a global vertex bitmap when a table has more
+    vertices than the LDS slot holds, and to global memory altogether for meshes too large for LDS: all bit-exact.
+    (UVOL_WALK_FORCE is read once per process, so each placement runs in its own interpreter.)"""
+    import subprocess, sys, os
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import synth, uvol\nimport oracle as o\n"
+        "o.lib(); c = uvol.Codec(device=0)\n"
+        "frames = [synth.torus_mesh(16, 8), synth.sphere_mesh(120, 61, charts=(12, 6), frame=3), synth.grid_mesh()]\n"
+        "for f, r in zip(frames, c.encode_mesh_batch(frames)):\n"
+        "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
+    for force in ("", "vglobal", "global"):
+        env = dict(os.environ, UVOL_WALK_FORCE=force)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (force, r.stdout[-500:], r.stderr[-1500:])

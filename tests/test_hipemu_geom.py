@@ -53,3 +53,23 @@ def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
         c2 = uvol.Codec(lib_path=hipemu_lib, Q_POSITION_ATTR=qp, Q_TEXTURE_ATTR=qt, Q_NORMAL_ATTR=qn)
         assert c2.encode_mesh(**m) == oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=qp, qt=qt, qn=qn)
         c2.close()
+
+
+@pytest.mark.parametrize("force", ["vglobal", "global"])
+def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
+    """Visited bitmaps in LDS (default, covered above), vertex bitmap in global memory (a table with more vertices than
+    the LDS slot), everything in global memory (mesh too large for LDS): same bytes.  UVOL_WALK_FORCE is read once per
+    process, hence the fresh interpreter."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import synth, uvol\nimport oracle as o\n"
+        "o.lib(); c = uvol.Codec(lib_path=%r)\n"
+        "frames = [synth.torus_mesh(), synth.sphere_mesh(40, 21, charts=(5, 4)), synth.grid_mesh()]\n"
+        "for f, r in zip(frames, c.encode_mesh_batch(frames)):\n"
+        "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_WALK_FORCE=force), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

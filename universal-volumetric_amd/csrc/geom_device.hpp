@@ -85,6 +85,8 @@ struct GeoJob {
 };
 
 #define GEO_INV (-1)
+// corner codes for the serial walkers: 4 * face + k, so that face = code >> 2 and records are indexed without a division
+__device__ __forceinline__ int code_of_corner(int c) { return c < 0 ? -1 : (((c / 3) << 2) | (c % 3)); }
 __device__ __host__ __forceinline__ uint32_t uvol_blocks_dev(uint32_t n) { return (n + 255u) / 256u; }
 __device__ __host__ __forceinline__ int g_nxt(int c) { return (c % 3 == 2) ? c - 2 : c + 1; }
 __device__ __host__ __forceinline__ int g_prv(int c) { return (c % 3 == 0) ? c + 2 : c - 1; }

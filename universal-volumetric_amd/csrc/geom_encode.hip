@@ -204,12 +204,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 
 // ------------------------------------------------------------------------------------------------
 // K4: valence edgebreaker — split into
-//   k_pack_faces   (parallel)  32-byte per-face records {opp[3], (vertex<<1|open)[3]} so a walker needs ONE load per face
-//   k_eb_walk      (serial)    MeshEdgebreakerEncoderImpl::EncodeConnectivity traversal only: symbols, processed corners,
-//                              face encode times; visited faces / vertices are bitmaps in LDS
+//   k_pack_faces   (parallel)  16-byte per-corner records {vertex<<1|open, right, left, opposite} indexed by corner code
+//                              4*face+k, so a walker step is ONE load and no division / select
+//   k_eb_walk      (serial)    MeshEdgebreakerEncoderImpl::EncodeConnectivity traversal only: symbols + processed corners;
+//                              visited faces / vertices are bitmaps in LDS (k_face_time inverts proc[] afterwards)
 //   k_eb_events    (parallel)  topology-split events from (symbol, neighbour symbol) pairs, order-preserving compaction
-//   k_eb_valence   (serial)    MeshEdgebreakerTraversalValenceEncoder bookkeeping replayed over the known symbol
-//                              sequence (all addresses known in advance -> lanes prefetch a chunk of 64 symbols)
+//   k_eb_valence   (1 wave)    MeshEdgebreakerTraversalValenceEncoder bookkeeping replayed over the known symbol
+//                              sequence: runs between split symbols are resolved by all 64 lanes at once
 //   k_eb_ctx       (1 wave)    ballot-ordered scatter of the symbols into the 6 valence-context streams
 // (SURVEY A.3 / A.10).  The serial kernels run one frame per workgroup; a batch keeps that many CUs busy.
 // ------------------------------------------------------------------------------------------------
@@ -256,78 +257,34 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
   const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
   const int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
   const uint8_t *vopen = J.vopen_d[which];
-  int32_t *rec = J.rec[which] + 8 * (size_t)f;
-  int r[8];
+  int r[3], vc[3];
   for (int k = 0; k < 3; k++) {
     const int c = 3 * (int)f + k;
     r[k] = (seam && seam[c]) ? GEO_INV : opp[c];
     const int v = vert[c];
-    r[3 + k] = (v << 1) | (vopen[v] ? 1 : 0);
+    vc[k] = (v << 1) | (vopen[v] ? 1 : 0);
   }
-  r[6] = 0; r[7] = 0;
-  int4 *dst = reinterpret_cast<int4 *>(rec);
-  dst[0] = make_int4(r[0], r[1], r[2], r[3]); dst[1] = make_int4(r[4], r[5], r[6], r[7]);
+  int4 *dst = reinterpret_cast<int4 *>(J.rec[which]) + 4 * (size_t)f;
+  for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
   if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
 
-struct FaceRec { int o[3]; int v[3]; };
-__device__ __forceinline__ FaceRec load_rec(const int32_t *rec, int f) {
-  const int4 *p = reinterpret_cast<const int4 *>(rec + 8 * (size_t)f);
-  const int4 a = p[0], b = p[1];
-  FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
-}
-// typed-pointer variants for the lane-0 walkers (P = UVOL_G / UVOL_L pointer)
+// typed-pointer helpers for the one-lane walkers (P = UVOL_G / UVOL_L pointer)
 #ifdef HIPEMU
 typedef int4 uvol_i4;
 #else
 typedef int uvol_i4 __attribute__((ext_vector_type(4)));      // loadable through an address-space-qualified pointer
 #endif
-template <typename P> __device__ __forceinline__ FaceRec load_rec_p(P rec4, int f) {
-  const uvol_i4 a = rec4[2 * (size_t)f], b = rec4[2 * (size_t)f + 1];
-  FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
-}
 template <typename P> __device__ __forceinline__ bool pbit_get(P w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 template <typename P> __device__ __forceinline__ void pbit_set(P w, int i) { UVOL_OR_NORET(&w[i >> 5], 1u << (i & 31)); }   // fire and forget
-__device__ __forceinline__ int sel3(const int a[3], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : a[2]); }
-__device__ __forceinline__ bool bit_get(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
-__device__ __forceinline__ void bit_set(uint32_t *w, int i) { w[i >> 5] |= 1u << (i & 31); }
+__device__ __forceinline__ int code_nxt(int x) { return (x & 3) == 2 ? x - 2 : x + 1; }
+__device__ __forceinline__ int code_prv(int x) { return (x & 3) == 0 ? x + 2 : x - 1; }
+__device__ __forceinline__ int corner_of_code(int x) { return 3 * (x >> 2) + (x & 3); }
 
-// Walker LDS layout: [face bits fw words][vertex bits vcw words][WALK_LINES tags][pad][WALK_LINES x 64 records of 32 B].
-// vcw is sized by the host from the input attribute counts (a table with more vertices keeps its vertex bitmap in
-// global memory): ~37 KiB instead of 50 KiB per walker for a 200k-face / 100k-vertex mesh, i.e. 4 walkers per CU.
-// The record cache is direct-mapped on groups of 64 consecutive faces; a miss is filled by the WHOLE wave with one
-// coalesced 2 KiB read (lane k fetches face 64*g + k), so the otherwise idle 63 lanes turn the walker's dependent
-// 32-byte HBM reads into LDS hits whenever the traversal stays inside recently touched face neighbourhoods.
-#define WALK_LINES 32
-struct WalkLds { uint32_t *fbits, *vbits, *gtag; int4 *cdata; uint32_t lmask; };
-__device__ __forceinline__ size_t walk_lds_words(uint32_t fw, uint32_t vcw) { return ((size_t)fw + vcw + WALK_LINES + 3) & ~(size_t)3; }
-__device__ __forceinline__ WalkLds walk_lds_carve(uint32_t *lds, uint32_t fw, uint32_t vcw, int lines) {
-  WalkLds w; w.lmask = (uint32_t)lines - 1u; w.fbits = lds; w.vbits = lds + fw; w.gtag = lds + fw + vcw; w.cdata = reinterpret_cast<int4 *>(lds + walk_lds_words(fw, vcw)); return w;
-}
-template <bool CACHE>
-__device__ __forceinline__ FaceRec walk_rec(const int32_t *rec, int f, int nf, const WalkLds &W, uint32_t lane) {
-  if (!CACHE) return load_rec(rec, f);
-  const uint32_t g = (uint32_t)f >> 6, line = g & W.lmask;
-  if (UVOL_READLANE(W.gtag[line], 0) != g + 1) {    // wave-uniform miss (lane 0's view of the tag): every lane fetches one record of the group
-    const int ff = (int)(g << 6) + (int)lane;
-    if (ff < nf) { const int4 *p = reinterpret_cast<const int4 *>(rec + 8 * (size_t)ff); const int4 a = p[0], b = p[1]; W.cdata[(line * 64 + lane) * 2] = a; W.cdata[(line * 64 + lane) * 2 + 1] = b; }
-    if (lane == 0) W.gtag[line] = g + 1;
-    __syncthreads();
-  }
-  const int4 a = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2], b = W.cdata[(line * 64 + ((uint32_t)f & 63)) * 2 + 1];
-  FaceRec r; r.o[0] = a.x; r.o[1] = a.y; r.o[2] = a.z; r.v[0] = a.w; r.v[1] = b.x; r.v[2] = b.y; return r;
-}
-// Lane 0 is the only reader/writer of the visited bitmaps and of the cache tags; its view is broadcast with v_readlane
-// so that all 64 lanes follow the same control flow without relying on lock-step LDS read-modify-write races.
-// (UNI = false: only lane 0 is alive — the plain lane-0 walker used when the record cache is off)
-template <bool UNI> __device__ __forceinline__ bool ubit_get(const uint32_t *w, int i) { if (!UNI) return bit_get(w, i); return UVOL_READLANE((uint32_t)bit_get(w, i), 0) != 0; }
-__device__ __forceinline__ void ubit_set(uint32_t *w, int i, uint32_t lane) { if (lane == 0) bit_set(w, i); }
-// lane 0 owns the explicit DFS stack in global memory; values are broadcast so that control flow stays wave-uniform
-template <bool UNI> __device__ __forceinline__ int walk_stack_top(const int32_t *stack, int sp, uint32_t lane) { if (!UNI) return stack[sp - 1]; int t = 0; if (lane == 0) t = stack[sp - 1]; return (int)UVOL_READLANE(t, 0); }
-
-// Lane-0 edgebreaker walk (the variant without the record cache): one lane, typed pointers, no scatter stores —
-// face_time is rebuilt from proc[] by k_face_time afterwards.  Per face: one 32-byte record read from HBM, one
-// sequential proc/symb store pair, a fire-and-forget ds_or for the face bit and LDS reads for the vertex / neighbour bits.
+// Edgebreaker walk, one lane per frame: typed pointers (global_* / ds_* instructions, exactly counted waits), no scatter
+// stores (face_time is rebuilt from proc[] by k_face_time).  Per face: ONE 16-byte record read from HBM — the dependent
+// access that bounds the walk —, one sequential proc/symb store pair, a fire-and-forget ds_or for the face bit and one
+// LDS round trip for the vertex / neighbour bits.  Corners are carried as codes (4 * face + k).
 template <typename FB, typename VB>
 __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   const int nf = (int)J.nf;
@@ -339,57 +296,57 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   for (int f0 = 0; f0 < nf; f0++) {
     if (pbit_get(fbits, f0)) continue;
-    const FaceRec r0 = load_rec_p(rec, f0);
-    int interior = 1, start_corner = 3 * f0;
+    const uvol_i4 q0 = rec[4 * (size_t)f0], q1 = rec[4 * (size_t)f0 + 1], q2 = rec[4 * (size_t)f0 + 2];
+    const int o0[3] = { q0.w, q1.w, q2.w }, v0[3] = { q0.x, q1.x, q2.x };
+    int interior = 1, start = 4 * f0;
     for (int k = 0; k < 3; k++) {
-      if (r0.o[k] < 0) { interior = 0; start_corner = 3 * f0 + k; break; }
-      if (r0.v[k] & 1) {              // boundary vertex: swing right to the boundary edge
-        int ci = 3 * f0 + k, rc = ci;
-        while (rc >= 0) { ci = rc; const FaceRec rr = load_rec_p(rec, rc / 3); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
-        interior = 0; start_corner = g_prv(ci); break;
+      if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
+      if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
+        int ci = 4 * f0 + k, rc = ci;
+        while (rc >= 0) { ci = rc; const int o = rec[rc].z; rc = o < 0 ? -1 : code_prv(o); }
+        interior = 0; start = code_prv(ci); break;
       }
     }
     start_bits[nstart] = (uint8_t)interior;
     nstart++;
     int from;
     if (interior) {
-      pbit_set(vbits, r0.v[0] >> 1); pbit_set(vbits, r0.v[1] >> 1); pbit_set(vbits, r0.v[2] >> 1);
+      pbit_set(vbits, v0[0] >> 1); pbit_set(vbits, v0[1] >> 1); pbit_set(vbits, v0[2] >> 1);
       pbit_set(fbits, f0);
       initc[ninit] = 3 * f0 + 1;
       ninit++;
-      from = r0.o[1];
-      if (from < 0 || pbit_get(fbits, from / 3)) continue;
-    } else from = start_corner;
+      from = o0[1];
+      if (from < 0 || pbit_get(fbits, from >> 2)) continue;
+    } else from = start;
     int sp = 0;
     stack[sp] = from;
     sp++;
     int top = from;                                   // value at stack[sp-1] when known without a load
     bool top_known = true;
     while (sp > 0) {
-      int corner = top_known ? top : stack[sp - 1];
+      int x = top_known ? top : stack[sp - 1];
       top_known = false;
-      if (corner < 0 || pbit_get(fbits, corner / 3)) { sp--; continue; }
+      if (x < 0 || pbit_get(fbits, x >> 2)) { sp--; continue; }
       for (;;) {
-        const int face = corner / 3, k = corner - 3 * face;
-        const FaceRec r = load_rec_p(rec, face);
-        proc[nproc] = corner;
+        const uvol_i4 q = rec[x];
+        const int face = x >> 2, vi = q.x, rcn = q.y, lcn = q.z;
+        proc[nproc] = 3 * face + (x & 3);
         pbit_set(fbits, face);
-        const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = vbits[v >> 5];
-        const uint32_t rw_ = rcn < 0 ? 0xffffffffu : fbits[(rcn / 3) >> 5], lw_ = lcn < 0 ? 0xffffffffu : fbits[(lcn / 3) >> 5];
-        int sym;
-        bool fresh_interior = false;
-        if (!((vw_ >> (v & 31)) & 1u)) { pbit_set(vbits, v); fresh_interior = !(vi & 1); }
-        if (fresh_interior) { symb[nproc] = T_C; nproc++; corner = rcn; continue; }
-        const bool rvis = rcn < 0 ? true : ((rw_ >> ((rcn / 3) & 31)) & 1u) != 0, lvis = lcn < 0 ? true : ((lw_ >> ((lcn / 3) & 31)) & 1u) != 0;
-        if (rvis) { if (lvis) { sym = T_E; } else { sym = T_R; } } else { sym = lvis ? T_L : T_S; }
+        const uint32_t rw_ = rcn < 0 ? 0xffffffffu : fbits[rcn >> 7], lw_ = lcn < 0 ? 0xffffffffu : fbits[lcn >> 7];
+        if (!((vw_ >> (v & 31)) & 1u)) {
+          pbit_set(vbits, v);
+          if (!(vi & 1)) { symb[nproc] = T_C; nproc++; x = rcn; continue; }
+        }
+        const bool rvis = ((rw_ >> ((rcn >> 2) & 31)) & 1u) != 0, lvis = ((lw_ >> ((lcn >> 2) & 31)) & 1u) != 0;
+        const int sym = rvis ? (lvis ? T_E : T_R) : (lvis ? T_L : T_S);
         symb[nproc] = (uint8_t)sym;
         nproc++;
         if (sym == T_E) { sp--; break; }
-        if (sym == T_R) { corner = lcn; continue; }
-        if (sym == T_L) { corner = rcn; continue; }
+        if (sym == T_R) { x = lcn; continue; }
+        if (sym == T_L) { x = rcn; continue; }
         nsplit++;
         stack[sp - 1] = lcn; stack[sp] = rcn;
         sp++; top = rcn; top_known = true;
@@ -404,99 +361,23 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   J.rb[0].zeros = z;
 }
 
-template <bool LDS, bool CACHE>
-__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int lines, int vcap_words) {
+// LDS: [face bits, fw words][vertex bits, vcap_words]; vcap_words is sized by the host from the input attribute counts and
+// the LDS slot (a table with more vertices keeps its vertex bitmap in global memory).  LDS = false: both in global memory.
+template <bool LDS>
+__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int vcap_words) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
   const uint32_t lane = threadIdx.x;
-  const int nf = (int)J.nf;
   const bool ok = J.status == 0;
-  // LDS holds nf face bits + up to nf vertex bits (vertices are densely numbered; a table with more vertices than
-  // faces keeps its vertex bitmap in global memory instead) + the record cache
-  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32;
-  const uint32_t vcw = (uint32_t)vcap_words;
+  const uint32_t fw = ((uint32_t)J.nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32, vcw = (uint32_t)vcap_words;
   const bool v_in_lds = LDS && vw <= vcw;
-  WalkLds W = walk_lds_carve(lds, fw, vcw, lines);
-  uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.fvis);
-  uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.vvis);
-  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
-  if (!ok || (!CACHE && lane != 0)) return;       // without the cache the 63 helper lanes have nothing to do
-  if (!CACHE) {                                   // lane-0 walker: typed pointers per (face bits, vertex bits) placement
-    if (LDS) {
-      if (v_in_lds) eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-      else eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
-    } else eb_walk_lane0(J, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis)), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
-    return;
-  }
-  const int32_t *rec = J.rec[0];
-  int32_t *proc = J.proc, *stack = J.stack; uint8_t *symb = J.symb;
-  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
-  enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
-  // every lane runs the same (wave-uniform) control flow; lane 0 performs the global stores
-  for (int f0 = 0; f0 < nf; f0++) {
-    if (ubit_get<CACHE>(fbits, f0)) continue;
-    const FaceRec r0 = walk_rec<CACHE>(rec, f0, nf, W, lane);
-    int interior = 1, start_corner = 3 * f0;
-    for (int k = 0; k < 3; k++) {
-      if (r0.o[k] < 0) { interior = 0; start_corner = 3 * f0 + k; break; }
-      if (r0.v[k] & 1) {              // boundary vertex: swing right to the boundary edge
-        int ci = 3 * f0 + k, rc = ci;
-        while (rc >= 0) { ci = rc; const FaceRec rr = walk_rec<CACHE>(rec, rc / 3, nf, W, lane); const int o = sel3(rr.o, (rc % 3 + 2) % 3); rc = o < 0 ? -1 : g_prv(o); }
-        interior = 0; start_corner = g_prv(ci); break;
-      }
-    }
-    if (lane == 0) J.start_bits[nstart] = (uint8_t)interior;
-    nstart++;
-    int from;
-    if (interior) {
-      ubit_set(vbits, r0.v[0] >> 1, lane); ubit_set(vbits, r0.v[1] >> 1, lane); ubit_set(vbits, r0.v[2] >> 1, lane);
-      ubit_set(fbits, f0, lane);
-      if (lane == 0) J.initc[ninit] = 3 * f0 + 1;
-      ninit++;
-      from = r0.o[1];
-      if (from < 0 || ubit_get<CACHE>(fbits, from / 3)) continue;
-    } else from = start_corner;
-    int sp = 0;
-    if (lane == 0) stack[sp] = from;
-    sp++;
-    int top = from;                                   // value at stack[sp-1] when known without a load
-    bool top_known = true;
-    while (sp > 0) {
-      int corner = top_known ? top : walk_stack_top<CACHE>(stack, sp, lane);
-      top_known = false;
-      if (corner < 0 || ubit_get<CACHE>(fbits, corner / 3)) { sp--; continue; }
-      for (;;) {
-        const int face = corner / 3, k = corner - 3 * face;
-        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
-        ubit_set(fbits, face, lane);
-        const int vi = sel3(r.v, k), rcn = sel3(r.o, (k + 1) % 3), lcn = sel3(r.o, (k + 2) % 3);
-        if (lane == 0) proc[nproc] = corner;
-        int sym;
-        const int v = vi >> 1;
-        bool fresh_interior = false;
-        if (!ubit_get<CACHE>(vbits, v)) { ubit_set(vbits, v, lane); fresh_interior = !(vi & 1); }
-        if (fresh_interior) { if (lane == 0) symb[nproc] = T_C; nproc++; corner = rcn; continue; }
-        const bool rvis = rcn < 0 ? true : ubit_get<CACHE>(fbits, rcn / 3), lvis = lcn < 0 ? true : ubit_get<CACHE>(fbits, lcn / 3);
-        if (rvis) { if (lvis) { sym = T_E; } else { sym = T_R; } } else { sym = lvis ? T_L : T_S; }
-        if (lane == 0) symb[nproc] = (uint8_t)sym;
-        nproc++;
-        if (sym == T_E) { sp--; break; }
-        if (sym == T_R) { corner = lcn; continue; }
-        if (sym == T_L) { corner = rcn; continue; }
-        nsplit++;
-        if (lane == 0) { stack[sp - 1] = lcn; stack[sp] = rcn; }
-        sp++; top = rcn; top_known = true;
-        break;
-      }
-    }
-  }
-  if (lane != 0) return;
-  J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
-  if (nproc + ninit != nf) J.status = -10;
-  J.rb[0].n = (uint32_t)nstart;
-  uint32_t z = 0; for (int i = 0; i < nstart; i++) z += J.start_bits[i] == 0;
-  J.rb[0].zeros = z;
+  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0; __syncthreads(); }
+  if (!ok || lane != 0) return;
+  if (LDS) {
+    if (v_in_lds) eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+    else eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+  } else eb_walk_lane0(J, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis)), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
 }
 
 // face_time[f] = index of the symbol that encoded face f (-1 for the faces that only start a component): the inverse
@@ -514,7 +395,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs) {
   if (i >= J.ne[t]) return;
   if (t > 0 && (t - 1 >= J.nad || !J.interior_seams[t - 1])) return;
   const int c = J.order[t][i];
-  J.v2d[t][J.rec[1 + t][8 * (size_t)(c / 3) + 3 + c % 3] >> 1] = (int32_t)i;
+  J.v2d[t][J.rec[1 + t][4 * (size_t)code_of_corner(c)] >> 1] = (int32_t)i;
 }
 
 // topology-split events (CheckAndStoreTopologySplitEvent): symbol i contributes an event for each already-encoded
@@ -701,11 +582,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: DepthFirstTraverser — serial per (table, frame).  t=0 base table, t=1,2 attribute tables.
-// One 32-byte record load per face; visited faces / vertices are bitmaps in LDS.
+// K5: DepthFirstTraverser — serial per (table, frame), one lane each.  t=0 base table, t=1,2 attribute tables.
+// One 16-byte record load per face; visited faces / vertices are bitmaps in LDS; order[] is the only output stream
+// (v2d[], its inverse, is rebuilt by k_v2d).  Same structure as eb_walk_lane0.
 // ------------------------------------------------------------------------------------------------
-// Lane-0 DepthFirstTraverser (variant without the record cache): typed pointers, order[] is the only output stream —
-// v2d[] (its inverse) is rebuilt by k_v2d afterwards.
 template <typename FB, typename VB>
 __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vbits) {
   const int nf = (int)J.nf;
@@ -714,33 +594,32 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   int n = 0;
   for (int f = 0; f < nf; f++) {
     if (pbit_get(fbits, f)) continue;
-    int cid = 3 * f, sp = 0;
-    stack[sp] = cid;
+    int x = 4 * f, sp = 0;
+    stack[sp] = x;
     sp++;
-    int top = cid; bool top_known = true;
-    { const FaceRec r0 = load_rec_p(rec, f); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
-      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); order[n] = cid + 1; n++; }
-      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); order[n] = cid + 2; n++; } }
+    int top = x; bool top_known = true;
+    { const int vn = rec[x + 1].x >> 1, vp = rec[x + 2].x >> 1;
+      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); order[n] = 3 * f + 1; n++; }
+      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); order[n] = 3 * f + 2; n++; } }
     while (sp > 0) {
-      cid = top_known ? top : stack[sp - 1];
+      x = top_known ? top : stack[sp - 1];
       top_known = false;
-      if (cid < 0 || pbit_get(fbits, cid / 3)) { sp--; continue; }
+      if (x < 0 || pbit_get(fbits, x >> 2)) { sp--; continue; }
       for (;;) {
-        const int face = cid / 3, k = cid - 3 * face;
-        const FaceRec r = load_rec_p(rec, face);
+        const uvol_i4 q = rec[x];
+        const int face = x >> 2, vi = q.x, rc = q.y, lc = q.z;
         pbit_set(fbits, face);
-        const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = vbits[v >> 5];
-        const uint32_t rw_ = rc < 0 ? 0xffffffffu : fbits[(rc / 3) >> 5], lw_ = lc < 0 ? 0xffffffffu : fbits[(lc / 3) >> 5];
+        const uint32_t rw_ = rc < 0 ? 0xffffffffu : fbits[rc >> 7], lw_ = lc < 0 ? 0xffffffffu : fbits[lc >> 7];
         if (!((vw_ >> (v & 31)) & 1u)) {
-          pbit_set(vbits, v); order[n] = cid; n++;
-          if (!(vi & 1)) { cid = rc; continue; }
+          pbit_set(vbits, v); order[n] = 3 * face + (x & 3); n++;
+          if (!(vi & 1)) { x = rc; continue; }
         }
-        const bool rvis = rc < 0 ? true : ((rw_ >> ((rc / 3) & 31)) & 1u) != 0, lvis = lc < 0 ? true : ((lw_ >> ((lc / 3) & 31)) & 1u) != 0;
-        if (rvis) { if (lvis) { sp--; break; } cid = lc; }
-        else { if (lvis) cid = rc; else { stack[sp - 1] = lc; stack[sp] = rc; sp++; top = rc; top_known = true; break; } }
+        const bool rvis = ((rw_ >> ((rc >> 2) & 31)) & 1u) != 0, lvis = ((lw_ >> ((lc >> 2) & 31)) & 1u) != 0;
+        if (rvis) { if (lvis) { sp--; break; } x = lc; }
+        else { if (lvis) x = rc; else { stack[sp - 1] = lc; stack[sp] = rc; sp++; top = rc; top_known = true; break; } }
       }
     }
   }
@@ -748,8 +627,8 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   if (t == 0 && (uint32_t)n != J.nverts) J.status = -11;
 }
 
-template <bool LDS, bool CACHE>
-__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines, int vcap_words) {
+template <bool LDS>
+__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, int dbg) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
   UVOL_SERIAL_PRIO();
@@ -757,67 +636,20 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int lines, int vc
   const uint32_t lane = threadIdx.x;
   const int ai = t > 0 ? t - 1 : 0;
   const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
-  const int nf = (int)J.nf;
-  const uint32_t fw = ((uint32_t)nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32;
-  const uint32_t vcw = (uint32_t)vcap_words;
+  const uint32_t fw = ((uint32_t)J.nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32, vcw = (uint32_t)vcap_words;
   const bool v_in_lds = LDS && vw <= vcw;
-  WalkLds W = walk_lds_carve(lds, fw, vcw, lines & 0xff);
-  uint32_t *fbits = LDS ? W.fbits : reinterpret_cast<uint32_t *>(J.t_fvis[t]);
-  uint32_t *vbits = v_in_lds ? W.vbits : reinterpret_cast<uint32_t *>(J.t_vvis[t]);
-  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw + (CACHE ? WALK_LINES : 0); k += 64) lds[k] = 0; __syncthreads(); }
-  if (!ok || (!CACHE && lane != 0)) return;
+  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0; __syncthreads(); }
+  if (!ok || lane != 0) return;
 #ifndef HIPEMU
-  const unsigned long long t_begin = (lines & 0x100) ? wall_clock64() : 0ull;
-#define TRAVERSE_DBG() if ((lines & 0x100) && blockIdx.y == 0 && lane == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5)
-#else
-#define TRAVERSE_DBG()
+  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
 #endif
-  if (!CACHE) {
-    if (LDS) {
-      if (v_in_lds) traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-      else traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
-    } else traverse_lane0(J, t, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t])), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
-    TRAVERSE_DBG();
-    return;
-  }
-  const int32_t *rec = J.rec[1 + t];
-  int32_t *stack = J.t_stack[t], *order = J.order[t];
-  int n = 0;
-#define T_VISIT(vid, c) do { ubit_set(vbits, (vid), lane); if (lane == 0) order[n] = (c); n++; } while (0)
-#define T_FVIS(c) ((c) < 0 ? true : ubit_get<CACHE>(fbits, (c) / 3))
-  for (int f = 0; f < nf; f++) {
-    if (ubit_get<CACHE>(fbits, f)) continue;
-    int cid = 3 * f, sp = 0;
-    if (lane == 0) stack[sp] = cid;
-    sp++;
-    int top = cid; bool top_known = true;
-    { const FaceRec r0 = walk_rec<CACHE>(rec, f, nf, W, lane); const int vn = r0.v[1] >> 1, vp = r0.v[2] >> 1;
-      if (!ubit_get<CACHE>(vbits, vn)) T_VISIT(vn, cid + 1);
-      if (!ubit_get<CACHE>(vbits, vp)) T_VISIT(vp, cid + 2); }
-    while (sp > 0) {
-      cid = top_known ? top : walk_stack_top<CACHE>(stack, sp, lane);
-      top_known = false;
-      if (cid < 0 || ubit_get<CACHE>(fbits, cid / 3)) { sp--; continue; }
-      for (;;) {
-        const int face = cid / 3, k = cid - 3 * face;
-        const FaceRec r = walk_rec<CACHE>(rec, face, nf, W, lane);
-        ubit_set(fbits, face, lane);
-        const int vi = sel3(r.v, k), rc = sel3(r.o, (k + 1) % 3), lc = sel3(r.o, (k + 2) % 3);
-        const int v = vi >> 1;
-        if (!ubit_get<CACHE>(vbits, v)) {
-          T_VISIT(v, cid);
-          if (!(vi & 1)) { cid = rc; continue; }
-        }
-        if (T_FVIS(rc)) { if (T_FVIS(lc)) { sp--; break; } cid = lc; }
-        else { if (T_FVIS(lc)) cid = rc; else { if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; } sp++; top = rc; top_known = true; break; } }
-      }
-    }
-  }
-#undef T_VISIT
-#undef T_FVIS
-  if (lane != 0) return;
-  J.ne[t] = (uint32_t)n;
-  if (t == 0 && (uint32_t)n != J.nverts) J.status = -11;
+  if (LDS) {
+    if (v_in_lds) traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+    else traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+  } else traverse_lane0(J, t, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t])), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+#ifndef HIPEMU
+  if (dbg && blockIdx.y == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, (int)J.nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1413,10 +1245,8 @@ int geo_create(uvol_ctx *ctx) {
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->geo->max_lds = (size_t)v;
   const size_t want = ctx->geo->max_lds;
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ctx->geo->num_cu = v;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   (void)hipGetLastError();
 #else
   ctx->geo->max_lds = 160 * 1024;
@@ -1477,7 +1307,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
   CARVE(J.opp, int32_t, nc + 3); CARVE(J.vert, int32_t, nc + 3); CARVE(J.ring, int32_t, nc + 3); CARVE(J.vopen, uint8_t, nc + 3);
   CARVE(J.vval, int32_t, nc + nfi + 3); CARVE(J.c2vm, int32_t, nc + 3);
   CARVE(J.proc, int32_t, nfi + 1); CARVE(J.initc, int32_t, nfi + 1); CARVE(J.stack, int32_t, nfi + 2);
-  for (int w = 0; w < 4; w++) { CARVE(J.rec[w], int32_t, 8 * (nfi + 1)); CARVE(J.vopen_d[w], uint8_t, nc + 3); }
+  for (int w = 0; w < 4; w++) { CARVE(J.rec[w], int32_t, 16 * (nfi + 1)); CARVE(J.vopen_d[w], uint8_t, nc + 3); }
   CARVE(J.dflag, uint8_t, nc + 3); CARVE(J.dtmp, int32_t, nc + 3); CARVE(J.ring_d, int32_t, nc + 3);
   CARVE(J.symb, uint8_t, nfi + 64); CARVE(J.ctx_of, uint8_t, nfi + 64);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2); CARVE(J.ev_spl, int32_t, 2 * nfi + 2); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2);
@@ -1648,28 +1478,21 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
   // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
   // whatever fits the same number of walkers per CU, so the slack of the LDS slot is not wasted.
-  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4, tag_bytes = (size_t)WALK_LINES * 4;
+  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4;
   const size_t v_min_bytes = std::min<size_t>((((size_t)max_vals + max_vals / 16 + 31) / 32 + 2) * 4, ((3 * (size_t)max_nfi + 31) / 32) * 4);
-  size_t per_cu = lds_cu / (fw_bytes + v_min_bytes + tag_bytes); if (per_cu < 1) per_cu = 1;
+  size_t per_cu = lds_cu / (fw_bytes + v_min_bytes); if (per_cu < 1) per_cu = 1;
   const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
-  const size_t walk_vcw = slot > fw_bytes + tag_bytes + v_min_bytes ? (slot - fw_bytes - tag_bytes) / 4 : v_min_bytes / 4;
-  const size_t walk_lds = ((walk_fw + walk_vcw + WALK_LINES + 3) & ~(size_t)3) * 4;                 // bitmaps (+ tag words)
-  static const int walk_lines = [] { const char *e = getenv("UVOL_WALK_LINES"); int v = e ? atoi(e) : WALK_LINES; int p2 = 1; while (p2 * 2 <= v && p2 * 2 <= WALK_LINES) p2 *= 2; return p2; }();
-  const size_t walk_lds_c = walk_lds + (size_t)walk_lines * 64 * 32;                              // + record cache
-  const bool use_lds = walk_lds <= G->max_lds;
-  // the record cache costs 64 KiB of LDS per walker: only worth it while every walker can still have a CU of its own
-  // (n edgebreaker walkers, 3n attribute traversers).  UVOL_WALK_CACHE overrides: bit 0 = walker, bit 1 = traversers.
-  static const int cache_env = [] { const char *e = getenv("UVOL_WALK_CACHE"); return e ? atoi(e) : -1; }();
-  const bool cache_fits = walk_lds_c <= G->max_lds;
-  const bool use_cache = cache_fits && (cache_env >= 0 ? (cache_env & 1) != 0 : 3 * n <= G->num_cu);
-  const bool use_cache_t = cache_fits && (cache_env >= 0 ? (cache_env & 2) != 0 : 3 * n <= G->num_cu);
+  // UVOL_WALK_FORCE (tests): "vglobal" = vertex bitmaps in global memory, "global" = both bitmaps in global memory
+  static const int walk_force = [] { const char *e = getenv("UVOL_WALK_FORCE"); return !e ? 0 : (!strcmp(e, "vglobal") ? 1 : (!strcmp(e, "global") ? 2 : 0)); }();
+  const size_t walk_vcw = walk_force == 1 ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
+  const size_t walk_lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4;
+  const bool use_lds = walk_lds <= G->max_lds && walk_force != 2;
   {
     DENSE_TABLE(0);
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_cache) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds_c, dj, walk_lines, (int)walk_vcw);
-    else if (use_lds) LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, 1, (int)walk_vcw);
-    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 1, 0);
+    if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj, (int)walk_vcw);
+    else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj, 0);
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
@@ -1700,9 +1523,8 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    if (use_cache_t) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds_c, dj, walk_lines, (int)walk_vcw);
-    else if (use_lds) LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, 1 | (uvol_debug() ? 0x100 : 0), (int)walk_vcw);
-    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 1, 0);
+    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj, (int)walk_vcw, uvol_debug() ? 1 : 0);
+    else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj, 0, 0);
     LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
   }
   {
