@@ -33,13 +33,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=240)
+    ap.add_argument("--frames-per-step", type=int, default=480)
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
-    ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
+    ap.add_argument("--geo-streams", type=int, default=2, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
