@@ -156,64 +156,31 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_zero(TexJob *job, int force) 
 }
 // leaf statistics: LDS-privatised counters (CT = u64 for weighted cells, u32 for unit-weight selector
 // vectors whose per-workgroup partial sums cannot overflow) for the first LCAP leaves, global atomics beyond
+// (leaf_base: the statistics of leaves [leaf_base, leaf_base + LCAP) — one pass per LCAP leaves of the codebook, so no
+//  leaf ever falls back to contended global atomics; a pass whose range is beyond the current leaf count returns at once)
 template <int DIM, int LCAP, typename CT>
-__global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force, uint32_t leaf_base) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[DIM == 4 ? 0 : 1];
-  if (V.done && !force) return;
+  if ((V.done && !force) || V.nl <= leaf_base) return;
   UVOL_DYN_SMEM(CT, lds);                       // [LCAP * (1 + 2*DIM)]
-  const uint32_t nl = V.nl, ncap = nl < (uint32_t)LCAP ? nl : (uint32_t)LCAP, stride = 1 + 2 * DIM;
+  const uint32_t nl = V.nl - leaf_base, ncap = nl < (uint32_t)LCAP ? nl : (uint32_t)LCAP, stride = 1 + 2 * DIM;
   for (uint32_t k = threadIdx.x; k < ncap * stride; k += UVOL_BLOCK) lds[k] = 0;
   __syncthreads();
-  const uint32_t lane = threadIdx.x & 63;
   for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
     const uint32_t i = base + threadIdx.x;
-    bool todo = i < V.n_items;
+    const bool todo = i < V.n_items;
     const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
-    if (DIM == 16) {
-      // Unit-weight selector vectors: while the wave's items sit in few leaves (the contended early
-      // rounds) count with ballots — c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 —
-      // and let 33 lanes post one add each; whatever is left after 4 leaders takes the atomic path.
-      const uint32_t sw = todo ? J.bsel[J.item[i]] : 0;
-      unsigned long long rem = __ballot(todo);
-      for (int rounds = 0; rounds < 4 && rem; rounds++) {
-        const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
-        const uint32_t ll = UVOL_READLANE(l, leader);
-        const bool inm = todo && l == ll;
-        const unsigned long long m = __ballot(inm);
-        uint32_t myv = 0;
-        for (int d = 0; d < 16; d++) {
-          const uint32_t xv = (sw >> (2 * d)) & 3u;
-          const uint32_t c1 = (uint32_t)__popcll(__ballot(inm && xv == 1)), c2 = (uint32_t)__popcll(__ballot(inm && xv == 2)), c3 = (uint32_t)__popcll(__ballot(inm && xv == 3));
-          if (lane == (uint32_t)(1 + d)) myv = c1 + 2 * c2 + 3 * c3;
-          if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
-        }
-        if (lane == 0) myv = (uint32_t)__popcll(m);
-        if (lane < 33 && myv) {
-          if (ll < ncap) atomicAdd(&lds[(size_t)ll * stride + lane], (CT)myv);
-          else if (lane == 0) atomicAdd(&V.stW[ll], (unsigned long long)myv);
-          else if (lane <= 16) atomicAdd(&V.stS[(size_t)ll * DIM + (lane - 1)], (unsigned long long)myv);
-          else atomicAdd(&V.stQ[(size_t)ll * DIM + (lane - 17)], (unsigned long long)myv);
-        }
-        rem &= ~m;
-        if (inm) todo = false;
-      }
-    }
-    if (!todo) continue;
+    if (!todo || l < leaf_base || l - leaf_base >= ncap) continue;          // other leaves: another pass
     int x[DIM]; unsigned long long w; vq_item<DIM>(J, i, x, w);
-    if (l < ncap) {
-      CT *p = lds + (size_t)l * stride;
-      atomicAdd(&p[0], (CT)w);
-      for (int d = 0; d < DIM; d++) { atomicAdd(&p[1 + d], (CT)(w * (unsigned long long)x[d])); atomicAdd(&p[1 + DIM + d], (CT)(w * (unsigned long long)(x[d] * x[d]))); }
-    } else {
-      atomicAdd(&V.stW[l], w);
-      for (int d = 0; d < DIM; d++) { atomicAdd(&V.stS[(size_t)l * DIM + d], w * (unsigned long long)x[d]); atomicAdd(&V.stQ[(size_t)l * DIM + d], w * (unsigned long long)(x[d] * x[d])); }
-    }
+    CT *p = lds + (size_t)(l - leaf_base) * stride;
+    atomicAdd(&p[0], (CT)w);
+    for (int d = 0; d < DIM; d++) { atomicAdd(&p[1 + d], (CT)(w * (unsigned long long)x[d])); atomicAdd(&p[1 + DIM + d], (CT)(w * (unsigned long long)(x[d] * x[d]))); }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < ncap * stride; k += UVOL_BLOCK) {
     const unsigned long long v = (unsigned long long)lds[k]; if (!v) continue;
-    const uint32_t l = k / stride, f = k % stride;
+    const uint32_t l = leaf_base + k / stride, f = k % stride;
     if (f == 0) atomicAdd(&V.stW[l], v);
     else if (f <= (uint32_t)DIM) atomicAdd(&V.stS[(size_t)l * DIM + (f - 1)], v);
     else atomicAdd(&V.stQ[(size_t)l * DIM + (f - 1 - DIM)], v);
@@ -1041,23 +1008,23 @@ inline void put16(uint8_t *&p, uint16_t v) { memcpy(p, &v, 2); p += 2; }
   } while (0)
 
 template <int DIM, int LCAP, typename CT>
-static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG) {
+static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG, uint32_t kmax) {
   const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   const unsigned kb = uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM);
   const unsigned sb = std::min<unsigned>(item_blocks, 512u);
   for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
     TLAUNCH((k_vq_zero<DIM>), dim3(kb), dim3(UVOL_BLOCK), 0, dj, 0);
-    TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(sb), dim3(UVOL_BLOCK), shmem, dj, 0);
+    for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(sb), dim3(UVOL_BLOCK), shmem, dj, 0, lb);
     TLAUNCH((k_vq_decide<DIM>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_apply<DIM>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_advance<DIM>), dim3(1), dim3(64), 0, dj);
   }
 }
 template <int DIM, int LCAP, typename CT>
-static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG) {
+static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG, uint32_t kmax) {
   const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   TLAUNCH((k_vq_zero<DIM>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM)), dim3(UVOL_BLOCK), 0, dj, 1);
-  TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1);
+  for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1, lb);
 }
 
 // selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
@@ -1123,9 +1090,9 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     TLAUNCH(k_tscan_b, dim3(1), dim3(UVOL_BLOCK), 0, dj, bcell);
     TLAUNCH(k_cell_compact, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_cell_leaf_init, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
-    run_vq_rounds<4, 800, unsigned long long>(ctx, dj, bcell, NSEG);
+    run_vq_rounds<4, 800, unsigned long long>(ctx, dj, bcell, NSEG, J.Kmax_e);
     for (int it = 0; it <= 2; it++) {
-      run_vq_stats<4, 800, unsigned long long>(ctx, dj, bcell, NSEG);
+      run_vq_stats<4, 800, unsigned long long>(ctx, dj, bcell, NSEG, J.Kmax_e);
       TLAUNCH(k_ep_entries, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
       if (it < 2) TLAUNCH(k_ep_assign, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
     }
