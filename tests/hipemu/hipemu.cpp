@@ -88,6 +88,8 @@ void hipemu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
   const int nthreads = (int)(block.x * block.y * block.z);
   if (nthreads > MAXT || nthreads <= 0) { fprintf(stderr, "hipemu: bad block size %d\n", nthreads); abort(); }
   const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  // one kernel at a time: several host threads (e.g. uvolenc's geometry and texture stages) share the helper pool
+  static std::mutex launch_mu; std::lock_guard<std::mutex> launch_guard(launch_mu);
   static int ncores = [] { int n = (int)std::thread::hardware_concurrency(); const char *e = getenv("HIPEMU_THREADS"); if (e) n = atoi(e); return n < 1 ? 1 : (n > 16 ? 16 : n); }();
   const int nworkers = (int)std::min<size_t>((size_t)ncores, nblocks);
   std::atomic<size_t> next{0};

@@ -30,6 +30,14 @@ def test_uvolenc_end_to_end(oracle, tmp_path):
     t = man["texture"]["targets"]["ktx2"]
     assert (t["sequenceCount"], t["sequenceSize"], t["resolution"]) == (3, 5, [64, 64])
     assert "Frames and frame rates are compatible" in r.stdout
+    # every URL the stock player would request resolves to a file uvolenc wrote (node re-statement of the
+    # player's template substitution, tests/player_urls.js)
+    import shutil
+    if shutil.which("node"):
+        urls = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "player_urls.js"), os.path.join(out, "uvol.json")], text=True))
+        assert len(urls["geometry"]) == 12 and len(urls["texture"]) == 3 and urls["batchSize"] == 5
+        for rel in urls["geometry"] + urls["texture"]:
+            assert os.path.isfile(os.path.join(out, rel)), rel
     assert json.load(open(os.path.join(out, "uvol.encoderpy.json")))["geometry"]["frameCount"] == 12
 
 

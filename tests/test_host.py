@@ -103,6 +103,19 @@ def test_manifest_is_playable_by_stock_player_url_templating(H):
     assert m["geometry"]["targets"][gt] == {"format": "draco", "frameRate": 30, "frameCount": 250}
 
 
+def test_manifest_urls_by_node_player_restatement(H, tmp_path):
+    """Same check through tests/player_urls.js (node 12): the manifest parses as v2 and yields the file names uvolenc writes."""
+    import shutil, subprocess
+    if not shutil.which("node"):
+        pytest.skip("node not available")
+    mp = tmp_path / "uvol.json"
+    mp.write_bytes(H.uvolh_manifest(json.dumps(CFG).encode(), 12, 3, 64, 64, 5, 0, b"", b""))
+    urls = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "player_urls.js"), str(mp)], text=True))
+    assert urls["geometry"] == ["geometry_draco/%05d.drc" % k for k in range(12)]
+    assert urls["texture"] == ["texture_ktx2_baseColor_default/%05d.ktx2" % k for k in range(3)]
+    assert (urls["geometryTarget"], urls["textureTarget"], urls["batchSize"]) == ("draco", "ktx2", 5)
+
+
 def test_obj_and_png_ingest(H, tmp_path):
     import synth
     from PIL import Image

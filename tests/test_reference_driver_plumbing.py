@@ -53,3 +53,30 @@ def test_shim_exit_codes(tmp_path):
     b = os.path.join(ROOT, "tests", "hipemu", "bin")
     assert subprocess.call([os.path.join(b, "draco_encoder"), "-i", str(tmp_path / "missing.obj"), "-o", str(tmp_path / "x.drc")], stderr=subprocess.DEVNULL) != 0
     assert subprocess.call([os.path.join(b, "basisu"), "-ktx2", "-multifile_printf", str(tmp_path / "m_%05u.png"), "-multifile_num", "2", "-output_file", str(tmp_path / "x.ktx2")], stderr=subprocess.DEVNULL) != 0
+
+
+def test_uvolenc_hipemu_pipeline(oracle, tmp_path):
+    """The uvolenc host driver linked against the tests/hipemu build (no GPU): several geometry batches (double-buffered
+    parallel OBJ ingest), full texture segments through the batched entry point plus a short last segment, both stages
+    running concurrently; every file byte-identical with the oracle and the manifest playable (tests/player_urls.js)."""
+    import shutil
+    import cli_helpers
+    pkg = os.path.join(ROOT, "universal-volumetric_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "hipemu-bins"])
+    cfgp, cfg, meshes, texs = cli_helpers.make_sequence(str(tmp_path), n_frames=7, tex=32, batch=3)
+    r = subprocess.run([os.path.join(ROOT, "tests", "hipemu", "bin", "uvolenc"), cfgp, "--batch-frames", "3", "--ingest-threads", "3"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = cfg["OutputDirectory"]
+    for k, m in enumerate(meshes):
+        got = open(os.path.join(out, "geometry_draco", "%05d.drc" % k), "rb").read()
+        assert got == oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"])
+    for s, n in enumerate([3, 3, 1]):
+        got = open(os.path.join(out, "texture_ktx2_baseColor_default", "%05d.ktx2" % s), "rb").read()
+        assert got == oracle.ktx2_encode(texs[3 * s:3 * s + n])
+    assert r.stdout.index("Obtained DRACO files") < r.stdout.index("Obtained KTX2 files")
+    if shutil.which("node"):
+        urls = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "player_urls.js"), os.path.join(out, "uvol.json")], text=True))
+        assert len(urls["geometry"]) == 7 and len(urls["texture"]) == 3
+        for rel in urls["geometry"] + urls["texture"]:
+            assert os.path.isfile(os.path.join(out, rel)), rel

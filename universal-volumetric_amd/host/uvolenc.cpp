@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <future>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 
@@ -18,6 +22,16 @@ static std::string dirname_of(const std::string &p) { size_t k = p.find_last_of(
 static std::string basename_of(const std::string &p) { size_t k = p.find_last_of('/'); return k == std::string::npos ? p : p.substr(k + 1); }
 static std::string join(const std::string &a, const std::string &b) { if (a.empty()) return b; if (!b.empty() && b[0] == '/') return b; return a + "/" + b; }
 
+// fn(k) for k in [0, n) on up to nthreads host threads (ingest: OBJ text parsing / PNG inflate; egress: file writes)
+static void parallel_for(size_t n, int nthreads, const std::function<void(size_t)> &fn) {
+  const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), n));
+  if (nt <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++) th.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(k); });
+  for (auto &t : th) t.join();
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { std::printf("❌ Invalid number of arguments. Please supply project-config.json as argument\n"); return 1; }
   if (!std::strcmp(argv[1], "create-template")) {
@@ -25,11 +39,12 @@ int main(int argc, char **argv) {
     if (!write_file("project-config-template.json", t.data(), t.size())) return 1;
     std::printf("✅ Written template object to project-config-template.json\n"); return 0;
   }
-  int n_gpus = 1, device0 = 0, frames_per_batch = 32; bool force = false, encpy = false;
+  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device0 = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--batch-frames") && i + 1 < argc) frames_per_batch = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) ingest_threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--force")) force = true;
     else if (!std::strcmp(argv[i], "--encoder-py-manifest")) encpy = true;
   }
@@ -45,86 +60,139 @@ int main(int argc, char **argv) {
   uvol_params prm; uvol_params_default(&prm);
   prm.q_position_attr = cfg.q_position; prm.q_texture_attr = cfg.q_texture; prm.q_normal_attr = cfg.q_normal; prm.q_generic_attr = cfg.q_generic;
   prm.draco_compression_level = cfg.compression_level; prm.ktx2_batch_size = cfg.ktx2_batch_size; prm.max_batch = frames_per_batch;
-  std::vector<uvol_ctx *> ctxs((size_t)n_gpus, nullptr);
-  for (int g = 0; g < n_gpus; g++) if (uvol_ctx_create(device0 + g, &prm, &ctxs[g]) != UVOL_OK) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
+  // one geometry and one texture context (= HIP stream) per GPU: the two stages of a GPU run side by side
+  std::vector<uvol_ctx *> ctxs((size_t)n_gpus, nullptr), tctxs((size_t)n_gpus, nullptr);
+  for (int g = 0; g < n_gpus; g++) if (uvol_ctx_create(device0 + g, &prm, &ctxs[g]) != UVOL_OK || uvol_ctx_create(device0 + g, &prm, &tctxs[g]) != UVOL_OK) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
+  if (ingest_threads <= 0) ingest_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / (2u * (unsigned)n_gpus)));
 
   std::printf("🎯 Dealing with Geomety data\n");
   if (!cfg.abc_file_path.empty()) { std::printf("❌ ABCFilePath needs Blender (bpy); export OBJ files and use OBJFilesPath\n"); return 1; }
   const std::string geo_dir = join(cfg.output_directory, "geometry_draco");
   int pad = 5;
+  std::atomic<int> geo_failed{-1};
+  std::vector<std::thread> geo_threads;
+  std::vector<std::string> obj_files; std::string obj_dir;
   if (!cfg.obj_files_path.empty()) {
     std::printf("🚧 Obtained OBJ files path\n");
-    const std::string dir = dirname_of(cfg.obj_files_path), pat = basename_of(cfg.obj_files_path);
+    obj_dir = dirname_of(cfg.obj_files_path); const std::string pat = basename_of(cfg.obj_files_path);
     { int h = (int)std::count(pat.begin(), pat.end(), '#'); if (h > 0) pad = h; }
-    std::vector<std::string> files; for (auto &f : list_dir(dir)) if (match_pattern_lenient(pat, f)) files.push_back(f);
+    for (auto &f : list_dir(obj_dir)) if (match_pattern_lenient(pat, f)) obj_files.push_back(f);
     if (!make_dirs(geo_dir)) return 1;
-    std::atomic<int> failed{-1};
-    // contiguous blocks of frames per GPU, each GPU encodes batches of frames_per_batch frames
-    std::vector<std::thread> th;
-    for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {
+    // contiguous blocks of frames per GPU; each GPU encodes batches of frames_per_batch frames.  The OBJ text
+    // of batch b+1 is parsed by the ingest threads while the GPU encodes batch b, .drc files are written in parallel.
+    struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; };
+    for (int g = 0; g < n_gpus; g++) geo_threads.emplace_back([&, g] {
+      const std::vector<std::string> &files = obj_files;
       const size_t lo = files.size() * (size_t)g / n_gpus, hi = files.size() * (size_t)(g + 1) / n_gpus;
-      for (size_t b0 = lo; b0 < hi && failed < 0; b0 += (size_t)frames_per_batch) {
-        const size_t nb = std::min(hi - b0, (size_t)frames_per_batch);
-        std::vector<ObjMesh> ms(nb); std::vector<uvol_mesh> um(nb); std::vector<std::vector<uint8_t>> outs(nb);
+      auto load = [&](size_t b0) {
+        auto B = std::make_shared<GeoBatch>(); B->b0 = b0; B->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; B->ms.resize(B->nb);
+        std::mutex mu;
+        parallel_for(B->nb, ingest_threads, [&](size_t k) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), B->ms[k], e)) { std::lock_guard<std::mutex> l(mu); if (B->bad < 0 || (int)k < B->bad) { B->bad = (int)k; B->err = e; } } });
+        return B;
+      };
+      std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo);
+      for (size_t b0 = lo; b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
+        std::shared_ptr<GeoBatch> B = nextb.get();
+        nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch);
+        const size_t nb = B->nb;
+        if (B->bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)B->bad].c_str(), B->err.c_str()); geo_failed = (int)(b0 + (size_t)B->bad); break; }
+        std::vector<uvol_mesh> um(nb); std::vector<std::vector<uint8_t>> outs(nb);
         std::vector<uint8_t *> op(nb); std::vector<size_t> caps(nb), lens(nb); std::vector<int> st(nb);
         for (size_t k = 0; k < nb; k++) {
-          std::string e; if (!read_obj(join(dir, files[b0 + k]), ms[k], e)) { std::printf("Failed to compress %s\n%s\n", files[b0 + k].c_str(), e.c_str()); failed = (int)(b0 + k); return; }
-          uvol_mesh &m = um[k]; std::memset(&m, 0, sizeof m);
-          m.pos = ms[k].pos.data(); m.n_pos = (uint32_t)ms[k].pos.size() / 3; m.idx_pos = ms[k].idx_pos.data(); m.n_faces = (uint32_t)ms[k].idx_pos.size() / 3;
-          if (!ms[k].uv.empty()) { m.uv = ms[k].uv.data(); m.n_uv = (uint32_t)ms[k].uv.size() / 2; m.idx_uv = ms[k].idx_uv.data(); }
-          if (!ms[k].nrm.empty()) { m.nrm = ms[k].nrm.data(); m.n_nrm = (uint32_t)ms[k].nrm.size() / 3; m.idx_nrm = ms[k].idx_nrm.data(); }
+          const ObjMesh &o = B->ms[k]; uvol_mesh &m = um[k]; std::memset(&m, 0, sizeof m);
+          m.pos = o.pos.data(); m.n_pos = (uint32_t)o.pos.size() / 3; m.idx_pos = o.idx_pos.data(); m.n_faces = (uint32_t)o.idx_pos.size() / 3;
+          if (!o.uv.empty()) { m.uv = o.uv.data(); m.n_uv = (uint32_t)o.uv.size() / 2; m.idx_uv = o.idx_uv.data(); }
+          if (!o.nrm.empty()) { m.nrm = o.nrm.data(); m.n_nrm = (uint32_t)o.nrm.size() / 3; m.idx_nrm = o.idx_nrm.data(); }
           caps[k] = uvol_mesh_bound(&m); outs[k].resize(caps[k]); op[k] = outs[k].data();
         }
-        if (uvol_encode_mesh_batch(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data()) != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); failed = (int)b0; return; }
-        for (size_t k = 0; k < nb; k++) {
-          if (st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); failed = (int)(b0 + k); return; }   // scripts/Encoder.py:263-266
-          char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, b0 + k);
-          if (!write_file(join(geo_dir, name), outs[k].data(), lens[k])) { failed = (int)(b0 + k); return; }
-        }
+        if (uvol_encode_mesh_batch(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data()) != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); geo_failed = (int)b0; break; }
+        for (size_t k = 0; k < nb; k++) if (st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); geo_failed = (int)(b0 + k); break; }   // scripts/Encoder.py:263-266
+        if (geo_failed >= 0) break;
+        std::atomic<int> wbad{-1};
+        parallel_for(nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, b0 + k); if (!write_file(join(geo_dir, name), outs[k].data(), lens[k])) wbad = (int)(b0 + k); });
+        if (wbad >= 0) { geo_failed = wbad.load(); break; }
       }
+      if (nextb.valid()) nextb.wait();
     });
-    for (auto &t : th) t.join();
-    if (failed >= 0) return 1;
-    cfg.draco_files_path = join(geo_dir, std::string((size_t)pad, '#') + ".drc");
   }
-  if (!cfg.draco_files_path.empty()) std::printf("✅ Obtained DRACO files\n");
 
   std::printf("🎯 Dealing with Texture data\n");
   const std::string tex_dir = join(cfg.output_directory, "texture_ktx2_baseColor_default");
   uint32_t tex_w = 0, tex_h = 0;
+  std::atomic<int> tex_failed{-1};
+  std::vector<std::thread> tex_threads;
+  std::vector<int> starts; std::string cpat;
   if (!cfg.images_path.empty()) {
     std::printf("🚧 Obtained Images path.\n");
-    const std::string cpat = convert_pounds_to_c_style(cfg.images_path);     // scripts/Encoder.py:274
+    cpat = convert_pounds_to_c_style(cfg.images_path);     // scripts/Encoder.py:274
     if (!make_dirs(tex_dir)) return 1;
-    std::vector<int> starts; for (int i = cfg.ktx2_first_file; i < cfg.ktx2_file_count; i += cfg.ktx2_batch_size) starts.push_back(i);   // :282-287
-    std::atomic<int> failed{-1};
-    std::vector<std::thread> th;
-    for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {
+    for (int i = cfg.ktx2_first_file; i < cfg.ktx2_file_count; i += cfg.ktx2_batch_size) starts.push_back(i);   // :282-287
+    // Segments of KTX2_BATCH_SIZE images are independent.  Full segments go to the GPU `segs_per_call` at a time
+    // through the batched entry point (one launch per stage for all of them); PNGs of the next call are inflated by the
+    // ingest threads meanwhile.  A short last segment (fewer layers) is encoded on its own.
+    const int segs_per_call = std::max(1, frames_per_batch / std::max(1, cfg.ktx2_batch_size));
+    struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::string err; int bad = -1; };
+    for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
       const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;
-      for (size_t s = lo; s < hi && failed < 0; s++) {
-        std::vector<Image> imgs; std::vector<const uint8_t *> ptrs;
-        for (int k = 0; k < cfg.ktx2_batch_size; k++) {
-          char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s] + k));
-          Image im; std::string e;
-          if (!read_png(path, im, e)) { if (k == 0 || starts[s] + k < cfg.ktx2_file_count) { std::printf("Failed to compress images with indices: [%d, %d]\n%s\n", starts[s], starts[s] + cfg.ktx2_batch_size, e.c_str()); failed = starts[s]; return; } break; }
-          if (!imgs.empty() && (im.w != imgs[0].w || im.h != imgs[0].h)) { std::printf("Failed to compress images with indices: [%d, %d]\nimage sizes differ\n", starts[s], starts[s] + cfg.ktx2_batch_size); failed = starts[s]; return; }
-          imgs.push_back(std::move(im));
+      const int B = cfg.ktx2_batch_size;
+      auto load = [&](size_t s0) {
+        auto T = std::make_shared<TexBatch>(); T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->imgs.resize(T->ns);
+        for (auto &v : T->imgs) v.resize((size_t)B);
+        std::mutex mu; std::vector<std::vector<uint8_t>> present(T->ns, std::vector<uint8_t>((size_t)B, 0));
+        parallel_for(T->ns * (size_t)B, ingest_threads, [&](size_t j) {
+          const size_t s = j / (size_t)B; const int k = (int)(j % (size_t)B);
+          char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s0 + s] + k));
+          std::string e;
+          if (read_png(path, T->imgs[s][(size_t)k], e)) present[s][(size_t)k] = 1;
+          else if (k == 0 || starts[s0 + s] + k < cfg.ktx2_file_count) { std::lock_guard<std::mutex> l(mu); if (T->bad < 0 || (int)s < T->bad) { T->bad = (int)s; T->err = e; } }
+        });
+        for (size_t s = 0; s < T->ns; s++) { size_t n = 0; while (n < (size_t)B && present[s][n]) n++; T->imgs[s].resize(n); }   // layers of a short last segment
+        return T;
+      };
+      auto fail = [&](int first, const char *why) { std::printf("Failed to compress images with indices: [%d, %d]\n%s\n", first, first + B, why); tex_failed = first; };   // :293-298
+      std::future<std::shared_ptr<TexBatch>> nextb = std::async(std::launch::async, load, lo);
+      for (size_t s0 = lo; s0 < hi && tex_failed < 0; s0 += (size_t)segs_per_call) {
+        std::shared_ptr<TexBatch> T = nextb.get();
+        nextb = std::async(std::launch::async, load, s0 + (size_t)segs_per_call);
+        if (T->bad >= 0) { fail(starts[s0 + (size_t)T->bad], T->err.c_str()); break; }
+        const uint32_t w = T->imgs[0][0].w, h = T->imgs[0][0].h; bool same = true;
+        for (auto &seg : T->imgs) for (auto &im : seg) if (im.w != w || im.h != h) same = false;
+        if (!same) { fail(starts[s0], "image sizes differ"); break; }
+        tex_w = w; tex_h = h;
+        std::vector<std::vector<uint8_t>> outs(T->ns); std::vector<size_t> lens(T->ns, 0);
+        // full segments: one batched call; segments with fewer layers: one call each
+        std::vector<size_t> full; for (size_t s = 0; s < T->ns; s++) if ((int)T->imgs[s].size() == B) full.push_back(s);
+        if (!full.empty()) {
+          std::vector<const uint8_t *> ptrs; std::vector<uint8_t *> op; std::vector<size_t> caps, ln(full.size(), 0);
+          for (size_t s : full) { for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data()); outs[s].resize(uvol_texture_bound(w, h, B)); op.push_back(outs[s].data()); caps.push_back(outs[s].size()); }
+          if (uvol_encode_texture_segments(tctxs[g], ptrs.data(), (int)full.size(), B, w, h, op.data(), caps.data(), ln.data()) != UVOL_OK) { fail(starts[s0 + full[0]], uvol_last_error(tctxs[g])); break; }
+          for (size_t q = 0; q < full.size(); q++) lens[full[q]] = ln[q];
         }
-        for (auto &im : imgs) ptrs.push_back(im.rgba.data());
-        tex_w = imgs[0].w; tex_h = imgs[0].h;
-        std::vector<uint8_t> out(uvol_texture_bound(tex_w, tex_h, (int)imgs.size())); size_t len = 0;
-        if (uvol_encode_texture_segment(ctxs[g], ptrs.data(), (int)ptrs.size(), tex_w, tex_h, out.data(), out.size(), &len) != UVOL_OK) {
-          std::printf("Failed to compress images with indices: [%d, %d]\n%s\n", starts[s], starts[s] + cfg.ktx2_batch_size, uvol_last_error(ctxs[g])); failed = starts[s]; return; }   // :293-298
-        char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s] - cfg.ktx2_first_file) / cfg.ktx2_batch_size);
-        if (!write_file(join(tex_dir, name), out.data(), len)) { failed = starts[s]; return; }
+        for (size_t s = 0; s < T->ns && tex_failed < 0; s++) if ((int)T->imgs[s].size() != B) {
+          std::vector<const uint8_t *> ptrs; for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data());
+          outs[s].resize(uvol_texture_bound(w, h, (int)ptrs.size()));
+          if (uvol_encode_texture_segment(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].data(), outs[s].size(), &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
+        }
+        if (tex_failed >= 0) break;
+        std::atomic<int> wbad{-1};
+        parallel_for(T->ns, ingest_threads, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].data(), lens[s])) wbad = starts[s0 + s]; });
+        if (wbad >= 0) { tex_failed = wbad.load(); break; }
       }
+      if (nextb.valid()) nextb.wait();
     });
-    for (auto &t : th) t.join();
-    if (failed >= 0) return 1;
-    cfg.ktx2_files_path = join(tex_dir, std::string((size_t)pad, '#') + ".ktx2");
   }
+  // both stages were started above and run concurrently (geometry and texture contexts of each GPU); join and report in
+  // the order the reference prints (scripts/Encoder.py:244-302)
+  for (auto &t : geo_threads) t.join();
+  if (geo_failed >= 0) { for (auto &t : tex_threads) t.join(); return 1; }
+  if (!cfg.obj_files_path.empty()) cfg.draco_files_path = join(geo_dir, std::string((size_t)pad, '#') + ".drc");
+  if (!cfg.draco_files_path.empty()) std::printf("✅ Obtained DRACO files\n");
+  for (auto &t : tex_threads) t.join();
+  if (tex_failed >= 0) return 1;
+  if (!cfg.images_path.empty()) cfg.ktx2_files_path = join(tex_dir, std::string((size_t)pad, '#') + ".ktx2");
   if (!cfg.ktx2_files_path.empty()) std::printf("✅ Obtained KTX2 files\n");
   for (auto *c : ctxs) uvol_ctx_destroy(c);
+  for (auto *c : tctxs) uvol_ctx_destroy(c);
 
   FrameCounts fc;
   if (!check_total_frames(cfg.draco_files_path, cfg.ktx2_files_path, cfg.ktx2_batch_size, cfg.geometry_frame_rate, cfg.texture_frame_rate, fc, err)) { std::printf("❌ %s\n", err.c_str()); return 1; }
