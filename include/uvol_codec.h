@@ -114,6 +114,21 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
                                      uint32_t width, uint32_t height,
                                      uint8_t *const *outs, const size_t *caps, size_t *out_lens);
 
+/* ---- decode path, texture half ----
+ * Replaces, for the RGBA32 target, what the stock player does per .ktx2 segment: KTX2Loader parses the container and
+ * hands every array layer to the basis transcoder (reference src/lib/KTX2Loader.js:469-580; src/V2/player.ts:338-356
+ * uploads the layers as one sampler2DArray).  Input: BasisLZ/ETC1S .ktx2 files as uvol_encode_texture_segment[s] or
+ * `basisu -ktx2 -tex_type video` write them (no alpha slices, one mip level).  Output: RGBA8, rows in stored order. */
+/* host-only: container dimensions of one file (UVOL_E_INVALID if it is not a KTX2/BasisLZ file this decoder handles) */
+int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, uint32_t *height, uint32_t *layers);
+/* n_segments files of one width / height / layer count; rgba[s * layers + l] receives width*height*4 bytes
+ * (layer_cap = size of each buffer).  One kernel launch per stage for the whole batch. */
+int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                 uint8_t *const *rgba, size_t layer_cap);
+/* Same, writing straight into device buffers (rgba_dev = host array of device pointers). */
+int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                     uint8_t *const *rgba_dev, size_t layer_cap);
+
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int uvol_profile_enable(uvol_ctx *ctx, int on);

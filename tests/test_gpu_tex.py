@@ -53,3 +53,52 @@ def test_gpu_batched_segments_equal_single_calls(oracle, gpu_codec):
     res = gpu_codec.encode_texture_segments(segs)
     for seg, r in zip(segs, res):
         assert r == oracle.ktx2_encode(seg)
+
+
+def test_gpu_texture_decode_matches_oracle(oracle, gpu_codec):
+    """Decode path (texture half) on the GPU against the pinned oracle decoder: the reference's own fixture
+    (Basis Universal 1.16, 1024x1024x5) and this codec's output; host and device output variants."""
+    import os, synth
+    from conftest import GOLDEN
+    fixture = open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read()
+    ours = [gpu_codec.encode_texture_segment(synth.texture_sequence(n, size=size, seed=seed)) for size, n, seed in [(64, 2, 1), (52, 3, 5), (256, 5, 2)]]
+    for data in [fixture] + ours:
+        want = oracle.ktx2_decode(data)
+        got = gpu_codec.decode_texture_segments([data])[0]
+        for l in range(want.n_slices):
+            assert np.array_equal(got[l], want.images[l]), l
+    # batched + device-resident outputs.  torch (device memory) must initialise its HIP runtime before the codec library is
+    # loaded, as in bench.py, hence a fresh interpreter.
+    import subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np, torch; torch.zeros(1, device='cuda:0')\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import synth, uvol, oracle as o\no.lib(); c = uvol.Codec(device=0)\n"
+        "segs = [c.encode_texture_segment(synth.texture_sequence(5, size=128, seed=s)) for s in (3, 4, 5)]\n"
+        "bufs = [torch.empty((5, 128, 128, 4), dtype=torch.uint8, device='cuda:0') for _ in segs]\n"
+        "c.decode_texture_segments_dev(segs, [b[l].data_ptr() for b in bufs for l in range(5)], 128 * 128 * 4)\n"
+        "torch.cuda.synchronize()\n"
+        "for d, b in zip(segs, bufs):\n"
+        "    w = o.ktx2_decode(d)\n"
+        "    assert all(np.array_equal(b[l].cpu().numpy(), w.images[l]) for l in range(5))\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_gpu_texture_roundtrip_at_bench_size(gpu_codec):
+    """Size-independent property at BASELINE's texture size: decode(encode(x)) is x within ETC1S quality (PSNR), for
+    every layer of a 2048x2048x5 segment, and skipped P-frame blocks reproduce the previous layer exactly."""
+    import synth
+    tex = synth.texture_sequence(5, size=2048, seed=11)
+    data = gpu_codec.encode_texture_segment(tex)
+    got = gpu_codec.decode_texture_segments([data])[0]
+    assert got.shape == (5, 2048, 2048, 4)
+    for l in range(5):
+        src = np.asarray(tex[l])[::-1].astype(np.float64)          # the encoder stores rows bottom-up (-y_flip)
+        mse = np.mean((src[..., :3] - got[l][..., :3].astype(np.float64)) ** 2)
+        psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-9))
+        assert psnr > 24.0, (l, psnr)
+        assert (got[l][..., 3] == 255).all()

@@ -9,3 +9,32 @@ def test_hipemu_texture_matches_oracle_bytes(oracle, hipemu_lib):
         tex = synth.texture_sequence(n, size=size, seed=seed)
         assert cd.encode_texture_segment(tex) == oracle.ktx2_encode(tex)
     cd.close()
+
+
+def test_hipemu_texture_decode_matches_oracle(oracle, hipemu_lib):
+    """Decode path: the HIP ETC1S/BasisLZ decoder, through the shim, against the pinned oracle decoder —
+    on the reference's own fixture (written by Basis Universal 1.16) and on this codec's output, ragged sizes included."""
+    import os, synth, uvol
+    from conftest import GOLDEN
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    fixture = open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read()
+    ours = [oracle.ktx2_encode(synth.texture_sequence(n, size=size, seed=seed)) for size, n, seed in [(64, 2, 1), (52, 3, 5)]]
+    for data in [fixture] + ours:
+        want = oracle.ktx2_decode(data)
+        assert cd.ktx2_info(data) == (want.width, want.height, want.n_slices)
+        got = cd.decode_texture_segments([data])[0]
+        assert got.shape == (want.n_slices, want.height, want.width, 4)
+        for l in range(want.n_slices):
+            assert np.array_equal(got[l], want.images[l]), l
+    # a batch of two segments in one call
+    two = [oracle.ktx2_encode(synth.texture_sequence(2, size=40, seed=s)) for s in (7, 8)]
+    for data, got in zip(two, cd.decode_texture_segments(two)):
+        want = oracle.ktx2_decode(data)
+        assert all(np.array_equal(got[l], want.images[l]) for l in range(2))
+    # error paths: truncated / foreign data is refused, never decoded by something else
+    import pytest
+    with pytest.raises(uvol.UvolError):
+        cd.decode_texture_segments([fixture[:90]])
+    with pytest.raises(uvol.UvolError):
+        cd.decode_texture_segments([b"\x00" * 200])
+    cd.close()

@@ -1,0 +1,394 @@
+// tex_decode.hip — batched KTX2 / BasisLZ ETC1S -> RGBA8 decode (texture half).
+// Replaces, for the RGBA32 target, the transcoder call the stock player makes per layer
+// (reference src/lib/KTX2Loader.js:469-580 -> basis_transcoder `transcodeImage`); the bitstream is SURVEY Appendix B.0-B.4.
+// Checked bit for bit in tests/ against a CPU restatement that is itself pinned on the reference's 50 .ktx2 fixtures.
+//
+// Structure (n segments per call, one launch per stage):
+//   host              container header + supercompression global data offsets (a few hundred bytes per file)
+//   k_tdec_tables     1 lane / segment: endpoint + selector codebooks (delta + Huffman), the four slice models
+//   k_tdec_slices     1 wave / segment: lanes build the decode LUTs in LDS, lane 0 walks the slices' VLC streams
+//                     (macroblock endpoint predictors + RLE, delta endpoints, selector history) -> per-block indices;
+//                     P-frame skips copy the previous slice, so the slices of a segment are decoded in order
+//   k_tdec_unpack     1 thread / block: (colour5, intensity table, 16 selectors) -> 16 RGBA8 texels, 16-byte row stores
+// Bound: the VLC walk is serial per segment (latency / scalar ALU), the unpack is HBM-write bound (4 B per texel).
+#include "uvol_common.hpp"
+
+#define TD_MAX_LAYERS 64
+#define TD_MAX_SYMS 16512          // >= TEX_MAX_CODEBOOK + history + RLE symbol
+#define TD_LUT_EPM 10
+#define TD_LUT_DEM 11
+#define TD_LUT_SM 11
+#define TD_LUT_RLE 8
+
+struct DHuff { uint32_t n, valid; uint32_t first_code[18], first_idx[18], count[18]; uint32_t *sorted; uint8_t *sizes; };
+
+struct TexDecJob {
+  const uint8_t *file; uint32_t file_len;
+  uint32_t width, height, layers, bx, by;
+  uint32_t ne, ns, ep_off, ep_len, sel_off, sel_len, tab_off, tab_len, level_off, level_len;
+  uint32_t slice_flags[TD_MAX_LAYERS], slice_off[TD_MAX_LAYERS], slice_len[TD_MAX_LAYERS];
+  uint8_t *endpoints;            // ne * 4: r5 g5 b5 inten
+  uint32_t *selectors;           // ns: byte j = row j, texel x at bits 2x..2x+1
+  uint16_t *ei, *si;             // layers * bx * by
+  DHuff hm[4];                   // epm, dem, sm, rle
+  DHuff tmp[5];                  // codebook models (3 colour-delta, intensity-delta, selector byte-delta)
+  uint32_t hist_size;
+  uint8_t *out[TD_MAX_LAYERS];   // device RGBA8 buffers, width * height * 4 each, rows in stored order
+  int32_t status;
+};
+
+// ---- LSB-first bit reader over global memory: aligned dwords, the next one always in flight ----
+struct DBits {
+  UVOL_G(const uint32_t) w; uint32_t nwords, wi, have, pre; unsigned long long win, consumed;
+};
+__device__ __forceinline__ void db_refill(DBits &B) {
+  while (B.have <= 32) { B.win |= (unsigned long long)B.pre << B.have; B.have += 32; B.wi++; B.pre = B.wi < B.nwords ? B.w[B.wi] : 0u; }
+}
+__device__ __forceinline__ void db_init(DBits &B, const uint8_t *p, uint32_t nbytes) {
+  const uint32_t a = (uint32_t)((size_t)p & 3);
+  B.w = UVOL_TO_G(const uint32_t, reinterpret_cast<const uint32_t *>(p - a));
+  B.nwords = (a + nbytes + 3) / 4; B.wi = 0; B.have = 0; B.win = 0; B.consumed = 0;
+  B.pre = B.nwords ? B.w[0] : 0u;
+  db_refill(B);
+  B.win >>= 8 * a; B.have -= 8 * a;
+}
+__device__ __forceinline__ uint32_t db_peek(DBits &B, uint32_t n) { if (B.have < n) db_refill(B); return (uint32_t)(B.win & ((1ull << n) - 1)); }
+__device__ __forceinline__ void db_skip(DBits &B, uint32_t n) { B.win >>= n; B.have -= n; B.consumed += n; }
+__device__ __forceinline__ uint32_t db_get(DBits &B, uint32_t n) { const uint32_t v = db_peek(B, n); db_skip(B, n); return v; }
+
+// ---- canonical (deflate-style) Huffman, max code length 16, codes matched MSB-first ----
+__device__ inline int dh_init(DHuff &H, uint32_t n) {     // H.sizes[0..n) filled
+  H.n = n; H.valid = 0;
+  for (int l = 0; l < 18; l++) { H.count[l] = 0; H.first_code[l] = 0; H.first_idx[l] = 0; }
+  for (uint32_t i = 0; i < n; i++) { const uint32_t s = H.sizes[i]; if (s > 16) return -1; if (s) H.count[s]++; }
+  uint32_t code = 0, idx = 0;
+  for (int l = 1; l <= 16; l++) { code = (code + H.count[l - 1]) << 1; H.first_code[l] = code; H.first_idx[l] = idx; idx += H.count[l]; }
+  uint32_t fill[18]; for (int l = 0; l < 18; l++) fill[l] = H.first_idx[l];
+  for (uint32_t i = 0; i < n; i++) { const uint32_t s = H.sizes[i]; if (s) H.sorted[fill[s]++] = i; }
+  H.valid = idx > 0;
+  return 0;
+}
+__device__ inline int dh_dec(const DHuff &H, DBits &B) {  // bit by bit (codebooks, and slice codes longer than the LUT)
+  uint32_t code = 0;
+  for (int l = 1; l <= 16; l++) {
+    code = (code << 1) | db_get(B, 1);
+    const uint32_t c = H.count[l];
+    if (c && code >= H.first_code[l] && code - H.first_code[l] < c) return (int)H.sorted[H.first_idx[l] + (code - H.first_code[l])];
+  }
+  return -1;
+}
+__device__ inline int d_read_huff(DBits &B, DHuff &out) {
+  const int ZZ[21] = { 17, 18, 19, 20, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 16 };
+  out.n = 0; out.valid = 0;
+  const uint32_t total = db_get(B, 14);
+  if (total == 0) return 0;
+  if (total > TD_MAX_SYMS) return -1;
+  const uint32_t ncl = db_get(B, 5); if (ncl < 1 || ncl > 21) return -1;
+  uint8_t cls[21]; uint32_t csorted[21];
+  for (int i = 0; i < 21; i++) cls[i] = 0;
+  for (uint32_t i = 0; i < ncl; i++) cls[ZZ[i]] = (uint8_t)db_get(B, 3);
+  DHuff clt; clt.sizes = cls; clt.sorted = csorted;
+  if (dh_init(clt, 21)) return -1;
+  uint32_t k = 0;
+  while (k < total) {
+    const int c = dh_dec(clt, B); if (c < 0) return -1;
+    if (c <= 16) out.sizes[k++] = (uint8_t)c;
+    else if (c == 17) { uint32_t r = 3 + db_get(B, 3); while (r-- && k < total + 200 && k < TD_MAX_SYMS + 256) out.sizes[k++] = 0; }
+    else if (c == 18) { uint32_t r = 11 + db_get(B, 7); while (r-- && k < total + 200 && k < TD_MAX_SYMS + 256) out.sizes[k++] = 0; }
+    else { uint32_t rep = c == 19 ? 3 + db_get(B, 2) : 7 + db_get(B, 7); if (k == 0) return -1; const uint8_t pv = out.sizes[k - 1]; while (rep-- && k < total + 200 && k < TD_MAX_SYMS + 256) out.sizes[k++] = pv; }
+  }
+  if (k != total) return -2;
+  return dh_init(out, total);
+}
+__device__ __forceinline__ uint32_t d_vlc(DBits &B, int cb) {
+  uint32_t v = 0; int ofs = 0;
+  for (;;) { const uint32_t s = db_get(B, (uint32_t)cb + 1); v |= (s & ((1u << cb) - 1)) << ofs; ofs += cb; if (!(s >> cb) || ofs > 28) break; }
+  return v;
+}
+
+// ---- K1: codebooks + slice models, one lane per segment ----
+__global__ void __launch_bounds__(64) k_tdec_tables(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.x];
+  if (threadIdx.x != 0 || J.status != 0) return;
+  const uint32_t ne = J.ne, ns = J.ns;
+  { DBits R; db_init(R, J.file + J.ep_off, J.ep_len);
+    if (d_read_huff(R, J.tmp[0]) || d_read_huff(R, J.tmp[1]) || d_read_huff(R, J.tmp[2]) || d_read_huff(R, J.tmp[3])) { J.status = -7; return; }
+    const int gray = (int)db_get(R, 1);
+    int prev[3] = { 16, 16, 16 }, pi = 0;
+    for (uint32_t i = 0; i < ne; i++) {
+      const int d = dh_dec(J.tmp[3], R); if (d < 0) { J.status = -7; return; } pi = (d + pi) & 7;
+      for (int c = 0; c < (gray ? 1 : 3); c++) {
+        const DHuff &mm = prev[c] <= 9 ? J.tmp[0] : (prev[c] <= 21 ? J.tmp[1] : J.tmp[2]);
+        const int dd = dh_dec(mm, R); if (dd < 0) { J.status = -7; return; }
+        prev[c] = (prev[c] + dd) & 31;
+      }
+      if (gray) prev[1] = prev[2] = prev[0];
+      J.endpoints[4 * i] = (uint8_t)prev[0]; J.endpoints[4 * i + 1] = (uint8_t)prev[1]; J.endpoints[4 * i + 2] = (uint8_t)prev[2]; J.endpoints[4 * i + 3] = (uint8_t)pi;
+    } }
+  { DBits R; db_init(R, J.file + J.sel_off, J.sel_len);
+    const int global = (int)db_get(R, 1), hybrid = (int)db_get(R, 1), raw = (int)db_get(R, 1);
+    if (global || hybrid) { J.status = -8; return; }
+    if (raw) { for (uint32_t i = 0; i < ns; i++) { uint32_t v = 0; for (int j = 0; j < 4; j++) v |= db_get(R, 8) << (8 * j); J.selectors[i] = v; } }
+    else {
+      if (d_read_huff(R, J.tmp[4])) { J.status = -8; return; }
+      uint32_t prevb[4] = { 0, 0, 0, 0 };
+      for (uint32_t i = 0; i < ns; i++) {
+        uint32_t v = 0;
+        for (int j = 0; j < 4; j++) {
+          uint32_t cur;
+          if (i == 0) cur = db_get(R, 8);
+          else { const int d = dh_dec(J.tmp[4], R); if (d < 0) { J.status = -8; return; } cur = ((uint32_t)d ^ prevb[j]) & 255u; }
+          prevb[j] = cur; v |= cur << (8 * j);
+        }
+        J.selectors[i] = v;
+      }
+    } }
+  { DBits R; db_init(R, J.file + J.tab_off, J.tab_len);
+    if (d_read_huff(R, J.hm[0]) || d_read_huff(R, J.hm[1]) || d_read_huff(R, J.hm[2]) || d_read_huff(R, J.hm[3])) { J.status = -9; return; }
+    J.hist_size = db_get(R, 13); }
+  if (!J.hm[0].valid || !J.hm[1].valid || !J.hm[2].valid || !J.hm[3].valid) { J.status = -9; return; }
+  if (J.hist_size == 0 || J.hist_size > 64) { J.status = -10; return; }
+}
+
+// ---- K2: slices ----
+// LUT entry: (symbol << 8) | code length, indexed by the next LB bits in stream order; 0 = code longer than LB bits
+__device__ inline void lut_build(const DHuff &H, uint32_t *lut, int LB, uint32_t lane) {
+  for (uint32_t k = lane; k < (1u << LB); k += 64) lut[k] = 0;
+  __syncthreads();
+  for (uint32_t i = lane; i < H.n; i += 64) {
+    const uint32_t l = H.sizes[i];
+    if (!l || l > (uint32_t)LB) continue;
+    // canonical code of symbol i: first_code[l] + (rank of i among the symbols of length l) = position in sorted[]
+    uint32_t lo = H.first_idx[l], hi = lo + H.count[l];
+    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) / 2; if (H.sorted[mid] <= i) lo = mid; else hi = mid; }
+    const uint32_t code = H.first_code[l] + (lo - H.first_idx[l]);
+    uint32_t rc = 0; for (uint32_t b = 0; b < l; b++) rc |= ((code >> (l - 1 - b)) & 1u) << b;     // first bit read = MSB of the code
+    for (uint32_t f = 0; f < (1u << ((uint32_t)LB - l)); f++) lut[rc | (f << l)] = (i << 8) | l;
+  }
+  __syncthreads();
+}
+template <int LB, typename LP>
+__device__ __forceinline__ int lut_dec(const DHuff &H, LP lut, DBits &B) {
+  const uint32_t e = lut[db_peek(B, LB)];
+  if (e) { db_skip(B, e & 255u); return (int)(e >> 8); }
+  return dh_dec(H, B);
+}
+
+__global__ void __launch_bounds__(64) k_tdec_slices(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.x];
+  UVOL_DYN_SMEM(uint32_t, lds);
+  const uint32_t lane = threadIdx.x;
+  const bool ok = J.status == 0;
+  uint32_t *l_epm = lds, *l_dem = l_epm + (1u << TD_LUT_EPM), *l_sm = l_dem + (1u << TD_LUT_DEM), *l_rle = l_sm + (1u << TD_LUT_SM);
+  uint32_t *l_hist = l_rle + (1u << TD_LUT_RLE);                 // 64 words
+  uint16_t *l_pe = reinterpret_cast<uint16_t *>(l_hist + 64);     // 2 rows x (bx + 1)
+  const uint32_t bx = J.bx, by = J.by, rowsz = (bx + 2) & ~1u;
+  uint8_t *l_pb = reinterpret_cast<uint8_t *>(l_pe + 2 * rowsz);  // 2 rows x (bx + 1)
+  if (ok) { lut_build(J.hm[0], l_epm, TD_LUT_EPM, lane); lut_build(J.hm[1], l_dem, TD_LUT_DEM, lane); lut_build(J.hm[2], l_sm, TD_LUT_SM, lane); lut_build(J.hm[3], l_rle, TD_LUT_RLE, lane); }
+  else { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
+  if (!ok || lane != 0) return;
+  UVOL_L(const uint32_t) epm = UVOL_TO_L(const uint32_t, l_epm); UVOL_L(const uint32_t) dem = UVOL_TO_L(const uint32_t, l_dem);
+  UVOL_L(const uint32_t) sm = UVOL_TO_L(const uint32_t, l_sm); UVOL_L(const uint32_t) rle = UVOL_TO_L(const uint32_t, l_rle);
+  UVOL_L(uint32_t) hist = UVOL_TO_L(uint32_t, l_hist); UVOL_L(uint16_t) pe = UVOL_TO_L(uint16_t, l_pe); UVOL_L(uint8_t) pb = UVOL_TO_L(uint8_t, l_pb);
+  const uint32_t ne = J.ne, ns = J.ns, hs = J.hist_size, nsl = J.layers;
+  const size_t nbk = (size_t)bx * by;
+  for (uint32_t sl = 0; sl < nsl; sl++) {
+    if ((unsigned long long)J.slice_off[sl] + J.slice_len[sl] > J.level_len) { J.status = -11; return; }
+    const bool is_p = (J.slice_flags[sl] & 2u) != 0;
+    if (is_p && sl == 0) { J.status = -11; return; }
+    DBits R; db_init(R, J.file + J.level_off + J.slice_off[sl], J.slice_len[sl]);
+    UVOL_G(uint16_t) oe = UVOL_TO_G(uint16_t, J.ei + sl * nbk); UVOL_G(uint16_t) os = UVOL_TO_G(uint16_t, J.si + sl * nbk);
+    UVOL_G(const uint16_t) pve = UVOL_TO_G(const uint16_t, J.ei + (sl ? sl - 1 : 0) * nbk); UVOL_G(const uint16_t) pvs = UVOL_TO_G(const uint16_t, J.si + (sl ? sl - 1 : 0) * nbk);
+    for (uint32_t i = 0; i < hs; i++) hist[i] = i;
+    uint32_t rover = hs / 2; const uint32_t RLE = ns + hs;
+    uint32_t prev_sym = 0, rep = 0, prev_ei = 0, sel_rle = 0;
+    for (uint32_t i = 0; i < 2 * rowsz; i++) pe[i] = 0;
+    for (uint32_t i = 0; i < 2 * rowsz; i++) pb[i] = 0;
+    for (uint32_t y = 0; y < by; y++) {
+      const uint32_t cur = y & 1;
+      UVOL_L(uint16_t) pe_c = pe + cur * rowsz; UVOL_L(uint16_t) pe_o = pe + (cur ^ 1) * rowsz;
+      UVOL_L(uint8_t) pb_c = pb + cur * rowsz; UVOL_L(uint8_t) pb_o = pb + (cur ^ 1) * rowsz;
+      uint32_t pbits = 0;
+      for (uint32_t x = 0; x < bx; x++) {
+        if ((x & 1) == 0) {
+          if ((y & 1) == 0) {
+            if (rep) { rep--; pbits = prev_sym; }
+            else {
+              const int d = lut_dec<TD_LUT_EPM>(J.hm[0], epm, R); if (d < 0) { J.status = -12; return; }
+              if (d == 256) { rep = d_vlc(R, 4) + 3 - 1; pbits = prev_sym; } else { prev_sym = (uint32_t)d; pbits = (uint32_t)d; }
+            }
+            pb_o[x] = (uint8_t)(pbits >> 4);
+          } else pbits = pb_c[x];
+        }
+        const uint32_t pred = pbits & 3; pbits >>= 2;
+        uint32_t ei; bool skip = false;
+        if (pred == 0) { if (x == 0) { J.status = -13; return; } ei = prev_ei; }
+        else if (pred == 1) { if (y == 0) { J.status = -13; return; } ei = pe_o[x]; }
+        else if (pred == 2) {
+          if (is_p) { skip = true; ei = pve[x + (size_t)y * bx]; }
+          else { if (x == 0 || y == 0) { J.status = -13; return; } ei = pe_o[x - 1]; }
+        } else { const int d = lut_dec<TD_LUT_DEM>(J.hm[1], dem, R); if (d < 0) { J.status = -12; return; } ei = (uint32_t)d + prev_ei; if (ei >= ne) ei -= ne; }
+        if (ei >= ne) { J.status = -14; return; }
+        pe_c[x] = (uint16_t)ei; prev_ei = ei;
+        uint32_t si;
+        if (skip) si = pvs[x + (size_t)y * bx];
+        else {
+          uint32_t sym;
+          if (sel_rle > 0) { sel_rle--; sym = ns; }
+          else {
+            const int d = lut_dec<TD_LUT_SM>(J.hm[2], sm, R); if (d < 0) { J.status = -12; return; } sym = (uint32_t)d;
+            if (sym == RLE) { const int rr = lut_dec<TD_LUT_RLE>(J.hm[3], rle, R); if (rr < 0) { J.status = -12; return; } sel_rle = rr == 63 ? d_vlc(R, 7) + 3 : (uint32_t)rr + 3; sym = ns; sel_rle--; }
+          }
+          if (sym >= ns) { const uint32_t h = sym - ns; if (h >= hs) { J.status = -14; return; } si = hist[h]; if (h) { const uint32_t t = hist[h]; hist[h] = hist[h / 2]; hist[h / 2] = t; } }
+          else { si = sym; hist[rover] = si; rover++; if (rover == hs) rover = hs / 2; }
+        }
+        if (si >= ns) { J.status = -14; return; }
+        oe[x + (size_t)y * bx] = (uint16_t)ei; os[x + (size_t)y * bx] = (uint16_t)si;
+      }
+    }
+    if (R.consumed > 8ull * J.slice_len[sl]) { J.status = -15; return; }
+  }
+}
+
+// ---- K3: unpack, one thread per (block, layer, segment) ----
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_unpack(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.z];
+  if (J.status != 0) return;
+  const uint32_t layer = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const uint32_t bx = J.bx, by = J.by, W = J.width, H = J.height;
+  if (layer >= J.layers || b >= bx * by) return;
+  const int INTEN[8][4] = { {-8, -2, 2, 8}, {-17, -5, 5, 17}, {-29, -9, 9, 29}, {-42, -13, 13, 42}, {-60, -18, 18, 60}, {-80, -24, 24, 80}, {-106, -33, 33, 106}, {-183, -47, 47, 183} };
+  const uint32_t X = b % bx, Y = b / bx;
+  const size_t o = (size_t)layer * bx * by + b;
+  const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
+  int base[3]; for (int c = 0; c < 3; c++) base[c] = (e[c] << 3) | (e[c] >> 2);
+  const int t = e[3];
+  uint8_t *out = J.out[layer];
+  for (int y = 0; y < 4; y++) {
+    const uint32_t py = Y * 4 + (uint32_t)y; if (py >= H) break;
+    uint32_t px4[4];
+    for (int x = 0; x < 4; x++) {
+      const int d = INTEN[t][(sel >> (8 * y + 2 * x)) & 3];
+      int r = base[0] + d, g = base[1] + d, bb = base[2] + d;
+      r = r < 0 ? 0 : (r > 255 ? 255 : r); g = g < 0 ? 0 : (g > 255 ? 255 : g); bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
+      px4[x] = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)bb << 16) | 0xff000000u;
+    }
+    uint32_t *row = reinterpret_cast<uint32_t *>(out + 4 * ((size_t)py * W + X * 4));
+    if (X * 4 + 3 < W && (W & 3) == 0) *reinterpret_cast<uint4 *>(row) = make_uint4(px4[0], px4[1], px4[2], px4[3]);
+    else for (int x = 0; x < 4; x++) if (X * 4 + (uint32_t)x < W) row[x] = px4[x];
+  }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct TexDecState { uvol_devbuf files, slab, outs, jobs; std::vector<TexDecJob> hjobs; uint8_t *pinned = nullptr; size_t pinned_cap = 0; };
+
+static inline uint32_t rd32h(const uint8_t *b) { uint32_t v; memcpy(&v, b, 4); return v; }
+static inline uint64_t rd64h(const uint8_t *b) { uint64_t v; memcpy(&v, b, 8); return v; }
+
+// container header + supercompression global data of one file
+static int tdec_parse(const uint8_t *b, size_t n, TexDecJob &J) {
+  static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
+  if (!b || n < 104 || memcmp(b, ident, 12)) return -1;
+  const uint32_t vk = rd32h(b + 12), W = rd32h(b + 20), H = rd32h(b + 24), layers = rd32h(b + 32), faces = rd32h(b + 36), levels = rd32h(b + 40), sc = rd32h(b + 44);
+  const uint64_t sgd_off = rd64h(b + 64), sgd_len = rd64h(b + 72), lv_off = rd64h(b + 80), lv_len = rd64h(b + 88);
+  if (vk != 0 || sc != 1 || levels != 1 || faces != 1 || W == 0 || H == 0) return -2;
+  if (sgd_off + sgd_len > n || lv_off + lv_len > n || lv_len > 0xffffffffull) return -3;
+  const uint32_t nsl = layers ? layers : 1;
+  if (nsl > TD_MAX_LAYERS) return -4;
+  if (sgd_len < 20 + 20ull * nsl) return -5;
+  const uint8_t *s = b + sgd_off;
+  J.width = W; J.height = H; J.layers = nsl; J.bx = (W + 3) / 4; J.by = (H + 3) / 4;
+  J.ne = (uint32_t)s[0] | ((uint32_t)s[1] << 8); J.ns = (uint32_t)s[2] | ((uint32_t)s[3] << 8);
+  J.ep_len = rd32h(s + 4); J.sel_len = rd32h(s + 8); J.tab_len = rd32h(s + 12);
+  for (uint32_t i = 0; i < nsl; i++) { const uint8_t *d = s + 20 + 20 * i; J.slice_flags[i] = rd32h(d); J.slice_off[i] = rd32h(d + 4); J.slice_len[i] = rd32h(d + 8); if (rd32h(d + 12) || rd32h(d + 16)) return -6; }
+  const uint64_t p = sgd_off + 20 + 20ull * nsl;
+  if (p - sgd_off + J.ep_len + J.sel_len + J.tab_len > sgd_len) return -5;
+  J.ep_off = (uint32_t)p; J.sel_off = J.ep_off + J.ep_len; J.tab_off = J.sel_off + J.sel_len;
+  J.level_off = (uint32_t)lv_off; J.level_len = (uint32_t)lv_len;
+  if (J.ne == 0 || J.ns == 0 || J.ne > TD_MAX_SYMS - 80 || J.ns > TD_MAX_SYMS - 80) return -5;
+  J.file_len = (uint32_t)n;
+  return 0;
+}
+
+extern "C" int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, uint32_t *height, uint32_t *layers) {
+  TexDecJob J; memset(&J, 0, sizeof J);
+  if (tdec_parse(ktx2, len, J)) return UVOL_E_INVALID;
+  if (width) *width = J.width; if (height) *height = J.height; if (layers) *layers = J.layers;
+  return UVOL_OK;
+}
+
+int texdec_create(uvol_ctx *ctx) { ctx->texdec = new TexDecState(); return UVOL_OK; }
+void texdec_destroy(uvol_ctx *ctx) {
+  TexDecState *t = ctx->texdec; if (!t) return;
+  for (uvol_devbuf *b : { &t->files, &t->slab, &t->outs, &t->jobs }) if (b->p) (void)hipFree(b->p);
+  if (t->pinned) (void)hipHostFree(t->pinned);
+  delete t; ctx->texdec = nullptr;
+}
+
+#define DLAUNCH(k, grid, block, shmem, ...)                                                      \
+  do {                                                                                           \
+    if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s\n", #k); fflush(stderr); }              \
+    hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, __VA_ARGS__);                         \
+    if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
+  } while (0)
+
+// n segments (all of one width / height / layer count), rgba[s * layers + l] = width*height*4 bytes each
+int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device) {
+  TexDecState *T = ctx->texdec;
+  if (n <= 0) return UVOL_OK;
+  T->hjobs.assign((size_t)n, TexDecJob{});
+  size_t files_total = 0;
+  std::vector<size_t> foff((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const int rc = tdec_parse(files[i], lens[i], T->hjobs[i]);
+    if (rc) { ctx->set_error("segment %d: not a KTX2 / BasisLZ ETC1S file this decoder supports (parse code %d)", i, rc); return rc == -2 || rc == -6 ? UVOL_E_UNSUPPORTED : UVOL_E_INVALID; }
+    if (T->hjobs[i].width != T->hjobs[0].width || T->hjobs[i].height != T->hjobs[0].height || T->hjobs[i].layers != T->hjobs[0].layers) { ctx->set_error("segment %d: size / layer count differs from segment 0", i); return UVOL_E_INVALID; }
+    foff[i] = files_total; files_total += (lens[i] + 16 + 255) & ~(size_t)255;
+  }
+  const TexDecJob &J0 = T->hjobs[0];
+  const size_t layer_bytes = (size_t)J0.width * J0.height * 4, nbk = (size_t)J0.bx * J0.by, L = J0.layers;
+  if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small: %zu < %zu", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
+  // per-segment workspace: codebooks, block indices, Huffman size / sorted arrays of 9 models
+  auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t ws = a256((size_t)TD_MAX_SYMS * 4) + a256((size_t)TD_MAX_SYMS * 4) + 2 * a256(L * nbk * 2) + 9 * (a256((size_t)TD_MAX_SYMS + 512) + a256((size_t)TD_MAX_SYMS * 4 + 64));
+  const size_t out_seg = outputs_on_device ? 0 : L * a256(layer_bytes);
+  int rc;
+  if ((rc = uvol_ensure(ctx, T->files, files_total + 64))) return rc;
+  if ((rc = uvol_ensure(ctx, T->slab, ws * (size_t)n))) return rc;
+  if ((rc = uvol_ensure(ctx, T->jobs, sizeof(TexDecJob) * (size_t)n))) return rc;
+  if (!outputs_on_device && (rc = uvol_ensure(ctx, T->outs, out_seg * (size_t)n))) return rc;
+  for (int i = 0; i < n; i++) {
+    TexDecJob &J = T->hjobs[i];
+    uint8_t *fd = (uint8_t *)T->files.p + foff[i];
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(fd, files[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+    J.file = fd;
+    uint8_t *w = (uint8_t *)T->slab.p + ws * (size_t)i; size_t o = 0;
+    auto take = [&](size_t bytes) { uint8_t *p = w + o; o += a256(bytes); return p; };
+    J.endpoints = take((size_t)TD_MAX_SYMS * 4); J.selectors = (uint32_t *)take((size_t)TD_MAX_SYMS * 4);
+    J.ei = (uint16_t *)take(L * nbk * 2); J.si = (uint16_t *)take(L * nbk * 2);
+    for (int k = 0; k < 9; k++) { DHuff &H = k < 4 ? J.hm[k] : J.tmp[k - 4]; H.sizes = take((size_t)TD_MAX_SYMS + 512); H.sorted = (uint32_t *)take((size_t)TD_MAX_SYMS * 4 + 64); }
+    for (size_t l = 0; l < L; l++) J.out[l] = outputs_on_device ? rgba[(size_t)i * L + l] : (uint8_t *)T->outs.p + out_seg * (size_t)i + l * a256(layer_bytes);
+    J.status = 0;
+  }
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->jobs.p, T->hjobs.data(), sizeof(TexDecJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  TexDecJob *dj = (TexDecJob *)T->jobs.p;
+  const size_t rowsz = ((size_t)J0.bx + 2) & ~(size_t)1;
+  const size_t lds = ((1u << TD_LUT_EPM) + (1u << TD_LUT_DEM) + (1u << TD_LUT_SM) + (1u << TD_LUT_RLE) + 64) * 4 + 2 * rowsz * 2 + 2 * rowsz + 64;
+  if (lds > 64 * 1024) { ctx->set_error("texture too wide for the slice decoder's row buffers"); return UVOL_E_UNSUPPORTED; }
+  { uvol_ctx::Scope sc(ctx, "texdec.k1_tables", 0); DLAUNCH(k_tdec_tables, dim3((unsigned)n), dim3(64), 0, dj); }
+  { uvol_ctx::Scope sc(ctx, "texdec.k2_slices", 0); DLAUNCH(k_tdec_slices, dim3((unsigned)n), dim3(64), lds, dj); }
+  { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes); DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
+  UVOL_HIP_CHECK(ctx, hipGetLastError());
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; i++) if (T->hjobs[i].status != 0) { ctx->set_error("segment %d: corrupt BasisLZ stream (device status %d)", i, T->hjobs[i].status); return UVOL_E_ENCODE; }
+  if (!outputs_on_device) {
+    for (int i = 0; i < n; i++) for (size_t l = 0; l < L; l++)
+      UVOL_HIP_CHECK(ctx, hipMemcpyAsync(rgba[(size_t)i * L + l], T->hjobs[i].out[l], layer_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->resolve_profile();
+  return UVOL_OK;
+}

@@ -56,7 +56,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
   if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
   if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
   if (uvol_make_stream(ctx, &ctx->stream) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
-  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
+  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
   *out = ctx;
   return UVOL_OK;
 }
@@ -66,7 +66,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
-  geo_destroy(ctx); tex_destroy(ctx);
+  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -136,6 +136,17 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
   if (!ctx || !rgba_dev || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return tex_encode_segments(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
+}
+
+int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba, size_t layer_cap) {
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba, layer_cap, false);
+}
+int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba_dev, size_t layer_cap) {
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba_dev) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true);
 }
 
 int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; ctx->profiling = on != 0; return UVOL_OK; }

@@ -31,7 +31,8 @@ class Mesh(C.Structure):
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
-           "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
+           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
 
 
@@ -57,6 +58,9 @@ def load(path=None):
     for nm in ("uvol_encode_texture_segments", "uvol_encode_texture_segments_dev"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.uvol_ktx2_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for nm in ("uvol_decode_texture_segments", "uvol_decode_texture_segments_dev"):
+        getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.uvol_profile_reset.argtypes = [C.c_void_p]
     L.uvol_profile_count.argtypes = [C.c_void_p]
@@ -206,6 +210,36 @@ class Codec:
         if rc != UVOL_OK:
             raise UvolError(f"encode_texture_segment rc={rc}: {self.error()}")
         return out[:ln.value].tobytes()
+
+    # ---- decode path (texture half) ----
+    def ktx2_info(self, data: bytes):
+        w, h, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = self.L.uvol_ktx2_info(data, len(data), C.byref(w), C.byref(h), C.byref(n))
+        if rc != UVOL_OK:
+            raise UvolError(f"uvol_ktx2_info rc={rc}")
+        return w.value, h.value, n.value
+
+    def decode_texture_segments(self, files):
+        """files: list of .ktx2 bytes (one width / height / layer count) -> list (per segment) of [layers, H, W, 4] uint8 arrays,
+        rows in stored order (the encoder's -y_flip is part of the stored image)."""
+        files = [bytes(f) for f in files]
+        w, h, nl = self.ktx2_info(files[0]); n = len(files)
+        outs = [np.empty((nl, h, w, 4), dtype=np.uint8) for _ in range(n)]
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files])
+        ptrs = (C.c_void_p * (n * nl))(*[outs[s][l].ctypes.data for s in range(n) for l in range(nl)])
+        rc = self.L.uvol_decode_texture_segments(self.h, fp, ln, n, ptrs, w * h * 4)
+        if rc != UVOL_OK:
+            raise UvolError(f"decode_texture_segments rc={rc}: {self.error()}")
+        return outs
+
+    def decode_texture_segments_dev(self, files, dev_ptrs, layer_cap):
+        """Same, into caller-owned device buffers: dev_ptrs = flat list of n_segments*layers device pointers."""
+        files = [bytes(f) for f in files]; n = len(files)
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files])
+        ptrs = (C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs])
+        rc = self.L.uvol_decode_texture_segments_dev(self.h, fp, ln, n, ptrs, layer_cap)
+        if rc != UVOL_OK:
+            raise UvolError(f"decode_texture_segments_dev rc={rc}: {self.error()}")
 
     # ---- measurement ----
     def profile(self, on=True):
