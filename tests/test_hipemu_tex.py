@@ -26,6 +26,10 @@ def test_hipemu_texture_decode_matches_oracle(oracle, hipemu_lib):
         assert got.shape == (want.n_slices, want.height, want.width, 4)
         for l in range(want.n_slices):
             assert np.array_equal(got[l], want.images[l]), l
+    # 17 layers: more than the wave-per-slice pipeline takes -> the serial slice walker
+    many = oracle.ktx2_encode(synth.texture_sequence(17, size=24, seed=2))
+    want = oracle.ktx2_decode(many); got = cd.decode_texture_segments([many])[0]
+    assert want.n_slices == 17 and all(np.array_equal(got[l], want.images[l]) for l in range(17))
     # a batch of two segments in one call
     two = [oracle.ktx2_encode(synth.texture_sequence(2, size=40, seed=s)) for s in (7, 8)]
     for data, got in zip(two, cd.decode_texture_segments(two)):

@@ -152,10 +152,10 @@ __global__ void __launch_bounds__(64) k_tdec_tables(TexDecJob *jobs) {
 
 // ---- K2: slices ----
 // LUT entry: (symbol << 8) | code length, indexed by the next LB bits in stream order; 0 = code longer than LB bits
-__device__ inline void lut_build(const DHuff &H, uint32_t *lut, int LB, uint32_t lane) {
-  for (uint32_t k = lane; k < (1u << LB); k += 64) lut[k] = 0;
+__device__ inline void lut_build(const DHuff &H, uint32_t *lut, int LB, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t k = tid; k < (1u << LB); k += nthreads) lut[k] = 0;
   __syncthreads();
-  for (uint32_t i = lane; i < H.n; i += 64) {
+  for (uint32_t i = tid; i < H.n; i += nthreads) {
     const uint32_t l = H.sizes[i];
     if (!l || l > (uint32_t)LB) continue;
     // canonical code of symbol i: first_code[l] + (rank of i among the symbols of length l) = position in sorted[]
@@ -174,80 +174,143 @@ __device__ __forceinline__ int lut_dec(const DHuff &H, LP lut, DBits &B) {
   return dh_dec(H, B);
 }
 
+// decoder state of one slice between rows (registers of the slice's lane 0)
+struct SliceState { DBits R; uint32_t prev_sym, rep, prev_ei, sel_rle, rover; };
+struct SliceLuts { UVOL_L(const uint32_t) epm; UVOL_L(const uint32_t) dem; UVOL_L(const uint32_t) sm; UVOL_L(const uint32_t) rle; };
+// One row of blocks of one slice.  pe / pb: two rows of endpoint indices / macroblock predictor bits of THIS
+// slice (LDS); pve / pvs: row y of the previous slice (for P-frame skips); oe / os: row y of this slice.  0 or an error code.
+template <typename PV, typename OV>
+__device__ __forceinline__ int tdec_row(const TexDecJob &J, const SliceLuts &T, SliceState &S, uint32_t y, bool is_p, UVOL_L(uint32_t) hist,
+                                        UVOL_L(uint16_t) pe, UVOL_L(uint8_t) pb, uint32_t rowsz, PV pve, PV pvs, OV oe, OV os) {
+  const uint32_t bx = J.bx, ne = J.ne, ns = J.ns, hs = J.hist_size, RLE = ns + hs;
+  const uint32_t cur = y & 1;
+  UVOL_L(uint16_t) pe_c = pe + cur * rowsz; UVOL_L(uint16_t) pe_o = pe + (cur ^ 1) * rowsz;
+  UVOL_L(uint8_t) pb_c = pb + cur * rowsz; UVOL_L(uint8_t) pb_o = pb + (cur ^ 1) * rowsz;
+  uint32_t pbits = 0;
+  for (uint32_t x = 0; x < bx; x++) {
+    if ((x & 1) == 0) {
+      if ((y & 1) == 0) {
+        if (S.rep) { S.rep--; pbits = S.prev_sym; }
+        else {
+          const int d = lut_dec<TD_LUT_EPM>(J.hm[0], T.epm, S.R); if (d < 0) return -12;
+          if (d == 256) { S.rep = d_vlc(S.R, 4) + 3 - 1; pbits = S.prev_sym; } else { S.prev_sym = (uint32_t)d; pbits = (uint32_t)d; }
+        }
+        pb_o[x] = (uint8_t)(pbits >> 4);
+      } else pbits = pb_c[x];
+    }
+    const uint32_t pred = pbits & 3; pbits >>= 2;
+    uint32_t ei; bool skip = false;
+    if (pred == 0) { if (x == 0) return -13; ei = S.prev_ei; }
+    else if (pred == 1) { if (y == 0) return -13; ei = pe_o[x]; }
+    else if (pred == 2) {
+      if (is_p) { skip = true; ei = pve[x]; }
+      else { if (x == 0 || y == 0) return -13; ei = pe_o[x - 1]; }
+    } else { const int d = lut_dec<TD_LUT_DEM>(J.hm[1], T.dem, S.R); if (d < 0) return -12; ei = (uint32_t)d + S.prev_ei; if (ei >= ne) ei -= ne; }
+    if (ei >= ne) return -14;
+    pe_c[x] = (uint16_t)ei; S.prev_ei = ei;
+    uint32_t si;
+    if (skip) si = pvs[x];
+    else {
+      uint32_t sym;
+      if (S.sel_rle > 0) { S.sel_rle--; sym = ns; }
+      else {
+        const int d = lut_dec<TD_LUT_SM>(J.hm[2], T.sm, S.R); if (d < 0) return -12; sym = (uint32_t)d;
+        if (sym == RLE) { const int rr = lut_dec<TD_LUT_RLE>(J.hm[3], T.rle, S.R); if (rr < 0) return -12; S.sel_rle = rr == 63 ? d_vlc(S.R, 7) + 3 : (uint32_t)rr + 3; sym = ns; S.sel_rle--; }
+      }
+      if (sym >= ns) { const uint32_t h = sym - ns; if (h >= hs) return -14; si = hist[h]; if (h) { const uint32_t t = hist[h]; hist[h] = hist[h / 2]; hist[h / 2] = t; } }
+      else { si = sym; hist[S.rover] = si; S.rover++; if (S.rover == hs) S.rover = hs / 2; }
+    }
+    if (si >= ns) return -14;
+    oe[x] = (uint16_t)ei; os[x] = (uint16_t)si;
+  }
+  return 0;
+}
+__device__ __forceinline__ int tdec_slice_begin(const TexDecJob &J, uint32_t sl, SliceState &S, UVOL_L(uint32_t) hist, UVOL_L(uint16_t) pe, UVOL_L(uint8_t) pb, uint32_t rowsz) {
+  if ((unsigned long long)J.slice_off[sl] + J.slice_len[sl] > J.level_len) return -11;
+  if ((J.slice_flags[sl] & 2u) && sl == 0) return -11;
+  db_init(S.R, J.file + J.level_off + J.slice_off[sl], J.slice_len[sl]);
+  for (uint32_t i = 0; i < J.hist_size; i++) hist[i] = i;
+  S.rover = J.hist_size / 2; S.prev_sym = 0; S.rep = 0; S.prev_ei = 0; S.sel_rle = 0;
+  for (uint32_t i = 0; i < 2 * rowsz; i++) pe[i] = 0;
+  for (uint32_t i = 0; i < 2 * rowsz; i++) pb[i] = 0;
+  return 0;
+}
+
+// LDS layout shared by both slice kernels: [4 LUTs][per slice-wave: hist 64 x u32 | pe 2 x rowsz u16 | pb 2 x rowsz u8 | row buffers ei, si: 2 x rowsz u16 each]
+#define TD_LUT_WORDS ((1u << TD_LUT_EPM) + (1u << TD_LUT_DEM) + (1u << TD_LUT_SM) + (1u << TD_LUT_RLE))
+__host__ __device__ inline uint32_t td_wave_words(uint32_t rowsz) { return 64 + rowsz /* pe: 2 rows of u16 */ + (2 * rowsz + 3) / 4 /* pb */ + 2 * rowsz /* ei, si rows, double buffered */; }
+
+// Serial form (any layer count): one lane walks the slices of a segment one after the other; rows through global memory.
 __global__ void __launch_bounds__(64) k_tdec_slices(TexDecJob *jobs) {
   TexDecJob &J = jobs[blockIdx.x];
   UVOL_DYN_SMEM(uint32_t, lds);
   const uint32_t lane = threadIdx.x;
   const bool ok = J.status == 0;
   uint32_t *l_epm = lds, *l_dem = l_epm + (1u << TD_LUT_EPM), *l_sm = l_dem + (1u << TD_LUT_DEM), *l_rle = l_sm + (1u << TD_LUT_SM);
-  uint32_t *l_hist = l_rle + (1u << TD_LUT_RLE);                 // 64 words
-  uint16_t *l_pe = reinterpret_cast<uint16_t *>(l_hist + 64);     // 2 rows x (bx + 1)
+  uint32_t *l_w = lds + TD_LUT_WORDS;
   const uint32_t bx = J.bx, by = J.by, rowsz = (bx + 2) & ~1u;
-  uint8_t *l_pb = reinterpret_cast<uint8_t *>(l_pe + 2 * rowsz);  // 2 rows x (bx + 1)
-  if (ok) { lut_build(J.hm[0], l_epm, TD_LUT_EPM, lane); lut_build(J.hm[1], l_dem, TD_LUT_DEM, lane); lut_build(J.hm[2], l_sm, TD_LUT_SM, lane); lut_build(J.hm[3], l_rle, TD_LUT_RLE, lane); }
-  else { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
+  if (ok) { lut_build(J.hm[0], l_epm, TD_LUT_EPM, lane, 64); lut_build(J.hm[1], l_dem, TD_LUT_DEM, lane, 64); lut_build(J.hm[2], l_sm, TD_LUT_SM, lane, 64); lut_build(J.hm[3], l_rle, TD_LUT_RLE, lane, 64); }
   if (!ok || lane != 0) return;
-  UVOL_L(const uint32_t) epm = UVOL_TO_L(const uint32_t, l_epm); UVOL_L(const uint32_t) dem = UVOL_TO_L(const uint32_t, l_dem);
-  UVOL_L(const uint32_t) sm = UVOL_TO_L(const uint32_t, l_sm); UVOL_L(const uint32_t) rle = UVOL_TO_L(const uint32_t, l_rle);
-  UVOL_L(uint32_t) hist = UVOL_TO_L(uint32_t, l_hist); UVOL_L(uint16_t) pe = UVOL_TO_L(uint16_t, l_pe); UVOL_L(uint8_t) pb = UVOL_TO_L(uint8_t, l_pb);
-  const uint32_t ne = J.ne, ns = J.ns, hs = J.hist_size, nsl = J.layers;
+  SliceLuts T; T.epm = UVOL_TO_L(const uint32_t, l_epm); T.dem = UVOL_TO_L(const uint32_t, l_dem); T.sm = UVOL_TO_L(const uint32_t, l_sm); T.rle = UVOL_TO_L(const uint32_t, l_rle);
+  UVOL_L(uint32_t) hist = UVOL_TO_L(uint32_t, l_w); UVOL_L(uint16_t) pe = UVOL_TO_L(uint16_t, reinterpret_cast<uint16_t *>(l_w + 64));
+  UVOL_L(uint8_t) pb = UVOL_TO_L(uint8_t, reinterpret_cast<uint8_t *>(l_w + 64 + rowsz));
   const size_t nbk = (size_t)bx * by;
-  for (uint32_t sl = 0; sl < nsl; sl++) {
-    if ((unsigned long long)J.slice_off[sl] + J.slice_len[sl] > J.level_len) { J.status = -11; return; }
+  for (uint32_t sl = 0; sl < J.layers; sl++) {
+    SliceState S;
+    int rc = tdec_slice_begin(J, sl, S, hist, pe, pb, rowsz);
     const bool is_p = (J.slice_flags[sl] & 2u) != 0;
-    if (is_p && sl == 0) { J.status = -11; return; }
-    DBits R; db_init(R, J.file + J.level_off + J.slice_off[sl], J.slice_len[sl]);
-    UVOL_G(uint16_t) oe = UVOL_TO_G(uint16_t, J.ei + sl * nbk); UVOL_G(uint16_t) os = UVOL_TO_G(uint16_t, J.si + sl * nbk);
-    UVOL_G(const uint16_t) pve = UVOL_TO_G(const uint16_t, J.ei + (sl ? sl - 1 : 0) * nbk); UVOL_G(const uint16_t) pvs = UVOL_TO_G(const uint16_t, J.si + (sl ? sl - 1 : 0) * nbk);
-    for (uint32_t i = 0; i < hs; i++) hist[i] = i;
-    uint32_t rover = hs / 2; const uint32_t RLE = ns + hs;
-    uint32_t prev_sym = 0, rep = 0, prev_ei = 0, sel_rle = 0;
-    for (uint32_t i = 0; i < 2 * rowsz; i++) pe[i] = 0;
-    for (uint32_t i = 0; i < 2 * rowsz; i++) pb[i] = 0;
-    for (uint32_t y = 0; y < by; y++) {
-      const uint32_t cur = y & 1;
-      UVOL_L(uint16_t) pe_c = pe + cur * rowsz; UVOL_L(uint16_t) pe_o = pe + (cur ^ 1) * rowsz;
-      UVOL_L(uint8_t) pb_c = pb + cur * rowsz; UVOL_L(uint8_t) pb_o = pb + (cur ^ 1) * rowsz;
-      uint32_t pbits = 0;
-      for (uint32_t x = 0; x < bx; x++) {
-        if ((x & 1) == 0) {
-          if ((y & 1) == 0) {
-            if (rep) { rep--; pbits = prev_sym; }
-            else {
-              const int d = lut_dec<TD_LUT_EPM>(J.hm[0], epm, R); if (d < 0) { J.status = -12; return; }
-              if (d == 256) { rep = d_vlc(R, 4) + 3 - 1; pbits = prev_sym; } else { prev_sym = (uint32_t)d; pbits = (uint32_t)d; }
-            }
-            pb_o[x] = (uint8_t)(pbits >> 4);
-          } else pbits = pb_c[x];
-        }
-        const uint32_t pred = pbits & 3; pbits >>= 2;
-        uint32_t ei; bool skip = false;
-        if (pred == 0) { if (x == 0) { J.status = -13; return; } ei = prev_ei; }
-        else if (pred == 1) { if (y == 0) { J.status = -13; return; } ei = pe_o[x]; }
-        else if (pred == 2) {
-          if (is_p) { skip = true; ei = pve[x + (size_t)y * bx]; }
-          else { if (x == 0 || y == 0) { J.status = -13; return; } ei = pe_o[x - 1]; }
-        } else { const int d = lut_dec<TD_LUT_DEM>(J.hm[1], dem, R); if (d < 0) { J.status = -12; return; } ei = (uint32_t)d + prev_ei; if (ei >= ne) ei -= ne; }
-        if (ei >= ne) { J.status = -14; return; }
-        pe_c[x] = (uint16_t)ei; prev_ei = ei;
-        uint32_t si;
-        if (skip) si = pvs[x + (size_t)y * bx];
-        else {
-          uint32_t sym;
-          if (sel_rle > 0) { sel_rle--; sym = ns; }
-          else {
-            const int d = lut_dec<TD_LUT_SM>(J.hm[2], sm, R); if (d < 0) { J.status = -12; return; } sym = (uint32_t)d;
-            if (sym == RLE) { const int rr = lut_dec<TD_LUT_RLE>(J.hm[3], rle, R); if (rr < 0) { J.status = -12; return; } sel_rle = rr == 63 ? d_vlc(R, 7) + 3 : (uint32_t)rr + 3; sym = ns; sel_rle--; }
-          }
-          if (sym >= ns) { const uint32_t h = sym - ns; if (h >= hs) { J.status = -14; return; } si = hist[h]; if (h) { const uint32_t t = hist[h]; hist[h] = hist[h / 2]; hist[h / 2] = t; } }
-          else { si = sym; hist[rover] = si; rover++; if (rover == hs) rover = hs / 2; }
-        }
-        if (si >= ns) { J.status = -14; return; }
-        oe[x + (size_t)y * bx] = (uint16_t)ei; os[x + (size_t)y * bx] = (uint16_t)si;
-      }
+    for (uint32_t y = 0; y < by && !rc; y++) {
+      const size_t ro = (size_t)y * bx;
+      rc = tdec_row(J, T, S, y, is_p, hist, pe, pb, rowsz, UVOL_TO_G(const uint16_t, J.ei + (sl ? sl - 1 : 0) * nbk + ro), UVOL_TO_G(const uint16_t, J.si + (sl ? sl - 1 : 0) * nbk + ro),
+                    UVOL_TO_G(uint16_t, J.ei + sl * nbk + ro), UVOL_TO_G(uint16_t, J.si + sl * nbk + ro));
     }
-    if (R.consumed > 8ull * J.slice_len[sl]) { J.status = -15; return; }
+    if (!rc && S.R.consumed > 8ull * J.slice_len[sl]) rc = -15;
+    if (rc) { J.status = rc; return; }
   }
+}
+
+// Pipelined form (<= 16 layers): one wave per slice in one workgroup.  A P-frame row only needs the SAME row of the
+// previous slice, so wave s decodes row t - s at step t: a systolic pipeline with one workgroup barrier per row, rows handed
+// from slice to slice through double-buffered LDS row buffers and written to global memory by all 64 lanes (coalesced).
+__global__ void __launch_bounds__(1024) k_tdec_slices_pipe(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.x];
+  UVOL_DYN_SMEM(uint32_t, lds);
+  __shared__ int s_fail;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, sl = tid >> 6, nthreads = blockDim.x;
+  const bool ok = J.status == 0;
+  uint32_t *l_epm = lds, *l_dem = l_epm + (1u << TD_LUT_EPM), *l_sm = l_dem + (1u << TD_LUT_DEM), *l_rle = l_sm + (1u << TD_LUT_SM);
+  const uint32_t bx = J.bx, by = J.by, rowsz = (bx + 2) & ~1u, L = J.layers, ww = td_wave_words(rowsz);
+  if (tid == 0) s_fail = 0;
+  if (ok) { lut_build(J.hm[0], l_epm, TD_LUT_EPM, tid, nthreads); lut_build(J.hm[1], l_dem, TD_LUT_DEM, tid, nthreads); lut_build(J.hm[2], l_sm, TD_LUT_SM, tid, nthreads); lut_build(J.hm[3], l_rle, TD_LUT_RLE, tid, nthreads); }
+  if (!ok) return;                                   // uniform for the whole workgroup
+  SliceLuts T; T.epm = UVOL_TO_L(const uint32_t, l_epm); T.dem = UVOL_TO_L(const uint32_t, l_dem); T.sm = UVOL_TO_L(const uint32_t, l_sm); T.rle = UVOL_TO_L(const uint32_t, l_rle);
+  uint32_t *mine = lds + TD_LUT_WORDS + sl * ww, *prevw = lds + TD_LUT_WORDS + (sl ? sl - 1 : 0) * ww;
+  UVOL_L(uint32_t) hist = UVOL_TO_L(uint32_t, mine); UVOL_L(uint16_t) pe = UVOL_TO_L(uint16_t, reinterpret_cast<uint16_t *>(mine + 64));
+  UVOL_L(uint8_t) pb = UVOL_TO_L(uint8_t, reinterpret_cast<uint8_t *>(mine + 64 + rowsz));
+  const uint32_t rows_off = 64 + rowsz + (2 * rowsz + 3) / 4;                           // words; then ei[2][rowsz], si[2][rowsz] as u16
+  UVOL_L(uint16_t) my_rows = UVOL_TO_L(uint16_t, reinterpret_cast<uint16_t *>(mine + rows_off));
+  UVOL_L(const uint16_t) pv_rows = UVOL_TO_L(const uint16_t, reinterpret_cast<const uint16_t *>(prevw + rows_off));
+  const size_t nbk = (size_t)bx * by;
+  const bool is_p = sl < L && (J.slice_flags[sl] & 2u) != 0;
+  SliceState S;
+  if (sl < L && lane == 0) { const int rc = tdec_slice_begin(J, sl, S, hist, pe, pb, rowsz); if (rc) { s_fail = rc; } }
+  __syncthreads();
+  for (uint32_t t = 0; t < by + L - 1; t++) {
+    const bool active = sl < L && t >= sl && t - sl < by;
+    const uint32_t y = t - sl, buf = y & 1;
+    if (active && lane == 0 && !s_fail) {
+      const int rc = tdec_row(J, T, S, y, is_p, hist, pe, pb, rowsz, pv_rows + buf * rowsz, pv_rows + (2 + buf) * rowsz, my_rows + buf * rowsz, my_rows + (2 + buf) * rowsz);
+      if (rc) s_fail = rc;
+    }
+    __syncthreads();
+    if (active) {                                    // the finished row goes to global memory, 64 lanes wide
+      uint16_t *ge = J.ei + sl * nbk + (size_t)y * bx, *gs = J.si + sl * nbk + (size_t)y * bx;
+      for (uint32_t x = lane; x < bx; x += 64) { ge[x] = my_rows[buf * rowsz + x]; gs[x] = my_rows[(2 + buf) * rowsz + x]; }
+    }
+  }
+  if (sl < L && lane == 0 && !s_fail && S.R.consumed > 8ull * J.slice_len[sl]) s_fail = -15;
+  __syncthreads();
+  if (tid == 0 && s_fail) J.status = s_fail;
 }
 
 // ---- K3: unpack, one thread per (block, layer, segment) ----
@@ -282,7 +345,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_unpack(TexDecJob *jobs) {
 // ================================================================================================
 // host side
 // ================================================================================================
-struct TexDecState { uvol_devbuf files, slab, outs, jobs; std::vector<TexDecJob> hjobs; uint8_t *pinned = nullptr; size_t pinned_cap = 0; };
+struct TexDecState { uvol_devbuf files, slab, outs, jobs; std::vector<TexDecJob> hjobs; uint8_t *pinned = nullptr; size_t pinned_cap = 0; size_t max_lds = 64 * 1024; };
 
 static inline uint32_t rd32h(const uint8_t *b) { uint32_t v; memcpy(&v, b, 4); return v; }
 static inline uint64_t rd64h(const uint8_t *b) { uint64_t v; memcpy(&v, b, 8); return v; }
@@ -319,7 +382,19 @@ extern "C" int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, 
   return UVOL_OK;
 }
 
-int texdec_create(uvol_ctx *ctx) { ctx->texdec = new TexDecState(); return UVOL_OK; }
+int texdec_create(uvol_ctx *ctx) {
+  ctx->texdec = new TexDecState();
+#ifndef HIPEMU
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->texdec->max_lds = (size_t)v;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tdec_slices_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->texdec->max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tdec_slices), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->texdec->max_lds);
+  (void)hipGetLastError();
+#else
+  ctx->texdec->max_lds = 160 * 1024;
+#endif
+  return UVOL_OK;
+}
 void texdec_destroy(uvol_ctx *ctx) {
   TexDecState *t = ctx->texdec; if (!t) return;
   for (uvol_devbuf *b : { &t->files, &t->slab, &t->outs, &t->jobs }) if (b->p) (void)hipFree(b->p);
@@ -374,11 +449,14 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->jobs.p, T->hjobs.data(), sizeof(TexDecJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   TexDecJob *dj = (TexDecJob *)T->jobs.p;
-  const size_t rowsz = ((size_t)J0.bx + 2) & ~(size_t)1;
-  const size_t lds = ((1u << TD_LUT_EPM) + (1u << TD_LUT_DEM) + (1u << TD_LUT_SM) + (1u << TD_LUT_RLE) + 64) * 4 + 2 * rowsz * 2 + 2 * rowsz + 64;
-  if (lds > 64 * 1024) { ctx->set_error("texture too wide for the slice decoder's row buffers"); return UVOL_E_UNSUPPORTED; }
+  const uint32_t rowsz = (J0.bx + 2) & ~1u;
+  const size_t lds_serial = ((size_t)TD_LUT_WORDS + td_wave_words(rowsz)) * 4, lds_pipe = ((size_t)TD_LUT_WORDS + (size_t)L * td_wave_words(rowsz)) * 4;
+  const bool pipe = L <= 16 && lds_pipe <= T->max_lds;
+  if ((pipe ? lds_pipe : lds_serial) > T->max_lds) { ctx->set_error("texture too wide for the slice decoder's row buffers"); return UVOL_E_UNSUPPORTED; }
   { uvol_ctx::Scope sc(ctx, "texdec.k1_tables", 0); DLAUNCH(k_tdec_tables, dim3((unsigned)n), dim3(64), 0, dj); }
-  { uvol_ctx::Scope sc(ctx, "texdec.k2_slices", 0); DLAUNCH(k_tdec_slices, dim3((unsigned)n), dim3(64), lds, dj); }
+  { uvol_ctx::Scope sc(ctx, "texdec.k2_slices", 0);
+    if (pipe) DLAUNCH(k_tdec_slices_pipe, dim3((unsigned)n), dim3(64 * (unsigned)L), lds_pipe, dj);
+    else DLAUNCH(k_tdec_slices, dim3((unsigned)n), dim3(64), lds_serial, dj); }
   { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes); DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
