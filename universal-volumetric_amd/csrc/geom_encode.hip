@@ -275,7 +275,13 @@ typedef int4 uvol_i4;
 #else
 typedef int uvol_i4 __attribute__((ext_vector_type(4)));      // loadable through an address-space-qualified pointer
 #endif
-template <typename P> __device__ __forceinline__ bool pbit_get(P w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+// bitmap words: LDS pointers read with ds_read; global pointers with a device-scope load that bypasses the per-CU L1,
+// because the bits are set with atomic ORs performed in L2 (a plain load could return a stale L1 line)
+__device__ __forceinline__ uint32_t pword(UVOL_L(uint32_t) w, int k) { return w[k]; }
+#ifndef HIPEMU
+__device__ __forceinline__ uint32_t pword(UVOL_G(uint32_t) w, int k) { return UVOL_ALOAD(&w[k]); }
+#endif
+template <typename P> __device__ __forceinline__ bool pbit_get(P w, int i) { return (pword(w, i >> 5) >> (i & 31)) & 1u; }
 template <typename P> __device__ __forceinline__ void pbit_set(P w, int i) { UVOL_OR_NORET(&w[i >> 5], 1u << (i & 31)); }   // fire and forget
 __device__ __forceinline__ int code_nxt(int x) { return (x & 3) == 2 ? x - 2 : x + 1; }
 __device__ __forceinline__ int code_prv(int x) { return (x & 3) == 0 ? x + 2 : x - 1; }
@@ -334,8 +340,8 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
-        const uint32_t vw_ = vbits[v >> 5];
-        const uint32_t rw_ = rcn < 0 ? 0xffffffffu : fbits[rcn >> 7], lw_ = lcn < 0 ? 0xffffffffu : fbits[lcn >> 7];
+        const uint32_t vw_ = pword(vbits, v >> 5);
+        const uint32_t rw_ = rcn < 0 ? 0xffffffffu : pword(fbits, rcn >> 7), lw_ = lcn < 0 ? 0xffffffffu : pword(fbits, lcn >> 7);
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v);
           if (!(vi & 1)) { symb[nproc] = T_C; nproc++; x = rcn; continue; }
@@ -611,8 +617,8 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
-        const uint32_t vw_ = vbits[v >> 5];
-        const uint32_t rw_ = rc < 0 ? 0xffffffffu : fbits[rc >> 7], lw_ = lc < 0 ? 0xffffffffu : fbits[lc >> 7];
+        const uint32_t vw_ = pword(vbits, v >> 5);
+        const uint32_t rw_ = rc < 0 ? 0xffffffffu : pword(fbits, rc >> 7), lw_ = lc < 0 ? 0xffffffffu : pword(fbits, lc >> 7);
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v); order[n] = 3 * face + (x & 3); n++;
           if (!(vi & 1)) { x = rc; continue; }
