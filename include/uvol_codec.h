@@ -129,6 +129,26 @@ int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, cons
 int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                      uint8_t *const *rgba_dev, size_t layer_cap);
 
+/* ---- decode path, geometry half ----
+ * Replaces what the stock player obtains from the draco WASM decoder per frame (reference src/V2/player.ts:101, :313-336):
+ * Draco 2.2 TRIANGULAR_MESH / valence-edgebreaker files with the attribute decoders of the fixtures (position, tex-coord,
+ * normal, optional generic) -> de-quantised values per attribute in decoding order + one entry index per corner, i.e. the
+ * inverse of uvol_mesh. */
+typedef struct uvol_decoded_mesh {
+  /* in: capacities of the caller's buffers */
+  uint32_t cap_faces;              /* idx_* hold 3 * cap_faces entries */
+  size_t cap_values;               /* pos / nrm hold 3 * cap_values floats, uv 2 * cap_values (3 * n_faces always suffices) */
+  /* in: caller buffers (any may be NULL to skip that output) */
+  float *pos, *uv, *nrm;
+  uint32_t *idx_pos, *idx_uv, *idx_nrm;
+  /* out */
+  uint32_t n_faces, n_pos, n_uv, n_nrm;
+} uvol_decoded_mesh;
+/* host-only: face count of a .drc and the value count that always suffices (UVOL_E_INVALID for foreign data) */
+int uvol_drc_info(const uint8_t *drc, size_t len, uint32_t *n_faces, uint32_t *max_values);
+/* n frames, one kernel launch per stage; status[i] per frame (may be NULL) */
+int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
+
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int uvol_profile_enable(uvol_ctx *ctx, int on);

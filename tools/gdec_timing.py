@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Geometry decode-path timing on a real GPU: N x (100k-vertex / 200k-face .drc of this codec) decoded in one batch.
+usage: tools/gdec_timing.py [n_frames]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
+import numpy as np
+import uvol, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+c = uvol.Codec(device=0, max_batch=n)
+files = c.encode_mesh_batch([synth.sphere_mesh(frame=k) for k in range(4)])
+files = [files[i % 4] for i in range(n)]
+c.decode_mesh_batch(files[:2])
+c.profile(True); c.profile_reset()
+t = time.time(); res = c.decode_mesh_batch(files); dt = time.time() - t
+print(json.dumps(dict(frames=n, drc_bytes=len(files[0]), wall_s=dt, frames_per_s=n / dt, groups={g["name"]: round(g["total_ms"], 1) for g in c.profile_report()})))

@@ -1,0 +1,652 @@
+// geom_decode.hip — batched Draco 2.2 mesh decode (geometry half): `.drc` (TRIANGULAR_MESH, valence
+// edgebreaker, the attribute decoders of SURVEY A.0) -> per-attribute value arrays + per-corner indices.
+// Replaces what the stock player obtains from the draco WASM decoder per frame (reference src/V2/player.ts:101, :313-336:
+// DRACOLoader -> BufferGeometry with position / uv / normal).  Bitstream: SURVEY Appendix A.1-A.9.
+//
+// Stages (n frames per call, one launch per stage; serial stages run one lane per frame / stream / attribute):
+//   k_gdec_index    1 lane / frame     header, split events, every section's offset (rabs streams, symbol tables, payloads)
+//   k_gdec_rans     1 wave / stream    probability tables (lanes), slot->symbol LUT, serial rANS symbol decode
+//   k_gdec_conn     1 lane / frame     connectivity state machine (C/S/L/R/E + valence contexts + start faces) -> opp, c2v
+//   k_gdec_seams    1 lane / frame     attribute seam bits (rabs) in corner order
+//   k_gdec_atttab   1 lane / (attribute, frame)  attribute corner tables (vertex ids per seam-separated fan segment)
+//   k_gdec_open     parallel           on-boundary flags, job scalars for the shared traversal kernels
+//   k_pack_faces / k_traverse / k_v2d  (geom_encode.hip) the SAME DepthFirstTraverser kernels the encoder uses
+//   k_gdec_rans     again for the attribute symbol streams (their lengths are the traversal results)
+//   k_gdec_pred     1 lane / (decoder, frame)   parallelogram / tex-coord-portable / geometric-normal prediction + transforms
+//   k_gdec_finish   parallel           dequantisation (fp32, octahedral) and per-corner entry indices
+#include "uvol_common.hpp"
+#include "geom_device.hpp"
+
+#define GD_NRS 10          // rANS streams: 0..5 valence contexts, 6 + d = attribute decoder d (d < 4)
+#define GD_MAXDEC 4
+#define GD_MAXAD 4
+#define GD_MAX_NS (1u << 18)   // largest symbol alphabet of an attribute stream (16-bit quantisation residuals fit)
+#define GD_CTX_NS 16
+
+struct GDRans { uint32_t present, scheme, bl, prec_bits, ns, max_ns, max_prec_bits, tab_off, pay_off, pay_len, nvals; uint32_t *probs, *cum, *lut, *out; };
+struct GDRabs { uint32_t present, p0, pay_off, pay_len; };
+struct GDAtt {
+  int32_t att_data_id, dec_type, att_type, data_type, ncomp, unique_id, seq_type, pred_method, transform, nc;
+  int32_t lo, hi, n_orient, maxq, cen, qbits; float minv[4], range;
+  int32_t table;                 // 0 = base corner table, 1 + i = attribute table i
+  int32_t *vals;                 // ne * nc decoded integers, entry order
+  GDRabs aux;                    // uv orientation bits / normal flip bits
+};
+struct GeoDecJob {
+  const uint8_t *file; uint32_t file_len; int32_t status;
+  int32_t nev, nf, nad, nsym, nsplit, nts, ndec, nv, n_interior_start;
+  uint32_t ts_off, ts_bits_off;  // topology split events: varint pairs, then packed source-edge bits
+  GDRabs rb_start, rb_seam[GD_MAXAD];
+  GDRans rs[GD_NRS];
+  GDAtt att[GD_MAXDEC];
+  int32_t *sp_src, *sp_spl; uint8_t *sp_edge;
+  int32_t *opp, *c2v, *lm, *val, *stack, *tsac;
+  uint8_t *edge_seam[GD_MAXAD]; int32_t *t_c2v[GD_MAXAD], *t_lm[GD_MAXAD]; int32_t t_nv[GD_MAXAD]; uint8_t *vseam;
+  uint8_t *vopen[1 + GD_MAXAD];
+  uint8_t *aux_bits;             // decoded orientation / flip bits
+  // outputs (device): position / uv / normal values and per-corner entry indices
+  float *o_val[3]; uint32_t *o_idx[3]; uint32_t o_n[3]; int32_t o_dec[3];
+};
+
+// ---- byte reader (one lane) ----
+struct GRd { const uint8_t *b; uint32_t n, o; int err; };
+__device__ __forceinline__ uint32_t gr_u8(GRd &r) { if (r.o + 1 > r.n) { r.err = 1; return 0; } return r.b[r.o++]; }
+__device__ __forceinline__ int32_t gr_i32(GRd &r) { if (r.o + 4 > r.n) { r.err = 1; return 0; } uint32_t v = 0; for (int k = 0; k < 4; k++) v |= (uint32_t)r.b[r.o + k] << (8 * k); r.o += 4; return (int32_t)v; }
+__device__ __forceinline__ float gr_f32(GRd &r) { const int32_t v = gr_i32(r); float f; memcpy(&f, &v, 4); return f; }
+__device__ __forceinline__ uint32_t gr_varint(GRd &r) {
+  uint64_t v = 0; int s = 0;
+  for (;;) { if (r.o >= r.n || s > 63) { r.err = 1; return 0; } const uint32_t c = r.b[r.o++]; v |= (uint64_t)(c & 0x7f) << s; s += 7; if (c < 0x80) break; }
+  return (uint32_t)v;
+}
+// rabs section: prob byte, varint length, payload
+__device__ inline void gr_rabs(GRd &r, GDRabs &B) { B.present = 1; B.p0 = gr_u8(r); B.pay_len = gr_varint(r); B.pay_off = r.o; if (r.o + B.pay_len > r.n) r.err = 1; else r.o += B.pay_len; }
+// rANS symbol section (RAW scheme): scheme, bit length, alphabet size, probability table, varint length, payload
+__device__ inline void gr_rans(GRd &r, GDRans &S, uint32_t nvals) {
+  S.present = 1; S.nvals = nvals; S.scheme = gr_u8(r); S.bl = gr_u8(r);
+  if (S.scheme != 1) { r.err = 2; return; }
+  int pb = (3 * (int)S.bl) / 2; if (pb < 12) pb = 12; if (pb > 20) pb = 20; S.prec_bits = (uint32_t)pb;
+  S.ns = gr_varint(r); S.tab_off = r.o;
+  if (S.ns > S.max_ns || S.prec_bits > S.max_prec_bits) { r.err = 1; return; }
+  for (uint32_t i = 0; i < S.ns && !r.err;) { const uint32_t pd = gr_u8(r), tok = pd & 3; if (tok == 3) i += (pd >> 2) + 1; else { for (uint32_t k = 0; k < tok; k++) (void)gr_u8(r); i++; } }
+  S.pay_len = gr_varint(r); S.pay_off = r.o; if (r.o + S.pay_len > r.n) r.err = 1; else r.o += S.pay_len;
+}
+
+// ---- K1: index every section of the file ----
+__global__ void __launch_bounds__(64) k_gdec_index(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.x];
+  if (threadIdx.x != 0 || J.status != 0) return;
+  const uint8_t *b = J.file; const uint32_t n = J.file_len;
+  if (n < 11 || b[0] != 'D' || b[1] != 'R' || b[2] != 'A' || b[3] != 'C' || b[4] != 'O') { J.status = -1; return; }
+  if (b[7] != 1 || b[8] != 1) { J.status = -2; return; }
+  if (b[5] != 2 || b[6] != 2) { J.status = -3; return; }
+  if ((b[9] | (b[10] << 8)) != 0) { J.status = -4; return; }
+  GRd r; r.b = b; r.n = n; r.o = 11; r.err = 0;
+  if (gr_u8(r) != 2) { J.status = -5; return; }
+  const int nev = (int)gr_varint(r), nf = (int)gr_varint(r), nad = (int)gr_u8(r), nsym = (int)gr_varint(r), nsplit = (int)gr_varint(r), nts = (int)gr_varint(r);
+  if (r.err || nf <= 0 || nf != J.nf || nad > GD_MAXAD || nsym > nf || nts > nf || nev != J.nev) { J.status = -6; return; }
+  J.nad = nad; J.nsym = nsym; J.nsplit = nsplit; J.nts = nts;
+  { int last = 0; for (int i = 0; i < nts; i++) { const int d = (int)gr_varint(r), src = d + last, d2 = (int)gr_varint(r); J.sp_src[i] = src; J.sp_spl[i] = src - d2; last = src; }
+    if (r.o + (uint32_t)(nts + 7) / 8 > n) r.err = 1;
+    else { for (int i = 0; i < nts; i++) J.sp_edge[i] = (b[r.o + (i >> 3)] >> (i & 7)) & 1; if (nts > 0) r.o += (uint32_t)(nts + 7) / 8; } }
+  gr_rabs(r, J.rb_start);
+  for (int i = 0; i < nad; i++) gr_rabs(r, J.rb_seam[i]);
+  for (int i = 0; i < 6; i++) { const uint32_t cn = gr_varint(r); if (cn > (uint32_t)nf) r.err = 1; J.rs[i].present = 0; J.rs[i].nvals = cn; if (cn > 0 && !r.err) gr_rans(r, J.rs[i], cn); }
+  if (r.err) { J.status = -8; return; }
+  // attribute decoder headers (A.4)
+  const int ndec = (int)gr_u8(r); if (r.err || ndec < 1 || ndec > GD_MAXDEC) { J.status = -20; return; }
+  J.ndec = ndec;
+  for (int d = 0; d < ndec; d++) { GDAtt &A = J.att[d]; A.att_data_id = (int8_t)gr_u8(r); A.dec_type = (int)gr_u8(r); if (gr_u8(r) != 0) { J.status = -21; return; } }
+  for (int d = 0; d < ndec; d++) {
+    GDAtt &A = J.att[d];
+    if (gr_varint(r) != 1) { J.status = -22; return; }
+    A.att_type = (int)gr_u8(r); A.data_type = (int)gr_u8(r); A.ncomp = (int)gr_u8(r); (void)gr_u8(r); A.unique_id = (int)gr_varint(r);
+    A.seq_type = (int)gr_u8(r);
+  }
+  if (r.err) { J.status = -22; return; }
+  // attribute sections: prediction scheme, symbols, scheme data, transform data
+  for (int d = 0; d < ndec; d++) {
+    GDAtt &A = J.att[d];
+    if (A.dec_type == 1) { if (A.att_data_id < 0 || A.att_data_id >= nad || A.att_data_id > 1) { J.status = -23; return; } A.table = 1 + A.att_data_id; } else A.table = 0;
+    A.pred_method = (int8_t)gr_u8(r); A.transform = (int8_t)gr_u8(r);
+    if (gr_u8(r) != 1) { J.status = -24; return; }
+    A.nc = A.seq_type == 3 ? 2 : A.ncomp;
+    if (A.nc < 1 || A.nc > 4) { J.status = -24; return; }
+    gr_rans(r, J.rs[6 + d], 0);                      // value count = entries * nc, known after the traversal
+    A.aux.present = 0; A.n_orient = 0;
+    if ((A.pred_method == 1 || A.pred_method == 0) && A.transform == 1) { A.lo = gr_i32(r); A.hi = gr_i32(r); }
+    else if (A.pred_method == 5 && A.transform == 1 && A.nc == 2) { A.n_orient = gr_i32(r); if (A.n_orient < 0) { J.status = -26; return; } gr_rabs(r, A.aux); A.lo = gr_i32(r); A.hi = gr_i32(r); }
+    else if (A.pred_method == 6 && A.transform == 3 && A.nc == 2) { A.maxq = gr_i32(r); A.cen = gr_i32(r); gr_rabs(r, A.aux); }
+    else { J.status = -31; return; }
+    if (A.seq_type == 2) { for (int k = 0; k < A.ncomp && k < 4; k++) A.minv[k] = gr_f32(r); A.range = gr_f32(r); A.qbits = (int)gr_u8(r); }
+    else if (A.seq_type == 3) A.qbits = (int)gr_u8(r);
+    if (r.err) { J.status = r.err == 2 ? -25 : -32; return; }
+  }
+  if (r.o != n) { J.status = -33; return; }          // every fixture and every file of this codec is consumed to the byte
+}
+
+// arrays that start out "invalid" (-1): opposite corners, corner->vertex maps, split map
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_init(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x, nc = 3u * (uint32_t)J.nf;
+  if (i < nc) { J.opp[i] = GEO_INV; J.c2v[i] = GEO_INV; for (int k = 0; k < GD_MAXAD; k++) J.t_c2v[k][i] = GEO_INV; }
+  if (i < (uint32_t)J.nf + 2) J.tsac[i] = GEO_INV;
+}
+
+// ---- K2: rANS symbol decode, one wave per stream ----
+__device__ __forceinline__ int gd_ans_init(const uint8_t *buf, uint32_t n, uint32_t &off, uint32_t &st, uint32_t L, bool allow3) {
+  if (n == 0) return -1;
+  const int x = buf[n - 1] >> 6; off = n;
+  if (x == 0) { st = buf[n - 1] & 0x3f; off -= 1; }
+  else if (x == 1) { if (n < 2) return -1; st = ((uint32_t)buf[n - 2] | (uint32_t)buf[n - 1] << 8) & 0x3fff; off -= 2; }
+  else if (x == 2) { if (n < 3) return -1; st = ((uint32_t)buf[n - 3] | (uint32_t)buf[n - 2] << 8 | (uint32_t)buf[n - 1] << 16) & 0x3fffff; off -= 3; }
+  else { if (!allow3 || n < 4) return -1; st = ((uint32_t)buf[n - 4] | (uint32_t)buf[n - 3] << 8 | (uint32_t)buf[n - 2] << 16 | (uint32_t)buf[n - 1] << 24) & 0x3fffffff; off -= 4; }
+  st += L; return 0;
+}
+__global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, int count) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const int si = first + (int)blockIdx.x;
+  if (J.status != 0 || (int)blockIdx.x >= count) return;
+  GDRans &S = J.rs[si];
+  if (!S.present || S.nvals == 0) return;               // uniform for the wave
+  const uint32_t lane = threadIdx.x, ns = S.ns, prec = 1u << S.prec_bits, L = prec * 4;
+  __shared__ int s_err;
+  if (lane == 0) {
+    s_err = 0;
+    GRd r; r.b = J.file; r.n = J.file_len; r.o = S.tab_off; r.err = 0;
+    uint32_t i = 0;
+    while (i < ns && !r.err) {
+      const uint32_t pd = gr_u8(r), tok = pd & 3;
+      if (tok == 3) { uint32_t run = (pd >> 2) + 1; if (i + run > ns) { r.err = 1; break; } while (run--) S.probs[i++] = 0; }
+      else { uint32_t p = pd >> 2; for (uint32_t k = 0; k < tok; k++) p |= gr_u8(r) << (8 * (k + 1) - 2); S.probs[i++] = p; }
+    }
+    uint64_t c = 0;
+    for (i = 0; i < ns && !r.err; i++) { S.cum[i] = (uint32_t)c; c += S.probs[i]; if (c > prec) r.err = 1; }
+    if (r.err || c != prec) s_err = 1;
+  }
+  __syncthreads();
+  if (s_err) { if (lane == 0) J.status = -5; return; }
+  for (uint32_t s = lane; s < ns; s += 64) { const uint32_t c = S.cum[s], p = S.probs[s]; for (uint32_t j = 0; j < p; j++) S.lut[c + j] = s; }
+  __threadfence_block();
+  __syncthreads();
+  if (lane != 0) return;
+  const uint8_t *buf = J.file + S.pay_off; uint32_t off, st;
+  if (gd_ans_init(buf, S.pay_len, off, st, L, true)) { J.status = -6; return; }
+  const uint32_t mask = prec - 1, pb = S.prec_bits;
+  for (uint32_t k = 0; k < S.nvals; k++) {
+    while (st < L && off > 0) { off--; st = st * 256 + buf[off]; }
+    const uint32_t quo = st >> pb, rem = st & mask, s = S.lut[rem];
+    st = quo * S.probs[s] + rem - S.cum[s];
+    S.out[k] = s;
+  }
+}
+
+// ---- rabs bit decoder (one lane) ----
+struct GDBit { const uint8_t *buf; uint32_t off, st, p0; };
+__device__ __forceinline__ int gd_rabs_open(GDBit &R, const GeoDecJob &J, const GDRabs &B) {
+  R.buf = J.file + B.pay_off; R.p0 = B.p0;
+  if (B.pay_len == 0) { R.st = 4096; R.off = 0; return 0; }
+  return gd_ans_init(R.buf, B.pay_len, R.off, R.st, 4096, false);
+}
+__device__ __forceinline__ int gd_rabs_bit(GDBit &R) {
+  const uint32_t p = 256u - R.p0;
+  if (R.st < 4096 && R.off > 0) { R.off--; R.st = R.st * 256 + R.buf[R.off]; }
+  const uint32_t quot = R.st >> 8, rem = R.st & 255u, xn = quot * p;
+  if (rem < p) { R.st = xn + rem; return 1; }
+  R.st = R.st - xn - p; return 0;
+}
+
+// ---- K3: connectivity, one lane per frame ----
+__global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.x];
+  if (threadIdx.x != 0 || J.status != 0) return;
+  const int nf = J.nf, nsym = J.nsym, nts = J.nts, maxv = J.nev + J.nsplit + 3;
+  int32_t *opp = J.opp, *c2v = J.c2v, *lm = J.lm, *val = J.val, *stack = J.stack, *tsac = J.tsac;
+  int cnt[6]; for (int i = 0; i < 6; i++) cnt[i] = (int)J.rs[i].nvals;
+  GDBit SF; if (gd_rabs_open(SF, J, J.rb_start)) { J.status = -7; return; }
+  int rc = 0, nv = 0, sp = 0, nfaces = 0, active_ctx = -1, splits_left = nts, n_int = 0;
+  const int SYM2TOPO[5] = { 0, 1, 3, 5, 7 };
+#define GD_SETOPP(a, bb) do { opp[a] = (bb); opp[bb] = (a); } while (0)
+#define GD_ADDV() (nv < maxv ? (lm[nv] = GEO_INV, nv++) : (rc = -9, 0))
+  for (int sid = 0; sid < nsym && !rc; sid++) {
+    const int face = nfaces++; int check = 0, sym;
+    if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = J.rs[active_ctx].out[cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
+    else sym = 7;
+    const int corner = 3 * face;
+    if (sym == 0) {
+      if (sp == 0) { rc = -11; break; }
+      const int ca = stack[sp - 1], vx = c2v[g_nxt(ca)]; if (vx < 0 || lm[vx] < 0) { rc = -11; break; }
+      const int cb = g_nxt(lm[vx]);
+      if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -11; break; }
+      GD_SETOPP(ca, corner + 1); GD_SETOPP(cb, corner + 2);
+      const int vap = c2v[g_prv(ca)], vbn = c2v[g_nxt(cb)];
+      c2v[corner] = vx; c2v[corner + 1] = vbn; c2v[corner + 2] = vap; lm[vap] = corner + 2;
+      stack[sp - 1] = corner;
+    } else if (sym == 5 || sym == 3) {
+      if (sp == 0) { rc = -12; break; }
+      const int ca = stack[sp - 1]; if (opp[ca] != GEO_INV) { rc = -12; break; }
+      int oc, cl, cr;
+      if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; } else { oc = corner + 1; cl = corner; cr = corner + 2; }
+      GD_SETOPP(oc, ca); const int nvx = GD_ADDV(); if (rc) break; c2v[oc] = nvx; lm[nvx] = oc;
+      const int vr = c2v[g_prv(ca)]; c2v[cr] = vr; lm[vr] = cr;
+      c2v[cl] = c2v[g_nxt(ca)];
+      stack[sp - 1] = corner; check = 1;
+    } else if (sym == 1) {
+      if (sp == 0) { rc = -13; break; }
+      const int cb = stack[--sp];
+      if (tsac[sid] != GEO_INV) stack[sp++] = tsac[sid];
+      if (sp == 0) { rc = -13; break; }
+      const int ca = stack[sp - 1];
+      if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -13; break; }
+      GD_SETOPP(ca, corner + 2); GD_SETOPP(cb, corner + 1);
+      const int vp = c2v[g_prv(ca)]; c2v[corner] = vp; c2v[corner + 1] = c2v[g_nxt(ca)];
+      const int vbp = c2v[g_prv(cb)]; c2v[corner + 2] = vbp; lm[vbp] = corner + 2;
+      int cn = g_nxt(cb); const int vn = c2v[cn];
+      val[vp] += val[vn]; lm[vp] = lm[vn];
+      const int first = cn; int guard = 0;
+      while (cn != GEO_INV) { c2v[cn] = vp; const int o2 = opp[g_nxt(cn)]; cn = o2 < 0 ? GEO_INV : g_nxt(o2); if (cn == first || ++guard > 3 * nf) { rc = -13; break; } }
+      if (rc) break;
+      lm[vn] = GEO_INV;
+      stack[sp - 1] = corner;
+    } else {
+      const int v0 = GD_ADDV(), v1 = GD_ADDV(), v2 = GD_ADDV(); if (rc) break;
+      c2v[corner] = v0; c2v[corner + 1] = v1; c2v[corner + 2] = v2; lm[v0] = corner; lm[v1] = corner + 1; lm[v2] = corner + 2;
+      stack[sp++] = corner; check = 1;
+    }
+    { const int c = stack[sp - 1], nn = g_nxt(c), pp = g_prv(c);
+      if (sym == 0 || sym == 1) { val[c2v[nn]] += 1; val[c2v[pp]] += 1; }
+      else if (sym == 5) { val[c2v[c]] += 1; val[c2v[nn]] += 1; val[c2v[pp]] += 2; }
+      else if (sym == 3) { val[c2v[c]] += 1; val[c2v[nn]] += 2; val[c2v[pp]] += 1; }
+      else { val[c2v[c]] += 2; val[c2v[nn]] += 2; val[c2v[pp]] += 2; }
+      int av = val[c2v[nn]]; av = av < 2 ? 2 : (av > 7 ? 7 : av); active_ctx = av - 2; }
+    if (check) {
+      const int esid = nsym - sid - 1;
+      while (splits_left > 0 && J.sp_src[splits_left - 1] == esid) {
+        splits_left--;
+        const int top = stack[sp - 1];
+        const int nac = J.sp_edge[splits_left] == 1 ? g_nxt(top) : g_prv(top);
+        const int dsid = nsym - J.sp_spl[splits_left] - 1;
+        if (dsid < 0 || dsid > nsym) { rc = -14; break; }
+        tsac[dsid] = nac;
+      }
+    }
+  }
+  while (!rc && sp > 0) {
+    const int corner = stack[--sp];
+    if (gd_rabs_bit(SF)) {
+      const int vn = c2v[g_nxt(corner)], cb = g_nxt(lm[vn]), vx = c2v[g_nxt(cb)], cc = g_nxt(lm[vx]), vp = c2v[g_nxt(cc)];
+      if (nfaces >= nf) { rc = -15; break; }
+      const int face = nfaces++, nc = 3 * face;
+      GD_SETOPP(nc, corner); GD_SETOPP(nc + 1, cb); GD_SETOPP(nc + 2, cc);
+      c2v[nc] = vx; c2v[nc + 1] = vp; c2v[nc + 2] = vn;
+      n_int++;
+    }
+  }
+  if (!rc && nfaces != nf) rc = -16;
+  for (int i = 0; i < 6 && !rc; i++) if (cnt[i] != 0) rc = -17;
+  J.nv = nv; J.n_interior_start = n_int;
+  if (rc) J.status = rc;
+#undef GD_SETOPP
+#undef GD_ADDV
+}
+
+// ---- K4: seam bits (A.5), one lane per frame walks the corners in order ----
+__global__ void __launch_bounds__(64) k_gdec_seams(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.x];
+  if (threadIdx.x != 0 || J.status != 0) return;
+  const int nf = J.nf, nad = J.nad; const int32_t *opp = J.opp;
+  GDBit R[GD_MAXAD];
+  for (int i = 0; i < nad; i++) if (gd_rabs_open(R[i], J, J.rb_seam[i])) { J.status = -7; return; }
+  for (int f = 0; f < nf; f++) for (int k = 0; k < 3; k++) {
+    const int c = 3 * f + k, oc = opp[c];
+    if (oc == GEO_INV) { for (int i = 0; i < nad; i++) J.edge_seam[i][c] = 1; continue; }
+    if (oc / 3 < f) continue;
+    for (int i = 0; i < nad; i++) if (gd_rabs_bit(R[i])) { J.edge_seam[i][c] = 1; J.edge_seam[i][oc] = 1; }
+  }
+}
+
+// ---- K5: attribute corner tables, one lane per (attribute data, frame) ----
+__global__ void __launch_bounds__(64) k_gdec_atttab(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const int i = blockIdx.x;
+  if (threadIdx.x != 0 || J.status != 0 || i >= J.nad) return;
+  const int nf = J.nf, nv = J.nv; const int32_t *opp = J.opp, *c2v = J.c2v, *lm = J.lm; const uint8_t *es = J.edge_seam[i];
+  uint8_t *vseam = J.vseam + (size_t)i * ((size_t)nv + 64);
+  int32_t *tc = J.t_c2v[i], *tl = J.t_lm[i];
+  for (int c = 0; c < 3 * nf; c++) if (es[c]) { vseam[c2v[g_nxt(c)]] = 1; vseam[c2v[g_prv(c)]] = 1; }
+  GTab T; T.opp = opp; T.seam = es;
+  int tn = 0;
+  for (int v = 0; v < nv; v++) {
+    const int c = lm[v]; if (c == GEO_INV) continue;
+    int vid = tn, first = c;
+    if (vseam[v]) { int a = gt_swl(T, first); while (a != GEO_INV) { first = a; a = gt_swl(T, a); if (a == c) break; } }
+    tc[first] = vid; tl[tn++] = first;
+    int a = (opp[g_prv(first)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(first)]);
+    while (a != GEO_INV && a != first) {
+      if (es[g_nxt(a)]) { vid = tn; tl[tn++] = a; }
+      tc[a] = vid;
+      a = (opp[g_prv(a)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(a)]);
+    }
+  }
+  J.t_nv[i] = tn;
+}
+
+// ---- K6: on-boundary flags per table + the scalars the shared traversal kernels read from their GeoJob ----
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_open(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  GeoJob &G = gj[blockIdx.y];
+  const int t = blockIdx.z;                                  // 0 base, 1 + i attribute table
+  if (blockIdx.x == 0 && threadIdx.x == 0 && t == 0) {
+    G.status = J.status; G.nf = (uint32_t)J.nf; G.nc = 3u * (uint32_t)J.nf; G.nad = J.nad > 2 ? 2 : J.nad; G.nverts = 0xffffffffu;
+    G.nverts_t[1] = (uint32_t)J.nv;
+    for (int i = 0; i < 2; i++) { G.interior_seams[i] = i < J.nad ? 1 : 0; G.nverts_t[2 + i] = i < J.nad ? (uint32_t)J.t_nv[i] : 0; }
+  }
+  if (J.status != 0 || (t > 0 && t - 1 >= J.nad) || t > 2) return;
+  const int nvt = t == 0 ? J.nv : J.t_nv[t - 1];
+  const int v = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
+  if (v >= nvt) return;
+  GTab T; T.opp = J.opp; T.seam = t == 0 ? nullptr : J.edge_seam[t - 1];
+  const int lmc = t == 0 ? J.lm[v] : J.t_lm[t - 1][v];
+  J.vopen[t][v] = (lmc < 0 || gt_swl(T, lmc) < 0) ? 1 : 0;
+}
+
+// ---- K9: prediction decode, one lane per (decoder, frame).  phase 0: decoders on the base table (position, generic);
+//      phase 1: the ones that need decoded positions (tex-coord-portable, geometric normal) ----
+__device__ __forceinline__ int32_t gd_sgn(uint32_t s) { return (s & 1) ? -(int32_t)(s >> 1) - 1 : (int32_t)(s >> 1); }
+__device__ __forceinline__ int32_t gd_wrap(int32_t pred, int32_t corr, int32_t lo, int32_t hi) {
+  const int32_t md = 1 + hi - lo; int32_t v = (pred < lo ? lo : (pred > hi ? hi : pred)) + corr;
+  if (v > hi) v -= md; else if (v < lo) v += md;
+  return v;
+}
+__device__ inline void gd_oct_orig(const GOct &t, const int pred[2], const int corr[2], int32_t out[2]) {
+  int ps = pred[0] - t.CEN, pt = pred[1] - t.CEN;
+  const bool ind = (g_iabs(ps) + g_iabs(pt)) <= t.CEN;
+  if (!ind) g_invert_diamond(t, ps, pt);
+  const bool bl = (ps == 0 && pt == 0) || (ps < 0 && pt <= 0);
+  const int rc = g_rot_count(ps, pt);
+  if (!bl) g_rot(ps, pt, rc);
+  int os = g_modmax(t, ps + corr[0]), ot = g_modmax(t, pt + corr[1]);
+  if (!bl) g_rot(os, ot, (4 - rc) % 4);
+  if (!ind) g_invert_diamond(t, os, ot);
+  out[0] = os + t.CEN; out[1] = ot + t.CEN;
+}
+__global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, int phase) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const GeoJob &G = gj[blockIdx.y];
+  const int d = blockIdx.x;
+  if (threadIdx.x != 0 || J.status != 0 || G.status != 0 || d >= J.ndec) return;
+  GDAtt &A = J.att[d];
+  const bool needs_pos = A.pred_method == 5 || A.pred_method == 6;
+  if ((phase == 0) == needs_pos) return;
+  const int t = A.table, nc = A.nc, ne = (int)G.ne[t];
+  const int32_t *order = G.order[t], *v2d = G.v2d[t];
+  const int32_t *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1];
+  GTab X; X.opp = J.opp; X.seam = t == 0 ? nullptr : J.edge_seam[t - 1];
+  const uint32_t *syms = J.rs[6 + d].out; int32_t *out = A.vals;
+  int pdec = -1; for (int k = 0; k < J.ndec; k++) if (J.att[k].att_type == 0 && J.att[k].att_data_id == -1) pdec = k;
+  const int32_t *P = pdec >= 0 ? J.att[pdec].vals : nullptr; const int32_t *b_v2d = G.v2d[0], *c2v = J.c2v;
+  if (A.pred_method == 1 || A.pred_method == 0) {
+    const int32_t lo = A.lo, hi = A.hi;
+    for (int p = 0; p < ne; p++) {
+      int32_t pred[4] = { 0, 0, 0, 0 }; bool have = false;
+      if (p > 0 && A.pred_method == 1) {
+        const int ci = order[p], oci = gt_opp(X, ci);
+        if (oci != GEO_INV) {
+          const int a = v2d[xc2v[oci]], bn = v2d[xc2v[g_nxt(oci)]], bp = v2d[xc2v[g_prv(oci)]];
+          if (a < p && bn < p && bp < p) { for (int k = 0; k < nc; k++) pred[k] = out[bn * nc + k] + out[bp * nc + k] - out[a * nc + k]; have = true; }
+        }
+      }
+      if (!have && p > 0) for (int k = 0; k < nc; k++) pred[k] = out[(p - 1) * nc + k];
+      for (int k = 0; k < nc; k++) out[p * nc + k] = gd_wrap(pred[k], gd_sgn(syms[p * nc + k]), lo, hi);
+    }
+  } else if (A.pred_method == 5) {
+    if (!P) { J.status = -26; return; }
+    const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
+    { GDBit Rb; if (gd_rabs_open(Rb, J, A.aux)) { J.status = -26; return; } int last = 1; for (int k = 0; k < no; k++) { if (!gd_rabs_bit(Rb)) last = !last; ori[k] = (uint8_t)last; } }
+    const int32_t lo = A.lo, hi = A.hi; int nori = no;
+    for (int p = 0; p < ne; p++) {
+      const int c = order[p], cn = g_nxt(c), cp = g_prv(c);
+      const int nd = v2d[xc2v[cn]], pd = v2d[xc2v[cp]];
+      long long pred[2]; bool have = false;
+      if (pd < p && nd < p) {
+        const long long nuv[2] = { out[nd * 2], out[nd * 2 + 1] }, puv[2] = { out[pd * 2], out[pd * 2 + 1] };
+        if (puv[0] == nuv[0] && puv[1] == nuv[1]) { pred[0] = puv[0]; pred[1] = puv[1]; have = true; }
+        else {
+          const int32_t *tip = P + 3 * b_v2d[c2v[c]], *np_ = P + 3 * b_v2d[c2v[cn]], *pp_ = P + 3 * b_v2d[c2v[cp]];
+          long long pn[3], cnv[3], pn2 = 0, dd = 0;
+          for (int k = 0; k < 3; k++) { pn[k] = (long long)pp_[k] - np_[k]; pn2 += pn[k] * pn[k]; }
+          if (pn2 != 0) {
+            for (int k = 0; k < 3; k++) { cnv[k] = (long long)tip[k] - np_[k]; dd += pn[k] * cnv[k]; }
+            const long long pnuv[2] = { puv[0] - nuv[0], puv[1] - nuv[1] };
+            const long long xuv[2] = { nuv[0] * pn2 + dd * pnuv[0], nuv[1] * pn2 + dd * pnuv[1] };
+            long long cx2 = 0;
+            for (int k = 0; k < 3; k++) { const long long xp = np_[k] + (dd * pn[k]) / pn2, e = tip[k] - xp; cx2 += e * e; }
+            const long long ns_ = (long long)g_isqrt((uint64_t)cx2 * (uint64_t)pn2);
+            const long long cxuv[2] = { pnuv[1] * ns_, -pnuv[0] * ns_ };
+            if (nori <= 0) { J.status = -27; return; }
+            const int o_ = ori[--nori];
+            if (o_) { pred[0] = (xuv[0] + cxuv[0]) / pn2; pred[1] = (xuv[1] + cxuv[1]) / pn2; }
+            else { pred[0] = (xuv[0] - cxuv[0]) / pn2; pred[1] = (xuv[1] - cxuv[1]) / pn2; }
+            have = true;
+          }
+        }
+      }
+      if (!have) {
+        if (nd < p) { pred[0] = out[nd * 2]; pred[1] = out[nd * 2 + 1]; }
+        else if (p > 0) { pred[0] = out[(p - 1) * 2]; pred[1] = out[(p - 1) * 2 + 1]; }
+        else { pred[0] = pred[1] = 0; }
+      }
+      for (int k = 0; k < 2; k++) out[p * 2 + k] = gd_wrap((int32_t)pred[k], gd_sgn(syms[p * 2 + k]), lo, hi);
+    }
+    if (nori != 0) { J.status = -28; return; }
+  } else {
+    if (!P) { J.status = -29; return; }
+    GDBit Fb; if (gd_rabs_open(Fb, J, A.aux)) { J.status = -29; return; }
+    int q = 0; while ((1 << q) - 1 < A.maxq) q++;
+    const GOct ot = g_oct(q);
+    if (ot.MAXQ != A.maxq || ot.CEN != A.cen) { J.status = -30; return; }
+    for (int dd = 0; dd < ne; dd++) {
+      const int c0 = order[dd];
+      const int32_t *cenp = P + 3 * b_v2d[c2v[c0]];
+      long long N[3] = { 0, 0, 0 };
+      int c = c0; bool left = true;
+      while (c != GEO_INV) {
+        const int32_t *a = P + 3 * b_v2d[c2v[g_nxt(c)]], *bb = P + 3 * b_v2d[c2v[g_prv(c)]];
+        long long dn[3], dp[3];
+        for (int k = 0; k < 3; k++) { dn[k] = (long long)a[k] - cenp[k]; dp[k] = (long long)bb[k] - cenp[k]; }
+        N[0] += dn[1] * dp[2] - dn[2] * dp[1]; N[1] += dn[2] * dp[0] - dn[0] * dp[2]; N[2] += dn[0] * dp[1] - dn[1] * dp[0];
+        if (left) { c = gt_swl(X, c); if (c == c0) break; if (c == GEO_INV) { left = false; c = gt_swr(X, c0); } }
+        else c = gt_swr(X, c);
+      }
+      long long s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
+      if (s > (1 << 29)) { const long long qd = s / (1 << 29); for (int k = 0; k < 3; k++) N[k] /= qd; }
+      int pv[3];
+      s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
+      if (s == 0) { pv[0] = ot.CEN; pv[1] = 0; pv[2] = 0; }
+      else { const long long aa = (N[0] * ot.CEN) / s, bb2 = (N[1] * ot.CEN) / s; long long cc = ot.CEN - g_labs(aa) - g_labs(bb2); if (N[2] < 0) cc = -cc; pv[0] = (int)aa; pv[1] = (int)bb2; pv[2] = (int)cc; }
+      if (gd_rabs_bit(Fb)) { pv[0] = -pv[0]; pv[1] = -pv[1]; pv[2] = -pv[2]; }
+      int po[2]; g_vec_to_oct(ot, pv, po[0], po[1]);
+      const int corr[2] = { (int)syms[2 * dd], (int)syms[2 * dd + 1] };
+      gd_oct_orig(ot, po, corr, out + 2 * dd);
+    }
+  }
+}
+
+// attribute symbol counts = entries of the decoder's table x components (known after the traversal)
+__global__ void __launch_bounds__(64) k_gdec_counts(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.x]; GeoJob &G = gj[blockIdx.x];
+  if (threadIdx.x != 0) return;
+  if (G.status != 0 && J.status == 0) J.status = G.status;
+  if (J.status != 0) return;
+  for (int d = 0; d < J.ndec; d++) J.rs[6 + d].nvals = G.ne[J.att[d].table] * (uint32_t)J.att[d].nc;
+}
+
+// ---- K10: outputs.  blockIdx.z = 0 position, 1 tex-coord, 2 normal ----
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_finish(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
+  if (J.status != 0) return;
+  const int which = blockIdx.z;
+  int d = -1;
+  for (int k = 0; k < J.ndec; k++) { const int at = J.att[k].att_type; if ((which == 0 && at == 0) || (which == 1 && at == 3) || (which == 2 && at == 1)) { d = k; break; } }
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (d < 0) { if (i == 0) { J.o_n[which] = 0; J.o_dec[which] = -1; } return; }
+  const GDAtt &A = J.att[d];
+  const int t = A.table; const uint32_t ne = G.ne[t];
+  if (i == 0) { J.o_n[which] = ne; J.o_dec[which] = d; }
+  if (i < 3u * (uint32_t)J.nf && J.o_idx[which]) { const int32_t *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1]; J.o_idx[which][i] = (uint32_t)G.v2d[t][xc2v[i]]; }
+  if (i >= ne || !J.o_val[which]) return;
+  float *o = J.o_val[which];
+  if (A.seq_type == 2) {
+    const float delta = A.range / (float)((1u << A.qbits) - 1);
+    for (int k = 0; k < A.ncomp; k++) o[(size_t)i * A.ncomp + k] = A.minv[k] + (float)A.vals[(size_t)i * A.ncomp + k] * delta;
+  } else if (A.seq_type == 3) {
+    const GOct ot = g_oct(A.qbits);
+    float y = (float)A.vals[2 * (size_t)i] * (2.0f / (float)ot.MAXV) - 1.0f, z = (float)A.vals[2 * (size_t)i + 1] * (2.0f / (float)ot.MAXV) - 1.0f;
+    float x = 1.0f - fabsf(y) - fabsf(z); const float xo = x < 0 ? -x : 0;
+    y += y < 0 ? xo : -xo; z += z < 0 ? xo : -xo;
+    const float nn = sqrtf(x * x + y * y + z * z);
+    if (nn > 1e-6f) { x /= nn; y /= nn; z /= nn; } else { x = y = z = 0; }
+    o[3 * (size_t)i] = x; o[3 * (size_t)i + 1] = y; o[3 * (size_t)i + 2] = z;
+  } else for (int k = 0; k < A.ncomp; k++) o[(size_t)i * A.ncomp + k] = (float)A.vals[(size_t)i * A.ncomp + k];
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct GeoDecState { uvol_devbuf files, slab, jobs, gjobs, outs; std::vector<GeoDecJob> hjobs; std::vector<GeoJob> hg; };
+int geodec_create(uvol_ctx *ctx) { ctx->geodec = new GeoDecState(); return UVOL_OK; }
+void geodec_destroy(uvol_ctx *ctx) {
+  GeoDecState *t = ctx->geodec; if (!t) return;
+  for (uvol_devbuf *b : { &t->files, &t->slab, &t->jobs, &t->gjobs, &t->outs }) if (b->p) (void)hipFree(b->p);
+  delete t; ctx->geodec = nullptr;
+}
+
+static bool gdec_header(const uint8_t *b, size_t n, uint32_t *nev, uint32_t *nf) {
+  if (!b || n < 16 || memcmp(b, "DRACO", 5)) return false;
+  size_t o = 12; uint32_t v[2];
+  for (int k = 0; k < 2; k++) { uint64_t r = 0; int s = 0; for (;;) { if (o >= n || s > 35) return false; const uint8_t c = b[o++]; r |= (uint64_t)(c & 0x7f) << s; s += 7; if (c < 0x80) break; } v[k] = (uint32_t)r; }
+  *nev = v[0]; *nf = v[1];
+  return v[1] > 0 && v[1] <= (1u << 26) && v[0] <= 3 * v[1] + 8;
+}
+extern "C" int uvol_drc_info(const uint8_t *drc, size_t len, uint32_t *n_faces, uint32_t *max_values) {
+  uint32_t nev = 0, nf = 0;
+  if (!gdec_header(drc, len, &nev, &nf)) return UVOL_E_INVALID;
+  if (n_faces) *n_faces = nf;
+  if (max_values) *max_values = 3 * nf;
+  return UVOL_OK;
+}
+
+// geom_encode.hip: k_pack_faces + k_traverse + k_v2d over tables 1..3 of a GeoJob array (the encoder's own sequencing kernels)
+int geo_run_traversals(uvol_ctx *ctx, GeoJob *gj, int n, uint32_t max_nfi, uint32_t max_vals);
+
+#define GLAUNCH(k, grid, block, shmem, ...)                                                      \
+  do {                                                                                           \
+    if (uvol_debug()) { fprintf(stderr, "[uvol] launch %s\n", #k); fflush(stderr); }              \
+    hipLaunchKernelGGL(k, grid, block, shmem, ctx->stream, __VA_ARGS__);                         \
+    if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
+  } while (0)
+
+// workspace of one frame (base == nullptr: size only); also wires the GeoJob view the shared traversal kernels read:
+// table 1 = base corner table, 2 / 3 = attribute tables 0 / 1
+static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) -> uint8_t * { uint8_t *p = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return p; };
+  const size_t nf = (size_t)J.nf, nc = 3 * nf, maxv = (size_t)J.nev + nf + 8;          // nsplit <= nf
+  J.sp_src = (int32_t *)take(4 * (nf + 1)); J.sp_spl = (int32_t *)take(4 * (nf + 1)); J.sp_edge = take(nf + 8);
+  J.opp = (int32_t *)take(4 * nc); J.c2v = (int32_t *)take(4 * nc);
+  J.lm = (int32_t *)take(4 * maxv); J.val = (int32_t *)take(4 * maxv);
+  J.stack = (int32_t *)take(4 * (nf + 8)); J.tsac = (int32_t *)take(4 * (nf + 2));
+  for (int k = 0; k < GD_MAXAD; k++) { J.edge_seam[k] = take(nc); J.t_c2v[k] = (int32_t *)take(4 * nc); J.t_lm[k] = (int32_t *)take(4 * nc); }
+  J.vseam = take(GD_MAXAD * (maxv + 64));
+  for (int k = 0; k < 1 + GD_MAXAD; k++) J.vopen[k] = take(nc + 64);
+  J.aux_bits = take(GD_MAXDEC * (nc + 64));
+  for (int k = 0; k < 6; k++) { GDRans &S = J.rs[k]; S.max_ns = GD_CTX_NS; S.max_prec_bits = 12; S.probs = (uint32_t *)take(4 * GD_CTX_NS); S.cum = (uint32_t *)take(4 * GD_CTX_NS); S.lut = (uint32_t *)take(4 * (1u << 12)); S.out = (uint32_t *)take(4 * (nf + 1)); }
+  for (int k = 0; k < GD_MAXDEC; k++) {
+    GDRans &S = J.rs[6 + k]; S.max_ns = GD_MAX_NS; S.max_prec_bits = 20;
+    S.probs = (uint32_t *)take(4 * (size_t)GD_MAX_NS); S.cum = (uint32_t *)take(4 * (size_t)GD_MAX_NS); S.lut = (uint32_t *)take(4 * (size_t)(1u << 20));
+    S.out = (uint32_t *)take(4 * (4 * nc + 4)); J.att[k].vals = (int32_t *)take(4 * (4 * nc + 4));
+  }
+  G.status = 0; G.nf = (uint32_t)nf; G.nc = (uint32_t)nc; G.nad = 2; G.nverts = 0xffffffffu;
+  G.nopp = J.opp; G.bvert = J.c2v; G.avert[0] = J.t_c2v[0]; G.avert[1] = J.t_c2v[1]; G.seam[0] = J.edge_seam[0]; G.seam[1] = J.edge_seam[1];
+  G.vopen_d[1] = J.vopen[0]; G.vopen_d[2] = J.vopen[1]; G.vopen_d[3] = J.vopen[2];
+  for (int k = 1; k < 4; k++) G.rec[k] = (int32_t *)take(64 * (nf + 1));
+  for (int k = 0; k < 3; k++) { G.order[k] = (int32_t *)take(4 * (nc + 3)); G.v2d[k] = (int32_t *)take(4 * (nc + 3)); G.t_stack[k] = (int32_t *)take(4 * (nf + 2)); G.t_fvis[k] = take(nf + 64); G.t_vvis[k] = take(nc + 64); }
+  return o;
+}
+
+int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
+  GeoDecState *T = ctx->geodec;
+  if (n <= 0) return UVOL_OK;
+  T->hjobs.assign((size_t)n, GeoDecJob{}); T->hg.assign((size_t)n, GeoJob{});
+  std::vector<size_t> foff((size_t)n), woff((size_t)n), ooff((size_t)n);
+  size_t ftot = 0, wtot = 0, otot = 0; uint32_t max_nf = 0;
+  auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  for (int i = 0; i < n; i++) {
+    uint32_t nev = 0, nf = 0;
+    if (!gdec_header(files[i], lens[i], &nev, &nf)) { ctx->set_error("frame %d: not a Draco 2.2 edgebreaker mesh", i); return UVOL_E_INVALID; }
+    if (out[i].cap_faces < nf || out[i].cap_values < 3 * (size_t)nf) { ctx->set_error("frame %d: output capacity too small (%u faces)", i, nf); return UVOL_E_NOSPACE; }
+    GeoDecJob &J = T->hjobs[i]; J.nf = (int32_t)nf; J.nev = (int32_t)nev; J.file_len = (uint32_t)lens[i];
+    max_nf = std::max(max_nf, nf);
+    foff[i] = ftot; ftot += a256(lens[i] + 16);
+    GeoJob gtmp{}; const size_t w = gdec_carve(J, gtmp, nullptr);
+    woff[i] = wtot; wtot += a256(w);
+    { const size_t nc = 3 * (size_t)nf; ooff[i] = otot; otot += 3 * (a256(4 * 3 * nc) + a256(4 * nc)); }
+  }
+  int rc;
+  if ((rc = uvol_ensure(ctx, T->files, ftot + 64))) return rc;
+  if ((rc = uvol_ensure(ctx, T->slab, wtot))) return rc;
+  if ((rc = uvol_ensure(ctx, T->jobs, sizeof(GeoDecJob) * (size_t)n))) return rc;
+  if ((rc = uvol_ensure(ctx, T->gjobs, sizeof(GeoJob) * (size_t)n))) return rc;
+  if ((rc = uvol_ensure(ctx, T->outs, otot))) return rc;
+  UVOL_HIP_CHECK(ctx, hipMemsetAsync(T->slab.p, 0, wtot, ctx->stream));
+  for (int i = 0; i < n; i++) {
+    GeoDecJob &J = T->hjobs[i]; GeoJob &G = T->hg[i];
+    uint8_t *fd = (uint8_t *)T->files.p + foff[i];
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(fd, files[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+    J.file = fd; J.status = 0;
+    (void)gdec_carve(J, G, (uint8_t *)T->slab.p + woff[i]);
+    const size_t nc = 3 * (size_t)J.nf;
+    uint8_t *ob = (uint8_t *)T->outs.p + ooff[i]; size_t oo = 0;
+    for (int k = 0; k < 3; k++) { J.o_val[k] = (float *)(ob + oo); oo += a256(4 * 3 * nc); J.o_idx[k] = (uint32_t *)(ob + oo); oo += a256(4 * nc); }
+  }
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->jobs.p, T->hjobs.data(), sizeof(GeoDecJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->gjobs.p, T->hg.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  GeoDecJob *dj = (GeoDecJob *)T->jobs.p; GeoJob *gj = (GeoJob *)T->gjobs.p;
+  const unsigned N = (unsigned)n, bc = uvol_blocks((size_t)3 * max_nf);
+  { uvol_ctx::Scope sc(ctx, "geodec.k1_index", 0); GLAUNCH(k_gdec_init, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj); GLAUNCH(k_gdec_index, dim3(N), dim3(64), 0, dj); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(6, N), dim3(64), 0, dj, 0, 6); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn, dim3(N), dim3(64), 0, dj); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k4_seams_tables", 0);
+    GLAUNCH(k_gdec_seams, dim3(N), dim3(64), 0, dj);
+    GLAUNCH(k_gdec_atttab, dim3(GD_MAXAD, N), dim3(64), 0, dj);
+    GLAUNCH(k_gdec_open, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
+    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, 3 * max_nf / 2 + 64))) return rc;
+    GLAUNCH(k_gdec_counts, dim3(N), dim3(64), 0, dj, gj); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(GD_MAXDEC, N), dim3(64), 0, dj, 6, GD_MAXDEC); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k7_predict", 0);
+    GLAUNCH(k_gdec_pred, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj, 0);
+    GLAUNCH(k_gdec_pred, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj, 1); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k8_finish", 0); GLAUNCH(k_gdec_finish, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
+  UVOL_HIP_CHECK(ctx, hipGetLastError());
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(GeoDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int worst = UVOL_OK;
+  for (int i = 0; i < n; i++) {
+    const GeoDecJob &J = T->hjobs[i]; uvol_decoded_mesh &M = out[i];
+    const int st = J.status == 0 ? UVOL_OK : UVOL_E_ENCODE;
+    if (status) status[i] = st;
+    if (st != UVOL_OK) { ctx->set_error("frame %d: corrupt or unsupported .drc (device status %d)", i, J.status); worst = st; continue; }
+    M.n_faces = (uint32_t)J.nf;
+    float *vals[3] = { M.pos, M.uv, M.nrm }; uint32_t *idx[3] = { M.idx_pos, M.idx_uv, M.idx_nrm }; uint32_t *cnt[3] = { &M.n_pos, &M.n_uv, &M.n_nrm };
+    const int comps[3] = { 3, 2, 3 };
+    for (int k = 0; k < 3; k++) {
+      *cnt[k] = J.o_n[k];
+      if (!J.o_n[k]) continue;
+      if (vals[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(vals[k], J.o_val[k], (size_t)J.o_n[k] * comps[k] * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (idx[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(idx[k], J.o_idx[k], (size_t)J.nf * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->resolve_profile();
+  return status ? UVOL_OK : worst;
+}

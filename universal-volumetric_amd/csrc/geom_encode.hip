@@ -630,7 +630,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
     }
   }
   J.ne[t] = (uint32_t)n;
-  if (t == 0 && (uint32_t)n != J.nverts) J.status = -11;
+  if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
 
 template <bool LDS>
@@ -1395,6 +1395,38 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
   for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * UVOL_BLOCK) p[i] = make_uint4(0, 0, 0, 0);
 }
 
+// LDS sizing of the serial walkers for a batch: the largest face count and attribute-value count (see geo_encode_batch)
+static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t *lds_bytes, int *vcap_words) {
+  const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
+  // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
+  // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
+  // whatever fits the same number of walkers per CU, so the slack of the LDS slot is not wasted.
+  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4;
+  const size_t v_min_bytes = std::min<size_t>((((size_t)max_vals + max_vals / 16 + 31) / 32 + 2) * 4, ((3 * (size_t)max_nfi + 31) / 32) * 4);
+  size_t per_cu = lds_cu / (fw_bytes + v_min_bytes); if (per_cu < 1) per_cu = 1;
+  const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
+  // UVOL_WALK_FORCE (tests): "vglobal" = vertex bitmaps in global memory, "global" = both bitmaps in global memory
+  static const int walk_force = [] { const char *e = getenv("UVOL_WALK_FORCE"); return !e ? 0 : (!strcmp(e, "vglobal") ? 1 : (!strcmp(e, "global") ? 2 : 0)); }();
+  const size_t walk_vcw = walk_force == 1 ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
+  const size_t walk_lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4;
+  *lds_bytes = walk_lds; *vcap_words = walk_vcw;
+  return walk_lds <= G->max_lds && walk_force != 2;
+}
+
+// attribute sequencing of a prepared GeoJob array (tables 1..3): corner records, DepthFirstTraverser, inverse maps.
+// Shared with the decode path (geom_decode.hip), which fills the same job fields from a decoded corner table.
+int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint32_t max_vals) {
+  GeoState *G = ctx->geo;
+  const unsigned N = (unsigned)n, bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi);
+  size_t walk_lds = 0; int vcw = 0;
+  const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &vcw);
+  for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w);
+  if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0);
+  else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj, 0, 0);
+  LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
+  return UVOL_OK;
+}
+
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   GeoState *G = ctx->geo;
@@ -1480,24 +1512,13 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
-  const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
-  // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
-  // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
-  // whatever fits the same number of walkers per CU, so the slack of the LDS slot is not wasted.
-  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4;
-  const size_t v_min_bytes = std::min<size_t>((((size_t)max_vals + max_vals / 16 + 31) / 32 + 2) * 4, ((3 * (size_t)max_nfi + 31) / 32) * 4);
-  size_t per_cu = lds_cu / (fw_bytes + v_min_bytes); if (per_cu < 1) per_cu = 1;
-  const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
-  // UVOL_WALK_FORCE (tests): "vglobal" = vertex bitmaps in global memory, "global" = both bitmaps in global memory
-  static const int walk_force = [] { const char *e = getenv("UVOL_WALK_FORCE"); return !e ? 0 : (!strcmp(e, "vglobal") ? 1 : (!strcmp(e, "global") ? 2 : 0)); }();
-  const size_t walk_vcw = walk_force == 1 ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
-  const size_t walk_lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4;
-  const bool use_lds = walk_lds <= G->max_lds && walk_force != 2;
+  size_t walk_lds = 0; int walk_vcw = 0;
+  const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &walk_vcw);
   {
     DENSE_TABLE(0);
     LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj, (int)walk_vcw);
+    if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw);
     else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj, 0);
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
@@ -1529,7 +1550,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj, (int)walk_vcw, uvol_debug() ? 1 : 0);
+    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj, walk_vcw, uvol_debug() ? 1 : 0);
     else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj, 0, 0);
     LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
   }

@@ -56,7 +56,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
   if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
   if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
   if (uvol_make_stream(ctx, &ctx->stream) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
-  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
+  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
   *out = ctx;
   return UVOL_OK;
 }
@@ -66,7 +66,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
-  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx);
+  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -147,6 +147,18 @@ int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, 
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba_dev) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true);
+}
+
+int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
+  if (!ctx || !drc || !lens || n < 0 || !out) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  const int mb = ctx->prm.max_batch;
+  for (int b0 = 0; b0 < n; b0 += mb) {
+    const int nb = n - b0 < mb ? n - b0 : mb;
+    const int rc = geo_decode_batch(ctx, drc + b0, lens + b0, nb, out + b0, status ? status + b0 : nullptr);
+    if (rc != UVOL_OK) return rc;
+  }
+  return UVOL_OK;
 }
 
 int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; ctx->profiling = on != 0; return UVOL_OK; }

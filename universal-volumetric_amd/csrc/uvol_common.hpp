@@ -98,6 +98,7 @@ struct uvol_devbuf {
 struct GeoState;   // geometry pipeline state (geom_encode.hip)
 struct TexState;   // texture pipeline state (tex_encode.hip)
 struct TexDecState;  // texture decode state (tex_decode.hip)
+struct GeoDecState;  // geometry decode state (geom_decode.hip)
 
 struct uvol_ctx {
   int device = 0;
@@ -111,6 +112,7 @@ struct uvol_ctx {
   GeoState *geo = nullptr;
   TexState *tex = nullptr;
   TexDecState *texdec = nullptr;
+  GeoDecState *geodec = nullptr;
 
   void set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(err, sizeof(err), fmt, ap); va_end(ap);
@@ -163,6 +165,9 @@ int geo_create(uvol_ctx *ctx);
 void geo_destroy(uvol_ctx *ctx);
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+int geodec_create(uvol_ctx *ctx);
+void geodec_destroy(uvol_ctx *ctx);
+int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
 int texdec_create(uvol_ctx *ctx);
 void texdec_destroy(uvol_ctx *ctx);
 int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device);

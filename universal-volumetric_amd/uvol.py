@@ -14,6 +14,12 @@ DEFAULT_LIB = os.path.join(_HERE, "libuvolcodec.so")
 UVOL_OK, UVOL_E_INVALID, UVOL_E_NODEVICE, UVOL_E_HIP, UVOL_E_NOSPACE, UVOL_E_ENCODE, UVOL_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
 
+class DecodedMesh(C.Structure):
+    _fields_ = [("cap_faces", C.c_uint32), ("cap_values", C.c_size_t), ("pos", C.c_void_p), ("uv", C.c_void_p), ("nrm", C.c_void_p),
+                ("idx_pos", C.c_void_p), ("idx_uv", C.c_void_p), ("idx_nrm", C.c_void_p),
+                ("n_faces", C.c_uint32), ("n_pos", C.c_uint32), ("n_uv", C.c_uint32), ("n_nrm", C.c_uint32)]
+
+
 class Params(C.Structure):
     """project-config.json numeric fields used on the hot path (scripts/Encoder.py:171-179)."""
     _fields_ = [("Q_POSITION_ATTR", C.c_int32), ("Q_TEXTURE_ATTR", C.c_int32), ("Q_NORMAL_ATTR", C.c_int32),
@@ -32,7 +38,7 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
-           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
 
 
@@ -61,6 +67,8 @@ def load(path=None):
     L.uvol_ktx2_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for nm in ("uvol_decode_texture_segments", "uvol_decode_texture_segments_dev"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t]
+    L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.uvol_profile_reset.argtypes = [C.c_void_p]
     L.uvol_profile_count.argtypes = [C.c_void_p]
@@ -240,6 +248,38 @@ class Codec:
         rc = self.L.uvol_decode_texture_segments_dev(self.h, fp, ln, n, ptrs, layer_cap)
         if rc != UVOL_OK:
             raise UvolError(f"decode_texture_segments_dev rc={rc}: {self.error()}")
+
+    # ---- decode path (geometry half) ----
+    def decode_mesh_batch(self, files, raise_on_error=True):
+        """files: list of .drc bytes -> list of dicts {pos [n,3], uv [n,2], nrm [n,3] float32 in decoding order,
+        idx_pos / idx_uv / idx_nrm [3*faces] uint32 entry index per corner}; absent attributes are None."""
+        files = [bytes(f) for f in files]; n = len(files)
+        metas = (DecodedMesh * n)(); keep = []
+        for i, f in enumerate(files):
+            nf, mv = C.c_uint32(), C.c_uint32()
+            if self.L.uvol_drc_info(f, len(f), C.byref(nf), C.byref(mv)) != UVOL_OK:
+                raise UvolError(f"frame {i}: not a .drc this decoder handles")
+            a = dict(pos=np.empty((mv.value, 3), np.float32), uv=np.empty((mv.value, 2), np.float32), nrm=np.empty((mv.value, 3), np.float32),
+                     idx_pos=np.empty(3 * nf.value, np.uint32), idx_uv=np.empty(3 * nf.value, np.uint32), idx_nrm=np.empty(3 * nf.value, np.uint32))
+            keep.append(a)
+            m = metas[i]; m.cap_faces = nf.value; m.cap_values = mv.value
+            for k, v in a.items():
+                setattr(m, k, v.ctypes.data)
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files]); st = (C.c_int * n)()
+        rc = self.L.uvol_decode_mesh_batch(self.h, fp, ln, n, metas, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"decode_mesh_batch rc={rc}: {self.error()}")
+        res = []
+        for i in range(n):
+            if st[i] != UVOL_OK:
+                if raise_on_error:
+                    raise UvolError(f"frame {i} failed status={st[i]}: {self.error()}")
+                res.append(None); continue
+            m, a = metas[i], keep[i]
+            cnt = dict(pos=m.n_pos, uv=m.n_uv, nrm=m.n_nrm)
+            res.append({k: (a[k][:cnt[k]].copy() if cnt[k] else None) for k in ("pos", "uv", "nrm")} |
+                       {"idx_" + k: (a["idx_" + k].copy() if cnt[k] else None) for k in ("pos", "uv", "nrm")} | {"n_faces": m.n_faces})
+        return res
 
     # ---- measurement ----
     def profile(self, on=True):
