@@ -10,7 +10,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 c = uvol.Codec(device=0, max_batch=n)
 files = c.encode_mesh_batch([synth.sphere_mesh(frame=k) for k in range(4)])
 files = [files[i % 4] for i in range(n)]
-c.decode_mesh_batch(files[:2])
+c.decode_mesh_batch(files, fetch=False)            # warm-up: allocates the workspaces of the whole batch
 c.profile(True); c.profile_reset()
-t = time.time(); res = c.decode_mesh_batch(files); dt = time.time() - t
-print(json.dumps(dict(frames=n, drc_bytes=len(files[0]), wall_s=dt, frames_per_s=n / dt, groups={g["name"]: round(g["total_ms"], 1) for g in c.profile_report()})))
+t = time.time(); res = c.decode_mesh_batch(files, fetch=False); dt = time.time() - t
+c.profile(False)
+t = time.time(); res2 = c.decode_mesh_batch(files); dt2 = time.time() - t
+print(json.dumps(dict(frames=n, drc_bytes=len(files[0]), wall_s=dt, frames_per_s=n / dt, frames_per_s_with_fetch_to_host=n / dt2, groups={g["name"]: round(g["total_ms"], 1) for g in c.profile_report()})))

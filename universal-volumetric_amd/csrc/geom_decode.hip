@@ -41,9 +41,11 @@ struct GeoDecJob {
   GDAtt att[GD_MAXDEC];
   int32_t *sp_src, *sp_spl; uint8_t *sp_edge;
   int32_t *opp, *c2v, *lm, *val, *stack, *tsac;
-  uint8_t *edge_seam[GD_MAXAD]; int32_t *t_c2v[GD_MAXAD], *t_lm[GD_MAXAD]; int32_t t_nv[GD_MAXAD]; uint8_t *vseam;
+  uint8_t *edge_seam[GD_MAXAD]; int32_t *t_c2v[GD_MAXAD], *t_lm[GD_MAXAD]; int32_t t_nv[GD_MAXAD]; uint8_t *vseam; int32_t *t_cnt; uint8_t *seam_bits;
   uint8_t *vopen[1 + GD_MAXAD];
   uint8_t *aux_bits;             // decoded orientation / flip bits
+  int32_t *nbr;                  // parallelogram neighbour entries, 3 per entry and decoder
+  uint8_t *uvgeo;                // GDUvGeo per tex-coord entry
   // outputs (device): position / uv / normal values and per-corner entry indices
   float *o_val[3]; uint32_t *o_idx[3]; uint32_t o_n[3]; int32_t o_dec[3];
 };
@@ -200,7 +202,9 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.x];
   if (threadIdx.x != 0 || J.status != 0) return;
   const int nf = J.nf, nsym = J.nsym, nts = J.nts, maxv = J.nev + J.nsplit + 3;
-  int32_t *opp = J.opp, *c2v = J.c2v, *lm = J.lm, *val = J.val, *stack = J.stack, *tsac = J.tsac;
+  UVOL_G(int32_t) opp = UVOL_TO_G(int32_t, J.opp); UVOL_G(int32_t) c2v = UVOL_TO_G(int32_t, J.c2v); UVOL_G(int32_t) lm = UVOL_TO_G(int32_t, J.lm);
+  UVOL_G(int32_t) val = UVOL_TO_G(int32_t, J.val); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) tsac = UVOL_TO_G(int32_t, J.tsac);
+  UVOL_G(const uint32_t) ctxs[6]; for (int i = 0; i < 6; i++) ctxs[i] = UVOL_TO_G(const uint32_t, J.rs[i].out);
   int cnt[6]; for (int i = 0; i < 6; i++) cnt[i] = (int)J.rs[i].nvals;
   GDBit SF; if (gd_rabs_open(SF, J, J.rb_start)) { J.status = -7; return; }
   int rc = 0, nv = 0, sp = 0, nfaces = 0, active_ctx = -1, splits_left = nts, n_int = 0;
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
 #define GD_ADDV() (nv < maxv ? (lm[nv] = GEO_INV, nv++) : (rc = -9, 0))
   for (int sid = 0; sid < nsym && !rc; sid++) {
     const int face = nfaces++; int check = 0, sym;
-    if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = J.rs[active_ctx].out[cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
+    if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = ctxs[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
     else sym = 7;
     const int corner = 3 * face;
     if (sym == 0) {
@@ -289,45 +293,88 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
 #undef GD_ADDV
 }
 
-// ---- K4: seam bits (A.5), one lane per frame walks the corners in order ----
+// ---- K4: seam bits (A.5).  One wave per frame: (a) count the edges that carry a bit (opposite face has the larger
+// index) with ballots, (b) lanes 0..nad-1 each decode their attribute's rabs stream into a byte array — the only serial
+// part —, (c) ballot-ranked assignment of the bits to both corners of each edge, 64 corners at a time. ----
 __global__ void __launch_bounds__(64) k_gdec_seams(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.x];
-  if (threadIdx.x != 0 || J.status != 0) return;
-  const int nf = J.nf, nad = J.nad; const int32_t *opp = J.opp;
-  GDBit R[GD_MAXAD];
-  for (int i = 0; i < nad; i++) if (gd_rabs_open(R[i], J, J.rb_seam[i])) { J.status = -7; return; }
-  for (int f = 0; f < nf; f++) for (int k = 0; k < 3; k++) {
-    const int c = 3 * f + k, oc = opp[c];
-    if (oc == GEO_INV) { for (int i = 0; i < nad; i++) J.edge_seam[i][c] = 1; continue; }
-    if (oc / 3 < f) continue;
-    for (int i = 0; i < nad; i++) if (gd_rabs_bit(R[i])) { J.edge_seam[i][c] = 1; J.edge_seam[i][oc] = 1; }
+  if (J.status != 0) return;
+  const uint32_t lane = threadIdx.x;
+  const int nc = 3 * J.nf, nad = J.nad; const int32_t *opp = J.opp;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint32_t n_elig = 0;
+  for (int base = 0; base < nc; base += 64) {
+    const int c = base + (int)lane; const int oc = c < nc ? opp[c] : GEO_INV;
+    n_elig += (uint32_t)__popcll(__ballot(c < nc && oc != GEO_INV && oc / 3 >= c / 3));
+  }
+  if ((int)lane < nad) {
+    GDBit R; uint8_t *bits = J.seam_bits + (size_t)lane * ((size_t)nc + 64);
+    if (gd_rabs_open(R, J, J.rb_seam[lane])) J.status = -7;
+    else for (uint32_t k = 0; k < n_elig; k++) bits[k] = (uint8_t)gd_rabs_bit(R);
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (J.status != 0) return;
+  uint32_t rank0 = 0;
+  for (int base = 0; base < nc; base += 64) {
+    const int c = base + (int)lane; const int oc = c < nc ? opp[c] : GEO_INV;
+    const bool el = c < nc && oc != GEO_INV && oc / 3 >= c / 3;
+    const unsigned long long m = __ballot(el);
+    if (c < nc && oc == GEO_INV) for (int i = 0; i < nad; i++) J.edge_seam[i][c] = 1;
+    if (el) { const uint32_t k = rank0 + (uint32_t)__popcll(m & lt); for (int i = 0; i < nad; i++) if (J.seam_bits[(size_t)i * ((size_t)nc + 64) + k]) { J.edge_seam[i][c] = 1; J.edge_seam[i][oc] = 1; } }
+    rank0 += (uint32_t)__popcll(m);
   }
 }
 
-// ---- K5: attribute corner tables, one lane per (attribute data, frame) ----
-__global__ void __launch_bounds__(64) k_gdec_atttab(GeoDecJob *jobs) {
+// ---- K5: attribute corner tables.  The ids of the attribute vertices around base vertex v are consecutive and start at
+// the number of attribute vertices of all earlier base vertices: (a) per-vertex count = 1 + interior seam crossings of its
+// fan (thread per vertex), (b) exclusive scan over the vertices (one wave per (attribute, frame)), (c) the same fan walk
+// again, writing ids (thread per vertex). ----
+__device__ __forceinline__ int gd_fan_first(const GTab &T, const uint8_t *vseam, int v, int c) {
+  int first = c;
+  if (vseam[v]) { int a = gt_swl(T, first); while (a != GEO_INV) { first = a; a = gt_swl(T, a); if (a == c) break; } }
+  return first;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_vseam(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.y];
-  const int i = blockIdx.x;
-  if (threadIdx.x != 0 || J.status != 0 || i >= J.nad) return;
-  const int nf = J.nf, nv = J.nv; const int32_t *opp = J.opp, *c2v = J.c2v, *lm = J.lm; const uint8_t *es = J.edge_seam[i];
-  uint8_t *vseam = J.vseam + (size_t)i * ((size_t)nv + 64);
-  int32_t *tc = J.t_c2v[i], *tl = J.t_lm[i];
-  for (int c = 0; c < 3 * nf; c++) if (es[c]) { vseam[c2v[g_nxt(c)]] = 1; vseam[c2v[g_prv(c)]] = 1; }
+  const int i = blockIdx.z, c = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
+  if (J.status != 0 || i >= J.nad || c >= 3 * J.nf) return;
+  if (J.edge_seam[i][c]) { uint8_t *vseam = J.vseam + (size_t)i * ((size_t)J.nev + J.nf + 72); vseam[J.c2v[g_nxt(c)]] = 1; vseam[J.c2v[g_prv(c)]] = 1; }
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_atttab(GeoDecJob *jobs, int pass) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const int i = blockIdx.z, v = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
+  if (J.status != 0 || i >= J.nad || v >= J.nv) return;
+  const int32_t *opp = J.opp; const uint8_t *es = J.edge_seam[i];
+  const uint8_t *vseam = J.vseam + (size_t)i * ((size_t)J.nev + J.nf + 72);
+  int32_t *cntp = J.t_cnt + (size_t)i * ((size_t)J.nev + J.nf + 72);
+  const int c = J.lm[v];
+  if (c == GEO_INV) { if (pass == 0) cntp[v] = 0; return; }
   GTab T; T.opp = opp; T.seam = es;
-  int tn = 0;
-  for (int v = 0; v < nv; v++) {
-    const int c = lm[v]; if (c == GEO_INV) continue;
-    int vid = tn, first = c;
-    if (vseam[v]) { int a = gt_swl(T, first); while (a != GEO_INV) { first = a; a = gt_swl(T, a); if (a == c) break; } }
-    tc[first] = vid; tl[tn++] = first;
-    int a = (opp[g_prv(first)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(first)]);
-    while (a != GEO_INV && a != first) {
-      if (es[g_nxt(a)]) { vid = tn; tl[tn++] = a; }
-      tc[a] = vid;
-      a = (opp[g_prv(a)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(a)]);
-    }
+  const int first = gd_fan_first(T, vseam, v, c);
+  int vid = pass ? cntp[v] : 0, tn = vid + 1;
+  if (pass) { J.t_c2v[i][first] = vid; J.t_lm[i][vid] = first; }
+  int a = (opp[g_prv(first)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(first)]);
+  while (a != GEO_INV && a != first) {
+    if (es[g_nxt(a)]) { vid = tn; if (pass) J.t_lm[i][tn] = a; tn++; }
+    if (pass) J.t_c2v[i][a] = vid;
+    a = (opp[g_prv(a)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(a)]);
   }
-  J.t_nv[i] = tn;
+  if (pass == 0) cntp[v] = tn;            // number of attribute vertices of v
+}
+__global__ void __launch_bounds__(64) k_gdec_attscan(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const int i = blockIdx.x; const uint32_t lane = threadIdx.x;
+  if (J.status != 0 || i >= J.nad) return;
+  int32_t *cntp = J.t_cnt + (size_t)i * ((size_t)J.nev + J.nf + 72);
+  int run = 0;
+  for (int base = 0; base < J.nv; base += 64) {
+    const int v = base + (int)lane; int x = v < J.nv ? cntp[v] : 0; const int mine = x;
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+    if (v < J.nv) cntp[v] = run + x - mine;
+    run += __shfl(x, 63);
+  }
+  if (lane == 0) J.t_nv[i] = run;
 }
 
 // ---- K6: on-boundary flags per table + the scalars the shared traversal kernels read from their GeoJob ----
@@ -369,65 +416,147 @@ __device__ inline void gd_oct_orig(const GOct &t, const int pred[2], const int c
   if (!ind) g_invert_diamond(t, os, ot);
   out[0] = os + t.CEN; out[1] = ot + t.CEN;
 }
+// parallelogram neighbours of every entry (thread per entry): nb[3p..3p+2] = entries (a, next, prev) of the opposite
+// corner when all three are decoded before p, else -1.  Depends only on the connectivity, so the serial recurrence below
+// needs no pointer chasing.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_pgram(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
+  const int d = blockIdx.z;
+  if (J.status != 0 || G.status != 0 || d >= J.ndec) return;
+  const GDAtt &A = J.att[d];
+  if (!(A.pred_method == 1 || A.pred_method == 0)) return;
+  const int t = A.table, p = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
+  if (p >= (int)G.ne[t]) return;
+  int32_t *nb = J.nbr + (size_t)d * ((size_t)9 * J.nf + 64) + 3 * (size_t)p;
+  nb[0] = nb[1] = nb[2] = -1;
+  if (p == 0 || A.pred_method != 1) return;
+  const int32_t *v2d = G.v2d[t], *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1];
+  GTab X; X.opp = J.opp; X.seam = t == 0 ? nullptr : J.edge_seam[t - 1];
+  const int oci = gt_opp(X, G.order[t][p]);
+  if (oci == GEO_INV) return;
+  const int a = v2d[xc2v[oci]], bn = v2d[xc2v[g_nxt(oci)]], bp = v2d[xc2v[g_prv(oci)]];
+  if (a < p && bn < p && bp < p) { nb[0] = a; nb[1] = bn; nb[2] = bp; }
+}
+
+// tex-coord-portable prediction (A.8): everything that depends only on the decoded POSITIONS is computed per entry in
+// parallel — neighbour entries, |pn|^2, the projection dot product and the integer square root —; the serial recurrence
+// keeps the two uv reads, four multiplies and two truncating divisions.  uvg[p] = { nd, pd, pn2, dd, ns }.
+struct GDUvGeo { int32_t nd, pd; long long pn2, dd, ns; };
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_uvgeo(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
+  const int d = blockIdx.z;
+  if (J.status != 0 || G.status != 0 || d >= J.ndec) return;
+  const GDAtt &A = J.att[d];
+  if (A.pred_method != 5) return;
+  const int t = A.table, p = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
+  if (p >= (int)G.ne[t]) return;
+  int pdec = -1; for (int k = 0; k < J.ndec; k++) if (J.att[k].att_type == 0 && J.att[k].att_data_id == -1) pdec = k;
+  if (pdec < 0) return;
+  const int32_t *P = J.att[pdec].vals, *b_v2d = G.v2d[0], *c2v = J.c2v, *v2d = G.v2d[t], *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1];
+  const int c = G.order[t][p], cn = g_nxt(c), cp = g_prv(c);
+  GDUvGeo g; g.nd = v2d[xc2v[cn]]; g.pd = v2d[xc2v[cp]]; g.pn2 = 0; g.dd = 0; g.ns = 0;
+  if (g.pd < p && g.nd < p) {
+    const int32_t *tip = P + 3 * b_v2d[c2v[c]], *np_ = P + 3 * b_v2d[c2v[cn]], *pp_ = P + 3 * b_v2d[c2v[cp]];
+    long long pn[3], pn2 = 0, dd = 0;
+    for (int k = 0; k < 3; k++) { pn[k] = (long long)pp_[k] - np_[k]; pn2 += pn[k] * pn[k]; }
+    if (pn2 != 0) {
+      for (int k = 0; k < 3; k++) dd += pn[k] * ((long long)tip[k] - np_[k]);
+      long long cx2 = 0;
+      for (int k = 0; k < 3; k++) { const long long xp = np_[k] + (dd * pn[k]) / pn2, e = tip[k] - xp; cx2 += e * e; }
+      g.ns = (long long)g_isqrt((uint64_t)cx2 * (uint64_t)pn2);
+    }
+    g.pn2 = pn2; g.dd = dd;
+  }
+  reinterpret_cast<GDUvGeo *>(J.uvgeo)[p] = g;
+}
+
+// geometric-normal prediction (A.9): independent per entry once the flip bits are known -> thread per entry
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_normals(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
+  const int d = blockIdx.z;
+  if (J.status != 0 || G.status != 0 || d >= J.ndec) return;
+  GDAtt &A = J.att[d];
+  if (A.pred_method != 6) return;
+  const int t = A.table, dd = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
+  if (dd >= (int)G.ne[t]) return;
+  int pdec = -1; for (int k = 0; k < J.ndec; k++) if (J.att[k].att_type == 0 && J.att[k].att_data_id == -1) pdec = k;
+  if (pdec < 0) return;
+  const int32_t *P = J.att[pdec].vals, *b_v2d = G.v2d[0], *c2v = J.c2v;
+  GTab X; X.opp = J.opp; X.seam = t == 0 ? nullptr : J.edge_seam[t - 1];
+  int q = 0; while ((1 << q) - 1 < A.maxq) q++;
+  const GOct ot = g_oct(q);
+  const uint32_t *syms = J.rs[6 + d].out; const uint8_t *flips = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
+  const int c0 = G.order[t][dd];
+  const int32_t *cenp = P + 3 * b_v2d[c2v[c0]];
+  long long N[3] = { 0, 0, 0 };
+  int c = c0; bool left = true;
+  while (c != GEO_INV) {
+    const int32_t *a = P + 3 * b_v2d[c2v[g_nxt(c)]], *bb = P + 3 * b_v2d[c2v[g_prv(c)]];
+    long long dn[3], dp[3];
+    for (int k = 0; k < 3; k++) { dn[k] = (long long)a[k] - cenp[k]; dp[k] = (long long)bb[k] - cenp[k]; }
+    N[0] += dn[1] * dp[2] - dn[2] * dp[1]; N[1] += dn[2] * dp[0] - dn[0] * dp[2]; N[2] += dn[0] * dp[1] - dn[1] * dp[0];
+    if (left) { c = gt_swl(X, c); if (c == c0) break; if (c == GEO_INV) { left = false; c = gt_swr(X, c0); } }
+    else c = gt_swr(X, c);
+  }
+  long long s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
+  if (s > (1 << 29)) { const long long qd = s / (1 << 29); for (int k = 0; k < 3; k++) N[k] /= qd; }
+  int pv[3];
+  s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
+  if (s == 0) { pv[0] = ot.CEN; pv[1] = 0; pv[2] = 0; }
+  else { const long long aa = (N[0] * ot.CEN) / s, bb2 = (N[1] * ot.CEN) / s; long long cc = ot.CEN - g_labs(aa) - g_labs(bb2); if (N[2] < 0) cc = -cc; pv[0] = (int)aa; pv[1] = (int)bb2; pv[2] = (int)cc; }
+  if (flips[dd]) { pv[0] = -pv[0]; pv[1] = -pv[1]; pv[2] = -pv[2]; }
+  int po[2]; g_vec_to_oct(ot, pv, po[0], po[1]);
+  const int corr[2] = { (int)syms[2 * dd], (int)syms[2 * dd + 1] };
+  gd_oct_orig(ot, po, corr, A.vals + 2 * dd);
+}
+
 __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, int phase) {
   GeoDecJob &J = jobs[blockIdx.y];
   const GeoJob &G = gj[blockIdx.y];
   const int d = blockIdx.x;
   if (threadIdx.x != 0 || J.status != 0 || G.status != 0 || d >= J.ndec) return;
   GDAtt &A = J.att[d];
-  const bool needs_pos = A.pred_method == 5 || A.pred_method == 6;
+  if (A.pred_method == 6) return;                       // normals: k_gdec_flips + k_gdec_normals
+  const bool needs_pos = A.pred_method == 5;
   if ((phase == 0) == needs_pos) return;
   const int t = A.table, nc = A.nc, ne = (int)G.ne[t];
-  const int32_t *order = G.order[t], *v2d = G.v2d[t];
-  const int32_t *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1];
-  GTab X; X.opp = J.opp; X.seam = t == 0 ? nullptr : J.edge_seam[t - 1];
-  const uint32_t *syms = J.rs[6 + d].out; int32_t *out = A.vals;
+  // typed (global) pointers: the recurrence stores out[p] and reads earlier entries — with generic pointers every read
+  // would wait for the previous store's acknowledgement (see uvol_common.hpp)
+  UVOL_G(const uint32_t) syms = UVOL_TO_G(const uint32_t, J.rs[6 + d].out); UVOL_G(int32_t) out = UVOL_TO_G(int32_t, A.vals);
   int pdec = -1; for (int k = 0; k < J.ndec; k++) if (J.att[k].att_type == 0 && J.att[k].att_data_id == -1) pdec = k;
-  const int32_t *P = pdec >= 0 ? J.att[pdec].vals : nullptr; const int32_t *b_v2d = G.v2d[0], *c2v = J.c2v;
   if (A.pred_method == 1 || A.pred_method == 0) {
     const int32_t lo = A.lo, hi = A.hi;
+    UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)9 * J.nf + 64));
     for (int p = 0; p < ne; p++) {
-      int32_t pred[4] = { 0, 0, 0, 0 }; bool have = false;
-      if (p > 0 && A.pred_method == 1) {
-        const int ci = order[p], oci = gt_opp(X, ci);
-        if (oci != GEO_INV) {
-          const int a = v2d[xc2v[oci]], bn = v2d[xc2v[g_nxt(oci)]], bp = v2d[xc2v[g_prv(oci)]];
-          if (a < p && bn < p && bp < p) { for (int k = 0; k < nc; k++) pred[k] = out[bn * nc + k] + out[bp * nc + k] - out[a * nc + k]; have = true; }
-        }
-      }
-      if (!have && p > 0) for (int k = 0; k < nc; k++) pred[k] = out[(p - 1) * nc + k];
+      int32_t pred[4] = { 0, 0, 0, 0 };
+      const int a = nbr[3 * p], bn = nbr[3 * p + 1], bp = nbr[3 * p + 2];
+      if (a >= 0) { for (int k = 0; k < nc; k++) pred[k] = out[bn * nc + k] + out[bp * nc + k] - out[a * nc + k]; }
+      else if (p > 0) for (int k = 0; k < nc; k++) pred[k] = out[(p - 1) * nc + k];
       for (int k = 0; k < nc; k++) out[p * nc + k] = gd_wrap(pred[k], gd_sgn(syms[p * nc + k]), lo, hi);
     }
   } else if (A.pred_method == 5) {
-    if (!P) { J.status = -26; return; }
+    if (pdec < 0) { J.status = -26; return; }
     const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
     { GDBit Rb; if (gd_rabs_open(Rb, J, A.aux)) { J.status = -26; return; } int last = 1; for (int k = 0; k < no; k++) { if (!gd_rabs_bit(Rb)) last = !last; ori[k] = (uint8_t)last; } }
     const int32_t lo = A.lo, hi = A.hi; int nori = no;
+    UVOL_G(const long long) uvg = UVOL_TO_G(const long long, reinterpret_cast<const long long *>(J.uvgeo));      // GDUvGeo = 4 x 8 bytes
     for (int p = 0; p < ne; p++) {
-      const int c = order[p], cn = g_nxt(c), cp = g_prv(c);
-      const int nd = v2d[xc2v[cn]], pd = v2d[xc2v[cp]];
+      GDUvGeo g; { const long long w0 = uvg[4 * (size_t)p]; g.nd = (int32_t)(w0 & 0xffffffffll); g.pd = (int32_t)(w0 >> 32); g.pn2 = uvg[4 * (size_t)p + 1]; g.dd = uvg[4 * (size_t)p + 2]; g.ns = uvg[4 * (size_t)p + 3]; }
+      const int nd = g.nd, pd = g.pd;
       long long pred[2]; bool have = false;
       if (pd < p && nd < p) {
         const long long nuv[2] = { out[nd * 2], out[nd * 2 + 1] }, puv[2] = { out[pd * 2], out[pd * 2 + 1] };
         if (puv[0] == nuv[0] && puv[1] == nuv[1]) { pred[0] = puv[0]; pred[1] = puv[1]; have = true; }
-        else {
-          const int32_t *tip = P + 3 * b_v2d[c2v[c]], *np_ = P + 3 * b_v2d[c2v[cn]], *pp_ = P + 3 * b_v2d[c2v[cp]];
-          long long pn[3], cnv[3], pn2 = 0, dd = 0;
-          for (int k = 0; k < 3; k++) { pn[k] = (long long)pp_[k] - np_[k]; pn2 += pn[k] * pn[k]; }
-          if (pn2 != 0) {
-            for (int k = 0; k < 3; k++) { cnv[k] = (long long)tip[k] - np_[k]; dd += pn[k] * cnv[k]; }
-            const long long pnuv[2] = { puv[0] - nuv[0], puv[1] - nuv[1] };
-            const long long xuv[2] = { nuv[0] * pn2 + dd * pnuv[0], nuv[1] * pn2 + dd * pnuv[1] };
-            long long cx2 = 0;
-            for (int k = 0; k < 3; k++) { const long long xp = np_[k] + (dd * pn[k]) / pn2, e = tip[k] - xp; cx2 += e * e; }
-            const long long ns_ = (long long)g_isqrt((uint64_t)cx2 * (uint64_t)pn2);
-            const long long cxuv[2] = { pnuv[1] * ns_, -pnuv[0] * ns_ };
-            if (nori <= 0) { J.status = -27; return; }
-            const int o_ = ori[--nori];
-            if (o_) { pred[0] = (xuv[0] + cxuv[0]) / pn2; pred[1] = (xuv[1] + cxuv[1]) / pn2; }
-            else { pred[0] = (xuv[0] - cxuv[0]) / pn2; pred[1] = (xuv[1] - cxuv[1]) / pn2; }
-            have = true;
-          }
+        else if (g.pn2 != 0) {
+          const long long pn2 = g.pn2, dd = g.dd, ns_ = g.ns;
+          const long long pnuv[2] = { puv[0] - nuv[0], puv[1] - nuv[1] };
+          const long long xuv[2] = { nuv[0] * pn2 + dd * pnuv[0], nuv[1] * pn2 + dd * pnuv[1] };
+          const long long cxuv[2] = { pnuv[1] * ns_, -pnuv[0] * ns_ };
+          if (nori <= 0) { J.status = -27; return; }
+          const int o_ = ori[--nori];
+          if (o_) { pred[0] = (xuv[0] + cxuv[0]) / pn2; pred[1] = (xuv[1] + cxuv[1]) / pn2; }
+          else { pred[0] = (xuv[0] - cxuv[0]) / pn2; pred[1] = (xuv[1] - cxuv[1]) / pn2; }
+          have = true;
         }
       }
       if (!have) {
@@ -438,37 +567,23 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
       for (int k = 0; k < 2; k++) out[p * 2 + k] = gd_wrap((int32_t)pred[k], gd_sgn(syms[p * 2 + k]), lo, hi);
     }
     if (nori != 0) { J.status = -28; return; }
-  } else {
-    if (!P) { J.status = -29; return; }
-    GDBit Fb; if (gd_rabs_open(Fb, J, A.aux)) { J.status = -29; return; }
-    int q = 0; while ((1 << q) - 1 < A.maxq) q++;
-    const GOct ot = g_oct(q);
-    if (ot.MAXQ != A.maxq || ot.CEN != A.cen) { J.status = -30; return; }
-    for (int dd = 0; dd < ne; dd++) {
-      const int c0 = order[dd];
-      const int32_t *cenp = P + 3 * b_v2d[c2v[c0]];
-      long long N[3] = { 0, 0, 0 };
-      int c = c0; bool left = true;
-      while (c != GEO_INV) {
-        const int32_t *a = P + 3 * b_v2d[c2v[g_nxt(c)]], *bb = P + 3 * b_v2d[c2v[g_prv(c)]];
-        long long dn[3], dp[3];
-        for (int k = 0; k < 3; k++) { dn[k] = (long long)a[k] - cenp[k]; dp[k] = (long long)bb[k] - cenp[k]; }
-        N[0] += dn[1] * dp[2] - dn[2] * dp[1]; N[1] += dn[2] * dp[0] - dn[0] * dp[2]; N[2] += dn[0] * dp[1] - dn[1] * dp[0];
-        if (left) { c = gt_swl(X, c); if (c == c0) break; if (c == GEO_INV) { left = false; c = gt_swr(X, c0); } }
-        else c = gt_swr(X, c);
-      }
-      long long s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
-      if (s > (1 << 29)) { const long long qd = s / (1 << 29); for (int k = 0; k < 3; k++) N[k] /= qd; }
-      int pv[3];
-      s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
-      if (s == 0) { pv[0] = ot.CEN; pv[1] = 0; pv[2] = 0; }
-      else { const long long aa = (N[0] * ot.CEN) / s, bb2 = (N[1] * ot.CEN) / s; long long cc = ot.CEN - g_labs(aa) - g_labs(bb2); if (N[2] < 0) cc = -cc; pv[0] = (int)aa; pv[1] = (int)bb2; pv[2] = (int)cc; }
-      if (gd_rabs_bit(Fb)) { pv[0] = -pv[0]; pv[1] = -pv[1]; pv[2] = -pv[2]; }
-      int po[2]; g_vec_to_oct(ot, pv, po[0], po[1]);
-      const int corr[2] = { (int)syms[2 * dd], (int)syms[2 * dd + 1] };
-      gd_oct_orig(ot, po, corr, out + 2 * dd);
-    }
   }
+}
+
+// flip bits of the normal decoders: the only sequential part of the geometric-normal scheme (one lane per decoder)
+__global__ void __launch_bounds__(64) k_gdec_flips(GeoDecJob *jobs, GeoJob *gj) {
+  GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
+  const int d = blockIdx.x;
+  if (threadIdx.x != 0 || J.status != 0 || G.status != 0 || d >= J.ndec) return;
+  GDAtt &A = J.att[d];
+  if (A.pred_method != 6) return;
+  int q = 0; while ((1 << q) - 1 < A.maxq) q++;
+  const GOct ot = g_oct(q);
+  if (ot.MAXQ != A.maxq || ot.CEN != A.cen) { J.status = -30; return; }
+  GDBit Fb; if (gd_rabs_open(Fb, J, A.aux)) { J.status = -29; return; }
+  uint8_t *flips = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
+  const int ne = (int)G.ne[A.table];
+  for (int k = 0; k < ne; k++) flips[k] = (uint8_t)gd_rabs_bit(Fb);
 }
 
 // attribute symbol counts = entries of the decoder's table x components (known after the traversal)
@@ -556,9 +671,9 @@ static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base) {
   J.lm = (int32_t *)take(4 * maxv); J.val = (int32_t *)take(4 * maxv);
   J.stack = (int32_t *)take(4 * (nf + 8)); J.tsac = (int32_t *)take(4 * (nf + 2));
   for (int k = 0; k < GD_MAXAD; k++) { J.edge_seam[k] = take(nc); J.t_c2v[k] = (int32_t *)take(4 * nc); J.t_lm[k] = (int32_t *)take(4 * nc); }
-  J.vseam = take(GD_MAXAD * (maxv + 64));
+  J.vseam = take(GD_MAXAD * (maxv + 64)); J.t_cnt = (int32_t *)take(4 * GD_MAXAD * (maxv + 64)); J.seam_bits = take(GD_MAXAD * (nc + 64));
   for (int k = 0; k < 1 + GD_MAXAD; k++) J.vopen[k] = take(nc + 64);
-  J.aux_bits = take(GD_MAXDEC * (nc + 64));
+  J.aux_bits = take(GD_MAXDEC * (nc + 64)); J.nbr = (int32_t *)take(4 * GD_MAXDEC * (3 * nc + 64)); J.uvgeo = take(32 * (nc + 8));
   for (int k = 0; k < 6; k++) { GDRans &S = J.rs[k]; S.max_ns = GD_CTX_NS; S.max_prec_bits = 12; S.probs = (uint32_t *)take(4 * GD_CTX_NS); S.cum = (uint32_t *)take(4 * GD_CTX_NS); S.lut = (uint32_t *)take(4 * (1u << 12)); S.out = (uint32_t *)take(4 * (nf + 1)); }
   for (int k = 0; k < GD_MAXDEC; k++) {
     GDRans &S = J.rs[6 + k]; S.max_ns = GD_MAX_NS; S.max_prec_bits = 20;
@@ -578,14 +693,14 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   if (n <= 0) return UVOL_OK;
   T->hjobs.assign((size_t)n, GeoDecJob{}); T->hg.assign((size_t)n, GeoJob{});
   std::vector<size_t> foff((size_t)n), woff((size_t)n), ooff((size_t)n);
-  size_t ftot = 0, wtot = 0, otot = 0; uint32_t max_nf = 0;
+  size_t ftot = 0, wtot = 0, otot = 0; uint32_t max_nf = 0, max_nev = 0;
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   for (int i = 0; i < n; i++) {
     uint32_t nev = 0, nf = 0;
     if (!gdec_header(files[i], lens[i], &nev, &nf)) { ctx->set_error("frame %d: not a Draco 2.2 edgebreaker mesh", i); return UVOL_E_INVALID; }
     if (out[i].cap_faces < nf || out[i].cap_values < 3 * (size_t)nf) { ctx->set_error("frame %d: output capacity too small (%u faces)", i, nf); return UVOL_E_NOSPACE; }
     GeoDecJob &J = T->hjobs[i]; J.nf = (int32_t)nf; J.nev = (int32_t)nev; J.file_len = (uint32_t)lens[i];
-    max_nf = std::max(max_nf, nf);
+    max_nf = std::max(max_nf, nf); max_nev = std::max(max_nev, nev);
     foff[i] = ftot; ftot += a256(lens[i] + 16);
     GeoJob gtmp{}; const size_t w = gdec_carve(J, gtmp, nullptr);
     woff[i] = wtot; wtot += a256(w);
@@ -617,14 +732,21 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn, dim3(N), dim3(64), 0, dj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k4_seams_tables", 0);
     GLAUNCH(k_gdec_seams, dim3(N), dim3(64), 0, dj);
-    GLAUNCH(k_gdec_atttab, dim3(GD_MAXAD, N), dim3(64), 0, dj);
+    GLAUNCH(k_gdec_vseam, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj);
+    GLAUNCH(k_gdec_atttab, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj, 0);
+    GLAUNCH(k_gdec_attscan, dim3(GD_MAXAD, N), dim3(64), 0, dj);
+    GLAUNCH(k_gdec_atttab, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj, 1);
     GLAUNCH(k_gdec_open, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
-    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, 3 * max_nf / 2 + 64))) return rc;
+    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) return rc;
     GLAUNCH(k_gdec_counts, dim3(N), dim3(64), 0, dj, gj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(GD_MAXDEC, N), dim3(64), 0, dj, 6, GD_MAXDEC); }
   { uvol_ctx::Scope sc(ctx, "geodec.k7_predict", 0);
+    GLAUNCH(k_gdec_pgram, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
+    GLAUNCH(k_gdec_flips, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj);
     GLAUNCH(k_gdec_pred, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj, 0);
+    GLAUNCH(k_gdec_normals, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
+    GLAUNCH(k_gdec_uvgeo, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
     GLAUNCH(k_gdec_pred, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj, 1); }
   { uvol_ctx::Scope sc(ctx, "geodec.k8_finish", 0); GLAUNCH(k_gdec_finish, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());

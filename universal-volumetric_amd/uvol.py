@@ -250,7 +250,7 @@ class Codec:
             raise UvolError(f"decode_texture_segments_dev rc={rc}: {self.error()}")
 
     # ---- decode path (geometry half) ----
-    def decode_mesh_batch(self, files, raise_on_error=True):
+    def decode_mesh_batch(self, files, raise_on_error=True, fetch=True):
         """files: list of .drc bytes -> list of dicts {pos [n,3], uv [n,2], nrm [n,3] float32 in decoding order,
         idx_pos / idx_uv / idx_nrm [3*faces] uint32 entry index per corner}; absent attributes are None."""
         files = [bytes(f) for f in files]; n = len(files)
@@ -264,7 +264,7 @@ class Codec:
             keep.append(a)
             m = metas[i]; m.cap_faces = nf.value; m.cap_values = mv.value
             for k, v in a.items():
-                setattr(m, k, v.ctypes.data)
+                setattr(m, k, v.ctypes.data if fetch else None)        # fetch=False: decode only, results stay on the device (timing)
         fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files]); st = (C.c_int * n)()
         rc = self.L.uvol_decode_mesh_batch(self.h, fp, ln, n, metas, st)
         if rc != UVOL_OK:
@@ -277,6 +277,8 @@ class Codec:
                 res.append(None); continue
             m, a = metas[i], keep[i]
             cnt = dict(pos=m.n_pos, uv=m.n_uv, nrm=m.n_nrm)
+            if not fetch:
+                res.append(dict(n_faces=m.n_faces, n_pos=m.n_pos, n_uv=m.n_uv, n_nrm=m.n_nrm)); continue
             res.append({k: (a[k][:cnt[k]].copy() if cnt[k] else None) for k in ("pos", "uv", "nrm")} |
                        {"idx_" + k: (a["idx_" + k].copy() if cnt[k] else None) for k in ("pos", "uv", "nrm")} | {"n_faces": m.n_faces})
         return res
