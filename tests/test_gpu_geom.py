@@ -139,3 +139,17 @@ def test_gpu_mesh_roundtrip_at_bench_size(oracle, gpu_codec):
     assert np.allclose(np.linalg.norm(d["nrm"], axis=1), 1.0, atol=1e-3)
     uv_step = float((m["uv"].max(0) - m["uv"].min(0)).max()) / (2 ** 10 - 1)
     assert (d["uv"] >= m["uv"].min(0) - uv_step).all() and (d["uv"] <= m["uv"].max(0) + uv_step).all()
+
+
+def test_gpu_baseline_config1_single_50k_vertex_frame(oracle, gpu_codec):
+    """BASELINE.json configs[1]: one 50k-vertex frame through quantise + edgebreaker + rANS on the GPU; the decoded
+    triangle index arrays equal the input after canonicalisation (helpers.check_roundtrip) and the bytes equal the oracle's;
+    then the same frame back through the GPU decoder."""
+    import synth
+    from test_hipemu_geom import _check_decoded
+    m = synth.sphere_mesh(283, 177, charts=(28, 18), frame=2)
+    assert 49000 < len(m["pos"]) < 51000
+    data = gpu_codec.encode_mesh(**m)
+    assert data == _oracle_bytes(oracle, m)
+    check_roundtrip(oracle, m, data)
+    _check_decoded(oracle, data, gpu_codec.decode_mesh_batch([data])[0])
