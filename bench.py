@@ -33,13 +33,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=480)
+    ap.add_argument("--frames-per-step", type=int, default=720)
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
-    ap.add_argument("--geo-streams", type=int, default=2, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
+    ap.add_argument("--geo-streams", type=int, default=3, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
@@ -92,9 +92,11 @@ def main():
 
     cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
     gcfg, tcfg = dict(cfg), dict(cfg)
+    GS = max(1, args.geo_streams)
+    if GS >= 3 and F >= 700:                # > 700 frames in flight: attribute traversers with their vertex bitmap in L2 (see uvol_codec.h)
+        gcfg.update(traverse_vbits_l2=1)
     if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)
         gcfg.update(cu_mod=4, cu_residues=int(args.cu_split) // 16); tcfg.update(cu_mod=4, cu_residues=int(args.cu_split) % 16)
-    GS = max(1, args.geo_streams)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]
     texs = [uvol.Codec(device=local_rank, **tcfg) for _ in range(max(1, args.tex_streams))]
     out = {}

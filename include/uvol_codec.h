@@ -50,7 +50,9 @@ typedef struct uvol_params {
   int32_t max_batch;                /* frames in flight per geometry batch, default 32 */
   int32_t cu_mod;                   /* optional CU partition: stream runs only on CUs with (index % cu_mod) in cu_residues; 0 = all CUs */
   int32_t cu_residues;              /* bit r set = residue r allowed */
-  int32_t reserved[5];
+  int32_t traverse_vbits_l2;        /* 1: the attribute traversers keep only their face bitmap in LDS and the vertex bitmap in L2
+                                       (6 instead of 3 per CU): pays off when several contexts keep > 700 frames in flight */
+  int32_t reserved[4];
 } uvol_params;
 
 void uvol_params_default(uvol_params *p);

@@ -1396,7 +1396,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
 }
 
 // LDS sizing of the serial walkers for a batch: the largest face count and attribute-value count (see geo_encode_batch)
-static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t *lds_bytes, int *vcap_words) {
+static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t *lds_bytes, int *vcap_words, bool vertex_bits_global = false) {
   const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
   // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
   // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
@@ -1407,7 +1407,7 @@ static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals
   const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
   // UVOL_WALK_FORCE (tests): "vglobal" = vertex bitmaps in global memory, "global" = both bitmaps in global memory
   static const int walk_force = [] { const char *e = getenv("UVOL_WALK_FORCE"); return !e ? 0 : (!strcmp(e, "vglobal") ? 1 : (!strcmp(e, "global") ? 2 : 0)); }();
-  const size_t walk_vcw = walk_force == 1 ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
+  const size_t walk_vcw = (walk_force == 1 || vertex_bits_global) ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
   const size_t walk_lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4;
   *lds_bytes = walk_lds; *vcap_words = walk_vcw;
   return walk_lds <= G->max_lds && walk_force != 2;
@@ -1550,7 +1550,13 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj, walk_vcw, uvol_debug() ? 1 : 0);
+    // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): the traversers keep only the face bitmap in LDS (25 KB -> 6 per
+    // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
+    static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
+    const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
+    size_t t_lds = walk_lds; int t_vcw = walk_vcw;
+    if (tvg) (void)walk_lds_plan(G, max_nfi, max_vals, &t_lds, &t_vcw, true);
+    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0);
     else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj, 0, 0);
     LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
   }
