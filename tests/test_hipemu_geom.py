@@ -105,3 +105,35 @@ def test_hipemu_mesh_decode_matches_oracle(oracle, hipemu_lib):
     with pytest.raises(uvol.UvolError):
         cd.decode_mesh_batch([files[0][:40]])
     cd.close()
+
+
+def test_hipemu_decoders_survive_corrupt_input(oracle, hipemu_lib):
+    """Decoders take files from outside: bit flips, truncation and overwritten words must end in a decoded result or a
+    clean error (every index is validated before the parallel stages use it, fan walks are bounded), never in a crash."""
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    m = synth.torus_mesh()
+    drc = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"])
+    ktx = oracle.ktx2_encode(synth.texture_sequence(2, size=32, seed=1))
+    rng = np.random.default_rng(11)
+    outcomes = {"drc": [0, 0], "ktx2": [0, 0]}
+    for kind, base, first in (("drc", drc, 11), ("ktx2", ktx, 80)):
+        for it in range(14):
+            b = bytearray(base)
+            mode = it % 3
+            if mode == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(first, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                b = b[:int(rng.integers(first + 1, len(b)))]
+            else:
+                i = int(rng.integers(first + 1, len(b) - 4)); b[i:i + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            try:
+                (cd.decode_mesh_batch if kind == "drc" else cd.decode_texture_segments)([bytes(b)])
+                outcomes[kind][0] += 1
+            except uvol.UvolError:
+                outcomes[kind][1] += 1
+    assert outcomes["drc"][1] > 0 and outcomes["ktx2"][1] > 0          # truncations at least are always rejected
+    # and the codec still works afterwards
+    assert cd.encode_mesh(**m) == drc
+    cd.close()

@@ -147,11 +147,16 @@ __device__ __forceinline__ int gd_ans_init(const uint8_t *buf, uint32_t n, uint3
 __global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, int count) {
   GeoDecJob &J = jobs[blockIdx.y];
   const int si = first + (int)blockIdx.x;
-  if (J.status != 0 || (int)blockIdx.x >= count) return;
+  if ((int)blockIdx.x >= count) return;
   GDRans &S = J.rs[si];
-  if (!S.present || S.nvals == 0) return;               // uniform for the wave
-  const uint32_t lane = threadIdx.x, ns = S.ns, prec = 1u << S.prec_bits, L = prec * 4;
-  __shared__ int s_err;
+  const uint32_t lane = threadIdx.x;
+  // the job status can be changed by the sibling workgroups of this frame (other streams) while this one runs: sample it
+  // ONCE per workgroup so that all lanes take the same path to the barriers below
+  __shared__ int s_err, s_go;
+  if (lane == 0) s_go = (J.status == 0 && S.present && S.nvals != 0) ? 1 : 0;
+  __syncthreads();
+  if (!s_go) return;
+  const uint32_t ns = S.ns, prec = 1u << S.prec_bits, L = prec * 4;
   if (lane == 0) {
     s_err = 0;
     GRd r; r.b = J.file; r.n = J.file_len; r.o = S.tab_off; r.err = 0;
@@ -211,6 +216,8 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   const int SYM2TOPO[5] = { 0, 1, 3, 5, 7 };
 #define GD_SETOPP(a, bb) do { opp[a] = (bb); opp[bb] = (a); } while (0)
 #define GD_ADDV() (nv < maxv ? (lm[nv] = GEO_INV, nv++) : (rc = -9, 0))
+#define GD_BADV(v) ((unsigned)(v) >= (unsigned)nv)          /* vertex id not (yet) allocated: corrupt stream */
+#define GD_BADC(c) ((unsigned)(c) >= (unsigned)(3 * nf))
   for (int sid = 0; sid < nsym && !rc; sid++) {
     const int face = nfaces++; int check = 0, sym;
     if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = ctxs[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
@@ -218,33 +225,34 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
     const int corner = 3 * face;
     if (sym == 0) {
       if (sp == 0) { rc = -11; break; }
-      const int ca = stack[sp - 1], vx = c2v[g_nxt(ca)]; if (vx < 0 || lm[vx] < 0) { rc = -11; break; }
+      const int ca = stack[sp - 1]; if (GD_BADC(ca)) { rc = -11; break; } const int vx = c2v[g_nxt(ca)]; if (GD_BADV(vx) || GD_BADC(lm[vx])) { rc = -11; break; }
       const int cb = g_nxt(lm[vx]);
       if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -11; break; }
       GD_SETOPP(ca, corner + 1); GD_SETOPP(cb, corner + 2);
-      const int vap = c2v[g_prv(ca)], vbn = c2v[g_nxt(cb)];
+      const int vap = c2v[g_prv(ca)], vbn = c2v[g_nxt(cb)]; if (GD_BADV(vap) || GD_BADV(vbn)) { rc = -11; break; }
       c2v[corner] = vx; c2v[corner + 1] = vbn; c2v[corner + 2] = vap; lm[vap] = corner + 2;
       stack[sp - 1] = corner;
     } else if (sym == 5 || sym == 3) {
       if (sp == 0) { rc = -12; break; }
-      const int ca = stack[sp - 1]; if (opp[ca] != GEO_INV) { rc = -12; break; }
+      const int ca = stack[sp - 1]; if (GD_BADC(ca) || opp[ca] != GEO_INV) { rc = -12; break; }
       int oc, cl, cr;
       if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; } else { oc = corner + 1; cl = corner; cr = corner + 2; }
       GD_SETOPP(oc, ca); const int nvx = GD_ADDV(); if (rc) break; c2v[oc] = nvx; lm[nvx] = oc;
-      const int vr = c2v[g_prv(ca)]; c2v[cr] = vr; lm[vr] = cr;
-      c2v[cl] = c2v[g_nxt(ca)];
+      const int vr = c2v[g_prv(ca)], vl = c2v[g_nxt(ca)]; if (GD_BADV(vr) || GD_BADV(vl)) { rc = -12; break; } c2v[cr] = vr; lm[vr] = cr;
+      c2v[cl] = vl;
       stack[sp - 1] = corner; check = 1;
     } else if (sym == 1) {
       if (sp == 0) { rc = -13; break; }
       const int cb = stack[--sp];
-      if (tsac[sid] != GEO_INV) stack[sp++] = tsac[sid];
+      if (tsac[sid] != GEO_INV) { if (sp >= nf + 4) { rc = -13; break; } stack[sp++] = tsac[sid]; }
       if (sp == 0) { rc = -13; break; }
       const int ca = stack[sp - 1];
-      if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -13; break; }
+      if (GD_BADC(ca) || GD_BADC(cb) || ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -13; break; }
       GD_SETOPP(ca, corner + 2); GD_SETOPP(cb, corner + 1);
-      const int vp = c2v[g_prv(ca)]; c2v[corner] = vp; c2v[corner + 1] = c2v[g_nxt(ca)];
-      const int vbp = c2v[g_prv(cb)]; c2v[corner + 2] = vbp; lm[vbp] = corner + 2;
-      int cn = g_nxt(cb); const int vn = c2v[cn];
+      const int vp = c2v[g_prv(ca)], vq = c2v[g_nxt(ca)], vbp = c2v[g_prv(cb)]; int cn = g_nxt(cb); const int vn = c2v[cn];
+      if (GD_BADV(vp) || GD_BADV(vq) || GD_BADV(vbp) || GD_BADV(vn)) { rc = -13; break; }
+      c2v[corner] = vp; c2v[corner + 1] = vq;
+      c2v[corner + 2] = vbp; lm[vbp] = corner + 2;
       val[vp] += val[vn]; lm[vp] = lm[vn];
       const int first = cn; int guard = 0;
       while (cn != GEO_INV) { c2v[cn] = vp; const int o2 = opp[g_nxt(cn)]; cn = o2 < 0 ? GEO_INV : g_nxt(o2); if (cn == first || ++guard > 3 * nf) { rc = -13; break; } }
@@ -254,9 +262,11 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
     } else {
       const int v0 = GD_ADDV(), v1 = GD_ADDV(), v2 = GD_ADDV(); if (rc) break;
       c2v[corner] = v0; c2v[corner + 1] = v1; c2v[corner + 2] = v2; lm[v0] = corner; lm[v1] = corner + 1; lm[v2] = corner + 2;
+      if (sp >= nf + 4) { rc = -13; break; }
       stack[sp++] = corner; check = 1;
     }
     { const int c = stack[sp - 1], nn = g_nxt(c), pp = g_prv(c);
+      if (GD_BADC(c) || GD_BADV(c2v[c]) || GD_BADV(c2v[nn]) || GD_BADV(c2v[pp])) { rc = -18; break; }
       if (sym == 0 || sym == 1) { val[c2v[nn]] += 1; val[c2v[pp]] += 1; }
       else if (sym == 5) { val[c2v[c]] += 1; val[c2v[nn]] += 1; val[c2v[pp]] += 2; }
       else if (sym == 3) { val[c2v[c]] += 1; val[c2v[nn]] += 2; val[c2v[pp]] += 1; }
@@ -266,7 +276,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
       const int esid = nsym - sid - 1;
       while (splits_left > 0 && J.sp_src[splits_left - 1] == esid) {
         splits_left--;
-        const int top = stack[sp - 1];
+        const int top = stack[sp - 1]; if (GD_BADC(top)) { rc = -14; break; }
         const int nac = J.sp_edge[splits_left] == 1 ? g_nxt(top) : g_prv(top);
         const int dsid = nsym - J.sp_spl[splits_left] - 1;
         if (dsid < 0 || dsid > nsym) { rc = -14; break; }
@@ -276,9 +286,12 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   }
   while (!rc && sp > 0) {
     const int corner = stack[--sp];
+    if (GD_BADC(corner)) { rc = -15; break; }
     if (gd_rabs_bit(SF)) {
-      const int vn = c2v[g_nxt(corner)], cb = g_nxt(lm[vn]), vx = c2v[g_nxt(cb)], cc = g_nxt(lm[vx]), vp = c2v[g_nxt(cc)];
-      if (nfaces >= nf) { rc = -15; break; }
+      const int vn = c2v[g_nxt(corner)]; if (GD_BADV(vn) || GD_BADC(lm[vn])) { rc = -15; break; }
+      const int cb = g_nxt(lm[vn]), vx = c2v[g_nxt(cb)]; if (GD_BADV(vx) || GD_BADC(lm[vx])) { rc = -15; break; }
+      const int cc = g_nxt(lm[vx]), vp = c2v[g_nxt(cc)]; if (GD_BADV(vp)) { rc = -15; break; }
+      if (nfaces >= nf || opp[corner] != GEO_INV || opp[cb] != GEO_INV || opp[cc] != GEO_INV) { rc = -15; break; }
       const int face = nfaces++, nc = 3 * face;
       GD_SETOPP(nc, corner); GD_SETOPP(nc + 1, cb); GD_SETOPP(nc + 2, cc);
       c2v[nc] = vx; c2v[nc + 1] = vp; c2v[nc + 2] = vn;
@@ -291,6 +304,23 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   if (rc) J.status = rc;
 #undef GD_SETOPP
 #undef GD_ADDV
+#undef GD_BADV
+#undef GD_BADC
+}
+
+// every corner must carry an allocated vertex and a symmetric opposite before the parallel stages index with them
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_validate(GeoDecJob *jobs, int what) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  const int c = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x), nc = 3 * J.nf;
+  if (J.status != 0 || c >= nc) return;
+  if (what == 0) {
+    const int v = J.c2v[c], o = J.opp[c];
+    bool bad = (unsigned)v >= (unsigned)J.nv || o < GEO_INV || o >= nc || (o >= 0 && J.opp[o] != c);
+    if (!bad && J.lm[v] == GEO_INV) bad = true;
+    if (bad) J.status = -19;
+  } else {
+    for (int i = 0; i < J.nad; i++) if ((unsigned)J.t_c2v[i][c] >= (unsigned)J.t_nv[i]) J.status = -19;
+  }
 }
 
 // ---- K4: seam bits (A.5).  One wave per frame: (a) count the edges that carry a bit (opposite face has the larger
@@ -332,7 +362,7 @@ __global__ void __launch_bounds__(64) k_gdec_seams(GeoDecJob *jobs) {
 // again, writing ids (thread per vertex). ----
 __device__ __forceinline__ int gd_fan_first(const GTab &T, const uint8_t *vseam, int v, int c) {
   int first = c;
-  if (vseam[v]) { int a = gt_swl(T, first); while (a != GEO_INV) { first = a; a = gt_swl(T, a); if (a == c) break; } }
+  if (vseam[v]) { int a = gt_swl(T, first), guard = 0; while (a != GEO_INV) { first = a; a = gt_swl(T, a); if (a == c || ++guard > 4096) break; } }
   return first;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_vseam(GeoDecJob *jobs) {
@@ -355,7 +385,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_atttab(GeoDecJob *jobs, int
   int vid = pass ? cntp[v] : 0, tn = vid + 1;
   if (pass) { J.t_c2v[i][first] = vid; J.t_lm[i][vid] = first; }
   int a = (opp[g_prv(first)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(first)]);
+  int guard = 0;
   while (a != GEO_INV && a != first) {
+    if (++guard > 4096) { J.status = -19; break; }             // fans are short; a cycle that misses `first` means corrupt tables
     if (es[g_nxt(a)]) { vid = tn; if (pass) J.t_lm[i][tn] = a; tn++; }
     if (pass) J.t_c2v[i][a] = vid;
     a = (opp[g_prv(a)] == GEO_INV) ? GEO_INV : g_prv(opp[g_prv(a)]);
@@ -489,8 +521,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_normals(GeoDecJob *jobs, Ge
   const int c0 = G.order[t][dd];
   const int32_t *cenp = P + 3 * b_v2d[c2v[c0]];
   long long N[3] = { 0, 0, 0 };
-  int c = c0; bool left = true;
-  while (c != GEO_INV) {
+  int c = c0, guard = 0; bool left = true;
+  while (c != GEO_INV && ++guard <= 4096) {
     const int32_t *a = P + 3 * b_v2d[c2v[g_nxt(c)]], *bb = P + 3 * b_v2d[c2v[g_prv(c)]];
     long long dn[3], dp[3];
     for (int k = 0; k < 3; k++) { dn[k] = (long long)a[k] - cenp[k]; dp[k] = (long long)bb[k] - cenp[k]; }
@@ -640,7 +672,7 @@ static bool gdec_header(const uint8_t *b, size_t n, uint32_t *nev, uint32_t *nf)
   size_t o = 12; uint32_t v[2];
   for (int k = 0; k < 2; k++) { uint64_t r = 0; int s = 0; for (;;) { if (o >= n || s > 35) return false; const uint8_t c = b[o++]; r |= (uint64_t)(c & 0x7f) << s; s += 7; if (c < 0x80) break; } v[k] = (uint32_t)r; }
   *nev = v[0]; *nf = v[1];
-  return v[1] > 0 && v[1] <= (1u << 26) && v[0] <= 3 * v[1] + 8;
+  return v[1] > 0 && v[1] <= (1u << 26) && v[0] <= 3 * v[1] + 8 && (uint64_t)v[1] <= 16ull * n;      // a face costs > 1/16 byte
 }
 extern "C" int uvol_drc_info(const uint8_t *drc, size_t len, uint32_t *n_faces, uint32_t *max_values) {
   uint32_t nev = 0, nf = 0;
@@ -729,13 +761,14 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   const unsigned N = (unsigned)n, bc = uvol_blocks((size_t)3 * max_nf);
   { uvol_ctx::Scope sc(ctx, "geodec.k1_index", 0); GLAUNCH(k_gdec_init, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj); GLAUNCH(k_gdec_index, dim3(N), dim3(64), 0, dj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(6, N), dim3(64), 0, dj, 0, 6); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn, dim3(N), dim3(64), 0, dj); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 0); }
   { uvol_ctx::Scope sc(ctx, "geodec.k4_seams_tables", 0);
     GLAUNCH(k_gdec_seams, dim3(N), dim3(64), 0, dj);
     GLAUNCH(k_gdec_vseam, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj);
     GLAUNCH(k_gdec_atttab, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj, 0);
     GLAUNCH(k_gdec_attscan, dim3(GD_MAXAD, N), dim3(64), 0, dj);
     GLAUNCH(k_gdec_atttab, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj, 1);
+    GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 1);
     GLAUNCH(k_gdec_open, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
     if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) return rc;

@@ -356,7 +356,7 @@ static int tdec_parse(const uint8_t *b, size_t n, TexDecJob &J) {
   if (!b || n < 104 || memcmp(b, ident, 12)) return -1;
   const uint32_t vk = rd32h(b + 12), W = rd32h(b + 20), H = rd32h(b + 24), layers = rd32h(b + 32), faces = rd32h(b + 36), levels = rd32h(b + 40), sc = rd32h(b + 44);
   const uint64_t sgd_off = rd64h(b + 64), sgd_len = rd64h(b + 72), lv_off = rd64h(b + 80), lv_len = rd64h(b + 88);
-  if (vk != 0 || sc != 1 || levels != 1 || faces != 1 || W == 0 || H == 0) return -2;
+  if (vk != 0 || sc != 1 || levels != 1 || faces != 1 || W == 0 || H == 0 || W > 16384 || H > 16384) return -2;
   if (sgd_off + sgd_len > n || lv_off + lv_len > n || lv_len > 0xffffffffull) return -3;
   const uint32_t nsl = layers ? layers : 1;
   if (nsl > TD_MAX_LAYERS) return -4;
