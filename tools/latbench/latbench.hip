@@ -23,6 +23,34 @@ __global__ void __launch_bounds__(64) chase(const int4 *recs, int *out, long lon
     out[(size_t)blockIdx.x * steps + threadIdx.x] = idx8;
     return;
   }
+  if (variant == 11 || variant == 12) {
+    // 11: chase + ~60 dependent scalar-ish ALU ops per step on the loaded value (a stand-in for the walkers' bookkeeping)
+    // 12: same work, but the NEXT step's record is requested as soon as its index is known (start of the step) through a
+    //     formally divergent address, and only moved to scalars (readfirstlane) when the following step needs it
+    if (threadIdx.x) return;
+    G(const v4i) rr = (G(const v4i))(recs + 2 * (size_t)blockIdx.x * nrec);
+    const int dz = (int)__builtin_amdgcn_mbcnt_lo(~0u, 0u);
+    int idx = (int)((blockIdx.x * 7919u) % (unsigned)nrec), acc = 0;
+    const long long t0 = wall_clock64();
+    if (variant == 11) {
+      for (int s = 0; s < steps; s++) {
+        const v4i a = rr[2 * (size_t)idx];
+        int w = a.y; for (int k = 0; k < 60; k++) w = (w * 5 + k) ^ (w >> 3);
+        acc += w; idx = a.x;
+      }
+    } else {
+      v4i cur = rr[2 * (size_t)idx];                 // record of the current index
+      for (int s = 0; s < steps; s++) {
+        const int nxt = __builtin_amdgcn_readfirstlane(cur.x), payload = __builtin_amdgcn_readfirstlane(cur.y);
+        const v4i pre = rr[2 * (size_t)(nxt + dz)];  // in flight during the bookkeeping below
+        int w = payload; for (int k = 0; k < 60; k++) w = (w * 5 + k) ^ (w >> 3);
+        acc += w; idx = nxt; cur = pre;
+      }
+    }
+    const long long t1 = wall_clock64();
+    clk[blockIdx.x] = t1 - t0; out[(size_t)blockIdx.x * steps] = idx; out[(size_t)blockIdx.x * steps + 1] = acc;
+    return;
+  }
   if (threadIdx.x) return;
   if (variant == 9 || variant == 10) {   // chase through LDS-DMA slots: 9 = load the needed record only; 10 = speculative pair issued early + 40 ALU ops
     extern __shared__ v4i lds[];
@@ -99,7 +127,7 @@ int main(int argc, char **argv) {
   int4 *d; int *out; long long *clk;
   hipMalloc(&d, h.size() * 4); hipMalloc(&out, (size_t)blocks * steps * 4); hipMalloc(&clk, blocks * 8);
   hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  for (int variant = 0; variant <= 10; variant++) {
+  for (int variant = 0; variant <= 12; variant++) {
     const int v = variant == 4 ? 0 : variant;
     for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(chase, dim3(blocks), dim3(64), 1024, 0, d, out, clk, nrec, steps, v, variant == 4); hipDeviceSynchronize(); }
     std::vector<long long> c(blocks); hipMemcpy(c.data(), clk, blocks * 8, hipMemcpyDeviceToHost);

@@ -275,6 +275,15 @@ typedef int4 uvol_i4;
 #else
 typedef int uvol_i4 __attribute__((ext_vector_type(4)));      // loadable through an address-space-qualified pointer
 #endif
+// the three live words {vertex, right, left} of a corner record as ONE 12-byte load: a prefetched 16-byte load would leave
+// its dead 4th register free for the allocator to reuse at once, which forces a wait right behind the load
+#ifdef HIPEMU
+struct uvol_i3 { int x, y, z; };
+template <typename P> __device__ __forceinline__ uvol_i3 rec3(P rec, int code) { const uvol_i4 q = rec[code]; uvol_i3 r; r.x = q.x; r.y = q.y; r.z = q.z; return r; }
+#else
+typedef int uvol_i3 __attribute__((ext_vector_type(3)));
+template <typename P> __device__ __forceinline__ uvol_i3 rec3(P rec, int code) { return *(UVOL_G(const uvol_i3))(rec + code); }
+#endif
 // bitmap words: LDS pointers read with ds_read; global pointers with a device-scope load that bypasses the per-CU L1,
 // because the bits are set with atomic ORs performed in L2 (a plain load could return a stale L1 line)
 __device__ __forceinline__ uint32_t pword(UVOL_L(uint32_t) w, int k) { return w[k]; }
@@ -298,6 +307,7 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack);
   UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
   UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
+  const int dz = UVOL_LANE_ZERO();
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   for (int f0 = 0; f0 < nf; f0++) {
@@ -333,30 +343,37 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
       int x = top_known ? top : stack[sp - 1];
       top_known = false;
       if (x < 0 || pbit_get(fbits, x >> 2)) { sp--; continue; }
+      int vi, rcn, lcn;
+      { const uvol_i4 q = rec[x]; vi = q.x; rcn = q.y; lcn = q.z; }
       for (;;) {
-        const uvol_i4 q = rec[x];
-        const int face = x >> 2, vi = q.x, rcn = q.y, lcn = q.z;
+        const int face = x >> 2;
+        // both records this step can move to are requested now and taken (readfirstlane) only by the branch that goes there
+        const uvol_i3 pR = rec3(rec, (rcn < 0 ? x : rcn) + dz), pL = rec3(rec, (lcn < 0 ? x : lcn) + dz);
         proc[nproc] = 3 * face + (x & 3);
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = pword(vbits, v >> 5);
         const uint32_t rw_ = rcn < 0 ? 0xffffffffu : pword(fbits, rcn >> 7), lw_ = lcn < 0 ? 0xffffffffu : pword(fbits, lcn >> 7);
+#define W_GO_R() do { x = rcn; vi = UVOL_READFIRST(pR.x); lcn = UVOL_READFIRST(pR.z); rcn = UVOL_READFIRST(pR.y); } while (0)
+#define W_GO_L() do { x = lcn; vi = UVOL_READFIRST(pL.x); rcn = UVOL_READFIRST(pL.y); lcn = UVOL_READFIRST(pL.z); } while (0)
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v);
-          if (!(vi & 1)) { symb[nproc] = T_C; nproc++; x = rcn; continue; }
+          if (!(vi & 1)) { symb[nproc] = T_C; nproc++; W_GO_R(); continue; }
         }
         const bool rvis = ((rw_ >> ((rcn >> 2) & 31)) & 1u) != 0, lvis = ((lw_ >> ((lcn >> 2) & 31)) & 1u) != 0;
         const int sym = rvis ? (lvis ? T_E : T_R) : (lvis ? T_L : T_S);
         symb[nproc] = (uint8_t)sym;
         nproc++;
         if (sym == T_E) { sp--; break; }
-        if (sym == T_R) { x = lcn; continue; }
-        if (sym == T_L) { x = rcn; continue; }
+        if (sym == T_R) { W_GO_L(); continue; }
+        if (sym == T_L) { W_GO_R(); continue; }
         nsplit++;
         stack[sp - 1] = lcn; stack[sp] = rcn;
         sp++; top = rcn; top_known = true;
         break;
+#undef W_GO_R
+#undef W_GO_L
       }
     }
   }
@@ -597,6 +614,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   const int nf = (int)J.nf;
   UVOL_G(const uvol_i4) rec = UVOL_TO_G(const uvol_i4, reinterpret_cast<const uvol_i4 *>(J.rec[1 + t]));
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  const int dz = UVOL_LANE_ZERO();
   int n = 0;
   for (int f = 0; f < nf; f++) {
     if (pbit_get(fbits, f)) continue;
@@ -611,21 +629,28 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
       x = top_known ? top : stack[sp - 1];
       top_known = false;
       if (x < 0 || pbit_get(fbits, x >> 2)) { sp--; continue; }
+      int vi, rc, lc;
+      { const uvol_i4 q = rec[x]; vi = q.x; rc = q.y; lc = q.z; }
       for (;;) {
-        const uvol_i4 q = rec[x];
-        const int face = x >> 2, vi = q.x, rc = q.y, lc = q.z;
+        const int face = x >> 2;
+        // both records this step can move to are requested now and taken (readfirstlane) only by the branch that goes there
+        const uvol_i3 pR = rec3(rec, (rc < 0 ? x : rc) + dz), pL = rec3(rec, (lc < 0 ? x : lc) + dz);
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = pword(vbits, v >> 5);
         const uint32_t rw_ = rc < 0 ? 0xffffffffu : pword(fbits, rc >> 7), lw_ = lc < 0 ? 0xffffffffu : pword(fbits, lc >> 7);
+#define T_GO_R() do { x = rc; vi = UVOL_READFIRST(pR.x); lc = UVOL_READFIRST(pR.z); rc = UVOL_READFIRST(pR.y); } while (0)
+#define T_GO_L() do { x = lc; vi = UVOL_READFIRST(pL.x); rc = UVOL_READFIRST(pL.y); lc = UVOL_READFIRST(pL.z); } while (0)
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v); order[n] = 3 * face + (x & 3); n++;
-          if (!(vi & 1)) { x = rc; continue; }
+          if (!(vi & 1)) { T_GO_R(); continue; }
         }
         const bool rvis = ((rw_ >> ((rc >> 2) & 31)) & 1u) != 0, lvis = ((lw_ >> ((lc >> 2) & 31)) & 1u) != 0;
-        if (rvis) { if (lvis) { sp--; break; } x = lc; }
-        else { if (lvis) x = rc; else { stack[sp - 1] = lc; stack[sp] = rc; sp++; top = rc; top_known = true; break; } }
+        if (rvis) { if (lvis) { sp--; break; } T_GO_L(); }
+        else { if (lvis) T_GO_R(); else { stack[sp - 1] = lc; stack[sp] = rc; sp++; top = rc; top_known = true; break; } }
+#undef T_GO_R
+#undef T_GO_L
       }
     }
   }
