@@ -48,7 +48,8 @@ typedef struct uvol_params {
   int32_t etc1s_quality;            /* basisu -q equivalent, 1..255, default 128 (Encoder.py passes none) */
   int32_t y_flip;                   /* basisu -y_flip (Encoder.py:290 always passes it), default 1 */
   int32_t max_batch;                /* frames in flight per geometry batch, default 32 */
-  int32_t cu_mod;                   /* optional CU partition: stream runs only on CUs with (index % cu_mod) in cu_residues; 0 = all CUs */
+  int32_t cu_mod;                   /* experimental CU partition (hipExtStreamCreateWithCUMask): CUs with (index % cu_mod) in cu_residues; 0 = all.
+                                       Measured without effect on kernel placement under ROCm 7.2 on this pool; off by default */
   int32_t cu_residues;              /* bit r set = residue r allowed */
   int32_t traverse_vbits_l2;        /* 1: the attribute traversers keep only their face bitmap in LDS and the vertex bitmap in L2
                                        (6 instead of 3 per CU): pays off when several contexts keep > 700 frames in flight */

@@ -38,17 +38,19 @@ struct TexDecJob {
 };
 
 // ---- LSB-first bit reader over global memory: aligned dwords, the next one always in flight ----
+// (`pre` is requested through a formally divergent address and only moved to scalars when it is consumed, so the load
+//  is really in flight while the previous 32 bits are decoded — see UVOL_LANE_ZERO / UVOL_READFIRST)
 struct DBits {
-  UVOL_G(const uint32_t) w; uint32_t nwords, wi, have, pre; unsigned long long win, consumed;
+  UVOL_G(const uint32_t) w; uint32_t nwords, wi, have, pre; int dz; unsigned long long win, consumed;
 };
 __device__ __forceinline__ void db_refill(DBits &B) {
-  while (B.have <= 32) { B.win |= (unsigned long long)B.pre << B.have; B.have += 32; B.wi++; B.pre = B.wi < B.nwords ? B.w[B.wi] : 0u; }
+  while (B.have <= 32) { B.win |= (unsigned long long)(uint32_t)UVOL_READFIRST(B.pre) << B.have; B.have += 32; B.wi++; B.pre = B.wi < B.nwords ? B.w[B.wi + B.dz] : 0u; }
 }
 __device__ __forceinline__ void db_init(DBits &B, const uint8_t *p, uint32_t nbytes) {
   const uint32_t a = (uint32_t)((size_t)p & 3);
   B.w = UVOL_TO_G(const uint32_t, reinterpret_cast<const uint32_t *>(p - a));
-  B.nwords = (a + nbytes + 3) / 4; B.wi = 0; B.have = 0; B.win = 0; B.consumed = 0;
-  B.pre = B.nwords ? B.w[0] : 0u;
+  B.nwords = (a + nbytes + 3) / 4; B.wi = 0; B.have = 0; B.win = 0; B.consumed = 0; B.dz = UVOL_LANE_ZERO();
+  B.pre = B.nwords ? B.w[B.dz] : 0u;
   db_refill(B);
   B.win >>= 8 * a; B.have -= 8 * a;
 }
