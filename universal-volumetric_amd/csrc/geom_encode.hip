@@ -311,6 +311,8 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   for (int f0 = 0; f0 < nf; f0++) {
+    // component starts: fully visited words of the face bitmap are skipped 32 faces at a time
+    if ((f0 & 31) == 0) { while (f0 + 32 <= nf && pword(fbits, f0 >> 5) == 0xffffffffu) f0 += 32; if (f0 >= nf) break; }
     if (pbit_get(fbits, f0)) continue;
     const uvol_i4 q0 = rec[4 * (size_t)f0], q1 = rec[4 * (size_t)f0 + 1], q2 = rec[4 * (size_t)f0 + 2];
     const int o0[3] = { q0.w, q1.w, q2.w }, v0[3] = { q0.x, q1.x, q2.x };
@@ -617,6 +619,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   const int dz = UVOL_LANE_ZERO();
   int n = 0;
   for (int f = 0; f < nf; f++) {
+    if ((f & 31) == 0) { while (f + 32 <= nf && pword(fbits, f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; }
     if (pbit_get(fbits, f)) continue;
     int x = 4 * f, sp = 0;
     stack[sp] = x;
