@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traverse-vbits-l2", type=int, default=-1, help="-1 auto (on with >= 3 geometry streams and >= 700 frames), 0 off, 1 on")
+    ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--geo-stagger-ms", type=float, default=0.0, help="one-time start delay of geometry stream g: g * this")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
@@ -94,6 +95,8 @@ def main():
     cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
     gcfg, tcfg = dict(cfg), dict(cfg)
     GS = max(1, args.geo_streams)
+    if args.tex_priority:
+        tcfg.update(stream_priority=1)
     if args.traverse_vbits_l2 == 1 or (args.traverse_vbits_l2 < 0 and GS >= 3 and F >= 700):                # > 700 frames in flight: attribute traversers with their vertex bitmap in L2 (see uvol_codec.h)
         gcfg.update(traverse_vbits_l2=1)
     if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)

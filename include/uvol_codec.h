@@ -53,7 +53,9 @@ typedef struct uvol_params {
   int32_t cu_residues;              /* bit r set = residue r allowed */
   int32_t traverse_vbits_l2;        /* 1: the attribute traversers keep only their face bitmap in LDS and the vertex bitmap in L2
                                        (6 instead of 3 per CU): pays off when several contexts keep > 700 frames in flight */
-  int32_t reserved[4];
+  int32_t stream_priority;          /* 1: create the context's HIP stream with the highest priority (short, LDS-hungry texture
+                                       kernels then get free CU slots before the long geometry walkers take them) */
+  int32_t reserved[3];
 } uvol_params;
 
 void uvol_params_default(uvol_params *p);

@@ -22,6 +22,13 @@ hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
     }
   }
 #endif
+#ifndef HIPEMU
+  if (ctx->prm.stream_priority > 0) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+  }
+#endif
   return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 

@@ -25,7 +25,7 @@ class Params(C.Structure):
     _fields_ = [("Q_POSITION_ATTR", C.c_int32), ("Q_TEXTURE_ATTR", C.c_int32), ("Q_NORMAL_ATTR", C.c_int32),
                 ("Q_GENERIC_ATTR", C.c_int32), ("DRACO_COMPRESSION_LEVEL", C.c_int32), ("KTX2_BATCH_SIZE", C.c_int32),
                 ("etc1s_quality", C.c_int32), ("y_flip", C.c_int32), ("max_batch", C.c_int32), ("cu_mod", C.c_int32), ("cu_residues", C.c_int32),
-                ("traverse_vbits_l2", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("traverse_vbits_l2", C.c_int32), ("stream_priority", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Mesh(C.Structure):
