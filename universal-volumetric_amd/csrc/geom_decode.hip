@@ -559,21 +559,36 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
   if (A.pred_method == 1 || A.pred_method == 0) {
     const int32_t lo = A.lo, hi = A.hi;
     UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)9 * J.nf + 64));
+    // the sequential inputs of entry p + 1 (neighbour entries, symbols) are requested while entry p is computed
+    // (UVOL_LANE_ZERO / UVOL_READFIRST, see uvol_common.hpp); only the reads of earlier OUTPUTS stay in the chain
+    const int dz = UVOL_LANE_ZERO();
+    int n0 = ne > 0 ? nbr[dz] : -1, n1 = ne > 0 ? nbr[1 + dz] : -1, n2 = ne > 0 ? nbr[2 + dz] : -1;
+    uint32_t sy[4] = { 0, 0, 0, 0 }; for (int k = 0; k < nc && ne > 0; k++) sy[k] = syms[k + dz];
     for (int p = 0; p < ne; p++) {
       int32_t pred[4] = { 0, 0, 0, 0 };
-      const int a = nbr[3 * p], bn = nbr[3 * p + 1], bp = nbr[3 * p + 2];
+      const int a = UVOL_READFIRST(n0), bn = UVOL_READFIRST(n1), bp = UVOL_READFIRST(n2);
+      uint32_t cs[4]; for (int k = 0; k < nc; k++) cs[k] = (uint32_t)UVOL_READFIRST(sy[k]);
+      if (p + 1 < ne) { n0 = nbr[3 * (p + 1) + dz]; n1 = nbr[3 * (p + 1) + 1 + dz]; n2 = nbr[3 * (p + 1) + 2 + dz]; for (int k = 0; k < nc; k++) sy[k] = syms[(p + 1) * nc + k + dz]; }
       if (a >= 0) { for (int k = 0; k < nc; k++) pred[k] = out[bn * nc + k] + out[bp * nc + k] - out[a * nc + k]; }
       else if (p > 0) for (int k = 0; k < nc; k++) pred[k] = out[(p - 1) * nc + k];
-      for (int k = 0; k < nc; k++) out[p * nc + k] = gd_wrap(pred[k], gd_sgn(syms[p * nc + k]), lo, hi);
+      for (int k = 0; k < nc; k++) out[p * nc + k] = gd_wrap(pred[k], gd_sgn(cs[k]), lo, hi);
     }
   } else if (A.pred_method == 5) {
     if (pdec < 0) { J.status = -26; return; }
     const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
     { GDBit Rb; if (gd_rabs_open(Rb, J, A.aux)) { J.status = -26; return; } int last = 1; for (int k = 0; k < no; k++) { if (!gd_rabs_bit(Rb)) last = !last; ori[k] = (uint8_t)last; } }
     const int32_t lo = A.lo, hi = A.hi; int nori = no;
-    UVOL_G(const long long) uvg = UVOL_TO_G(const long long, reinterpret_cast<const long long *>(J.uvgeo));      // GDUvGeo = 4 x 8 bytes
+    const int dz = UVOL_LANE_ZERO();
+    UVOL_G(const int32_t) uvw = UVOL_TO_G(const int32_t, reinterpret_cast<const int32_t *>(J.uvgeo));           // the same records as 8 words
+    int32_t gw[8]; uint32_t sy0 = 0, sy1 = 0;
+    for (int k = 0; k < 8 && ne > 0; k++) gw[k] = uvw[k + dz];
+    if (ne > 0) { sy0 = syms[dz]; sy1 = syms[1 + dz]; }
     for (int p = 0; p < ne; p++) {
-      GDUvGeo g; { const long long w0 = uvg[4 * (size_t)p]; g.nd = (int32_t)(w0 & 0xffffffffll); g.pd = (int32_t)(w0 >> 32); g.pn2 = uvg[4 * (size_t)p + 1]; g.dd = uvg[4 * (size_t)p + 2]; g.ns = uvg[4 * (size_t)p + 3]; }
+      GDUvGeo g; uint32_t cs[2];
+      { uint32_t u[8]; for (int k = 0; k < 8; k++) u[k] = (uint32_t)UVOL_READFIRST(gw[k]);
+        g.nd = (int32_t)u[0]; g.pd = (int32_t)u[1]; g.pn2 = (long long)(((unsigned long long)u[3] << 32) | u[2]); g.dd = (long long)(((unsigned long long)u[5] << 32) | u[4]); g.ns = (long long)(((unsigned long long)u[7] << 32) | u[6]);
+        cs[0] = (uint32_t)UVOL_READFIRST(sy0); cs[1] = (uint32_t)UVOL_READFIRST(sy1); }
+      if (p + 1 < ne) { for (int k = 0; k < 8; k++) gw[k] = uvw[8 * (size_t)(p + 1) + k + dz]; sy0 = syms[2 * (p + 1) + dz]; sy1 = syms[2 * (p + 1) + 1 + dz]; }
       const int nd = g.nd, pd = g.pd;
       long long pred[2]; bool have = false;
       if (pd < p && nd < p) {
@@ -596,7 +611,7 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
         else if (p > 0) { pred[0] = out[(p - 1) * 2]; pred[1] = out[(p - 1) * 2 + 1]; }
         else { pred[0] = pred[1] = 0; }
       }
-      for (int k = 0; k < 2; k++) out[p * 2 + k] = gd_wrap((int32_t)pred[k], gd_sgn(syms[p * 2 + k]), lo, hi);
+      for (int k = 0; k < 2; k++) out[p * 2 + k] = gd_wrap((int32_t)pred[k], gd_sgn(cs[k]), lo, hi);
     }
     if (nori != 0) { J.status = -28; return; }
   }
