@@ -213,6 +213,8 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   int cnt[6]; for (int i = 0; i < 6; i++) cnt[i] = (int)J.rs[i].nvals;
   GDBit SF; if (gd_rabs_open(SF, J, J.rb_start)) { J.status = -7; return; }
   int rc = 0, nv = 0, sp = 0, nfaces = 0, active_ctx = -1, splits_left = nts, n_int = 0;
+  int top = GEO_INV;                 // mirror of stack[sp - 1]: the machine reads its own last write most of the time
+  int fv0 = 0, fv1 = 0, fv2 = 0;     // vertices of the new face's corners 0, 1, 2 (known without re-reading c2v)
   const int SYM2TOPO[5] = { 0, 1, 3, 5, 7 };
 #define GD_SETOPP(a, bb) do { opp[a] = (bb); opp[bb] = (a); } while (0)
 #define GD_ADDV() (nv < maxv ? (lm[nv] = GEO_INV, nv++) : (rc = -9, 0))
@@ -225,25 +227,27 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
     const int corner = 3 * face;
     if (sym == 0) {
       if (sp == 0) { rc = -11; break; }
-      const int ca = stack[sp - 1]; if (GD_BADC(ca)) { rc = -11; break; } const int vx = c2v[g_nxt(ca)]; if (GD_BADV(vx) || GD_BADC(lm[vx])) { rc = -11; break; }
+      const int ca = top; if (GD_BADC(ca)) { rc = -11; break; } const int vx = c2v[g_nxt(ca)]; if (GD_BADV(vx) || GD_BADC(lm[vx])) { rc = -11; break; }
       const int cb = g_nxt(lm[vx]);
       if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -11; break; }
       GD_SETOPP(ca, corner + 1); GD_SETOPP(cb, corner + 2);
       const int vap = c2v[g_prv(ca)], vbn = c2v[g_nxt(cb)]; if (GD_BADV(vap) || GD_BADV(vbn)) { rc = -11; break; }
       c2v[corner] = vx; c2v[corner + 1] = vbn; c2v[corner + 2] = vap; lm[vap] = corner + 2;
-      stack[sp - 1] = corner;
+      fv0 = vx; fv1 = vbn; fv2 = vap;
+      stack[sp - 1] = corner; top = corner;
     } else if (sym == 5 || sym == 3) {
       if (sp == 0) { rc = -12; break; }
-      const int ca = stack[sp - 1]; if (GD_BADC(ca) || opp[ca] != GEO_INV) { rc = -12; break; }
+      const int ca = top; if (GD_BADC(ca) || opp[ca] != GEO_INV) { rc = -12; break; }
       int oc, cl, cr;
       if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; } else { oc = corner + 1; cl = corner; cr = corner + 2; }
       GD_SETOPP(oc, ca); const int nvx = GD_ADDV(); if (rc) break; c2v[oc] = nvx; lm[nvx] = oc;
       const int vr = c2v[g_prv(ca)], vl = c2v[g_nxt(ca)]; if (GD_BADV(vr) || GD_BADV(vl)) { rc = -12; break; } c2v[cr] = vr; lm[vr] = cr;
       c2v[cl] = vl;
-      stack[sp - 1] = corner; check = 1;
+      if (sym == 5) { fv0 = vr; fv1 = vl; fv2 = nvx; } else { fv0 = vl; fv1 = nvx; fv2 = vr; }
+      stack[sp - 1] = corner; top = corner; check = 1;
     } else if (sym == 1) {
       if (sp == 0) { rc = -13; break; }
-      const int cb = stack[--sp];
+      const int cb = top; --sp;
       if (tsac[sid] != GEO_INV) { if (sp >= nf + 4) { rc = -13; break; } stack[sp++] = tsac[sid]; }
       if (sp == 0) { rc = -13; break; }
       const int ca = stack[sp - 1];
@@ -258,25 +262,27 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
       while (cn != GEO_INV) { c2v[cn] = vp; const int o2 = opp[g_nxt(cn)]; cn = o2 < 0 ? GEO_INV : g_nxt(o2); if (cn == first || ++guard > 3 * nf) { rc = -13; break; } }
       if (rc) break;
       lm[vn] = GEO_INV;
-      stack[sp - 1] = corner;
+      fv0 = c2v[corner]; fv1 = c2v[corner + 1]; fv2 = c2v[corner + 2];      // the merge loop above may have re-mapped them
+      stack[sp - 1] = corner; top = corner;
     } else {
       const int v0 = GD_ADDV(), v1 = GD_ADDV(), v2 = GD_ADDV(); if (rc) break;
       c2v[corner] = v0; c2v[corner + 1] = v1; c2v[corner + 2] = v2; lm[v0] = corner; lm[v1] = corner + 1; lm[v2] = corner + 2;
       if (sp >= nf + 4) { rc = -13; break; }
-      stack[sp++] = corner; check = 1;
+      fv0 = v0; fv1 = v1; fv2 = v2;
+      stack[sp++] = corner; top = corner; check = 1;
     }
-    { const int c = stack[sp - 1], nn = g_nxt(c), pp = g_prv(c);
-      if (GD_BADC(c) || GD_BADV(c2v[c]) || GD_BADV(c2v[nn]) || GD_BADV(c2v[pp])) { rc = -18; break; }
-      if (sym == 0 || sym == 1) { val[c2v[nn]] += 1; val[c2v[pp]] += 1; }
-      else if (sym == 5) { val[c2v[c]] += 1; val[c2v[nn]] += 1; val[c2v[pp]] += 2; }
-      else if (sym == 3) { val[c2v[c]] += 1; val[c2v[nn]] += 2; val[c2v[pp]] += 1; }
-      else { val[c2v[c]] += 2; val[c2v[nn]] += 2; val[c2v[pp]] += 2; }
-      int av = val[c2v[nn]]; av = av < 2 ? 2 : (av > 7 ? 7 : av); active_ctx = av - 2; }
+    { // the active corner is corner 0 of the face just added: its vertices are fv0 (corner), fv1 (next), fv2 (prev)
+      if (GD_BADV(fv0) || GD_BADV(fv1) || GD_BADV(fv2)) { rc = -18; break; }
+      if (sym == 0 || sym == 1) { val[fv1] += 1; val[fv2] += 1; }
+      else if (sym == 5) { val[fv0] += 1; val[fv1] += 1; val[fv2] += 2; }
+      else if (sym == 3) { val[fv0] += 1; val[fv1] += 2; val[fv2] += 1; }
+      else { val[fv0] += 2; val[fv1] += 2; val[fv2] += 2; }
+      int av = val[fv1]; av = av < 2 ? 2 : (av > 7 ? 7 : av); active_ctx = av - 2; }
     if (check) {
       const int esid = nsym - sid - 1;
       while (splits_left > 0 && J.sp_src[splits_left - 1] == esid) {
         splits_left--;
-        const int top = stack[sp - 1]; if (GD_BADC(top)) { rc = -14; break; }
+        if (GD_BADC(top)) { rc = -14; break; }
         const int nac = J.sp_edge[splits_left] == 1 ? g_nxt(top) : g_prv(top);
         const int dsid = nsym - J.sp_spl[splits_left] - 1;
         if (dsid < 0 || dsid > nsym) { rc = -14; break; }
