@@ -915,29 +915,29 @@ __global__ void __launch_bounds__(64) k_stream_setup(GeoJob *jobs) {
 // ------------------------------------------------------------------------------------------------
 // grid (blocks, stream, frame).  Alphabets that fit (<= HIST_LDS entries) are counted in LDS first: the six
 // valence-context streams have 5 symbols, so global atomics would serialise on 5 addresses per frame.
-#define HIST_LDS 8192
+#define HIST_LDS 2048          // 8 KiB: fits the LDS the resident walkers leave free; rarer, larger symbols go to global atomics
 __global__ void __launch_bounds__(UVOL_BLOCK) k_hist(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.z];
   __shared__ uint32_t lh[HIST_LDS];
   const bool ok = J.status == 0;
   RansStream &S = J.rs[blockIdx.y];
   const uint32_t n = ok ? S.n : 0;
-  const bool in_lds = S.alpha_cap <= HIST_LDS;
+  const uint32_t nlds = S.alpha_cap < HIST_LDS ? S.alpha_cap : HIST_LDS;     // symbols below nlds are counted in LDS first
   const uint32_t per_block = 16 * UVOL_BLOCK, b0 = blockIdx.x * per_block;
   if (b0 >= n) return;                                   // block-uniform
-  if (in_lds) { for (uint32_t k = threadIdx.x; k < S.alpha_cap; k += UVOL_BLOCK) lh[k] = 0; }
+  for (uint32_t k = threadIdx.x; k < nlds; k += UVOL_BLOCK) lh[k] = 0;
   __syncthreads();
   uint32_t mx = 0;
   for (uint32_t i = b0 + threadIdx.x; i < n && i < b0 + per_block; i += UVOL_BLOCK) {
     const uint32_t s = S.syms[i];
     if (s >= S.alpha_cap) { J.status = -30; continue; }
-    if (in_lds) atomicAdd(&lh[s], 1u); else atomicAdd(&S.freq[s], 1u);
+    if (s < nlds) atomicAdd(&lh[s], 1u); else atomicAdd(&S.freq[s], 1u);
     mx = s > mx ? s : mx;
   }
   for (int d = 32; d >= 1; d >>= 1) { uint32_t m2 = __shfl_xor(mx, d); mx = m2 > mx ? m2 : mx; }
   if ((threadIdx.x & 63) == 0 && mx) atomicMax(&S.max_sym, mx);
   __syncthreads();
-  if (in_lds) for (uint32_t k = threadIdx.x; k < S.alpha_cap; k += UVOL_BLOCK) { const uint32_t v = lh[k]; if (v) atomicAdd(&S.freq[k], v); }
+  for (uint32_t k = threadIdx.x; k < nlds; k += UVOL_BLOCK) { const uint32_t v = lh[k]; if (v) atomicAdd(&S.freq[k], v); }
 }
 
 // RAnsSymbolEncoder::Create + table serialisation, one lane per stream
@@ -1018,9 +1018,10 @@ __device__ __forceinline__ uint2 g_recip(uint32_t d) {          // {m, s - 1}; d
   const unsigned long long m = ((1ull << (31 + sh)) + d - 1) / d;
   return make_uint2((uint32_t)m, sh - 1);
 }
-// The table only needs to be close, not in the dependent chain: 2048 entries (16 KiB, static) keep every stream of every
-// frame resident at once (14 one-wave workgroups per frame); larger alphabets read {prob, cum} from global memory / L2.
-#define RANS_LDS_ENTRIES 2048
+// The table only needs to be close, not in the dependent chain: 1024 entries (8 KiB, static) keep every stream of every
+// frame resident at once (14 one-wave workgroups per frame) and fit the LDS that resident walkers leave free; larger
+// alphabets read {prob, cum} from global memory / L2.
+#define RANS_LDS_ENTRIES 1024
 // one rabs step with the constants of one bit value (LIM = 4096 * ls, MULT = 256 - ls)
 #define RABS_STEP(LIM, M, SH, ADD, MULT)                                                                        \
   {                                                                                                             \
