@@ -134,6 +134,12 @@ int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, cons
 int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                      uint8_t *const *rgba_dev, size_t layer_cap);
 
+/* ETC1 target (the player's `etc2` raw-texture family, reference src/Interfaces.ts:19, src/V2/player.ts:338-356; any ETC2 sampler
+ * reads ETC1 blocks): blocks[s * layers + l] receives ceil(w/4) * ceil(h/4) 8-byte ETC1 blocks in raster order (layer_cap =
+ * size of each buffer); an exact re-pack, every ETC1S block is a valid ETC1 block.  outputs_on_device: blocks are device pointers. */
+int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                         uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
+
 /* ---- decode path, geometry half ----
  * Replaces what the stock player obtains from the draco WASM decoder per frame (reference src/V2/player.ts:101, :313-336):
  * Draco 2.2 TRIANGULAR_MESH / valence-edgebreaker files with the attribute decoders of the fixtures (position, tex-coord,

@@ -59,3 +59,31 @@ def check_roundtrip(O, mesh, drc_bytes, qp=11, qt=10):
     err = np.abs(recon - pos).max()
     assert err <= step / 2 * 1.001 + 1e-4 * max(1.0, float(np.abs(pos).max())), (err, step)
     return d
+
+
+def etc1_decode_blocks(blocks, width, height):
+    """Independent ETC1 block decoder (Khronos data-format spec, ETC1 / ETC2 RGB8 'individual' and 'differential' modes) used to
+    check the ETC1 transcode target: blocks [by, bx, 8] uint8 -> RGBA8 [height, width, 4]."""
+    MOD = np.array([[2, 8], [5, 17], [9, 29], [13, 42], [18, 60], [24, 80], [33, 106], [47, 183]], np.int32)
+    by, bx = blocks.shape[:2]
+    out = np.zeros((by * 4, bx * 4, 4), np.uint8); out[..., 3] = 255
+    b = blocks.astype(np.int32)
+    diff = (b[..., 3] >> 1) & 1; flip = b[..., 3] & 1
+    t1 = (b[..., 3] >> 5) & 7; t2 = (b[..., 3] >> 2) & 7
+    base1 = np.zeros((by, bx, 3), np.int32); base2 = np.zeros((by, bx, 3), np.int32)
+    for c in range(3):
+        hi5 = b[..., c] >> 3; d3 = b[..., c] & 7; d3 = np.where(d3 >= 4, d3 - 8, d3)
+        c1d = (hi5 << 3) | (hi5 >> 2); s5 = hi5 + d3; c2d = (s5 << 3) | (s5 >> 2)
+        hi4 = b[..., c] >> 4; lo4 = b[..., c] & 15
+        base1[..., c] = np.where(diff == 1, c1d, hi4 * 17); base2[..., c] = np.where(diff == 1, c2d, lo4 * 17)
+    msb = (b[..., 4] << 8) | b[..., 5]; lsb = (b[..., 6] << 8) | b[..., 7]
+    for x in range(4):
+        for y in range(4):
+            i = 4 * x + y
+            idx = (((msb >> i) & 1) << 1) | ((lsb >> i) & 1)
+            second = np.where(flip == 1, y >= 2, x >= 2)
+            tab = np.where(second, t2, t1)
+            mag = MOD[tab, idx & 1]; mod = np.where(idx >= 2, -mag, mag)
+            base = np.where(second[..., None], base2, base1)
+            out[y::4, x::4, :3] = np.clip(base + mod[..., None], 0, 255).astype(np.uint8)
+    return out[:height, :width]

@@ -102,3 +102,18 @@ def test_gpu_texture_roundtrip_at_bench_size(gpu_codec):
         psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-9))
         assert psnr > 24.0, (l, psnr)
         assert (got[l][..., 3] == 255).all()
+
+
+def test_gpu_texture_etc1_target(oracle, gpu_codec):
+    """ETC1 transcode target on the GPU: blocks decoded by the independent ETC1 decoder of tests/helpers.py equal the pinned
+    decoder's RGBA, for the reference fixture and a 2048x2048x5 segment of this codec."""
+    import os, synth
+    from conftest import GOLDEN
+    from helpers import etc1_decode_blocks
+    fixture = open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read()
+    big = gpu_codec.encode_texture_segment(synth.texture_sequence(5, size=2048, seed=4))
+    for data in (fixture, big):
+        want = oracle.ktx2_decode(data)
+        blocks = gpu_codec.transcode_texture_segments_etc1([data])[0]
+        for l in range(want.n_slices):
+            assert np.array_equal(etc1_decode_blocks(blocks[l], want.width, want.height), want.images[l]), l

@@ -42,3 +42,20 @@ def test_hipemu_texture_decode_matches_oracle(oracle, hipemu_lib):
     with pytest.raises(uvol.UvolError):
         cd.decode_texture_segments([b"\x00" * 200])
     cd.close()
+
+
+def test_hipemu_texture_etc1_target(oracle, hipemu_lib):
+    """ETC1 transcode target: the re-packed blocks, decoded by an independent ETC1 decoder (tests/helpers.py, from the public
+    format description), give exactly the RGBA the pinned decoder produces — for the reference fixture and for own output."""
+    import os, synth, uvol
+    from conftest import GOLDEN
+    from helpers import etc1_decode_blocks
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    files = [open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read(), oracle.ktx2_encode(synth.texture_sequence(3, size=52, seed=5))]
+    for data in files:
+        want = oracle.ktx2_decode(data)
+        blocks = cd.transcode_texture_segments_etc1([data])[0]
+        assert blocks.shape == (want.n_slices, (want.height + 3) // 4, (want.width + 3) // 4, 8)
+        for l in range(want.n_slices):
+            assert np.array_equal(etc1_decode_blocks(blocks[l], want.width, want.height), want.images[l]), l
+    cd.close()

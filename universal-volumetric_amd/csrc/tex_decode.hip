@@ -344,6 +344,31 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_unpack(TexDecJob *jobs) {
   }
 }
 
+// ---- K3': ETC1 target (the `etc2` raw-texture family of the player, reference src/Interfaces.ts:19, src/V2/player.ts:338-356):
+// every ETC1S block IS an ETC1 block — differential mode with a zero delta, both sub-blocks on the same intensity table —
+// so the transcode is a re-pack of (colour5, table, selectors) into the 8-byte block, one thread per block.
+// Block bytes: R5|dR3, G5|dG3, B5|dB3, table1(3)|table2(3)|diff(1)|flip(1), then pixel-index MSB and LSB planes (16 bits each,
+// big-endian, pixel i = 4 * x + y); ETC1S selector 0..3 (dark -> bright) maps to the ETC1 index {3, 2, 0, 1}.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_etc1(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.z];
+  if (J.status != 0) return;
+  const uint32_t layer = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (layer >= J.layers || b >= J.bx * J.by) return;
+  const size_t o = (size_t)layer * J.bx * J.by + b;
+  const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
+  uint32_t msb = 0, lsb = 0;
+  for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+    const uint32_t s2 = (sel >> (8 * y + 2 * x)) & 3u, idx = s2 == 0 ? 3u : (s2 == 1 ? 2u : (s2 == 2 ? 0u : 1u));
+    const int i = 4 * x + y;
+    msb |= (idx >> 1) << i; lsb |= (idx & 1u) << i;
+  }
+  const uint32_t t = e[3];
+  uint8_t *out = J.out[layer] + 8 * (size_t)b;
+  out[0] = (uint8_t)(e[0] << 3); out[1] = (uint8_t)(e[1] << 3); out[2] = (uint8_t)(e[2] << 3);
+  out[3] = (uint8_t)((t << 5) | (t << 2) | 2u);
+  out[4] = (uint8_t)(msb >> 8); out[5] = (uint8_t)msb; out[6] = (uint8_t)(lsb >> 8); out[7] = (uint8_t)lsb;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -412,7 +437,7 @@ void texdec_destroy(uvol_ctx *ctx) {
   } while (0)
 
 // n segments (all of one width / height / layer count), rgba[s * layers + l] = width*height*4 bytes each
-int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device) {
+int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target) {
   TexDecState *T = ctx->texdec;
   if (n <= 0) return UVOL_OK;
   T->hjobs.assign((size_t)n, TexDecJob{});
@@ -425,7 +450,8 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
     foff[i] = files_total; files_total += (lens[i] + 16 + 255) & ~(size_t)255;
   }
   const TexDecJob &J0 = T->hjobs[0];
-  const size_t layer_bytes = (size_t)J0.width * J0.height * 4, nbk = (size_t)J0.bx * J0.by, L = J0.layers;
+  const size_t nbk = (size_t)J0.bx * J0.by, L = J0.layers;
+  const size_t layer_bytes = target == 1 ? nbk * 8 : (size_t)J0.width * J0.height * 4;        // target 1: ETC1 blocks, 0: RGBA8
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small: %zu < %zu", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   // per-segment workspace: codebooks, block indices, Huffman size / sorted arrays of 9 models
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -459,7 +485,9 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   { uvol_ctx::Scope sc(ctx, "texdec.k2_slices", 0);
     if (pipe) DLAUNCH(k_tdec_slices_pipe, dim3((unsigned)n), dim3(64 * (unsigned)L), lds_pipe, dj);
     else DLAUNCH(k_tdec_slices, dim3((unsigned)n), dim3(64), lds_serial, dj); }
-  { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes); DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
+  { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes);
+    if (target == 1) DLAUNCH(k_tdec_etc1, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
+    else DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -148,12 +148,17 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
 int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba, size_t layer_cap) {
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba, layer_cap, false);
+  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba, layer_cap, false, 0);
 }
 int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba_dev, size_t layer_cap) {
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba_dev) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true);
+  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true, 0);
+}
+int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_decode_segments(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 1);
 }
 
 int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {

@@ -183,7 +183,7 @@ void geodec_destroy(uvol_ctx *ctx);
 int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
 int texdec_create(uvol_ctx *ctx);
 void texdec_destroy(uvol_ctx *ctx);
-int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device);
+int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target);
 int tex_create(uvol_ctx *ctx);
 void tex_destroy(uvol_ctx *ctx);
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
