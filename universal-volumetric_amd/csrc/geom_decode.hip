@@ -548,6 +548,33 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_normals(GeoDecJob *jobs, Ge
   gd_oct_orig(ot, po, corr, A.vals + 2 * dd);
 }
 
+// parallelogram + wrap recurrence of one decoder (A.6).  The sequential inputs of entry p + 1 (neighbour entries, symbols)
+// are requested while entry p is computed (UVOL_LANE_ZERO / UVOL_READFIRST); only the reads of earlier OUTPUTS stay in the chain.
+template <int NC>
+__device__ __forceinline__ void gd_pgram_loop(int ne, UVOL_G(const int32_t) nbr, UVOL_G(const uint32_t) syms, UVOL_G(int32_t) out, int32_t lo, int32_t hi) {
+  const int dz = UVOL_LANE_ZERO();
+  int n0 = ne > 0 ? nbr[dz] : -1, n1 = ne > 0 ? nbr[1 + dz] : -1, n2 = ne > 0 ? nbr[2 + dz] : -1;
+  uint32_t sy[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) sy[k] = ne > 0 ? syms[k + dz] : 0u;
+  for (int p = 0; p < ne; p++) {
+    int32_t pred[NC];
+    const int a = UVOL_READFIRST(n0), bn = UVOL_READFIRST(n1), bp = UVOL_READFIRST(n2);
+    uint32_t cs[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) cs[k] = (uint32_t)UVOL_READFIRST(sy[k]);
+    if (p + 1 < ne) {
+      n0 = nbr[3 * (p + 1) + dz]; n1 = nbr[3 * (p + 1) + 1 + dz]; n2 = nbr[3 * (p + 1) + 2 + dz];
+#pragma unroll
+      for (int k = 0; k < NC; k++) sy[k] = syms[(p + 1) * NC + k + dz];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) pred[k] = a >= 0 ? out[bn * NC + k] + out[bp * NC + k] - out[a * NC + k] : (p > 0 ? out[(p - 1) * NC + k] : 0);
+#pragma unroll
+    for (int k = 0; k < NC; k++) out[p * NC + k] = gd_wrap(pred[k], gd_sgn(cs[k]), lo, hi);
+  }
+}
+
 __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, int phase) {
   GeoDecJob &J = jobs[blockIdx.y];
   const GeoJob &G = gj[blockIdx.y];
@@ -565,20 +592,12 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
   if (A.pred_method == 1 || A.pred_method == 0) {
     const int32_t lo = A.lo, hi = A.hi;
     UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)9 * J.nf + 64));
-    // the sequential inputs of entry p + 1 (neighbour entries, symbols) are requested while entry p is computed
-    // (UVOL_LANE_ZERO / UVOL_READFIRST, see uvol_common.hpp); only the reads of earlier OUTPUTS stay in the chain
-    const int dz = UVOL_LANE_ZERO();
-    int n0 = ne > 0 ? nbr[dz] : -1, n1 = ne > 0 ? nbr[1 + dz] : -1, n2 = ne > 0 ? nbr[2 + dz] : -1;
-    uint32_t sy[4] = { 0, 0, 0, 0 }; for (int k = 0; k < nc && ne > 0; k++) sy[k] = syms[k + dz];
-    for (int p = 0; p < ne; p++) {
-      int32_t pred[4] = { 0, 0, 0, 0 };
-      const int a = UVOL_READFIRST(n0), bn = UVOL_READFIRST(n1), bp = UVOL_READFIRST(n2);
-      uint32_t cs[4]; for (int k = 0; k < nc; k++) cs[k] = (uint32_t)UVOL_READFIRST(sy[k]);
-      if (p + 1 < ne) { n0 = nbr[3 * (p + 1) + dz]; n1 = nbr[3 * (p + 1) + 1 + dz]; n2 = nbr[3 * (p + 1) + 2 + dz]; for (int k = 0; k < nc; k++) sy[k] = syms[(p + 1) * nc + k + dz]; }
-      if (a >= 0) { for (int k = 0; k < nc; k++) pred[k] = out[bn * nc + k] + out[bp * nc + k] - out[a * nc + k]; }
-      else if (p > 0) for (int k = 0; k < nc; k++) pred[k] = out[(p - 1) * nc + k];
-      for (int k = 0; k < nc; k++) out[p * nc + k] = gd_wrap(pred[k], gd_sgn(cs[k]), lo, hi);
-    }
+    // component count as a template parameter: the per-component arrays must stay in registers (a run-time bound sends
+    // them to scratch memory)
+    if (nc == 3) gd_pgram_loop<3>(ne, nbr, syms, out, lo, hi);
+    else if (nc == 1) gd_pgram_loop<1>(ne, nbr, syms, out, lo, hi);
+    else if (nc == 2) gd_pgram_loop<2>(ne, nbr, syms, out, lo, hi);
+    else gd_pgram_loop<4>(ne, nbr, syms, out, lo, hi);
   } else if (A.pred_method == 5) {
     if (pdec < 0) { J.status = -26; return; }
     const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
