@@ -140,6 +140,12 @@ int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, 
 int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                          uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
 
+/* BC7 target (KTX2Loader's choice on desktop GPUs, reference src/lib/KTX2Loader.js:591-689): blocks[s * layers + l] receives
+ * ceil(w/4) * ceil(h/4) 16-byte BC7 mode-6 blocks in raster order.  Lossy re-fit of the four ETC1S colours to 16 interpolation
+ * weights (endpoint error <= 1, inner colours to the nearest weight); gated by PSNR against the RGBA32 decode, not bit parity. */
+int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                        uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
+
 /* ---- decode path, geometry half ----
  * Replaces what the stock player obtains from the draco WASM decoder per frame (reference src/V2/player.ts:101, :313-336):
  * Draco 2.2 TRIANGULAR_MESH / valence-edgebreaker files with the attribute decoders of the fixtures (position, tex-coord,

@@ -87,3 +87,63 @@ def etc1_decode_blocks(blocks, width, height):
             base = np.where(second[..., None], base2, base1)
             out[y::4, x::4, :3] = np.clip(base + mod[..., None], 0, 255).astype(np.uint8)
     return out[:height, :width]
+
+
+def bc7_decode_blocks(blocks, width, height):
+    """Independent BC7 decoder for the two single-subset modes the BC7 transcode target emits (Khronos data-format spec, BPTC):
+    mode 5 (7-bit RGB endpoints, 8-bit alpha endpoints, 2-bit colour and alpha indices, rotation) and mode 6 (7-bit RGBA
+    endpoints + p-bits, 4-bit indices).  blocks [by, bx, 16] uint8 -> RGBA8 [height, width, 4]; other modes assert."""
+    W2 = np.array([0, 21, 43, 64], np.int64)
+    W4 = np.array([0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64], np.int64)
+    by, bx = blocks.shape[:2]
+    b = blocks.reshape(by, bx, 16).astype(np.uint64)
+    lo = np.zeros((by, bx), np.uint64); hi = np.zeros((by, bx), np.uint64)
+    for i in range(8):
+        lo |= b[..., i] << np.uint64(8 * i); hi |= b[..., 8 + i] << np.uint64(8 * i)
+
+    def bits(pos, n):
+        mask = np.uint64((1 << n) - 1)
+        if pos >= 64:
+            return ((hi >> np.uint64(pos - 64)) & mask).astype(np.int64)
+        v = lo >> np.uint64(pos)
+        if pos + n > 64:
+            v = v | (hi << np.uint64(64 - pos))
+        return (v & mask).astype(np.int64)
+
+    m5 = bits(0, 6) == 32; m6 = bits(0, 7) == 64
+    assert np.all(m5 | m6), "block is neither BC7 mode 5 nor mode 6"
+    out = np.zeros((by * 4, bx * 4, 4), np.uint8)
+    # mode 6
+    ep = np.zeros((by, bx, 4, 2), np.int64)
+    for c in range(4):
+        for k in range(2):
+            ep[..., c, k] = (bits(7 + 14 * c + 7 * k, 7) << 1) | bits(63 + k, 1)
+    pos = 65; px6 = []
+    for i in range(16):
+        n = 3 if i == 0 else 4
+        w = W4[bits(pos, n)][..., None]; pos += n
+        px6.append((ep[..., 0] * (64 - w) + ep[..., 1] * w + 32) >> 6)
+    # mode 5
+    assert np.all(bits(6, 2)[m5] == 0), "rotation not expected"
+    e5 = np.zeros((by, bx, 4, 2), np.int64)
+    for c in range(3):
+        for k in range(2):
+            v = bits(8 + 14 * c + 7 * k, 7); e5[..., c, k] = (v << 1) | (v >> 6)
+    e5[..., 3, 0] = bits(50, 8); e5[..., 3, 1] = bits(58, 8)
+    cpos = 66; apos = 97; px5 = []
+    for i in range(16):
+        n = 1 if i == 0 else 2
+        wc = W2[bits(cpos, n)][..., None]; wa = W2[bits(apos, n)]; cpos += n; apos += n
+        rgb = (e5[..., :3, 0] * (64 - wc) + e5[..., :3, 1] * wc + 32) >> 6
+        a = (e5[..., 3, 0] * (64 - wa) + e5[..., 3, 1] * wa + 32) >> 6
+        px5.append(np.concatenate([rgb, a[..., None]], axis=-1))
+    for i in range(16):
+        y, x = divmod(i, 4)
+        out[y::4, x::4] = np.where(m5[..., None], px5[i], px6[i]).astype(np.uint8)
+    return out[:height, :width]
+
+
+def psnr_rgb(a, b):
+    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+    mse = float(np.mean(d * d))
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)

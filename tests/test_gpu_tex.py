@@ -117,3 +117,20 @@ def test_gpu_texture_etc1_target(oracle, gpu_codec):
         blocks = gpu_codec.transcode_texture_segments_etc1([data])[0]
         for l in range(want.n_slices):
             assert np.array_equal(etc1_decode_blocks(blocks[l], want.width, want.height), want.images[l]), l
+
+
+@pytest.mark.gpu
+def test_gpu_texture_bc7_target(oracle, gpu_codec):
+    """BC7 transcode target on the GPU: mode-6 blocks, decoded independently, within the PSNR gate of the pinned RGBA decode."""
+    import os, synth
+    from conftest import GOLDEN
+    from helpers import bc7_decode_blocks, psnr_rgb
+    files = [open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read(), gpu_codec.encode_texture_segment(synth.texture_sequence(3, size=256, seed=8))]
+    for data, gate in zip(files, (48.0, 34.0)):
+        want = oracle.ktx2_decode(data)
+        blocks = gpu_codec.transcode_texture_segments_bc7([data])[0]
+        for l in range(want.n_slices):
+            got = bc7_decode_blocks(blocks[l], want.width, want.height)
+            assert np.all(got[..., 3] == 255)
+            err = np.abs(got[..., :3].astype(np.int32) - want.images[l][..., :3].astype(np.int32))
+            assert psnr_rgb(got, want.images[l]) > gate, (l, psnr_rgb(got, want.images[l]), err.max())

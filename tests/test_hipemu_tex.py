@@ -59,3 +59,24 @@ def test_hipemu_texture_etc1_target(oracle, hipemu_lib):
         for l in range(want.n_slices):
             assert np.array_equal(etc1_decode_blocks(blocks[l], want.width, want.height), want.images[l]), l
     cd.close()
+
+
+def test_hipemu_texture_bc7_target(oracle, hipemu_lib):
+    """BC7 transcode target (PSNR gate, not bit parity): mode-6 blocks decoded by an independent BC7 decoder
+    (tests/helpers.py) stay above 48 dB PSNR against the pinned RGBA decode on the reference fixture and above 34 dB on the synthetic noise segment
+    (its high-intensity blocks clamp differently per channel, which no single BC7 line can follow); alpha is exactly opaque."""
+    import os, synth, uvol
+    from conftest import GOLDEN
+    from helpers import bc7_decode_blocks, psnr_rgb
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    files = [open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read(), oracle.ktx2_encode(synth.texture_sequence(3, size=52, seed=5))]
+    for data, gate in zip(files, (48.0, 34.0)):
+        want = oracle.ktx2_decode(data)
+        blocks = cd.transcode_texture_segments_bc7([data])[0]
+        assert blocks.shape == (want.n_slices, (want.height + 3) // 4, (want.width + 3) // 4, 16)
+        for l in range(want.n_slices):
+            got = bc7_decode_blocks(blocks[l], want.width, want.height)
+            assert np.all(got[..., 3] == 255)
+            err = np.abs(got[..., :3].astype(np.int32) - want.images[l][..., :3].astype(np.int32))
+            assert psnr_rgb(got, want.images[l]) > gate, (l, psnr_rgb(got, want.images[l]), err.max())
+    cd.close()

@@ -369,6 +369,70 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_etc1(TexDecJob *jobs) {
   out[4] = (uint8_t)(msb >> 8); out[5] = (uint8_t)msb; out[6] = (uint8_t)(lsb >> 8); out[7] = (uint8_t)lsb;
 }
 
+// ---- K3'': BC7 target (what KTX2Loader picks on desktop GPUs, reference src/lib/KTX2Loader.js:591-689: astc, then bptc).  An ETC1S
+// block has four colours base + {-a, -b, +b, +a}, clamped per channel.  Two single-subset BC7 modes can hold them with the
+// darkest / brightest colour as endpoints: mode 5 (7-bit RGB endpoints widened by bit replication, 2-bit indices, weights
+// 0/21/43/64 - close to ETC1's inner colours at ~0.35 of the span, and exact for black and white; separate 8-bit alpha = 255)
+// and mode 6 (7-bit endpoints + p-bit, 4-bit indices; opaque alpha forces both p-bits to 1, so endpoints are odd values).
+// Each of the four colours takes the index closest in squared error over the three channels (clamping can bend the line,
+// hence the search); the block keeps the mode with the smaller error summed over its 16 pixels (ties: mode 5).  Not a
+// restatement of the basis transcoder's table-driven mode-5 path: the gate for this target is PSNR against the RGBA32 decode.
+// Bit layouts, LSB first.  Mode 5: 6 bits (1 << 5); rotation 2 (= 0); R0 R1 G0 G1 B0 B1, 7 bits each; A0 A1, 8 bits each;
+// colour indices 1 + 15 * 2 bits; alpha indices 1 + 15 * 2 bits (all 0).  Mode 6: 7 bits (1 << 6); R0 R1 G0 G1 B0 B1 A0 A1,
+// 7 bits each; P0 P1; indices 3 + 15 * 4 bits.  Pixel 0's index has its MSB implied 0: otherwise swap the endpoints and
+// complement the indices.  Pixels in raster order.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_bc7(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.z];
+  if (J.status != 0) return;
+  const uint32_t layer = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (layer >= J.layers || b >= J.bx * J.by) return;
+  const size_t o = (size_t)layer * J.bx * J.by + b;
+  const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
+  const int MODS[8][4] = { { -8, -2, 2, 8 }, { -17, -5, 5, 17 }, { -29, -9, 9, 29 }, { -42, -13, 13, 42 }, { -60, -18, 18, 60 }, { -80, -24, 24, 80 }, { -106, -33, 33, 106 }, { -183, -47, 47, 183 } };
+  const int W2[4] = { 0, 21, 43, 64 };
+  const int W4[16] = { 0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64 };
+  int col[4][3], lo7[3], hi7[3];
+  for (int c = 0; c < 3; c++) {
+    const int base = (e[c] << 3) | (e[c] >> 2);
+    for (int k = 0; k < 4; k++) { const int v = base + MODS[e[3] & 7][k]; col[k][c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    lo7[c] = col[0][c] >> 1; hi7[c] = col[3][c] >> 1;
+  }
+  uint32_t hist[4] = { 0, 0, 0, 0 };
+  for (int i = 0; i < 16; i++) hist[(sel >> (2 * i)) & 3u]++;
+  uint32_t idx5[4], idx6[4], err5 = 0, err6 = 0;
+  for (int k = 0; k < 4; k++) {
+    uint32_t b5 = 0, e5 = 0xffffffffu, b6 = 0, e6 = 0xffffffffu;
+    for (uint32_t w = 0; w < 4; w++) {
+      uint32_t err = 0;
+      for (int c = 0; c < 3; c++) { const int l = (lo7[c] << 1) | (lo7[c] >> 6), h = (hi7[c] << 1) | (hi7[c] >> 6), d = ((l * (64 - W2[w]) + h * W2[w] + 32) >> 6) - col[k][c]; err += (uint32_t)(d * d); }
+      if (err < e5) { e5 = err; b5 = w; }
+    }
+    for (uint32_t w = 0; w < 16; w++) {
+      uint32_t err = 0;
+      for (int c = 0; c < 3; c++) { const int d = (((2 * lo7[c] + 1) * (64 - W4[w]) + (2 * hi7[c] + 1) * W4[w] + 32) >> 6) - col[k][c]; err += (uint32_t)(d * d); }
+      if (err < e6) { e6 = err; b6 = w; }
+    }
+    idx5[k] = b5; idx6[k] = b6; err5 += hist[k] * e5; err6 += hist[k] * e6;
+  }
+  unsigned long long lo, hi = 0; int pos;
+  auto put = [&](unsigned long long v, int n) { if (pos < 64) { lo |= v << pos; if (pos + n > 64) hi |= v >> (64 - pos); } else hi |= v << (pos - 64); pos += n; };
+  if (err5 <= err6) {
+    const bool swap = idx5[sel & 3u] >= 2u;              // pixel 0 = selector bits 0..1 (x = 0, y = 0)
+    lo = 1ull << 5; pos = 8;
+    for (int c = 0; c < 3; c++) { put((unsigned)(swap ? hi7[c] : lo7[c]), 7); put((unsigned)(swap ? lo7[c] : hi7[c]), 7); }
+    put(255u, 8); put(255u, 8);
+    for (int i = 0; i < 16; i++) { uint32_t ix = idx5[(sel >> (2 * i)) & 3u]; if (swap) ix = 3u - ix; put(ix, i == 0 ? 1 : 2); }
+  } else {
+    const bool swap = idx6[sel & 3u] >= 8u;
+    lo = 1ull << 6; pos = 7;
+    for (int c = 0; c < 3; c++) { put((unsigned)(swap ? hi7[c] : lo7[c]), 7); put((unsigned)(swap ? lo7[c] : hi7[c]), 7); }
+    put(127u, 7); put(127u, 7); put(1u, 1); put(1u, 1);
+    for (int i = 0; i < 16; i++) { uint32_t ix = idx6[(sel >> (2 * i)) & 3u]; if (swap) ix = 15u - ix; put(ix, i == 0 ? 3 : 4); }
+  }
+  unsigned long long *out = (unsigned long long *)(J.out[layer] + 16 * (size_t)b);
+  out[0] = lo; out[1] = hi;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -451,7 +515,7 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   }
   const TexDecJob &J0 = T->hjobs[0];
   const size_t nbk = (size_t)J0.bx * J0.by, L = J0.layers;
-  const size_t layer_bytes = target == 1 ? nbk * 8 : (size_t)J0.width * J0.height * 4;        // target 1: ETC1 blocks, 0: RGBA8
+  const size_t layer_bytes = target == 1 ? nbk * 8 : (target == 2 ? nbk * 16 : (size_t)J0.width * J0.height * 4);   // 0: RGBA8, 1: ETC1 blocks, 2: BC7 blocks
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small: %zu < %zu", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   // per-segment workspace: codebooks, block indices, Huffman size / sorted arrays of 9 models
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -487,6 +551,7 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
     else DLAUNCH(k_tdec_slices, dim3((unsigned)n), dim3(64), lds_serial, dj); }
   { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes);
     if (target == 1) DLAUNCH(k_tdec_etc1, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
+    else if (target == 2) DLAUNCH(k_tdec_bc7, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
     else DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

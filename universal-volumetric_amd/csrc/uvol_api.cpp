@@ -161,6 +161,12 @@ int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *kt
   return tex_decode_segments(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 1);
 }
 
+int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return tex_decode_segments(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 2);
+}
+
 int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
   if (!ctx || !drc || !lens || n < 0 || !out) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);

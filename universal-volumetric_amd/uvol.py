@@ -38,7 +38,7 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
-           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
 
 
@@ -68,6 +68,7 @@ def load(path=None):
     for nm in ("uvol_decode_texture_segments", "uvol_decode_texture_segments_dev"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t]
     L.uvol_transcode_texture_segments_etc1.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
+    L.uvol_transcode_texture_segments_bc7.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -251,6 +252,18 @@ class Codec:
         rc = self.L.uvol_transcode_texture_segments_etc1(self.h, fp, ln, n, ptrs, bx * by * 8, 0)
         if rc != UVOL_OK:
             raise UvolError(f"transcode_texture_segments_etc1 rc={rc}: {self.error()}")
+        return outs
+
+    def transcode_texture_segments_bc7(self, files):
+        """files: list of .ktx2 bytes -> list (per segment) of [layers, by, bx, 16] uint8 arrays of BC7 mode-6 blocks (raster order)."""
+        files = [bytes(f) for f in files]
+        w, h, nl = self.ktx2_info(files[0]); n = len(files); bx, by = (w + 3) // 4, (h + 3) // 4
+        outs = [np.empty((nl, by, bx, 16), dtype=np.uint8) for _ in range(n)]
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files])
+        ptrs = (C.c_void_p * (n * nl))(*[outs[s][l].ctypes.data for s in range(n) for l in range(nl)])
+        rc = self.L.uvol_transcode_texture_segments_bc7(self.h, fp, ln, n, ptrs, bx * by * 16, 0)
+        if rc != UVOL_OK:
+            raise UvolError(f"transcode_texture_segments_bc7 rc={rc}: {self.error()}")
         return outs
 
     def decode_texture_segments_dev(self, files, dev_ptrs, layer_cap):
