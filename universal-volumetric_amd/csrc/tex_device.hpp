@@ -104,6 +104,35 @@ __device__ inline uint32_t t_eval_block(const uint32_t px[16], int c5r, int c5g,
   return tot;
 }
 
+// One 16x16x64 signed-i8 matrix-core tile (v_mfma_i32_16x16x64_i8): acc[r] += sum_k A[row][k] * B[k][col] with
+// row = 4 * (lane >> 4) + r, col = lane & 15.  Lane l supplies 16 k-values of A's row (l & 15) and 16 k-values of B's column
+// (l & 15), both for k-group (l >> 4); A and B use the same lane/byte -> k map, so a caller that builds both operands itself
+// only depends on the row / column / accumulator maps stated here.
+#ifdef HIPEMU
+__device__ inline void t_mfma_i8_16x16x64(const uint32_t a[4], const uint32_t b[4], int acc[4]) {
+  const int lane = hipemu_lane(), col = lane & 15, rg = lane >> 4;
+  const unsigned long long a01 = a[0] | ((unsigned long long)a[1] << 32), a23 = a[2] | ((unsigned long long)a[3] << 32);
+  const unsigned long long b01 = b[0] | ((unsigned long long)b[1] << 32), b23 = b[2] | ((unsigned long long)b[3] << 32);
+  bool ok;
+  for (int g = 0; g < 4; g++) {
+    const unsigned long long B0 = hipemu_wave_exchange(b01, col + 16 * g, &ok), B1 = hipemu_wave_exchange(b23, col + 16 * g, &ok);
+    for (int r = 0; r < 4; r++) {
+      const unsigned long long A0 = hipemu_wave_exchange(a01, 4 * rg + r + 16 * g, &ok), A1 = hipemu_wave_exchange(a23, 4 * rg + r + 16 * g, &ok);
+      int sum = 0;
+      for (int j = 0; j < 8; j++) sum += (int)(int8_t)(A0 >> (8 * j)) * (int)(int8_t)(B0 >> (8 * j)) + (int)(int8_t)(A1 >> (8 * j)) * (int)(int8_t)(B1 >> (8 * j));
+      acc[r] += sum;
+    }
+  }
+}
+#else
+typedef int t_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void t_mfma_i8_16x16x64(const uint32_t a[4], const uint32_t b[4], int acc[4]) {
+  const t_v4i va = { (int)a[0], (int)a[1], (int)a[2], (int)a[3] }, vb = { (int)b[0], (int)b[1], (int)b[2], (int)b[3] }, vc = { acc[0], acc[1], acc[2], acc[3] };
+  const t_v4i vd = __builtin_amdgcn_mfma_i32_16x16x64_i8(va, vb, vc, 0, 0, 0);
+  acc[0] = vd.x; acc[1] = vd.y; acc[2] = vd.z; acc[3] = vd.w;
+}
+#endif
+
 __device__ __forceinline__ void t_cell_coords(uint32_t cell, int x[4]) {
   x[0] = t_expand5((cell >> 10) & 31); x[1] = t_expand5((cell >> 5) & 31); x[2] = t_expand5(cell & 31); x[3] = t_inten((cell >> 15) & 7, 3);
 }

@@ -454,35 +454,88 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_centroids(TexJob *job) {
   for (int d = 0; d < 16; d++) v |= (uint32_t)((2 * (long long)V.stS[(size_t)k * 16 + d] + W) / (2 * W)) << (2 * d);
   J.scb[k] = v;
 }
-// assignment by true block SSE: the 16 per-texel error rows stay in registers (4 x u16 per u64)
+// assignment by true block SSE.  The SSE of item j under codebook entry i is sum_t E_j[t][sel_i(t)] = a 64-long dot product of
+// the item's per-texel error table (16 texels x 4 selector values, u16 each) with the entry's one-hot selector vector: a
+// nearest-codeword search, which is what the matrix cores are for.  The u16 errors go in as two signed-i8 planes (byte ^ 0x80,
+// i.e. byte - 128; every one-hot vector has exactly 16 ones, so starting the accumulator at 16 * 128 restores the true sum),
+// one v_mfma_i32_16x16x64_i8 per plane per (16 entries x 16 items) tile, exact in the i32 accumulators.  k = 4 * texel +
+// selector, lane (x, g) holds k-group g = texels 4g..4g+3 for both operands.  Each wave keeps 4 item tiles (64 items) in
+// registers and streams the codebook (one-hot rows in LDS, chunks of SA_CHUNK entries) past them; the running minimum is one
+// v_min_u32 on (sse << 11 | entry), which also gives the lowest entry among equal SSEs like the ascending scan it replaces.
+// Rows past nl repeat entry nl - 1 (same SSE, larger index: never selected).
+#define SA_CHUNK 512u
 __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_assign(TexJob *job) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[1];
-  __shared__ uint32_t scb[UVOL_BLOCK];
-  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  const bool live = i < V.n_items;
-  unsigned long long rows[16];
-  for (int t = 0; t < 16; t++) rows[t] = 0;
-  if (live) {
-    const uint32_t b = J.item[i], tup = J.ecb[J.bei[b]];
-    const uint32_t l = b / J.nb, r = b % J.nb;
-    uint32_t px[16]; t_load_block(J, l, r % J.bx, r / J.bx, px);
-    t_eval_block<false, true>(px, (int)((tup >> 10) & 31), (int)((tup >> 5) & 31), (int)(tup & 31), (int)(tup >> 15), nullptr, rows);
-  }
-  uint32_t bd = 0xffffffffu, bk = 0;
-  for (uint32_t k0 = 0; k0 < V.nl; k0 += UVOL_BLOCK) {
-    __syncthreads();
-    if (k0 + threadIdx.x < V.nl) scb[threadIdx.x] = J.scb[k0 + threadIdx.x];
-    __syncthreads();
-    const uint32_t kn = V.nl - k0 < UVOL_BLOCK ? V.nl - k0 : UVOL_BLOCK;
-    if (live) for (uint32_t k = 0; k < kn; k++) {
-      const uint32_t v = scb[k]; uint32_t d = 0;
-#pragma unroll
-      for (int t = 0; t < 16; t++) d += (uint32_t)((rows[t] >> (16 * ((v >> (2 * t)) & 3))) & 0xffffu);
-      if (d < bd) { bd = d; bk = k0 + k; }
+  if (blockIdx.x * UVOL_BLOCK >= V.n_items) return;
+  __shared__ uint32_t lds[SA_CHUNK * 16];                              // 32 KiB: item planes first, then code chunks
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, i = blockIdx.x * UVOL_BLOCK + tid;
+  {
+    unsigned long long rows[16];
+    for (int t = 0; t < 16; t++) rows[t] = 0;
+    if (i < V.n_items) {
+      const uint32_t b = J.item[i], tup = J.ecb[J.bei[b]];
+      const uint32_t l = b / J.nb, r = b % J.nb;
+      uint32_t px[16]; t_load_block(J, l, r % J.bx, r / J.bx, px);
+      t_eval_block<false, true>(px, (int)((tup >> 10) & 31), (int)((tup >> 5) & 31), (int)(tup & 31), (int)(tup >> 15), nullptr, rows);
+    }
+    // [wave][tile][plane][g][x][w]: what lane (x, g) reads back as one 16-byte fragment
+    const uint32_t tile = lane >> 4, x = lane & 15u;
+    for (int t = 0; t < 16; t++) {
+      const uint32_t lo32 = (uint32_t)rows[t], hi32 = (uint32_t)(rows[t] >> 32);
+      const uint32_t lo = (lo32 & 0xffu) | ((lo32 >> 8) & 0xff00u) | ((hi32 & 0xffu) << 16) | ((hi32 << 8) & 0xff000000u);
+      const uint32_t hi = ((lo32 >> 8) & 0xffu) | ((lo32 >> 16) & 0xff00u) | ((hi32 << 8) & 0xff0000u) | (hi32 & 0xff000000u);
+      const uint32_t g = (uint32_t)t >> 2, w = (uint32_t)t & 3u;
+      lds[((((wv * 4 + tile) * 2 + 0) * 4 + g) * 16 + x) * 4 + w] = lo ^ 0x80808080u;
+      lds[((((wv * 4 + tile) * 2 + 1) * 4 + g) * 16 + x) * 4 + w] = hi ^ 0x80808080u;
     }
   }
-  if (live) V.leaf[i] = bk;
+  __syncthreads();
+  uint32_t blo[4][4], bhi[4][4], best[4];
+  for (uint32_t tile = 0; tile < 4; tile++) {
+    const uint32_t o0 = (((wv * 4 + tile) * 2 + 0) * 64 + lane) * 4, o1 = (((wv * 4 + tile) * 2 + 1) * 64 + lane) * 4;
+    for (int w = 0; w < 4; w++) { blo[tile][w] = lds[o0 + w]; bhi[tile][w] = lds[o1 + w]; }
+    best[tile] = 0xffffffffu;
+  }
+  const uint32_t nl = V.nl;
+  for (uint32_t c0 = 0; c0 < nl; c0 += SA_CHUNK) {
+    const uint32_t cn = nl - c0 < SA_CHUNK ? nl - c0 : SA_CHUNK, ctn = (cn + 15u) >> 4;
+    __syncthreads();
+    // one-hot rows, [code tile][g][x][w]: word (g, w) of entry x = 1 << 8 * selector(texel 4g + w)
+    for (uint32_t idx = tid; idx < ctn * 256u; idx += UVOL_BLOCK) {
+      const uint32_t ct = idx >> 8, rem = idx & 255u, g = rem >> 6, x = (rem >> 2) & 15u, w = rem & 3u;
+      uint32_t k = c0 + ct * 16 + x; if (k >= nl) k = nl - 1;
+      lds[idx] = 1u << (8u * ((J.scb[k] >> (2u * (4u * g + w))) & 3u));
+    }
+    __syncthreads();
+    uint32_t kbr[4];                                                   // entry index of accumulator row r, kept as four registers
+    for (uint32_t r = 0; r < 4; r++) { kbr[r] = c0 + 4 * (lane >> 4) + r; UVOL_OPAQUE(kbr[r]); }
+    for (uint32_t ct = 0; ct < ctn; ct++) {
+      uint32_t a[4];
+      for (int w = 0; w < 4; w++) a[w] = lds[(ct * 64 + lane) * 4 + w];
+#pragma unroll
+      for (int tile = 0; tile < 4; tile++) {
+        int H[4] = { 2048, 2048, 2048, 2048 }, L[4] = { 2048, 2048, 2048, 2048 };
+        t_mfma_i8_16x16x64(a, bhi[tile], H);
+        t_mfma_i8_16x16x64(a, blo[tile], L);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          uint32_t d = ((uint32_t)H[r] << 8) + (uint32_t)L[r];
+          UVOL_OPAQUE(d);                                              // keep (H << 8) + L one v_lshl_add, then one v_lshl_or
+          const uint32_t key = (d << 11) | kbr[r];
+          best[tile] = key < best[tile] ? key : best[tile];
+        }
+      }
+      for (uint32_t r = 0; r < 4; r++) kbr[r] += 16;
+    }
+  }
+  for (uint32_t tile = 0; tile < 4; tile++) {
+    uint32_t m = best[tile], o;
+    o = __shfl_xor(m, 16); m = o < m ? o : m;
+    o = __shfl_xor(m, 32); m = o < m ? o : m;
+    const uint32_t it = blockIdx.x * UVOL_BLOCK + wv * 64 + tile * 16 + (lane & 15u);
+    if (lane < 16 && it < V.n_items) V.leaf[it] = m & 2047u;
+  }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_used(TexJob *job, int phase) {
   TJOB_OR_RETURN;

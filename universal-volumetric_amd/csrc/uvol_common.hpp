@@ -73,9 +73,12 @@
 #ifdef HIPEMU
 #define UVOL_LANE_ZERO() 0
 #define UVOL_READFIRST(v) (v)
+#define UVOL_OPAQUE(v) ((void)0)
 #else
 #define UVOL_LANE_ZERO() ((int)__builtin_amdgcn_mbcnt_lo(~0u, 0u))
 #define UVOL_READFIRST(v) (__builtin_amdgcn_readfirstlane((int)(v)))
+// empty asm the optimiser cannot look through: stops it re-associating across `v` (emits no instruction)
+#define UVOL_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
 
 // dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
