@@ -125,6 +125,14 @@ def main():
         """k passes over the batch.  Every stream (geometry sub-batch / texture share) runs its k passes back to back on its
         own host thread; with --lockstep all streams meet at a barrier after every pass instead.  --geo-stagger-ms delays
         geometry stream g by g * that much once, so that the streams' serial phases interleave instead of colliding."""
+        errors = []
+
+        def guarded(fn, *a):
+            try:
+                fn(*a)
+            except BaseException as e:          # a failed stream must fail the whole bench, not shrink the work silently
+                errors.append(e)
+
         def loop(fn, arg, delay):
             if delay > 0:
                 time.sleep(delay)
@@ -132,21 +140,27 @@ def main():
                 fn(arg)
         if args.lockstep:
             for _ in range(k):
-                th = [threading.Thread(target=run_geo, args=(gi,)) for gi in range(GS) if args.only != "tex"] + \
-                     [threading.Thread(target=run_tex, args=(ti,)) for ti in range(len(texs)) if args.only != "geo"]
+                th = [threading.Thread(target=guarded, args=(run_geo, gi)) for gi in range(GS) if args.only != "tex"] + \
+                     [threading.Thread(target=guarded, args=(run_tex, ti)) for ti in range(len(texs)) if args.only != "geo"]
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
         else:
-            th = [threading.Thread(target=loop, args=(run_geo, gi, gi * args.geo_stagger_ms * 1e-3)) for gi in range(GS) if args.only != "tex"] + \
-                 [threading.Thread(target=loop, args=(run_tex, ti, 0.0)) for ti in range(len(texs)) if args.only != "geo"]
+            th = [threading.Thread(target=guarded, args=(loop, run_geo, gi, gi * args.geo_stagger_ms * 1e-3)) for gi in range(GS) if args.only != "tex"] + \
+                 [threading.Thread(target=guarded, args=(loop, run_tex, ti, 0.0)) for ti in range(len(texs)) if args.only != "geo"]
             for t in th:
                 t.start()
             for t in th:
                 t.join()
+        if errors:
+            raise errors[0]
         out["ktx2"] = [k_ for ti in range(len(texs)) for k_ in out.get("ktx2_%d" % ti, [])]
         out["drc"] = [k_ for gi in range(GS) for k_ in out.get("drc_%d" % gi, [])]
+        if args.only != "tex" and (len(out["drc"]) != F or not all(len(d_) for d_ in out["drc"])):
+            raise RuntimeError("bench: %d of %d geometry frames encoded" % (len(out["drc"]), F))
+        if args.only != "geo" and (len(out["ktx2"]) != nseg or not all(len(k_) for k_ in out["ktx2"])):
+            raise RuntimeError("bench: %d of %d texture segments encoded" % (len(out["ktx2"]), nseg))
 
     def barrier():
         if world > 1:

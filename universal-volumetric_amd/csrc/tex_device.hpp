@@ -51,6 +51,7 @@ struct TexJob {
   uint32_t *hscratch;       // Huffman build scratch
   uint8_t *sec[3]; uint32_t sec_cap[3], sec_len[3];     // endpoints / selectors / tables bit sections
   uint8_t *slice[TEX_MAX_LAYERS]; uint32_t slice_cap, slice_len[TEX_MAX_LAYERS];
+  unsigned long long pack_off, pack_len;                 // this segment's sections + slices, concatenated, in the batch's packed output buffer
   unsigned long long slice_bits[TEX_MAX_LAYERS];
   uint32_t n_skipped;
 };

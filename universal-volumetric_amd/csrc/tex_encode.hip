@@ -990,15 +990,42 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_c(TexJob *job) {
 // ================================================================================================
 // host side (K13: container)
 // ================================================================================================
+// K13a: payload of every segment (3 table sections + L slices, the order they have in the container) -> one packed device
+// buffer, so that the batch leaves the GPU in ONE device-to-host copy (was 3 + L copies per segment: 1152 at 144 segments).
+__global__ void k_tex_pack_offsets(TexJob *job, int n_seg) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long off = 0;
+  for (int s = 0; s < n_seg; s++) {
+    TexJob &J = job[s];
+    unsigned long long len = 0;
+    if (J.status == 0) { for (int k = 0; k < 3; k++) len += J.sec_len[k]; for (uint32_t l = 0; l < J.L; l++) len += J.slice_len[l]; }
+    J.pack_off = off; J.pack_len = len; off += (len + 15ull) & ~15ull;
+  }
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tex_pack(TexJob *job, uint8_t *packed, unsigned long long cap) {
+  TJOB_OR_RETURN;
+  if (J.pack_off + J.pack_len > cap) return;                           // host re-checks and reports
+  uint8_t *dst = packed + J.pack_off;
+  const size_t stride = (size_t)gridDim.x * UVOL_BLOCK, t0 = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  for (uint32_t p = 0; p < 3 + J.L; p++) {
+    const uint8_t *src = p < 3 ? J.sec[p] : J.slice[p - 3]; const uint32_t len = p < 3 ? J.sec_len[p] : J.slice_len[p - 3];
+    for (size_t i = t0; i < len; i += stride) dst[i] = src[i];
+    dst += len;
+  }
+}
+
 struct TexState {
-  uvol_devbuf slab, layers, job;
+  uvol_devbuf slab, layers, job, packed;
   std::vector<TexJob> hjobs;
+  uint8_t *pinned = nullptr; size_t pinned_cap = 0;
 };
 int tex_create(uvol_ctx *ctx) { ctx->tex = new TexState(); return UVOL_OK; }
 void tex_destroy(uvol_ctx *ctx) {
   if (!ctx->tex) return;
   TexState *t = ctx->tex;
   if (t->slab.p) (void)hipFree(t->slab.p);
+  if (t->packed.p) (void)hipFree(t->packed.p);
+  if (t->pinned) (void)hipHostFree(t->pinned);
   if (t->layers.p) (void)hipFree(t->layers.p);
   if (t->job.p) (void)hipFree(t->job.p);
   delete t; ctx->tex = nullptr;
@@ -1199,8 +1226,33 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     TLAUNCH(k_pack_b, dim3(J.L), dim3(UVOL_BLOCK), 0, dj, bslots);
     TLAUNCH(k_pack_c, dim3(bslots, J.L), dim3(UVOL_BLOCK), 0, dj);
   }
+  // packed payloads: sections <= caps, slices <= slice_cap each; the bound below is what the workspace itself can hold
+  size_t pack_cap = 0;
+  { const TexJob &Jc = T->hjobs[0]; pack_cap = (((size_t)Jc.sec_cap[0] + Jc.sec_cap[1] + Jc.sec_cap[2] + (size_t)Jc.slice_cap * (size_t)n_layers) + 15) & ~(size_t)15; }
+  // typical output is ~1 % of that bound: start from 1/8 of it and grow on demand (checked after the copy of the job records)
+  size_t want_pack = std::max<size_t>(T->packed.cap, pack_cap * (size_t)n_seg / 8 + 4096);
+  if (int rc = uvol_ensure(ctx, T->packed, want_pack)) return rc;
+  { uvol_ctx::Scope sc(ctx, "tex.k13_pack", 0);
+    hipLaunchKernelGGL(k_tex_pack_offsets, dim3(1), dim3(64), 0, ctx->stream, dj, n_seg);
+    TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)T->packed.p, (unsigned long long)T->packed.cap); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexJob) * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  size_t packed_total = 0;
+  for (int s = 0; s < n_seg; s++) packed_total = std::max<size_t>(packed_total, (size_t)(T->hjobs[s].pack_off + ((T->hjobs[s].pack_len + 15ull) & ~15ull)));
+  if (packed_total > T->packed.cap) {                                  // rare: grow and gather again
+    if (int rc = uvol_ensure(ctx, T->packed, packed_total)) return rc;
+    TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)T->packed.p, (unsigned long long)T->packed.cap);
+    UVOL_HIP_CHECK(ctx, hipGetLastError());
+  }
+  if (packed_total > T->pinned_cap) {
+    if (T->pinned) (void)hipHostFree(T->pinned);
+    T->pinned = nullptr; T->pinned_cap = 0;
+    const size_t want = packed_total + packed_total / 4 + 4096;
+    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&T->pinned, want, hipHostMallocDefault));
+    T->pinned_cap = want;
+  }
+  if (packed_total) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->pinned, T->packed.p, packed_total, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
   // ---- K13: KTX2 containers ----
@@ -1234,10 +1286,9 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     while ((uint64_t)(p - out) < sgd_off) *p++ = 0;
     put16(p, (uint16_t)R.ne); put16(p, (uint16_t)R.ns); put32(p, R.sec_len[0]); put32(p, R.sec_len[1]); put32(p, R.sec_len[2]); put32(p, 0);
     { uint32_t off = 0; for (int l = 0; l < n_layers; l++) { put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, R.slice_len[l]); put32(p, 0); put32(p, 0); off += R.slice_len[l]; } }
-    for (int k = 0; k < 3; k++) { UVOL_HIP_CHECK(ctx, hipMemcpyAsync(p, R.sec[k], R.sec_len[k], hipMemcpyDeviceToHost, ctx->stream)); p += R.sec_len[k]; }
-    for (int l = 0; l < n_layers; l++) { UVOL_HIP_CHECK(ctx, hipMemcpyAsync(p, R.slice[l], R.slice_len[l], hipMemcpyDeviceToHost, ctx->stream)); p += R.slice_len[l]; }
+    if (R.pack_len != sgd_len - 20 - 20 * (uint64_t)n_layers + lvl_len) { ctx->set_error("texture segment %d: packed payload length mismatch", s); worst = UVOL_E_ENCODE; continue; }
+    memcpy(p, T->pinned + R.pack_off, (size_t)R.pack_len);            // sections then slices, already in container order
   }
-  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return worst;
 }
 
