@@ -186,11 +186,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
   int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
   uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
   int32_t *ring = which == 0 ? J.ring : nullptr;
-  int l = (int)c; bool closed = false; uint32_t guard = 0;
-  for (;;) { int nl = gt_swl(T, l); if (nl < 0) break; if (nl == (int)c) { closed = true; break; } l = nl; if (++guard > J.nc) { J.status = -22; return; } }
+  int l = (int)c, mn = (int)c, cnt = 1; bool closed = false; uint32_t guard = 0;                  // one swing: min id and size of a closed fan on the way
+  for (;;) { int nl = gt_swl(T, l); if (nl < 0) break; if (nl == (int)c) { closed = true; break; } l = nl; mn = l < mn ? l : mn; cnt++; if (++guard > J.nc) { J.status = -22; return; } }
   if (closed) {
-    int mn = (int)c, cnt = 0, a = (int)c;
-    do { mn = a < mn ? a : mn; cnt++; a = gt_swl(T, a); } while (a != (int)c && cnt <= (int)J.nc);
     vert[c] = mn;
     if ((int)c == mn) { vopen[mn] = 0; if (ring) ring[mn] = cnt; if (which == 0) atomicAdd(&J.nverts, 1u); }
   } else {
