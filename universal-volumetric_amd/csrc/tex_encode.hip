@@ -159,20 +159,25 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_zero(TexJob *job, int force) 
 // (leaf_base: the statistics of leaves [leaf_base, leaf_base + LCAP) — one pass per LCAP leaves of the codebook, so no
 //  leaf ever falls back to contended global atomics; a pass whose range is beyond the current leaf count returns at once)
 template <int DIM, int LCAP, typename CT>
-__global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force, uint32_t leaf_base) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force, uint32_t leaf_base, uint32_t lds_leaves) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[DIM == 4 ? 0 : 1];
   if ((V.done && !force) || V.nl <= leaf_base) return;
-  UVOL_DYN_SMEM(CT, lds);                       // [LCAP * (1 + 2*DIM)]
-  const uint32_t nl = V.nl - leaf_base, ncap = nl < (uint32_t)LCAP ? nl : (uint32_t)LCAP, stride = 1 + 2 * DIM;
+  UVOL_DYN_SMEM(CT, lds);                       // [lds_leaves * (1 + 2*DIM)], lds_leaves <= LCAP (round r has <= 2^r leaves)
+  const uint32_t nl = V.nl - leaf_base, pass = nl < (uint32_t)LCAP ? nl : (uint32_t)LCAP, ncap = pass < lds_leaves ? pass : lds_leaves, stride = 1 + 2 * DIM;
   for (uint32_t k = threadIdx.x; k < ncap * stride; k += UVOL_BLOCK) lds[k] = 0;
   __syncthreads();
   for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
     const uint32_t i = base + threadIdx.x;
     const bool todo = i < V.n_items;
     const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
-    if (!todo || l < leaf_base || l - leaf_base >= ncap) continue;          // other leaves: another pass
+    if (!todo || l < leaf_base || l - leaf_base >= pass) continue;          // other leaves: another pass
     int x[DIM]; unsigned long long w; vq_item<DIM>(J, i, x, w);
+    if (l - leaf_base >= ncap) {                                            // not expected (host sizes the LDS for the round): stay correct
+      atomicAdd(&V.stW[l], w);
+      for (int d = 0; d < DIM; d++) { atomicAdd(&V.stS[(size_t)l * DIM + d], w * (unsigned long long)x[d]); atomicAdd(&V.stQ[(size_t)l * DIM + d], w * (unsigned long long)(x[d] * x[d])); }
+      continue;
+    }
     CT *p = lds + (size_t)(l - leaf_base) * stride;
     atomicAdd(&p[0], (CT)w);
     for (int d = 0; d < DIM; d++) { atomicAdd(&p[1 + d], (CT)(w * (unsigned long long)x[d])); atomicAdd(&p[1 + DIM + d], (CT)(w * (unsigned long long)(x[d] * x[d]))); }
@@ -1089,12 +1094,14 @@ inline void put16(uint8_t *&p, uint16_t v) { memcpy(p, &v, 2); p += 2; }
 
 template <int DIM, int LCAP, typename CT>
 static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG, uint32_t kmax) {
-  const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   const unsigned kb = uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM);
   const unsigned sb = std::min<unsigned>(item_blocks, 512u);
   for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
     TLAUNCH((k_vq_zero<DIM>), dim3(kb), dim3(UVOL_BLOCK), 0, dj, 0);
-    for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(sb), dim3(UVOL_BLOCK), shmem, dj, 0, lb);
+    // every leaf splits at most once per round: round r has <= 2^r leaves, so early rounds need (and reserve) little LDS and
+    // no second pass - they fit next to the geometry walkers' bitmaps instead of waiting for a CU with 58 KB free
+    const uint32_t leaves_r = r < 20 ? std::min<uint32_t>(kmax, 1u << r) : kmax, lds_leaves = std::min<uint32_t>((uint32_t)LCAP, std::max<uint32_t>(leaves_r, 16u));
+    for (uint32_t lb = 0; lb < leaves_r; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(sb), dim3(UVOL_BLOCK), (size_t)lds_leaves * (1 + 2 * DIM) * sizeof(CT), dj, 0, lb, lds_leaves);
     TLAUNCH((k_vq_decide<DIM>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_apply<DIM>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_advance<DIM>), dim3(1), dim3(64), 0, dj);
@@ -1104,20 +1111,22 @@ template <int DIM, int LCAP, typename CT>
 static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG, uint32_t kmax) {
   const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   TLAUNCH((k_vq_zero<DIM>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM)), dim3(UVOL_BLOCK), 0, dj, 1);
-  for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1, lb);
+  for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1, lb, (uint32_t)LCAP);
 }
 
 // selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
 static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < 960u ? J.Kmax_s : 960u; }
 static inline unsigned sel_stat_blocks(const TexJob &J) { return std::max<unsigned>(512u, (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }
-static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force) {
-  const uint32_t lcap = sel_lcap(J);
+static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force, int round = -1) {
+  // round r of the tree build has <= 2^r leaves: reserve LDS for those only (leaves past the cap would still be counted, through
+  // global atomics)
+  const uint32_t lcap = (round >= 0 && round < 20) ? std::min<uint32_t>(sel_lcap(J), std::max<uint32_t>(1u << round, 16u)) : sel_lcap(J);
   TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
   TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap);
 }
 static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
   for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
-    run_sel_stats(ctx, dj, J, NSEG, 0);
+    run_sel_stats(ctx, dj, J, NSEG, 0, r);
     TLAUNCH((k_vq_decide<16>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_apply<16>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_advance<16>), dim3(1), dim3(64), 0, dj);
