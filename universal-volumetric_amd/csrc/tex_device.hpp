@@ -19,7 +19,7 @@
 #define TEX_MODEL_CAP (TEX_MAX_CODEBOOK + TEX_HS + 8)
 
 struct TexVQ {
-  uint32_t n_items, K, nl, done, m_round;
+  uint32_t n_items, K, nl, done, m_round, round_active;
   uint32_t *leaf;                          // [n_items]
   unsigned long long *stW, *stS, *stQ;     // [K], [K*DIM], [K*DIM]
   uint8_t *splittable, *chosen; int32_t *axis; long long *th, *prio; uint32_t *newidx;   // [K]

@@ -278,7 +278,7 @@ template <int DIM>
 __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[DIM == 4 ? 0 : 1];
-  if (V.done) return;
+  if (V.done) { if (threadIdx.x == 0) V.round_active = 0; return; }
   const uint32_t nl = V.nl, K = V.K;
   __shared__ uint32_t s_navail, s_carry;
   if (threadIdx.x == 0) { s_navail = 0; s_carry = 0; }
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job) {
   if (mine) atomicAdd(&s_navail, mine);
   __syncthreads();
   const uint32_t navail = s_navail;
-  if (navail == 0) { if (threadIdx.x == 0) V.done = 1; return; }
+  if (navail == 0) { if (threadIdx.x == 0) { V.done = 1; V.round_active = 0; } return; }
   const uint32_t room = K - nl, m = navail < room ? navail : room;
   for (uint32_t l = threadIdx.x; l < nl; l += UVOL_BLOCK) {
     uint8_t ch = V.splittable[l];
@@ -321,13 +321,17 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job) {
     if (threadIdx.x == 0) s_carry = c + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) { V.m_round = m; }
+  // the round's bookkeeping, formerly two more launches per round (k_vq_advance after the split, k_vq_zero before the next
+  // statistics pass): k_vq_apply keys on round_active, not on done, so the leaf count can advance here; the statistics
+  // have all been read above (every thread passed the barriers of the scan), so they are cleared for the next round here
+  if (threadIdx.x == 0) { V.m_round = m; V.round_active = 1; V.nl = nl + m; if (nl + m >= K) V.done = 1; }
+  for (uint32_t i = threadIdx.x; i < K * DIM; i += UVOL_BLOCK) { if (i < K) V.stW[i] = 0; V.stS[i] = 0; V.stQ[i] = 0; }
 }
 template <int DIM>
 __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_apply(TexJob *job) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[DIM == 4 ? 0 : 1];
-  if (V.done) return;
+  if (!V.round_active) return;
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (i >= V.n_items) return;
   const uint32_t l = V.leaf[i];
@@ -338,15 +342,6 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_apply(TexJob *job) {
     if ((long long)xv > V.th[l]) V.leaf[i] = V.newidx[l];
   }
 }
-template <int DIM>
-__global__ void __launch_bounds__(64) k_vq_advance(TexJob *job) {
-  TJOB_OR_RETURN;
-  TexVQ &V = J.vq[DIM == 4 ? 0 : 1];
-  if (threadIdx.x != 0 || V.done) return;
-  V.nl += V.m_round;
-  if (V.nl >= V.K) V.done = 1;
-}
-
 // endpoint Lloyd: cluster centroid -> legal (colour5, inten) tuple; nearest-entry reassignment
 __global__ void __launch_bounds__(UVOL_BLOCK) k_ep_entries(TexJob *job) {
   TJOB_OR_RETURN;
@@ -1092,44 +1087,50 @@ inline void put16(uint8_t *&p, uint16_t v) { memcpy(p, &v, 2); p += 2; }
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
   } while (0)
 
+// workgroups per segment of a statistics pass (grid-stride over the items, any count is correct): each one zeroes and flushes
+// its private LDS table, so a batch of many segments takes few per segment - 512 x 144 of them spent their time on that and
+// on waiting for LDS next to the geometry walkers
+static inline unsigned vq_stat_blocks(unsigned item_blocks, unsigned nseg) {
+  const unsigned per = std::max(32u, std::min(512u, 4096u / std::max(1u, nseg)));
+  return std::min(item_blocks, per);
+}
 template <int DIM, int LCAP, typename CT>
 static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG, uint32_t kmax) {
   const unsigned kb = uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM);
-  const unsigned sb = std::min<unsigned>(item_blocks, 512u);
+  const unsigned sb = vq_stat_blocks(item_blocks, NSEG);
+  TLAUNCH((k_vq_zero<DIM>), dim3(kb), dim3(UVOL_BLOCK), 0, dj, 0);                // later rounds: cleared by k_vq_decide
   for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
-    TLAUNCH((k_vq_zero<DIM>), dim3(kb), dim3(UVOL_BLOCK), 0, dj, 0);
     // every leaf splits at most once per round: round r has <= 2^r leaves, so early rounds need (and reserve) little LDS and
     // no second pass - they fit next to the geometry walkers' bitmaps instead of waiting for a CU with 58 KB free
     const uint32_t leaves_r = r < 20 ? std::min<uint32_t>(kmax, 1u << r) : kmax, lds_leaves = std::min<uint32_t>((uint32_t)LCAP, std::max<uint32_t>(leaves_r, 16u));
     for (uint32_t lb = 0; lb < leaves_r; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(sb), dim3(UVOL_BLOCK), (size_t)lds_leaves * (1 + 2 * DIM) * sizeof(CT), dj, 0, lb, lds_leaves);
     TLAUNCH((k_vq_decide<DIM>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_apply<DIM>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
-    TLAUNCH((k_vq_advance<DIM>), dim3(1), dim3(64), 0, dj);
   }
 }
 template <int DIM, int LCAP, typename CT>
 static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsigned NSEG, uint32_t kmax) {
   const size_t shmem = (size_t)LCAP * (1 + 2 * DIM) * sizeof(CT);
   TLAUNCH((k_vq_zero<DIM>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * DIM)), dim3(UVOL_BLOCK), 0, dj, 1);
-  for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(std::min<unsigned>(item_blocks, 512u)), dim3(UVOL_BLOCK), shmem, dj, 1, lb, (uint32_t)LCAP);
+  for (uint32_t lb = 0; lb < kmax; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(vq_stat_blocks(item_blocks, NSEG)), dim3(UVOL_BLOCK), shmem, dj, 1, lb, (uint32_t)LCAP);
 }
 
 // selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
 static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < 960u ? J.Kmax_s : 960u; }
-static inline unsigned sel_stat_blocks(const TexJob &J) { return std::max<unsigned>(512u, (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }
+static inline unsigned sel_stat_blocks(const TexJob &J, unsigned nseg) { return std::max<unsigned>(std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))), (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }   // >= NB / SEL_STATS_ITEMS: the 16-bit partial sums
 static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force, int round = -1) {
   // round r of the tree build has <= 2^r leaves: reserve LDS for those only (leaves past the cap would still be counted, through
   // global atomics)
   const uint32_t lcap = (round >= 0 && round < 20) ? std::min<uint32_t>(sel_lcap(J), std::max<uint32_t>(1u << round, 16u)) : sel_lcap(J);
-  TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
-  TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap);
+  if (force) TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
+  TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap);
 }
 static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
+  TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, 0);   // later rounds: cleared by k_vq_decide
   for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
     run_sel_stats(ctx, dj, J, NSEG, 0, r);
     TLAUNCH((k_vq_decide<16>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH((k_vq_apply<16>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
-    TLAUNCH((k_vq_advance<16>), dim3(1), dim3(64), 0, dj);
   }
 }
 
