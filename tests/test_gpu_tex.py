@@ -20,6 +20,23 @@ def test_gpu_flat_single_layer(oracle, gpu_codec):
     assert gpu_codec.encode_texture_segment(flat) == oracle.ktx2_encode(flat)
 
 
+def test_gpu_texture_edge_cases(oracle, gpu_codec):
+    """Same edge shapes as the shim test, on the GPU (the selector search runs on the matrix cores there): one block, ragged
+    sizes, flat, identical layers, two colours; and a batch mixing nothing but tiny segments."""
+    rng = np.random.default_rng(11)
+    def rgba(a):
+        a = np.asarray(a, np.uint8); out = np.full(a.shape[:2] + (4,), 255, np.uint8); out[..., :3] = a; return out
+    one_block = [rgba(rng.integers(0, 256, (4, 4, 3)))]
+    ragged = [rgba(rng.integers(0, 256, (13, 7, 3))) for _ in range(2)]
+    flat = [rgba(np.full((20, 20, 3), 77))]
+    same = [rgba(rng.integers(0, 256, (16, 24, 3)))] * 3
+    two = np.zeros((32, 32, 3), np.uint8); two[:, 16:] = (250, 10, 40); two_col = [rgba(two), rgba(two[:, ::-1])]
+    for name, tex in (("one_block", one_block), ("ragged", ragged), ("flat", flat), ("same", same), ("two_colour", two_col)):
+        assert gpu_codec.encode_texture_segment(tex) == oracle.ktx2_encode(tex), name
+    noise = [[rgba(rng.integers(0, 256, (64, 64, 3))) for _ in range(2)] for _ in range(3)]       # noise: codebooks at their caps
+    assert gpu_codec.encode_texture_segments(noise) == [oracle.ktx2_encode(t) for t in noise]
+
+
 def test_gpu_reference_texture_reencode(oracle, gpu_codec):
     """Real captured content (decoded reference segment, 1024^2 x 5): byte-exact vs oracle, fixture-like bpp."""
     ref = open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read()

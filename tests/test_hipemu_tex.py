@@ -11,6 +11,25 @@ def test_hipemu_texture_matches_oracle_bytes(oracle, hipemu_lib):
     cd.close()
 
 
+def test_hipemu_texture_edge_cases_match_oracle(oracle, hipemu_lib):
+    """Edge shapes of the encode path, bit-exact against the oracle: one 4x4 block, ragged sizes that need edge replication, a
+    flat image (one endpoint, one selector: codebooks of size 1), identical layers (every P-frame block skipped) and a
+    two-colour image (codebooks smaller than one matrix-core tile in the selector search)."""
+    import uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    rng = np.random.default_rng(11)
+    def rgba(a):
+        a = np.asarray(a, np.uint8); out = np.full(a.shape[:2] + (4,), 255, np.uint8); out[..., :3] = a; return out
+    one_block = [rgba(rng.integers(0, 256, (4, 4, 3)))]
+    ragged = [rgba(rng.integers(0, 256, (13, 7, 3))) for _ in range(2)]
+    flat = [rgba(np.full((20, 20, 3), 77))]
+    same = [rgba(rng.integers(0, 256, (16, 24, 3)))] * 3
+    two = np.zeros((32, 32, 3), np.uint8); two[:, 16:] = (250, 10, 40); two_col = [rgba(two), rgba(two[:, ::-1])]
+    for name, tex in (("one_block", one_block), ("ragged", ragged), ("flat", flat), ("same", same), ("two_colour", two_col)):
+        assert cd.encode_texture_segment(tex) == oracle.ktx2_encode(tex), name
+    cd.close()
+
+
 def test_hipemu_texture_decode_matches_oracle(oracle, hipemu_lib):
     """Decode path: the HIP ETC1S/BasisLZ decoder, through the shim, against the pinned oracle decoder —
     on the reference's own fixture (written by Basis Universal 1.16) and on this codec's output, ragged sizes included."""
