@@ -172,7 +172,8 @@ int uvol_profile_enable(uvol_ctx *ctx, int on);
 int uvol_profile_reset(uvol_ctx *ctx);
 /* Number of distinct kernel groups recorded so far. */
 int uvol_profile_count(uvol_ctx *ctx);
-/* name/launch-count/total-ms/algorithmic-bytes of group i. */
+/* name/launch-count/total-ms/algorithmic-bytes of group i (for the matrix-core sub-group tex.k10_sel_assign the last field
+ * counts integer multiply/add operations instead of bytes). */
 int uvol_profile_get(uvol_ctx *ctx, int i, char *name, size_t name_cap,
                      uint64_t *launches, double *total_ms, uint64_t *algo_bytes);
 

@@ -1201,7 +1201,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     for (int it = 0; it < 2; it++) {
       run_sel_stats(ctx, dj, J, NSEG, 1);
       TLAUNCH(k_sel_centroids, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
-      TLAUNCH(k_sel_assign, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
+      { uvol_ctx::Scope sc2(ctx, "tex.k10_sel_assign", 0); TLAUNCH(k_sel_assign, dim3(bNB), dim3(UVOL_BLOCK), 0, dj); }   // work (integer ops) added after the job read-back
     }
     TLAUNCH(k_sel_used, dim3(bK), dim3(UVOL_BLOCK), 0, dj, 0);
     TLAUNCH(k_sel_used, dim3(bNB), dim3(UVOL_BLOCK), 0, dj, 1);
@@ -1248,6 +1248,11 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexJob) * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->profiling) {            // matrix-core work of the two k_sel_assign launches: items x entries (padded to tiles of 16) x 64-long dot x 2 planes x 2 ops
+    uint64_t ops = 0;
+    for (int s = 0; s < n_seg; s++) { const TexVQ &V = T->hjobs[s].vq[1]; ops += 2ull * (uint64_t)V.n_items * (uint64_t)((V.nl + 15u) & ~15u) * 64ull * 2ull * 2ull; }
+    ctx->prof[ctx->prof_index("tex.k10_sel_assign")].algo_bytes += ops;
+  }
   size_t packed_total = 0;
   for (int s = 0; s < n_seg; s++) packed_total = std::max<size_t>(packed_total, (size_t)(T->hjobs[s].pack_off + ((T->hjobs[s].pack_len + 15ull) & ~15ull)));
   if (packed_total > T->packed.cap) {                                  // rare: grow and gather again
