@@ -58,7 +58,7 @@ struct GeoJob {
   uint32_t out_len;
   // ---- workspace ----
   uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3];
-  uint64_t *e_key; uint32_t *e_val; uint32_t e_cap;
+  uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
   int32_t *opp, *vert, *ring; uint8_t *vopen;

@@ -136,39 +136,58 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: opposite corners through a directed-edge hash table (key (a,b) -> min corner)
+// K3: opposite corners.  opp[c] = the lowest corner facing the reversed edge, if c itself is the lowest corner on its own
+// directed edge (a -> b) = (vertex of next(c), vertex of prev(c)); otherwise none.  Directed edges are bucketed by their
+// from-vertex (count -> scan -> fill), so a corner reads two short contiguous buckets (its own edge's and the reversed
+// edge's, ~valence entries each) out of a 4.8 MB array with the mesh's own locality - a 24 MB open-addressing hash table
+// of 64-bit keys did the same with 242 MB of scattered HBM traffic per frame, 29 % of the whole frame's (r01_i PMC passes).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t edge_key(uint32_t a, uint32_t b) { return ((uint64_t)(a + 1) << 32) | (uint64_t)(b + 1); }
-__global__ void __launch_bounds__(UVOL_BLOCK) k_edge_insert(GeoJob *jobs) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_he_count(GeoJob *jobs) {
   JOB_OR_RETURN;
-  uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (c >= J.nc) return;
-  uint64_t key = edge_key((uint32_t)J.cp[g_nxt(c)], (uint32_t)J.cp[g_prv(c)]);
-  uint32_t s = (uint32_t)g_mix64(key) & (J.e_cap - 1);
-  for (uint32_t guard = 0; guard <= J.e_cap; guard++) {
-    unsigned long long cur = J.e_key[s];
-    if (cur == 0) { unsigned long long old = atomicCAS((unsigned long long *)&J.e_key[s], 0ull, (unsigned long long)key); cur = old == 0 ? key : old; }
-    if (cur == key) { atomicMax(&J.e_val[s], 0xffffffffu - c); return; }
-    s = (s + 1) & (J.e_cap - 1);
-  }
-  J.status = -21;
+  atomicAdd(&J.he_start[(uint32_t)J.cp[g_nxt(c)]], 1u);
 }
-__device__ inline int edge_find(const GeoJob &J, uint64_t key) {
-  uint32_t s = (uint32_t)g_mix64(key) & (J.e_cap - 1);
-  for (uint32_t guard = 0; guard <= J.e_cap; guard++) {
-    uint64_t cur = J.e_key[s];
-    if (cur == 0) return -1;
-    if (cur == key) return (int)(0xffffffffu - J.e_val[s]);
-    s = (s + 1) & (J.e_cap - 1);
+// one workgroup per frame: exclusive scan of the per-vertex counts in place, cursor = start
+__global__ void __launch_bounds__(UVOL_BLOCK) k_he_scan(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  if (J.status != 0) return;
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const uint32_t n = J.n_pos;
+  for (uint32_t b0 = 0; b0 < n; b0 += UVOL_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < n ? J.he_start[i] : 0, tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    if (i < n) { J.he_start[i] = c + ex; J.he_cur[i] = c + ex; }
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
   }
-  return -1;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_he_fill(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c >= J.nc) return;
+  const uint32_t a = (uint32_t)J.cp[g_nxt(c)], b = (uint32_t)J.cp[g_prv(c)];
+  const uint32_t slot = atomicAdd(&J.he_cur[a], 1u);
+  J.he_ent[slot] = ((unsigned long long)b << 32) | (unsigned long long)c;
+}
+// lowest corner on the directed edge (from -> to), or -1; the order inside a bucket is arbitrary, the minimum is not
+__device__ __forceinline__ int he_find(const GeoJob &J, uint32_t from, uint32_t to) {
+  const uint32_t s = J.he_start[from], e = J.he_cur[from];
+  uint32_t best = 0xffffffffu;
+  for (uint32_t i = s; i < e; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == to) { const uint32_t cc = (uint32_t)v; best = cc < best ? cc : best; } }
+  return best == 0xffffffffu ? -1 : (int)best;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_edge_match(GeoJob *jobs) {
   JOB_OR_RETURN;
   uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (c >= J.nc) return;
   uint32_t a = (uint32_t)J.cp[g_nxt(c)], b = (uint32_t)J.cp[g_prv(c)];
-  int self = edge_find(J, edge_key(a, b)), o = edge_find(J, edge_key(b, a));
+  int self = he_find(J, a, b), o = he_find(J, b, a);
   J.opp[c] = (self == (int)c && o >= 0) ? o : GEO_INV;
 }
 
@@ -1321,8 +1340,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
     J.dd_cap[k] = pow2_at_least(2ull * n + 2);
     CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k]);
   }
-  J.e_cap = pow2_at_least(2ull * nc + 2);
-  CARVE(J.e_key, uint64_t, J.e_cap); CARVE(J.e_val, uint32_t, J.e_cap);
+  CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1);
   CARVE(J.fvis, uint8_t, nfi + 64); CARVE(J.vvis, uint8_t, nc + 64); CARVE(J.f2split, int32_t, 4);
   for (int t = 0; t < 3; t++) { CARVE(J.t_fvis[t], uint8_t, nfi + 64); CARVE(J.t_vvis[t], uint8_t, nc + 64); }
   for (int s = 0; s < GEO_NSTREAM; s++) {
@@ -1335,6 +1353,7 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
   *fill7f_bytes = ((C.off + 255) & ~(size_t)255) - *zero_bytes;
   // ---- the rest ----
   CARVE(J.canon[0], uint32_t, J.n_pos + 1); CARVE(J.canon[1], uint32_t, J.n_uv + 1); CARVE(J.canon[2], uint32_t, J.n_nrm + 1);
+  CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1); CARVE(J.he_ent, unsigned long long, nc + 1);
   CARVE(J.keep, uint8_t, nfi + 1); CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8); CARVE(J.bsum2, uint32_t, nc / UVOL_BLOCK + 8);
   CARVE(J.cp, int32_t, nc + 3); CARVE(J.cu, int32_t, nc + 3); CARVE(J.cn, int32_t, nc + 3);
   CARVE(J.opp, int32_t, nc + 3); CARVE(J.vert, int32_t, nc + 3); CARVE(J.ring, int32_t, nc + 3); CARVE(J.vopen, uint8_t, nc + 3);
@@ -1535,7 +1554,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k3_corner_table", (uint64_t)n * 0 + (uint64_t)3 * max_nfi * 4 * 3);
-    LAUNCH(k_edge_insert, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_he_count, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_he_scan, dim3(1, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_he_fill, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
