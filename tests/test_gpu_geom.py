@@ -116,6 +116,22 @@ def test_gpu_mesh_decode_matches_oracle(oracle, gpu_codec):
         _check_decoded(oracle, data, got)
 
 
+def test_gpu_traverse_vbits_l2_at_bench_size(oracle, gpu_codec):
+    """bench.py's default contexts keep the attribute traversers' vertex bitmaps in L2 (`traverse_vbits_l2`, workgroup-scope
+    loads next to atomic ORs): bit-identical to the LDS placement and to the oracle on 100k-vertex frames, several frames per
+    batch so that many traversers share an XCD's L2."""
+    import synth, uvol
+    frames = [synth.sphere_mesh(frame=k) for k in range(6)]
+    c2 = uvol.Codec(device=0, traverse_vbits_l2=1)
+    try:
+        got = c2.encode_mesh_batch(frames)
+    finally:
+        c2.close()
+    assert got == gpu_codec.encode_mesh_batch(frames)
+    f = frames[0]
+    assert got[0] == oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"))
+
+
 def test_gpu_mesh_roundtrip_at_bench_size(oracle, gpu_codec):
     """encode -> decode of a 100k-vertex / 200k-face frame: identical with the oracle decoder, and order-independent
     properties of the round trip: same bounding box within a quantisation step, same total surface area within 2 %,

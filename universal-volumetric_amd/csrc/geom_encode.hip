@@ -301,11 +301,12 @@ template <typename P> __device__ __forceinline__ uvol_i3 rec3(P rec, int code) {
 typedef int uvol_i3 __attribute__((ext_vector_type(3)));
 template <typename P> __device__ __forceinline__ uvol_i3 rec3(P rec, int code) { return *(UVOL_G(const uvol_i3))(rec + code); }
 #endif
-// bitmap words: LDS pointers read with ds_read; global pointers with a device-scope load that bypasses the per-CU L1,
-// because the bits are set with atomic ORs performed in L2 (a plain load could return a stale L1 line)
+// bitmap words: LDS pointers read with ds_read; global pointers with a workgroup-scope atomic load (sc0: not served from a
+// possibly stale per-CU L1 line - the bits are set with atomic ORs performed in L2 - but, unlike the device-scope load used
+// before, served by this XCD's L2 instead of the memory-side cache: one walker wave is the only reader and writer of its bitmap)
 __device__ __forceinline__ uint32_t pword(UVOL_L(uint32_t) w, int k) { return w[k]; }
 #ifndef HIPEMU
-__device__ __forceinline__ uint32_t pword(UVOL_G(uint32_t) w, int k) { return UVOL_ALOAD(&w[k]); }
+__device__ __forceinline__ uint32_t pword(UVOL_G(uint32_t) w, int k) { return __hip_atomic_load(&w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 template <typename P> __device__ __forceinline__ bool pbit_get(P w, int i) { return (pword(w, i >> 5) >> (i & 31)) & 1u; }
 template <typename P> __device__ __forceinline__ void pbit_set(P w, int i) { UVOL_OR_NORET(&w[i >> 5], 1u << (i & 31)); }   // fire and forget
