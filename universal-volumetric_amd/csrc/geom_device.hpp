@@ -65,7 +65,8 @@ struct GeoJob {
   uint8_t *fvis, *vvis; int32_t *vval, *c2vm, *f2split, *proc, *initc, *stack;
   int32_t *ev_src, *ev_spl; uint8_t *ev_edge;
   int32_t *rec[4]; uint8_t *symb, *ctx_of; int32_t *face_time;
-  uint8_t *dflag; int32_t *dtmp; uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // dense vertex ids per table
+  uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // dense vertex ids per table
+  uint8_t *dflagT[3]; int32_t *dtmpT[3]; uint32_t *bsumT[3];                                   // per-table scratch: tables 1..3 are renumbered by the same launches (grid z)
   uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
   uint8_t *start_bits;
   int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert; uint8_t *bopen;

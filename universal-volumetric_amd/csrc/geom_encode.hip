@@ -34,12 +34,12 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
 }
 
 // scan selectors
-enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3, SCAN_DENSE = 4 };
+enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3 };
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
 // register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
-__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return (sel == SCAN_KEEP || sel == SCAN_EVENTS) ? J.keep : (sel == SCAN_ELIG ? J.elig : (sel == SCAN_DENSE ? J.dflag : J.has_ori)); }
-__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : ((sel == SCAN_ELIG || sel == SCAN_DENSE) ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return (sel == SCAN_KEEP || sel == SCAN_EVENTS) ? J.keep : (sel == SCAN_ELIG ? J.elig : J.has_ori); }
+__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
   const uint8_t *flags = scan_flags(J, sel); const uint32_t n = scan_count(J, sel);
@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
   JOB_OR_RETURN;
   uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (c >= J.nc) return;
+  if (which < 0) which = -which + (int)blockIdx.z;       // -2 with gridDim.z = 2: both attribute tables in one launch
   // value-returning selects only (see the miscompile note at scan_flags)
   const int ai = which >= 2 ? which - 2 : 0;
   if (which >= 2 && (ai >= J.nad || !J.interior_seams[ai])) return;
@@ -235,34 +236,6 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 // numbered by an order-preserving scan and the table's corner->vertex array is rewritten in place.
 __device__ __forceinline__ bool dense_table_live(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return !(which >= 2 && (ai >= J.nad || !J.interior_seams[ai])); }
 __device__ __forceinline__ int32_t *dense_vert(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]); }
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense_flags(GeoJob *jobs, int which) {
-  JOB_OR_RETURN;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  J.dflag[c] = (dense_table_live(J, which) && dense_vert(J, which)[c] == (int32_t)c) ? 1 : 0;
-}
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense_assign(GeoJob *jobs, int which) {
-  GeoJob &J = jobs[blockIdx.y];
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  const bool live = J.status == 0 && c < J.nc;
-  uint32_t v = live ? J.dflag[c] : 0, tot;
-  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsum[blockIdx.x] : 0);
-  if (live && v) {
-    const int ai = which >= 2 ? which - 2 : 0;
-    const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
-    J.dtmp[c] = (int32_t)pos; J.vopen_d[which][pos] = vopen[c];
-    if (which == 0) J.ring_d[pos] = J.ring[c];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nverts_t[which] = J.bsum[uvol_blocks_dev(J.nc)];
-}
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense_apply(GeoJob *jobs, int which) {
-  JOB_OR_RETURN;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc || !dense_table_live(J, which)) return;
-  int32_t *vert = dense_vert(J, which);
-  vert[c] = J.dtmp[vert[c]];
-}
-
 // which: 0 old base table (edgebreaker), 1 new base, 2/3 attribute tables (DFS)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which) {
   JOB_OR_RETURN;
@@ -279,6 +252,80 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
     const int c = 3 * (int)f + k;
     r[k] = (seam && seam[c]) ? GEO_INV : opp[c];
     const int v = vert[c];
+    vc[k] = (v << 1) | (vopen[v] ? 1 : 0);
+  }
+  int4 *dst = reinterpret_cast<int4 *>(J.rec[which]) + 4 * (size_t)f;
+  for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
+  if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
+}
+
+// The same renumbering + record packing for up to three tables per launch (table = w0 + blockIdx.z, scratch per table): the
+// attribute stage was 18 launches of small kernels (5 per table + k_pack_faces), each of which waits its turn among the
+// kernels of the other contexts; now 4.  flags + block totals, totals scan, assign, apply + pack (a face's thread rewrites
+// its own three corner->vertex entries and packs them at once).
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_flags(GeoJob *jobs, int w0) {
+  GeoJob &J = jobs[blockIdx.y];
+  const int z = (int)blockIdx.z, which = w0 + z;
+  if (blockIdx.x >= uvol_blocks_dev(J.nc)) return;       // block-uniform exit
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && c < J.nc;
+  uint32_t v = (live && dense_table_live(J, which) && dense_vert(J, which)[c] == (int32_t)c) ? 1u : 0u, tot;
+  if (live) J.dflagT[z][c] = (uint8_t)v;
+  block_excl_scan(v, &tot);
+  if (threadIdx.x == 0) J.bsumT[z][blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_sums(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  uint32_t *bsum = J.bsumT[blockIdx.z];
+  const uint32_t nblocks = uvol_blocks_dev(J.nc);
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += UVOL_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < nblocks ? bsum[i] : 0, tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    if (i < nblocks) bsum[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[nblocks] = carry;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_assign(GeoJob *jobs, int w0) {
+  GeoJob &J = jobs[blockIdx.y];
+  const int z = (int)blockIdx.z, which = w0 + z;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && c < J.nc;
+  uint32_t v = live ? J.dflagT[z][c] : 0, tot;
+  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsumT[z][blockIdx.x] : 0);
+  if (live && v) {
+    const int ai = which >= 2 ? which - 2 : 0;
+    const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
+    J.dtmpT[z][c] = (int32_t)pos; J.vopen_d[which][pos] = vopen[c];
+    if (which == 0) J.ring_d[pos] = J.ring[c];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nverts_t[which] = J.bsumT[z][uvol_blocks_dev(J.nc)];
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_apply_pack(GeoJob *jobs, int w0) {
+  GeoJob &J = jobs[blockIdx.y];
+  if (J.status != 0) return;
+  const int z = (int)blockIdx.z, which = w0 + z;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (f >= J.nf || !dense_table_live(J, which)) return;
+  const int ai = which >= 2 ? which - 2 : 0;
+  const int32_t *opp = which == 0 ? J.opp : J.nopp;
+  const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
+  int32_t *vert = dense_vert(J, which);
+  const int32_t *dtmp = J.dtmpT[z];
+  const uint8_t *vopen = J.vopen_d[which];
+  int r[3], vc[3];
+  for (int k = 0; k < 3; k++) {
+    const int c = 3 * (int)f + k;
+    r[k] = (seam && seam[c]) ? GEO_INV : opp[c];
+    const int v = dtmp[vert[c]];
+    vert[c] = v;
     vc[k] = (v << 1) | (vopen[v] ? 1 : 0);
   }
   int4 *dst = reinterpret_cast<int4 *>(J.rec[which]) + 4 * (size_t)f;
@@ -1361,7 +1408,8 @@ size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_b
   CARVE(J.vval, int32_t, nc + nfi + 3); CARVE(J.c2vm, int32_t, nc + 3);
   CARVE(J.proc, int32_t, nfi + 1); CARVE(J.initc, int32_t, nfi + 1); CARVE(J.stack, int32_t, nfi + 2);
   for (int w = 0; w < 4; w++) { CARVE(J.rec[w], int32_t, 16 * (nfi + 1)); CARVE(J.vopen_d[w], uint8_t, nc + 3); }
-  CARVE(J.dflag, uint8_t, nc + 3); CARVE(J.dtmp, int32_t, nc + 3); CARVE(J.ring_d, int32_t, nc + 3);
+  CARVE(J.ring_d, int32_t, nc + 3);
+  for (int z = 0; z < 3; z++) { CARVE(J.dflagT[z], uint8_t, nc + 3); CARVE(J.dtmpT[z], int32_t, nc + 3); CARVE(J.bsumT[z], uint32_t, nc / UVOL_BLOCK + 8); }
   CARVE(J.symb, uint8_t, nfi + 64); CARVE(J.ctx_of, uint8_t, nfi + 64);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2); CARVE(J.ev_spl, int32_t, 2 * nfi + 2); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1);
@@ -1425,15 +1473,13 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
   } while (0)
 
-#define DENSE_TABLE(w)                                                               \
-  do {                                                                               \
-    LAUNCH(k_dense_flags, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));              \
-    LAUNCH(k_scan_blocks, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)SCAN_DENSE);       \
-    LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_DENSE);          \
-    LAUNCH(k_dense_assign, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));             \
-    LAUNCH(k_dense_apply, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)(w));              \
+#define DENSE_PACK(w0, nz)                                                                        \
+  do {                                                                                            \
+    LAUNCH(k_dense3_flags, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                   \
+    LAUNCH(k_dense3_sums, dim3(1, N, (nz)), dim3(UVOL_BLOCK), dj);                                \
+    LAUNCH(k_dense3_assign, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                  \
+    LAUNCH(k_dense3_apply_pack, dim3(bf, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));              \
   } while (0)
-
 // zero the hash tables / visited maps / histograms at the head of every job's workspace
 __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
@@ -1564,8 +1610,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   size_t walk_lds = 0; int walk_vcw = 0;
   const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &walk_vcw);
   {
-    DENSE_TABLE(0);
-    LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, 0);
+    DENSE_PACK(0, 1);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw);
     else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj, 0);
@@ -1593,11 +1638,10 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_scan_blocks, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
     LAUNCH(k_seam_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 2);
-    LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 3);
+    LAUNCH(k_fans, dim3(bc, N, 2), dim3(UVOL_BLOCK), dj, -2);
   }
   {
-    for (int w = 1; w <= 3; w++) { DENSE_TABLE(w); LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w); }
+    DENSE_PACK(1, 3);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): the traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
