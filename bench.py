@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
-    ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames kept in HBM and cycled")
+    ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames whose content is cycled")
+    ap.add_argument("--shared-inputs", action="store_true", help="DIAGNOSTIC: all frames read the same --distinct input buffers / one texture segment (as before r01_k)")
     ap.add_argument("--geo-streams", type=int, default=3, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,8 +82,12 @@ def main():
     V, Fc = len(meshes_h[0]["pos"]), len(meshes_h[0]["idx_pos"]) // 3
     keep = []
     dev_meshes = []
-    for m in meshes_h:
-        t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in m.items()}
+    # every frame of the step has its OWN input buffers in HBM (content cycles through the --distinct synthetic frames): no
+    # frame finds its inputs in a cache because another frame of the batch read the same addresses
+    base_t = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in m.items()} for m in meshes_h]
+    for i in range(F if not args.shared_inputs else args.distinct):
+        m = meshes_h[i % args.distinct]
+        t = base_t[i % args.distinct] if i < args.distinct else {k: v.clone() for k, v in base_t[i % args.distinct].items()}
         keep.append(t)
         mm = uvol.Mesh()
         mm.pos = t["pos"].data_ptr(); mm.n_pos = len(m["pos"]); mm.uv = t["uv"].data_ptr(); mm.n_uv = len(m["uv"])
@@ -92,6 +97,14 @@ def main():
         dev_meshes.append(mm)
     tex_d = [torch.from_numpy(a).to(dev) for a in tex_h]
     tex_ptrs = [t.data_ptr() for t in tex_d]
+    # texture segments: own buffers AND own content per segment (the base segment shifted by whole 4x4 blocks along x)
+    tex_seg_ptrs = []
+    for s_ in range(nseg):
+        if args.shared_inputs or s_ == 0:
+            tex_seg_ptrs += tex_ptrs
+        else:
+            seg = [torch.roll(t, shifts=(4 * s_) % args.tex_size, dims=1).contiguous() for t in tex_d]
+            keep.append(seg); tex_seg_ptrs += [t.data_ptr() for t in seg]
     torch.cuda.synchronize()
 
     cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
@@ -110,7 +123,7 @@ def main():
     host_frames = [meshes_h[i % args.distinct] for i in range(F)]
 
     gsl = [(gi * F // GS, (gi + 1) * F // GS) for gi in range(GS)]
-    gbatches = [(uvol.Mesh * (b - a))(*[dev_meshes[i % args.distinct] for i in range(a, b)]) for a, b in gsl]
+    gbatches = [(uvol.Mesh * (b - a))(*[dev_meshes[i % len(dev_meshes)] for i in range(a, b)]) for a, b in gsl]
 
     def run_geo(gi):
         a, b = gsl[gi]
@@ -121,7 +134,8 @@ def main():
         if args.host_inputs:
             out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([tex_h] * mine) if mine else []
         else:
-            out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev(tex_ptrs * mine, B, args.tex_size, args.tex_size) if mine else []
+            segs = range(ti, nseg, len(texs))
+            out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev([p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]], B, args.tex_size, args.tex_size) if mine else []
 
     def steps(k):
         """k passes over the batch.  Every stream (geometry sub-batch / texture share) runs its k passes back to back on its
@@ -214,7 +228,8 @@ def main():
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else "") + (" DIAGNOSTIC %s only" % args.only if args.only else ""),
             "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
-                                   "%d frames per step, qp11/qt10/qn8/cl7" % (V, Fc, args.tex_size, args.tex_size, B, F),
+                                   "%d frames per step, qp11/qt10/qn8/cl7; %s" % (V, Fc, args.tex_size, args.tex_size, B, F,
+                                   "DIAGNOSTIC shared input buffers" if args.shared_inputs else "every frame / segment reads its own input buffers in HBM"),
                        "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
                        "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
