@@ -1180,9 +1180,9 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     TLAUNCH(k_tscan_b, dim3(1), dim3(UVOL_BLOCK), 0, dj, bcell);
     TLAUNCH(k_cell_compact, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
     TLAUNCH(k_cell_leaf_init, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
-    run_vq_rounds<4, 800, unsigned long long>(ctx, dj, bcell, NSEG, J.Kmax_e);
+    run_vq_rounds<4, 256, unsigned long long>(ctx, dj, bcell, NSEG, J.Kmax_e);
     for (int it = 0; it <= 2; it++) {
-      run_vq_stats<4, 800, unsigned long long>(ctx, dj, bcell, NSEG, J.Kmax_e);
+      run_vq_stats<4, 256, unsigned long long>(ctx, dj, bcell, NSEG, J.Kmax_e);
       TLAUNCH(k_ep_entries, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
       if (it < 2) TLAUNCH(k_ep_assign, dim3(bcell), dim3(UVOL_BLOCK), 0, dj);
     }
