@@ -193,16 +193,17 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force,
 }
 // Selector-vector statistics (DIM 16, unit weights).  The host bounds the items one workgroup visits by SEL_STATS_ITEMS,
 // so every per-workgroup partial sum fits 16 bits (count <= 6144, S <= 3 * 6144, Q <= 9 * 6144 = 55296): two counters
-// share an LDS word, 17 words per leaf {W|S0, S1|S2, ... , Q15|-}, and lcap = min(Kmax_s, 960) leaves (<= 64 KiB) are
-// privatised — at the default quality (768 leaves) no selector statistic ever touches a global atomic in the item loop.
+// share an LDS word, 17 words per leaf {W|S0, S1|S2, ... , Q15|-}.  One pass privatises the lcap <= 256 leaves from leaf_base
+// (17 KiB of LDS: a workgroup finds room on a CU whose LDS is mostly held by the geometry walkers' bitmaps; with 52 KiB for
+// all 768 leaves the kernel waited for LDS 3-4x longer than it ran); the host runs one pass per 256 leaves the round can have.
 // field f: 0 = W, 1..16 = S[f-1], 17..32 = Q[f-17];  word = f >> 1, half = f & 1.
 #define SEL_STATS_ITEMS 6144
-__global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force, uint32_t lcap) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force, uint32_t lcap, uint32_t leaf_base) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[1];
-  if (V.done && !force) return;
-  UVOL_DYN_SMEM(uint32_t, lds);                 // [lcap * 17]
-  const uint32_t nl = V.nl, ncap = nl < lcap ? nl : lcap;
+  if ((V.done && !force) || V.nl <= leaf_base) return;
+  UVOL_DYN_SMEM(uint32_t, lds);                 // [lcap * 17]: the leaves [leaf_base, leaf_base + lcap) of this pass
+  const uint32_t nl = V.nl - leaf_base, ncap = nl < lcap ? nl : lcap;
   for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) lds[k] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
@@ -210,6 +211,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force
     const uint32_t i = base + threadIdx.x;
     bool todo = i < V.n_items;
     const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
+    todo = todo && l - leaf_base < ncap;                                   // leaves outside this pass's window: another pass
     // while the wave's items sit in few leaves (always in the early rounds, mostly later: neighbouring blocks look
     // alike) count with ballots — c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 — and let 33 lanes
     // post one add each; whatever is left after 4 leaders takes the per-item path.
@@ -217,8 +219,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force
     unsigned long long rem = __ballot(todo);
     for (int rounds = 0; rounds < 4 && rem; rounds++) {
       const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
-      const uint32_t ll = UVOL_READLANE(l, leader);
-      const bool inm = todo && l == ll;
+      const uint32_t ll = UVOL_READLANE(l, leader) - leaf_base;          // >= ncap (incl. wrapped): another pass counts that leaf
+      const bool inm = todo && l - leaf_base == ll;
       const unsigned long long m = __ballot(inm);
       uint32_t myv = 0;
       for (int d = 0; d < 16; d++) {
@@ -228,18 +230,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force
         if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
       }
       if (lane == 0) myv = (uint32_t)__popcll(m);
-      if (lane < 33 && myv) {
-        if (ll < ncap) atomicAdd(&lds[ll * 17 + (lane >> 1)], myv << ((lane & 1) * 16));
-        else if (lane == 0) atomicAdd(&V.stW[ll], (unsigned long long)myv);
-        else if (lane <= 16) atomicAdd(&V.stS[(size_t)ll * 16 + (lane - 1)], (unsigned long long)myv);
-        else atomicAdd(&V.stQ[(size_t)ll * 16 + (lane - 17)], (unsigned long long)myv);
-      }
+      if (lane < 33 && myv && ll < ncap) atomicAdd(&lds[ll * 17 + (lane >> 1)], myv << ((lane & 1) * 16));
       rem &= ~m;
       if (inm) todo = false;
     }
-    if (!todo) continue;
-    if (l < ncap) {
-      uint32_t *p = lds + (size_t)l * 17;
+    if (!todo || l - leaf_base >= ncap) continue;                        // other passes' leaves
+    {
+      uint32_t *p = lds + (size_t)(l - leaf_base) * 17;
       uint32_t prev = 1;                                                   // field 0: W += 1
       for (int d = 0; d < 16; d++) {                                       // fields 1..16: S
         const uint32_t xv = (sw >> (2 * d)) & 3u;
@@ -252,18 +249,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force
         if (v) atomicAdd(&p[9 + (d >> 1)], v);
       }
       { const uint32_t a = (sw >> 30) & 3u; if (a) atomicAdd(&p[16], a * a); }
-    } else {
-      atomicAdd(&V.stW[l], 1ull);
-      for (int d = 0; d < 16; d++) {
-        const unsigned long long xv = (sw >> (2 * d)) & 3u;
-        if (xv) { atomicAdd(&V.stS[(size_t)l * 16 + d], xv); atomicAdd(&V.stQ[(size_t)l * 16 + d], xv * xv); }
-      }
     }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) {
     const uint32_t v = lds[k]; if (!v) continue;
-    const uint32_t l = k / 17, w = k % 17;
+    const uint32_t l = leaf_base + k / 17, w = k % 17;
     for (int h = 0; h < 2; h++) {
       const unsigned long long part = h ? (v >> 16) : (v & 0xffffu); if (!part) continue;
       const uint32_t f = 2 * w + (uint32_t)h;
@@ -1116,14 +1107,15 @@ static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsign
 }
 
 // selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
-static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < 960u ? J.Kmax_s : 960u; }
+static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < 256u ? J.Kmax_s : 256u; }   // leaves per pass: 17 KiB of LDS, placeable next to the geometry walkers' bitmaps
 static inline unsigned sel_stat_blocks(const TexJob &J, unsigned nseg) { return std::max<unsigned>(std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))), (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }   // >= NB / SEL_STATS_ITEMS: the 16-bit partial sums
 static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force, int round = -1) {
   // round r of the tree build has <= 2^r leaves: reserve LDS for those only (leaves past the cap would still be counted, through
   // global atomics)
-  const uint32_t lcap = (round >= 0 && round < 20) ? std::min<uint32_t>(sel_lcap(J), std::max<uint32_t>(1u << round, 16u)) : sel_lcap(J);
+  const uint32_t leaves = (round >= 0 && round < 20) ? std::min<uint32_t>(J.Kmax_s, std::max<uint32_t>(1u << round, 16u)) : J.Kmax_s;
+  const uint32_t lcap = std::min<uint32_t>(sel_lcap(J), leaves);
   if (force) TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
-  TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap);
+  for (uint32_t lb = 0; lb < leaves; lb += lcap) TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap, lb);
 }
 static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
   TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, 0);   // later rounds: cleared by k_vq_decide
