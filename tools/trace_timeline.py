@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV as a per-stream timeline of the last bench step (diagnostic)."""
-import csv, sys, glob, re
+import csv, sys, glob, re, os
+THRESH = float(os.environ.get("TL_THRESH_MS", "0.8")) * 1e6
 f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/trace_r01/*/*kernel_trace.csv"))[-1]
 rows = list(csv.DictReader(open(f)))
 for r in rows:
@@ -26,4 +27,4 @@ for k, rs in bystream.items():
         if out and out[-1][0] == r["n"] and r["s"] - out[-1][2] < 2e6: out[-1][2] = r["e"]; out[-1][3] += 1
         else: out.append([r["n"], r["s"], r["e"], 1])
     for n, s, e, c in out:
-        if (e - s) > 0.8e6 or c > 20: print("   %8.1f -> %8.1f  (%7.1f ms) x%-4d %s" % ((s - T0) / 1e6, (e - T0) / 1e6, (e - s) / 1e6, c, n))
+        if (e - s) > THRESH or c > 20: print("   %8.1f -> %8.1f  (%7.1f ms) x%-4d %s" % ((s - T0) / 1e6, (e - T0) / 1e6, (e - s) / 1e6, c, n))

@@ -10,6 +10,7 @@
 //
 // There is no MFMA here by design: the path is integer/byte work bounded by dependent-load latency
 // (walkers) and HBM/L2 bandwidth (parallel stages).
+#include <chrono>
 #include "uvol_common.hpp"
 #include "geom_device.hpp"
 #include <algorithm>
@@ -1524,6 +1525,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   GeoState *G = ctx->geo;
   if (n <= 0) return UVOL_OK;
+  static const bool timing = [] { const char *e = getenv("UVOL_TIMING"); return e && *e == '1'; }();       // diagnostic: host-side phases of a batch on stderr
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   const uvol_params &prm = ctx->prm;
   if (prm.q_position_attr < 1 || prm.q_position_attr > 16 || prm.q_texture_attr < 1 || prm.q_texture_attr > 16 ||
       prm.q_normal_attr < 2 || prm.q_normal_attr > 16) { ctx->set_error("quantization bits out of supported range (1..16)"); return UVOL_E_UNSUPPORTED; }
@@ -1686,8 +1690,10 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_gather, dim3(64, GEO_MAXPIECES, N), dim3(UVOL_BLOCK), dj);
   }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
+  const double t_enq = ms_since(t_enter);
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->hjobs.data(), dj, sizeof(GeoJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const double t_gpu = ms_since(t_enter);
   int worst = UVOL_OK;
   // one device-to-host copy of the packed bitstreams into pinned staging, then plain memcpy into the caller's buffers
   size_t packed = 0;
@@ -1703,6 +1709,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->pinned, G->outs.p, packed, hipMemcpyDeviceToHost, ctx->stream));
     UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
+  const double t_d2h = ms_since(t_enter);
   for (int i = 0; i < n; i++) {
     const GeoJob &J = G->hjobs[i];
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
@@ -1712,5 +1719,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     if (status) status[i] = st;
   }
   ctx->resolve_profile();
+  if (timing) fprintf(stderr, "[uvol-timing] geo batch n=%d sizeof(GeoJob)=%zu: enqueued %.1f ms, gpu done %.1f, packed d2h %.1f, copied out %.1f (enter at %.1f)\n", n, sizeof(GeoJob), t_enq, t_gpu, t_d2h, ms_since(t_enter),
+                      std::chrono::duration<double, std::milli>(t_enter.time_since_epoch()).count());
   return status ? UVOL_OK : worst;
 }
