@@ -97,8 +97,8 @@ def test_gpu_walker_bitmap_placements(oracle):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
-    for force in ("", "vglobal", "global"):
-        env = dict(os.environ, UVOL_WALK_FORCE=force)
+    for force in ("", "vglobal", "global", "rec16"):            # rec16: 16-byte corner records (meshes with >= 2^18 faces), see the shim test
+        env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else dict(os.environ, UVOL_WALK_FORCE=force)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (force, r.stdout[-500:], r.stderr[-1500:])
 

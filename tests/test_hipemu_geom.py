@@ -55,11 +55,12 @@ def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
         c2.close()
 
 
-@pytest.mark.parametrize("force", ["vglobal", "global"])
+@pytest.mark.parametrize("force", ["vglobal", "global", "rec16"])
 def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
     """Visited bitmaps in LDS (default, covered above), vertex bitmap in global memory (a table with more vertices than
-    the LDS slot), everything in global memory (mesh too large for LDS): same bytes.  UVOL_WALK_FORCE is read once per
-    process, hence the fresh interpreter."""
+    the LDS slot), everything in global memory (mesh too large for LDS): same bytes.  "rec16": the 16-byte corner records
+    that batches with >= 2^18 faces per mesh use instead of the packed 8-byte ones (UVOL_REC16=1).  The switches are read
+    once per process, hence the fresh interpreter."""
     import subprocess, sys, os
     from conftest import ROOT
     code = (
@@ -71,7 +72,8 @@ def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_WALK_FORCE=force), capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else dict(os.environ, UVOL_WALK_FORCE=force)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 

@@ -237,8 +237,21 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 // numbered by an order-preserving scan and the table's corner->vertex array is rewritten in place.
 __device__ __forceinline__ bool dense_table_live(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return !(which >= 2 && (ai >= J.nad || !J.interior_seams[ai])); }
 __device__ __forceinline__ int32_t *dense_vert(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]); }
+// the three records of face f (r[k] = opposite corner of corner k, vc[k] = vertex << 1 | open) in either format
+__device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, const int vc[3], const int r[3], int r8) {
+  if (r8) {
+    uint2 *dst = reinterpret_cast<uint2 *>(rec) + 4 * (size_t)f;
+    for (int k = 0; k < 3; k++) {
+      const uint32_t R = (uint32_t)code_of_corner(r[(k + 1) % 3]) & 0x1fffffu, L = (uint32_t)code_of_corner(r[(k + 2) % 3]) & 0x1fffffu;
+      dst[k] = make_uint2(((uint32_t)vc[k] & 0x1fffffu) | (R << 21), (R >> 11) | (L << 10));
+    }
+  } else {
+    int4 *dst = reinterpret_cast<int4 *>(rec) + 4 * (size_t)f;
+    for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
+  }
+}
 // which: 0 old base table (edgebreaker), 1 new base, 2/3 attribute tables (DFS)
-__global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which, int r8) {
   JOB_OR_RETURN;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (f >= J.nf) return;
@@ -255,8 +268,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
     const int v = vert[c];
     vc[k] = (v << 1) | (vopen[v] ? 1 : 0);
   }
-  int4 *dst = reinterpret_cast<int4 *>(J.rec[which]) + 4 * (size_t)f;
-  for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
+  pack_face_records(J.rec[which], f, vc, r, r8);
   if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
 
@@ -309,7 +321,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_assign(GeoJob *jobs, int 
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nverts_t[which] = J.bsumT[z][uvol_blocks_dev(J.nc)];
 }
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_apply_pack(GeoJob *jobs, int w0) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_apply_pack(GeoJob *jobs, int w0, int r8) {
   GeoJob &J = jobs[blockIdx.y];
   if (J.status != 0) return;
   const int z = (int)blockIdx.z, which = w0 + z;
@@ -329,8 +341,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_apply_pack(GeoJob *jobs, 
     vert[c] = v;
     vc[k] = (v << 1) | (vopen[v] ? 1 : 0);
   }
-  int4 *dst = reinterpret_cast<int4 *>(J.rec[which]) + 4 * (size_t)f;
-  for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
+  pack_face_records(J.rec[which], f, vc, r, r8);
   if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
 
@@ -362,14 +373,46 @@ __device__ __forceinline__ int code_nxt(int x) { return (x & 3) == 2 ? x - 2 : x
 __device__ __forceinline__ int code_prv(int x) { return (x & 3) == 0 ? x + 2 : x - 1; }
 __device__ __forceinline__ int corner_of_code(int x) { return 3 * (x >> 2) + (x & 3); }
 
+// Corner records in two formats.  R8 = false: 16 bytes {vertex<<1|open, right, left, opposite} (any mesh size).  R8 = true:
+// 8 bytes, three 21-bit fields {vertex<<1|open : 0..20, right : 21..41, left : 42..62} (codes and ids < 2^20, -1 = all
+// ones), used whenever the batch allows it: a 128-byte line then holds the records of four faces instead of two, so more of
+// a walker's dependent loads hit a line a neighbouring face already brought in, and the walkers and k_pack move half the
+// bytes.  The opposite corner is not stored: opposite(k) = right field of the record of corner (k + 2) % 3.
+#ifdef HIPEMU
+struct uvol_u2 { uint32_t x, y; };
+#else
+typedef uint32_t uvol_u2 __attribute__((ext_vector_type(2)));
+#endif
+__device__ __forceinline__ void rec8_dec(uint32_t lo, uint32_t hi, int &vi, int &rc, int &lc) {
+  vi = (int)(lo & 0x1fffffu);
+  rc = (int)(((lo >> 21) | (hi << 11)) << 11) >> 11;
+  lc = (int)(hi << 1) >> 11;
+}
+template <bool R8> struct RecOps;
+template <> struct RecOps<false> {
+  typedef UVOL_G(const uvol_i4) Ptr; typedef uvol_i3 Pre;
+  static __device__ __forceinline__ Ptr ptr(const int32_t *p) { return UVOL_TO_G(const uvol_i4, reinterpret_cast<const uvol_i4 *>(p)); }
+  static __device__ __forceinline__ void get(Ptr rec, int code, int &vi, int &rc, int &lc) { const uvol_i4 q = rec[code]; vi = q.x; rc = q.y; lc = q.z; }
+  static __device__ __forceinline__ Pre pre(Ptr rec, int code) { return rec3(rec, code); }
+  static __device__ __forceinline__ void take(const Pre &p, int &vi, int &rc, int &lc) { vi = UVOL_READFIRST(p.x); const int l_ = UVOL_READFIRST(p.z); rc = UVOL_READFIRST(p.y); lc = l_; }
+};
+template <> struct RecOps<true> {
+  typedef UVOL_G(const uvol_u2) Ptr; typedef uvol_u2 Pre;
+  static __device__ __forceinline__ Ptr ptr(const int32_t *p) { return UVOL_TO_G(const uvol_u2, reinterpret_cast<const uvol_u2 *>(p)); }
+  static __device__ __forceinline__ void get(Ptr rec, int code, int &vi, int &rc, int &lc) { const uvol_u2 q = rec[code]; rec8_dec(q.x, q.y, vi, rc, lc); }
+  static __device__ __forceinline__ Pre pre(Ptr rec, int code) { return rec[code]; }
+  static __device__ __forceinline__ void take(const Pre &p, int &vi, int &rc, int &lc) { const uint32_t lo = (uint32_t)UVOL_READFIRST(p.x), hi = (uint32_t)UVOL_READFIRST(p.y); rec8_dec(lo, hi, vi, rc, lc); }
+};
+
 // Edgebreaker walk, one lane per frame: typed pointers (global_* / ds_* instructions, exactly counted waits), no scatter
 // stores (face_time is rebuilt from proc[] by k_face_time).  Per face: ONE 16-byte record read from HBM — the dependent
 // access that bounds the walk —, one sequential proc/symb store pair, a fire-and-forget ds_or for the face bit and one
 // LDS round trip for the vertex / neighbour bits.  Corners are carried as codes (4 * face + k).
-template <typename FB, typename VB>
+template <bool R8, typename FB, typename VB>
 __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
+  typedef RecOps<R8> RO;
   const int nf = (int)J.nf;
-  UVOL_G(const uvol_i4) rec = UVOL_TO_G(const uvol_i4, reinterpret_cast<const uvol_i4 *>(J.rec[0]));
+  const typename RO::Ptr rec = RO::ptr(J.rec[0]);
   UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack);
   UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
   UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
@@ -380,14 +423,15 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
     // component starts: fully visited words of the face bitmap are skipped 32 faces at a time
     if ((f0 & 31) == 0) { while (f0 + 32 <= nf && pword(fbits, f0 >> 5) == 0xffffffffu) f0 += 32; if (f0 >= nf) break; }
     if (pbit_get(fbits, f0)) continue;
-    const uvol_i4 q0 = rec[4 * (size_t)f0], q1 = rec[4 * (size_t)f0 + 1], q2 = rec[4 * (size_t)f0 + 2];
-    const int o0[3] = { q0.w, q1.w, q2.w }, v0[3] = { q0.x, q1.x, q2.x };
+    int v0[3], r0_[3], l0_[3];
+    for (int k = 0; k < 3; k++) RO::get(rec, 4 * f0 + k, v0[k], r0_[k], l0_[k]);
+    const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
     int interior = 1, start = 4 * f0;
     for (int k = 0; k < 3; k++) {
       if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
       if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
         int ci = 4 * f0 + k, rc = ci;
-        while (rc >= 0) { ci = rc; const int o = rec[rc].z; rc = o < 0 ? -1 : code_prv(o); }
+        while (rc >= 0) { ci = rc; int v_, r_, o; RO::get(rec, rc, v_, r_, o); rc = o < 0 ? -1 : code_prv(o); }
         interior = 0; start = code_prv(ci); break;
       }
     }
@@ -412,19 +456,19 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
       top_known = false;
       if (x < 0 || pbit_get(fbits, x >> 2)) { sp--; continue; }
       int vi, rcn, lcn;
-      { const uvol_i4 q = rec[x]; vi = q.x; rcn = q.y; lcn = q.z; }
+      RO::get(rec, x, vi, rcn, lcn);
       for (;;) {
         const int face = x >> 2;
         // both records this step can move to are requested now and taken (readfirstlane) only by the branch that goes there
-        const uvol_i3 pR = rec3(rec, (rcn < 0 ? x : rcn) + dz), pL = rec3(rec, (lcn < 0 ? x : lcn) + dz);
+        const typename RO::Pre pR = RO::pre(rec, (rcn < 0 ? x : rcn) + dz), pL = RO::pre(rec, (lcn < 0 ? x : lcn) + dz);
         proc[nproc] = 3 * face + (x & 3);
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = pword(vbits, v >> 5);
         const uint32_t rw_ = rcn < 0 ? 0xffffffffu : pword(fbits, rcn >> 7), lw_ = lcn < 0 ? 0xffffffffu : pword(fbits, lcn >> 7);
-#define W_GO_R() do { x = rcn; vi = UVOL_READFIRST(pR.x); lcn = UVOL_READFIRST(pR.z); rcn = UVOL_READFIRST(pR.y); } while (0)
-#define W_GO_L() do { x = lcn; vi = UVOL_READFIRST(pL.x); rcn = UVOL_READFIRST(pL.y); lcn = UVOL_READFIRST(pL.z); } while (0)
+#define W_GO_R() do { x = rcn; RO::take(pR, vi, rcn, lcn); } while (0)
+#define W_GO_L() do { x = lcn; RO::take(pL, vi, rcn, lcn); } while (0)
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v);
           if (!(vi & 1)) { symb[nproc] = T_C; nproc++; W_GO_R(); continue; }
@@ -454,7 +498,7 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
 
 // LDS: [face bits, fw words][vertex bits, vcap_words]; vcap_words is sized by the host from the input attribute counts and
 // the LDS slot (a table with more vertices keeps its vertex bitmap in global memory).  LDS = false: both in global memory.
-template <bool LDS>
+template <bool LDS, bool R8>
 __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int vcap_words) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
@@ -466,9 +510,9 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int vcap_words) {
   if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0; __syncthreads(); }
   if (!ok || lane != 0) return;
   if (LDS) {
-    if (v_in_lds) eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-    else eb_walk_lane0(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
-  } else eb_walk_lane0(J, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis)), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+    if (v_in_lds) eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+    else eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+  } else eb_walk_lane0<R8>(J, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis)), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
 }
 
 // face_time[f] = index of the symbol that encoded face f (-1 for the faces that only start a component): the inverse
@@ -479,14 +523,16 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_face_time(GeoJob *jobs) {
   if (i < (uint32_t)J.nsym) J.face_time[J.proc[i] / 3] = (int32_t)i;
 }
 // v2d[t][vertex] = position of the vertex in the coding order of table t: the inverse of order[t][] (same reason)
-__global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs, int r8) {
   JOB_OR_RETURN;
   const int t = blockIdx.z;
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (i >= J.ne[t]) return;
   if (t > 0 && (t - 1 >= J.nad || !J.interior_seams[t - 1])) return;
   const int c = J.order[t][i];
-  J.v2d[t][J.rec[1 + t][4 * (size_t)code_of_corner(c)] >> 1] = (int32_t)i;
+  const size_t code = (size_t)code_of_corner(c);
+  const int vi = r8 ? (int)((uint32_t)J.rec[1 + t][2 * code] & 0x1fffffu) : J.rec[1 + t][4 * code];
+  J.v2d[t][vi >> 1] = (int32_t)i;
 }
 
 // topology-split events (CheckAndStoreTopologySplitEvent): symbol i contributes an event for each already-encoded
@@ -677,10 +723,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 // One 16-byte record load per face; visited faces / vertices are bitmaps in LDS; order[] is the only output stream
 // (v2d[], its inverse, is rebuilt by k_v2d).  Same structure as eb_walk_lane0.
 // ------------------------------------------------------------------------------------------------
-template <typename FB, typename VB>
+template <bool R8, typename FB, typename VB>
 __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vbits) {
+  typedef RecOps<R8> RO;
   const int nf = (int)J.nf;
-  UVOL_G(const uvol_i4) rec = UVOL_TO_G(const uvol_i4, reinterpret_cast<const uvol_i4 *>(J.rec[1 + t]));
+  const typename RO::Ptr rec = RO::ptr(J.rec[1 + t]);
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
   const int dz = UVOL_LANE_ZERO();
   int n = 0;
@@ -691,7 +738,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
     stack[sp] = x;
     sp++;
     int top = x; bool top_known = true;
-    { const int vn = rec[x + 1].x >> 1, vp = rec[x + 2].x >> 1;
+    { int vn, vp, r_, l_; RO::get(rec, x + 1, vn, r_, l_); RO::get(rec, x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
       if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); order[n] = 3 * f + 1; n++; }
       if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); order[n] = 3 * f + 2; n++; } }
     while (sp > 0) {
@@ -699,18 +746,18 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
       top_known = false;
       if (x < 0 || pbit_get(fbits, x >> 2)) { sp--; continue; }
       int vi, rc, lc;
-      { const uvol_i4 q = rec[x]; vi = q.x; rc = q.y; lc = q.z; }
+      RO::get(rec, x, vi, rc, lc);
       for (;;) {
         const int face = x >> 2;
         // both records this step can move to are requested now and taken (readfirstlane) only by the branch that goes there
-        const uvol_i3 pR = rec3(rec, (rc < 0 ? x : rc) + dz), pL = rec3(rec, (lc < 0 ? x : lc) + dz);
+        const typename RO::Pre pR = RO::pre(rec, (rc < 0 ? x : rc) + dz), pL = RO::pre(rec, (lc < 0 ? x : lc) + dz);
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = pword(vbits, v >> 5);
         const uint32_t rw_ = rc < 0 ? 0xffffffffu : pword(fbits, rc >> 7), lw_ = lc < 0 ? 0xffffffffu : pword(fbits, lc >> 7);
-#define T_GO_R() do { x = rc; vi = UVOL_READFIRST(pR.x); lc = UVOL_READFIRST(pR.z); rc = UVOL_READFIRST(pR.y); } while (0)
-#define T_GO_L() do { x = lc; vi = UVOL_READFIRST(pL.x); rc = UVOL_READFIRST(pL.y); lc = UVOL_READFIRST(pL.z); } while (0)
+#define T_GO_R() do { x = rc; RO::take(pR, vi, rc, lc); } while (0)
+#define T_GO_L() do { x = lc; RO::take(pL, vi, rc, lc); } while (0)
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v); order[n] = 3 * face + (x & 3); n++;
           if (!(vi & 1)) { T_GO_R(); continue; }
@@ -727,7 +774,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
 
-template <bool LDS>
+template <bool LDS, bool R8>
 __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, int dbg) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
@@ -744,9 +791,9 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, i
   const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
 #endif
   if (LDS) {
-    if (v_in_lds) traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-    else traverse_lane0(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
-  } else traverse_lane0(J, t, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t])), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+    if (v_in_lds) traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+    else traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+  } else traverse_lane0<R8>(J, t, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t])), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
 #ifndef HIPEMU
   if (dbg && blockIdx.y == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, (int)J.nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5);
 #endif
@@ -1346,8 +1393,10 @@ int geo_create(uvol_ctx *ctx) {
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->geo->max_lds = (size_t)v;
   const size_t want = ctx->geo->max_lds;
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ctx->geo->num_cu = v;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   (void)hipGetLastError();
 #else
   ctx->geo->max_lds = 160 * 1024;
@@ -1479,7 +1528,7 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     LAUNCH(k_dense3_flags, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                   \
     LAUNCH(k_dense3_sums, dim3(1, N, (nz)), dim3(UVOL_BLOCK), dj);                                \
     LAUNCH(k_dense3_assign, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                  \
-    LAUNCH(k_dense3_apply_pack, dim3(bf, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));              \
+    LAUNCH(k_dense3_apply_pack, dim3(bf, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0), r8);          \
   } while (0)
 // zero the hash tables / visited maps / histograms at the head of every job's workspace
 __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
@@ -1509,15 +1558,23 @@ static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals
 
 // attribute sequencing of a prepared GeoJob array (tables 1..3): corner records, DepthFirstTraverser, inverse maps.
 // Shared with the decode path (geom_decode.hip), which fills the same job fields from a decoded corner table.
+// 8-byte corner records (RecOps<true>): every corner code (< 4 * faces, signed field: 20 bits + sign) and every
+// vertex id << 1 | open (< 6 * faces, unsigned 21-bit field) of the batch must fit, i.e. faces < 2^18; UVOL_REC16=1 (tests)
+// forces the 16-byte format
+static inline bool geo_rec8(bool use_lds, uint32_t max_nfi) {
+  static const bool force16 = [] { const char *e = getenv("UVOL_REC16"); return e && *e == '1'; }();
+  return use_lds && !force16 && 4ull * max_nfi < (1ull << 20);
+}
 int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint32_t max_vals) {
   GeoState *G = ctx->geo;
   const unsigned N = (unsigned)n, bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi);
   size_t walk_lds = 0; int vcw = 0;
   const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &vcw);
-  for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w);
-  if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0);
-  else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj, 0, 0);
-  LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
+  const int r8 = geo_rec8(use_lds, max_nfi) ? 1 : 0;
+  for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w, r8);
+  if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); }
+  else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 0, 0);
+  LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
   return UVOL_OK;
 }
 
@@ -1613,11 +1670,12 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   }
   size_t walk_lds = 0; int walk_vcw = 0;
   const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &walk_vcw);
+  const int r8 = geo_rec8(use_lds, max_nfi) ? 1 : 0;
   {
     DENSE_PACK(0, 1);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_lds) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw);
-    else LAUNCH((k_eb_walk<false>), dim3(N), dim3(64), dj, 0);
+    if (use_lds) { if (r8) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); else LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); }
+    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 0);
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
@@ -1653,9 +1711,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
     size_t t_lds = walk_lds; int t_vcw = walk_vcw;
     if (tvg) (void)walk_lds_plan(G, max_nfi, max_vals, &t_lds, &t_vcw, true);
-    if (use_lds) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0);
-    else LAUNCH((k_traverse<false>), dim3(3, N), dim3(64), dj, 0, 0);
-    LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
+    if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); }
+    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 0, 0);
+    LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
