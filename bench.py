@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 I8_PEAK_TOPS = 3944.0        # dense i8 MFMA (16x16x64), MI355X_MICROARCH.md
-PMC_FILE = "r01_k_pmc_traffic.json"
+PMC_FILE = "r01_l_pmc_traffic.json"
 
 
 def main():
