@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 
 // ------------------------------------------------------------------------------------------------
 // K4: valence edgebreaker — split into
-//   k_pack_faces   (parallel)  16-byte per-corner records {vertex<<1|open, right, left, opposite} indexed by corner code
+//   k_pack_faces   (parallel)  per-corner records {vertex<<1|open, right, left[, opposite]} (8 or 16 bytes, RecOps) indexed by corner code
 //                              4*face+k, so a walker step is ONE load and no division / select
 //   k_eb_walk      (serial)    MeshEdgebreakerEncoderImpl::EncodeConnectivity traversal only: symbols + processed corners;
 //                              visited faces / vertices are bitmaps in LDS (k_face_time inverts proc[] afterwards)
@@ -405,7 +405,7 @@ template <> struct RecOps<true> {
 };
 
 // Edgebreaker walk, one lane per frame: typed pointers (global_* / ds_* instructions, exactly counted waits), no scatter
-// stores (face_time is rebuilt from proc[] by k_face_time).  Per face: ONE 16-byte record read from HBM — the dependent
+// stores (face_time is rebuilt from proc[] by k_face_time).  Per face: ONE 8- or 16-byte record read from HBM — the dependent
 // access that bounds the walk —, one sequential proc/symb store pair, a fire-and-forget ds_or for the face bit and one
 // LDS round trip for the vertex / neighbour bits.  Corners are carried as codes (4 * face + k).
 template <bool R8, typename FB, typename VB>
@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 
 // ------------------------------------------------------------------------------------------------
 // K5: DepthFirstTraverser — serial per (table, frame), one lane each.  t=0 base table, t=1,2 attribute tables.
-// One 16-byte record load per face; visited faces / vertices are bitmaps in LDS; order[] is the only output stream
+// One record load per face (RecOps); visited faces / vertices are bitmaps in LDS; order[] is the only output stream
 // (v2d[], its inverse, is rebuilt by k_v2d).  Same structure as eb_walk_lane0.
 // ------------------------------------------------------------------------------------------------
 template <bool R8, typename FB, typename VB>
@@ -1530,7 +1530,7 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     LAUNCH(k_dense3_assign, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                  \
     LAUNCH(k_dense3_apply_pack, dim3(bf, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0), r8);          \
   } while (0)
-// zero the hash tables / visited maps / histograms at the head of every job's workspace
+// zero the dedup hash tables / half-edge counts / visited maps / histograms at the head of every job's workspace
 __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   uint4 *p = reinterpret_cast<uint4 *>(J.ws_base);
