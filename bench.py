@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traverse-vbits-l2", type=int, default=-1, help="-1 auto (on with >= 3 geometry streams and >= 700 frames), 0 off, 1 on")
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
+    ap.add_argument("--geo-priority", type=int, default=0, help="DIAGNOSTIC: geometry contexts on high-priority streams too")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--geo-stagger-ms", type=float, default=0.0, help="one-time start delay of geometry stream g: g * this")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
@@ -112,6 +113,8 @@ def main():
     GS = max(1, args.geo_streams)
     if args.tex_priority:
         tcfg.update(stream_priority=1)
+    if args.geo_priority:
+        gcfg.update(stream_priority=1)
     if args.traverse_vbits_l2 == 1 or (args.traverse_vbits_l2 < 0 and GS >= 3 and F >= 700):                # > 700 frames in flight: attribute traversers with their vertex bitmap in L2 (see uvol_codec.h)
         gcfg.update(traverse_vbits_l2=1)
     if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)
