@@ -248,6 +248,7 @@ def main():
             res["roofline_mfma"] = {"bound": "mfma", "kernel": "tex.k10_sel_assign", "achieved": tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s",
                                     "frac": tops / I8_PEAK_TOPS, "avg_launch_ms": mfma_grp["total_ms"] / max(1, mfma_grp["launches"]),
                                     "ops_per_launch": mfma_grp["algo_bytes"] / max(1, mfma_grp["launches"]), "dtype": "i8 x i8 -> i32"}
+        res["quality"] = quality_gates(geos[0], texs[0], out, meshes_h[0], tex_h, B) if not args.only else None
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
         print(json.dumps(res))
@@ -257,6 +258,29 @@ def main():
         t.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def quality_gates(geo, tex, out, mesh0, tex0, B):
+    """SURVEY 8(d) 'quality gates reported with the speed', outside the timed region: frame 0 / segment 0 of the timed outputs are
+    decoded on the GPU (this codec's decode path, itself bit-exact against the fixture-pinned decoders in the tests).  Geometry,
+    independent of vertex order: the largest distance from an input position to the nearest decoded position against half a
+    quantisation step per axis; texture: RGB PSNR of the decoded layers against the source (stored bottom-up, -y_flip) and
+    bits per texel of the segment."""
+    try:
+        import numpy as np
+        from scipy.spatial import cKDTree
+        d = geo.decode_mesh_batch([out["drc"][0]])[0]
+        pos = np.asarray(mesh0["pos"], np.float64)
+        step = float((pos.max(0) - pos.min(0)).max()) / (2 ** 11 - 1)
+        dist, _ = cKDTree(np.asarray(d["pos"], np.float64)).query(pos)
+        dec = tex.decode_texture_segments([out["ktx2"][0]])[0]
+        src = np.stack([np.asarray(a)[::-1] for a in tex0]).astype(np.float64)
+        mse = float(np.mean((src[..., :3] - dec[..., :3].astype(np.float64)) ** 2))
+        return {"frame": 0, "max_pos_err": float(dist.max()), "pos_half_step_diagonal": step / 2 * 3 ** 0.5, "faces": int(d["n_faces"]),
+                "texture_psnr_rgb_db": 10.0 * float(np.log10(255.0 ** 2 / max(mse, 1e-12))), "texture_bits_per_texel": 8.0 * len(out["ktx2"][0]) / (dec.shape[0] * dec.shape[1] * dec.shape[2])}
+    except Exception as e:                                   # never lose the bench line over the side report
+        print("quality gates not computed: %r" % (e,), file=sys.stderr)
+        return None
 
 
 def pmc_traffic(group, units):
