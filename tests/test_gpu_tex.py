@@ -37,6 +37,18 @@ def test_gpu_texture_edge_cases(oracle, gpu_codec):
     assert gpu_codec.encode_texture_segments(noise) == [oracle.ktx2_encode(t) for t in noise]
 
 
+def test_gpu_texture_quality_levels(oracle):
+    """etc1s_quality 1 / 255 on the GPU (codebook caps 32 / 32 and 3060 / 1530; 512 x 512 x 3 so that the large caps are reached)."""
+    import synth, uvol
+    tex = synth.texture_sequence(3, size=512, seed=9)
+    for q in (1, 255):
+        cd = uvol.Codec(device=0, etc1s_quality=q)
+        try:
+            assert cd.encode_texture_segment(tex) == oracle.ktx2_encode(tex, quality=q), q
+        finally:
+            cd.close()
+
+
 def test_gpu_reference_texture_reencode(oracle, gpu_codec):
     """Real captured content (decoded reference segment, 1024^2 x 5): byte-exact vs oracle, fixture-like bpp."""
     ref = open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read()

@@ -30,6 +30,17 @@ def test_hipemu_texture_edge_cases_match_oracle(oracle, hipemu_lib):
     cd.close()
 
 
+def test_hipemu_texture_quality_levels_match_oracle(oracle, hipemu_lib):
+    """etc1s_quality other than the default: 1 (codebook caps at their floor of 32 / 32, high skip threshold) and 255 (caps
+    3060 / 1530: several statistics passes, several LDS chunks in the selector search, skip threshold 0), bit-exact."""
+    import synth, uvol
+    tex = synth.texture_sequence(2, size=96, seed=9)
+    for q in (1, 255):
+        cd = uvol.Codec(lib_path=hipemu_lib, etc1s_quality=q)
+        assert cd.encode_texture_segment(tex) == oracle.ktx2_encode(tex, quality=q), q
+        cd.close()
+
+
 def test_hipemu_texture_decode_matches_oracle(oracle, hipemu_lib):
     """Decode path: the HIP ETC1S/BasisLZ decoder, through the shim, against the pinned oracle decoder —
     on the reference's own fixture (written by Basis Universal 1.16) and on this codec's output, ragged sizes included."""
