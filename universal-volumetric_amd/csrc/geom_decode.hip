@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(64) k_gdec_index(GeoDecJob *jobs) {
   GRd r; r.b = b; r.n = n; r.o = 11; r.err = 0;
   if (gr_u8(r) != 2) { J.status = -5; return; }
   const int nev = (int)gr_varint(r), nf = (int)gr_varint(r), nad = (int)gr_u8(r), nsym = (int)gr_varint(r), nsplit = (int)gr_varint(r), nts = (int)gr_varint(r);
-  if (r.err || nf <= 0 || nf != J.nf || nad > GD_MAXAD || nsym > nf || nts > nf || nev != J.nev) { J.status = -6; return; }
+  // every count comes from an untrusted varint: the slab is carved for nev + nf + 8 vertices (gdec_carve), so a vertex-split
+  // count above nf (one split needs one S symbol, one symbol per face) would let k_gdec_conn write past it
+  if (r.err || nf <= 0 || nf != J.nf || nad < 0 || nad > GD_MAXAD || nsym < 0 || nsym > nf || nts < 0 || nts > nf || nsplit < 0 || nsplit > nf || nev < 0 || nev != J.nev) { J.status = -6; return; }
   J.nad = nad; J.nsym = nsym; J.nsplit = nsplit; J.nts = nts;
   { int last = 0; for (int i = 0; i < nts; i++) { const int d = (int)gr_varint(r), src = d + last, d2 = (int)gr_varint(r); J.sp_src[i] = src; J.sp_spl[i] = src - d2; last = src; }
     if (r.o + (uint32_t)(nts + 7) / 8 > n) r.err = 1;

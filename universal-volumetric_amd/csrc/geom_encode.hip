@@ -245,9 +245,11 @@ __device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, cons
       const uint32_t R = (uint32_t)code_of_corner(r[(k + 1) % 3]) & 0x1fffffu, L = (uint32_t)code_of_corner(r[(k + 2) % 3]) & 0x1fffffu;
       dst[k] = make_uint2(((uint32_t)vc[k] & 0x1fffffu) | (R << 21), (R >> 11) | (L << 10));
     }
+    dst[3] = make_uint2(0u, 0u);                    // 4th slot of the face's block: "face visited" flag of the lane-per-walker kernels
   } else {
     int4 *dst = reinterpret_cast<int4 *>(rec) + 4 * (size_t)f;
     for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
+    dst[3] = make_int4(0, 0, 0, 0);
   }
 }
 // which: 0 old base table (edgebreaker), 1 new base, 2/3 attribute tables (DFS)
@@ -798,6 +800,178 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, i
   if (dbg && blockIdx.y == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, (int)J.nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5);
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// Lane-per-walker forms of K4 / K5.  The wave-per-walker kernels above keep one dependent-load chain per wave and their
+// visited bitmaps in LDS, which caps a CU at 3 - 6 walkers.  Here every LANE walks its own frame (or table of a frame): plain
+// SIMT code, divergent branches, nothing in LDS, so the number of chains in flight is bounded by frames in HBM, not by LDS.
+// The face-visited flag lives in the 4th slot of the face's own record block (it arrives with the record prefetch: no face
+// bitmap), the vertex-visited bitmap is a per-walker word array in global memory touched by its one lane only (plain
+// load / OR / store: a thread always sees its own stores).  `W` = lanes used per wave: few walkers are spread over many
+// waves (less branch serialisation per step), many walkers are packed up to 64 per wave.
+// Results are identical to the wave-per-walker kernels (same traversal, same output arrays).
+// ------------------------------------------------------------------------------------------------
+#define S_REC(code, vi, rc, lc)                                                                                         \
+  do {                                                                                                                  \
+    if (R8) { const uint2 q_ = *reinterpret_cast<const uint2 *>(rec + 2 * (size_t)(code)); rec8_dec(q_.x, q_.y, vi, rc, lc); } \
+    else { const int4 q_ = *reinterpret_cast<const int4 *>(rec + 4 * (size_t)(code)); vi = q_.x; rc = q_.y; lc = q_.z; }  \
+  } while (0)
+#define S_FLAG(code) (rec[(R8 ? 2 : 4) * (size_t)((code) | 3)])
+// raw prefetch of a neighbour's record + its face flag (decoded only by the branch that moves there)
+#define S_PRE(code, a, b, c, fl)                                                                                        \
+  do {                                                                                                                  \
+    if (R8) { const uint2 q_ = *reinterpret_cast<const uint2 *>(rec + 2 * (size_t)(code)); a = q_.x; b = q_.y; c = 0; }    \
+    else { const int4 q_ = *reinterpret_cast<const int4 *>(rec + 4 * (size_t)(code)); a = (uint32_t)q_.x; b = (uint32_t)q_.y; c = (uint32_t)q_.z; } \
+    fl = S_FLAG(code);                                                                                                  \
+  } while (0)
+#define S_TAKE(a, b, c, vi, rc, lc) do { if (R8) rec8_dec(a, b, vi, rc, lc); else { vi = (int)(a); rc = (int)(b); lc = (int)(c); } } while (0)
+
+template <bool R8>
+__device__ inline void eb_walk_simt(GeoJob &J) {
+  const int nf = (int)J.nf;
+  uint32_t *rec = reinterpret_cast<uint32_t *>(J.rec[0]);
+  uint32_t *vbits = reinterpret_cast<uint32_t *>(J.vvis);
+  int32_t *proc = J.proc, *stack = J.stack, *initc = J.initc; uint8_t *symb = J.symb, *start_bits = J.start_bits;
+  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
+  enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
+  for (int f0 = 0; f0 < nf && nproc + ninit < nf; f0++) {
+    if (S_FLAG(4 * f0)) continue;
+    int v0[3], r0_[3], l0_[3];
+    for (int k = 0; k < 3; k++) S_REC(4 * f0 + k, v0[k], r0_[k], l0_[k]);
+    const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
+    int interior = 1, start = 4 * f0;
+    for (int k = 0; k < 3; k++) {
+      if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
+      if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
+        int ci = 4 * f0 + k, rc = ci;
+        while (rc >= 0) { ci = rc; int v_, r_, l_; S_REC(rc, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
+        interior = 0; start = code_prv(ci); break;
+      }
+    }
+    start_bits[nstart] = (uint8_t)interior;
+    nstart++;
+    int from;
+    if (interior) {
+      for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = vbits[v >> 5]; vbits[v >> 5] = w | (1u << (v & 31)); }
+      S_FLAG(4 * f0) = 1u;
+      initc[ninit] = 3 * f0 + 1;
+      ninit++;
+      from = o0[1];
+      if (from < 0 || S_FLAG(from)) continue;
+    } else from = start;
+    int sp = 0;
+    stack[sp] = from;
+    sp++;
+    while (sp > 0) {
+      int x = stack[sp - 1];
+      if (x < 0 || S_FLAG(x)) { sp--; continue; }
+      int vi, rcn, lcn;
+      S_REC(x, vi, rcn, lcn);
+      for (;;) {
+        const int face = x >> 2;
+        S_FLAG(x) = 1u;
+        uint32_t ra, rb, rc_, rfl, la, lb, lc_, lfl;
+        S_PRE(rcn < 0 ? x : rcn, ra, rb, rc_, rfl);
+        S_PRE(lcn < 0 ? x : lcn, la, lb, lc_, lfl);
+        proc[nproc] = 3 * face + (x & 3);
+        const int v = vi >> 1;
+        const uint32_t vw = vbits[v >> 5];
+        if (!((vw >> (v & 31)) & 1u)) {
+          vbits[v >> 5] = vw | (1u << (v & 31));
+          if (!(vi & 1)) { symb[nproc] = T_C; nproc++; x = rcn; S_TAKE(ra, rb, rc_, vi, rcn, lcn); continue; }
+        }
+        const bool rvis = rcn < 0 || rfl != 0, lvis = lcn < 0 || lfl != 0;
+        const int sym = rvis ? (lvis ? T_E : T_R) : (lvis ? T_L : T_S);
+        symb[nproc] = (uint8_t)sym;
+        nproc++;
+        if (sym == T_E) { sp--; break; }
+        if (sym == T_R) { x = lcn; S_TAKE(la, lb, lc_, vi, rcn, lcn); continue; }
+        if (sym == T_L) { x = rcn; S_TAKE(ra, rb, rc_, vi, rcn, lcn); continue; }
+        nsplit++;
+        stack[sp - 1] = lcn; stack[sp] = rcn;
+        sp++;
+        break;
+      }
+    }
+  }
+  J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
+  if (nproc + ninit != nf) J.status = -10;
+  J.rb[0].n = (uint32_t)nstart;
+  uint32_t z = 0; for (int i = 0; i < nstart; i++) z += start_bits[i] == 0;
+  J.rb[0].zeros = z;
+}
+template <bool R8>
+__global__ void __launch_bounds__(64) k_eb_walk_simt(GeoJob *jobs, int n, int W) {
+  const int lane = (int)threadIdx.x;
+  if (lane >= W) return;
+  const int j = (int)blockIdx.x * W + lane;
+  if (j >= n) return;
+  GeoJob &J = jobs[j];
+  if (J.status != 0) return;
+  eb_walk_simt<R8>(J);
+}
+
+template <bool R8>
+__device__ inline void traverse_simt(GeoJob &J, int t) {
+  const int nf = (int)J.nf;
+  uint32_t *rec = reinterpret_cast<uint32_t *>(J.rec[1 + t]);
+  uint32_t *vbits = reinterpret_cast<uint32_t *>(J.t_vvis[t]);
+  int32_t *stack = J.t_stack[t], *order = J.order[t];
+  int n = 0, nvis = 0;
+  for (int f = 0; f < nf && nvis < nf; f++) {
+    if (S_FLAG(4 * f)) continue;
+    int x = 4 * f, sp = 0;
+    stack[sp] = x;
+    sp++;
+    { int vn, vp, r_, l_; S_REC(x + 1, vn, r_, l_); S_REC(x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
+      uint32_t w = vbits[vn >> 5];
+      if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f + 1; n++; }
+      w = vbits[vp >> 5];
+      if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f + 2; n++; } }
+    while (sp > 0) {
+      x = stack[sp - 1];
+      if (x < 0 || S_FLAG(x)) { sp--; continue; }
+      int vi, rc, lc;
+      S_REC(x, vi, rc, lc);
+      for (;;) {
+        const int face = x >> 2;
+        S_FLAG(x) = 1u;
+        nvis++;
+        uint32_t ra, rb, rc_, rfl, la, lb, lc_, lfl;
+        S_PRE(rc < 0 ? x : rc, ra, rb, rc_, rfl);
+        S_PRE(lc < 0 ? x : lc, la, lb, lc_, lfl);
+        const int v = vi >> 1;
+        const uint32_t vw = vbits[v >> 5];
+        if (!((vw >> (v & 31)) & 1u)) {
+          vbits[v >> 5] = vw | (1u << (v & 31)); order[n] = 3 * face + (x & 3); n++;
+          if (!(vi & 1)) { x = rc; S_TAKE(ra, rb, rc_, vi, rc, lc); continue; }
+        }
+        const bool rvis = rc < 0 || rfl != 0, lvis = lc < 0 || lfl != 0;
+        if (rvis) { if (lvis) { sp--; break; } x = lc; S_TAKE(la, lb, lc_, vi, rc, lc); }
+        else { if (lvis) { x = rc; S_TAKE(ra, rb, rc_, vi, rc, lc); } else { stack[sp - 1] = lc; stack[sp] = rc; sp++; break; } }
+      }
+    }
+  }
+  J.ne[t] = (uint32_t)n;
+  if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
+}
+// walker id = table * n + frame: the lanes of a wave walk the same table of consecutive frames (similar lengths)
+template <bool R8>
+__global__ void __launch_bounds__(64) k_traverse_simt(GeoJob *jobs, int n, int W) {
+  const int lane = (int)threadIdx.x;
+  if (lane >= W) return;
+  const int id = (int)blockIdx.x * W + lane;
+  if (id >= 3 * n) return;
+  const int t = id / n, j = id - t * n;
+  GeoJob &J = jobs[j];
+  const int ai = t > 0 ? t - 1 : 0;
+  if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
+  traverse_simt<R8>(J, t);
+}
+#undef S_REC
+#undef S_FLAG
+#undef S_PRE
+#undef S_TAKE
 
 // ------------------------------------------------------------------------------------------------
 // K1: attribute min/max (orderable-float atomics) and quantisation of the entries in coding order
@@ -1561,9 +1735,11 @@ static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals
 // 8-byte corner records (RecOps<true>): every corner code (< 4 * faces, signed field: 20 bits + sign) and every
 // vertex id << 1 | open (< 6 * faces, unsigned 21-bit field) of the batch must fit, i.e. faces < 2^18; UVOL_REC16=1 (tests)
 // forces the 16-byte format
+// UVOL_SIMT_W=<1..64> (diagnostic / tests): lane-per-walker kernels with that many lanes used per wave; 0 / unset = wave-per-walker
+static inline int geo_simt_w() { static const int w = [] { const char *e = getenv("UVOL_SIMT_W"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return w; }
 static inline bool geo_rec8(bool use_lds, uint32_t max_nfi) {
   static const bool force16 = [] { const char *e = getenv("UVOL_REC16"); return e && *e == '1'; }();
-  return use_lds && !force16 && 4ull * max_nfi < (1ull << 20);
+  return (use_lds || geo_simt_w() > 0) && !force16 && 4ull * max_nfi < (1ull << 20);
 }
 int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint32_t max_vals) {
   GeoState *G = ctx->geo;
@@ -1572,7 +1748,8 @@ int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint3
   const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &vcw);
   const int r8 = geo_rec8(use_lds, max_nfi) ? 1 : 0;
   for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w, r8);
-  if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); }
+  if (const int W = geo_simt_w()) { const unsigned nb = (3 * N + (unsigned)W - 1) / (unsigned)W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, W); }
+  else if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); }
   else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 0, 0);
   LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
   return UVOL_OK;
@@ -1588,7 +1765,10 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   const uvol_params &prm = ctx->prm;
   if (prm.q_position_attr < 1 || prm.q_position_attr > 16 || prm.q_texture_attr < 1 || prm.q_texture_attr > 16 ||
       prm.q_normal_attr < 2 || prm.q_normal_attr > 16) { ctx->set_error("quantization bits out of supported range (1..16)"); return UVOL_E_UNSUPPORTED; }
-  if (prm.draco_compression_level != 7) { ctx->set_error("only DRACO_COMPRESSION_LEVEL 7 tool-set is implemented"); return UVOL_E_UNSUPPORTED; }
+  // DRACO_COMPRESSION_LEVEL only selects the encoder's tools, it is not written to the file (scripts/Encoder.py:171-179 documents
+  // 0..10): every legal level is encoded with the cl-7 tool set (edgebreaker + valence contexts, parallelogram / tex-coord /
+  // geometric-normal prediction, RAW rANS), which any Draco decoder reads; the shims say so on stderr
+  if (prm.draco_compression_level < 0 || prm.draco_compression_level > 10) { ctx->set_error("DRACO_COMPRESSION_LEVEL %d outside 0..10", prm.draco_compression_level); return UVOL_E_INVALID; }
   G->hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), out_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
@@ -1674,7 +1854,8 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     DENSE_PACK(0, 1);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (use_lds) { if (r8) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); else LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); }
+    if (const int W = geo_simt_w()) { const unsigned nb = (N + (unsigned)W - 1) / (unsigned)W; if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, W); }
+    else if (use_lds) { if (r8) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); else LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); }
     else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 0);
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
@@ -1711,7 +1892,8 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
     size_t t_lds = walk_lds; int t_vcw = walk_vcw;
     if (tvg) (void)walk_lds_plan(G, max_nfi, max_vals, &t_lds, &t_vcw, true);
-    if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); }
+    if (const int W = geo_simt_w()) { const unsigned nb = (3 * N + (unsigned)W - 1) / (unsigned)W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, W); }
+    else if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); }
     else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 0, 0);
     LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
   }

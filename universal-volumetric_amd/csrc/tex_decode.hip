@@ -444,11 +444,12 @@ static inline uint64_t rd64h(const uint8_t *b) { uint64_t v; memcpy(&v, b, 8); r
 // container header + supercompression global data of one file
 static int tdec_parse(const uint8_t *b, size_t n, TexDecJob &J) {
   static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
-  if (!b || n < 104 || memcmp(b, ident, 12)) return -1;
+  if (!b || n < 104 || n > 0xffffffffull || memcmp(b, ident, 12)) return -1;       // offsets are kept as uint32 below
   const uint32_t vk = rd32h(b + 12), W = rd32h(b + 20), H = rd32h(b + 24), layers = rd32h(b + 32), faces = rd32h(b + 36), levels = rd32h(b + 40), sc = rd32h(b + 44);
   const uint64_t sgd_off = rd64h(b + 64), sgd_len = rd64h(b + 72), lv_off = rd64h(b + 80), lv_len = rd64h(b + 88);
   if (vk != 0 || sc != 1 || levels != 1 || faces != 1 || W == 0 || H == 0 || W > 16384 || H > 16384) return -2;
-  if (sgd_off + sgd_len > n || lv_off + lv_len > n || lv_len > 0xffffffffull) return -3;
+  // untrusted 64-bit fields: compared without forming a sum that could wrap
+  if (sgd_off > n || sgd_len > n - sgd_off || lv_off > n || lv_len > n - lv_off) return -3;
   const uint32_t nsl = layers ? layers : 1;
   if (nsl > TD_MAX_LAYERS) return -4;
   if (sgd_len < 20 + 20ull * nsl) return -5;
@@ -458,7 +459,8 @@ static int tdec_parse(const uint8_t *b, size_t n, TexDecJob &J) {
   J.ep_len = rd32h(s + 4); J.sel_len = rd32h(s + 8); J.tab_len = rd32h(s + 12);
   for (uint32_t i = 0; i < nsl; i++) { const uint8_t *d = s + 20 + 20 * i; J.slice_flags[i] = rd32h(d); J.slice_off[i] = rd32h(d + 4); J.slice_len[i] = rd32h(d + 8); if (rd32h(d + 12) || rd32h(d + 16)) return -6; }
   const uint64_t p = sgd_off + 20 + 20ull * nsl;
-  if (p - sgd_off + J.ep_len + J.sel_len + J.tab_len > sgd_len) return -5;
+  if (20 + 20ull * nsl + (uint64_t)J.ep_len + J.sel_len + J.tab_len > sgd_len) return -5;
+  for (uint32_t i = 0; i < nsl; i++) if ((uint64_t)J.slice_off[i] + J.slice_len[i] > lv_len) return -6;
   J.ep_off = (uint32_t)p; J.sel_off = J.ep_off + J.ep_len; J.tab_off = J.sel_off + J.sel_len;
   J.level_off = (uint32_t)lv_off; J.level_len = (uint32_t)lv_len;
   if (J.ne == 0 || J.ns == 0 || J.ne > TD_MAX_SYMS - 80 || J.ns > TD_MAX_SYMS - 80) return -5;

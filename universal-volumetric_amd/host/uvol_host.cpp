@@ -2,6 +2,7 @@
 #include "uvol_host.hpp"
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -269,6 +270,7 @@ bool read_png(const std::string &path, Image &img, std::string &err) {
     else if (!std::memcmp(t, "IEND", 4)) break;
     o += 12 + len;
   }
+  if (w > 16384 || h > 16384) { err = path + ": image larger than 16384 x 16384"; return false; }      // the encoder's own limit; also bounds the allocations below
   if (!w || !h || interlace || (depth != 8 && depth != 16) || (ctype != 0 && ctype != 2 && ctype != 3 && ctype != 4 && ctype != 6) || (ctype == 3 && depth != 8)) { err = path + ": unsupported PNG variant"; return false; }
   const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4, bpp = ch * depth / 8;
   const size_t stride = (size_t)w * bpp;

@@ -68,6 +68,10 @@ int main(int argc, char **argv) {
   std::printf("🎯 Dealing with Geomety data\n");
   if (!cfg.abc_file_path.empty()) { std::printf("❌ ABCFilePath needs Blender (bpy); export OBJ files and use OBJFilesPath\n"); return 1; }
   const std::string geo_dir = join(cfg.output_directory, "geometry_draco");
+  const std::string tex_dir = join(cfg.output_directory, "texture_ktx2_baseColor_default");
+  // every early exit happens before the first worker thread exists (a joinable std::thread destroyed on `return` terminates)
+  if (!cfg.obj_files_path.empty() && !make_dirs(geo_dir)) { std::printf("❌ cannot create %s\n", geo_dir.c_str()); return 1; }
+  if (!cfg.images_path.empty() && !make_dirs(tex_dir)) { std::printf("❌ cannot create %s\n", tex_dir.c_str()); return 1; }
   int pad = 5;
   std::atomic<int> geo_failed{-1};
   std::vector<std::thread> geo_threads;
@@ -77,7 +81,6 @@ int main(int argc, char **argv) {
     obj_dir = dirname_of(cfg.obj_files_path); const std::string pat = basename_of(cfg.obj_files_path);
     { int h = (int)std::count(pat.begin(), pat.end(), '#'); if (h > 0) pad = h; }
     for (auto &f : list_dir(obj_dir)) if (match_pattern_lenient(pat, f)) obj_files.push_back(f);
-    if (!make_dirs(geo_dir)) return 1;
     // contiguous blocks of frames per GPU; each GPU encodes batches of frames_per_batch frames.  The OBJ text
     // of batch b+1 is parsed by the ingest threads while the GPU encodes batch b, .drc files are written in parallel.
     struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; };
@@ -117,7 +120,6 @@ int main(int argc, char **argv) {
   }
 
   std::printf("🎯 Dealing with Texture data\n");
-  const std::string tex_dir = join(cfg.output_directory, "texture_ktx2_baseColor_default");
   uint32_t tex_w = 0, tex_h = 0;
   std::atomic<int> tex_failed{-1};
   std::vector<std::thread> tex_threads;
@@ -125,7 +127,6 @@ int main(int argc, char **argv) {
   if (!cfg.images_path.empty()) {
     std::printf("🚧 Obtained Images path.\n");
     cpat = convert_pounds_to_c_style(cfg.images_path);     // scripts/Encoder.py:274
-    if (!make_dirs(tex_dir)) return 1;
     for (int i = cfg.ktx2_first_file; i < cfg.ktx2_file_count; i += cfg.ktx2_batch_size) starts.push_back(i);   // :282-287
     // Segments of KTX2_BATCH_SIZE images are independent.  Full segments go to the GPU `segs_per_call` at a time
     // through the batched entry point (one launch per stage for all of them); PNGs of the next call are inflated by the
