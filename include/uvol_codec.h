@@ -86,6 +86,10 @@ typedef struct uvol_mesh {
 /* Upper bound of the .drc size for a mesh (use to size `out`). */
 size_t uvol_mesh_bound(const uvol_mesh *m);
 
+/* Device memory one frame of these dimensions occupies while it is in flight inside uvol_encode_mesh_batch[_dev] (workspace with
+ * lifetime-shared arrays + its share of the packed output area): frames in flight per GPU = HBM left / this. */
+size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m);
+
 /* Replaces one `draco_encoder` process (scripts/Encoder.py:260-262): OBJ arrays -> .drc bytes. */
 int uvol_encode_mesh(uvol_ctx *ctx, const uvol_mesh *mesh, uint8_t *out, size_t cap, size_t *out_len);
 

@@ -301,3 +301,117 @@ def psnr(a, b):
     a = np.asarray(a, dtype=np.float64)[..., :3]; b = np.asarray(b, dtype=np.float64)[..., :3]
     mse = ((a - b) ** 2).mean()
     return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+# ------------------------------------------------------------------------------------------------
+# UASTC LDR 4x4 + ASTC 4x4 transcode (oracle/uastc.c; parity unpinned against basisu, see its header)
+# ------------------------------------------------------------------------------------------------
+class UastcLBlock(C.Structure):
+    _fields_ = [("mode", C.c_int), ("ccs", C.c_int), ("ep", C.c_uint8 * 8), ("w", C.c_uint8 * 32), ("solid", C.c_uint8 * 4),
+                ("bc1_hint0", C.c_int), ("bc1_hint1", C.c_int), ("etc1_flip", C.c_int), ("etc1_diff", C.c_int), ("etc1_inten0", C.c_int),
+                ("etc1_inten1", C.c_int), ("etc1_bias", C.c_int), ("etc2_hints", C.c_int), ("etc1_sel", C.c_int), ("etc1_base", C.c_uint8 * 3)]
+
+
+def _uastc_setup():
+    L = lib()
+    if getattr(L, "_uastc_ready", False):
+        return L
+    L.uastc_unpack.argtypes = [C.c_void_p, C.POINTER(UastcLBlock)]
+    L.uastc_pack.argtypes = [C.POINTER(UastcLBlock), C.c_void_p]
+    L.uastc_decode_block.argtypes = [C.c_void_p, C.c_void_p]
+    L.uastc_to_astc.argtypes = [C.c_void_p, C.c_void_p]
+    L.astc_decode_block.argtypes = [C.c_void_p, C.c_void_p]
+    L.uastc_encode_block.argtypes = [C.c_void_p, C.c_void_p]
+    L.uastc_ktx2_encode.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(OrcBuf)]
+    L.uastc_ktx2_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.uastc_ktx2_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p]
+    L._uastc_ready = True
+    return L
+
+
+def uastc_encode_blocks(px):
+    """px: [n, 16, 4] uint8 texels (i = 4*y + x) -> [n, 16] uint8 UASTC blocks."""
+    L = _uastc_setup()
+    px = np.ascontiguousarray(px, dtype=np.uint8).reshape(-1, 64)
+    out = np.zeros((len(px), 16), np.uint8)
+    for i in range(len(px)):
+        L.uastc_encode_block(px[i].ctypes.data, out[i].ctypes.data)
+    return out
+
+
+def uastc_decode_blocks(blocks):
+    L = _uastc_setup()
+    b = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
+    out = np.zeros((len(b), 16, 4), np.uint8)
+    for i in range(len(b)):
+        rc = L.uastc_decode_block(b[i].ctypes.data, out[i].ctypes.data)
+        if rc:
+            raise ValueError(f"uastc_decode_block rc={rc} (block {i})")
+    return out
+
+
+def uastc_unpack(block):
+    L = _uastc_setup()
+    b = np.ascontiguousarray(block, dtype=np.uint8).reshape(16)
+    lb = UastcLBlock()
+    rc = L.uastc_unpack(b.ctypes.data, C.byref(lb))
+    if rc:
+        raise ValueError(f"uastc_unpack rc={rc}")
+    return lb
+
+
+def uastc_to_astc_blocks(blocks):
+    L = _uastc_setup()
+    b = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
+    out = np.zeros((len(b), 16), np.uint8)
+    for i in range(len(b)):
+        rc = L.uastc_to_astc(b[i].ctypes.data, out[i].ctypes.data)
+        if rc:
+            raise ValueError(f"uastc_to_astc rc={rc} (block {i})")
+    return out
+
+
+def astc_decode_blocks(blocks):
+    L = _uastc_setup()
+    b = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
+    out = np.zeros((len(b), 16, 4), np.uint8)
+    for i in range(len(b)):
+        rc = L.astc_decode_block(b[i].ctypes.data, out[i].ctypes.data)
+        if rc:
+            raise ValueError(f"astc_decode_block rc={rc} (block {i})")
+    return out
+
+
+def uastc_ktx2_encode(layers, y_flip=1) -> bytes:
+    L = _uastc_setup()
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in layers]
+    h, w = arrs[0].shape[:2]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    buf = OrcBuf()
+    rc = L.uastc_ktx2_encode(ptrs, len(arrs), w, h, y_flip, C.byref(buf))
+    if rc:
+        raise ValueError(f"uastc_ktx2_encode rc={rc}")
+    return _take(buf)
+
+
+def uastc_ktx2_info(data: bytes):
+    L = _uastc_setup()
+    w, h, n, lo, a = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_int()
+    rc = L.uastc_ktx2_info(data, len(data), C.byref(w), C.byref(h), C.byref(n), C.byref(lo), C.byref(a))
+    if rc:
+        raise ValueError(f"uastc_ktx2_info rc={rc}")
+    return dict(width=w.value, height=h.value, layers=n.value, level_off=lo.value, has_alpha=bool(a.value))
+
+
+def uastc_ktx2_decode(data: bytes, target="rgba"):
+    """target 'rgba': [layers, H, W, 4] uint8 (stored row order); 'astc': [layers, by, bx, 16] uint8 ASTC 4x4 blocks."""
+    L = _uastc_setup()
+    i = uastc_ktx2_info(data)
+    if target == "rgba":
+        out = np.zeros((i["layers"], i["height"], i["width"], 4), np.uint8)
+    else:
+        out = np.zeros((i["layers"], (i["height"] + 3) // 4, (i["width"] + 3) // 4, 16), np.uint8)
+    rc = L.uastc_ktx2_decode(data, len(data), 0 if target == "rgba" else 1, out.ctypes.data)
+    if rc:
+        raise ValueError(f"uastc_ktx2_decode rc={rc}")
+    return out

@@ -36,8 +36,12 @@ def test_hipemu_error_paths(hipemu_lib):
     bad = dict(pos=pos, idx_pos=np.array([0, 1, 7], np.uint32))
     res = cd.encode_mesh_batch([bad, good], raise_on_error=False)
     assert res[0] is None and res[1] is not None and res[1][:5] == b"DRACO"
+    # every documented DRACO_COMPRESSION_LEVEL (0..10, scripts/Encoder.py:171-179) is accepted and encoded with the cl 7 tool set
+    c3 = uvol.Codec(lib_path=hipemu_lib, DRACO_COMPRESSION_LEVEL=3)
+    assert c3.encode_mesh(**good) == res[1]
+    c3.close()
     with pytest.raises(uvol.UvolError):
-        uvol.Codec(lib_path=hipemu_lib, DRACO_COMPRESSION_LEVEL=3).encode_mesh(**good)
+        uvol.Codec(lib_path=hipemu_lib, DRACO_COMPRESSION_LEVEL=11).encode_mesh(**good)
     cd.close()
 
 
@@ -55,10 +59,11 @@ def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
         c2.close()
 
 
-@pytest.mark.parametrize("force", ["vglobal", "global", "rec16"])
+@pytest.mark.parametrize("force", ["vglobal", "global", "rec16", "simt5", "simt64"])
 def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
     """Visited bitmaps in LDS (default, covered above), vertex bitmap in global memory (a table with more vertices than
-    the LDS slot), everything in global memory (mesh too large for LDS): same bytes.  "rec16": the 16-byte corner records
+    the LDS slot), nothing in LDS (mesh too large for LDS: the lane-per-walker kernels, one lane per wave), "simtN": the
+    lane-per-walker kernels with N lanes per wave (what large batches use): same bytes.  "rec16": the 16-byte corner records
     that batches with >= 2^18 faces per mesh use instead of the packed 8-byte ones (UVOL_REC16=1).  The switches are read
     once per process, hence the fresh interpreter."""
     import subprocess, sys, os
@@ -72,7 +77,7 @@ def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
-    env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else dict(os.environ, UVOL_WALK_FORCE=force)
+    env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:]) if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
@@ -138,4 +143,22 @@ def test_hipemu_decoders_survive_corrupt_input(oracle, hipemu_lib):
     assert outcomes["drc"][1] > 0 and outcomes["ktx2"][1] > 0          # truncations at least are always rejected
     # and the codec still works afterwards
     assert cd.encode_mesh(**m) == drc
+    cd.close()
+
+
+def test_hipemu_compact_workspace_overflow_is_retried(oracle, hipemu_lib):
+    """The per-vertex arrays of the compact workspace hold 1.5 x the largest input attribute; a mesh with far more corner-table
+    vertices than values (non-manifold fans everywhere) overflows it on the device and is re-encoded alone with worst-case sizes:
+    same bytes as the oracle, and its batch neighbours are not disturbed."""
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    rng = np.random.default_rng(1)
+    pos = rng.random((12, 3)).astype(np.float32)
+    idx = rng.integers(0, 12, size=(6000, 3)).astype(np.uint32).reshape(-1)
+    t = synth.torus_mesh()
+    res = cd.encode_mesh_batch([t, dict(pos=pos, idx_pos=idx), t])
+    assert res[1] == oracle.drc_encode(pos, idx, None, None, None, None)
+    assert res[0] == res[2] == oracle.drc_encode(t["pos"], t["idx_pos"], t["uv"], t["idx_uv"], t["nrm"], t["idx_nrm"])
+    m = synth.sphere_mesh(400, 251)
+    assert cd.mesh_workspace(**m) < 80e6          # 100,002 vertices / 200,000 faces: was 220 MB before the arrays shared addresses
     cd.close()

@@ -754,11 +754,11 @@ static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base) {
     S.probs = (uint32_t *)take(4 * (size_t)GD_MAX_NS); S.cum = (uint32_t *)take(4 * (size_t)GD_MAX_NS); S.lut = (uint32_t *)take(4 * (size_t)(1u << 20));
     S.out = (uint32_t *)take(4 * (4 * nc + 4)); J.att[k].vals = (int32_t *)take(4 * (4 * nc + 4));
   }
-  G.status = 0; G.nf = (uint32_t)nf; G.nc = (uint32_t)nc; G.nad = 2; G.nverts = 0xffffffffu;
+  G.status = 0; G.nf = (uint32_t)nf; G.nc = (uint32_t)nc; G.nad = 2; G.nverts = 0xffffffffu; G.ecap = (uint32_t)(nc + 3);
   G.nopp = J.opp; G.bvert = J.c2v; G.avert[0] = J.t_c2v[0]; G.avert[1] = J.t_c2v[1]; G.seam[0] = J.edge_seam[0]; G.seam[1] = J.edge_seam[1];
   G.vopen_d[1] = J.vopen[0]; G.vopen_d[2] = J.vopen[1]; G.vopen_d[3] = J.vopen[2];
   for (int k = 1; k < 4; k++) G.rec[k] = (int32_t *)take(64 * (nf + 1));
-  for (int k = 0; k < 3; k++) { G.order[k] = (int32_t *)take(4 * (nc + 3)); G.v2d[k] = (int32_t *)take(4 * (nc + 3)); G.t_stack[k] = (int32_t *)take(4 * (nf + 2)); G.t_fvis[k] = take(nf + 64); G.t_vvis[k] = take(nc + 64); }
+  for (int k = 0; k < 3; k++) { G.order[k] = (int32_t *)take(4 * (nc + 3)); G.v2d[k] = (int32_t *)take(4 * (nc + 3)); G.t_stack[k] = (int32_t *)take(4 * (nf + 2)); G.t_vvis[k] = take(nc + 64); }
   return o;
 }
 

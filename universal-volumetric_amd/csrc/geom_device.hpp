@@ -62,7 +62,8 @@ struct GeoJob {
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
   int32_t *opp, *vert, *ring; uint8_t *vopen;
-  uint8_t *fvis, *vvis; int32_t *vval, *c2vm, *f2split, *proc, *initc, *stack;
+  uint8_t *vvis; int32_t *vval, *c2vm, *proc, *initc, *stack;      // vvis: vertex-visited bitmap of the edgebreaker walk when it is not in LDS
+  uint8_t *evcnt;                      // topology-split events per symbol (auxiliary stream)
   int32_t *ev_src, *ev_spl; uint8_t *ev_edge;
   int32_t *rec[4]; uint8_t *symb, *ctx_of; int32_t *face_time;
   uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // dense vertex ids per table
@@ -72,20 +73,26 @@ struct GeoJob {
   int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert; uint8_t *bopen;
   uint8_t *seam[2]; uint8_t *elig; uint8_t *seam_bits[2];
   int32_t *avert[2]; uint8_t *aopen[2];
-  int32_t *order[3], *v2d[3]; uint8_t *t_fvis[3], *t_vvis[3]; int32_t *t_stack[3];
+  int32_t *order[3], *v2d[3]; uint8_t *t_vvis[3]; int32_t *t_stack[3];
   int32_t *P, *U, *O;
   uint32_t *sym_pos, *sym_uv, *sym_nrm;
   uint8_t *has_ori, *ori_val, *ori_c, *ori_bits, *flips;
   RansStream rs[GEO_NSTREAM];
   RabsStream rb[GEO_NRABS];
   uint8_t *arena; uint32_t arena_cap;
+  uint32_t ecap;                                // capacity (entries) of the per-vertex / per-entry arrays (GEO_E_WS_OVERFLOW past it)
+  uint64_t slab_cap;                            // bytes of the batch's packed output area (GEO_E_SLAB_FULL past it)
   uint8_t *ws_base; uint64_t ws_zero;          // zero-initialised head of this job's workspace (k_job_clear)
   const uint8_t *piece_ptr[GEO_MAXPIECES]; uint32_t piece_len[GEO_MAXPIECES], piece_off[GEO_MAXPIECES]; uint32_t n_pieces;
-  uint8_t *out; uint32_t out_cap;
+  uint32_t out_cap;
   uint8_t *out_pack; uint64_t out_pack_off;     // packed output area of the batch + this frame's offset in it (k_out_offsets)
 };
 
 #define GEO_INV (-1)
+// device status codes the host reacts to: the compact workspace / the packed output area was too small for this frame
+// (geo_encode_batch re-encodes such a frame alone with worst-case sizes)
+#define GEO_E_WS_OVERFLOW (-50)
+#define GEO_E_SLAB_FULL (-51)
 // corner codes for the serial walkers: 4 * face + k, so that face = code >> 2 and records are indexed without a division
 __device__ __forceinline__ int code_of_corner(int c) { return c < 0 ? -1 : (((c / 3) << 2) | (c % 3)); }
 __device__ __host__ __forceinline__ uint32_t uvol_blocks_dev(uint32_t n) { return (n + 255u) / 256u; }

@@ -39,7 +39,7 @@ enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3 };
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
 // register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
-__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return (sel == SCAN_KEEP || sel == SCAN_EVENTS) ? J.keep : (sel == SCAN_ELIG ? J.elig : J.has_ori); }
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.keep : (sel == SCAN_EVENTS ? J.evcnt : (sel == SCAN_ELIG ? J.elig : J.has_ori)); }
 __device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
@@ -315,13 +315,17 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_assign(GeoJob *jobs, int 
   const bool live = J.status == 0 && c < J.nc;
   uint32_t v = live ? J.dflagT[z][c] : 0, tot;
   const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsumT[z][blockIdx.x] : 0);
-  if (live && v) {
+  if (live && v && pos < J.ecap) {                        // more vertices than the compact workspace holds: flagged below
     const int ai = which >= 2 ? which - 2 : 0;
     const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
     J.dtmpT[z][c] = (int32_t)pos; J.vopen_d[which][pos] = vopen[c];
     if (which == 0) J.ring_d[pos] = J.ring[c];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nverts_t[which] = J.bsumT[z][uvol_blocks_dev(J.nc)];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
+    const uint32_t total = J.bsumT[z][uvol_blocks_dev(J.nc)];
+    J.nverts_t[which] = total;
+    if (total > J.ecap) J.status = GEO_E_WS_OVERFLOW;
+  }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_apply_pack(GeoJob *jobs, int w0, int r8) {
   GeoJob &J = jobs[blockIdx.y];
@@ -499,8 +503,9 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
 }
 
 // LDS: [face bits, fw words][vertex bits, vcap_words]; vcap_words is sized by the host from the input attribute counts and
-// the LDS slot (a table with more vertices keeps its vertex bitmap in global memory).  LDS = false: both in global memory.
-template <bool LDS, bool R8>
+// the LDS slot (a table with more vertices keeps its vertex bitmap in global memory).  A mesh whose face bitmap does not fit
+// LDS is walked by the lane-per-walker kernels below (nothing in LDS).
+template <bool R8>
 __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int vcap_words) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
@@ -508,13 +513,12 @@ __global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int vcap_words) {
   const uint32_t lane = threadIdx.x;
   const bool ok = J.status == 0;
   const uint32_t fw = ((uint32_t)J.nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32, vcw = (uint32_t)vcap_words;
-  const bool v_in_lds = LDS && vw <= vcw;
-  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0; __syncthreads(); }
+  const bool v_in_lds = vw <= vcw;
+  if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0;
+  __syncthreads();
   if (!ok || lane != 0) return;
-  if (LDS) {
-    if (v_in_lds) eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-    else eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
-  } else eb_walk_lane0<R8>(J, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis)), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+  if (v_in_lds) eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+  else eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
 }
 
 // face_time[f] = index of the symbol that encoded face f (-1 for the faces that only start a component): the inverse
@@ -553,13 +557,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_flags(GeoJob *jobs) {
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (i >= J.nf) return;
   int a[2], b[2];
-  J.keep[i] = i < (uint32_t)J.nsym ? (uint8_t)eb_events_of(J, i, a, b) : 0;
+  J.evcnt[i] = i < (uint32_t)J.nsym ? (uint8_t)eb_events_of(J, i, a, b) : 0;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const bool live = J.status == 0 && i < J.nf;
-  uint32_t v = live ? J.keep[i] : 0, tot;
+  uint32_t v = live ? J.evcnt[i] : 0, tot;
   const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum2[blockIdx.x] : 0);
   if (live && v) {
     int a[2], b[2]; const int n = eb_events_of(J, i, a, b);
@@ -776,7 +780,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
 
-template <bool LDS, bool R8>
+template <bool R8>
 __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, int dbg) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
@@ -786,16 +790,15 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, i
   const int ai = t > 0 ? t - 1 : 0;
   const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
   const uint32_t fw = ((uint32_t)J.nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32, vcw = (uint32_t)vcap_words;
-  const bool v_in_lds = LDS && vw <= vcw;
-  if (LDS) { if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0; __syncthreads(); }
+  const bool v_in_lds = vw <= vcw;
+  if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0;
+  __syncthreads();
   if (!ok || lane != 0) return;
 #ifndef HIPEMU
   const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
 #endif
-  if (LDS) {
-    if (v_in_lds) traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-    else traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
-  } else traverse_lane0<R8>(J, t, UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t])), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
+  if (v_in_lds) traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
+  else traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
 #ifndef HIPEMU
   if (dbg && blockIdx.y == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, (int)J.nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5);
 #endif
@@ -1531,7 +1534,13 @@ __global__ void __launch_bounds__(64) k_layout(GeoJob *jobs) {
 __global__ void __launch_bounds__(64) k_out_offsets(GeoJob *jobs, int n) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint64_t off = 0;
-  for (int i = 0; i < n; i++) { jobs[i].out_pack_off = off; if (jobs[i].status == 0) off += ((uint64_t)jobs[i].out_len + 15) & ~(uint64_t)15; }
+  for (int i = 0; i < n; i++) {
+    jobs[i].out_pack_off = off;
+    if (jobs[i].status != 0) continue;
+    const uint64_t len = ((uint64_t)jobs[i].out_len + 15) & ~(uint64_t)15;
+    if (off + len > jobs[i].slab_cap) { jobs[i].status = GEO_E_SLAB_FULL; continue; }      // the packed area is sized for typical streams
+    off += len;
+  }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_gather(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.z];
@@ -1545,12 +1554,18 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gather(GeoJob *jobs) {
 // ================================================================================================
 // host side
 // ================================================================================================
+// workspace placement (see ws_collect / ws_place below)
+struct WsItem { size_t slot, bytes; int first, last; size_t off; };
+struct WsPlan {
+  std::vector<uint64_t> key; std::vector<size_t> offs; size_t total = 0, zero = 0;
+};
 struct GeoState {
   uvol_devbuf slab;       // all per-job workspaces
   uvol_devbuf inputs;     // staged inputs when the caller passes host pointers
   uvol_devbuf jobs;       // GeoJob[n]
   uvol_devbuf outs;       // output buffers
   std::vector<GeoJob> hjobs;
+  WsPlan plan; std::vector<WsItem> items;     // workspace placement of the last job dimensions seen
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
   size_t max_lds = 64 * 1024;
   int num_cu = 256;                    // CUs this context's streams may run on
@@ -1567,10 +1582,10 @@ int geo_create(uvol_ctx *ctx) {
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && v > 0) ctx->geo->max_lds = (size_t)v;
   const size_t want = ctx->geo->max_lds;
   if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ctx->geo->num_cu = v;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eb_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   (void)hipGetLastError();
 #else
   ctx->geo->max_lds = 160 * 1024;
@@ -1592,87 +1607,152 @@ void geo_destroy(uvol_ctx *ctx) {
 }
 
 namespace {
-struct Carver {
-  size_t off = 0;
-  template <class T> size_t take(size_t count) { off = (off + 255) & ~(size_t)255; size_t o = off; off += count * sizeof(T); return o; }
-};
 inline uint32_t pow2_at_least(uint64_t v) { uint32_t c = 16; while (c < v) c <<= 1; return c; }
 
-// Lays out one job's workspace. With base == nullptr only the sizes are computed.
-// zero_bytes = size of the leading region that must be zeroed before each batch.
-size_t layout_job(GeoJob &J, uint8_t *base, size_t *zero_bytes, size_t *fill7f_bytes) {
-  Carver C;
+// ------------------------------------------------------------------------------------------------
+// Workspace of one frame.  Every array has a lifetime [first, last] in pipeline phases; arrays whose lifetimes do not
+// overlap share addresses (greedy first-fit over the live intervals, largest first), so a 200 k-face frame needs ~55 MB
+// instead of 220 MB and a 288 GB GPU holds > 2000 frames in flight.  Arrays that must start out zero are pinned at the head
+// of the workspace (one k_job_clear launch per batch) and are never shared.
+// Per-vertex / per-entry arrays are sized for `ecap` entries (1.5 x the largest input attribute + slack) instead of the
+// worst case 3 * faces; a mesh that needs more (non-manifold fans, every corner its own vertex) fails with GEO_E_WS_OVERFLOW
+// on the device and is re-encoded alone with worst-case sizes (geo_encode_batch), so the compact layout never costs correctness.
+// Phases (main stream order; the auxiliary stream runs events / valence replay / context scatter between PH_FTIME and PH_HIST):
+enum { PH_DEDUP = 0, PH_FACES, PH_CT, PH_FANS0, PH_DENSE0, PH_WALK, PH_FTIME, PH_RENUM, PH_SEAMS, PH_DENSE1, PH_TRAV, PH_V2D, PH_QUANT,
+       PH_PRED, PH_HIST, PH_ENT, PH_LAYOUT, PH_PINNED = -1 };
+
+// Collects the arrays of job J (sizes from its input counts) and sets the capacities stored in J.  full = worst-case sizes.
+void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
+  items.clear();
   const size_t nfi = J.nf_in, nc = 3 * nfi;
-  const uint32_t maxq = (uint32_t)std::max(J.qp, std::max(J.qt, J.qn));
-  const uint32_t alpha_big = (1u << (maxq + 1)) + 8;
-#define CARVE(field, T, count) do { size_t o_ = C.take<T>(count); if (base) field = (T *)(base + o_); } while (0)
-  // ---- zero-initialised region ----
+  const size_t vmax = std::max<size_t>(J.n_pos, std::max<size_t>(J.n_uv, J.n_nrm));
+  const size_t ecap = full ? nc + 3 : std::min(nc + 3, vmax + vmax / 2 + 4096);
+  J.ecap = (uint32_t)ecap;
+  auto bitlen = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };
+#define CARVE(field, T, count, first, last) items.push_back(WsItem{(size_t)((char *)&(field) - (char *)&J), (size_t)(count) * sizeof(T), (first), (last), 0})
+  // ---- pinned, zero-initialised ----
   for (int k = 0; k < 3; k++) {
-    uint32_t n = k == 0 ? J.n_pos : (k == 1 ? J.n_uv : J.n_nrm);
+    const uint32_t n = k == 0 ? J.n_pos : (k == 1 ? J.n_uv : J.n_nrm);
     J.dd_cap[k] = pow2_at_least(2ull * n + 2);
-    CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k]);
+    CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k], PH_PINNED, PH_PINNED);
   }
-  CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1);
-  CARVE(J.fvis, uint8_t, nfi + 64); CARVE(J.vvis, uint8_t, nc + 64); CARVE(J.f2split, int32_t, 4);
-  for (int t = 0; t < 3; t++) { CARVE(J.t_fvis[t], uint8_t, nfi + 64); CARVE(J.t_vvis[t], uint8_t, nc + 64); }
+  CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
+  CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
+  for (int t = 0; t < 3; t++) CARVE(J.t_vvis[t], uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int s = 0; s < GEO_NSTREAM; s++) {
-    J.rs[s].alpha_cap = s < 6 ? 8 : alpha_big;
-    CARVE(J.rs[s].freq, uint32_t, J.rs[s].alpha_cap);
+    const int q = s == 6 ? J.qp : (s == 7 ? J.qt : J.qn);
+    J.rs[s].alpha_cap = s < 6 ? 8 : (1u << (q + 1)) + 8;
+    CARVE(J.rs[s].freq, uint32_t, J.rs[s].alpha_cap, PH_PINNED, PH_PINNED);
   }
-  *zero_bytes = (C.off + 255) & ~(size_t)255;
-  // ---- face encode times (preset to -1 by k_pack_faces, filled by k_face_time) ----
-  CARVE(J.face_time, int32_t, nfi + 1);
-  *fill7f_bytes = ((C.off + 255) & ~(size_t)255) - *zero_bytes;
-  // ---- the rest ----
-  CARVE(J.canon[0], uint32_t, J.n_pos + 1); CARVE(J.canon[1], uint32_t, J.n_uv + 1); CARVE(J.canon[2], uint32_t, J.n_nrm + 1);
-  CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1); CARVE(J.he_ent, unsigned long long, nc + 1);
-  CARVE(J.keep, uint8_t, nfi + 1); CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8); CARVE(J.bsum2, uint32_t, nc / UVOL_BLOCK + 8);
-  CARVE(J.cp, int32_t, nc + 3); CARVE(J.cu, int32_t, nc + 3); CARVE(J.cn, int32_t, nc + 3);
-  CARVE(J.opp, int32_t, nc + 3); CARVE(J.vert, int32_t, nc + 3); CARVE(J.ring, int32_t, nc + 3); CARVE(J.vopen, uint8_t, nc + 3);
-  CARVE(J.vval, int32_t, nc + nfi + 3); CARVE(J.c2vm, int32_t, nc + 3);
-  CARVE(J.proc, int32_t, nfi + 1); CARVE(J.initc, int32_t, nfi + 1); CARVE(J.stack, int32_t, nfi + 2);
-  for (int w = 0; w < 4; w++) { CARVE(J.rec[w], int32_t, 16 * (nfi + 1)); CARVE(J.vopen_d[w], uint8_t, nc + 3); }
-  CARVE(J.ring_d, int32_t, nc + 3);
-  for (int z = 0; z < 3; z++) { CARVE(J.dflagT[z], uint8_t, nc + 3); CARVE(J.dtmpT[z], int32_t, nc + 3); CARVE(J.bsumT[z], uint32_t, nc / UVOL_BLOCK + 8); }
-  CARVE(J.symb, uint8_t, nfi + 64); CARVE(J.ctx_of, uint8_t, nfi + 64);
-  CARVE(J.ev_src, int32_t, 2 * nfi + 2); CARVE(J.ev_spl, int32_t, 2 * nfi + 2); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2);
-  for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1);
-  CARVE(J.start_bits, uint8_t, nfi + 1);
-  CARVE(J.old_of_new, int32_t, nc + 3); CARVE(J.new_of_old, int32_t, nc + 3); CARVE(J.nopp, int32_t, nc + 3);
-  CARVE(J.npid, int32_t, nc + 3); CARVE(J.nuid, int32_t, nc + 3); CARVE(J.nnid, int32_t, nc + 3);
-  CARVE(J.bvert, int32_t, nc + 3); CARVE(J.bopen, uint8_t, nc + 3);
-  for (int i = 0; i < 2; i++) { CARVE(J.seam[i], uint8_t, nc + 3); CARVE(J.seam_bits[i], uint8_t, nc + 3); CARVE(J.avert[i], int32_t, nc + 3); CARVE(J.aopen[i], uint8_t, nc + 3); }
-  CARVE(J.elig, uint8_t, nc + 3);
-  for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, nc + 3); CARVE(J.v2d[t], int32_t, nc + 3); CARVE(J.t_stack[t], int32_t, nfi + 2); }
-  CARVE(J.P, int32_t, 3 * nc + 3); CARVE(J.U, int32_t, 2 * nc + 3); CARVE(J.O, int32_t, 2 * nc + 3);
-  CARVE(J.sym_pos, uint32_t, 3 * nc + 3); CARVE(J.sym_uv, uint32_t, 2 * nc + 3); CARVE(J.sym_nrm, uint32_t, 2 * nc + 3);
-  CARVE(J.has_ori, uint8_t, nc + 3); CARVE(J.ori_val, uint8_t, nc + 3); CARVE(J.ori_c, uint8_t, nc + 3); CARVE(J.ori_bits, uint8_t, nc + 3); CARVE(J.flips, uint8_t, nc + 3);
+  // ---- scan scratch (tiny, kept for the whole batch) ----
+  CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT); CARVE(J.bsum2, uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT);
+  for (int z = 0; z < 3; z++) CARVE(J.bsumT[z], uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT);
+  // ---- K2 / K3 ----
+  CARVE(J.canon[0], uint32_t, J.n_pos + 1, PH_DEDUP, PH_FACES); CARVE(J.canon[1], uint32_t, J.n_uv + 1, PH_DEDUP, PH_FACES); CARVE(J.canon[2], uint32_t, J.n_nrm + 1, PH_DEDUP, PH_FACES);
+  CARVE(J.keep, uint8_t, nfi + 1, PH_FACES, PH_FACES);
+  CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_RENUM);
+  CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_CT); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_CT);
+  CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_PRED);                     // events / valence replay (auxiliary stream) read it until the join
+  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_PRED); CARVE(J.ring, int32_t, nc + 3, PH_FANS0, PH_DENSE0); CARVE(J.vopen, uint8_t, nc + 3, PH_FANS0, PH_DENSE0);
+  // ---- K4 ----
+  CARVE(J.dflagT[0], uint8_t, nc + 3, PH_DENSE0, PH_DENSE1); CARVE(J.dtmpT[0], int32_t, nc + 3, PH_DENSE0, PH_DENSE1);
+  for (int z = 1; z < 3; z++) { CARVE(J.dflagT[z], uint8_t, nc + 3, PH_DENSE1, PH_DENSE1); CARVE(J.dtmpT[z], int32_t, nc + 3, PH_DENSE1, PH_DENSE1); }
+  const size_t rec_bytes = (r8 ? 32 : 64) * (nfi + 1);
+  CARVE(J.rec[0], uint8_t, rec_bytes, PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_DENSE0, PH_DENSE0);
+  for (int w = 1; w < 4; w++) { CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D); CARVE(J.vopen_d[w], uint8_t, ecap, PH_DENSE1, PH_DENSE1); }
+  CARVE(J.ring_d, int32_t, ecap, PH_DENSE0, PH_PRED);
+  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, PH_PRED);
+  CARVE(J.proc, int32_t, nfi + 1, PH_WALK, PH_PRED); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, PH_PRED);
+  CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_RENUM); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
+  // auxiliary stream (forked after PH_FTIME, joined before PH_HIST)
+  CARVE(J.evcnt, uint8_t, nfi + 1, PH_RENUM, PH_PRED);
+  CARVE(J.ev_src, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_spl, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT);
+  CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, PH_PRED); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, PH_PRED); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, PH_PRED);
+  for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1, PH_RENUM, PH_ENT);
+  // ---- renumbering, seams ----
+  CARVE(J.old_of_new, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
+  CARVE(J.npid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nuid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nnid, int32_t, nc + 3, PH_RENUM, PH_QUANT);
+  CARVE(J.bvert, int32_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.bopen, uint8_t, nc + 3, PH_SEAMS, PH_DENSE1);
+  for (int i = 0; i < 2; i++) {
+    CARVE(J.seam[i], uint8_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.seam_bits[i], uint8_t, nc + 3, PH_SEAMS, PH_ENT);
+    CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.aopen[i], uint8_t, nc + 3, PH_SEAMS, PH_DENSE1);
+  }
+  CARVE(J.elig, uint8_t, nc + 3, PH_SEAMS, PH_SEAMS);
+  // ---- K5, K1, K6 ----
+  for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, ecap, PH_TRAV, PH_PRED); CARVE(J.v2d[t], int32_t, ecap, PH_V2D, PH_PRED); CARVE(J.t_stack[t], int32_t, nfi + 2, PH_TRAV, PH_TRAV); }
+  CARVE(J.P, int32_t, 3 * ecap, PH_QUANT, PH_PRED); CARVE(J.U, int32_t, 2 * ecap, PH_QUANT, PH_PRED); CARVE(J.O, int32_t, 2 * ecap, PH_QUANT, PH_PRED);
+  CARVE(J.sym_pos, uint32_t, 3 * ecap, PH_PRED, PH_ENT); CARVE(J.sym_uv, uint32_t, 2 * ecap, PH_PRED, PH_ENT); CARVE(J.sym_nrm, uint32_t, 2 * ecap, PH_PRED, PH_ENT);
+  CARVE(J.has_ori, uint8_t, ecap, PH_PRED, PH_PRED); CARVE(J.ori_val, uint8_t, ecap, PH_PRED, PH_PRED); CARVE(J.ori_c, uint8_t, ecap, PH_PRED, PH_PRED);
+  CARVE(J.ori_bits, uint8_t, ecap, PH_PRED, PH_ENT); CARVE(J.flips, uint8_t, ecap, PH_PRED, PH_ENT);
+  // ---- K7 ----
   for (int s = 0; s < GEO_NSTREAM; s++) {
     RansStream &S = J.rs[s];
-    const size_t nsym = s < 6 ? nfi : (s == 6 ? 3 * nc : 2 * nc);
-    CARVE(S.probs, uint32_t, S.alpha_cap); CARVE(S.cum, uint32_t, S.alpha_cap);
-    CARVE(S.head, uint8_t, 3 * (size_t)S.alpha_cap + 32);
-    S.pay_cap = (uint32_t)(3 * nsym + 256); CARVE(S.pay, uint8_t, S.pay_cap);
+    const size_t nsym = s < 6 ? nfi : (s == 6 ? 3 * ecap : 2 * ecap);
+    CARVE(S.probs, uint32_t, S.alpha_cap, PH_HIST, PH_LAYOUT); CARVE(S.cum, uint32_t, S.alpha_cap, PH_HIST, PH_LAYOUT);
+    CARVE(S.head, uint8_t, 3 * (size_t)S.alpha_cap + 32, PH_HIST, PH_LAYOUT);
+    S.pay_cap = (uint32_t)(3 * nsym + 256); CARVE(S.pay, uint8_t, S.pay_cap, PH_ENT, PH_LAYOUT);
+    // counting-sort scratch of k_rans_tables: (precision + 2) counters + one slot per symbol of the alphabet
+    const int bl = bitlen(S.alpha_cap), pb = std::min(20, std::max(12, 3 * bl / 2));
+    CARVE(S.scratch, uint32_t, ((size_t)1 << pb) + 4 + S.alpha_cap, PH_HIST, PH_HIST);
     S.syms = nullptr; S.n = 0; S.max_sym = 0; S.head_len = 0; S.pay_len = 0; S.pay_off = 0; S.prec_bits = 12;
   }
-  // each big stream needs its own counting-sort scratch (k_rans_tables runs the 9 streams concurrently)
-  for (int s = 6; s < GEO_NSTREAM; s++) { uint32_t *sc = nullptr; CARVE(sc, uint32_t, (size_t)(1u << 20) + 4 + alpha_big); J.rs[s].scratch = sc; }
-  for (int s = 0; s < 6; s++) { uint32_t *sc = nullptr; CARVE(sc, uint32_t, (size_t)(1u << 12) + 32); J.rs[s].scratch = sc; }
   for (int b = 0; b < GEO_NRABS; b++) {
     RabsStream &B = J.rb[b];
-    const size_t nb = b == 0 ? nfi : nc;
-    B.cap = (uint32_t)(nb / 4 + nb / 8 + 256); CARVE(B.buf, uint8_t, B.cap);
+    const size_t nb = b == 0 ? nfi : (b < 3 ? nc : ecap);
+    B.cap = (uint32_t)(nb / 4 + nb / 8 + 256); CARVE(B.buf, uint8_t, B.cap, PH_ENT, PH_LAYOUT);
     B.bits = nullptr; B.n = 0; B.zeros = 0; B.off = 0; B.len = 0;
   }
-  J.arena_cap = (uint32_t)(20 * nfi + 1024); CARVE(J.arena, uint8_t, J.arena_cap);
+  J.arena_cap = (uint32_t)(20 * nfi + 1024); CARVE(J.arena, uint8_t, J.arena_cap, PH_LAYOUT, PH_LAYOUT);
 #undef CARVE
-  return (C.off + 255) & ~(size_t)255;
+}
+
+// first-fit placement over the lifetime intervals; pinned items first (they form the zeroed head)
+void ws_place(std::vector<WsItem> &items, WsPlan &P) {
+  auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  for (auto &it : items) if (it.first == PH_PINNED) { it.off = off; off = a256(off + it.bytes); }
+  P.zero = off;
+  std::vector<size_t> order;
+  for (size_t i = 0; i < items.size(); i++) if (items[i].first != PH_PINNED) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].bytes > items[b].bytes; });
+  std::vector<size_t> placed; std::vector<std::pair<size_t, size_t>> busy;
+  size_t total = P.zero;
+  for (size_t i : order) {
+    WsItem &it = items[i];
+    busy.clear();
+    for (size_t j : placed) if (items[j].first <= it.last && it.first <= items[j].last) busy.emplace_back(items[j].off, a256(items[j].off + items[j].bytes));
+    std::sort(busy.begin(), busy.end());
+    size_t cur = P.zero;
+    for (auto &b : busy) { if (cur + it.bytes <= b.first) break; cur = std::max(cur, b.second); }
+    it.off = cur; total = std::max(total, a256(cur + it.bytes));
+    placed.push_back(i);
+  }
+  static const bool dump = [] { const char *e = getenv("UVOL_WS_DUMP"); return e && *e == '1'; }();
+  if (dump) {
+    fprintf(stderr, "[uvol-ws] zero head %.2f MB, total %.2f MB\n", P.zero / 1e6, total / 1e6);
+    for (int ph = 0; ph <= PH_LAYOUT; ph++) { size_t live = 0; for (auto &it : items) if (it.first != PH_PINNED && it.first <= ph && ph <= it.last) live += a256(it.bytes); fprintf(stderr, "[uvol-ws]   phase %2d: %.2f MB live\n", ph, live / 1e6); }
+  }
+  P.total = total; P.offs.resize(items.size());
+  for (size_t i = 0; i < items.size(); i++) P.offs[i] = items[i].off;
+}
+
+// Lays out one job's workspace (sizes + capacities always; pointers when base != nullptr).  The placement is cached for runs
+// of jobs with the same dimensions (a sequence's frames usually are).
+size_t layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlan &P, std::vector<WsItem> &items) {
+  ws_collect(J, full, r8, items);
+  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25), items.size() };
+  if (key != P.key) { ws_place(items, P); P.key = key; }
+  if (base) for (size_t i = 0; i < items.size(); i++) *reinterpret_cast<uint8_t **>((char *)&J + items[i].slot) = base + P.offs[i];
+  return P.total;
 }
 }  // namespace
 
+// Upper bound of a .drc for quantisation bits <= 16: per value <= 2.5 bytes of rANS payload (20-bit precision) + 3 bytes of
+// probability table per distinct symbol, 21 values per face at most; connectivity symbols, seam / orientation bits and the
+// split events stay below 20 bytes per face; fixed headers and the zero runs of three 2^17-symbol tables below 64 KiB.
 size_t uvol_mesh_bound(const uvol_mesh *m) {
   if (!m) return 0;
-  return 4096 + (size_t)m->n_faces * 3 * 24;
+  return 65536 + (size_t)m->n_faces * 144;
 }
 
 #define LAUNCH(k, grid, block, ...)                                                              \
@@ -1712,51 +1792,78 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
   for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * UVOL_BLOCK) p[i] = make_uint4(0, 0, 0, 0);
 }
 
-// LDS sizing of the serial walkers for a batch: the largest face count and attribute-value count (see geo_encode_batch)
-static bool walk_lds_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t *lds_bytes, int *vcap_words, bool vertex_bits_global = false) {
+// How the serial walkers of a batch run.  Wave-per-walker (one lane of a wave per walker, visited bitmaps in LDS) is the
+// faster form per walker (one dependent load per face, 0.35 - 0.5 us) but a CU's LDS holds 3 of them; lane-per-walker (SIMT,
+// nothing in LDS, 0.55 - 0.65 us per face at 16 lanes per wave) has no such cap.  So: LDS walkers while all of a launch's
+// walkers are resident at once, SIMT walkers beyond that (measured on 720 frames in one launch: traversals 265 -> 135 ms).
+// UVOL_SIMT_W=<1..64> forces the SIMT form with that many lanes per wave, UVOL_WALK_FORCE=global its one-lane-per-wave form
+// (what a mesh too large for LDS gets), UVOL_WALK_FORCE=vglobal LDS walkers with their vertex bitmap in global memory (tests).
+struct WalkPlan { int simt_w; size_t lds; int vcw; };
+static inline int geo_simt_env() { static const int w = [] { const char *e = getenv("UVOL_SIMT_W"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return w; }
+static WalkPlan walk_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t n_walkers, bool vertex_bits_global = false) {
+  WalkPlan P{0, 0, 0};
   const size_t walk_fw = ((size_t)max_nfi + 31) / 32;
   // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
   // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
   // whatever fits the same number of walkers per CU, so the slack of the LDS slot is not wasted.
   const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4;
   const size_t v_min_bytes = std::min<size_t>((((size_t)max_vals + max_vals / 16 + 31) / 32 + 2) * 4, ((3 * (size_t)max_nfi + 31) / 32) * 4);
-  size_t per_cu = lds_cu / (fw_bytes + v_min_bytes); if (per_cu < 1) per_cu = 1;
-  const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
-  // UVOL_WALK_FORCE (tests): "vglobal" = vertex bitmaps in global memory, "global" = both bitmaps in global memory
   static const int walk_force = [] { const char *e = getenv("UVOL_WALK_FORCE"); return !e ? 0 : (!strcmp(e, "vglobal") ? 1 : (!strcmp(e, "global") ? 2 : 0)); }();
-  const size_t walk_vcw = (walk_force == 1 || vertex_bits_global) ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
-  const size_t walk_lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4;
-  *lds_bytes = walk_lds; *vcap_words = walk_vcw;
-  return walk_lds <= G->max_lds && walk_force != 2;
+  const bool vglobal = walk_force == 1 || vertex_bits_global;
+  size_t per_cu = lds_cu / (fw_bytes + (vglobal ? 4 : v_min_bytes)); if (per_cu < 1) per_cu = 1;
+  const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
+  const size_t walk_vcw = vglobal ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
+  P.lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4; P.vcw = (int)walk_vcw;
+  const bool lds_fits = P.lds <= G->max_lds;
+  if (geo_simt_env() > 0) P.simt_w = geo_simt_env();
+  else if (walk_force == 2 || !lds_fits) P.simt_w = 1;
+  else if (walk_force == 0 && n_walkers > per_cu * (size_t)G->num_cu) P.simt_w = n_walkers >= 1024 ? 16 : 4;
+  return P;
 }
-
-// attribute sequencing of a prepared GeoJob array (tables 1..3): corner records, DepthFirstTraverser, inverse maps.
-// Shared with the decode path (geom_decode.hip), which fills the same job fields from a decoded corner table.
 // 8-byte corner records (RecOps<true>): every corner code (< 4 * faces, signed field: 20 bits + sign) and every
 // vertex id << 1 | open (< 6 * faces, unsigned 21-bit field) of the batch must fit, i.e. faces < 2^18; UVOL_REC16=1 (tests)
 // forces the 16-byte format
-// UVOL_SIMT_W=<1..64> (diagnostic / tests): lane-per-walker kernels with that many lanes used per wave; 0 / unset = wave-per-walker
-static inline int geo_simt_w() { static const int w = [] { const char *e = getenv("UVOL_SIMT_W"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return w; }
-static inline bool geo_rec8(bool use_lds, uint32_t max_nfi) {
+static inline bool geo_rec8(uint32_t max_nfi) {
   static const bool force16 = [] { const char *e = getenv("UVOL_REC16"); return e && *e == '1'; }();
-  return (use_lds || geo_simt_w() > 0) && !force16 && 4ull * max_nfi < (1ull << 20);
+  return !force16 && 4ull * max_nfi < (1ull << 20);
 }
+static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
+  const unsigned N = (unsigned)n;
+  if (P.simt_w) { const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
+  else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), P.lds, dj, P.vcw, uvol_debug() ? 1 : 0);
+  else LAUNCH_SM((k_traverse<false>), dim3(3, N), dim3(64), P.lds, dj, P.vcw, uvol_debug() ? 1 : 0);
+}
+// attribute sequencing of a prepared GeoJob array (tables 1..3): corner records, DepthFirstTraverser, inverse maps.
+// Shared with the decode path (geom_decode.hip), which fills the same job fields from a decoded corner table.
 int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint32_t max_vals) {
   GeoState *G = ctx->geo;
   const unsigned N = (unsigned)n, bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi);
-  size_t walk_lds = 0; int vcw = 0;
-  const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &vcw);
-  const int r8 = geo_rec8(use_lds, max_nfi) ? 1 : 0;
+  const WalkPlan P = walk_plan(G, max_nfi, max_vals, (size_t)3 * N);
+  const int r8 = geo_rec8(max_nfi) ? 1 : 0;
   for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w, r8);
-  if (const int W = geo_simt_w()) { const unsigned nb = (3 * N + (unsigned)W - 1) / (unsigned)W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, W); }
-  else if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), walk_lds, dj, vcw, uvol_debug() ? 1 : 0); }
-  else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 0, 0);
+  launch_traversals(ctx, dj, n, P, r8);
   LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
   return UVOL_OK;
 }
 
+// device workspace one frame of these dimensions holds while it is in flight (compact layout + its share of the packed output area)
+extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
+  if (!ctx || !m || !m->n_faces) return 0;
+  GeoJob J{}; J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
+  J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
+  WsPlan P; std::vector<WsItem> items;
+  return layout_job(J, nullptr, false, geo_rec8(m->n_faces), P, items) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
+}
+static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
+                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full);
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  return geo_encode_batch_impl(ctx, meshes, n, on_device, outs, caps, out_lens, status, false);
+}
+
+// full = worst-case workspace and output sizes (the retry of a frame the compact layout could not hold)
+static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
+                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full) {
   GeoState *G = ctx->geo;
   if (n <= 0) return UVOL_OK;
   static const bool timing = [] { const char *e = getenv("UVOL_TIMING"); return e && *e == '1'; }();       // diagnostic: host-side phases of a batch on stderr
@@ -1770,9 +1877,11 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   // geometric-normal prediction, RAW rANS), which any Draco decoder reads; the shims say so on stderr
   if (prm.draco_compression_level < 0 || prm.draco_compression_level > 10) { ctx->set_error("DRACO_COMPRESSION_LEVEL %d outside 0..10", prm.draco_compression_level); return UVOL_E_INVALID; }
   G->hjobs.assign((size_t)n, GeoJob{});
-  std::vector<size_t> ws_off(n), in_off(n), out_off(n), zero_sz(n);
+  std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
   uint32_t max_nfi = 0, max_vals = 0; uint64_t algo_in = 0;
+  for (int i = 0; i < n; i++) max_nfi = std::max(max_nfi, meshes[i].n_faces);
+  const int r8 = geo_rec8(max_nfi) ? 1 : 0;
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
@@ -1781,14 +1890,16 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
     { int k = 0; if (J.has_uv) J.att_kind[k++] = 0; if (J.has_nrm) J.att_kind[k++] = 1; for (; k < 2; k++) J.att_kind[k] = -1; }
-    size_t zb, f7; size_t sz = layout_job(J, nullptr, &zb, &f7);
-    ws_off[i] = ws_total; ws_total += sz; zero_sz[i] = zb;
+    const size_t sz = layout_job(J, nullptr, full, r8 != 0, G->plan, G->items);
+    ws_off[i] = ws_total; ws_total += sz; zero_sz[i] = G->plan.zero;
     const size_t in_sz = ((size_t)m.n_pos * 12 + 255) / 256 * 256 + ((size_t)J.n_uv * 8 + 255) / 256 * 256 + ((size_t)J.n_nrm * 12 + 255) / 256 * 256 +
                          (size_t)(1 + J.has_uv + J.has_nrm) * (((size_t)m.n_faces * 12 + 255) / 256 * 256);
     in_off[i] = in_total; in_total += on_device ? 0 : in_sz;
-    size_t oc = std::min(caps[i], uvol_mesh_bound(&m)); oc = (oc + 255) & ~(size_t)255;
-    out_off[i] = out_total; out_total += oc; J.out_cap = (uint32_t)std::min<size_t>(caps[i], 0xffffffffu);
-    max_nfi = std::max(max_nfi, m.n_faces); max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm)));
+    // the frames' streams are packed back to back (k_out_offsets), so the batch's output area is sized for typical streams
+    // (8 bytes per face; the defaults give 1.3), not for the sum of the callers' capacities; GEO_E_SLAB_FULL -> retried alone
+    const size_t oc = full ? caps[i] : std::min<size_t>(caps[i], 32768 + 8 * (size_t)m.n_faces);
+    out_total += (oc + 255) & ~(size_t)255; J.out_cap = (uint32_t)std::min<size_t>(caps[i], 0xffffffffu);
+    max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm)));
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
   int rc;
@@ -1799,9 +1910,9 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     uint8_t *base = (uint8_t *)G->slab.p + ws_off[i];
-    size_t zb, f7; layout_job(J, base, &zb, &f7);
+    (void)layout_job(J, base, full, r8 != 0, G->plan, G->items);
     J.ws_base = base; J.ws_zero = zero_sz[i];          // cleared by ONE k_job_clear launch for the whole batch (was 2 memsets per frame)
-    J.out = (uint8_t *)G->outs.p + out_off[i]; J.out_pack = (uint8_t *)G->outs.p;
+    J.out_pack = (uint8_t *)G->outs.p; J.slab_cap = out_total;
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
     else {
       uint8_t *ib = (uint8_t *)G->inputs.p + in_off[i]; size_t o = 0;
@@ -1848,15 +1959,13 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
   }
-  size_t walk_lds = 0; int walk_vcw = 0;
-  const bool use_lds = walk_lds_plan(G, max_nfi, max_vals, &walk_lds, &walk_vcw);
-  const int r8 = geo_rec8(use_lds, max_nfi) ? 1 : 0;
+  const WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)N);
   {
     DENSE_PACK(0, 1);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (const int W = geo_simt_w()) { const unsigned nb = (N + (unsigned)W - 1) / (unsigned)W; if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, W); }
-    else if (use_lds) { if (r8) LAUNCH_SM((k_eb_walk<true, true>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); else LAUNCH_SM((k_eb_walk<true, false>), dim3(N), dim3(64), walk_lds, dj, walk_vcw); }
-    else LAUNCH((k_eb_walk<false, false>), dim3(N), dim3(64), dj, 0);
+    if (wp_walk.simt_w) { const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W; if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
+    else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), wp_walk.lds, dj, wp_walk.vcw);
+    else LAUNCH_SM((k_eb_walk<false>), dim3(N), dim3(64), wp_walk.lds, dj, wp_walk.vcw);
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
@@ -1886,15 +1995,11 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
   {
     DENSE_PACK(1, 3);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
-    // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): the traversers keep only the face bitmap in LDS (25 KB -> 6 per
+    // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): LDS traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
     static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
     const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
-    size_t t_lds = walk_lds; int t_vcw = walk_vcw;
-    if (tvg) (void)walk_lds_plan(G, max_nfi, max_vals, &t_lds, &t_vcw, true);
-    if (const int W = geo_simt_w()) { const unsigned nb = (3 * N + (unsigned)W - 1) / (unsigned)W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, W); }
-    else if (use_lds) { if (r8) LAUNCH_SM((k_traverse<true, true>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); else LAUNCH_SM((k_traverse<true, false>), dim3(3, N), dim3(64), t_lds, dj, t_vcw, uvol_debug() ? 1 : 0); }
-    else LAUNCH((k_traverse<false, false>), dim3(3, N), dim3(64), dj, 0, 0);
+    launch_traversals(ctx, dj, n, walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg), r8);
     LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
   }
   {
@@ -1950,15 +2055,26 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_devi
     UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   const double t_d2h = ms_since(t_enter);
+  std::vector<int> retry;
   for (int i = 0; i < n; i++) {
     const GeoJob &J = G->hjobs[i];
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
     out_lens[i] = J.out_len;
     if (st == UVOL_OK) memcpy(outs[i], G->pinned + J.out_pack_off, J.out_len);
+    else if (!full && (J.status == GEO_E_WS_OVERFLOW || J.status == GEO_E_SLAB_FULL)) { retry.push_back(i); st = UVOL_OK; }
     else { ctx->set_error("mesh %d: encode failed (device status %d)", i, J.status); worst = st; }
     if (status) status[i] = st;
   }
   ctx->resolve_profile();
+  // frames the compact workspace (or the packed output area) could not hold: once more, alone, with worst-case sizes
+  for (int i : retry) {
+    if (timing) fprintf(stderr, "[uvol-timing] mesh %d: device status %d, re-encoding with worst-case workspace\n", i, G->hjobs.empty() ? 0 : 0);
+    int st1 = UVOL_OK;
+    const int rc1 = geo_encode_batch_impl(ctx, meshes + i, 1, on_device, outs + i, caps + i, out_lens + i, &st1, true);
+    if (rc1 != UVOL_OK) return rc1;
+    if (status) status[i] = st1;
+    if (st1 != UVOL_OK) worst = st1;
+  }
   if (timing) fprintf(stderr, "[uvol-timing] geo batch n=%d sizeof(GeoJob)=%zu: enqueued %.1f ms, gpu done %.1f, packed d2h %.1f, copied out %.1f (enter at %.1f)\n", n, sizeof(GeoJob), t_enq, t_gpu, t_d2h, ms_since(t_enter),
                       std::chrono::duration<double, std::milli>(t_enter.time_since_epoch()).count());
   return status ? UVOL_OK : worst;

@@ -35,7 +35,7 @@ class Mesh(C.Structure):
 
 
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
-           "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_encode_mesh", "uvol_encode_mesh_batch",
+           "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
@@ -53,6 +53,7 @@ def load(path=None):
     L.uvol_last_error.argtypes = [C.c_void_p]; L.uvol_last_error.restype = C.c_char_p
     L.uvol_sync.argtypes = [C.c_void_p]
     L.uvol_mesh_bound.argtypes = [C.POINTER(Mesh)]; L.uvol_mesh_bound.restype = C.c_size_t
+    L.uvol_mesh_workspace.argtypes = [C.c_void_p, C.POINTER(Mesh)]; L.uvol_mesh_workspace.restype = C.c_size_t
     L.uvol_encode_mesh.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     for nm in ("uvol_encode_mesh_batch", "uvol_encode_mesh_batch_dev"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -132,6 +133,11 @@ class Codec:
         if nrm is not None and idx_nrm is not None:
             m.nrm = nrm.ctypes.data; m.n_nrm = len(nrm); m.idx_nrm = idx_nrm.ctypes.data
         return m, (pos, uv, nrm, idx_pos, idx_uv, idx_nrm)
+
+    def mesh_workspace(self, pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None) -> int:
+        """Device bytes one frame of these dimensions holds while in flight."""
+        m, keep = self._mesh_host(pos, idx_pos, uv, idx_uv, nrm, idx_nrm)
+        return int(self.L.uvol_mesh_workspace(self.h, C.byref(m)))
 
     def encode_mesh(self, pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None) -> bytes:
         return self.encode_mesh_batch([dict(pos=pos, idx_pos=idx_pos, uv=uv, idx_uv=idx_uv, nrm=nrm, idx_nrm=idx_nrm)])[0]
