@@ -55,7 +55,9 @@ typedef struct uvol_params {
                                        (6 instead of 3 per CU): pays off when several contexts keep > 700 frames in flight */
   int32_t stream_priority;          /* 1: create the context's HIP stream with the highest priority (short, LDS-hungry texture
                                        kernels then get free CU slots before the long geometry walkers take them) */
-  int32_t reserved[3];
+  int32_t uastc;                    /* basisu -uastc: 1 = the texture entry points write UASTC LDR 4x4 .ktx2 files (DFD colour model 166, no
+                                       supercompression; every layer an independent image) instead of ETC1S/BasisLZ; default 0 (Encoder.py:290 passes no -uastc) */
+  int32_t reserved[2];
 } uvol_params;
 
 void uvol_params_default(uvol_params *p);
@@ -127,7 +129,8 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
  * Replaces, for the RGBA32 target, what the stock player does per .ktx2 segment: KTX2Loader parses the container and
  * hands every array layer to the basis transcoder (reference src/lib/KTX2Loader.js:469-580; src/V2/player.ts:338-356
  * uploads the layers as one sampler2DArray).  Input: BasisLZ/ETC1S .ktx2 files as uvol_encode_texture_segment[s] or
- * `basisu -ktx2 -tex_type video` write them (no alpha slices, one mip level).  Output: RGBA8, rows in stored order. */
+ * `basisu -ktx2 -tex_type video` write them (no alpha slices, one mip level), or the UASTC .ktx2 files this codec writes with
+ * uvol_params.uastc (told apart by the DFD colour model).  Output: RGBA8, rows in stored order. */
 /* host-only: container dimensions of one file (UVOL_E_INVALID if it is not a KTX2/BasisLZ file this decoder handles) */
 int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, uint32_t *height, uint32_t *layers);
 /* n_segments files of one width / height / layer count; rgba[s * layers + l] receives width*height*4 bytes
@@ -149,6 +152,14 @@ int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *kt
  * weights (endpoint error <= 1, inner colours to the nearest weight); gated by PSNR against the RGBA32 decode, not bit parity. */
 int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                         uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
+
+/* ASTC 4x4 target for UASTC sources (KTX2Loader's first choice for them, reference src/lib/KTX2Loader.js:591-600, :648-689; BASELINE
+ * configs[4] "KTX2 -> ASTC"): blocks[s * layers + l] receives ceil(w/4) * ceil(h/4) 16-byte ASTC blocks in raster order.  A direct
+ * re-pack of the UASTC block (same endpoints and weights; the pair is swapped and the weights mirrored where ASTC would apply blue
+ * contraction; solid blocks become void-extent blocks): an ASTC decoder reproduces the UASTC texels exactly.  ETC1S sources are
+ * rejected with UVOL_E_UNSUPPORTED (the stock player never picks ASTC for them). */
+int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                         uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
 
 /* ---- decode path, geometry half ----
  * Replaces what the stock player obtains from the draco WASM decoder per frame (reference src/V2/player.ts:101, :313-336):

@@ -178,6 +178,9 @@ static void cell_coords(uint32_t cell, int32_t x[4]) { x[0] = expand5((cell >> 1
 
 int ktx2_encode(const uint8_t *const *layers, int L, uint32_t W, uint32_t H, const ktx2_enc_params *prm, orc_buf *out) {
   if (L < 1 || L > KTX2_MAX_LAYERS || W == 0 || H == 0 || W > 16384 || H > 16384) return -1;
+  /* basisu writes alpha slices for images with alpha != 255; neither this restatement nor the product implements them:
+   * both refuse such input (the product with UVOL_E_UNSUPPORTED) instead of dropping the channel */
+  for (int l = 0; l < L; l++) for (size_t i = 0; i < (size_t)W * H; i++) if (layers[l][4 * i + 3] != 255) return -60;
   const int q = clampi(prm && prm->quality > 0 ? prm->quality : 128, 1, 255), yflip = prm ? prm->y_flip : 1;
   const uint32_t bx = (W + 3) / 4, by = (H + 3) / 4, nb = bx * by, NB = nb * (uint32_t)L;
   const uint32_t Kmax_e = (uint32_t)clampi(q * 12, 32, 16128), Kmax_s = (uint32_t)clampi(q * 6, 32, 16128);

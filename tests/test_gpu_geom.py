@@ -97,8 +97,10 @@ def test_gpu_walker_bitmap_placements(oracle):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
-    for force in ("", "vglobal", "global", "rec16"):            # rec16: 16-byte corner records (meshes with >= 2^18 faces), see the shim test
-        env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else dict(os.environ, UVOL_WALK_FORCE=force)
+    # rec16: 16-byte corner records (meshes with >= 2^18 faces); simtN: lane-per-walker kernels, N lanes per wave (large batches);
+    # entwave: the wave-per-stream entropy coder instead of the lane-per-stream one
+    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "entwave"):
+        env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (force, r.stdout[-500:], r.stderr[-1500:])
 
@@ -169,3 +171,39 @@ def test_gpu_baseline_config1_single_50k_vertex_frame(oracle, gpu_codec):
     assert data == _oracle_bytes(oracle, m)
     check_roundtrip(oracle, m, data)
     _check_decoded(oracle, data, gpu_codec.decode_mesh_batch([data])[0])
+
+
+def test_gpu_lane_per_walker_at_bench_size(oracle):
+    """What large batches run (lane-per-walker edgebreaker walk / attribute traversals, lane-per-stream entropy coder) on
+    100k-vertex frames, forced through the environment switches: bit-identical to the default kernels and to the oracle."""
+    import subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import synth, uvol\nimport oracle as o\n"
+        "o.lib(); c = uvol.Codec(device=0)\n"
+        "frames = [synth.sphere_mesh(frame=k, seed=k) for k in range(5)]\n"
+        "res = c.encode_mesh_batch(frames)\n"
+        "f = frames[0]\n"
+        "assert res[0] == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
+        "import hashlib; print('ok', hashlib.sha1(b''.join(res)).hexdigest())\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
+    outs = []
+    for env in (dict(), dict(UVOL_SIMT_W="16", UVOL_ENTROPY_W="8"), dict(UVOL_SIMT_W="3", UVOL_ENTROPY_WAVE="1")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_gpu_compact_workspace_overflow_is_retried(oracle, gpu_codec):
+    """A mesh with far more corner-table vertices than input values overflows the compact per-vertex arrays on the device and
+    is re-encoded alone with worst-case sizes; its batch neighbours are unaffected (see the shim test of the same name)."""
+    import synth
+    rng = np.random.default_rng(1)
+    pos = rng.random((12, 3)).astype(np.float32)
+    idx = rng.integers(0, 12, size=(6000, 3)).astype(np.uint32).reshape(-1)
+    t = synth.torus_mesh()
+    res = gpu_codec.encode_mesh_batch([t, dict(pos=pos, idx_pos=idx), t])
+    assert res[1] == oracle.drc_encode(pos, idx, None, None, None, None)
+    assert res[0] == res[2] == _oracle_bytes(oracle, t)
+    assert gpu_codec.mesh_workspace(**synth.sphere_mesh()) < 80e6

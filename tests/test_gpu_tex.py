@@ -163,3 +163,54 @@ def test_gpu_texture_bc7_target(oracle, gpu_codec):
             assert np.all(got[..., 3] == 255)
             err = np.abs(got[..., :3].astype(np.int32) - want.images[l][..., :3].astype(np.int32))
             assert psnr_rgb(got, want.images[l]) > gate, (l, psnr_rgb(got, want.images[l]), err.max())
+
+
+def test_gpu_uastc_mode_bit_exact(oracle):
+    """UASTC LDR 4x4 mode (uvol_params.uastc = `basisu -uastc`): the .ktx2, its RGBA decode and its ASTC 4x4 transcode are
+    bit-exact against oracle/uastc.c (parity with basisu itself is unpinned, see that file); the transcoded ASTC blocks decode
+    (independent ASTC decoder of the oracle) to exactly the UASTC texels; opaque, alpha, solid and ragged content."""
+    import synth, uvol
+    cd = uvol.Codec(device=0, uastc=1)
+    try:
+        rng = np.random.default_rng(2)
+        tex = synth.texture_sequence(3, size=256, seed=5)
+        tex[1] = tex[1].copy(); tex[1][..., 3] = rng.integers(0, 256, size=tex[1].shape[:2]).astype(np.uint8)
+        tex[2] = tex[2].copy(); tex[2][:128] = 7
+        ragged = [t[:50, :37].copy() for t in synth.texture_sequence(2, size=64, seed=1)]
+        for name, t in (("mixed", tex), ("ragged", ragged)):
+            k = cd.encode_texture_segment(t)
+            assert k == oracle.uastc_ktx2_encode(t), name
+            dec = cd.decode_texture_segments([k])[0]
+            assert np.array_equal(dec, oracle.uastc_ktx2_decode(k)), name
+            astc = cd.transcode_texture_segments_astc([k])[0]
+            assert np.array_equal(astc, oracle.uastc_ktx2_decode(k, "astc")), name
+            px = oracle.astc_decode_blocks(astc.reshape(-1, 16))                       # [blocks, 16 texels, 4]
+            nl, by, bx = astc.shape[:3]
+            img = px.reshape(nl, by, bx, 4, 4, 4).transpose(0, 1, 3, 2, 4, 5).reshape(nl, by * 4, bx * 4, 4)[:, :dec.shape[1], :dec.shape[2]]
+            assert np.array_equal(img, dec), name
+        segs = [synth.texture_sequence(2, size=128, seed=s) for s in range(3)]
+        assert cd.encode_texture_segments(segs) == [oracle.uastc_ktx2_encode(t) for t in segs]
+        with pytest.raises(uvol.UvolError):                                            # ASTC is the target of UASTC sources only
+            etc = uvol.Codec(device=0)
+            try:
+                etc.transcode_texture_segments_astc([etc.encode_texture_segment(segs[0])])
+            finally:
+                etc.close()
+    finally:
+        cd.close()
+
+
+def test_gpu_uastc_roundtrip_at_bench_size():
+    """2048^2 x 5 layers: decode(encode(x)) against x (stored bottom-up), PSNR and size; size-independent check at full size."""
+    import synth, uvol
+    cd = uvol.Codec(device=0, uastc=1)
+    try:
+        tex = synth.texture_sequence(5, size=2048, seed=0)
+        k = cd.encode_texture_segment(tex)
+        assert len(k) < 2048 * 2048 * 5 + 4096
+        dec = cd.decode_texture_segments([k])[0]
+        src = np.stack([np.asarray(a)[::-1] for a in tex]).astype(np.float64)
+        mse = float(np.mean((src[..., :3] - dec[..., :3].astype(np.float64)) ** 2))
+        assert 10 * np.log10(255.0 ** 2 / mse) > 40.0
+    finally:
+        cd.close()

@@ -110,3 +110,41 @@ def test_hipemu_texture_bc7_target(oracle, hipemu_lib):
             err = np.abs(got[..., :3].astype(np.int32) - want.images[l][..., :3].astype(np.int32))
             assert psnr_rgb(got, want.images[l]) > gate, (l, psnr_rgb(got, want.images[l]), err.max())
     cd.close()
+
+
+def test_hipemu_uastc_mode_matches_oracle(oracle, hipemu_lib):
+    """UASTC LDR 4x4 mode through the shim: .ktx2, RGBA decode and ASTC 4x4 transcode bit-exact against oracle/uastc.c."""
+    import numpy as np
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib, uastc=1)
+    rng = np.random.default_rng(2)
+    tex = synth.texture_sequence(3, size=64, seed=5)
+    tex[1] = tex[1].copy(); tex[1][..., 3] = rng.integers(0, 256, size=tex[1].shape[:2]).astype(np.uint8)
+    tex[2] = tex[2].copy(); tex[2][:32] = 7
+    ragged = [t[:50, :37].copy() for t in synth.texture_sequence(2, size=64, seed=1)]
+    for t in (tex, ragged):
+        k = cd.encode_texture_segment(t)
+        assert k == oracle.uastc_ktx2_encode(t)
+        assert np.array_equal(cd.decode_texture_segments([k])[0], oracle.uastc_ktx2_decode(k))
+        assert np.array_equal(cd.transcode_texture_segments_astc([k])[0], oracle.uastc_ktx2_decode(k, "astc"))
+    assert cd.ktx2_info(k) == (37, 50, 2)
+    cd.close()
+
+
+def test_hipemu_etc1s_refuses_alpha(oracle, hipemu_lib):
+    """basisu would write alpha slices for a non-opaque image; this codec's ETC1S path has none, so it fails loudly (as does the
+    oracle) instead of dropping the channel — and the UASTC mode takes the same image."""
+    import numpy as np, pytest
+    import synth, uvol
+    tex = synth.texture_sequence(2, size=32, seed=4)
+    tex[1] = tex[1].copy(); tex[1][5, 7, 3] = 254
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    with pytest.raises(uvol.UvolError, match="alpha"):
+        cd.encode_texture_segment(tex)
+    assert cd.encode_texture_segment([tex[0]]) == oracle.ktx2_encode([tex[0]])       # the context stays usable
+    cd.close()
+    with pytest.raises(ValueError):
+        oracle.ktx2_encode(tex)
+    cu = uvol.Codec(lib_path=hipemu_lib, uastc=1)
+    assert cu.encode_texture_segment(tex) == oracle.uastc_ktx2_encode(tex)
+    cu.close()

@@ -75,8 +75,71 @@ def test_uvolenc_hipemu_pipeline(oracle, tmp_path):
         got = open(os.path.join(out, "texture_ktx2_baseColor_default", "%05d.ktx2" % s), "rb").read()
         assert got == oracle.ktx2_encode(texs[3 * s:3 * s + n])
     assert r.stdout.index("Obtained DRACO files") < r.stdout.index("Obtained KTX2 files")
-    if shutil.which("node"):
-        urls = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "player_urls.js"), os.path.join(out, "uvol.json")], text=True))
-        assert len(urls["geometry"]) == 7 and len(urls["texture"]) == 3
+    assert shutil.which("node"), "node (>= 12) is part of this container: the player-URL check must run, not be skipped"
+    import player_urls
+    urls = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "player_urls.js"), os.path.join(out, "uvol.json")], text=True))
+    assert urls == player_urls.resolve(os.path.join(out, "uvol.json"))          # the Python restatement used on the GPU box agrees with the node one
+    assert len(urls["geometry"]) == 7 and len(urls["texture"]) == 3
+    for rel in urls["geometry"] + urls["texture"]:
+        assert os.path.isfile(os.path.join(out, rel)), rel
+
+
+def test_uvolenc_hipemu_targets_etc2_and_multi_gpu_plan(oracle, tmp_path):
+    """`--targets ktx2,etc2` (src/Interfaces.ts:19, :60-73): one raw ETC2-RGB block image per frame next to the KTX2
+    segments, both targets in the manifest; a renderer with the ETC extension picks `etc2` (src/V2/player.ts:208-222) and every URL
+    resolves; the blocks decode (independent ETC1 decoder of tests/helpers.py) to the RGBA decode of the segment.  `--gpus 2` on
+    the one emulated device exercises the segment-aligned frame blocks of shard_plan (same files as one GPU)."""
+    import shutil
+    import numpy as np
+    import cli_helpers, helpers, player_urls
+    pkg = os.path.join(ROOT, "universal-volumetric_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "hipemu-bins"])
+    cfgp, cfg, meshes, texs = cli_helpers.make_sequence(str(tmp_path), n_frames=7, tex=32, batch=3)
+    r = subprocess.run([os.path.join(ROOT, "tests", "hipemu", "bin", "uvolenc"), cfgp, "--batch-frames", "3", "--targets", "ktx2,etc2"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = cfg["OutputDirectory"]
+    man = json.load(open(os.path.join(out, "uvol.json")))
+    assert set(man["texture"]["targets"]) == {"ktx2", "etc2"}
+    e = man["texture"]["targets"]["etc2"]
+    assert (e["format"], e["sequenceSize"], e["sequenceCount"], e["resolution"], e["frameRate"]) == ("etc2", 1, 7, [32, 32], 30)
+    for supports, want in ((False, "ktx2"), (True, "etc2")):
+        urls = player_urls.resolve(os.path.join(out, "uvol.json"), supports_etc2=supports)
+        assert urls["textureTarget"] == want
+        if shutil.which("node"):
+            js = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "tests", "player_urls.js"), os.path.join(out, "uvol.json")] + (["--supports", "etc2"] if supports else []), text=True))
+            assert js == urls
         for rel in urls["geometry"] + urls["texture"]:
             assert os.path.isfile(os.path.join(out, rel)), rel
+    assert urls["texture"] == ["texture_etc2_baseColor_default/%05d.etc2" % k for k in range(7)] and urls["batchSize"] == 1
+    for s, n in enumerate([3, 3, 1]):
+        ref = oracle.ktx2_decode(open(os.path.join(out, "texture_ktx2_baseColor_default", "%05d.ktx2" % s), "rb").read())
+        for l in range(n):
+            raw = np.frombuffer(open(os.path.join(out, "texture_etc2_baseColor_default", "%05d.etc2" % (3 * s + l)), "rb").read(), np.uint8)
+            assert raw.size == 8 * 8 * 8
+            assert np.array_equal(helpers.etc1_decode_blocks(raw.reshape(8, 8, 8), 32, 32), ref.images[l])
+    # two "GPUs" (the shim has one device: --gpus is clamped, so call the plan itself) and the same output with 2 ranks of frames
+    import ctypes as C
+    L = C.CDLL(os.path.join(pkg, "libuvolhost.so"))
+    L.uvolh_shard_plan.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
+    import shard
+    for n, b, w in [(1200, 5, 8), (7, 3, 2), (13, 5, 8), (10, 7, 3)]:
+        for rk in range(w):
+            o4 = (C.c_long * 4)(); L.uvolh_shard_plan(n, b, w, rk, o4)
+            assert tuple(o4) == tuple(shard.plan(n, b, w, rk))
+
+
+def test_audio_duration_probe(tmp_path):
+    """scripts/Encoder.py:331-347 compares the audio duration with the geometry / texture durations; uvolenc probes WAV and MP3
+    files itself (no audioread here): a PCM WAV of known length and a synthetic CBR MPEG-1 Layer III stream behind an ID3v2 tag."""
+    import ctypes as C, struct, wave
+    pkg = os.path.join(ROOT, "universal-volumetric_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "libuvolhost.so"])
+    L = C.CDLL(os.path.join(pkg, "libuvolhost.so")); L.uvolh_audio_duration.restype = C.c_double; L.uvolh_audio_duration.argtypes = [C.c_char_p]
+    w = wave.open(str(tmp_path / "a.wav"), "wb"); w.setnchannels(2); w.setsampwidth(2); w.setframerate(48000); w.writeframes(b"\0" * (4 * 48000 * 3)); w.close()
+    assert abs(L.uvolh_audio_duration(str(tmp_path / "a.wav").encode()) - 3.0) < 1e-9
+    # 100 frames, MPEG-1 Layer III, 128 kbit/s, 44.1 kHz, no padding: 417 bytes and 1152 samples each
+    hdr = bytes([0xFF, 0xFB, 0x90, 0x00]); frame = hdr + b"\0" * (417 - 4)
+    (tmp_path / "a.mp3").write_bytes(b"ID3\x03\x00\x00\x00\x00\x00\x0a" + b"\0" * 10 + frame * 100)
+    assert abs(L.uvolh_audio_duration(str(tmp_path / "a.mp3").encode()) - 100 * 1152 / 44100) < 1e-9
+    assert L.uvolh_audio_duration(str(tmp_path / "missing.mp3").encode()) < 0

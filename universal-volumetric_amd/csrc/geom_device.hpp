@@ -23,7 +23,8 @@ struct RansStream {
   uint32_t *freq;         // [alpha_cap] histogram (zeroed per batch)
   uint32_t *probs;        // [alpha_cap]
   uint32_t *cum;          // [alpha_cap]
-  uint32_t *scratch;      // counting-sort scratch [(1<<20)+alpha_cap] shared per job
+  uint32_t *scratch;      // counting-sort scratch of k_rans_tables
+  uint4 *tab;             // [alpha_cap] {prob | shift << 24, cum, reciprocal, 0} per symbol (lane-per-stream coder)
   uint32_t alpha_cap;
   uint32_t max_sym;       // atomicMax target
   uint32_t prec_bits;
@@ -61,18 +62,18 @@ struct GeoJob {
   uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
-  int32_t *opp, *vert, *ring; uint8_t *vopen;
+  int32_t *opp, *vert;                // vert: vertex id per corner of the old-order table (position id, or n_pos + k for further fans of a non-manifold position)
+  uint32_t extra_v, nseg[2]; uint8_t *vseam[2];   // ids handed out beyond n_pos; attribute segments; per-vertex 'an interior seam of attribute i touches it'
   uint8_t *vvis; int32_t *vval, *c2vm, *proc, *initc, *stack;      // vvis: vertex-visited bitmap of the edgebreaker walk when it is not in LDS
   uint8_t *evcnt;                      // topology-split events per symbol (auxiliary stream)
   int32_t *ev_src, *ev_spl; uint8_t *ev_edge;
   int32_t *rec[4]; uint8_t *symb, *ctx_of; int32_t *face_time;
-  uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // dense vertex ids per table
-  uint8_t *dflagT[3]; int32_t *dtmpT[3]; uint32_t *bsumT[3];                                   // per-table scratch: tables 1..3 are renumbered by the same launches (grid z)
+  uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // per vertex id: on a boundary, ring size; size of the id space per table (encoder: only vopen_d[0])
   uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
   uint8_t *start_bits;
-  int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert; uint8_t *bopen;
+  int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert;
   uint8_t *seam[2]; uint8_t *elig; uint8_t *seam_bits[2];
-  int32_t *avert[2]; uint8_t *aopen[2];
+  int32_t *avert[2];
   int32_t *order[3], *v2d[3]; uint8_t *t_vvis[3]; int32_t *t_stack[3];
   int32_t *P, *U, *O;
   uint32_t *sym_pos, *sym_uv, *sym_nrm;

@@ -192,38 +192,62 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_edge_match(GeoJob *jobs) {
   J.opp[c] = (self == (int)c && o >= 0) ? o : GEO_INV;
 }
 
-// fans: vert[c] = canonical corner (left-most if open, min id if closed); which: 0 old base, 1 new base, 2/3 attribute 0/1
-__global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
+// ------------------------------------------------------------------------------------------------
+// Vertices.  A corner-table vertex is a fan of corners around a position.  On a manifold mesh that IS the position, so the
+// vertex id of a corner is its canonical position id (cp[]); only a position shared by several fans (non-manifold vertex)
+// needs more ids.  One thread per POSITION walks one fan of its corner bucket (the half-edge buckets of K3 list every corner
+// at the position): if the fan has as many corners as the bucket, the position is one vertex — open flag, ring size and the
+// corners' ids follow without walking from every corner (k_fans did that: valence x more dependent loads, 20 % of the
+// geometry time at 2160 frames per launch).  Otherwise every fan is walked from its representative corner and all but the
+// first get ids n_pos + k.  Ids are identities, not an order: nothing in the bitstream depends on how vertices are numbered
+// (visited bitmaps, valences and entry maps are keyed by them), so ids may have holes (unused positions) and the extra ids of
+// non-manifold fans may be handed out in any order.
+// Table 1 (decoder-order base table) re-uses these ids through the corner renumbering; the attribute tables split only the
+// vertices an interior seam touches (k_aseg_a / k_aseg_b), every other vertex keeps its base id.
+// ------------------------------------------------------------------------------------------------
+// fan of corner c in table T: representative (left-most corner of an open fan, lowest corner of a closed one), size, open flag
+__device__ inline int fan_probe(const GTab &T, int c, int limit, int &cnt, bool &open) {
+  int l = c, mn = c; cnt = 1; open = true;
+  for (;;) { const int nl = gt_swl(T, l); if (nl < 0) break; if (nl == c) { open = false; break; } l = nl; mn = l < mn ? l : mn; if (++cnt > limit) return -1; }
+  if (!open) return mn;
+  for (int a = gt_swr(T, c); a >= 0; a = gt_swr(T, a)) if (++cnt > limit) return -1;
+  return l;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_vert0(GeoJob *jobs) {
   JOB_OR_RETURN;
-  uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  if (which < 0) which = -which + (int)blockIdx.z;       // -2 with gridDim.z = 2: both attribute tables in one launch
-  // value-returning selects only (see the miscompile note at scan_flags)
-  const int ai = which >= 2 ? which - 2 : 0;
-  if (which >= 2 && (ai >= J.nad || !J.interior_seams[ai])) return;
-  GTab T;
-  T.opp = which == 0 ? J.opp : J.nopp;
-  T.seam = which >= 2 ? J.seam[ai] : nullptr;
-  int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
-  uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
-  int32_t *ring = which == 0 ? J.ring : nullptr;
-  int l = (int)c, mn = (int)c, cnt = 1; bool closed = false; uint32_t guard = 0;                  // one swing: min id and size of a closed fan on the way
-  for (;;) { int nl = gt_swl(T, l); if (nl < 0) break; if (nl == (int)c) { closed = true; break; } l = nl; mn = l < mn ? l : mn; cnt++; if (++guard > J.nc) { J.status = -22; return; } }
-  if (closed) {
-    vert[c] = mn;
-    if ((int)c == mn) { vopen[mn] = 0; if (ring) ring[mn] = cnt; if (which == 0) atomicAdd(&J.nverts, 1u); }
-  } else {
-    vert[c] = l;
-    if ((int)c == l) {
-      int cnt = 0; for (int a = l; a >= 0 && cnt <= (int)J.nc; a = gt_swr(T, a)) cnt++;
-      vopen[l] = 1; if (ring) ring[l] = cnt + 1; if (which == 0) atomicAdd(&J.nverts, 1u);
-    }
+  const uint32_t p = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (p >= J.n_pos) return;
+  const uint32_t s = J.he_start[p], n = J.he_cur[p] - s;
+  if (n == 0) { J.ring_d[p] = 0; J.vopen_d[0][p] = 0; return; }        // position no face uses: its id stays a hole
+  GTab T; T.opp = J.opp; T.seam = nullptr;
+  const int c0 = g_nxt((int)(uint32_t)J.he_ent[s]);                    // bucket entry = corner facing the edge; its next corner sits at p
+  int cnt; bool open;
+  if (fan_probe(T, c0, (int)n, cnt, open) < 0) { J.status = -22; return; }
+  if ((uint32_t)cnt == n) {                                             // one fan: the position is the vertex
+    for (uint32_t i = 0; i < n; i++) J.vert[g_nxt((int)(uint32_t)J.he_ent[s + i])] = (int32_t)p;
+    J.vopen_d[0][p] = open ? 1 : 0; J.ring_d[p] = (int32_t)(open ? n + 1 : n);
+    atomicAdd(&J.nverts, 1u);
+    return;
   }
+  bool first = true;                                                    // non-manifold vertex: one id per fan
+  for (uint32_t i = 0; i < n; i++) {
+    const int c = g_nxt((int)(uint32_t)J.he_ent[s + i]);
+    const int rep = fan_probe(T, c, (int)n, cnt, open);
+    if (rep < 0) { J.status = -22; return; }
+    if (rep != c) continue;                                             // each fan is handled once, from its representative
+    const uint32_t id = first ? p : J.n_pos + atomicAdd(&J.extra_v, 1u);
+    first = false;
+    atomicAdd(&J.nverts, 1u);
+    int a = rep;
+    for (int k = 0; k < cnt; k++) { J.vert[a] = (int32_t)id; a = open ? gt_swr(T, a) : gt_swl(T, a); }
+    if (id < J.ecap) { J.vopen_d[0][id] = open ? 1 : 0; J.ring_d[id] = open ? cnt + 1 : cnt; }
+  }
+  if (first) J.status = -22;
 }
 
 // ------------------------------------------------------------------------------------------------
 // K4: valence edgebreaker — split into
-//   k_pack_faces   (parallel)  per-corner records {vertex<<1|open, right, left[, opposite]} (8 or 16 bytes, RecOps) indexed by corner code
+//   k_pack0        (parallel)  per-corner records {vertex<<1|open, right, left[, opposite]} (8 or 16 bytes, RecOps) indexed by corner code
 //                              4*face+k, so a walker step is ONE load and no division / select
 //   k_eb_walk      (serial)    MeshEdgebreakerEncoderImpl::EncodeConnectivity traversal only: symbols + processed corners;
 //                              visited faces / vertices are bitmaps in LDS (k_face_time inverts proc[] afterwards)
@@ -233,10 +257,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_fans(GeoJob *jobs, int which) {
 //   k_eb_ctx       (1 wave)    ballot-ordered scatter of the symbols into the 6 valence-context streams
 // (SURVEY A.3 / A.10).  The serial kernels run one frame per workgroup; a batch keeps that many CUs busy.
 // ------------------------------------------------------------------------------------------------
-// dense vertex ids per table (so the walkers' vertex-visited bitmap is nverts bits, not 3*nf): canonical corners are
-// numbered by an order-preserving scan and the table's corner->vertex array is rewritten in place.
 __device__ __forceinline__ bool dense_table_live(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return !(which >= 2 && (ai >= J.nad || !J.interior_seams[ai])); }
-__device__ __forceinline__ int32_t *dense_vert(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]); }
 // the three records of face f (r[k] = opposite corner of corner k, vc[k] = vertex << 1 | open) in either format
 __device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, const int vc[3], const int r[3], int r8) {
   if (r8) {
@@ -252,7 +273,7 @@ __device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, cons
     dst[3] = make_int4(0, 0, 0, 0);
   }
 }
-// which: 0 old base table (edgebreaker), 1 new base, 2/3 attribute tables (DFS)
+// decode path (geom_decode.hip prepares vert / vopen_d itself): which: 1 new base, 2/3 attribute tables (DFS)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which, int r8) {
   JOB_OR_RETURN;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
@@ -273,82 +294,41 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
   pack_face_records(J.rec[which], f, vc, r, r8);
   if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
-
-// The same renumbering + record packing for up to three tables per launch (table = w0 + blockIdx.z, scratch per table): the
-// attribute stage was 18 launches of small kernels (5 per table + k_pack_faces), each of which waits its turn among the
-// kernels of the other contexts; now 4.  flags + block totals, totals scan, assign, apply + pack (a face's thread rewrites
-// its own three corner->vertex entries and packs them at once).
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_flags(GeoJob *jobs, int w0) {
-  GeoJob &J = jobs[blockIdx.y];
-  const int z = (int)blockIdx.z, which = w0 + z;
-  if (blockIdx.x >= uvol_blocks_dev(J.nc)) return;       // block-uniform exit
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  const bool live = J.status == 0 && c < J.nc;
-  uint32_t v = (live && dense_table_live(J, which) && dense_vert(J, which)[c] == (int32_t)c) ? 1u : 0u, tot;
-  if (live) J.dflagT[z][c] = (uint8_t)v;
-  block_excl_scan(v, &tot);
-  if (threadIdx.x == 0) J.bsumT[z][blockIdx.x] = tot;
-}
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_sums(GeoJob *jobs) {
-  GeoJob &J = jobs[blockIdx.y];
-  uint32_t *bsum = J.bsumT[blockIdx.z];
-  const uint32_t nblocks = uvol_blocks_dev(J.nc);
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t b0 = 0; b0 < nblocks; b0 += UVOL_BLOCK) {
-    const uint32_t i = b0 + threadIdx.x;
-    uint32_t v = i < nblocks ? bsum[i] : 0, tot;
-    const uint32_t ex = block_excl_scan(v, &tot);
-    const uint32_t c = carry;
-    if (i < nblocks) bsum[i] = c + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c + tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) bsum[nblocks] = carry;
-}
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_assign(GeoJob *jobs, int w0) {
-  GeoJob &J = jobs[blockIdx.y];
-  const int z = (int)blockIdx.z, which = w0 + z;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  const bool live = J.status == 0 && c < J.nc;
-  uint32_t v = live ? J.dflagT[z][c] : 0, tot;
-  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsumT[z][blockIdx.x] : 0);
-  if (live && v && pos < J.ecap) {                        // more vertices than the compact workspace holds: flagged below
-    const int ai = which >= 2 ? which - 2 : 0;
-    const uint8_t *vopen = which == 0 ? J.vopen : (which == 1 ? J.bopen : J.aopen[ai]);
-    J.dtmpT[z][c] = (int32_t)pos; J.vopen_d[which][pos] = vopen[c];
-    if (which == 0) J.ring_d[pos] = J.ring[c];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
-    const uint32_t total = J.bsumT[z][uvol_blocks_dev(J.nc)];
-    J.nverts_t[which] = total;
-    if (total > J.ecap) J.status = GEO_E_WS_OVERFLOW;
-  }
-}
-__global__ void __launch_bounds__(UVOL_BLOCK) k_dense3_apply_pack(GeoJob *jobs, int w0, int r8) {
-  GeoJob &J = jobs[blockIdx.y];
-  if (J.status != 0) return;
-  const int z = (int)blockIdx.z, which = w0 + z;
+// encoder, table 0 (old order): records for the edgebreaker walk; also publishes the size of the vertex id space
+__global__ void __launch_bounds__(UVOL_BLOCK) k_pack0(GeoJob *jobs, int r8) {
+  JOB_OR_RETURN;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (f >= J.nf || !dense_table_live(J, which)) return;
-  const int ai = which >= 2 ? which - 2 : 0;
-  const int32_t *opp = which == 0 ? J.opp : J.nopp;
-  const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
-  int32_t *vert = dense_vert(J, which);
-  const int32_t *dtmp = J.dtmpT[z];
-  const uint8_t *vopen = J.vopen_d[which];
+  if (f == 0) { const uint32_t tot = J.n_pos + J.extra_v; J.nverts_t[0] = tot; J.nverts_t[1] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
+  if (f >= J.nf) return;
   int r[3], vc[3];
   for (int k = 0; k < 3; k++) {
     const int c = 3 * (int)f + k;
-    r[k] = (seam && seam[c]) ? GEO_INV : opp[c];
-    const int v = dtmp[vert[c]];
-    vert[c] = v;
-    vc[k] = (v << 1) | (vopen[v] ? 1 : 0);
+    r[k] = J.opp[c];
+    const uint32_t v = (uint32_t)J.vert[c];
+    vc[k] = (int)((v << 1) | ((v < J.ecap && J.vopen_d[0][v]) ? 1u : 0u));
+  }
+  pack_face_records(J.rec[0], f, vc, r, r8);
+  J.face_time[f] = -1;                            // faces that start a component without a symbol keep -1 (see k_face_time)
+}
+// encoder, tables 1..3 (decoder order; table = 1 + blockIdx.z): base table and the attribute tables that have interior seams.
+// An attribute vertex an interior seam does not touch keeps its base id and open flag; the segments of the others are open.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_pack3(GeoJob *jobs, int r8) {
+  JOB_OR_RETURN;
+  const int which = 1 + (int)blockIdx.z;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (f >= J.nf || !dense_table_live(J, which)) return;
+  const int ai = which >= 2 ? which - 2 : 0;
+  const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
+  const int32_t *vert = which == 1 ? J.bvert : J.avert[ai];
+  const uint32_t nbase = J.nverts_t[0];
+  int r[3], vc[3];
+  for (int k = 0; k < 3; k++) {
+    const int c = 3 * (int)f + k;
+    r[k] = (seam && seam[c]) ? GEO_INV : J.nopp[c];
+    const uint32_t v = (uint32_t)vert[c];
+    vc[k] = (int)((v << 1) | ((v >= nbase || J.vopen_d[0][v]) ? 1u : 0u));
   }
   pack_face_records(J.rec[which], f, vc, r, r8);
-  if (which == 0) J.face_time[f] = -1;            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
 
 // typed-pointer helpers for the one-lane walkers (P = UVOL_G / UVOL_L pointer)
@@ -572,6 +552,14 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nev = (int)J.bsum2[uvol_blocks_dev(J.nf)];
 }
 
+// working copies the replay mutates: corner -> vertex map (S symbols re-map corners to new vertices) and the valence per vertex
+__global__ void __launch_bounds__(UVOL_BLOCK) k_valence_init(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const uint32_t t = blockIdx.x * UVOL_BLOCK + threadIdx.x, stride = gridDim.x * UVOL_BLOCK;
+  for (uint32_t c = t; c < J.nc; c += stride) J.c2vm[c] = J.vert[c];
+  const uint32_t nv0 = J.nverts_t[0] < J.ecap ? J.nverts_t[0] : J.ecap;
+  for (uint32_t v = t; v < nv0; v += stride) J.vval[v] = J.ring_d[v];
+}
 // valence bookkeeping replay: ctx_of[i] = context (0..5) under which symbol i-1 is coded (i >= 1).
 // The context of symbol i is the clamped valence of the vertex at next(corner_i) just before i updates it.  Between two
 // split symbols valences only receive fixed decrements (C: n-1 p-1; R: a-1 n-1 p-2; L: a-1 n-2 p-1; E: a-2 n-2 p-2), so
@@ -586,12 +574,9 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
   const int nsym = ok ? J.nsym : 0, nc = (int)J.nc;
   const int32_t *opp = J.opp, *proc = J.proc, *ftime = J.face_time; const uint8_t *symb = J.symb;
   int32_t *vval = J.vval, *c2vm = J.c2vm;
-  // initial valences / corner->vertex replica (parallel over lanes)
+  // initial valences / corner->vertex replica: filled by k_valence_init (parallel) before this launch
   const int nv0 = ok ? (int)J.nverts_t[0] : 0;
-  for (int i = (int)lane; i < (ok ? nc : 0); i += 64) c2vm[i] = J.vert[i];
-  for (int i = (int)lane; i < nv0; i += 64) vval[i] = J.ring_d[i];
-  __threadfence();
-  __syncthreads();
+  (void)nc;
   int nvval = nv0;
   for (int base = 0; base < nsym; base += 64) {
     const int mi = base + (int)lane;
@@ -622,7 +607,7 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
           UVOL_AADD(&vval[vn_], -(int)((dpk >> 2) & 3u));
           UVOL_AADD(&vval[vp_], -(int)(dpk >> 4));
         }
-        __threadfence();
+        UVOL_WAVE_FENCE();
         UVOL_WAVE_SYNC();
       }
       if (e < cnt) {                                                            // the split symbol: serial, lane 0
@@ -643,7 +628,7 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
         }
         nvval++;
         // refresh the not-yet-consumed vertex ids of this chunk (corners right of the split now map to the new vertex)
-        __threadfence();
+        UVOL_WAVE_FENCE();
         UVOL_WAVE_SYNC();
         if (mi < nsym && (int)lane > e) { va_ = c2vm[c_]; vn_ = c2vm[g_nxt(c_)]; vp_ = c2vm[g_prv(c_)]; }
       }
@@ -691,6 +676,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_b(GeoJob *jobs) {
   int o = J.old_of_new[c], oo = J.opp[o];
   J.nopp[c] = oo < 0 ? GEO_INV : J.new_of_old[oo];
   J.npid[c] = J.cp[o]; J.nuid[c] = J.cu[o]; J.nnid[c] = J.cn[o];
+  J.bvert[c] = J.vert[o];                        // the same vertices under the decoder's corner numbering
 }
 
 // attribute seams (MeshAttributeCornerTable::InitFromAttribute) + seam-bit eligibility
@@ -706,7 +692,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
     if (oc < 0) s = 1;
     else {
       s = (ids[g_nxt(c)] != ids[g_prv(oc)] || ids[g_prv(c)] != ids[g_nxt(oc)]) ? 1 : 0;
-      if (s) J.interior_seams[i] = 1;
+      if (s) { J.interior_seams[i] = 1; J.vseam[i][J.bvert[g_nxt(c)]] = 1; J.vseam[i][J.bvert[g_prv(c)]] = 1; }      // both ends of the edge get split
     }
     J.seam[i][c] = s;
   }
@@ -717,11 +703,43 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
   bool live = J.status == 0 && c < J.nc;
   uint32_t v = live ? J.elig[c] : 0, tot;
   uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsum[blockIdx.x] : 0);
-  if (live && v) for (int i = 0; i < J.nad; i++) { uint8_t s = J.seam[i][c]; J.seam_bits[i][pos] = s; if (!s) atomicAdd(&J.rb[1 + i].zeros, 1u); }
+  // zero counts: one global atomic per block and attribute (was one per wave on the same two words: 9 k per frame)
+  __shared__ uint32_t zc[2];
+  if (threadIdx.x < 2) zc[threadIdx.x] = 0;
+  __syncthreads();
+  if (live && v) for (int i = 0; i < J.nad; i++) { uint8_t s = J.seam[i][c]; J.seam_bits[i][pos] = s; if (!s) atomicAdd(&zc[i], 1u); }
+  __syncthreads();
+  if (threadIdx.x < 2 && zc[threadIdx.x]) atomicAdd(&J.rb[1 + threadIdx.x].zeros, zc[threadIdx.x]);
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
     uint32_t n = J.bsum[uvol_blocks_dev(J.nc)];
     J.n_elig = n; for (int i = 0; i < J.nad; i++) J.rb[1 + i].n = n;
   }
+}
+
+// attribute vertices of the vertices an interior seam touches (grid z = attribute slot): pass a gives every segment (maximal
+// run of fan corners no seam / boundary separates) an id nverts_base + k at its left-most corner, pass b hands it to the other
+// corners of the segment; all other corners keep their base vertex
+__global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const int i = (int)blockIdx.z;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c >= J.nc || i >= J.nad || !J.interior_seams[i]) return;
+  const int32_t v = J.bvert[c];
+  if (!J.vseam[i][v]) { J.avert[i][c] = v; return; }
+  GTab T; T.opp = J.nopp; T.seam = J.seam[i];
+  if (gt_swl(T, (int)c) < 0) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const int i = (int)blockIdx.z;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c == 0 && i < J.nad && J.interior_seams[i]) { const uint32_t tot = J.nverts_t[0] + J.nseg[i]; J.nverts_t[2 + i] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
+  if (c >= J.nc || i >= J.nad || !J.interior_seams[i]) return;
+  if (!J.vseam[i][J.bvert[c]]) return;
+  GTab T; T.opp = J.nopp; T.seam = J.seam[i];
+  int l = (int)c; uint32_t guard = 0;
+  for (;;) { const int nl = gt_swl(T, l); if (nl < 0) break; l = nl; if (++guard > J.nc) { J.status = -22; return; } }
+  if (l != (int)c) J.avert[i][c] = J.avert[i][l];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,19 +998,28 @@ __global__ void __launch_bounds__(64) k_traverse_simt(GeoJob *jobs, int n, int W
 // K1: attribute min/max (orderable-float atomics) and quantisation of the entries in coding order
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(UVOL_BLOCK) k_minmax(GeoJob *jobs) {
-  JOB_OR_RETURN;
-  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  GeoJob &J = jobs[blockIdx.y];
   uint32_t mn[5], mx[5];
   for (int k = 0; k < 5; k++) { mn[k] = 0xffffffffu; mx[k] = 0; }
-  if (i < J.n_pos) for (int k = 0; k < 3; k++) { uint32_t u = g_float_order(J.pos[3 * (size_t)i + k]); mn[k] = u; mx[k] = u; }
-  if (J.has_uv && i < J.n_uv) for (int k = 0; k < 2; k++) { uint32_t u = g_float_order(J.uv[2 * (size_t)i + k]); mn[3 + k] = u; mx[3 + k] = u; }
+  const bool ok = J.status == 0;
+  // a few blocks per frame stride over the values: 10 atomics per BLOCK on the frame's bounding-box words (they were per wave)
+  for (uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x; ok && i < J.n_pos; i += gridDim.x * UVOL_BLOCK)
+    for (int k = 0; k < 3; k++) { const uint32_t u = g_float_order(J.pos[3 * (size_t)i + k]); mn[k] = u < mn[k] ? u : mn[k]; mx[k] = u > mx[k] ? u : mx[k]; }
+  for (uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x; ok && J.has_uv && i < J.n_uv; i += gridDim.x * UVOL_BLOCK)
+    for (int k = 0; k < 2; k++) { const uint32_t u = g_float_order(J.uv[2 * (size_t)i + k]); mn[3 + k] = u < mn[3 + k] ? u : mn[3 + k]; mx[3 + k] = u > mx[3 + k] ? u : mx[3 + k]; }
+  __shared__ uint32_t smn[5], smx[5];
+  if (threadIdx.x < 5) { smn[threadIdx.x] = 0xffffffffu; smx[threadIdx.x] = 0; }
+  __syncthreads();
   for (int k = 0; k < 5; k++) {
     uint32_t a = mn[k], b = mx[k];
     for (int d = 32; d >= 1; d >>= 1) { uint32_t a2 = __shfl_xor(a, d), b2 = __shfl_xor(b, d); a = a2 < a ? a2 : a; b = b2 > b ? b2 : b; }
-    if ((threadIdx.x & 63) == 0) {
-      if (k < 3) { atomicMin(&J.pos_min_u[k], a); atomicMax(&J.pos_max_u[k], b); }
-      else if (J.has_uv) { atomicMin(&J.uv_min_u[k - 3], a); atomicMax(&J.uv_max_u[k - 3], b); }
-    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&smn[k], a); atomicMax(&smx[k], b); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 5 && ok && smn[threadIdx.x] <= smx[threadIdx.x]) {
+    const int k = (int)threadIdx.x;
+    if (k < 3) { atomicMin(&J.pos_min_u[k], smn[k]); atomicMax(&J.pos_max_u[k], smx[k]); }
+    else if (J.has_uv) { atomicMin(&J.uv_min_u[k - 3], smn[k]); atomicMax(&J.uv_max_u[k - 3], smx[k]); }
   }
 }
 __device__ inline float quant_range(const uint32_t *mn, const uint32_t *mx, int ncomp) {
@@ -1450,6 +1477,114 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lane-per-stream form of the entropy coder.  k_entropy_encode spends one wave per stream: 14 x frames waves, which at
+// > 1000 frames per launch run in rounds.  Here every LANE encodes its own stream (the lanes of a wave take the same stream of
+// consecutive frames, so their lengths are similar); nothing is in LDS.  k_rans_recip (parallel) turns the normalised
+// probability table into one 16-byte entry per symbol {prob | shift << 24, cum (+ the prob == 1 correction), reciprocal}: a
+// symbol costs one table load and a dozen integer instructions, symbols and entries are fetched four at a time one group
+// ahead.  Output bytes are collected four to a word.  Byte-identical to k_entropy_encode.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(UVOL_BLOCK) k_rans_recip(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.z];
+  if (J.status != 0) return;
+  RansStream &S = J.rs[blockIdx.y];
+  if (S.n == 0) return;
+  const uint32_t k = blockIdx.x * UVOL_BLOCK + threadIdx.x, ns = S.max_sym + 1;
+  if (k >= ns) return;
+  const uint32_t p = S.probs[k], prec = 1u << S.prec_bits;
+  const uint2 rc = g_recip(p);
+  S.tab[k] = make_uint4(p | (rc.y << 24), S.cum[k] + (p == 1 ? prec - 1 : 0), rc.x, 0u);
+}
+struct SByteOut {
+  uint8_t *p; uint32_t w, cap, acc;
+  __device__ __forceinline__ void put(uint32_t b) {
+    acc |= (b & 255u) << (8 * (w & 3u)); w++;
+    if ((w & 3u) == 0) { if (w <= cap) *reinterpret_cast<uint32_t *>(p + w - 4) = acc; acc = 0; }
+  }
+  __device__ __forceinline__ void flush() { if (w <= cap) for (uint32_t k = w & ~3u; k < w; k++) p[k] = (uint8_t)(acc >> (8 * (k & 3u))); }
+};
+__device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
+  const uint32_t n = S.n;
+  if (!n) return;
+  const uint32_t prec = 1u << S.prec_bits, L = prec * 4;
+  const uint32_t *syms = S.syms; const uint4 *tab = S.tab;
+  SByteOut O; O.p = S.pay + 8; O.w = 0; O.cap = S.pay_cap - 80; O.acc = 0;
+  uint32_t st = L;
+#define SR_STEP(E)                                                                     \
+  { const uint32_t p_ = (E).x & 0xffffffu, lim_ = p_ << 10;                             \
+    while (st >= lim_) { O.put(st); st >>= 8; }                                         \
+    const uint32_t q_ = (uint32_t)(((unsigned long long)st * (E).z) >> 32) >> ((E).x >> 24); \
+    st = st + (E).y + q_ * (prec - p_); }
+  uint32_t hi = n;
+  while (hi & 3u) { hi--; const uint4 e = tab[syms[hi]]; SR_STEP(e); }          // the tail: the groups below are 16-byte aligned
+  if (hi) {
+    uint4 sy = *reinterpret_cast<const uint4 *>(syms + hi - 4);
+    uint4 e0 = tab[sy.w], e1 = tab[sy.z], e2 = tab[sy.y], e3 = tab[sy.x];
+    while (hi) {
+      hi -= 4;
+      const uint4 c0 = e0, c1 = e1, c2 = e2, c3 = e3;
+      if (hi) { sy = *reinterpret_cast<const uint4 *>(syms + hi - 4); e0 = tab[sy.w]; e1 = tab[sy.z]; e2 = tab[sy.y]; e3 = tab[sy.x]; }
+      SR_STEP(c0); SR_STEP(c1); SR_STEP(c2); SR_STEP(c3);
+    }
+  }
+#undef SR_STEP
+  uint32_t w = O.w;
+  if (w + 4 > O.cap) { J.status = -32; return; }
+  O.flush();
+  uint8_t *pay = O.p;
+  st -= L;
+  if (st < (1u << 6)) pay[w++] = (uint8_t)st;
+  else if (st < (1u << 14)) { const uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
+  else if (st < (1u << 22)) { const uint32_t v = (2u << 22) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; }
+  else { const uint32_t v = (3u << 30) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; pay[w++] = (v >> 24) & 255; }
+  const uint32_t vl = g_varint_len(w);
+  g_put_varint(S.pay + 8 - vl, w);
+  S.pay_off = 8 - vl; S.pay_len = vl + w;
+}
+__device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
+  const uint32_t n = B.n; const uint64_t total = n ? n : 1;
+  const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
+  uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
+  const uint32_t p = 256 - p0;
+  SByteOut O; O.p = B.buf + 8; O.w = 0; O.cap = B.cap - 80; O.acc = 0;
+  uint32_t st = 4096;
+  const uint2 r1 = g_recip(p), r0 = g_recip(p0);
+  const uint32_t a1 = (p == 1 ? 255u : 0u), a0 = p + (p0 == 1 ? 255u : 0u);
+  const uint32_t lim1 = 4096u * p, lim0 = 4096u * p0, mu1 = 256u - p, mu0 = 256u - p0;
+  const uint8_t *bits = B.bits;
+  for (uint32_t i = n; i-- > 0;) {
+    const bool one = bits[i] != 0;
+    const uint32_t lim = one ? lim1 : lim0, m = one ? r1.x : r0.x, sh = one ? r1.y : r0.y, add = one ? a1 : a0, mul = one ? mu1 : mu0;
+    if (st >= lim) { O.put(st); st >>= 8; }
+    const uint32_t q = (uint32_t)(((unsigned long long)st * m) >> 32) >> sh;
+    st = st + add + q * mul;
+  }
+  uint32_t w = O.w;
+  if (w + 3 > O.cap) { J.status = -33; return; }
+  O.flush();
+  uint8_t *pay = O.p;
+  st -= 4096;
+  if (st < (1u << 6)) pay[w++] = (uint8_t)st;
+  else if (st < (1u << 14)) { const uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
+  else { const uint32_t v = (2u << 22) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; pay[w++] = (v >> 16) & 255; }
+  const uint32_t vl = g_varint_len(w);
+  g_put_varint(B.buf + 8 - vl, w);
+  B.buf[8 - vl - 1] = (uint8_t)p0;
+  B.off = 8 - vl - 1; B.len = 1 + vl + w;
+}
+// grid (frame blocks, stream); lanes of a wave = the same stream of W consecutive frames
+__global__ void __launch_bounds__(64) k_entropy_simt(GeoJob *jobs, int n, int W) {
+  const int lane = (int)threadIdx.x;
+  if (lane >= W) return;
+  const int j = (int)blockIdx.x * W + lane;
+  if (j >= n) return;
+  GeoJob &J = jobs[j];
+  if (J.status != 0) return;
+  const int t = (int)blockIdx.y;
+  if (t < GEO_NSTREAM) rans_encode_lane(J, J.rs[t]); else rabs_encode_lane(J, J.rb[t - GEO_NSTREAM]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout: small header pieces + piece list (single lane per frame), then a parallel gather
 // ------------------------------------------------------------------------------------------------
 __device__ inline void add_piece(GeoJob &J, const uint8_t *p, uint32_t len, uint32_t &total) {
@@ -1626,7 +1761,8 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   items.clear();
   const size_t nfi = J.nf_in, nc = 3 * nfi;
   const size_t vmax = std::max<size_t>(J.n_pos, std::max<size_t>(J.n_uv, J.n_nrm));
-  const size_t ecap = full ? nc + 3 : std::min(nc + 3, vmax + vmax / 2 + 4096);
+  // vertex ids are position ids + one id per further fan of a non-manifold position + (attribute tables) one per seam segment
+  const size_t ecap = full ? vmax + 2 * nc + 3 : std::min(vmax + 2 * nc + 3, vmax + vmax / 2 + 4096);
   J.ecap = (uint32_t)ecap;
   auto bitlen = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };
 #define CARVE(field, T, count, first, last) items.push_back(WsItem{(size_t)((char *)&(field) - (char *)&J), (size_t)(count) * sizeof(T), (first), (last), 0})
@@ -1638,6 +1774,7 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   }
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
+  for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint8_t, ecap + 8, PH_PINNED, PH_PINNED);
   for (int t = 0; t < 3; t++) CARVE(J.t_vvis[t], uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int s = 0; s < GEO_NSTREAM; s++) {
     const int q = s == 6 ? J.qp : (s == 7 ? J.qt : J.qn);
@@ -1646,21 +1783,18 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   }
   // ---- scan scratch (tiny, kept for the whole batch) ----
   CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT); CARVE(J.bsum2, uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT);
-  for (int z = 0; z < 3; z++) CARVE(J.bsumT[z], uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT);
   // ---- K2 / K3 ----
   CARVE(J.canon[0], uint32_t, J.n_pos + 1, PH_DEDUP, PH_FACES); CARVE(J.canon[1], uint32_t, J.n_uv + 1, PH_DEDUP, PH_FACES); CARVE(J.canon[2], uint32_t, J.n_nrm + 1, PH_DEDUP, PH_FACES);
   CARVE(J.keep, uint8_t, nfi + 1, PH_FACES, PH_FACES);
   CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_RENUM);
-  CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_CT); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_CT);
+  CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_FANS0); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_FANS0);      // k_vert0 walks the buckets
   CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_PRED);                     // events / valence replay (auxiliary stream) read it until the join
-  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_PRED); CARVE(J.ring, int32_t, nc + 3, PH_FANS0, PH_DENSE0); CARVE(J.vopen, uint8_t, nc + 3, PH_FANS0, PH_DENSE0);
+  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_PRED);
   // ---- K4 ----
-  CARVE(J.dflagT[0], uint8_t, nc + 3, PH_DENSE0, PH_DENSE1); CARVE(J.dtmpT[0], int32_t, nc + 3, PH_DENSE0, PH_DENSE1);
-  for (int z = 1; z < 3; z++) { CARVE(J.dflagT[z], uint8_t, nc + 3, PH_DENSE1, PH_DENSE1); CARVE(J.dtmpT[z], int32_t, nc + 3, PH_DENSE1, PH_DENSE1); }
   const size_t rec_bytes = (r8 ? 32 : 64) * (nfi + 1);
-  CARVE(J.rec[0], uint8_t, rec_bytes, PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_DENSE0, PH_DENSE0);
-  for (int w = 1; w < 4; w++) { CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D); CARVE(J.vopen_d[w], uint8_t, ecap, PH_DENSE1, PH_DENSE1); }
-  CARVE(J.ring_d, int32_t, ecap, PH_DENSE0, PH_PRED);
+  CARVE(J.rec[0], uint8_t, rec_bytes, PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
+  for (int w = 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
+  CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_PRED);
   CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, PH_PRED);
   CARVE(J.proc, int32_t, nfi + 1, PH_WALK, PH_PRED); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, PH_PRED);
   CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_RENUM); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
@@ -1672,10 +1806,10 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   // ---- renumbering, seams ----
   CARVE(J.old_of_new, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
   CARVE(J.npid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nuid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nnid, int32_t, nc + 3, PH_RENUM, PH_QUANT);
-  CARVE(J.bvert, int32_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.bopen, uint8_t, nc + 3, PH_SEAMS, PH_DENSE1);
+  CARVE(J.bvert, int32_t, nc + 3, PH_RENUM, PH_PRED);
   for (int i = 0; i < 2; i++) {
     CARVE(J.seam[i], uint8_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.seam_bits[i], uint8_t, nc + 3, PH_SEAMS, PH_ENT);
-    CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.aopen[i], uint8_t, nc + 3, PH_SEAMS, PH_DENSE1);
+    CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED);
   }
   CARVE(J.elig, uint8_t, nc + 3, PH_SEAMS, PH_SEAMS);
   // ---- K5, K1, K6 ----
@@ -1690,6 +1824,7 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
     const size_t nsym = s < 6 ? nfi : (s == 6 ? 3 * ecap : 2 * ecap);
     CARVE(S.probs, uint32_t, S.alpha_cap, PH_HIST, PH_LAYOUT); CARVE(S.cum, uint32_t, S.alpha_cap, PH_HIST, PH_LAYOUT);
     CARVE(S.head, uint8_t, 3 * (size_t)S.alpha_cap + 32, PH_HIST, PH_LAYOUT);
+    CARVE(S.tab, uint4, S.alpha_cap, PH_HIST, PH_ENT);
     S.pay_cap = (uint32_t)(3 * nsym + 256); CARVE(S.pay, uint8_t, S.pay_cap, PH_ENT, PH_LAYOUT);
     // counting-sort scratch of k_rans_tables: (precision + 2) counters + one slot per symbol of the alphabet
     const int bl = bitlen(S.alpha_cap), pb = std::min(20, std::max(12, 3 * bl / 2));
@@ -1777,13 +1912,6 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
   } while (0)
 
-#define DENSE_PACK(w0, nz)                                                                        \
-  do {                                                                                            \
-    LAUNCH(k_dense3_flags, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                   \
-    LAUNCH(k_dense3_sums, dim3(1, N, (nz)), dim3(UVOL_BLOCK), dj);                                \
-    LAUNCH(k_dense3_assign, dim3(bc, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0));                  \
-    LAUNCH(k_dense3_apply_pack, dim3(bf, N, (nz)), dim3(UVOL_BLOCK), dj, (int)(w0), r8);          \
-  } while (0)
 // zero the dedup hash tables / half-edge counts / visited maps / histograms at the head of every job's workspace
 __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
@@ -1957,11 +2085,11 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_he_scan, dim3(1, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_he_fill, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 0);
+    LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
   }
   const WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)N);
   {
-    DENSE_PACK(0, 1);
+    LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, r8);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) { const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W; if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), wp_walk.lds, dj, wp_walk.vcw);
@@ -1977,6 +2105,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH_ON(G->aux, k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
     LAUNCH_ON(G->aux, k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
     LAUNCH_ON(G->aux, k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH_ON(G->aux, k_valence_init, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     { uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence", 0, G->aux); LAUNCH_ON(G->aux, k_eb_valence, dim3(N), dim3(64), dj); }
     LAUNCH_ON(G->aux, k_eb_ctx, dim3(N), dim3(64), dj);
   }
@@ -1985,15 +2114,15 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_renumber_b, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_fans, dim3(bc, N), dim3(UVOL_BLOCK), dj, 1);
     LAUNCH(k_seams, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_blocks, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
     LAUNCH(k_seam_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_fans, dim3(bc, N, 2), dim3(UVOL_BLOCK), dj, -2);
+    LAUNCH(k_aseg_a, dim3(bc, N, 2), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_aseg_b, dim3(bc, N, 2), dim3(UVOL_BLOCK), dj);
   }
   {
-    DENSE_PACK(1, 3);
+    LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, r8);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): LDS traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
@@ -2004,7 +2133,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
-    LAUNCH(k_minmax, dim3(bv, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_quantize, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
   }
   {
@@ -2026,7 +2155,15 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k7_entropy_encode", 0);
-    LAUNCH(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), dj, uvol_debug() ? 1 : 0);
+    // UVOL_ENTROPY_WAVE=1 (tests / diagnostic): the wave-per-stream kernel
+    static const bool ent_wave = [] { const char *e = getenv("UVOL_ENTROPY_WAVE"); return e && *e == '1'; }();
+    if (ent_wave) LAUNCH(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), dj, uvol_debug() ? 1 : 0);
+    else {
+      static const int ent_w_env = [] { const char *e = getenv("UVOL_ENTROPY_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+      const unsigned W = ent_w_env ? (unsigned)ent_w_env : std::min(64u, std::max(1u, (14u * N + 4095u) / 4096u));      // ~4096 waves per launch
+      LAUNCH(k_rans_recip, dim3(uvol_blocks(((size_t)2 << std::max(prm.q_position_attr, std::max(prm.q_texture_attr, prm.q_normal_attr))) + 8), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_entropy_simt, dim3((N + W - 1) / W, GEO_NSTREAM + GEO_NRABS), dim3(64), dj, n, (int)W);
+    }
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k8_layout_gather", 0);

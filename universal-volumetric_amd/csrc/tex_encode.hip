@@ -66,11 +66,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_skip(TexJob *job) {
   const uint32_t b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (b >= J.nb) return;
   const uint32_t X = b % J.bx, Y = b / J.bx;
-  uint32_t anchor[16], cur[16];
-  t_load_block(J, 0, X, Y, anchor);
+  uint32_t anchor[16], cur[16], amask = 0xff000000u;
+  t_load_block(J, 0, X, Y, anchor, &amask);
   J.skip[b] = 0;
   for (uint32_t l = 1; l < J.L; l++) {
-    t_load_block(J, l, X, Y, cur);
+    t_load_block(J, l, X, Y, cur, &amask);
     uint32_t d = 0;
     for (int i = 0; i < 16; i++) {
       const int dr = (int)(cur[i] & 255) - (int)(anchor[i] & 255), dg = (int)((cur[i] >> 8) & 255) - (int)((anchor[i] >> 8) & 255), db = (int)((cur[i] >> 16) & 255) - (int)((anchor[i] >> 16) & 255);
@@ -80,6 +80,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_skip(TexJob *job) {
     J.skip[(size_t)l * J.nb + b] = sk ? 1 : 0;
     if (!sk) for (int i = 0; i < 16; i++) anchor[i] = cur[i];
   }
+  // basisu writes alpha slices for such images; this path does not: fail loudly rather than drop the channel (every block of
+  // every layer passes through here)
+  if ((amask & 0xff000000u) != 0xff000000u) J.status = TEX_E_ALPHA;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1023,7 +1026,7 @@ void tex_destroy(uvol_ctx *ctx) {
 }
 size_t uvol_texture_bound(uint32_t w, uint32_t h, int n) {
   const size_t nb = (size_t)((w + 3) / 4) * ((h + 3) / 4);
-  return 65536 + 6 * (size_t)TEX_MAX_CODEBOOK * 4 + (nb * 8 + 64) * (size_t)(n > 0 ? n : 1);
+  return 65536 + 6 * (size_t)TEX_MAX_CODEBOOK * 4 + (nb * 16 + 64) * (size_t)(n > 0 ? n : 1);      // 16 bytes per block and layer: the UASTC mode
 }
 
 namespace {
@@ -1274,6 +1277,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   int worst = UVOL_OK;
   for (int s = 0; s < n_seg; s++) {
     const TexJob &R = T->hjobs[s];
+    if (R.status == TEX_E_ALPHA) { ctx->set_error("texture segment %d: image has alpha != 255; ETC1S alpha slices are not implemented (make the images opaque, or use the UASTC mode: uvol_params.uastc / basisu -uastc, which encodes alpha)", s); worst = UVOL_E_UNSUPPORTED; out_lens[s] = 0; continue; }
     if (R.status != 0) { ctx->set_error("texture segment %d: device status %d", s, R.status); worst = UVOL_E_ENCODE; out_lens[s] = 0; continue; }
     const uint64_t sgd_len = 20 + 20 * (uint64_t)n_layers + R.sec_len[0] + R.sec_len[1] + R.sec_len[2];
     uint64_t lvl_len = 0; for (int l = 0; l < n_layers; l++) lvl_len += R.slice_len[l];

@@ -1,0 +1,588 @@
+// tex_uastc.hip — hand-written HIP (gfx950) UASTC LDR 4x4 texture mode: RGBA8 layers -> UASTC blocks -> KTX2, and the decode
+// side UASTC -> RGBA8 / ASTC 4x4.
+//
+// What it stands for in the reference: `basisu -uastc -ktx2 -tex_type video ...` — the second texture mode of the encoder the
+// reference driver spawns (scripts/Encoder.py:290 passes no -uastc; the north star and SURVEY §8 f4 ask for the mode) — and,
+// on the consumer side, the UASTC -> ASTC 4x4 transcode the stock player's KTX2Loader requests first for UASTC sources
+// (src/lib/KTX2Loader.js:591-600, :648-689).  Formats: UASTC LDR 4x4 specification (basis_universal) and the ASTC LDR profile;
+// the single-subset modes 0, 6, 18 (opaque), 10, 11, 12 (alpha) and 8 (solid) are emitted — see oracle/uastc.c for what pins
+// them (parity with basisu itself is unpinned: no binary, no fixture).
+//
+// One thread per 4x4 block, blocks are independent: a streaming kernel (64 B of texels in, 16 B out per block) whose
+// arithmetic is a handful of exact integer least-squares fits per block.  Everything is integer and matches oracle/uastc.c
+// bit for bit.  No MFMA: there is no contraction; the bound is VALU integer throughput and, for the transcodes, HBM.
+#include "uvol_common.hpp"
+#include <algorithm>
+
+// ---- mode tables (UASTC specification) ----
+struct UMode { uint8_t huff, hufflen, wbits, range, comps, planes, bias, bc1h1, alpha; uint16_t astc_bm; };
+__device__ __forceinline__ UMode u_mode(int m) {
+  // only the emitted modes; {prefix code, length, weight bits, endpoint range, components, planes, has bias, has bc1 hint 1, has alpha, ASTC block mode}
+  switch (m) {
+    case 0: return UMode{0x1, 4, 4, 19, 3, 1, 1, 1, 0, 0x242};
+    case 6: return UMode{0x1B, 5, 2, 18, 3, 2, 1, 1, 0, 0x442};
+    case 10: return UMode{0x2, 3, 4, 13, 4, 1, 0, 0, 1, 0x242};
+    case 11: return UMode{0x0, 2, 2, 13, 4, 2, 0, 0, 1, 0x442};
+    case 12: return UMode{0x6, 3, 3, 19, 4, 1, 0, 0, 1, 0x53};
+    default: return UMode{0x9, 4, 5, 11, 3, 1, 1, 1, 0, 0x253};     // 18
+  }
+}
+// ASTC integer-sequence parameters of the endpoint ranges in use: 11 = 32 levels, 13 = 48, 18 = 160, 19 = 192
+__device__ __forceinline__ int u_rbits(int range) { return range == 11 ? 5 : (range == 13 ? 4 : (range == 18 ? 5 : 6)); }
+__device__ __forceinline__ int u_rtrit(int range) { return (range == 13 || range == 19) ? 1 : 0; }
+__device__ __forceinline__ int u_rquint(int range) { return range == 18 ? 1 : 0; }
+__device__ __forceinline__ int u_rlevels(int range) { return range == 11 ? 32 : (range == 13 ? 48 : (range == 18 ? 160 : 192)); }
+__device__ __forceinline__ int u_slot(int range) { return range == 11 ? 0 : (range == 13 ? 1 : (range == 18 ? 2 : 3)); }
+
+// endpoint unquantisation tables of those four ranges and their inverses (nearest level), built on the host at context creation
+struct UTab { uint8_t uq[4][256]; uint8_t qof[4][256]; };
+
+static int u_host_unquant(int bits, int tr, int qu, int v) {          // ASTC "endpoint unquantization"
+  if (!tr && !qu) { int r = 0, have = 0; while (have < 8) { r = (r << bits) | v; have += bits; } return (r >> (have - 8)) & 255; }
+  const int D = v >> bits, m = v & ((1 << bits) - 1), a = m & 1, b = (m >> 1) & 1, c = (m >> 2) & 1, d = (m >> 3) & 1, e = (m >> 4) & 1, f = (m >> 5) & 1, A = a ? 0x1FF : 0;
+  int B = 0, C = 0;
+  if (tr) { if (bits == 4) { C = 22; B = (d << 8) | (c << 7) | (b << 6) | (d << 2) | (c << 1) | b; } else { C = 5; B = (f << 8) | (e << 7) | (d << 6) | (c << 5) | (b << 4) | f; } }
+  else { C = 6; B = (e << 8) | (d << 7) | (c << 6) | (b << 5) | e; }
+  int T = D * C + B; T ^= A;
+  return (A & 0x80) | (T >> 2);
+}
+static void u_host_tables(UTab &T) {
+  static const int ranges[4] = { 11, 13, 18, 19 }, bits[4] = { 5, 4, 5, 6 }, tr[4] = { 0, 1, 0, 1 }, qu[4] = { 0, 0, 1, 0 }, lev[4] = { 32, 48, 160, 192 };
+  (void)ranges;
+  memset(&T, 0, sizeof T);
+  for (int s = 0; s < 4; s++) {
+    for (int v = 0; v < lev[s]; v++) T.uq[s][v] = (uint8_t)u_host_unquant(bits[s], tr[s], qu[s], v);
+    for (int x = 0; x < 256; x++) {                                   // nearest level; among equals the lower value, then the lower code
+      int best = 0, bd = 1 << 30, bu = 0;
+      for (int v = 0; v < lev[s]; v++) { const int u = T.uq[s][v], dd = u > x ? u - x : x - u; if (dd < bd || (dd == bd && u < bu)) { bd = dd; best = v; bu = u; } }
+      T.qof[s][x] = (uint8_t)best;
+    }
+  }
+}
+
+__device__ __forceinline__ int u_wunq(int wb, int k) {                 // weight index -> 0..64 (bit replication, > 32 moves up by one)
+  const int r = wb == 2 ? 21 * k : (wb == 3 ? 9 * k : (wb == 4 ? ((k << 2) | (k >> 2)) : (wb == 5 ? ((k << 1) | (k >> 4)) : 63 * k)));
+  return r > 32 ? r + 1 : r;
+}
+__device__ __forceinline__ int u_interp(int l, int h, int w) { l = (l << 8) | l; h = (h << 8) | h; return ((l * (64 - w) + h * w + 32) >> 6) >> 8; }
+__device__ __forceinline__ long long u_rdiv(long long n, long long d) { return n >= 0 ? (n + d / 2) / d : -((-n + d / 2) / d); }
+__device__ __forceinline__ int u_comp(uint32_t px, int c) { return (int)((px >> (8 * c)) & 255u); }
+
+// 128-bit block under construction (LSB first)
+struct UBits {
+  unsigned long long lo, hi;
+  __device__ __forceinline__ void put(int &o, uint32_t v, int n) {
+    if (n <= 0) return;
+    const unsigned long long x = (unsigned long long)v & ((1ull << n) - 1ull);
+    if (o < 64) { lo |= x << o; if (o + n > 64) hi |= x >> (64 - o); } else hi |= x << (o - 64);
+    o += n;
+  }
+  __device__ __forceinline__ uint32_t get(int &o, int n) const {
+    if (n <= 0) return 0;
+    unsigned long long x;
+    if (o < 64) { x = lo >> o; if (o + n > 64) x |= hi << (64 - o); } else x = hi >> (o - 64);
+    o += n;
+    return (uint32_t)(x & ((1ull << n) - 1ull));
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+// one weight plane over the components of `cmask` (bit c = component c), in component order: endpoint codes, weights, SSE.
+// Principal axis by an integer power iteration on the 16x-scaled covariance, endpoints = the texels at the ends of the axis,
+// nearest weights by exhaustive search under the exact ASTC interpolation, then ONE exact integer least-squares refit of the
+// endpoints for those weights, kept when it lowers the error.
+__device__ inline uint32_t u_fit_plane(const uint32_t px[16], int cmask, int range, int wb, const UTab *T, uint8_t qlo[4], uint8_t qhi[4], uint8_t w[16]) {
+  const int slot = u_slot(range), nlev = 1 << wb;
+  int comp[4] = { 0, 0, 0, 0 }, nc = 0;
+  for (int c = 0; c < 4; c++) if ((cmask >> c) & 1) comp[nc++] = c;
+  int lo[4] = { 0, 0, 0, 0 }, hi[4] = { 0, 0, 0, 0 };
+  if (nc == 1) {
+    int mn = 255, mx = 0;
+    for (int i = 0; i < 16; i++) { const int v = u_comp(px[i], comp[0]); mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    lo[0] = mn; hi[0] = mx;
+  } else {
+    // 32-bit where the ranges allow it (64-bit integer multiplies are four instructions here): |16 c - S| <= 4080, a covariance
+    // entry <= 16 * 4080^2 < 2^29, the axis is renormalised below 2^15, a projection is below 2^31; same values as the oracle's int64
+    int S[4] = { 0, 0, 0, 0 }, cov[4][4], mn[4] = { 255, 255, 255, 255 }, mx[4] = { 0, 0, 0, 0 }; long long v[4] = { 0, 0, 0, 0 };
+    for (int c = 0; c < nc; c++) for (int i = 0; i < 16; i++) { const int x = u_comp(px[i], comp[c]); S[c] += x; mn[c] = x < mn[c] ? x : mn[c]; mx[c] = x > mx[c] ? x : mx[c]; }
+    for (int a = 0; a < nc; a++) for (int b = a; b < nc; b++) { int s = 0; for (int i = 0; i < 16; i++) s += (16 * u_comp(px[i], comp[a]) - S[a]) * (16 * u_comp(px[i], comp[b]) - S[b]); cov[a][b] = s; cov[b][a] = s; }
+    long long any = 0; for (int c = 0; c < nc; c++) { v[c] = mx[c] - mn[c]; any |= v[c]; }
+    if (!any) for (int c = 0; c < nc; c++) v[c] = 1;
+    for (int it = 0; it < 4; it++) {
+      long long nv[4] = { 0, 0, 0, 0 }, m = 0;
+      for (int a = 0; a < nc; a++) { long long s = 0; for (int b = 0; b < nc; b++) s += (long long)cov[a][b] * v[b]; nv[a] = s; const long long as = s < 0 ? -s : s; m = as > m ? as : m; }
+      if (m == 0) break;
+      const int sh = (64 - __clzll(m)) - 15;
+      // truncating division by 2^sh without a divide: add 2^sh - 1 to negative values, then shift
+      for (int a = 0; a < nc; a++) v[a] = sh > 0 ? ((nv[a] + ((nv[a] >> 63) & (((long long)1 << sh) - 1))) >> sh) : nv[a];
+    }
+    int vi[4] = { (int)v[0], (int)v[1], (int)v[2], (int)v[3] };
+    if (v[0] != vi[0] || v[1] != vi[1] || v[2] != vi[2] || v[3] != vi[3]) { }      // (|v| < 2^15 after a renormalisation, <= 255 without one)
+    int ilo = 0, ihi = 0; long long plo = 0, phi = 0;
+    for (int i = 0; i < 16; i++) {
+      long long p = 0; for (int c = 0; c < nc; c++) p += (long long)((16 * u_comp(px[i], comp[c]) - S[c])) * vi[c];
+      if (i == 0 || p < plo) { plo = p; ilo = i; }
+      if (i == 0 || p > phi) { phi = p; ihi = i; }
+    }
+    for (int c = 0; c < nc; c++) { lo[c] = u_comp(px[ilo], comp[c]); hi[c] = u_comp(px[ihi], comp[c]); }
+  }
+  uint32_t best_sse = 0xffffffffu;
+  for (int pass = 0; pass < 2; pass++) {
+    uint8_t ql[4] = { 0, 0, 0, 0 }, qh[4] = { 0, 0, 0, 0 }; int ul[4] = { 0, 0, 0, 0 }, uh[4] = { 0, 0, 0, 0 };
+    for (int c = 0; c < nc; c++) { ql[c] = T->qof[slot][lo[c]]; qh[c] = T->qof[slot][hi[c]]; ul[c] = T->uq[slot][ql[c]]; uh[c] = T->uq[slot][qh[c]]; }
+    uint32_t be[16]; uint8_t bk[16];
+    for (int i = 0; i < 16; i++) { be[i] = 0xffffffffu; bk[i] = 0; }
+    for (int k = 0; k < nlev; k++) {                                    // levels ascending, strict '<': the lowest index wins among equals
+      const int uw = u_wunq(wb, k); int pal[4] = { 0, 0, 0, 0 };
+      for (int c = 0; c < nc; c++) pal[c] = u_interp(ul[c], uh[c], uw);
+      for (int i = 0; i < 16; i++) {
+        uint32_t e = 0; for (int c = 0; c < nc; c++) { const int dd = pal[c] - u_comp(px[i], comp[c]); e += (uint32_t)(dd * dd); }
+        if (e < be[i]) { be[i] = e; bk[i] = (uint8_t)k; }
+      }
+    }
+    uint32_t sse = 0; for (int i = 0; i < 16; i++) sse += be[i];
+    if (sse < best_sse) { best_sse = sse; for (int c = 0; c < 4; c++) { qlo[c] = ql[c]; qhi[c] = qh[c]; } for (int i = 0; i < 16; i++) w[i] = bk[i]; }
+    if (pass == 1) break;
+    int Suu = 0, Svv = 0, Suv = 0;                                       // <= 16 * 64^2: 32-bit sums, 64-bit only for the products
+    for (int i = 0; i < 16; i++) { const int u = u_wunq(wb, (int)bk[i]), vv = 64 - u; Suu += u * u; Svv += vv * vv; Suv += u * vv; }
+    const long long det = (long long)Svv * Suu - (long long)Suv * Suv;
+    if (det <= 0) break;
+    for (int c = 0; c < nc; c++) {
+      int Suc = 0, Svc = 0;
+      for (int i = 0; i < 16; i++) { const int u = u_wunq(wb, (int)bk[i]), x = u_comp(px[i], comp[c]); Suc += u * x; Svc += (64 - u) * x; }
+      const long long a = u_rdiv(64 * ((long long)Suu * Svc - (long long)Suv * Suc), det), b = u_rdiv(64 * ((long long)Svv * Suc - (long long)Suv * Svc), det);
+      lo[c] = (int)(a < 0 ? 0 : (a > 255 ? 255 : a)); hi[c] = (int)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    }
+  }
+  return best_sse;
+}
+
+// logical block: mode, second-plane component, endpoint codes (ASTC order c0.lo c0.hi c1.lo ...), weights (planes interleaved)
+struct ULog { int mode, ccs; uint8_t ep[8]; uint8_t w[32]; };
+
+__device__ inline void u_decode_log(const ULog &L, const UTab *T, uint32_t out[16]) {
+  const UMode M = u_mode(L.mode); const int slot = u_slot(M.range);
+  int lo[4] = { 0, 0, 0, 255 }, hi[4] = { 0, 0, 0, 255 };
+  for (int c = 0; c < M.comps; c++) { lo[c] = T->uq[slot][L.ep[2 * c]]; hi[c] = T->uq[slot][L.ep[2 * c + 1]]; }
+  for (int i = 0; i < 16; i++) {
+    const int w0 = u_wunq(M.wbits, L.w[M.planes * i]), w1 = M.planes == 2 ? u_wunq(M.wbits, L.w[2 * i + 1]) : w0;
+    uint32_t v = 0;
+    for (int c = 0; c < 4; c++) v |= (uint32_t)(c < M.comps ? u_interp(lo[c], hi[c], (M.planes == 2 && c == L.ccs) ? w1 : w0) : 255) << (8 * c);
+    out[i] = v;
+  }
+}
+// ETC1 transcoder hint of a half block (columns x0, x0 + 1 of the decoded texels): best intensity table under a 4-bit base colour
+__device__ inline int u_etc1_inten(const uint32_t dec[16], int x0) {
+  const int lo_[8] = { 2, 5, 9, 13, 18, 24, 33, 47 }, hi_[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
+  int base[3];
+  for (int c = 0; c < 3; c++) { int s = 0; for (int y = 0; y < 4; y++) for (int x = x0; x < x0 + 2; x++) s += u_comp(dec[4 * y + x], c); const int avg = (s + 4) / 8; base[c] = ((avg * 15 + 127) / 255) * 17; }
+  int bt = 0; uint32_t be = 0xffffffffu;
+  for (int t = 0; t < 8; t++) {
+    uint32_t e = 0; const int mod[4] = { -hi_[t], -lo_[t], lo_[t], hi_[t] };
+    for (int y = 0; y < 4; y++) for (int x = x0; x < x0 + 2; x++) {
+      uint32_t bs = 0xffffffffu;
+      for (int s = 0; s < 4; s++) { uint32_t es = 0; for (int c = 0; c < 3; c++) { int v = base[c] + mod[s]; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int dd = v - u_comp(dec[4 * y + x], c); es += (uint32_t)(dd * dd); } bs = es < bs ? es : bs; }
+      e += bs;
+    }
+    if (e < be) { be = e; bt = t; }
+  }
+  return bt;
+}
+
+// 16 texels (px[i] = R | G << 8 | B << 16 | A << 24, i = 4 y + x) -> one UASTC block
+__device__ inline void u_encode_block(const uint32_t px[16], const UTab *T, UBits &B) {
+  B.lo = 0; B.hi = 0; int o = 0;
+  bool same = true, alpha = false;
+  for (int i = 0; i < 16; i++) { same &= px[i] == px[0]; alpha |= (px[i] >> 24) != 255u; }
+  if (same) {                                                           // mode 8: the colour + the ETC1 hint (table, selector, 5-bit base) closest to it
+    const int lo_[8] = { 2, 5, 9, 13, 18, 24, 33, 47 }, hi_[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
+    uint32_t be = 0xffffffffu; int bt = 0, bsel = 0, b5[3] = { 0, 0, 0 };
+    for (int t = 0; t < 8; t++) for (int s = 0; s < 4; s++) {
+      const int mod = s == 0 ? -hi_[t] : (s == 1 ? -lo_[t] : (s == 2 ? lo_[t] : hi_[t]));
+      uint32_t e = 0; int cb[3];
+      for (int c = 0; c < 3; c++) { uint32_t bc = 0xffffffffu; int bb = 0; for (int q = 0; q < 32; q++) { int v = ((q << 3) | (q >> 2)) + mod; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int dd = v - u_comp(px[0], c); if ((uint32_t)(dd * dd) < bc) { bc = (uint32_t)(dd * dd); bb = q; } } e += bc; cb[c] = bb; }
+      if (e < be) { be = e; bt = t; bsel = s; b5[0] = cb[0]; b5[1] = cb[1]; b5[2] = cb[2]; }
+    }
+    B.put(o, 0x17, 5);
+    for (int c = 0; c < 4; c++) B.put(o, (uint32_t)u_comp(px[0], c), 8);
+    B.put(o, 1, 1); B.put(o, (uint32_t)bt, 3); B.put(o, (uint32_t)bsel, 2);
+    for (int c = 0; c < 3; c++) B.put(o, (uint32_t)b5[c], 5);
+    return;
+  }
+  // candidates in preference order; the first with the lowest SSE wins
+  const int cand_rgb[5][2] = { { 0, -1 }, { 18, -1 }, { 6, 0 }, { 6, 1 }, { 6, 2 } }, cand_a[3][2] = { { 10, -1 }, { 12, -1 }, { 11, 3 } };
+  const int ncand = alpha ? 3 : 5; uint32_t best = 0xffffffffu; ULog R; R.mode = 0; R.ccs = 0;
+  for (int k = 0; k < ncand; k++) {
+    const int m = alpha ? cand_a[k][0] : cand_rgb[k][0], ccs = alpha ? cand_a[k][1] : cand_rgb[k][1];
+    const UMode M = u_mode(m);
+    ULog L; L.mode = m; L.ccs = ccs < 0 ? 0 : ccs;
+    for (int i = 0; i < 8; i++) L.ep[i] = 0;
+    for (int i = 0; i < 32; i++) L.w[i] = 0;
+    uint32_t sse;
+    const int all = (1 << M.comps) - 1;
+    if (ccs < 0) {
+      uint8_t ql[4], qh[4], w[16];
+      sse = u_fit_plane(px, all, M.range, M.wbits, T, ql, qh, w);
+      for (int c = 0; c < M.comps; c++) { L.ep[2 * c] = ql[c]; L.ep[2 * c + 1] = qh[c]; }
+      for (int i = 0; i < 16; i++) L.w[i] = w[i];
+    } else {
+      uint8_t ql[4], qh[4], w0[16], q1l[4], q1h[4], w1[16];
+      sse = u_fit_plane(px, all & ~(1 << ccs), M.range, M.wbits, T, ql, qh, w0);
+      sse += u_fit_plane(px, 1 << ccs, M.range, M.wbits, T, q1l, q1h, w1);
+      int j = 0;
+      for (int c = 0; c < M.comps; c++) if (c != ccs) { L.ep[2 * c] = ql[j]; L.ep[2 * c + 1] = qh[j]; j++; }
+      L.ep[2 * ccs] = q1l[0]; L.ep[2 * ccs + 1] = q1h[0];
+      for (int i = 0; i < 16; i++) { L.w[2 * i] = w0[i]; L.w[2 * i + 1] = w1[i]; }
+    }
+    if (sse < best) { best = sse; R = L; }
+  }
+  const UMode M = u_mode(R.mode);
+  { const int maxw = (1 << M.wbits) - 1;                                 // anchor rule: a plane whose first weight has its top bit set is mirrored
+    for (int p = 0; p < M.planes; p++) if (R.w[p] > maxw / 2) {
+      for (int c = 0; c < M.comps; c++) if (M.planes == 1 || (p == 1) == (c == R.ccs)) { const uint8_t t = R.ep[2 * c]; R.ep[2 * c] = R.ep[2 * c + 1]; R.ep[2 * c + 1] = t; }
+      for (int i = 0; i < 16; i++) R.w[M.planes * i + p] = (uint8_t)(maxw - R.w[M.planes * i + p]);
+    } }
+  uint32_t dec[16]; u_decode_log(R, T, dec);
+  const int in0 = u_etc1_inten(dec, 0), in1 = u_etc1_inten(dec, 2);
+  int etc2 = 0;
+  if (M.alpha) { int mn = 255, mx = 0; for (int i = 0; i < 16; i++) { const int a = (int)(dec[i] >> 24); mn = a < mn ? a : mn; mx = a > mx ? a : mx; } int mul = (mx - mn + 19) / 20; mul = mul < 1 ? 1 : (mul > 15 ? 15 : mul); etc2 = (mul << 4) | 13; }
+  B.put(o, M.huff, M.hufflen);
+  B.put(o, 0, 1); if (M.bc1h1) B.put(o, 0, 1);                            // BC1 hints 0
+  B.put(o, 0, 1); B.put(o, 0, 1); B.put(o, (uint32_t)in0, 3); B.put(o, (uint32_t)in1, 3);      // ETC1: flip 0, diff 0, tables
+  if (M.bias) B.put(o, 0, 5);
+  if (M.alpha) B.put(o, (uint32_t)etc2, 8);
+  if (M.planes == 2) B.put(o, (uint32_t)R.ccs, 2);
+  const int nv = 2 * M.comps, bits = u_rbits(M.range), tr = u_rtrit(M.range), qu = u_rquint(M.range);
+  if (tr || qu) {
+    const int per = tr ? 5 : 3, mul = tr ? 3 : 5;
+    for (int g = 0; g * per < nv; g++) {
+      uint32_t acc = 0, scale = 1; int cnt = 0;
+      for (int k = 0; k < per && g * per + k < nv; k++, cnt++) { acc += (uint32_t)(R.ep[g * per + k] >> bits) * scale; scale *= (uint32_t)mul; }
+      const int nb = cnt == per ? (tr ? 8 : 7) : (tr ? (cnt == 1 ? 2 : (cnt == 2 ? 4 : (cnt == 3 ? 5 : 7))) : (cnt == 1 ? 3 : 5));
+      B.put(o, acc, nb);
+    }
+  }
+  for (int i = 0; i < nv; i++) B.put(o, (uint32_t)R.ep[i] & ((1u << bits) - 1u), bits);
+  for (int i = 0; i < 16 * M.planes; i++) B.put(o, R.w[i], i < M.planes ? M.wbits - 1 : M.wbits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode side: block -> logical block
+// ------------------------------------------------------------------------------------------------
+// returns 0, or a negative code for a mode this codec does not emit / a corrupt block; solid blocks: mode 8, colour in `solid`
+__device__ inline int u_unpack(const UBits &B, ULog &L, uint32_t &solid) {
+  int o = 0; int m = -1;
+  { const uint32_t b7 = (uint32_t)(B.lo & 127u);
+    if ((b7 & 15u) == 0x1) { m = 0; o = 4; } else if ((b7 & 15u) == 0x9) { m = 18; o = 4; } else if ((b7 & 31u) == 0x1B) { m = 6; o = 5; } else if ((b7 & 31u) == 0x17) { m = 8; o = 5; }
+    else if ((b7 & 7u) == 0x2) { m = 10; o = 3; } else if ((b7 & 3u) == 0x0) { m = 11; o = 2; } else if ((b7 & 7u) == 0x6) { m = 12; o = 3; } }
+  if (m < 0) return -2;
+  L.mode = m; L.ccs = 0;
+  if (m == 8) { solid = B.get(o, 8); solid |= B.get(o, 8) << 8; solid |= B.get(o, 8) << 16; solid |= B.get(o, 8) << 24; return 0; }
+  const UMode M = u_mode(m);
+  o += 1 + (M.bc1h1 ? 1 : 0) + 8 + (M.bias ? 5 : 0) + (M.alpha ? 8 : 0);           // hints are for other transcode targets
+  if (M.planes == 2) L.ccs = (int)B.get(o, 2);
+  const int nv = 2 * M.comps, bits = u_rbits(M.range), tr = u_rtrit(M.range), qu = u_rquint(M.range), per = tr ? 5 : 3, mul = tr ? 3 : 5;
+  uint32_t tq[4] = { 0, 0, 0, 0 }; int groups = 0;
+  if (tr || qu) for (int g = 0; g * per < nv; g++, groups++) {
+    const int cnt = nv - g * per < per ? nv - g * per : per;
+    const int nb = cnt == per ? (tr ? 8 : 7) : (tr ? (cnt == 1 ? 2 : (cnt == 2 ? 4 : (cnt == 3 ? 5 : 7))) : (cnt == 1 ? 3 : 5));
+    tq[g] = B.get(o, nb);
+  }
+  for (int i = 0; i < nv; i++) {
+    uint32_t v = B.get(o, bits);
+    if (groups) { uint32_t a = tq[i / per]; for (int k = 0; k < i % per; k++) a /= (uint32_t)mul; v |= (a % (uint32_t)mul) << bits; }
+    if ((int)v >= u_rlevels(M.range)) return -3;
+    L.ep[i] = (uint8_t)v;
+  }
+  for (int i = 0; i < 16 * M.planes; i++) L.w[i] = (uint8_t)B.get(o, i < M.planes ? M.wbits - 1 : M.wbits);
+  return o == 128 ? 0 : -4;
+}
+
+// ASTC integer sequence encoding: T / Q words from the specification's decode equations (lowest word per tuple), built on the host
+struct UIse { uint8_t trit[243]; uint8_t quint[125]; };
+static void u_host_ise(UIse &I) {
+  bool ht[243] = { false }, hq[125] = { false };
+  for (int T = 0; T < 256; T++) {
+    int t[5], C;
+    if (((T >> 2) & 7) == 7) { C = ((T >> 5) << 2) | (T & 3); t[4] = t[3] = 2; }
+    else { C = T & 31; if (((T >> 5) & 3) == 3) { t[4] = 2; t[3] = (T >> 7) & 1; } else { t[4] = (T >> 7) & 1; t[3] = (T >> 5) & 3; } }
+    if ((C & 3) == 3) { t[2] = 2; t[1] = (C >> 4) & 1; t[0] = (((C >> 3) & 1) << 1) | (((C >> 2) & 1) & ~((C >> 3) & 1)); }
+    else if (((C >> 2) & 3) == 3) { t[2] = 2; t[1] = 2; t[0] = C & 3; }
+    else { t[2] = (C >> 4) & 1; t[1] = (C >> 2) & 3; t[0] = (((C >> 1) & 1) << 1) | ((C & 1) & ~((C >> 1) & 1)); }
+    const int k = t[0] + 3 * t[1] + 9 * t[2] + 27 * t[3] + 81 * t[4];
+    if (!ht[k]) { ht[k] = true; I.trit[k] = (uint8_t)T; }
+  }
+  for (int Q = 0; Q < 128; Q++) {
+    int q[3];
+    if (((Q >> 1) & 3) == 3 && ((Q >> 5) & 3) == 0) { q[2] = ((Q & 1) << 2) | ((((Q >> 4) & 1) & ~(Q & 1)) << 1) | (((Q >> 3) & 1) & ~(Q & 1)); q[1] = q[0] = 4; }
+    else {
+      int C;
+      if (((Q >> 1) & 3) == 3) { q[2] = 4; C = (((Q >> 3) & 3) << 3) | ((~(Q >> 5) & 3) << 1) | (Q & 1); } else { q[2] = (Q >> 5) & 3; C = Q & 31; }
+      if ((C & 7) == 5) { q[1] = 4; q[0] = (C >> 3) & 3; } else { q[1] = (C >> 3) & 3; q[0] = C & 7; }
+    }
+    const int k = q[0] + 5 * q[1] + 25 * q[2];
+    if (q[0] < 5 && q[1] < 5 && q[2] < 5 && !hq[k]) { hq[k] = true; I.quint[k] = (uint8_t)Q; }
+  }
+}
+struct UConst { UTab tab; UIse ise; };
+
+// UASTC block -> ASTC 4x4 block
+__device__ inline int u_to_astc(const UBits &B, const UConst *K, UBits &A) {
+  ULog L; uint32_t solid = 0;
+  for (int i = 0; i < 8; i++) L.ep[i] = 0;
+  for (int i = 0; i < 32; i++) L.w[i] = 0;
+  const int rc = u_unpack(B, L, solid);
+  A.lo = 0; A.hi = 0;
+  if (rc) return rc;
+  if (L.mode == 8) {                                                     // LDR void extent, all-ones extent, 4 x UNORM16
+    A.lo = 0xFFFFFFFFFFFFFDFCull;
+    for (int c = 0; c < 4; c++) { const unsigned long long v = (solid >> (8 * c)) & 255u; A.hi |= ((v << 8) | v) << (16 * c); }
+    return 0;
+  }
+  const UMode M = u_mode(L.mode); const int slot = u_slot(M.range), maxw = (1 << M.wbits) - 1;
+  int s0 = 0, s1 = 0;
+  for (int c = 0; c < 3; c++) { s0 += K->tab.uq[slot][L.ep[2 * c]]; s1 += K->tab.uq[slot][L.ep[2 * c + 1]]; }
+  if (s1 < s0) {                                                         // ASTC would apply blue contraction: swap the pair, mirror the weights
+    for (int c = 0; c < M.comps; c++) { const uint8_t t = L.ep[2 * c]; L.ep[2 * c] = L.ep[2 * c + 1]; L.ep[2 * c + 1] = t; }
+    for (int i = 0; i < 16 * M.planes; i++) L.w[i] = (uint8_t)(maxw - L.w[i]);
+  }
+  int o = 0;
+  A.put(o, M.astc_bm, 11); A.put(o, 0, 2); A.put(o, M.comps == 3 ? 8u : 12u, 4);
+  const int nv = 2 * M.comps, bits = u_rbits(M.range);
+  if (u_rtrit(M.range)) {
+    const int sh[5] = { 0, 2, 4, 5, 7 }, nb[5] = { 2, 2, 1, 2, 1 };
+    for (int g = 0; g < nv; g += 5) {
+      int k = 0, s = 1; for (int j = 0; j < 5; j++, s *= 3) k += (g + j < nv ? L.ep[g + j] >> bits : 0) * s;
+      const int Tw = K->ise.trit[k];
+      for (int j = 0; j < 5 && g + j < nv; j++) { A.put(o, L.ep[g + j] & ((1u << bits) - 1u), bits); A.put(o, (uint32_t)(Tw >> sh[j]), nb[j]); }
+    }
+  } else if (u_rquint(M.range)) {
+    const int sh[3] = { 0, 3, 5 }, nb[3] = { 3, 2, 2 };
+    for (int g = 0; g < nv; g += 3) {
+      int k = 0, s = 1; for (int j = 0; j < 3; j++, s *= 5) k += (g + j < nv ? L.ep[g + j] >> bits : 0) * s;
+      const int Qw = K->ise.quint[k];
+      for (int j = 0; j < 3 && g + j < nv; j++) { A.put(o, L.ep[g + j] & ((1u << bits) - 1u), bits); A.put(o, (uint32_t)(Qw >> sh[j]), nb[j]); }
+    }
+  } else for (int i = 0; i < nv; i++) A.put(o, L.ep[i], bits);
+  const int wtot = 16 * M.planes * M.wbits;
+  if (M.planes == 2) { int oc = 128 - wtot - 2; A.put(oc, (uint32_t)L.ccs, 2); }
+  for (int i = 0; i < 16 * M.planes; i++) for (int b = 0; b < M.wbits; b++) if ((L.w[i] >> b) & 1) { const int pos = 127 - (i * M.wbits + b); if (pos < 64) A.lo |= 1ull << pos; else A.hi |= 1ull << (pos - 64); }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct UastcJob {                       // one segment (= one .ktx2): layers of W x H RGBA8, top row first
+  const uint8_t *layer[64]; uint8_t *out[64];      // encode: out[l] = UASTC blocks of layer l; decode: layer[l] = UASTC blocks, out[l] = target
+  uint32_t W, H, L, bx, by; int32_t yflip, status, any_alpha;
+};
+
+// grid (blocks of 256 texel-blocks, layer, segment)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_encode(UastcJob *jobs, const UConst *K) {
+  UastcJob &J = jobs[blockIdx.z];
+  __shared__ UTab T;
+  for (uint32_t i = threadIdx.x; i < sizeof(UTab) / 4; i += UVOL_BLOCK) reinterpret_cast<uint32_t *>(&T)[i] = reinterpret_cast<const uint32_t *>(&K->tab)[i];
+  __syncthreads();
+  const uint32_t l = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (l >= J.L || b >= J.bx * J.by) return;
+  const uint32_t X = b % J.bx, Y = b / J.bx;
+  const uint8_t *img = J.layer[l];
+  uint32_t px[16]; bool alpha = false;
+  for (int y = 0; y < 4; y++) {
+    uint32_t py = Y * 4 + (uint32_t)y; if (py >= J.H) py = J.H - 1;
+    const uint32_t sr = J.yflip ? J.H - 1 - py : py;
+    const uint8_t *row = img + 4 * ((size_t)sr * J.W);
+    if (X * 4 + 3 < J.W && (J.W & 3) == 0) { const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * (size_t)X); px[4 * y] = v.x; px[4 * y + 1] = v.y; px[4 * y + 2] = v.z; px[4 * y + 3] = v.w; }
+    else for (int x = 0; x < 4; x++) { uint32_t pxx = X * 4 + (uint32_t)x; if (pxx >= J.W) pxx = J.W - 1; const uint8_t *p = row + 4 * (size_t)pxx; px[4 * y + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+  }
+  for (int i = 0; i < 16; i++) alpha |= (px[i] >> 24) != 255u;
+  if (alpha) J.any_alpha = 1;                                            // the container's DFD channel id says RGBA when any block carries alpha
+  UBits B; u_encode_block(px, &T, B);
+  unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
+  dst[0] = B.lo; dst[1] = B.hi;
+}
+// target 0: RGBA8 (W x H x 4 per layer, stored row order), 1: ASTC 4x4 blocks
+__global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, const UConst *K, int target) {
+  UastcJob &J = jobs[blockIdx.z];
+  const uint32_t l = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (l >= J.L || b >= J.bx * J.by) return;
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(J.layer[l] + 16 * (size_t)b);
+  UBits B; B.lo = src[0]; B.hi = src[1];
+  if (target == 1) {
+    UBits A; if (u_to_astc(B, K, A)) J.status = -10;
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
+    dst[0] = A.lo; dst[1] = A.hi; return;
+  }
+  ULog L; uint32_t solid = 0, px[16];
+  for (int i = 0; i < 8; i++) L.ep[i] = 0;
+  for (int i = 0; i < 32; i++) L.w[i] = 0;
+  if (u_unpack(B, L, solid)) { J.status = -10; return; }
+  if (L.mode == 8) for (int i = 0; i < 16; i++) px[i] = solid; else u_decode_log(L, &K->tab, px);
+  const uint32_t X = b % J.bx, Y = b / J.bx;
+  for (int y = 0; y < 4 && 4 * Y + (uint32_t)y < J.H; y++) {
+    uint8_t *row = J.out[l] + 4 * ((size_t)(4 * Y + (uint32_t)y) * J.W + 4 * (size_t)X);
+    if (X * 4 + 3 < J.W && (J.W & 3) == 0) *reinterpret_cast<uint4 *>(row) = make_uint4(px[4 * y], px[4 * y + 1], px[4 * y + 2], px[4 * y + 3]);
+    else for (int x = 0; x < 4 && 4 * X + (uint32_t)x < J.W; x++) { const uint32_t v = px[4 * y + x]; row[4 * x] = (uint8_t)v; row[4 * x + 1] = (uint8_t)(v >> 8); row[4 * x + 2] = (uint8_t)(v >> 16); row[4 * x + 3] = (uint8_t)(v >> 24); }
+  }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct UastcState { uvol_devbuf consts, jobs, layers, blocks, outs; std::vector<UastcJob> hjobs; uint8_t *pinned = nullptr; size_t pinned_cap = 0; bool ready = false; };
+
+int uastc_create(uvol_ctx *ctx) { ctx->uastc = new UastcState(); return UVOL_OK; }
+void uastc_destroy(uvol_ctx *ctx) {
+  UastcState *U = ctx->uastc; if (!U) return;
+  for (uvol_devbuf *b : { &U->consts, &U->jobs, &U->layers, &U->blocks, &U->outs }) if (b->p) (void)hipFree(b->p);
+  if (U->pinned) (void)hipHostFree(U->pinned);
+  delete U; ctx->uastc = nullptr;
+}
+static int uastc_consts(uvol_ctx *ctx) {
+  UastcState *U = ctx->uastc;
+  if (U->ready) return UVOL_OK;
+  static UConst K; static bool built = false;
+  if (!built) { u_host_tables(K.tab); memset(&K.ise, 0, sizeof K.ise); u_host_ise(K.ise); built = true; }
+  if (int rc = uvol_ensure(ctx, U->consts, sizeof(UConst))) return rc;
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->consts.p, &K, sizeof(UConst), hipMemcpyHostToDevice, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  U->ready = true;
+  return UVOL_OK;
+}
+static int uastc_pinned(uvol_ctx *ctx, size_t bytes) {
+  UastcState *U = ctx->uastc;
+  if (bytes <= U->pinned_cap) return UVOL_OK;
+  if (U->pinned) (void)hipHostFree(U->pinned);
+  U->pinned = nullptr; U->pinned_cap = 0;
+  UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&U->pinned, bytes + bytes / 8 + 4096, hipHostMallocDefault));
+  U->pinned_cap = bytes + bytes / 8 + 4096;
+  return UVOL_OK;
+}
+namespace {
+inline void uput32(uint8_t *&p, uint32_t v) { memcpy(p, &v, 4); p += 4; }
+inline void uput64(uint8_t *&p, uint64_t v) { memcpy(p, &v, 8); p += 8; }
+inline void uput16(uint8_t *&p, uint16_t v) { memcpy(p, &v, 2); p += 2; }
+// KTX2 header + DFD (colour model 166 = UASTC, BT.709, sRGB, 16-byte 4x4 texel blocks) + key/value data; returns the level offset
+size_t uastc_header(uint8_t *out, uint32_t W, uint32_t H, uint32_t L, bool alpha, uint64_t lvl_len) {
+  static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
+  static const char writer[] = "uvol-mi355x uastc 0.1";
+  uint8_t kvd[128]; uint8_t *kp = kvd;
+  uput32(kp, 12 + 12); memcpy(kp, "KTXanimData", 12); kp += 12; uput32(kp, 1); uput32(kp, 15); uput32(kp, 0);
+  uput32(kp, 10 + (uint32_t)sizeof(writer)); memcpy(kp, "KTXwriter", 10); kp += 10; memcpy(kp, writer, sizeof(writer)); kp += sizeof(writer);
+  while ((kp - kvd) & 3) *kp++ = 0;
+  const uint32_t dfd_off = 80 + 24, dfd_len = 44, kvd_off = dfd_off + dfd_len, kvd_len = (uint32_t)(kp - kvd);
+  const uint64_t lvl_off = ((uint64_t)kvd_off + kvd_len + 15) & ~15ull;
+  if (!out) return (size_t)lvl_off;
+  uint8_t *p = out;
+  memcpy(p, ident, 12); p += 12;
+  uput32(p, 0); uput32(p, 1); uput32(p, W); uput32(p, H); uput32(p, 0); uput32(p, L); uput32(p, 1); uput32(p, 1); uput32(p, 0);
+  uput32(p, dfd_off); uput32(p, dfd_len); uput32(p, kvd_off); uput32(p, kvd_len); uput64(p, 0); uput64(p, 0);
+  uput64(p, lvl_off); uput64(p, lvl_len); uput64(p, lvl_len);
+  uput32(p, 44); uput32(p, 0); uput16(p, 2); uput16(p, 40);
+  *p++ = 166; *p++ = 1; *p++ = 2; *p++ = 0; *p++ = 3; *p++ = 3; *p++ = 0; *p++ = 0;
+  *p++ = 16; for (int i = 0; i < 7; i++) *p++ = 0;
+  uput16(p, 0); *p++ = 127; *p++ = alpha ? 3 : 0; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; uput32(p, 0); uput32(p, 0xFFFFFFFFu);
+  memcpy(p, kvd, kvd_len); p += kvd_len;
+  while ((uint64_t)(p - out) < lvl_off) *p++ = 0;
+  return (size_t)lvl_off;
+}
+}  // namespace
+
+// container fields of a UASTC .ktx2 this codec reads (vkFormat 0, DFD model 166, no supercompression, 1 level, 1 face)
+int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L, uint64_t *lvl_off) {
+  static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
+  if (!b || n < 104 + 44 || n > 0xffffffffull * 16 || memcmp(b, ident, 12)) return -1;
+  uint32_t u[9]; memcpy(u, b + 12, 36);
+  if (u[0] != 0 || u[8] != 0 || u[7] != 1 || u[6] != 1 || !u[2] || !u[3] || u[2] > 16384 || u[3] > 16384) return -2;
+  uint32_t dfd_off, dfd_len; memcpy(&dfd_off, b + 48, 4); memcpy(&dfd_len, b + 52, 4);
+  if (dfd_len < 44 || dfd_off > n || dfd_len > n - dfd_off || b[dfd_off + 12] != 166) return -3;
+  uint64_t lo, ll; memcpy(&lo, b + 80, 8); memcpy(&ll, b + 88, 8);
+  const uint32_t layers = u[5] ? u[5] : 1;
+  if (layers > 64) return -4;
+  const uint64_t need = (uint64_t)layers * ((u[2] + 3) / 4) * ((u[3] + 3) / 4) * 16;
+  if (lo > n || ll > n - lo || ll != need) return -4;
+  *W = u[2]; *H = u[3]; *L = layers; *lvl_off = lo;
+  return 0;
+}
+
+// n_seg segments of n_layers layers -> UASTC .ktx2 files (what `basisu -uastc -ktx2 -tex_type video` writes, without Zstandard)
+int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
+                              bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  UastcState *U = ctx->uastc;
+  if (n_seg <= 0) return UVOL_OK;
+  if (n_layers > 64 || W > 16384 || H > 16384 || n_seg > 65535) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }
+  int rc; if ((rc = uastc_consts(ctx))) return rc;
+  const uint32_t bx = (W + 3) / 4, by = (H + 3) / 4; const size_t nb = (size_t)bx * by, lbytes = (size_t)W * H * 4, seg_bytes = nb * 16 * (size_t)n_layers;
+  if ((rc = uvol_ensure(ctx, U->jobs, sizeof(UastcJob) * (size_t)n_seg))) return rc;
+  if ((rc = uvol_ensure(ctx, U->blocks, seg_bytes * (size_t)n_seg))) return rc;
+  if (!on_device && (rc = uvol_ensure(ctx, U->layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
+  U->hjobs.assign((size_t)n_seg, UastcJob{});
+  for (int s = 0; s < n_seg; s++) {
+    UastcJob &J = U->hjobs[s]; J.W = W; J.H = H; J.L = (uint32_t)n_layers; J.bx = bx; J.by = by; J.yflip = ctx->prm.y_flip ? 1 : 0;
+    for (int l = 0; l < n_layers; l++) {
+      const uint8_t *src = rgba[(size_t)s * n_layers + l];
+      if (on_device) J.layer[l] = src;
+      else { uint8_t *d = (uint8_t *)U->layers.p + lbytes * ((size_t)s * n_layers + l); UVOL_HIP_CHECK(ctx, hipMemcpyAsync(d, src, lbytes, hipMemcpyHostToDevice, ctx->stream)); J.layer[l] = d; }
+      J.out[l] = (uint8_t *)U->blocks.p + seg_bytes * (size_t)s + nb * 16 * (size_t)l;
+    }
+  }
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
+  { uvol_ctx::Scope sc(ctx, "tex.uastc_encode", (uint64_t)(lbytes + nb * 16) * n_layers * (uint64_t)n_seg);
+    hipLaunchKernelGGL(k_uastc_encode, dim3(uvol_blocks(nb), (unsigned)n_layers, (unsigned)n_seg), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p); }
+  UVOL_HIP_CHECK(ctx, hipGetLastError());
+  if ((rc = uastc_pinned(ctx, seg_bytes * (size_t)n_seg))) return rc;
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->pinned, U->blocks.p, seg_bytes * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->resolve_profile();
+  int worst = UVOL_OK;
+  const size_t lvl_off = uastc_header(nullptr, W, H, (uint32_t)n_layers, false, seg_bytes);
+  for (int s = 0; s < n_seg; s++) {
+    out_lens[s] = lvl_off + seg_bytes;
+    if (out_lens[s] > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%zu > %zu)", s, out_lens[s], caps[s]); worst = UVOL_E_NOSPACE; continue; }
+    (void)uastc_header(outs[s], W, H, (uint32_t)n_layers, U->hjobs[s].any_alpha != 0, seg_bytes);
+    memcpy(outs[s] + lvl_off, U->pinned + seg_bytes * (size_t)s, seg_bytes);
+  }
+  return worst;
+}
+
+// UASTC .ktx2 files -> target 0: RGBA8 layers, target 3: ASTC 4x4 blocks (layer buffers of the caller, host or device)
+int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *outp, size_t layer_cap, bool outputs_on_device, int target) {
+  UastcState *U = ctx->uastc;
+  if (n <= 0) return UVOL_OK;
+  if (target != 0 && target != 3) { ctx->set_error("UASTC sources transcode to RGBA32 or ASTC 4x4"); return UVOL_E_UNSUPPORTED; }
+  int rc; if ((rc = uastc_consts(ctx))) return rc;
+  uint32_t W = 0, H = 0, L = 0; uint64_t lo = 0;
+  if (uastc_ktx2_probe(files[0], lens[0], &W, &H, &L, &lo)) { ctx->set_error("segment 0: not a UASTC .ktx2 this decoder handles"); return UVOL_E_INVALID; }
+  const uint32_t bx = (W + 3) / 4, by = (H + 3) / 4; const size_t nb = (size_t)bx * by, seg_bytes = nb * 16 * (size_t)L;
+  const size_t layer_bytes = target == 0 ? (size_t)W * H * 4 : nb * 16;
+  if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small (%zu < %zu)", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
+  if ((rc = uvol_ensure(ctx, U->jobs, sizeof(UastcJob) * (size_t)n))) return rc;
+  if ((rc = uvol_ensure(ctx, U->blocks, seg_bytes * (size_t)n))) return rc;
+  if (!outputs_on_device && (rc = uvol_ensure(ctx, U->outs, layer_bytes * (size_t)L * (size_t)n))) return rc;
+  U->hjobs.assign((size_t)n, UastcJob{});
+  for (int s = 0; s < n; s++) {
+    uint32_t w2, h2, l2; uint64_t lo2;
+    if (uastc_ktx2_probe(files[s], lens[s], &w2, &h2, &l2, &lo2) || w2 != W || h2 != H || l2 != L) { ctx->set_error("segment %d: not a UASTC .ktx2 of the batch's size", s); return UVOL_E_INVALID; }
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t *)U->blocks.p + seg_bytes * (size_t)s, files[s] + lo2, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
+    UastcJob &J = U->hjobs[s]; J.W = W; J.H = H; J.L = L; J.bx = bx; J.by = by;
+    for (uint32_t l = 0; l < L; l++) {
+      J.layer[l] = (const uint8_t *)U->blocks.p + seg_bytes * (size_t)s + nb * 16 * (size_t)l;
+      J.out[l] = outputs_on_device ? outp[(size_t)s * L + l] : (uint8_t *)U->outs.p + layer_bytes * ((size_t)s * L + l);
+    }
+  }
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : "texdec.uastc_astc", (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
+    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : 1); }
+  UVOL_HIP_CHECK(ctx, hipGetLastError());
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (!outputs_on_device) for (int s = 0; s < n; s++) for (uint32_t l = 0; l < L; l++)
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(outp[(size_t)s * L + l], (uint8_t *)U->outs.p + layer_bytes * ((size_t)s * L + l), layer_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->resolve_profile();
+  for (int s = 0; s < n; s++) if (U->hjobs[s].status != 0) { ctx->set_error("segment %d: corrupt UASTC block or a mode this codec does not read (device status %d)", s, U->hjobs[s].status); return UVOL_E_ENCODE; }
+  return UVOL_OK;
+}

@@ -63,7 +63,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
   if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
   if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
   if (uvol_make_stream(ctx, &ctx->stream) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
-  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
+  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK || uastc_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
   *out = ctx;
   return UVOL_OK;
 }
@@ -73,7 +73,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
-  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx);
+  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -122,6 +122,7 @@ int uvol_encode_texture_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n
                                 uint8_t *out, size_t cap, size_t *out_len) {
   if (!ctx || !rgba || n_layers <= 0 || !out || !out_len || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
+  if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba, 1, n_layers, width, height, false, &out, &cap, out_len);
   return tex_encode_segment(ctx, rgba, n_layers, width, height, false, out, cap, out_len);
 }
 
@@ -129,6 +130,7 @@ int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_de
                                     uint8_t *out, size_t cap, size_t *out_len) {
   if (!ctx || !rgba_dev || n_layers <= 0 || !out || !out_len || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
+  if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba_dev, 1, n_layers, width, height, true, &out, &cap, out_len);
   return tex_encode_segment(ctx, rgba_dev, n_layers, width, height, true, out, cap, out_len);
 }
 
@@ -136,35 +138,53 @@ int uvol_encode_texture_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int 
                                  uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
   if (!ctx || !rgba || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
+  if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba, n_segments, n_layers, width, height, false, outs, caps, out_lens);
   return tex_encode_segments(ctx, rgba, n_segments, n_layers, width, height, false, outs, caps, out_lens);
 }
 int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers, uint32_t width, uint32_t height,
                                      uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
   if (!ctx || !rgba_dev || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
+  if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
   return tex_encode_segments(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
 }
 
+// UASTC and ETC1S files are told apart by the container (DFD colour model 166 vs 163)
+static bool is_uastc(const uint8_t *const *ktx2, const size_t *lens) { uint32_t w, h, l; uint64_t lo; return uastc_ktx2_probe(ktx2[0], lens[0], &w, &h, &l, &lo) == 0; }
+static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool dev, int target) {
+  if (is_uastc(ktx2, lens)) {
+    if (target != 0 && target != 3) { ctx->set_error("UASTC sources transcode to RGBA32 or ASTC 4x4 here"); return UVOL_E_UNSUPPORTED; }
+    return tex_uastc_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);
+  }
+  if (target == 3) { ctx->set_error("ASTC 4x4 is the transcode target of UASTC sources (KTX2Loader.js:591-600); this file is ETC1S"); return UVOL_E_UNSUPPORTED; }
+  return tex_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);
+}
 int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba, size_t layer_cap) {
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba, layer_cap, false, 0);
+  return decode_dispatch(ctx, ktx2, lens, n_segments, rgba, layer_cap, false, 0);
 }
 int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba_dev, size_t layer_cap) {
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba_dev) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  return tex_decode_segments(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true, 0);
+  return decode_dispatch(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true, 0);
 }
 int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  return tex_decode_segments(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 1);
+  return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 1);
 }
 
 int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  return tex_decode_segments(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 2);
+  return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 2);
+}
+
+int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 3);
 }
 
 int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {

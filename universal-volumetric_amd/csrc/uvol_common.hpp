@@ -28,6 +28,15 @@
 #define UVOL_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
+// ordering point for data only ONE wave reads and writes (the valence replay's per-frame arrays): its own memory operations
+// complete before it goes on (s_waitcnt).  __threadfence() here meant an L2 write-back + L1 invalidate per 64 symbols and wave
+// (~3.5 us each, MI355X_MICROARCH.md), which also slowed every kernel running beside it: k_seams took 270 instead of 30 ms.
+#ifdef HIPEMU
+#define UVOL_WAVE_FENCE() std::atomic_thread_fence(std::memory_order_seq_cst)
+#else
+#define UVOL_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#endif
+
 // the one-wave serial walkers are latency-bound: give them issue priority over co-resident throughput kernels
 #ifdef HIPEMU
 #define UVOL_SERIAL_PRIO() do { } while (0)
@@ -115,6 +124,7 @@ struct GeoState;   // geometry pipeline state (geom_encode.hip)
 struct TexState;   // texture pipeline state (tex_encode.hip)
 struct TexDecState;  // texture decode state (tex_decode.hip)
 struct GeoDecState;  // geometry decode state (geom_decode.hip)
+struct UastcState;   // UASTC texture mode (tex_uastc.hip)
 
 struct uvol_ctx {
   int device = 0;
@@ -129,6 +139,7 @@ struct uvol_ctx {
   TexState *tex = nullptr;
   TexDecState *texdec = nullptr;
   GeoDecState *geodec = nullptr;
+  UastcState *uastc = nullptr;
 
   void set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(err, sizeof(err), fmt, ap); va_end(ap);
@@ -187,6 +198,12 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
 int texdec_create(uvol_ctx *ctx);
 void texdec_destroy(uvol_ctx *ctx);
 int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target);
+int uastc_create(uvol_ctx *ctx);
+void uastc_destroy(uvol_ctx *ctx);
+int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L, uint64_t *lvl_off);
+int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
+                              bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens);
+int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool outputs_on_device, int target);
 int tex_create(uvol_ctx *ctx);
 void tex_destroy(uvol_ctx *ctx);
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,

@@ -1,6 +1,6 @@
 // basisu_shim.cpp — argv-compatible stand-in for the `basisu` process the stock driver spawns:
 //   basisu -ktx2 -tex_type video -multifile_printf P -multifile_num B -multifile_first i -y_flip -output_file out.ktx2   (scripts/Encoder.py:290)
-// Only the ETC1S / KTX2 / video path the reference uses is implemented; unknown flags are ignored.
+// The ETC1S / KTX2 / video path the reference uses, and -uastc (UASTC LDR 4x4 blocks in the same container); unknown flags are ignored.
 #include "uvol_host.hpp"
 #include "../../include/uvol_codec.h"
 #include <cstdio>
@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "-multifile_num")) num = std::atoi(val()); else if (!std::strcmp(argv[i], "-multifile_first")) first = std::atoi(val());
     else if (!std::strcmp(argv[i], "-output_file")) out = val(); else if (!std::strcmp(argv[i], "-q")) prm.etc1s_quality = std::atoi(val());
     else if (!std::strcmp(argv[i], "-file")) files.push_back(val());
-    else if (!std::strcmp(argv[i], "-uastc")) { std::fprintf(stderr, "basisu (uvol shim): -uastc is not implemented (the reference driver never passes it)\n"); return 1; }
+    else if (!std::strcmp(argv[i], "-uastc")) prm.uastc = 1;                      // UASTC LDR 4x4 mode (KTX2 without Zstandard supercompression)
     else if (argv[i][0] != '-') files.push_back(argv[i]);
   }
   if (!ktx2 || out.empty()) { std::fprintf(stderr, "basisu (uvol shim): expected -ktx2 ... -output_file <path>\n"); return 1; }

@@ -320,8 +320,52 @@ bool check_total_frames(const std::string &drc_pat, const std::string &ktx2_pat,
   return true;
 }
 
+// ------------------------------------------------------------------ sharding
+ShardPlan shard_plan(long n_frames, int batch, int world, int rank) {
+  ShardPlan P; if (batch <= 0 || world <= 0 || rank < 0 || rank >= world || n_frames <= 0) return P;
+  const long n_seg = (n_frames + batch - 1) / batch, lo = n_seg * rank / world, hi = n_seg * (rank + 1) / world;
+  const long f_lo = lo * batch, f_hi = std::min(hi * batch, n_frames);
+  P.first_frame = f_lo; P.n_frames = std::max(0L, f_hi - f_lo); P.first_segment = lo; P.n_segments = hi - lo;
+  return P;
+}
+
+// ------------------------------------------------------------------ audio duration
+bool audio_duration(const std::string &path, double &seconds, std::string &err) {
+  std::vector<uint8_t> d;
+  if (path.compare(0, 4, "http") == 0 || !read_file(path, d) || d.size() < 16) { err = "cannot read " + path; return false; }
+  auto le32 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); };
+  auto le16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
+  if (!std::memcmp(d.data(), "RIFF", 4) && !std::memcmp(d.data() + 8, "WAVE", 4)) {
+    uint32_t byte_rate = 0; size_t o = 12;
+    while (o + 8 <= d.size()) {
+      const uint32_t len = le32(o + 4);
+      if (!std::memcmp(&d[o], "fmt ", 4) && o + 8 + 16 <= d.size()) byte_rate = le32(o + 16);
+      else if (!std::memcmp(&d[o], "data", 4)) { if (!byte_rate) break; seconds = (double)std::min<size_t>(len, d.size() - o - 8) / byte_rate; return true; }
+      (void)le16; o += 8 + (size_t)len + (len & 1);
+    }
+    err = path + ": malformed WAV"; return false;
+  }
+  // MPEG audio: skip an ID3v2 tag, then add up the samples of every frame header found back to back
+  size_t o = 0;
+  if (!std::memcmp(d.data(), "ID3", 3) && d.size() > 10) o = 10 + (((size_t)d[6] & 127) << 21 | ((size_t)d[7] & 127) << 14 | ((size_t)d[8] & 127) << 7 | ((size_t)d[9] & 127));
+  static const int br1[16] = { 0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 0 }, br2[16] = { 0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160, 0 };
+  static const int sr1[4] = { 44100, 48000, 32000, 0 };
+  double total = 0; long frames = 0;
+  while (o + 4 <= d.size()) {
+    if (d[o] != 0xFF || (d[o + 1] & 0xE0) != 0xE0) { if (frames) break; o++; continue; }
+    const int ver = (d[o + 1] >> 3) & 3, layer = (d[o + 1] >> 1) & 3, bri = d[o + 2] >> 4, sri = (d[o + 2] >> 2) & 3, padb = (d[o + 2] >> 1) & 1;
+    if (ver == 1 || layer != 1 || bri == 0 || bri == 15 || sri == 3) { if (frames) break; o++; continue; }      // Layer III only
+    const int sr = sr1[sri] >> (ver == 3 ? 0 : (ver == 2 ? 1 : 2)), br = (ver == 3 ? br1[bri] : br2[bri]) * 1000, spf = ver == 3 ? 1152 : 576;
+    const size_t flen = (size_t)(spf / 8 * br / sr + padb);
+    if (flen < 4) break;
+    total += (double)spf / sr; frames++; o += flen;
+  }
+  if (!frames) { err = path + ": neither WAV nor MPEG Layer III audio"; return false; }
+  seconds = total; return true;
+}
+
 // ------------------------------------------------------------------ manifests
-Json manifest_player(const Config &c, long geo_frames, long tex_segments, uint32_t tw, uint32_t th, int pad) {
+Json manifest_player(const Config &c, long geo_frames, long tex_segments, uint32_t tw, uint32_t th, int pad, long etc2_frames) {
   const std::string hashes = "[" + std::string((size_t)pad, '#') + "]";
   Json m = Json::object();
   m.set("version", Json::string("v2"));
@@ -333,7 +377,15 @@ Json manifest_player(const Config &c, long geo_frames, long tex_segments, uint32
   res.arr.push_back(Json::number(tw, true)); res.arr.push_back(Json::number(th, true));
   td.set("format", Json::string("ktx2")); td.set("resolution", res); td.set("type", Json::string("baseColor")); td.set("tag", Json::string("default"));
   td.set("sequenceSize", Json::number(c.ktx2_batch_size, true)); td.set("sequenceCount", Json::number((double)tex_segments, true)); td.set("frameRate", Json::number(c.texture_frame_rate));
-  tt.set("ktx2", td); t.set("targets", tt); t.set("path", Json::string("texture_[target]_[type]_[tag]/" + hashes + "[ext]")); m.set("texture", t);
+  tt.set("ktx2", td);
+  if (etc2_frames > 0) {                    // raw ETC2 RGB (ETC1 subset) blocks, one frame per file: sequenceSize 1 (the player indexes segments, src/V2/player.ts:418-446)
+    Json te = Json::object(), res2 = Json::array();
+    res2.arr.push_back(Json::number(tw, true)); res2.arr.push_back(Json::number(th, true));
+    te.set("format", Json::string("etc2")); te.set("resolution", res2); te.set("type", Json::string("baseColor")); te.set("tag", Json::string("default"));
+    te.set("sequenceSize", Json::number(1, true)); te.set("sequenceCount", Json::number((double)etc2_frames, true)); te.set("frameRate", Json::number(c.texture_frame_rate));
+    tt.set("etc2", te);
+  }
+  t.set("targets", tt); t.set("path", Json::string("texture_[target]_[type]_[tag]/" + hashes + "[ext]")); m.set("texture", t);
   return m;
 }
 Json manifest_encoder_py(const Config &c, long geo_frames, long tex_segments, const std::string &drc_rel, const std::string &ktx2_rel) {   // scripts/Encoder.py:311-328
@@ -373,6 +425,17 @@ const char *uvolh_manifest(const char *config_json, long geo_frames, long segmen
   g_ret = uvolh::json_dump(encoder_py_shape ? uvolh::manifest_encoder_py(c, geo_frames, segments, drc_rel, ktx2_rel) : uvolh::manifest_player(c, geo_frames, segments, w, h, pad));
   return g_ret.c_str();
 }
+const char *uvolh_manifest_targets(const char *config_json, long geo_frames, long segments, unsigned w, unsigned h, int pad, long etc2_frames) {
+  uvolh::Config c; std::string err;
+  if (!uvolh::load_config(config_json, c, err)) { g_ret = "error: " + err; return g_ret.c_str(); }
+  g_ret = uvolh::json_dump(uvolh::manifest_player(c, geo_frames, segments, w, h, pad, etc2_frames));
+  return g_ret.c_str();
+}
+int uvolh_shard_plan(long n_frames, int batch, int world, int rank, long *out4) {
+  const uvolh::ShardPlan P = uvolh::shard_plan(n_frames, batch, world, rank);
+  out4[0] = P.first_frame; out4[1] = P.n_frames; out4[2] = P.first_segment; out4[3] = P.n_segments; return 0;
+}
+double uvolh_audio_duration(const char *path) { double s = 0; std::string err; return uvolh::audio_duration(path, s, err) ? s : -1.0; }
 const char *uvolh_template(void) { g_ret = uvolh::config_template(); return g_ret.c_str(); }
 int uvolh_read_obj_counts(const char *path, unsigned *out6) {
   uvolh::ObjMesh m; std::string err; if (!uvolh::read_obj(path, m, err)) return -1;

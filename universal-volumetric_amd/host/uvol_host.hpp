@@ -60,9 +60,21 @@ bool make_dirs(const std::string &dir);
 struct FrameCounts { long geometry_frames = 0, texture_frames = 0, texture_segments = 0; double geometry_duration = 0, texture_duration = 0; bool compatible = false; };
 bool check_total_frames(const std::string &drc_path_pattern, const std::string &ktx2_path_pattern, int batch, double geo_rate, double tex_rate, FrameCounts &out, std::string &err);
 
+// ---- sharding (the C++ mirror of shard.py plan()) ----
+// contiguous blocks of WHOLE texture segments per rank; the geometry frames with the same indices go to the same rank
+struct ShardPlan { long first_frame = 0, n_frames = 0, first_segment = 0, n_segments = 0; };
+ShardPlan shard_plan(long n_frames, int batch, int world, int rank);
+
+// ---- audio (scripts/Encoder.py:331-347: duration of AudioURL against the geometry / texture durations) ----
+// duration in seconds of a .wav (RIFF/PCM) or .mp3 (MPEG-1/2/2.5 Layer III frame scan, ID3v2 skipped) file; false when the file
+// cannot be read or is neither (remote URLs, other containers): the caller then skips the check like a missing AudioURL
+bool audio_duration(const std::string &path, double &seconds, std::string &err);
+
 // ---- manifests ----
 // The shape src/V2/player.ts reads (src/Interfaces.ts:75-132): targets are objects keyed by target name.
-Json manifest_player(const Config &c, long geometry_frames, long texture_segments, uint32_t tex_w, uint32_t tex_h, int pad_width);
+// extra_etc2_frames > 0 adds the raw `etc2` texture target next to `ktx2` (src/Interfaces.ts:19, :60-73; src/V2/player.ts:208-222 picks
+// the supported target of highest TEXTURE_FORMAT_PRIORITY, :338-356 loads one raw ETC2 RGB image per .etc2 file): one file per frame
+Json manifest_player(const Config &c, long geometry_frames, long texture_segments, uint32_t tex_w, uint32_t tex_h, int pad_width, long extra_etc2_frames = 0);
 // The literal dict scripts/Encoder.py:311-328 writes (kept behind --encoder-py-manifest).
 Json manifest_encoder_py(const Config &c, long geometry_frames, long texture_segments, const std::string &drc_rel, const std::string &ktx2_rel);
 

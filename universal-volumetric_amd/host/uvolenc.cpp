@@ -2,10 +2,20 @@
 // (scripts/Encoder.py:157-373), calling the HIP codec in-process through the C ABI instead of spawning
 // draco_encoder / basisu once per frame / per batch.  Output layout and manifest follow what the stock
 // player reads (src/Interfaces.ts:75-132, src/V2/player.ts:141-174).
+//
+//   uvolenc project-config.json [--gpus N] [--device D] [--batch-frames F] [--ingest-threads T] [--targets ktx2[,etc2]] [--uastc]
+//                               [--force] [--encoder-py-manifest]
+//   --targets   texture targets to write (src/Interfaces.ts:19 TextureFileFormat): `ktx2` always; `etc2` adds one raw ETC2 RGB
+//               (ETC1-subset) block image per frame, transcoded on the GPU from the ETC1S segments, and a second target in the manifest
+//   --uastc     the KTX2 files carry UASTC LDR 4x4 blocks (`basisu -uastc`) instead of ETC1S/BasisLZ
+//   --gpus N    rank r of N encodes the segment-aligned block shard_plan() gives it: whole texture segments and the
+//               geometry frames with the same indices; one host thread per GPU and stage, no data crosses between GPUs
 #include "uvol_host.hpp"
 #include "../../include/uvol_codec.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,18 +49,32 @@ int main(int argc, char **argv) {
     if (!write_file("project-config-template.json", t.data(), t.size())) return 1;
     std::printf("✅ Written template object to project-config-template.json\n"); return 0;
   }
-  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false;
+  const auto t_start = std::chrono::steady_clock::now();
+  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device0 = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--batch-frames") && i + 1 < argc) frames_per_batch = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) ingest_threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--force")) force = true;
+    else if (!std::strcmp(argv[i], "--uastc")) uastc = true;
     else if (!std::strcmp(argv[i], "--encoder-py-manifest")) encpy = true;
+    else if (!std::strcmp(argv[i], "--targets") && i + 1 < argc) {
+      const std::string t = argv[++i]; size_t a = 0;
+      while (a <= t.size()) {
+        size_t b = t.find(',', a); if (b == std::string::npos) b = t.size();
+        const std::string k = t.substr(a, b - a);
+        if (k == "etc2") want_etc2 = true; else if (k != "ktx2" && !k.empty()) { std::printf("❌ unknown texture target '%s' (ktx2, etc2)\n", k.c_str()); return 1; }
+        a = b + 1;
+      }
+    }
   }
+  if (want_etc2 && uastc) { std::printf("❌ the etc2 target is transcoded from ETC1S segments; it cannot be combined with --uastc\n"); return 1; }
   std::vector<uint8_t> raw; if (!read_file(argv[1], raw)) { std::printf("❌ cannot read %s\n", argv[1]); return 1; }
   Config cfg; std::string err;
   if (!load_config(std::string(raw.begin(), raw.end()), cfg, err)) { std::printf("❌ %s\n", err.c_str()); return 1; }
+  if (cfg.compression_level < 0 || cfg.compression_level > 10) { std::printf("❌ DRACO_COMPRESSION_LEVEL must be in [0, 10]\n"); return 1; }
+  if (cfg.compression_level != 7) std::printf("💡 DRACO_COMPRESSION_LEVEL %d: encoded with the compression-level-7 tool set (same bitstream syntax)\n", cfg.compression_level);
   char cwd[4096]; if (!getcwd(cwd, sizeof cwd)) return 1;
   cfg.output_directory = join(cwd, cfg.output_directory);          // scripts/Encoder.py:201
   if (!make_dirs(cfg.output_directory)) { std::printf("❌ cannot create %s\n", cfg.output_directory.c_str()); return 1; }
@@ -59,7 +83,7 @@ int main(int argc, char **argv) {
 
   uvol_params prm; uvol_params_default(&prm);
   prm.q_position_attr = cfg.q_position; prm.q_texture_attr = cfg.q_texture; prm.q_normal_attr = cfg.q_normal; prm.q_generic_attr = cfg.q_generic;
-  prm.draco_compression_level = cfg.compression_level; prm.ktx2_batch_size = cfg.ktx2_batch_size; prm.max_batch = frames_per_batch;
+  prm.draco_compression_level = cfg.compression_level; prm.ktx2_batch_size = cfg.ktx2_batch_size; prm.max_batch = frames_per_batch; prm.uastc = uastc ? 1 : 0;
   // one geometry and one texture context (= HIP stream) per GPU: the two stages of a GPU run side by side
   std::vector<uvol_ctx *> ctxs((size_t)n_gpus, nullptr), tctxs((size_t)n_gpus, nullptr);
   for (int g = 0; g < n_gpus; g++) if (uvol_ctx_create(device0 + g, &prm, &ctxs[g]) != UVOL_OK || uvol_ctx_create(device0 + g, &prm, &tctxs[g]) != UVOL_OK) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
@@ -68,51 +92,55 @@ int main(int argc, char **argv) {
   std::printf("🎯 Dealing with Geomety data\n");
   if (!cfg.abc_file_path.empty()) { std::printf("❌ ABCFilePath needs Blender (bpy); export OBJ files and use OBJFilesPath\n"); return 1; }
   const std::string geo_dir = join(cfg.output_directory, "geometry_draco");
-  const std::string tex_dir = join(cfg.output_directory, "texture_ktx2_baseColor_default");
+  const std::string tex_dir = join(cfg.output_directory, "texture_ktx2_baseColor_default"), etc_dir = join(cfg.output_directory, "texture_etc2_baseColor_default");
   // every early exit happens before the first worker thread exists (a joinable std::thread destroyed on `return` terminates)
   if (!cfg.obj_files_path.empty() && !make_dirs(geo_dir)) { std::printf("❌ cannot create %s\n", geo_dir.c_str()); return 1; }
-  if (!cfg.images_path.empty() && !make_dirs(tex_dir)) { std::printf("❌ cannot create %s\n", tex_dir.c_str()); return 1; }
+  if (!cfg.images_path.empty() && (!make_dirs(tex_dir) || (want_etc2 && !make_dirs(etc_dir)))) { std::printf("❌ cannot create %s\n", tex_dir.c_str()); return 1; }
+  if (want_etc2 && cfg.images_path.empty()) { std::printf("❌ --targets etc2 needs ImagesPath (the raw target is transcoded while the segments are encoded)\n"); return 1; }
   int pad = 5;
   std::atomic<int> geo_failed{-1};
   std::vector<std::thread> geo_threads;
   std::vector<std::string> obj_files; std::string obj_dir;
+  const int B = cfg.ktx2_batch_size;
   if (!cfg.obj_files_path.empty()) {
     std::printf("🚧 Obtained OBJ files path\n");
     obj_dir = dirname_of(cfg.obj_files_path); const std::string pat = basename_of(cfg.obj_files_path);
     { int h = (int)std::count(pat.begin(), pat.end(), '#'); if (h > 0) pad = h; }
     for (auto &f : list_dir(obj_dir)) if (match_pattern_lenient(pat, f)) obj_files.push_back(f);
-    // contiguous blocks of frames per GPU; each GPU encodes batches of frames_per_batch frames.  The OBJ text
+    // Segment-aligned blocks of frames per GPU (shard_plan): rank g gets the frames of ITS texture segments, so a
+    // GPU's geometry and texture outputs cover the same time span; each GPU encodes batches of frames_per_batch frames.  The OBJ text
     // of batch b+1 is parsed by the ingest threads while the GPU encodes batch b, .drc files are written in parallel.
     struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; };
     for (int g = 0; g < n_gpus; g++) geo_threads.emplace_back([&, g] {
       const std::vector<std::string> &files = obj_files;
-      const size_t lo = files.size() * (size_t)g / n_gpus, hi = files.size() * (size_t)(g + 1) / n_gpus;
+      const ShardPlan sp = shard_plan((long)files.size(), B, n_gpus, g);
+      const size_t lo = (size_t)sp.first_frame, hi = lo + (size_t)sp.n_frames;
       auto load = [&](size_t b0) {
-        auto B = std::make_shared<GeoBatch>(); B->b0 = b0; B->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; B->ms.resize(B->nb);
+        auto Bt = std::make_shared<GeoBatch>(); Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; Bt->ms.resize(Bt->nb);
         std::mutex mu;
-        parallel_for(B->nb, ingest_threads, [&](size_t k) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), B->ms[k], e)) { std::lock_guard<std::mutex> l(mu); if (B->bad < 0 || (int)k < B->bad) { B->bad = (int)k; B->err = e; } } });
-        return B;
+        parallel_for(Bt->nb, ingest_threads, [&](size_t k) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), Bt->ms[k], e)) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = e; } } });
+        return Bt;
       };
       std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo);
       for (size_t b0 = lo; b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
-        std::shared_ptr<GeoBatch> B = nextb.get();
+        std::shared_ptr<GeoBatch> Bt = nextb.get();
         nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch);
-        const size_t nb = B->nb;
-        if (B->bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)B->bad].c_str(), B->err.c_str()); geo_failed = (int)(b0 + (size_t)B->bad); break; }
-        std::vector<uvol_mesh> um(nb); std::vector<std::vector<uint8_t>> outs(nb);
+        const size_t nb = Bt->nb;
+        if (Bt->bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)Bt->bad].c_str(), Bt->err.c_str()); geo_failed = (int)(b0 + (size_t)Bt->bad); break; }
+        std::vector<uvol_mesh> um(nb); std::vector<std::unique_ptr<uint8_t[]>> outs(nb);
         std::vector<uint8_t *> op(nb); std::vector<size_t> caps(nb), lens(nb); std::vector<int> st(nb);
         for (size_t k = 0; k < nb; k++) {
-          const ObjMesh &o = B->ms[k]; uvol_mesh &m = um[k]; std::memset(&m, 0, sizeof m);
+          const ObjMesh &o = Bt->ms[k]; uvol_mesh &m = um[k]; std::memset(&m, 0, sizeof m);
           m.pos = o.pos.data(); m.n_pos = (uint32_t)o.pos.size() / 3; m.idx_pos = o.idx_pos.data(); m.n_faces = (uint32_t)o.idx_pos.size() / 3;
           if (!o.uv.empty()) { m.uv = o.uv.data(); m.n_uv = (uint32_t)o.uv.size() / 2; m.idx_uv = o.idx_uv.data(); }
           if (!o.nrm.empty()) { m.nrm = o.nrm.data(); m.n_nrm = (uint32_t)o.nrm.size() / 3; m.idx_nrm = o.idx_nrm.data(); }
-          caps[k] = uvol_mesh_bound(&m); outs[k].resize(caps[k]); op[k] = outs[k].data();
+          caps[k] = uvol_mesh_bound(&m); outs[k].reset(new uint8_t[caps[k]]); op[k] = outs[k].get();          // (not zero-filled: the bound is a worst case)
         }
         if (uvol_encode_mesh_batch(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data()) != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); geo_failed = (int)b0; break; }
         for (size_t k = 0; k < nb; k++) if (st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); geo_failed = (int)(b0 + k); break; }   // scripts/Encoder.py:263-266
         if (geo_failed >= 0) break;
         std::atomic<int> wbad{-1};
-        parallel_for(nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, b0 + k); if (!write_file(join(geo_dir, name), outs[k].data(), lens[k])) wbad = (int)(b0 + k); });
+        parallel_for(nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, b0 + k); if (!write_file(join(geo_dir, name), outs[k].get(), lens[k])) wbad = (int)(b0 + k); });
         if (wbad >= 0) { geo_failed = wbad.load(); break; }
       }
       if (nextb.valid()) nextb.wait();
@@ -122,6 +150,7 @@ int main(int argc, char **argv) {
   std::printf("🎯 Dealing with Texture data\n");
   uint32_t tex_w = 0, tex_h = 0;
   std::atomic<int> tex_failed{-1};
+  std::atomic<long> etc2_frames{0};
   std::vector<std::thread> tex_threads;
   std::vector<int> starts; std::string cpat;
   if (!cfg.images_path.empty()) {
@@ -134,8 +163,7 @@ int main(int argc, char **argv) {
     const int segs_per_call = std::max(1, frames_per_batch / std::max(1, cfg.ktx2_batch_size));
     struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::string err; int bad = -1; };
     for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
-      const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;
-      const int B = cfg.ktx2_batch_size;
+      const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;       // = shard_plan's segment block
       auto load = [&](size_t s0) {
         auto T = std::make_shared<TexBatch>(); T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->imgs.resize(T->ns);
         for (auto &v : T->imgs) v.resize((size_t)B);
@@ -160,24 +188,38 @@ int main(int argc, char **argv) {
         for (auto &seg : T->imgs) for (auto &im : seg) if (im.w != w || im.h != h) same = false;
         if (!same) { fail(starts[s0], "image sizes differ"); break; }
         tex_w = w; tex_h = h;
-        std::vector<std::vector<uint8_t>> outs(T->ns); std::vector<size_t> lens(T->ns, 0);
+        std::vector<std::unique_ptr<uint8_t[]>> outs(T->ns); std::vector<size_t> lens(T->ns, 0);
         // full segments: one batched call; segments with fewer layers: one call each
         std::vector<size_t> full; for (size_t s = 0; s < T->ns; s++) if ((int)T->imgs[s].size() == B) full.push_back(s);
         if (!full.empty()) {
           std::vector<const uint8_t *> ptrs; std::vector<uint8_t *> op; std::vector<size_t> caps, ln(full.size(), 0);
-          for (size_t s : full) { for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data()); outs[s].resize(uvol_texture_bound(w, h, B)); op.push_back(outs[s].data()); caps.push_back(outs[s].size()); }
+          for (size_t s : full) { for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data()); const size_t cap = uvol_texture_bound(w, h, B); outs[s].reset(new uint8_t[cap]); op.push_back(outs[s].get()); caps.push_back(cap); }
           if (uvol_encode_texture_segments(tctxs[g], ptrs.data(), (int)full.size(), B, w, h, op.data(), caps.data(), ln.data()) != UVOL_OK) { fail(starts[s0 + full[0]], uvol_last_error(tctxs[g])); break; }
           for (size_t q = 0; q < full.size(); q++) lens[full[q]] = ln[q];
         }
         for (size_t s = 0; s < T->ns && tex_failed < 0; s++) if ((int)T->imgs[s].size() != B) {
           std::vector<const uint8_t *> ptrs; for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data());
-          outs[s].resize(uvol_texture_bound(w, h, (int)ptrs.size()));
-          if (uvol_encode_texture_segment(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].data(), outs[s].size(), &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
+          const size_t cap = uvol_texture_bound(w, h, (int)ptrs.size()); outs[s].reset(new uint8_t[cap]);
+          if (uvol_encode_texture_segment(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].get(), cap, &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
         }
         if (tex_failed >= 0) break;
         std::atomic<int> wbad{-1};
-        parallel_for(T->ns, ingest_threads, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].data(), lens[s])) wbad = starts[s0 + s]; });
+        parallel_for(T->ns, ingest_threads, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].get(), lens[s])) wbad = starts[s0 + s]; });
         if (wbad >= 0) { tex_failed = wbad.load(); break; }
+        // raw `etc2` target (src/V2/player.ts:338-356): every layer of the segments just written, transcoded on the GPU to ETC1 blocks
+        // (valid ETC2 RGB), one .etc2 file per FRAME (the player builds one CompressedTexture per file)
+        if (want_etc2) {
+          const size_t nbk = (size_t)((w + 3) / 4) * ((h + 3) / 4) * 8;
+          for (size_t s = 0; s < T->ns && tex_failed < 0; s++) {
+            const size_t nl = T->imgs[s].size();
+            std::vector<std::unique_ptr<uint8_t[]>> blk(nl); std::vector<uint8_t *> bp(nl);
+            for (size_t l = 0; l < nl; l++) { blk[l].reset(new uint8_t[nbk]); bp[l] = blk[l].get(); }
+            const uint8_t *fp = outs[s].get(); const size_t fl = lens[s];
+            if (uvol_transcode_texture_segments_etc1(tctxs[g], &fp, &fl, 1, bp.data(), nbk, 0) != UVOL_OK) { fail(starts[s0 + s], uvol_last_error(tctxs[g])); break; }
+            for (size_t l = 0; l < nl; l++) { char name[64]; std::snprintf(name, sizeof name, "%0*d.etc2", pad, starts[s0 + s] - cfg.ktx2_first_file + (int)l); if (!write_file(join(etc_dir, name), bp[l], nbk)) { tex_failed = starts[s0 + s]; break; } }
+            etc2_frames += (long)nl;
+          }
+        }
       }
       if (nextb.valid()) nextb.wait();
     });
@@ -185,15 +227,15 @@ int main(int argc, char **argv) {
   // both stages were started above and run concurrently (geometry and texture contexts of each GPU); join and report in
   // the order the reference prints (scripts/Encoder.py:244-302)
   for (auto &t : geo_threads) t.join();
-  if (geo_failed >= 0) { for (auto &t : tex_threads) t.join(); return 1; }
-  if (!cfg.obj_files_path.empty()) cfg.draco_files_path = join(geo_dir, std::string((size_t)pad, '#') + ".drc");
-  if (!cfg.draco_files_path.empty()) std::printf("✅ Obtained DRACO files\n");
   for (auto &t : tex_threads) t.join();
-  if (tex_failed >= 0) return 1;
-  if (!cfg.images_path.empty()) cfg.ktx2_files_path = join(tex_dir, std::string((size_t)pad, '#') + ".ktx2");
-  if (!cfg.ktx2_files_path.empty()) std::printf("✅ Obtained KTX2 files\n");
   for (auto *c : ctxs) uvol_ctx_destroy(c);
   for (auto *c : tctxs) uvol_ctx_destroy(c);
+  if (geo_failed >= 0 || tex_failed >= 0) return 1;
+  const double t_encode = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (!cfg.obj_files_path.empty()) cfg.draco_files_path = join(geo_dir, std::string((size_t)pad, '#') + ".drc");
+  if (!cfg.draco_files_path.empty()) std::printf("✅ Obtained DRACO files\n");
+  if (!cfg.images_path.empty()) cfg.ktx2_files_path = join(tex_dir, std::string((size_t)pad, '#') + ".ktx2");
+  if (!cfg.ktx2_files_path.empty()) std::printf("✅ Obtained KTX2 files\n");
 
   FrameCounts fc;
   if (!check_total_frames(cfg.draco_files_path, cfg.ktx2_files_path, cfg.ktx2_batch_size, cfg.geometry_frame_rate, cfg.texture_frame_rate, fc, err)) { std::printf("❌ %s\n", err.c_str()); return 1; }
@@ -202,12 +244,26 @@ int main(int argc, char **argv) {
     std::printf("❌ Number of Geometry frames and Texture frames are not compatible with the given frame rates\n");
     if (!force) { std::printf("(re-run with --force to proceed anyway)\n"); return 1; }        // the reference prompts y/n (:141-146)
   } else std::printf("✅ Frames and frame rates are compatible\n");
+  // audio duration against the two durations (scripts/Encoder.py:331-347); the reference asks y/n on a mismatch, this driver needs --force
+  if (!cfg.audio_url.empty()) {
+    double sec = 0; std::string aerr;
+    if (!audio_duration(join(cwd, cfg.audio_url), sec, aerr)) std::printf("💡 Audio duration not checked (%s)\n", aerr.c_str());
+    else if (fc.geometry_duration == sec && fc.texture_duration == sec) std::printf("✅ Audio duration matches with the frame count and frame rates\n");
+    else {
+      std::printf("❌ Audio duration doesn't match with the frame count and frame rates\nUVOL durations (without audio):  {'geometry': %.17g, 'texture': %.17g}\nAudio duration: %.17g\n", fc.geometry_duration, fc.texture_duration, sec);
+      if (!force) { std::printf("(re-run with --force to proceed anyway)\n"); return 1; }
+    }
+  } else std::printf("💡 Audio file not supplied, Skipping duration check...\n");
   if (!tex_w) { std::vector<uint8_t> k; std::string d = dirname_of(cfg.ktx2_files_path); for (auto &f : list_dir(d)) if (match_pattern_lenient(basename_of(cfg.ktx2_files_path), f)) { if (read_file(join(d, f), k) && k.size() >= 28) { std::memcpy(&tex_w, &k[20], 4); std::memcpy(&tex_h, &k[24], 4); } break; } }
-  const std::string man = json_dump(manifest_player(cfg, fc.geometry_frames, fc.texture_segments, tex_w, tex_h, pad));
+  const std::string man = json_dump(manifest_player(cfg, fc.geometry_frames, fc.texture_segments, tex_w, tex_h, pad, want_etc2 ? etc2_frames.load() : 0));
   const std::string mpath = join(cfg.output_directory, "uvol.json");
   if (!write_file(mpath, man.data(), man.size())) return 1;
   if (encpy) { const std::string m2 = json_dump(manifest_encoder_py(cfg, fc.geometry_frames, fc.texture_segments, "geometry_draco/" + std::string((size_t)pad, '#') + ".drc", "texture_ktx2_baseColor_default/" + std::string((size_t)pad, '#') + ".ktx2"));
     write_file(join(cfg.output_directory, "uvol.encoderpy.json"), m2.data(), m2.size()); }
   std::printf("✅ Written Manifest file: %s.\n", mpath.c_str());
+  if (std::fmod(cfg.geometry_frame_rate, cfg.texture_frame_rate) != 0 && std::fmod(cfg.texture_frame_rate, cfg.geometry_frame_rate) != 0)      // scripts/Encoder.py:368-373
+    std::printf("⚠️ Warning: Frame rates are not factors of one another. Ambiguities may arise when calulating appropriate texture for geometry frames.\n");
+  // machine-readable timing of the encode phase (files read -> all .drc / .ktx2 written), for the end-to-end figure of SURVEY §8d
+  std::printf("[uvolenc] frames %ld, encode phase %.3f s, %.1f frames/s, %d GPU(s), %d ingest threads per stage\n", fc.geometry_frames, t_encode, t_encode > 0 ? (double)fc.geometry_frames / t_encode : 0.0, n_gpus, ingest_threads);
   return 0;
 }

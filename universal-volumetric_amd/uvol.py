@@ -25,7 +25,7 @@ class Params(C.Structure):
     _fields_ = [("Q_POSITION_ATTR", C.c_int32), ("Q_TEXTURE_ATTR", C.c_int32), ("Q_NORMAL_ATTR", C.c_int32),
                 ("Q_GENERIC_ATTR", C.c_int32), ("DRACO_COMPRESSION_LEVEL", C.c_int32), ("KTX2_BATCH_SIZE", C.c_int32),
                 ("etc1s_quality", C.c_int32), ("y_flip", C.c_int32), ("max_batch", C.c_int32), ("cu_mod", C.c_int32), ("cu_residues", C.c_int32),
-                ("traverse_vbits_l2", C.c_int32), ("stream_priority", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("traverse_vbits_l2", C.c_int32), ("stream_priority", C.c_int32), ("uastc", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Mesh(C.Structure):
@@ -38,7 +38,7 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
-           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
 
 
@@ -70,6 +70,7 @@ def load(path=None):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t]
     L.uvol_transcode_texture_segments_etc1.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
     L.uvol_transcode_texture_segments_bc7.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
+    L.uvol_transcode_texture_segments_astc.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -270,6 +271,18 @@ class Codec:
         rc = self.L.uvol_transcode_texture_segments_bc7(self.h, fp, ln, n, ptrs, bx * by * 16, 0)
         if rc != UVOL_OK:
             raise UvolError(f"transcode_texture_segments_bc7 rc={rc}: {self.error()}")
+        return outs
+
+    def transcode_texture_segments_astc(self, files):
+        """files: list of UASTC .ktx2 bytes -> list (per segment) of [layers, by, bx, 16] uint8 arrays of ASTC 4x4 blocks (raster order)."""
+        files = [bytes(f) for f in files]
+        w, h, nl = self.ktx2_info(files[0]); n = len(files); bx, by = (w + 3) // 4, (h + 3) // 4
+        outs = [np.empty((nl, by, bx, 16), dtype=np.uint8) for _ in range(n)]
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files])
+        ptrs = (C.c_void_p * (n * nl))(*[outs[s][l].ctypes.data for s in range(n) for l in range(nl)])
+        rc = self.L.uvol_transcode_texture_segments_astc(self.h, fp, ln, n, ptrs, bx * by * 16, 0)
+        if rc != UVOL_OK:
+            raise UvolError(f"transcode_texture_segments_astc rc={rc}: {self.error()}")
         return outs
 
     def decode_texture_segments_dev(self, files, dev_ptrs, layer_cap):
