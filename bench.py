@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 I8_PEAK_TOPS = 3944.0        # dense i8 MFMA (16x16x64), MI355X_MICROARCH.md
-PMC_FILE = "r01_l_pmc_traffic.json"
+PMC_FILE = "r02_pmc_traffic.json"
 
 
 def main():
@@ -35,17 +35,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=720)
+    ap.add_argument("--frames-per-step", type=int, default=2160, help="frames in flight per step (per GPU); a frame holds ~75 MB of geometry workspace + 27 MB of inputs")
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames whose content is cycled")
     ap.add_argument("--shared-inputs", action="store_true", help="DIAGNOSTIC: all frames read the same --distinct input buffers / one texture segment (as before r01_k)")
-    ap.add_argument("--geo-streams", type=int, default=3, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
+    ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
+    ap.add_argument("--mesh-order", choices=["lattice", "shuffled"], default="lattice", help="DIAGNOSTIC 'shuffled': seeded permutation of faces and values (scan-like storage order, no cache-line locality between consecutive faces)")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traverse-vbits-l2", type=int, default=-1, help="-1 auto (on with >= 3 geometry streams and >= 700 frames), 0 off, 1 on")
+    ap.add_argument("--traverse-vbits-l2", type=int, default=0, help="LDS walkers (small batches): 1 = attribute traversers keep their vertex bitmap in L2")
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
     ap.add_argument("--geo-priority", type=int, default=0, help="DIAGNOSTIC: geometry contexts on high-priority streams too")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
@@ -79,6 +80,8 @@ def main():
 
     # ---- synthetic frames (seeded), uploaded once; inputs are resident in HBM when timing starts ----
     meshes_h = [synth.sphere_mesh(args.segs, args.rings, frame=k, seed=k) for k in range(args.distinct)]
+    if args.mesh_order == "shuffled":
+        meshes_h = [synth.shuffle_mesh(m, seed=100 + k) for k, m in enumerate(meshes_h)]
     tex_h = synth.texture_sequence(B, size=args.tex_size, seed=0)
     V, Fc = len(meshes_h[0]["pos"]), len(meshes_h[0]["idx_pos"]) // 3
     keep = []
@@ -115,7 +118,7 @@ def main():
         tcfg.update(stream_priority=1)
     if args.geo_priority:
         gcfg.update(stream_priority=1)
-    if args.traverse_vbits_l2 == 1 or (args.traverse_vbits_l2 < 0 and GS >= 3 and F >= 700):                # > 700 frames in flight: attribute traversers with their vertex bitmap in L2 (see uvol_codec.h)
+    if args.traverse_vbits_l2 == 1:
         gcfg.update(traverse_vbits_l2=1)
     if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)
         gcfg.update(cu_mod=4, cu_residues=int(args.cu_split) // 16); tcfg.update(cu_mod=4, cu_residues=int(args.cu_split) % 16)
@@ -231,10 +234,11 @@ def main():
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else "") + (" DIAGNOSTIC %s only" % args.only if args.only else ""),
             "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
-                                   "%d frames per step, qp11/qt10/qn8/cl7; %s" % (V, Fc, args.tex_size, args.tex_size, B, F,
+                                   "%d frames per step, qp11/qt10/qn8/cl7; %s%s" % (V, Fc, args.tex_size, args.tex_size, B, F, "DIAGNOSTIC shuffled face / value order; " if args.mesh_order == "shuffled" else "",
                                    "DIAGNOSTIC shared input buffers" if args.shared_inputs else "every frame / segment reads its own input buffers in HBM"),
                        "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
-                       "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len},
+                       "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len, "mesh_order": args.mesh_order,
+                       "geometry_workspace_bytes_per_frame": geos[0].mesh_workspace(**meshes_h[0])},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], units), "avg_launch_ms": avg_ms, "units_per_launch": units,
                          "algorithmic_bytes_per_frame": algo_per_frame,
@@ -308,9 +312,32 @@ def cpu_baseline(mesh, tex, B):
     O.ktx2_encode(tex)
     t_tex = time.perf_counter() - t
     fps = B / (B * t_geo + t_tex)
-    return {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "2 geometry frames (%.3f s each) + 1 texture segment of %d layers (%.2f s), serial like scripts/Encoder.py" % (t_geo, B, t_tex),
-            "host_cores_available": os.cpu_count()}
+    res = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "2 geometry frames (%.3f s each) + 1 texture segment of %d layers (%.2f s), serial like scripts/Encoder.py" % (t_geo, B, t_tex),
+           "host_cores_available": os.cpu_count()}
+    # the same port on several host cores at once (basisu itself is multithreaded): P processes, each one texture
+    # segment + its B geometry frames; bounded to one round (~ the serial sample's duration)
+    try:
+        import multiprocessing as mp
+        P = max(1, min(16, (os.cpu_count() or 1) // 2))
+        ctx = mp.get_context("fork")
+        t = time.perf_counter()
+        with ctx.Pool(P) as pool:
+            pool.map(_cpu_segment, [(mesh, tex, B)] * P)
+        dt = time.perf_counter() - t
+        res["parallel"] = {"value": P * B / dt, "unit": "frames/s", "cores": P, "sample": "%d processes x (1 texture segment + %d geometry frames) in %.2f s" % (P, B, dt)}
+    except Exception as e:                                   # the single-core figure above stands on its own
+        res["parallel"] = {"error": repr(e)}
+    return res
+
+
+def _cpu_segment(a):
+    mesh, tex, B = a
+    import oracle as O
+    for _ in range(B):
+        O.drc_encode(mesh["pos"], mesh["idx_pos"], mesh["uv"], mesh["idx_uv"], mesh["nrm"], mesh["idx_nrm"])
+    O.ktx2_encode(tex)
+    return 0
 
 
 if __name__ == "__main__":

@@ -85,7 +85,7 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *
 void hipemu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 void hipemu_syncthreads();
 // wave collectives: exchange one 64-bit value per lane
-unsigned long long hipemu_wave_exchange(unsigned long long v, int src_lane, bool *valid);
+unsigned long long hipemu_wave_exchange(unsigned long long v, int src_lane, bool *valid, int width = 64);
 unsigned long long hipemu_wave_ballot(int pred);
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
@@ -99,7 +99,7 @@ inline int hipemu_lane() { return (int)((threadIdx.x + blockDim.x * (threadIdx.y
 template <class T> inline T __shfl(T v, int src, int width = 64) {
   unsigned long long u = 0; memcpy(&u, &v, sizeof(T));
   int lane = hipemu_lane(); int base = lane & ~(width - 1);
-  bool ok; unsigned long long r = hipemu_wave_exchange(u, base + (src & (width - 1)), &ok);
+  bool ok; unsigned long long r = hipemu_wave_exchange(u, base + (src & (width - 1)), &ok, width);
   T o; memcpy(&o, &r, sizeof(T)); return ok ? o : v;
 }
 template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
@@ -116,7 +116,7 @@ template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
 }
 template <class T> inline T __shfl_xor(T v, int m, int width = 64) {
   unsigned long long u = 0; memcpy(&u, &v, sizeof(T));
-  int lane = hipemu_lane(); bool ok; unsigned long long r = hipemu_wave_exchange(u, lane ^ m, &ok);
+  int lane = hipemu_lane(); bool ok; unsigned long long r = hipemu_wave_exchange(u, lane ^ m, &ok, width);
   T o; memcpy(&o, &r, sizeof(T)); return ok ? o : v;
 }
 inline unsigned long long __ballot(int p) { return hipemu_wave_ballot(p); }

@@ -29,6 +29,7 @@ struct BlockExec {
   // block barrier + per-wave barriers (counter/generation: independent of fiber scheduling order)
   int arrived = 0; unsigned generation = 0;
   int warr[MAXT / 64] = {0}; unsigned wgen[MAXT / 64] = {0};
+  int garr[MAXT / 16] = {0}; unsigned ggen[MAXT / 16] = {0};      // 16-lane sub-group rendezvous (shuffles with width 16 under group-divergent control flow)
   // wave exchange
   unsigned long long slots[MAXT]; int preds[MAXT];
   const std::function<void()> *body = nullptr;
@@ -60,6 +61,7 @@ void run_block(BlockExec *E) {
   if (n == 1) { threadIdx = {0, 0, 0}; (*E->body)(); return; }
   E->arrived = 0;
   for (int w = 0; w < MAXT / 64; w++) E->warr[w] = 0;
+  for (int w = 0; w < MAXT / 16; w++) E->garr[w] = 0;
   for (int t = 0; t < n; t++) {
     Fiber &F = E->fib[t];
     if (!F.stack) F.stack = (char *)malloc(STACK);
@@ -136,11 +138,26 @@ static inline void wave_barrier(BlockExec *E, int w, int wn) {
   while (E->wgen[w] == g) yield_to_sched();
 }
 
-unsigned long long hipemu_wave_exchange(unsigned long long v, int src_lane, bool *valid) {
+static inline void group_barrier(BlockExec *E, int g, int gn) {
+  unsigned gen = E->ggen[g];
+  if (++E->garr[g] == gn) { E->garr[g] = 0; E->ggen[g]++; return; }
+  while (E->ggen[g] == gen) yield_to_sched();
+}
+// width 64: the whole wave meets; width 16: only the 16-lane group of the caller does (the groups of a wave may be in different
+// branches, as on the GPU, where a width-16 shuffle only needs its own 16 source lanes to be active)
+unsigned long long hipemu_wave_exchange(unsigned long long v, int src_lane, bool *valid, int width) {
   BlockExec *E = tl_exec;
   if (!E || E->nthreads == 1) { *valid = src_lane == 0; return v; }
   const int tid = flat_tid(), n = E->nthreads, w = tid / 64, wn = std::min(64, n - w * 64);
   E->slots[tid] = v;
+  if (width == 16) {
+    const int g = tid / 16, gn = std::min(16, n - g * 16);
+    group_barrier(E, g, gn);
+    const bool ok = src_lane >= 0 && src_lane < wn;
+    const unsigned long long r = ok ? E->slots[w * 64 + src_lane] : v;
+    group_barrier(E, g, gn);
+    *valid = ok; return r;
+  }
   wave_barrier(E, w, wn);
   const bool ok = src_lane >= 0 && src_lane < wn;
   const unsigned long long r = ok ? E->slots[w * 64 + src_lane] : v;

@@ -78,7 +78,10 @@ def test_gpu_batched_segments_equal_single_calls(oracle, gpu_codec):
     """uvol_encode_texture_segments (one launch per stage for the whole batch) == per-segment calls == oracle."""
     import synth
     segs = [synth.texture_sequence(3, size=128, seed=s) for s in (1, 2, 3, 4)]
-    segs.append([np.full((128, 128, 4), v, np.uint8) for v in (10, 10, 200)])
+    flat = [np.full((128, 128, 4), v, np.uint8) for v in (10, 10, 200)]
+    for a in flat:
+        a[..., 3] = 255                             # opaque: the ETC1S path refuses alpha != 255 (test_hipemu_etc1s_refuses_alpha)
+    segs.append(flat)
     res = gpu_codec.encode_texture_segments(segs)
     for seg, r in zip(segs, res):
         assert r == oracle.ktx2_encode(seg)

@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world size 2 over gloo — shard plan, the manifest all_gather, and rank 0's accounting."""
+"""N>1 path on CPU: world sizes 2, 4 and 8 over gloo — shard plan, the manifest all_gather, and rank 0's accounting."""
 import os
 import sys
 import pytest
@@ -21,15 +21,19 @@ def _worker(rank, world, port, n_frames, batch, q):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames,batch", [(1200, 5), (23, 5), (7, 7)])
-def test_two_rank_gather_and_accounting(n_frames, batch):
-    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = 29500 + (n_frames % 200)
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, batch, q)) for r in range(2)]
-    [p.start() for p in ps]; table, tot = q.get(timeout=120); [p.join(60) for p in ps]
+@pytest.mark.parametrize("n_frames,batch,world", [(1200, 5, 2), (23, 5, 2), (7, 7, 2), (1200, 5, 4), (1200, 5, 8), (13, 5, 8)])
+def test_multi_rank_gather_and_accounting(n_frames, batch, world):
+    """BASELINE configs[3] (1200 frames over 8 ranks) and ragged cases: every rank encodes its segment-aligned block (the codec is
+    replaced by its byte count here), ONE all_gather of 4 x int64 per rank, rank 0 derives the manifest counters; ranks without
+    work (13 frames over 8 ranks) contribute zeros."""
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = 29500 + (n_frames % 200) + 7 * world
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n_frames, batch, q)) for r in range(world)]
+    [p.start() for p in ps]; table, tot = q.get(timeout=300); [p.join(120) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     n_seg = (n_frames + batch - 1) // batch
     assert tot[0] == n_frames and tot[1] == n_seg and tot[2] == n_frames          # geometry frames == texture frames
-    assert sum(r[0] for r in table) == n_frames and all(r[0] <= r[1] * batch for r in table)
+    assert len(table) == world and sum(r[0] for r in table) == n_frames and all(r[0] <= r[1] * batch for r in table)
+    assert sum(r[3] for r in table) == 1000 * n_frames
 
 
 def test_plan_is_segment_aligned_and_contiguous():

@@ -87,3 +87,35 @@ def test_encoder_flat_and_single_layer(oracle):
     d = oracle.ktx2_decode(k)
     assert d.n_endpoints == 1 and d.n_selectors == 1
     assert np.abs(d.images[0][..., :3].astype(int) - flat[0][..., :3].astype(int)).max() <= 8
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/lib/ktx-parse.module.js"), reason="/root/reference only exists in the build container")
+def test_container_cross_read_with_the_reference_ktx_parse(oracle, tmp_path):
+    """SURVEY 8(c) 'other in-repo oracles': the reference's own vendored KTX-Parse (src/lib/ktx-parse.module.js, what the stock
+    KTX2Loader uses for the container, KTX2Loader.js:299-301) reads this encoder's ETC1S file and the reference's fixture to the same
+    header / DFD / key-value fields.  A third-party reader, not the builder's decoder; needs node >= 12 (part of this container)."""
+    import shutil, subprocess, synth
+    node = shutil.which("node")
+    assert node, "node (>= 12) is part of this container: the cross-read must run, not be skipped"
+    shutil.copy("/root/reference/src/lib/ktx-parse.module.js", tmp_path / "ktxparse.mjs")
+    mine = oracle.ktx2_encode(synth.texture_sequence(3, size=64, seed=1))
+    (tmp_path / "mine.ktx2").write_bytes(mine)
+    shutil.copy(os.path.join(GOLDEN, "00000.ktx2"), tmp_path / "ref.ktx2")
+    js = ("import { read } from './ktxparse.mjs'; import fs from 'fs';"
+          "const out = {};"
+          "for (const n of ['mine', 'ref']) { const c = read(new Uint8Array(fs.readFileSync(n + '.ktx2'))); const d = c.dataFormatDescriptor[0];"
+          " out[n] = {vk: c.vkFormat, ts: c.typeSize, w: c.pixelWidth, h: c.pixelHeight, d: c.pixelDepth, layers: c.layerCount, faces: c.faceCount, sc: c.supercompressionScheme,"
+          " model: d.colorModel, prim: d.colorPrimaries, transfer: d.transferFunction, flags: d.flags, dim: Array.from(d.texelBlockDimension), samples: d.samples.length,"
+          " bitLength: d.samples[0].bitLength, chan: d.samples[0].channelID === undefined ? d.samples[0].channelType : d.samples[0].channelID,"
+          " kv: Object.keys(c.keyValue).sort(), levels: c.levels.length, ep: c.globalData.endpointCount, sel: c.globalData.selectorCount, images: c.globalData.imageDescs.length}; }"
+          "console.log(JSON.stringify(out))")
+    (tmp_path / "r.mjs").write_text(js)
+    r = subprocess.run([node, "--experimental-modules", "r.mjs"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-800:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    d = oracle.ktx2_decode(mine)
+    same = ("vk", "ts", "d", "faces", "sc", "model", "prim", "transfer", "flags", "dim", "samples", "bitLength", "chan", "levels")
+    assert {k: o["mine"][k] for k in same} == {k: o["ref"][k] for k in same}          # same container family as `basisu -ktx2 -tex_type video`
+    assert (o["mine"]["w"], o["mine"]["h"], o["mine"]["layers"], o["mine"]["ep"], o["mine"]["sel"]) == (64, 64, 3, d.n_endpoints, d.n_selectors)
+    assert (o["ref"]["w"], o["ref"]["layers"], o["ref"]["ep"], o["ref"]["sel"]) == (1024, 5, 1506, 734)
+    assert "KTXanimData" in o["mine"]["kv"] and "KTXwriter" in o["mine"]["kv"] and o["mine"]["kv"] == o["ref"]["kv"]

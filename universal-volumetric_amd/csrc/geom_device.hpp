@@ -58,12 +58,12 @@ struct GeoJob {
   int32_t wrap_lo[2], wrap_hi[2];                                  // [0]=pos, [1]=uv
   uint32_t out_len;
   // ---- workspace ----
-  uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3];
+  uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3]; uint32_t n_dup[3];      // n_dup: phase 0 of the dedup saw two equal values
   uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
   int32_t *opp, *vert;                // vert: vertex id per corner of the old-order table (position id, or n_pos + k for further fans of a non-manifold position)
-  uint32_t extra_v, nseg[2]; uint8_t *vseam[2];   // ids handed out beyond n_pos; attribute segments; per-vertex 'an interior seam of attribute i touches it'
+  uint32_t extra_v, nseg[2]; uint32_t *vseam[2];   // ids handed out beyond n_pos; attribute segments; per-vertex 'an interior seam of attribute i touches it'
   uint8_t *vvis; int32_t *vval, *c2vm, *proc, *initc, *stack;      // vvis: vertex-visited bitmap of the edgebreaker walk when it is not in LDS
   uint8_t *evcnt;                      // topology-split events per symbol (auxiliary stream)
   int32_t *ev_src, *ev_spl; uint8_t *ev_edge;

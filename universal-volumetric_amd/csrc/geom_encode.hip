@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dedup(GeoJob *jobs, int which, i
   const uint32_t *data = (const uint32_t *)(which == 0 ? J.pos : (which == 1 ? J.uv : J.nrm));
   uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (i >= n || data == nullptr) return;
+  // phase 1 without duplicates (the usual case: phase 0 found no two equal values) is the identity: no second round of probes
+  if (phase == 1 && J.n_dup[which] == 0) { J.canon[which][i] = i; return; }
   uint32_t *tab = J.dd_tab[which]; const uint32_t cap = J.dd_cap[which];
   uint32_t w[NW]; uint64_t h = 1469598103934665603ULL;
   for (int k = 0; k < NW; k++) { w[k] = data[(size_t)i * NW + k]; h = g_mix64(h ^ w[k]); }
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dedup(GeoJob *jobs, int which, i
     if (phase == 0 && cur == 0) { uint32_t old = atomicCAS(&tab[s], 0u, i + 1); if (old == 0) return; cur = old; }
     if (cur == 0) break;
     if (words_eq<NW>(w, data + (size_t)(cur - 1) * NW)) {
-      if (phase == 0) atomicMin(&tab[s], i + 1); else J.canon[which][i] = cur - 1;
+      if (phase == 0) { atomicMin(&tab[s], i + 1); J.n_dup[which] = 1; } else J.canon[which][i] = cur - 1;
       return;
     }
     s = (s + 1) & (cap - 1);
@@ -101,6 +103,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dedup(GeoJob *jobs, int which, i
   if (phase == 1) J.status = -20;
 }
 
+// three ints moved as one 12-byte access
+#ifdef HIPEMU
+struct uvol_s3 { int32_t x, y, z; };
+#else
+typedef int32_t uvol_s3 __attribute__((ext_vector_type(3), aligned(4)));
+#endif
 // per input face: canonical ids, keep flag, index validation
 __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
   JOB_OR_RETURN;
@@ -122,12 +130,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs) {
   bool live = J.status == 0 && f < J.nf_in;
   uint32_t v = live ? J.keep[f] : 0, tot;
   uint32_t pos = block_excl_scan(v, &tot) + (blockIdx.x <= uvol_blocks_dev(J.nf_in) ? J.bsum[blockIdx.x] : 0);
-  if (live && v) {
-    for (int k = 0; k < 3; k++) {
-      J.cp[3 * pos + k] = (int32_t)J.canon[0][J.ipos[3 * f + k]];
-      J.cu[3 * pos + k] = J.has_uv ? (int32_t)J.canon[1][J.iuv[3 * f + k]] : 0;
-      J.cn[3 * pos + k] = J.has_nrm ? (int32_t)J.canon[2][J.inrm[3 * f + k]] : 0;
-    }
+  if (live && v) {                                        // one 12-byte store per array and face instead of three dword stores
+    uvol_s3 a, b, c;
+    a.x = (int32_t)J.canon[0][J.ipos[3 * f]]; a.y = (int32_t)J.canon[0][J.ipos[3 * f + 1]]; a.z = (int32_t)J.canon[0][J.ipos[3 * f + 2]];
+    b.x = b.y = b.z = 0; c.x = c.y = c.z = 0;
+    if (J.has_uv) { b.x = (int32_t)J.canon[1][J.iuv[3 * f]]; b.y = (int32_t)J.canon[1][J.iuv[3 * f + 1]]; b.z = (int32_t)J.canon[1][J.iuv[3 * f + 2]]; }
+    if (J.has_nrm) { c.x = (int32_t)J.canon[2][J.inrm[3 * f]]; c.y = (int32_t)J.canon[2][J.inrm[3 * f + 1]]; c.z = (int32_t)J.canon[2][J.inrm[3 * f + 2]]; }
+    *reinterpret_cast<uvol_s3 *>(J.cp + 3 * (size_t)pos) = a; *reinterpret_cast<uvol_s3 *>(J.cu + 3 * (size_t)pos) = b; *reinterpret_cast<uvol_s3 *>(J.cn + 3 * (size_t)pos) = c;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
     uint32_t nf = J.bsum[uvol_blocks_dev(J.nf_in)];
@@ -261,12 +270,14 @@ __device__ __forceinline__ bool dense_table_live(const GeoJob &J, int which) { c
 // the three records of face f (r[k] = opposite corner of corner k, vc[k] = vertex << 1 | open) in either format
 __device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, const int vc[3], const int r[3], int r8) {
   if (r8) {
-    uint2 *dst = reinterpret_cast<uint2 *>(rec) + 4 * (size_t)f;
+    uint4 *dst = reinterpret_cast<uint4 *>(rec) + 2 * (size_t)f;      // the face's 32-byte block as two 16-byte stores
+    uint2 q[3];
     for (int k = 0; k < 3; k++) {
       const uint32_t R = (uint32_t)code_of_corner(r[(k + 1) % 3]) & 0x1fffffu, L = (uint32_t)code_of_corner(r[(k + 2) % 3]) & 0x1fffffu;
-      dst[k] = make_uint2(((uint32_t)vc[k] & 0x1fffffu) | (R << 21), (R >> 11) | (L << 10));
+      q[k] = make_uint2(((uint32_t)vc[k] & 0x1fffffu) | (R << 21), (R >> 11) | (L << 10));
     }
-    dst[3] = make_uint2(0u, 0u);                    // 4th slot of the face's block: "face visited" flag of the lane-per-walker kernels
+    dst[0] = make_uint4(q[0].x, q[0].y, q[1].x, q[1].y);
+    dst[1] = make_uint4(q[2].x, q[2].y, 0u, 0u);    // 4th slot of the face's block: "face visited" flag of the lane-per-walker kernels
   } else {
     int4 *dst = reinterpret_cast<int4 *>(rec) + 4 * (size_t)f;
     for (int k = 0; k < 3; k++) dst[k] = make_int4(vc[k], code_of_corner(r[(k + 1) % 3]), code_of_corner(r[(k + 2) % 3]), code_of_corner(r[k]));
@@ -692,7 +703,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
     if (oc < 0) s = 1;
     else {
       s = (ids[g_nxt(c)] != ids[g_prv(oc)] || ids[g_prv(c)] != ids[g_nxt(oc)]) ? 1 : 0;
-      if (s) { J.interior_seams[i] = 1; J.vseam[i][J.bvert[g_nxt(c)]] = 1; J.vseam[i][J.bvert[g_prv(c)]] = 1; }      // both ends of the edge get split
+      if (s) { J.interior_seams[i] = 1; const uint32_t va = (uint32_t)J.bvert[g_nxt(c)], vb = (uint32_t)J.bvert[g_prv(c)];      // both ends of the edge get split
+        atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31)); }
     }
     J.seam[i][c] = s;
   }
@@ -725,7 +737,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
   const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (c >= J.nc || i >= J.nad || !J.interior_seams[i]) return;
   const int32_t v = J.bvert[c];
-  if (!J.vseam[i][v]) { J.avert[i][c] = v; return; }
+  if (!((J.vseam[i][(uint32_t)v >> 5] >> ((uint32_t)v & 31)) & 1u)) { J.avert[i][c] = v; return; }
   GTab T; T.opp = J.nopp; T.seam = J.seam[i];
   if (gt_swl(T, (int)c) < 0) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
 }
@@ -735,7 +747,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
   const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (c == 0 && i < J.nad && J.interior_seams[i]) { const uint32_t tot = J.nverts_t[0] + J.nseg[i]; J.nverts_t[2 + i] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
   if (c >= J.nc || i >= J.nad || !J.interior_seams[i]) return;
-  if (!J.vseam[i][J.bvert[c]]) return;
+  { const uint32_t v = (uint32_t)J.bvert[c]; if (!((J.vseam[i][v >> 5] >> (v & 31)) & 1u)) return; }
   GTab T; T.opp = J.nopp; T.seam = J.seam[i];
   int l = (int)c; uint32_t guard = 0;
   for (;;) { const int nl = gt_swl(T, l); if (nl < 0) break; l = nl; if (++guard > J.nc) { J.status = -22; return; } }
@@ -1774,7 +1786,7 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   }
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
-  for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint8_t, ecap + 8, PH_PINNED, PH_PINNED);
+  for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint32_t, ecap / 32 + 2, PH_PINNED, PH_PINNED);      // one bit per vertex: the whole map stays in L2
   for (int t = 0; t < 3; t++) CARVE(J.t_vvis[t], uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int s = 0; s < GEO_NSTREAM; s++) {
     const int q = s == 6 ? J.qp : (s == 7 ? J.qt : J.qn);

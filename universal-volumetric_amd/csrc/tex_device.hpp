@@ -92,6 +92,28 @@ __device__ inline uint32_t t_eval_block(const uint32_t px[16], int c5r, int c5g,
   int cr[4], cg[4], cb[4];
   for (int s = 0; s < 4; s++) { const int d = t_inten(t, s); cr[s] = t_clampi(br + d, 0, 255); cg[s] = t_clampi(bg + d, 0, 255); cb[s] = t_clampi(bb + d, 0, 255); }
   uint32_t tot = 0, sel = 0;
+  if (!WANT_ROWS) {
+    // No channel clamps under any of the four modifiers (the usual case away from black / white): the error of selector s is
+    // A + 2 d_s B + 3 d_s^2 with A = sum_c (base_c - p_c)^2, B = sum_c (base_c - p_c) — the same integers as the per-channel
+    // form below, for 17 instead of 36 operations per texel.
+    const int d0 = t_inten(t, 0), d1 = t_inten(t, 1), d2 = t_inten(t, 2), d3 = t_inten(t, 3);
+    const int lo = br < bg ? (br < bb ? br : bb) : (bg < bb ? bg : bb), hi = br > bg ? (br > bb ? br : bb) : (bg > bb ? bg : bb);
+    if (lo + d0 >= 0 && hi + d3 <= 255) {
+      const int k0 = 3 * d0 * d0, k1 = 3 * d1 * d1, k2 = 3 * d2 * d2, k3 = 3 * d3 * d3;
+      for (int i = 0; i < 16; i++) {
+        const int er = br - (int)(px[i] & 255), eg = bg - (int)((px[i] >> 8) & 255), eb = bb - (int)((px[i] >> 16) & 255);
+        const int A = er * er + eg * eg + eb * eb, B2 = 2 * (er + eg + eb);
+        const uint32_t e0 = (uint32_t)(A + d0 * B2 + k0), e1 = (uint32_t)(A + d1 * B2 + k1), e2 = (uint32_t)(A + d2 * B2 + k2), e3 = (uint32_t)(A + d3 * B2 + k3);
+        uint32_t be = e0; int bs = 0;
+        if (e1 < be) { be = e1; bs = 1; }
+        if (e2 < be) { be = e2; bs = 2; }
+        if (e3 < be) { be = e3; bs = 3; }
+        tot += be; sel |= (uint32_t)bs << (2 * i);
+      }
+      if (WANT_SEL) *sel_out = sel;
+      return tot;
+    }
+  }
   for (int i = 0; i < 16; i++) {
     const int r = (int)(px[i] & 255), g = (int)((px[i] >> 8) & 255), b = (int)((px[i] >> 16) & 255);
     uint32_t be = 0xffffffffu; int bs = 0; unsigned long long row = 0;

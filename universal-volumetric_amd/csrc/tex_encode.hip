@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_skip(TexJob *job) {
   const uint32_t X = b % J.bx, Y = b / J.bx;
   uint32_t anchor[16], cur[16], amask = 0xff000000u;
   t_load_block(J, 0, X, Y, anchor, &amask);
-  J.skip[b] = 0;
+  J.skip[b] = 0; J.flag[b] = 1;
   for (uint32_t l = 1; l < J.L; l++) {
     t_load_block(J, l, X, Y, cur, &amask);
     uint32_t d = 0;
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_skip(TexJob *job) {
       d += (uint32_t)(dr * dr + dg * dg + db * db);
     }
     const bool sk = d <= J.T_skip;
-    J.skip[(size_t)l * J.nb + b] = sk ? 1 : 0;
+    J.skip[(size_t)l * J.nb + b] = sk ? 1 : 0; J.flag[(size_t)l * J.nb + b] = sk ? 0 : 1;      // coded blocks -> item list (k_item_compact)
     if (!sk) for (int i = 0; i < 16; i++) anchor[i] = cur[i];
   }
   // basisu writes alpha slices for such images; this path does not: fail loudly rather than drop the channel (every block of
@@ -90,9 +90,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_skip(TexJob *job) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_fit(TexJob *job) {
   TJOB_OR_RETURN;
-  const uint32_t b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (b >= J.NB) return;
-  if (J.skip[b]) { J.cell[b] = 0; return; }
+  // one lane per CODED block (item list built right after the skip decision): with ~56 % of a video segment's blocks skipped,
+  // a grid over all blocks ran this — the most expensive texture kernel — with fewer than half of its lanes active
+  const uint32_t it = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (it >= J.n_items) return;
+  const uint32_t b = J.item[it];
   const uint32_t l = b / J.nb, r = b % J.nb;
   uint32_t px[16]; t_load_block(J, l, r % J.bx, r / J.bx, px);
   int sum[3] = {0, 0, 0};
@@ -406,10 +408,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_unique(TexJob *job, int which) {
 // per coded block: endpoint index, optimal selectors under the codebook endpoint, "coded" flag for the item list
 __global__ void __launch_bounds__(UVOL_BLOCK) k_block_assign(TexJob *job) {
   TJOB_OR_RETURN;
-  const uint32_t b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (b >= J.NB) return;
-  if (J.skip[b]) { J.flag[b] = 0; return; }
-  J.flag[b] = 1;
+  const uint32_t it = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (it >= J.n_items) return;
+  const uint32_t b = J.item[it];
   const uint32_t cl = J.vq[0].leaf[J.cidx[J.cell[b]]], tup = J.ent[cl];
   J.bei[b] = (uint16_t)J.emap[cl];
   const uint32_t l = b / J.nb, r = b % J.nb;
@@ -1166,7 +1167,10 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   const TexJob &J = J0;
   const unsigned bnb = uvol_blocks(J.nb), bNB = uvol_blocks(J.NB), bcell = (1u << 18) / UVOL_BLOCK, bK = uvol_blocks(TEX_MAX_CODEBOOK);
   const uint64_t src_bytes = (uint64_t)lbytes * n_layers * (uint64_t)n_seg;
-  { uvol_ctx::Scope sc(ctx, "tex.k11_skip", src_bytes); TLAUNCH(k_tex_skip, dim3(bnb), dim3(UVOL_BLOCK), 0, dj); }
+  { uvol_ctx::Scope sc(ctx, "tex.k11_skip", src_bytes); TLAUNCH(k_tex_skip, dim3(bnb), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH(k_tscan_a, dim3(bNB), dim3(UVOL_BLOCK), 0, dj, J.NB);                 // coded blocks, ascending: the item list of the fit and of the selector stages
+    TLAUNCH(k_tscan_b, dim3(1), dim3(UVOL_BLOCK), 0, dj, bNB);
+    TLAUNCH(k_item_compact, dim3(bNB), dim3(UVOL_BLOCK), 0, dj); }
   { uvol_ctx::Scope sc(ctx, "tex.k9_endpoint_fit", src_bytes); TLAUNCH(k_tex_fit, dim3(bNB), dim3(UVOL_BLOCK), 0, dj); }
   {
     uvol_ctx::Scope sc(ctx, "tex.k10_endpoint_codebook", 0);
@@ -1186,9 +1190,6 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   {
     uvol_ctx::Scope sc(ctx, "tex.k9b_block_selectors", src_bytes);
     TLAUNCH(k_block_assign, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
-    TLAUNCH(k_tscan_a, dim3(bNB), dim3(UVOL_BLOCK), 0, dj, J.NB);
-    TLAUNCH(k_tscan_b, dim3(1), dim3(UVOL_BLOCK), 0, dj, bNB);
-    TLAUNCH(k_item_compact, dim3(bNB), dim3(UVOL_BLOCK), 0, dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "tex.k10_selector_codebook", src_bytes * 2);

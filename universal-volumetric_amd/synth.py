@@ -200,3 +200,23 @@ def edge_case_meshes():
     g = grid_mesh(7, 5, holes=False)
     c["open_grid"] = g
     return c
+
+
+def shuffle_mesh(m, seed=0):
+    """The same surface with scan-like storage order: a seeded permutation of the faces and of every value array (indices
+    relabelled), as a photogrammetry / marching-cubes export has it — consecutive faces are no longer neighbours, so the serial
+    walkers find none of a face's neighbours on the cache line they just fetched (the UV-sphere lattice stores four consecutive
+    faces per 128 bytes: best case)."""
+    rng = np.random.default_rng(seed)
+    nf = len(m["idx_pos"]) // 3
+    fperm = rng.permutation(nf)
+    out = {}
+    for val, idx, cols in (("pos", "idx_pos", 3), ("uv", "idx_uv", 2), ("nrm", "idx_nrm", 3)):
+        if m.get(val) is None:
+            continue
+        a = np.asarray(m[val]).reshape(-1, cols); n = len(a)
+        vperm = rng.permutation(n)                     # new position k holds old value vperm[k]
+        inv = np.empty(n, np.int64); inv[vperm] = np.arange(n)
+        out[val] = np.ascontiguousarray(a[vperm])
+        out[idx] = np.ascontiguousarray(inv[np.asarray(m[idx]).reshape(nf, 3)[fperm]].astype(np.uint32).reshape(-1))
+    return out
