@@ -407,10 +407,16 @@ static uint32_t fit_plane(const uint8_t px[64], const int *comp, int nc, int ran
     uint8_t ql[4], qh[4], ww[16]; int pal[32][4];
     for (int c = 0; c < nc; c++) { ql[c] = g_q_of[range][lo[c]]; qh[c] = g_q_of[range][hi[c]]; }
     for (int k = 0; k < nlev; k++) { const int uw = astc_unquant_weight_bits(wb, k); for (int c = 0; c < nc; c++) pal[k][c] = astc_interp(g_uq[range][ql[c]], g_uq[range][qh[c]], uw); }
+    /* weight of a texel: the level its projection on the endpoint line rounds to, and that level's two neighbours, compared under
+     * the exact interpolation (lowest level among equals) — 3 instead of up to 32 evaluations per texel */
+    int den = 0, dl[4];
+    for (int c = 0; c < nc; c++) { dl[c] = (int)g_uq[range][qh[c]] - (int)g_uq[range][ql[c]]; den += dl[c] * dl[c]; }
     uint32_t sse = 0;
     for (int i = 0; i < 16; i++) {
+      int num = 0; for (int c = 0; c < nc; c++) num += ((int)px[4 * i + comp[c]] - (int)g_uq[range][ql[c]]) * dl[c];
+      int k0 = 0; if (den > 0) { const int t = num < 0 ? 0 : (num > den ? den : num); k0 = (t * (nlev - 1) + den / 2) / den; }
       uint32_t be = 0xffffffffu; int bk = 0;
-      for (int k = 0; k < nlev; k++) { uint32_t e = 0; for (int c = 0; c < nc; c++) { const int dd = pal[k][c] - (int)px[4 * i + comp[c]]; e += (uint32_t)(dd * dd); } if (e < be) { be = e; bk = k; } }
+      for (int k = k0 - 1; k <= k0 + 1; k++) { if (k < 0 || k >= nlev) continue; uint32_t e = 0; for (int c = 0; c < nc; c++) { const int dd = pal[k][c] - (int)px[4 * i + comp[c]]; e += (uint32_t)(dd * dd); } if (e < be) { be = e; bk = k; } }
       ww[i] = (uint8_t)bk; sse += be;
     }
     if (sse < best_sse) { best_sse = sse; memcpy(qlo, ql, 4); memcpy(qhi, qh, 4); memcpy(w, ww, 16); }
@@ -466,9 +472,18 @@ void uastc_encode_lblock(const uint8_t px[64], uastc_lblock *out) {
     return;
   }
   /* candidates in preference order; the first with the lowest SSE wins */
-  static const int cand_rgb[5][2] = { { 0, -1 }, { 18, -1 }, { 6, 0 }, { 6, 1 }, { 6, 2 } }, cand_a[3][2] = { { 10, -1 }, { 12, -1 }, { 11, 3 } };
-  const int ncand = alpha ? 3 : 5; uint32_t best = 0xffffffffu;
+  uastc_lblock first_rgb; memset(&first_rgb, 0, sizeof first_rgb);
+  /* opaque blocks: mode 0, mode 18, and the dual-plane mode 6 with its second plane on the channel the mode-0 fit serves worst
+   * (largest squared error; the lowest channel among equals); alpha blocks: modes 10, 12 and 11 (second plane = alpha) */
+  int cand_rgb[3][2] = { { 0, -1 }, { 18, -1 }, { 6, 0 } }; static const int cand_a[3][2] = { { 10, -1 }, { 12, -1 }, { 11, 3 } };
+  const int ncand = 3; uint32_t best = 0xffffffffu;
   for (int k = 0; k < ncand; k++) {
+    if (!alpha && k == 2) {
+      uint8_t d0[64]; uastc_lblock_rgba(&first_rgb, d0);
+      uint32_t ce[3] = { 0, 0, 0 };
+      for (int i = 0; i < 16; i++) for (int c = 0; c < 3; c++) { const int dd = (int)d0[4 * i + c] - (int)px[4 * i + c]; ce[c] += (uint32_t)(dd * dd); }
+      cand_rgb[2][1] = ce[1] > ce[0] ? (ce[2] > ce[1] ? 2 : 1) : (ce[2] > ce[0] ? 2 : 0);
+    }
     const int m = alpha ? cand_a[k][0] : cand_rgb[k][0], ccs = alpha ? cand_a[k][1] : cand_rgb[k][1];
     const int nc = UM_COMPS[m], range = UM_RANGE[m], wb = UM_WBITS[m];
     uastc_lblock L; memset(&L, 0, sizeof L); L.mode = m; L.ccs = ccs < 0 ? 0 : ccs;
@@ -487,6 +502,7 @@ void uastc_encode_lblock(const uint8_t px[64], uastc_lblock *out) {
       L.ep[2 * ccs] = q1l[0]; L.ep[2 * ccs + 1] = q1h[0];
       for (int i = 0; i < 16; i++) { L.w[2 * i] = w0[i]; L.w[2 * i + 1] = w1[i]; }
     }
+    if (!alpha && k == 0) first_rgb = L;
     if (sse < best) { best = sse; *out = L; }
   }
   /* anchor rule: the first weight of every plane is stored without its top bit -> mirror the plane when that bit is set

@@ -65,7 +65,20 @@ __device__ __forceinline__ int u_wunq(int wb, int k) {                 // weight
   return r > 32 ? r + 1 : r;
 }
 __device__ __forceinline__ int u_interp(int l, int h, int w) { l = (l << 8) | l; h = (h << 8) | h; return ((l * (64 - w) + h * w + 32) >> 6) >> 8; }
-__device__ __forceinline__ long long u_rdiv(long long n, long long d) { return n >= 0 ? (n + d / 2) / d : -((-n + d / 2) / d); }
+// round-to-nearest division (halves away from zero), 0 < d < 2^33, |n| < 2^41: the quotient through the f64 divider (both operands
+// are exact in a double, so it is off by at most one) + an exact integer correction, instead of the ~300-instruction 64-bit
+// integer division sequence - the least-squares refits divide 6 times per plane fit, uniformly across the 16 lanes of a block
+__device__ __forceinline__ long long u_udiv_exact(long long nn, long long d) {          // floor(nn / d), nn >= 0
+#ifdef HIPEMU
+  return nn / d;
+#else
+  long long q = (long long)((double)nn / (double)d);
+  const long long r = nn - q * d;
+  if (r < 0) q--; else if (r >= d) q++;
+  return q;
+#endif
+}
+__device__ __forceinline__ long long u_rdiv(long long n, long long d) { return n >= 0 ? u_udiv_exact(n + d / 2, d) : -u_udiv_exact(-n + d / 2, d); }
 __device__ __forceinline__ int u_comp(uint32_t px, int c) { return (int)((px >> (8 * c)) & 255u); }
 
 // 128-bit block under construction (LSB first)
@@ -101,143 +114,163 @@ __device__ inline void u_decode_log(const ULog &L, const UTab *T, uint32_t out[1
   }
 }
 // ------------------------------------------------------------------------------------------------
-// encoder: 16 lanes per 4x4 block (lane = texel), 4 blocks per wave.  Per plane: principal axis by an integer power iteration
-// on the 16x-scaled covariance, endpoints = the texels at the ends of the axis, nearest weights by exhaustive search under the exact
-// ASTC interpolation, then ONE exact integer least-squares refit of the endpoints for those weights, kept when it lowers the
-// error (oracle/uastc.c states the same algorithm one block at a time).  The per-texel work is spread over the lanes, sums /
-// arg-min / arg-max are 16-lane butterfly shuffles, every group-uniform quantity is computed redundantly by all 16 lanes.
-// (A first version with one lane per block needed 200 registers + scratch and encoded 715 frames/s of 2048^2.)
+// encoder: one lane per 4x4 block.  Per plane: principal axis by an integer power iteration on the 16x-scaled covariance,
+// endpoints = the texels at the ends of the axis, per texel the weight its projection on the endpoint line rounds to or one of
+// that level's two neighbours (exact ASTC interpolation decides), then ONE exact integer least-squares refit of the endpoints
+// for those weights, kept when it lowers the error (oracle/uastc.c states the same algorithm).  Opaque blocks try mode 0, mode 18
+// and the dual-plane mode 6 with its second plane on the channel mode 0 serves worst; alpha blocks modes 10, 12, 11.
+// (A 16-lanes-per-block variant with DPP reductions was measured at a third of this kernel's rate: most of the work per block
+// - axis, quantisation, refit, bit packing - is uniform across a block's texels and was replicated 16 times.)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int g_sum(int v) { for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16); return v; }
-__device__ __forceinline__ int g_min(int v) { for (int d = 8; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 16); v = o < v ? o : v; } return v; }
-__device__ __forceinline__ int g_max(int v) { for (int d = 8; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 16); v = o > v ? o : v; } return v; }
-__device__ __forceinline__ long long g_min64(long long v) { for (int d = 8; d >= 1; d >>= 1) { const long long o = __shfl_xor(v, d, 16); v = o < v ? o : v; } return v; }
-__device__ __forceinline__ long long g_max64(long long v) { for (int d = 8; d >= 1; d >>= 1) { const long long o = __shfl_xor(v, d, 16); v = o > v ? o : v; } return v; }
+// weights of one plane: 8 bits per texel in two words (texel i: bits 8 (i & 7) of w[i >> 3])
+struct UW16 { unsigned long long w[2]; };
+__device__ __forceinline__ int uw_get(const UW16 &W, int i) { return (int)((W.w[i >> 3] >> (8 * (i & 7))) & 255u); }
 
-// one weight plane; px = this lane's texel, ti = its index 0..15.  Returns the plane's SSE (uniform); ql / qh uniform; w = this texel's weight
-__device__ inline uint32_t u_fit_plane_coop(uint32_t px, int ti, int cmask, int range, int wb, const UTab *T, uint8_t ql_out[4], uint8_t qh_out[4], int &w_out) {
+__device__ inline uint32_t u_fit_plane(const uint32_t px[16], int cmask, int range, int wb, const UTab *T, uint8_t qlo[4], uint8_t qhi[4], UW16 &W) {
   const int slot = u_slot(range), nlev = 1 << wb;
   int comp[4] = { 0, 0, 0, 0 }, nc = 0;
   for (int c = 0; c < 4; c++) if ((cmask >> c) & 1) comp[nc++] = c;
-  int x[4] = { 0, 0, 0, 0 };
-  for (int c = 0; c < nc; c++) x[c] = u_comp(px, comp[c]);
   int lo[4] = { 0, 0, 0, 0 }, hi[4] = { 0, 0, 0, 0 };
-  if (nc == 1) { lo[0] = g_min(x[0]); hi[0] = g_max(x[0]); }
-  else {
-    int S[4] = { 0, 0, 0, 0 }, d[4] = { 0, 0, 0, 0 }, cov[4][4]; long long v[4] = { 0, 0, 0, 0 }, any = 0;
-    for (int c = 0; c < nc; c++) { S[c] = g_sum(x[c]); d[c] = 16 * x[c] - S[c]; v[c] = g_max(x[c]) - g_min(x[c]); any |= v[c]; }
-    for (int a = 0; a < nc; a++) for (int b = a; b < nc; b++) { const int sv = g_sum(d[a] * d[b]); cov[a][b] = sv; cov[b][a] = sv; }
+  if (nc == 1) {
+    int mn = 255, mx = 0;
+    for (int i = 0; i < 16; i++) { const int v = u_comp(px[i], comp[0]); mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    lo[0] = mn; hi[0] = mx;
+  } else {
+    // 32-bit where the ranges allow it: |16 c - S| <= 4080, a covariance entry < 2^29, the axis is renormalised below 2^15, a
+    // projection is below 2^31; same values as the oracle's int64
+    int S[4] = { 0, 0, 0, 0 }, cov[4][4], mn[4] = { 255, 255, 255, 255 }, mx[4] = { 0, 0, 0, 0 }; long long v[4] = { 0, 0, 0, 0 };
+    for (int c = 0; c < nc; c++) for (int i = 0; i < 16; i++) { const int x = u_comp(px[i], comp[c]); S[c] += x; mn[c] = x < mn[c] ? x : mn[c]; mx[c] = x > mx[c] ? x : mx[c]; }
+    for (int a = 0; a < nc; a++) for (int b = a; b < nc; b++) { int sv = 0; for (int i = 0; i < 16; i++) sv += (16 * u_comp(px[i], comp[a]) - S[a]) * (16 * u_comp(px[i], comp[b]) - S[b]); cov[a][b] = sv; cov[b][a] = sv; }
+    long long any = 0; for (int c = 0; c < nc; c++) { v[c] = mx[c] - mn[c]; any |= v[c]; }
     if (!any) for (int c = 0; c < nc; c++) v[c] = 1;
     for (int it = 0; it < 4; it++) {
       long long nv[4] = { 0, 0, 0, 0 }, m = 0;
-      for (int a = 0; a < nc; a++) { long long sv = 0; for (int b = 0; b < nc; b++) sv += (long long)cov[a][b] * v[b]; nv[a] = sv; const long long as = sv < 0 ? -sv : sv; m = as > m ? as : m; }
+      for (int a = 0; a < nc; a++) { long long sv = 0; for (int b = 0; b < nc; b++) sv += (long long)cov[a][b] * (int)v[b]; nv[a] = sv; const long long as = sv < 0 ? -sv : sv; m = as > m ? as : m; }
       if (m == 0) break;
       const int sh = (64 - __clzll(m)) - 15;
-      for (int a = 0; a < nc; a++) v[a] = sh > 0 ? ((nv[a] + ((nv[a] >> 63) & (((long long)1 << sh) - 1))) >> sh) : nv[a];
+      for (int a = 0; a < nc; a++) v[a] = sh > 0 ? ((nv[a] + ((nv[a] >> 63) & (((long long)1 << sh) - 1))) >> sh) : nv[a];      // truncating division by 2^sh
     }
-    long long p = 0; for (int c = 0; c < nc; c++) p += (long long)d[c] * (int)v[c];
-    // lowest projection -> its lowest texel index; highest projection -> its lowest texel index
-    const int ilo = (int)(g_min64((p << 8) | (long long)ti) & 255), ihi = 15 - (int)(g_max64((p << 8) | (long long)(15 - ti)) & 255);
-    for (int c = 0; c < nc; c++) { lo[c] = __shfl(x[c], ilo, 16); hi[c] = __shfl(x[c], ihi, 16); }
+    int ilo = 0, ihi = 0; long long plo = 0, phi = 0;
+    for (int i = 0; i < 16; i++) {
+      long long p = 0; for (int c = 0; c < nc; c++) p += (long long)(16 * u_comp(px[i], comp[c]) - S[c]) * (int)v[c];
+      if (i == 0 || p < plo) { plo = p; ilo = i; }
+      if (i == 0 || p > phi) { phi = p; ihi = i; }
+    }
+    for (int c = 0; c < nc; c++) { lo[c] = u_comp(px[ilo], comp[c]); hi[c] = u_comp(px[ihi], comp[c]); }
   }
   uint32_t best_sse = 0xffffffffu;
   for (int pass = 0; pass < 2; pass++) {
-    uint8_t ql[4] = { 0, 0, 0, 0 }, qh[4] = { 0, 0, 0, 0 }; int ul[4] = { 0, 0, 0, 0 }, uh[4] = { 0, 0, 0, 0 };
-    for (int c = 0; c < nc; c++) { ql[c] = T->qof[slot][lo[c]]; qh[c] = T->qof[slot][hi[c]]; ul[c] = T->uq[slot][ql[c]]; uh[c] = T->uq[slot][qh[c]]; }
-    uint32_t be = 0xffffffffu; int bk = 0;
-    for (int k = 0; k < nlev; k++) {
-      const int uw = u_wunq(wb, k); uint32_t e = 0;
-      for (int c = 0; c < nc; c++) { const int dd = u_interp(ul[c], uh[c], uw) - x[c]; e += (uint32_t)(dd * dd); }
-      if (e < be) { be = e; bk = k; }
+    uint8_t ql[4] = { 0, 0, 0, 0 }, qh[4] = { 0, 0, 0, 0 }; int ul[4] = { 0, 0, 0, 0 }, uh[4] = { 0, 0, 0, 0 }, dl[4] = { 0, 0, 0, 0 }, den = 0;
+    for (int c = 0; c < nc; c++) { ql[c] = T->qof[slot][lo[c]]; qh[c] = T->qof[slot][hi[c]]; ul[c] = T->uq[slot][ql[c]]; uh[c] = T->uq[slot][qh[c]]; dl[c] = uh[c] - ul[c]; den += dl[c] * dl[c]; }
+    UW16 ww; ww.w[0] = 0; ww.w[1] = 0; uint32_t sse = 0;
+    int Suu = 0, Svv = 0, Suv = 0, Suc[4] = { 0, 0, 0, 0 }, Svc[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < 16; i++) {
+      int num = 0; for (int c = 0; c < nc; c++) num += (u_comp(px[i], comp[c]) - ul[c]) * dl[c];
+      int k0 = 0; if (den > 0) { const int t = num < 0 ? 0 : (num > den ? den : num); k0 = (int)u_udiv_exact((long long)(t * (nlev - 1) + den / 2), (long long)den); }
+      uint32_t be = 0xffffffffu; int bk = 0;
+      for (int k = k0 - 1; k <= k0 + 1; k++) {
+        if (k < 0 || k >= nlev) continue;
+        const int uw = u_wunq(wb, k); uint32_t e = 0;
+        for (int c = 0; c < nc; c++) { const int dd = u_interp(ul[c], uh[c], uw) - u_comp(px[i], comp[c]); e += (uint32_t)(dd * dd); }
+        if (e < be) { be = e; bk = k; }
+      }
+      ww.w[i >> 3] |= (unsigned long long)bk << (8 * (i & 7)); sse += be;
+      const int u = u_wunq(wb, bk), vv = 64 - u;                         // sums of the least-squares refit, gathered on the way
+      Suu += u * u; Svv += vv * vv; Suv += u * vv;
+      for (int c = 0; c < nc; c++) { const int x = u_comp(px[i], comp[c]); Suc[c] += u * x; Svc[c] += vv * x; }
     }
-    const uint32_t sse = (uint32_t)g_sum((int)be);                        // < 2^31: 16 texels x 4 components x 255^2
-    if (sse < best_sse) { best_sse = sse; for (int c = 0; c < 4; c++) { ql_out[c] = ql[c]; qh_out[c] = qh[c]; } w_out = bk; }
+    if (sse < best_sse) { best_sse = sse; for (int c = 0; c < 4; c++) { qlo[c] = ql[c]; qhi[c] = qh[c]; } W = ww; }
     if (pass == 1) break;
-    const int u = u_wunq(wb, bk), vv = 64 - u;
-    const int Suu = g_sum(u * u), Svv = g_sum(vv * vv), Suv = g_sum(u * vv);
     const long long det = (long long)Svv * Suu - (long long)Suv * Suv;
     if (det <= 0) break;
     for (int c = 0; c < nc; c++) {
-      const int Suc = g_sum(u * x[c]), Svc = g_sum(vv * x[c]);
-      const long long a = u_rdiv(64 * ((long long)Suu * Svc - (long long)Suv * Suc), det), b = u_rdiv(64 * ((long long)Svv * Suc - (long long)Suv * Svc), det);
+      const long long a = u_rdiv(64 * ((long long)Suu * Svc[c] - (long long)Suv * Suc[c]), det), b = u_rdiv(64 * ((long long)Svv * Suc[c] - (long long)Suv * Svc[c]), det);
       lo[c] = (int)(a < 0 ? 0 : (a > 255 ? 255 : a)); hi[c] = (int)(b < 0 ? 0 : (b > 255 ? 255 : b));
     }
   }
   return best_sse;
 }
 
-// px = this lane's texel (R | G << 8 | B << 16 | A << 24), ti = 4 y + x; lane 0 of the group ends up with the block in B
-__device__ inline void u_encode_block_coop(uint32_t px, int ti, const UTab *T, UBits &B) {
+// 16 texels (px[i] = R | G << 8 | B << 16 | A << 24, i = 4 y + x) -> one UASTC block
+__device__ inline void u_encode_block(const uint32_t px[16], const UTab *T, UBits &B) {
   B.lo = 0; B.hi = 0; int o = 0;
-  const uint32_t px0 = (uint32_t)__shfl((int)px, 0, 16);
-  const bool same = g_sum(px != px0 ? 1 : 0) == 0, alpha = g_sum((px >> 24) != 255u ? 1 : 0) != 0;
-  if (same) {                                                           // mode 8; the 32 (table, selector) pairs of the ETC1 hint search, two per lane
-    const int lo_[8] = { 2, 5, 9, 13, 18, 24, 33, 47 }, hi_[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
-    long long bestk = 0x7fffffffffffffffLL; int myb[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
-    for (int j = 0; j < 2; j++) {
-      const int combo = 2 * ti + j, t = combo >> 2, sel = combo & 3;
-      const int mod = sel == 0 ? -hi_[t] : (sel == 1 ? -lo_[t] : (sel == 2 ? lo_[t] : hi_[t]));
-      uint32_t e = 0;
-      for (int c = 0; c < 3; c++) { uint32_t bc = 0xffffffffu; int bb = 0; for (int q = 0; q < 32; q++) { int v = ((q << 3) | (q >> 2)) + mod; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int dd = v - u_comp(px0, c); if ((uint32_t)(dd * dd) < bc) { bc = (uint32_t)(dd * dd); bb = q; } } e += bc; myb[j][c] = bb; }
-      const long long key = ((long long)e << 8) | combo;                  // lowest error, then the first pair in (table, selector) order
-      bestk = key < bestk ? key : bestk;
+  bool same = true, alpha = false;
+  for (int i = 0; i < 16; i++) { same &= px[i] == px[0]; alpha |= (px[i] >> 24) != 255u; }
+  const int lo_[8] = { 2, 5, 9, 13, 18, 24, 33, 47 }, hi_[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
+  if (same) {                                                           // mode 8: the colour + the ETC1 hint (table, selector, 5-bit base) closest to it
+    uint32_t be = 0xffffffffu; int bt = 0, bsel = 0, b5[3] = { 0, 0, 0 };
+    for (int t = 0; t < 8; t++) for (int sl = 0; sl < 4; sl++) {
+      const int mod = sl == 0 ? -hi_[t] : (sl == 1 ? -lo_[t] : (sl == 2 ? lo_[t] : hi_[t]));
+      uint32_t e = 0; int cb[3];
+      for (int c = 0; c < 3; c++) { uint32_t bc = 0xffffffffu; int bb = 0; for (int q = 0; q < 32; q++) { int v = ((q << 3) | (q >> 2)) + mod; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int dd = v - u_comp(px[0], c); if ((uint32_t)(dd * dd) < bc) { bc = (uint32_t)(dd * dd); bb = q; } } e += bc; cb[c] = bb; }
+      if (e < be) { be = e; bt = t; bsel = sl; b5[0] = cb[0]; b5[1] = cb[1]; b5[2] = cb[2]; }
     }
-    const int win = (int)(g_min64(bestk) & 255), wl = win >> 1, wj = win & 1;
-    int b5[3]; for (int c = 0; c < 3; c++) b5[c] = __shfl(wj ? myb[1][c] : myb[0][c], wl, 16);
     B.put(o, 0x17, 5);
-    for (int c = 0; c < 4; c++) B.put(o, (uint32_t)u_comp(px0, c), 8);
-    B.put(o, 1, 1); B.put(o, (uint32_t)(win >> 2), 3); B.put(o, (uint32_t)(win & 3), 2);
+    for (int c = 0; c < 4; c++) B.put(o, (uint32_t)u_comp(px[0], c), 8);
+    B.put(o, 1, 1); B.put(o, (uint32_t)bt, 3); B.put(o, (uint32_t)bsel, 2);
     for (int c = 0; c < 3; c++) B.put(o, (uint32_t)b5[c], 5);
     return;
   }
-  const int cand_rgb[5][2] = { { 0, -1 }, { 18, -1 }, { 6, 0 }, { 6, 1 }, { 6, 2 } }, cand_a[3][2] = { { 10, -1 }, { 12, -1 }, { 11, 3 } };
-  const int ncand = alpha ? 3 : 5; uint32_t best = 0xffffffffu;
-  int Rmode = 0, Rccs = 0, Rw0 = 0, Rw1 = 0; uint8_t Rep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-  for (int k = 0; k < ncand; k++) {
-    const int m = alpha ? cand_a[k][0] : cand_rgb[k][0], ccs = alpha ? cand_a[k][1] : cand_rgb[k][1];
+  const int cand_a[3][2] = { { 10, -1 }, { 12, -1 }, { 11, 3 } };
+  uint32_t best = 0xffffffffu; int ccs6 = 0;
+  int Rmode = 0, Rccs = 0; uint8_t Rep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; UW16 R0, R1; R0.w[0] = R0.w[1] = R1.w[0] = R1.w[1] = 0;
+  for (int k = 0; k < 3; k++) {
+    const int m = alpha ? cand_a[k][0] : (k == 0 ? 0 : (k == 1 ? 18 : 6)), ccs = alpha ? cand_a[k][1] : (k == 2 ? ccs6 : -1);
     const UMode M = u_mode(m); const int all = (1 << M.comps) - 1;
-    uint8_t ep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; int w0 = 0, w1 = 0; uint32_t sse;
+    uint8_t ep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; UW16 w0, w1; w0.w[0] = w0.w[1] = w1.w[0] = w1.w[1] = 0; uint32_t sse;
     if (ccs < 0) {
       uint8_t ql[4], qh[4];
-      sse = u_fit_plane_coop(px, ti, all, M.range, M.wbits, T, ql, qh, w0);
+      sse = u_fit_plane(px, all, M.range, M.wbits, T, ql, qh, w0);
       for (int c = 0; c < M.comps; c++) { ep[2 * c] = ql[c]; ep[2 * c + 1] = qh[c]; }
+      if (!alpha && k == 0) {                                           // per-channel error of the mode-0 fit -> second-plane channel of mode 6
+        const int sl = u_slot(M.range); uint32_t ce[3] = { 0, 0, 0 };
+        for (int i = 0; i < 16; i++) { const int uw = u_wunq(M.wbits, uw_get(w0, i)); for (int c = 0; c < 3; c++) { const int dd = u_interp(T->uq[sl][ql[c]], T->uq[sl][qh[c]], uw) - u_comp(px[i], c); ce[c] += (uint32_t)(dd * dd); } }
+        ccs6 = ce[1] > ce[0] ? (ce[2] > ce[1] ? 2 : 1) : (ce[2] > ce[0] ? 2 : 0);
+      }
     } else {
       uint8_t ql[4], qh[4], q1l[4], q1h[4];
-      sse = u_fit_plane_coop(px, ti, all & ~(1 << ccs), M.range, M.wbits, T, ql, qh, w0);
-      sse += u_fit_plane_coop(px, ti, 1 << ccs, M.range, M.wbits, T, q1l, q1h, w1);
+      sse = u_fit_plane(px, all & ~(1 << ccs), M.range, M.wbits, T, ql, qh, w0);
+      sse += u_fit_plane(px, 1 << ccs, M.range, M.wbits, T, q1l, q1h, w1);
       int j = 0;
       for (int c = 0; c < M.comps; c++) if (c != ccs) { ep[2 * c] = ql[j]; ep[2 * c + 1] = qh[j]; j++; }
       ep[2 * ccs] = q1l[0]; ep[2 * ccs + 1] = q1h[0];
     }
-    if (sse < best) { best = sse; Rmode = m; Rccs = ccs < 0 ? 0 : ccs; Rw0 = w0; Rw1 = w1; for (int i = 0; i < 8; i++) Rep[i] = ep[i]; }
+    if (sse < best) { best = sse; Rmode = m; Rccs = ccs < 0 ? 0 : ccs; R0 = w0; R1 = w1; for (int i = 0; i < 8; i++) Rep[i] = ep[i]; }
   }
   const UMode M = u_mode(Rmode); const int maxw = (1 << M.wbits) - 1;
-  for (int p = 0; p < M.planes; p++) {                                  // anchor rule (texel 0's weight of the plane decides for the whole group)
-    const int a0 = __shfl(p == 0 ? Rw0 : Rw1, 0, 16);
-    if (a0 > maxw / 2) {
+  for (int p = 0; p < M.planes; p++) {                                  // anchor rule: a plane whose first weight has its top bit set is mirrored
+    UW16 &Wp = p == 0 ? R0 : R1;
+    if (uw_get(Wp, 0) > maxw / 2) {
       for (int c = 0; c < M.comps; c++) if (M.planes == 1 || (p == 1) == (c == Rccs)) { const uint8_t t = Rep[2 * c]; Rep[2 * c] = Rep[2 * c + 1]; Rep[2 * c + 1] = t; }
-      if (p == 0) Rw0 = maxw - Rw0; else Rw1 = maxw - Rw1;
+      const unsigned long long mx8 = 0x0101010101010101ull * (unsigned long long)maxw;
+      Wp.w[0] = mx8 - Wp.w[0]; Wp.w[1] = mx8 - Wp.w[1];                  // every byte <= maxw: no borrow between bytes
     }
   }
-  // this lane's decoded texel, then the transcoder hints
-  const int slot = u_slot(M.range); uint32_t dec = 0;
-  { const int uw0 = u_wunq(M.wbits, Rw0), uw1 = M.planes == 2 ? u_wunq(M.wbits, Rw1) : uw0;
-    for (int c = 0; c < 4; c++) dec |= (uint32_t)(c < M.comps ? u_interp(T->uq[slot][Rep[2 * c]], T->uq[slot][Rep[2 * c + 1]], (M.planes == 2 && c == Rccs) ? uw1 : uw0) : 255) << (8 * c); }
-  int inten[2];
-  { const int lo_[8] = { 2, 5, 9, 13, 18, 24, 33, 47 }, hi_[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
-    const bool right = (ti & 3) >= 2; int base[3];
-    for (int c = 0; c < 3; c++) { const int v = u_comp(dec, c), tot = g_sum(v), lft = g_sum(right ? 0 : v); const int sm = right ? tot - lft : lft; const int avg = (sm + 4) / 8; base[c] = ((avg * 15 + 127) / 255) * 17; }
-    long long kl = 0x7fffffffffffffffLL, kr = 0x7fffffffffffffffLL;
+  // decoded texels -> transcoder hints: ETC1 halves are the left / right 2x4 columns (flip 0), individual 4-bit base colours (diff 0),
+  // no bias; BC1 hints 0; ETC2 alpha hint: table 13, multiplier from the alpha span
+  const int slot = u_slot(M.range); uint32_t dec[16];
+  for (int i = 0; i < 16; i++) {
+    const int uw0 = u_wunq(M.wbits, uw_get(R0, i)), uw1 = M.planes == 2 ? u_wunq(M.wbits, uw_get(R1, i)) : uw0; uint32_t v = 0;
+    for (int c = 0; c < 4; c++) v |= (uint32_t)(c < M.comps ? u_interp(T->uq[slot][Rep[2 * c]], T->uq[slot][Rep[2 * c + 1]], (M.planes == 2 && c == Rccs) ? uw1 : uw0) : 255) << (8 * c);
+    dec[i] = v;
+  }
+  int inten[2] = { 0, 0 };
+  for (int h = 0; h < 2; h++) {
+    const int x0 = 2 * h; int base[3];
+    for (int c = 0; c < 3; c++) { int sm = 0; for (int y = 0; y < 4; y++) for (int x = x0; x < x0 + 2; x++) sm += u_comp(dec[4 * y + x], c); const int avg = (sm + 4) / 8; base[c] = ((avg * 15 + 127) / 255) * 17; }
+    uint32_t be = 0xffffffffu;
     for (int t = 0; t < 8; t++) {
-      const int mod[4] = { -hi_[t], -lo_[t], lo_[t], hi_[t] }; uint32_t bs = 0xffffffffu;
-      for (int sl = 0; sl < 4; sl++) { uint32_t es = 0; for (int c = 0; c < 3; c++) { int v = base[c] + mod[sl]; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int dd = v - u_comp(dec, c); es += (uint32_t)(dd * dd); } bs = es < bs ? es : bs; }
-      const int el = g_sum(right ? 0 : (int)bs), et = g_sum((int)bs), er = et - el;
-      const long long a = ((long long)el << 4) | t, b = ((long long)er << 4) | t;        // lowest error, then the lowest table
-      kl = a < kl ? a : kl; kr = b < kr ? b : kr;
+      uint32_t e = 0; const int mod[4] = { -hi_[t], -lo_[t], lo_[t], hi_[t] };
+      for (int y = 0; y < 4; y++) for (int x = x0; x < x0 + 2; x++) {
+        uint32_t bs = 0xffffffffu;
+        for (int sl = 0; sl < 4; sl++) { uint32_t es = 0; for (int c = 0; c < 3; c++) { int v = base[c] + mod[sl]; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int dd = v - u_comp(dec[4 * y + x], c); es += (uint32_t)(dd * dd); } bs = es < bs ? es : bs; }
+        e += bs;
+      }
+      if (e < be) { be = e; inten[h] = t; }
     }
-    inten[0] = (int)(kl & 15); inten[1] = (int)(kr & 15); }
+  }
   int etc2 = 0;
-  if (M.alpha) { const int a = (int)(dec >> 24), mn = g_min(a), mx = g_max(a); int mul = (mx - mn + 19) / 20; mul = mul < 1 ? 1 : (mul > 15 ? 15 : mul); etc2 = (mul << 4) | 13; }
+  if (M.alpha) { int mn = 255, mx = 0; for (int i = 0; i < 16; i++) { const int a = (int)(dec[i] >> 24); mn = a < mn ? a : mn; mx = a > mx ? a : mx; } int mul = (mx - mn + 19) / 20; mul = mul < 1 ? 1 : (mul > 15 ? 15 : mul); etc2 = (mul << 4) | 13; }
   B.put(o, M.huff, M.hufflen);
   B.put(o, 0, 1); if (M.bc1h1) B.put(o, 0, 1);
   B.put(o, 0, 1); B.put(o, 0, 1); B.put(o, (uint32_t)inten[0], 3); B.put(o, (uint32_t)inten[1], 3);
@@ -255,10 +288,9 @@ __device__ inline void u_encode_block_coop(uint32_t px, int ti, const UTab *T, U
     }
   }
   for (int i = 0; i < nv; i++) B.put(o, (uint32_t)Rep[i] & ((1u << bits) - 1u), bits);
-  for (int i = 0; i < 16; i++) {                                        // every lane fetches every texel's weights; lane 0's copy is the one stored
-    const int a = __shfl(Rw0, i, 16), b = __shfl(Rw1, i, 16);
-    B.put(o, (uint32_t)a, i == 0 ? M.wbits - 1 : M.wbits);
-    if (M.planes == 2) B.put(o, (uint32_t)b, i == 0 ? M.wbits - 1 : M.wbits);
+  for (int i = 0; i < 16; i++) {
+    B.put(o, (uint32_t)uw_get(R0, i), i == 0 ? M.wbits - 1 : M.wbits);
+    if (M.planes == 2) B.put(o, (uint32_t)uw_get(R1, i), i == 0 ? M.wbits - 1 : M.wbits);
   }
 }
 
@@ -374,29 +406,29 @@ struct UastcJob {                       // one segment (= one .ktx2): layers of 
   uint32_t W, H, L, bx, by; int32_t yflip, status, any_alpha;
 };
 
-// grid (groups of 16 texel-blocks, layer, segment); 256 threads = 16 blocks x 16 texels
+// grid (blocks of 256 texel-blocks, layer, segment)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_encode(UastcJob *jobs, const UConst *K) {
   UastcJob &J = jobs[blockIdx.z];
   __shared__ UTab T;
   for (uint32_t i = threadIdx.x; i < sizeof(UTab) / 4; i += UVOL_BLOCK) reinterpret_cast<uint32_t *>(&T)[i] = reinterpret_cast<const uint32_t *>(&K->tab)[i];
   __syncthreads();
-  const uint32_t l = blockIdx.y, nb = J.bx * J.by;
-  const int ti = (int)(threadIdx.x & 15);
-  uint32_t b = blockIdx.x * (UVOL_BLOCK / 16) + (threadIdx.x >> 4);
-  const bool live = l < J.L && b < nb;              // whole 16-lane groups are live or not; dead groups run on block 0's texels (all lanes take part in the shuffles)
-  if (!live) b = 0;
+  const uint32_t l = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (l >= J.L || b >= J.bx * J.by) return;
   const uint32_t X = b % J.bx, Y = b / J.bx;
-  const uint8_t *img = J.layer[l < J.L ? l : 0];
-  uint32_t py = Y * 4 + (uint32_t)(ti >> 2); if (py >= J.H) py = J.H - 1;
-  uint32_t pxx = X * 4 + (uint32_t)(ti & 3); if (pxx >= J.W) pxx = J.W - 1;
-  const uint32_t sr = J.yflip ? J.H - 1 - py : py;
-  const uint32_t px = *reinterpret_cast<const uint32_t *>(img + 4 * ((size_t)sr * J.W + pxx));
-  UBits B; u_encode_block_coop(px, ti, &T, B);
-  if (live && (px >> 24) != 255u) J.any_alpha = 1;  // the container's DFD channel id says RGBA when any texel carries alpha
-  if (live && ti == 0) {
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
-    dst[0] = B.lo; dst[1] = B.hi;
+  const uint8_t *img = J.layer[l];
+  uint32_t px[16]; bool alpha = false;
+  for (int y = 0; y < 4; y++) {
+    uint32_t py = Y * 4 + (uint32_t)y; if (py >= J.H) py = J.H - 1;
+    const uint32_t sr = J.yflip ? J.H - 1 - py : py;
+    const uint8_t *row = img + 4 * ((size_t)sr * J.W);
+    if (X * 4 + 3 < J.W && (J.W & 3) == 0) { const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * (size_t)X); px[4 * y] = v.x; px[4 * y + 1] = v.y; px[4 * y + 2] = v.z; px[4 * y + 3] = v.w; }
+    else for (int x = 0; x < 4; x++) { uint32_t pxx = X * 4 + (uint32_t)x; if (pxx >= J.W) pxx = J.W - 1; const uint8_t *p = row + 4 * (size_t)pxx; px[4 * y + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
   }
+  for (int i = 0; i < 16; i++) alpha |= (px[i] >> 24) != 255u;
+  if (alpha) J.any_alpha = 1;                                            // the container's DFD channel id says RGBA when any block carries alpha
+  UBits B; u_encode_block(px, &T, B);
+  unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
+  dst[0] = B.lo; dst[1] = B.hi;
 }
 // target 0: RGBA8 (W x H x 4 per layer, stored row order), 1: ASTC 4x4 blocks
 __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, const UConst *K, int target) {
@@ -525,7 +557,7 @@ int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
   }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
   { uvol_ctx::Scope sc(ctx, "tex.uastc_encode", (uint64_t)(lbytes + nb * 16) * n_layers * (uint64_t)n_seg);
-    hipLaunchKernelGGL(k_uastc_encode, dim3((unsigned)((nb + 15) / 16), (unsigned)n_layers, (unsigned)n_seg), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p); }
+    hipLaunchKernelGGL(k_uastc_encode, dim3(uvol_blocks(nb), (unsigned)n_layers, (unsigned)n_seg), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   if ((rc = uastc_pinned(ctx, seg_bytes * (size_t)n_seg))) return rc;
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
