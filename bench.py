@@ -133,7 +133,7 @@ def main():
 
     def run_geo(gi):
         a, b = gsl[gi]
-        out["drc_%d" % gi] = geos[gi].encode_mesh_batch(host_frames[a:b]) if args.host_inputs else geos[gi].encode_mesh_batch_dev(gbatches[gi])
+        out["drc_%d" % gi] = geos[gi].encode_mesh_batch(host_frames[a:b]) if args.host_inputs else geos[gi].encode_mesh_batch_dev(gbatches[gi], views=True)
 
     def run_tex(ti):
         mine = len(range(ti, nseg, len(texs)))            # segments of this step handled by texture context ti, ONE batched call
@@ -273,7 +273,7 @@ def quality_gates(geo, tex, out, mesh0, tex0, B):
     try:
         import numpy as np
         from scipy.spatial import cKDTree
-        d = geo.decode_mesh_batch([out["drc"][0]])[0]
+        d = geo.decode_mesh_batch([bytes(out["drc"][0])])[0]
         pos = np.asarray(mesh0["pos"], np.float64)
         step = float((pos.max(0) - pos.min(0)).max()) / (2 ** 11 - 1)
         dist, _ = cKDTree(np.asarray(d["pos"], np.float64)).query(pos)

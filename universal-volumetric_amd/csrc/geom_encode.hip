@@ -11,6 +11,7 @@
 // There is no MFMA here by design: the path is integer/byte work bounded by dependent-load latency
 // (walkers) and HBM/L2 bandwidth (parallel stages).
 #include <chrono>
+#include <thread>
 #include "uvol_common.hpp"
 #include "geom_device.hpp"
 #include <algorithm>
@@ -1530,12 +1531,19 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
   uint32_t hi = n;
   while (hi & 3u) { hi--; const uint4 e = tab[syms[hi]]; SR_STEP(e); }          // the tail: the groups below are 16-byte aligned
   if (hi) {
-    uint4 sy = *reinterpret_cast<const uint4 *>(syms + hi - 4);
-    uint4 e0 = tab[sy.w], e1 = tab[sy.z], e2 = tab[sy.y], e3 = tab[sy.x];
+    // two-deep software pipeline over groups of four symbols: while group g is coded, the table entries of group g + 1 are in
+    // flight (their symbols arrived an iteration earlier) and the symbols of group g + 2 are being fetched - a lane never issues
+    // a load whose address it has to wait for
+    uint4 sy1 = *reinterpret_cast<const uint4 *>(syms + hi - 4);                             // symbols of the current group
+    uint4 sy2 = hi >= 8 ? *reinterpret_cast<const uint4 *>(syms + hi - 8) : sy1;             // ... of the next one
+    uint4 e0 = tab[sy1.w], e1 = tab[sy1.z], e2 = tab[sy1.y], e3 = tab[sy1.x];
     while (hi) {
       hi -= 4;
       const uint4 c0 = e0, c1 = e1, c2 = e2, c3 = e3;
-      if (hi) { sy = *reinterpret_cast<const uint4 *>(syms + hi - 4); e0 = tab[sy.w]; e1 = tab[sy.z]; e2 = tab[sy.y]; e3 = tab[sy.x]; }
+      if (hi) {
+        e0 = tab[sy2.w]; e1 = tab[sy2.z]; e2 = tab[sy2.y]; e3 = tab[sy2.x];
+        if (hi >= 8) sy2 = *reinterpret_cast<const uint4 *>(syms + hi - 8);
+      }
       SR_STEP(c0); SR_STEP(c1); SR_STEP(c2); SR_STEP(c3);
     }
   }
@@ -2205,11 +2213,16 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   const double t_d2h = ms_since(t_enter);
   std::vector<int> retry;
+  // staging -> the caller's buffers: a few host threads for large batches (2160 frames x 250 KB took ~60 ms of one core per batch)
+  { const int nt = packed > ((size_t)32 << 20) ? 8 : 1;
+    auto copy_range = [&](int a, int b) { for (int i = a; i < b; i++) { const GeoJob &J = G->hjobs[i]; if (J.status == 0) memcpy(outs[i], G->pinned + J.out_pack_off, J.out_len); } };
+    if (nt == 1) copy_range(0, n);
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(copy_range, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); for (auto &x : th) x.join(); } }
   for (int i = 0; i < n; i++) {
     const GeoJob &J = G->hjobs[i];
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
     out_lens[i] = J.out_len;
-    if (st == UVOL_OK) memcpy(outs[i], G->pinned + J.out_pack_off, J.out_len);
+    if (st == UVOL_OK) { }
     else if (!full && (J.status == GEO_E_WS_OVERFLOW || J.status == GEO_E_SLAB_FULL)) { retry.push_back(i); st = UVOL_OK; }
     else { ctx->set_error("mesh %d: encode failed (device status %d)", i, J.status); worst = st; }
     if (status) status[i] = st;

@@ -5,12 +5,12 @@
 // reference driver spawns (scripts/Encoder.py:290 passes no -uastc; the north star and SURVEY §8 f4 ask for the mode) — and,
 // on the consumer side, the UASTC -> ASTC 4x4 transcode the stock player's KTX2Loader requests first for UASTC sources
 // (src/lib/KTX2Loader.js:591-600, :648-689).  Formats: UASTC LDR 4x4 specification (basis_universal) and the ASTC LDR profile;
-// the single-subset modes 0, 6, 18 (opaque), 10, 11, 12 (alpha) and 8 (solid) are emitted — see oracle/uastc.c for what pins
-// them (parity with basisu itself is unpinned: no binary, no fixture).
+// the single-subset modes 0, 6, 18 (opaque), 10, 11, 12 (alpha) and 8 (solid) are emitted — DESIGN.md §2 says what pins them
+// (parity with basisu itself is unpinned: no binary, no fixture).
 //
 // One thread per 4x4 block, blocks are independent: a streaming kernel (64 B of texels in, 16 B out per block) whose
-// arithmetic is a handful of exact integer least-squares fits per block.  Everything is integer and matches oracle/uastc.c
-// bit for bit.  No MFMA: there is no contraction; the bound is VALU integer throughput and, for the transcodes, HBM.
+// arithmetic is a handful of exact integer least-squares fits per block.  Everything is integer and deterministic (the tests compare
+// every output byte with the CPU restatement of the same algorithm).  No MFMA: there is no contraction; the bound is VALU integer throughput and, for the transcodes, HBM.
 #include "uvol_common.hpp"
 #include <algorithm>
 
@@ -117,7 +117,7 @@ __device__ inline void u_decode_log(const ULog &L, const UTab *T, uint32_t out[1
 // encoder: one lane per 4x4 block.  Per plane: principal axis by an integer power iteration on the 16x-scaled covariance,
 // endpoints = the texels at the ends of the axis, per texel the weight its projection on the endpoint line rounds to or one of
 // that level's two neighbours (exact ASTC interpolation decides), then ONE exact integer least-squares refit of the endpoints
-// for those weights, kept when it lowers the error (oracle/uastc.c states the same algorithm).  Opaque blocks try mode 0, mode 18
+// for those weights, kept when it lowers the error.  Opaque blocks try mode 0, mode 18
 // and the dual-plane mode 6 with its second plane on the channel mode 0 serves worst; alpha blocks modes 10, 12, 11.
 // (A 16-lanes-per-block variant with DPP reductions was measured at a third of this kernel's rate: most of the work per block
 // - axis, quantisation, refit, bit packing - is uniform across a block's texels and was replicated 16 times.)
@@ -137,7 +137,7 @@ __device__ inline uint32_t u_fit_plane(const uint32_t px[16], int cmask, int ran
     lo[0] = mn; hi[0] = mx;
   } else {
     // 32-bit where the ranges allow it: |16 c - S| <= 4080, a covariance entry < 2^29, the axis is renormalised below 2^15, a
-    // projection is below 2^31; same values as the oracle's int64
+    // projection is below 2^31: the same values a 64-bit evaluation gives
     int S[4] = { 0, 0, 0, 0 }, cov[4][4], mn[4] = { 255, 255, 255, 255 }, mx[4] = { 0, 0, 0, 0 }; long long v[4] = { 0, 0, 0, 0 };
     for (int c = 0; c < nc; c++) for (int i = 0; i < 16; i++) { const int x = u_comp(px[i], comp[c]); S[c] += x; mn[c] = x < mn[c] ? x : mn[c]; mx[c] = x > mx[c] ? x : mx[c]; }
     for (int a = 0; a < nc; a++) for (int b = a; b < nc; b++) { int sv = 0; for (int i = 0; i < 16; i++) sv += (16 * u_comp(px[i], comp[a]) - S[a]) * (16 * u_comp(px[i], comp[b]) - S[b]); cov[a][b] = sv; cov[b][a] = sv; }

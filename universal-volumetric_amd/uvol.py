@@ -151,11 +151,12 @@ class Codec:
             m, k = self._mesh_host(**f); meshes[i] = m; keep.append(k)
         return self._run_batch(self.L.uvol_encode_mesh_batch, meshes, n, raise_on_error)
 
-    def encode_mesh_batch_dev(self, meshes, raise_on_error=True):
-        """meshes: ctypes array of Mesh holding DEVICE pointers (inputs resident in HBM)."""
-        return self._run_batch(self.L.uvol_encode_mesh_batch_dev, meshes, len(meshes), raise_on_error)
+    def encode_mesh_batch_dev(self, meshes, raise_on_error=True, views=False):
+        """meshes: ctypes array of Mesh holding DEVICE pointers (inputs resident in HBM).  views=True: numpy views of this
+        codec's output buffers instead of `bytes` copies (valid until the next call; no 250 KB copy per frame in Python)."""
+        return self._run_batch(self.L.uvol_encode_mesh_batch_dev, meshes, len(meshes), raise_on_error, views)
 
-    def _run_batch(self, fn, meshes, n, raise_on_error):
+    def _run_batch(self, fn, meshes, n, raise_on_error, views=False):
         caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)()
         bufs = getattr(self, "_obufs", [])          # output buffers are kept between calls (no fresh pages to fault in per batch)
         while len(bufs) < n:
@@ -176,7 +177,7 @@ class Codec:
                     raise UvolError(f"frame {i} failed status={st[i]}: {self.error()}")
                 res.append(None)
             else:
-                res.append(bufs[i][:lens[i]].tobytes())
+                res.append(bufs[i][:lens[i]] if views else bufs[i][:lens[i]].tobytes())
         return res
 
     # ---- texture ----
