@@ -7,8 +7,10 @@ and the doubled figure are recorded and the raw one is used for `traffic` (a low
 import collections, csv, json, sys
 fd, wd, outp = sys.argv[1], sys.argv[2], sys.argv[4]
 frames = int(sys.argv[3].split(':')[0]); frames_tex = int(sys.argv[3].split(':')[1]) if ':' in sys.argv[3] else frames
-GROUPS = {"geo.k4_eb_walk": "k_eb_walk", "geo.k5_traverse": "k_traverse", "geo.k4_eb_valence": "k_eb_valence", "geo.k7_entropy_encode": "k_entropy_encode",
-          "tex.k12_sel_tokens": "k_sel_tokens", "tex.k9_endpoint_fit": "k_tex_fit"}
+GROUPS = {"geo.k4_eb_walk": ["k_eb_walk"], "geo.k5_traverse": ["k_traverse"], "geo.k4_eb_valence": ["k_eb_valence"], "geo.k7_entropy_encode": ["k_entropy"],
+          "geo.k2_dedup": ["k_dedup", "k_faces", "k_compact_faces"], "geo.k3_corner_table": ["k_he_", "k_edge_match", "k_vert0"],
+          "geo.k4b_renumber_seams": ["k_renumber", "k_seams", "k_seam_bits", "k_aseg"],
+          "tex.k12_sel_tokens": ["k_sel_tokens"], "tex.k9_endpoint_fit": ["k_tex_fit"], "tex.k10_selector_codebook": ["k_sel_stats", "k_sel_assign", "k_sel_centroids", "k_sel_used", "k_vq_apply<16>", "k_vq_decide<16>", "k_vq_zero<16>", "k_copy_skipped"]}
 def load(d, c):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f"{d}/bench_counter_collection.csv")):
@@ -18,10 +20,11 @@ def load(d, c):
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 out = {"frames_per_launch": frames, "frames_per_texture_launch": frames_tex, "unit": "bytes", "kernels": {}}
 for g, pat in GROUPS.items():
-    f = [v for k, v in F.items() if pat in k]; w = [v for k, v in W.items() if pat in k]
+    f = [v for k, v in F.items() if any(p_ in k for p_ in pat)]; w = [v for k, v in W.items() if any(p_ in k for p_ in pat)]
     if not f or not w: continue
-    fb = sum(v[1] for v in f) / sum(v[0] for v in f) * 1024; wb = sum(v[1] for v in w) / sum(v[0] for v in w) * 1024
-    out["kernels"][g] = {"kernel": pat, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb, "write_bytes_per_launch": wb,
+    # bytes per LAUNCH OF THE GROUP (one batch): the sum over the group's kernels of one step
+    fb = sum(v[1] for v in f) * 1024; wb = sum(v[1] for v in w) * 1024
+    out["kernels"][g] = {"kernels": pat, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb, "write_bytes_per_launch": wb,
                          "hbm_bytes_per_launch": fb + wb, "hbm_bytes_per_frame": (fb + wb) / (frames_tex if g.startswith("tex.") else frames)}
 json.dump(out, open(outp, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_frame"] / 1e6, 2) for k, v in out["kernels"].items()}), "MB/frame")
