@@ -35,7 +35,21 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
   return base + x - v;
 }
 
-// scan selectors
+// sum of v over the workgroup; every thread of the block calls it (no early returns before it)
+__device__ inline uint32_t block_sum(uint32_t v) {
+  __shared__ uint32_t acc;
+  if (threadIdx.x == 0) acc = 0;
+  __syncthreads();
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc, v);
+  __syncthreads();
+  const uint32_t r = acc;
+  __syncthreads();
+  return r;
+}
+
+// scan selectors.  The producers of the KEEP / ELIG / EVENTS flags write the per-block sums themselves (block_sum), so only
+// SCAN_ORI still runs k_scan_blocks; k_scan_sums turns the sums into block offsets for all four.
 enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3 };
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
@@ -72,6 +86,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_sums(GeoJob *jobs, int sel)
   if (threadIdx.x == 0) bsum[nblocks] = carry;
 }
 
+// Corners per thread in the per-corner gather kernels (see k_renumber_b): they are latency-bound at full occupancy, so a
+// thread issues every level of its dependent loads for GEO_ILP corners (one block stride apart: coalesced) before using any.
+#define GEO_ILP 4
 // ------------------------------------------------------------------------------------------------
 // K2: bitwise value dedup.  table slot = (index+1), 0 = empty; final slot value = min index of the value.
 // ------------------------------------------------------------------------------------------------
@@ -114,16 +131,21 @@ typedef int32_t uvol_s3 __attribute__((ext_vector_type(3), aligned(4)));
 __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
   JOB_OR_RETURN;
   uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (f >= J.nf_in) return;
-  bool bad = false; uint32_t a[3];
-  for (int k = 0; k < 3; k++) {
-    uint32_t ip = J.ipos[3 * f + k]; if (ip >= J.n_pos) { bad = true; ip = 0; }
-    if (J.has_uv && J.iuv[3 * f + k] >= J.n_uv) bad = true;
-    if (J.has_nrm && J.inrm[3 * f + k] >= J.n_nrm) bad = true;
-    a[k] = J.canon[0][ip];
+  uint32_t keep = 0; bool bad = false;
+  if (f < J.nf_in) {
+    uint32_t a[3];
+    for (int k = 0; k < 3; k++) {
+      uint32_t ip = J.ipos[3 * f + k]; if (ip >= J.n_pos) { bad = true; ip = 0; }
+      if (J.has_uv && J.iuv[3 * f + k] >= J.n_uv) bad = true;
+      if (J.has_nrm && J.inrm[3 * f + k] >= J.n_nrm) bad = true;
+      a[k] = J.canon[0][ip];
+    }
+    keep = (a[0] != a[1] && a[1] != a[2] && a[0] != a[2]) ? 1u : 0u;
+    J.keep[f] = (uint8_t)keep;
   }
-  if (bad) J.status = -2;
-  J.keep[f] = (a[0] != a[1] && a[1] != a[2] && a[0] != a[2]) ? 1 : 0;
+  const uint32_t tot = block_sum(keep);                                  // block sums of the keep flags (was a k_scan_blocks pass)
+  if (threadIdx.x == 0 && blockIdx.x < uvol_blocks_dev(J.nf_in)) J.bsum[blockIdx.x] = tot;
+  if (bad) J.status = -2;                                                // after the barriers: a wave that has not started yet leaves at once when it sees it
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
@@ -155,9 +177,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(UVOL_BLOCK) k_he_count(GeoJob *jobs) {
   JOB_OR_RETURN;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  atomicAdd(&J.he_start[(uint32_t)J.cp[g_nxt(c)]], 1u);
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  uint32_t a[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; a[k] = c < nc ? (uint32_t)J.cp[g_nxt(c)] : 0xffffffffu; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) if (a[k] != 0xffffffffu) atomicAdd(&J.he_start[a[k]], 1u);
 }
 // one workgroup per frame: exclusive scan of the per-vertex counts in place, cursor = start
 __global__ void __launch_bounds__(UVOL_BLOCK) k_he_scan(GeoJob *jobs) {
@@ -180,11 +205,14 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_he_scan(GeoJob *jobs) {
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_he_fill(GeoJob *jobs) {
   JOB_OR_RETURN;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  const uint32_t a = (uint32_t)J.cp[g_nxt(c)], b = (uint32_t)J.cp[g_prv(c)];
-  const uint32_t slot = atomicAdd(&J.he_cur[a], 1u);
-  J.he_ent[slot] = ((unsigned long long)b << 32) | (unsigned long long)c;
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  uint32_t a[GEO_ILP], b[GEO_ILP], slot[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; const bool in = c < nc; a[k] = in ? (uint32_t)J.cp[g_nxt(c)] : 0xffffffffu; b[k] = in ? (uint32_t)J.cp[g_prv(c)] : 0u; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) slot[k] = a[k] != 0xffffffffu ? atomicAdd(&J.he_cur[a[k]], 1u) : 0u;
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) if (a[k] != 0xffffffffu) J.he_ent[slot[k]] = ((unsigned long long)b[k] << 32) | (unsigned long long)(c0 + k * UVOL_BLOCK);
 }
 // lowest corner on the directed edge (from -> to), or -1; the order inside a bucket is arbitrary, the minimum is not
 __device__ __forceinline__ int he_find(const GeoJob &J, uint32_t from, uint32_t to) {
@@ -193,13 +221,24 @@ __device__ __forceinline__ int he_find(const GeoJob &J, uint32_t from, uint32_t 
   for (uint32_t i = s; i < e; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == to) { const uint32_t cc = (uint32_t)v; best = cc < best ? cc : best; } }
   return best == 0xffffffffu ? -1 : (int)best;
 }
+// bucket bounds of both directed edges of GEO_ILP corners are fetched before any bucket is scanned
 __global__ void __launch_bounds__(UVOL_BLOCK) k_edge_match(GeoJob *jobs) {
   JOB_OR_RETURN;
-  uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  uint32_t a = (uint32_t)J.cp[g_nxt(c)], b = (uint32_t)J.cp[g_prv(c)];
-  int self = he_find(J, a, b), o = he_find(J, b, a);
-  J.opp[c] = (self == (int)c && o >= 0) ? o : GEO_INV;
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  uint32_t a[GEO_ILP], b[GEO_ILP], sa[GEO_ILP], ea[GEO_ILP], sb[GEO_ILP], eb[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK, cc = c < nc ? c : 0u; a[k] = (uint32_t)J.cp[g_nxt(cc)]; b[k] = (uint32_t)J.cp[g_prv(cc)]; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { sa[k] = J.he_start[a[k]]; ea[k] = J.he_cur[a[k]]; sb[k] = J.he_start[b[k]]; eb[k] = J.he_cur[b[k]]; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) {
+    const uint32_t c = c0 + k * UVOL_BLOCK;
+    if (c >= nc) continue;
+    uint32_t self = 0xffffffffu, o = 0xffffffffu;
+    for (uint32_t i = sa[k]; i < ea[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == b[k]) { const uint32_t cc = (uint32_t)v; self = cc < self ? cc : self; } }
+    for (uint32_t i = sb[k]; i < eb[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == a[k]) { const uint32_t cc = (uint32_t)v; o = cc < o ? cc : o; } }
+    J.opp[c] = (self == c && o != 0xffffffffu) ? (int)o : GEO_INV;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,9 +586,10 @@ __device__ inline int eb_events_of(const GeoJob &J, uint32_t i, int ev_spl[2], i
 __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_flags(GeoJob *jobs) {
   JOB_OR_RETURN;
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (i >= J.nf) return;
-  int a[2], b[2];
-  J.evcnt[i] = i < (uint32_t)J.nsym ? (uint8_t)eb_events_of(J, i, a, b) : 0;
+  uint32_t n = 0;
+  if (i < J.nf) { int a[2], b[2]; n = i < (uint32_t)J.nsym ? (uint32_t)eb_events_of(J, i, a, b) : 0u; J.evcnt[i] = (uint8_t)n; }
+  const uint32_t tot = block_sum(n);
+  if (threadIdx.x == 0 && blockIdx.x < uvol_blocks_dev(J.nf)) J.bsum2[blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
@@ -681,33 +721,60 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_a(GeoJob *jobs) {
   int o[3] = { c, g_nxt(c), g_prv(c) };
   for (int k = 0; k < 3; k++) { J.old_of_new[3 * f + k] = o[k]; J.new_of_old[o[k]] = (int)(3 * f + k); }
 }
+// The per-corner gather kernels below are latency-bound at full occupancy (three or four dependent loads per thread, ~2 us
+// each under load: 512 k resident threads / 6 us = what was measured), so every thread handles GEO_ILP corners, one block
+// stride apart (accesses stay coalesced), and issues each level of its loads for all of them before it uses any.
 __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_b(GeoJob *jobs) {
   JOB_OR_RETURN;
-  uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  int o = J.old_of_new[c], oo = J.opp[o];
-  J.nopp[c] = oo < 0 ? GEO_INV : J.new_of_old[oo];
-  J.npid[c] = J.cp[o]; J.nuid[c] = J.cu[o]; J.nnid[c] = J.cn[o];
-  J.bvert[c] = J.vert[o];                        // the same vertices under the decoder's corner numbering
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  int o[GEO_ILP], oo[GEO_ILP], p[GEO_ILP], u[GEO_ILP], n[GEO_ILP], v[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; o[k] = c < nc ? J.old_of_new[c] : 0; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { oo[k] = J.opp[o[k]]; p[k] = J.cp[o[k]]; u[k] = J.cu[o[k]]; n[k] = J.cn[o[k]]; v[k] = J.vert[o[k]]; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) oo[k] = oo[k] < 0 ? GEO_INV : J.new_of_old[oo[k]];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) {
+    const uint32_t c = c0 + k * UVOL_BLOCK;
+    if (c < nc) { J.nopp[c] = oo[k]; J.npid[c] = p[k]; J.nuid[c] = u[k]; J.nnid[c] = n[k]; J.bvert[c] = v[k]; }   // the same vertices under the decoder's corner numbering
+  }
 }
 
 // attribute seams (MeshAttributeCornerTable::InitFromAttribute) + seam-bit eligibility
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
   JOB_OR_RETURN;
-  uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc) return;
-  int oc = J.nopp[c];
-  J.elig[c] = (oc >= 0 && (uint32_t)oc / 3 > c / 3) ? 1 : 0;
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  int oc[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; oc[k] = c < nc ? J.nopp[c] : -1; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) {
+    const uint32_t c = c0 + k * UVOL_BLOCK; const uint32_t e = (c < nc && oc[k] >= 0 && (uint32_t)oc[k] / 3 > c / 3) ? 1u : 0u;
+    if (c < nc) J.elig[c] = (uint8_t)e;
+    const uint32_t tot = block_sum(e), b = blockIdx.x * GEO_ILP + k;     // block sums of the eligibility flags for k_seam_bits
+    if (threadIdx.x == 0 && b < uvol_blocks_dev(nc)) J.bsum[b] = tot;
+  }
   for (int i = 0; i < J.nad; i++) {
     const int32_t *ids = J.att_kind[i] == 0 ? J.nuid : J.nnid;
-    uint8_t s;
-    if (oc < 0) s = 1;
-    else {
-      s = (ids[g_nxt(c)] != ids[g_prv(oc)] || ids[g_prv(c)] != ids[g_nxt(oc)]) ? 1 : 0;
-      if (s) { J.interior_seams[i] = 1; const uint32_t va = (uint32_t)J.bvert[g_nxt(c)], vb = (uint32_t)J.bvert[g_prv(c)];      // both ends of the edge get split
-        atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31)); }
+    int a0[GEO_ILP], a1[GEO_ILP], b0[GEO_ILP], b1[GEO_ILP];
+#pragma unroll
+    for (int k = 0; k < GEO_ILP; k++) {
+      const uint32_t c = c0 + k * UVOL_BLOCK; const bool in = c < nc && oc[k] >= 0; const int cc = in ? (int)c : 0, oo = in ? oc[k] : 0;
+      a0[k] = ids[g_nxt(cc)]; a1[k] = ids[g_prv(cc)]; b0[k] = ids[g_prv(oo)]; b1[k] = ids[g_nxt(oo)];
     }
-    J.seam[i][c] = s;
+#pragma unroll
+    for (int k = 0; k < GEO_ILP; k++) {
+      const uint32_t c = c0 + k * UVOL_BLOCK;
+      if (c >= nc) continue;
+      uint8_t s = 1;
+      if (oc[k] >= 0) {
+        s = (a0[k] != b0[k] || a1[k] != b1[k]) ? 1 : 0;
+        if (s) { J.interior_seams[i] = 1; const uint32_t va = (uint32_t)J.bvert[g_nxt(c)], vb = (uint32_t)J.bvert[g_prv(c)];      // both ends of the edge get split
+          atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31)); }
+      }
+      J.seam[i][c] = s;
+    }
   }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
@@ -735,24 +802,42 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
 __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
   JOB_OR_RETURN;
   const int i = (int)blockIdx.z;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c >= J.nc || i >= J.nad || !J.interior_seams[i]) return;
-  const int32_t v = J.bvert[c];
-  if (!((J.vseam[i][(uint32_t)v >> 5] >> ((uint32_t)v & 31)) & 1u)) { J.avert[i][c] = v; return; }
+  if (i >= J.nad || !J.interior_seams[i]) return;
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  int32_t v[GEO_ILP]; uint32_t w[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? J.bvert[c] : 0; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][(uint32_t)v[k] >> 5];
   GTab T; T.opp = J.nopp; T.seam = J.seam[i];
-  if (gt_swl(T, (int)c) < 0) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) {
+    const uint32_t c = c0 + k * UVOL_BLOCK;
+    if (c >= nc) continue;
+    if (!((w[k] >> ((uint32_t)v[k] & 31)) & 1u)) { J.avert[i][c] = v[k]; continue; }
+    if (gt_swl(T, (int)c) < 0) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
+  }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
   JOB_OR_RETURN;
   const int i = (int)blockIdx.z;
-  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (c == 0 && i < J.nad && J.interior_seams[i]) { const uint32_t tot = J.nverts_t[0] + J.nseg[i]; J.nverts_t[2 + i] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
-  if (c >= J.nc || i >= J.nad || !J.interior_seams[i]) return;
-  { const uint32_t v = (uint32_t)J.bvert[c]; if (!((J.vseam[i][v >> 5] >> (v & 31)) & 1u)) return; }
+  if (i >= J.nad || !J.interior_seams[i]) return;
+  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  if (c0 == 0) { const uint32_t tot = J.nverts_t[0] + J.nseg[i]; J.nverts_t[2 + i] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
+  uint32_t v[GEO_ILP], w[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? (uint32_t)J.bvert[c] : 0u; }
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][v[k] >> 5];
   GTab T; T.opp = J.nopp; T.seam = J.seam[i];
-  int l = (int)c; uint32_t guard = 0;
-  for (;;) { const int nl = gt_swl(T, l); if (nl < 0) break; l = nl; if (++guard > J.nc) { J.status = -22; return; } }
-  if (l != (int)c) J.avert[i][c] = J.avert[i][l];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) {
+    const uint32_t c = c0 + k * UVOL_BLOCK;
+    if (c >= nc || !((w[k] >> (v[k] & 31)) & 1u)) continue;
+    int l = (int)c; uint32_t guard = 0;
+    for (;;) { const int nl = gt_swl(T, l); if (nl < 0) break; l = nl; if (++guard > nc) { J.status = -22; return; } }
+    if (l != (int)c) J.avert[i][c] = J.avert[i][l];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1786,12 +1871,13 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   J.ecap = (uint32_t)ecap;
   auto bitlen = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };
 #define CARVE(field, T, count, first, last) items.push_back(WsItem{(size_t)((char *)&(field) - (char *)&J), (size_t)(count) * sizeof(T), (first), (last), 0})
-  // ---- pinned, zero-initialised ----
+  // dedup hash tables: live in the first phase only, zeroed group by group right before use (k_dd_clear, geo_dedup_groups)
   for (int k = 0; k < 3; k++) {
     const uint32_t n = k == 0 ? J.n_pos : (k == 1 ? J.n_uv : J.n_nrm);
     J.dd_cap[k] = pow2_at_least(2ull * n + 2);
-    CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k], PH_PINNED, PH_PINNED);
+    CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k], PH_DEDUP, PH_DEDUP);
   }
+  // ---- pinned, zero-initialised ----
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint32_t, ecap / 32 + 2, PH_PINNED, PH_PINNED);      // one bit per vertex: the whole map stays in L2
@@ -1940,6 +2026,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_job_clear(GeoJob *jobs) {
   for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * UVOL_BLOCK) p[i] = make_uint4(0, 0, 0, 0);
 }
 
+// zero the three dedup hash tables of the jobs of one group (grid y = job, z = table)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dd_clear(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  uint4 *p = reinterpret_cast<uint4 *>(J.dd_tab[blockIdx.z]);
+  const size_t n16 = (size_t)J.dd_cap[blockIdx.z] / 4;                   // capacities are powers of two >= 4, tables 256-byte aligned
+  for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * UVOL_BLOCK) p[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (uint32_t i = (uint32_t)n16 * 4; i < J.dd_cap[blockIdx.z]; i++) J.dd_tab[blockIdx.z][i] = 0;
+}
+
 // How the serial walkers of a batch run.  Wave-per-walker (one lane of a wave per walker, visited bitmaps in LDS) is the
 // faster form per walker (one dependent load per face, 0.35 - 0.5 us) but a CU's LDS holds 3 of them; lane-per-walker (SIMT,
 // nothing in LDS, 0.55 - 0.65 us per face at 16 lanes per wave) has no such cap.  So: LDS walkers while all of a launch's
@@ -2027,7 +2122,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   G->hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
-  uint32_t max_nfi = 0, max_vals = 0; uint64_t algo_in = 0;
+  uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0; uint64_t algo_in = 0;
   for (int i = 0; i < n; i++) max_nfi = std::max(max_nfi, meshes[i].n_faces);
   const int r8 = geo_rec8(max_nfi) ? 1 : 0;
   for (int i = 0; i < n; i++) {
@@ -2047,7 +2142,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     // (8 bytes per face; the defaults give 1.3), not for the sum of the callers' capacities; GEO_E_SLAB_FULL -> retried alone
     const size_t oc = full ? caps[i] : std::min<size_t>(caps[i], 32768 + 8 * (size_t)m.n_faces);
     out_total += (oc + 255) & ~(size_t)255; J.out_cap = (uint32_t)std::min<size_t>(caps[i], 0xffffffffu);
-    max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm)));
+    max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm))); max_ecap = std::max(max_ecap, J.ecap);
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
   int rc;
@@ -2085,26 +2180,36 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   GeoJob *dj = (GeoJob *)G->jobs.p;
   const unsigned N = (unsigned)n;
   LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
-  const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals);
+  const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
+                 be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
-    LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, 0);
-    LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, 0);
-    LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 0);
-    LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, 1);
-    LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, 1);
-    LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 1);
+    // UVOL_DD_GROUP=<frames> (diagnostic) clears and de-duplicates the batch in groups of that many frames so that a group's hash
+    // tables could stay in the memory-side cache between the clear and the probes; measured: no difference for 8 / 32 / 128 /
+    // all frames per group (device atomics are performed memory-side either way), so the default is one group.
+    static const unsigned dd_env = [] { const char *e = getenv("UVOL_DD_GROUP"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 0); }();
+    const unsigned dd_group = dd_env ? dd_env : N;
+    for (unsigned y0 = 0; y0 < N; y0 += dd_group) {
+      const unsigned Ng = std::min(dd_group, N - y0);
+      GeoJob *gj = dj + y0;
+      LAUNCH(k_dd_clear, dim3(16, Ng, 3), dim3(UVOL_BLOCK), gj);
+      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 0, 0);
+      LAUNCH(k_dedup<2>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 1, 0);
+      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 2, 0);
+      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 0, 1);
+      LAUNCH(k_dedup<2>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 1, 1);
+      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 2, 1);
+    }
     LAUNCH(k_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_KEEP);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_KEEP);
     LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k3_corner_table", (uint64_t)n * 0 + (uint64_t)3 * max_nfi * 4 * 3);
-    LAUNCH(k_he_count, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_he_count, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_he_scan, dim3(1, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_he_fill, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_edge_match, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_he_fill, dim3(bci, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_edge_match, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
   }
   const WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)N);
@@ -2122,7 +2227,6 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(G->aux, G->ev_walk, 0));
   {
     LAUNCH_ON(G->aux, k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH_ON(G->aux, k_scan_blocks, dim3(bf, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
     LAUNCH_ON(G->aux, k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
     LAUNCH_ON(G->aux, k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH_ON(G->aux, k_valence_init, dim3(bc, N), dim3(UVOL_BLOCK), dj);
@@ -2133,13 +2237,12 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   {
     uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_renumber_b, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_seams, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_scan_blocks, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
+    LAUNCH(k_renumber_b, dim3(bci, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_seams, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
     LAUNCH(k_seam_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_aseg_a, dim3(bc, N, 2), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_aseg_b, dim3(bc, N, 2), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_aseg_a, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_aseg_b, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
   }
   {
     LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, r8);
@@ -2149,23 +2252,23 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
     const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
     launch_traversals(ctx, dj, n, walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg), r8);
-    LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
+    LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, r8);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
     LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_quantize, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_quantize, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k6_predict", 0);
     LAUNCH(k_stream_setup, dim3(N), dim3(64), dj);
-    LAUNCH(k_pred_pos, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_pred_uv, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_scan_blocks, dim3(bc, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ORI);
+    LAUNCH(k_pred_pos, dim3(be, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_pred_uv, dim3(be, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_scan_blocks, dim3(be, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ORI);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ORI);
-    LAUNCH(k_ori_compact, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_ori_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_pred_nrm, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_ori_compact, dim3(be, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_ori_bits, dim3(be, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_pred_nrm, dim3(be, N), dim3(UVOL_BLOCK), dj);
   }
   UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
