@@ -207,3 +207,19 @@ def test_gpu_compact_workspace_overflow_is_retried(oracle, gpu_codec):
     assert res[1] == oracle.drc_encode(pos, idx, None, None, None, None)
     assert res[0] == res[2] == _oracle_bytes(oracle, t)
     assert gpu_codec.mesh_workspace(**synth.sphere_mesh()) < 80e6
+
+
+def test_gpu_partitioned_dedup_duplicates_and_overflow_retry(oracle, monkeypatch):
+    """Partitioned dedup on the GPU: duplicated values (lowest index wins, like the oracle), and the GEO_E_DD_OVERFLOW retry through
+    the hash-table kernels when the LDS table is made too small (UVOL_DD_SLOTS=4)."""
+    import synth, uvol
+    from test_hipemu_geom import _dup_mesh
+    m = _dup_mesh(); t = synth.torus_mesh(); s = synth.sphere_mesh(120, 61)
+    want = [oracle.drc_encode(x["pos"], x["idx_pos"], x["uv"], x["idx_uv"], x["nrm"], x["idx_nrm"]) for x in (m, t, s)]
+    cd = uvol.Codec(device=0)
+    try:
+        assert cd.encode_mesh_batch([m, t, s]) == want
+        monkeypatch.setenv("UVOL_DD_SLOTS", "4")
+        assert cd.encode_mesh_batch([m, t, s]) == want
+    finally:
+        cd.close()

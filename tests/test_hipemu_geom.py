@@ -162,3 +162,33 @@ def test_hipemu_compact_workspace_overflow_is_retried(oracle, hipemu_lib):
     m = synth.sphere_mesh(400, 251)
     assert cd.mesh_workspace(**m) < 80e6          # 100,002 vertices / 200,000 faces: was 220 MB before the arrays shared addresses
     cd.close()
+
+
+def _dup_mesh():
+    """A torus whose value arrays hold every value several times (different indices, same bits) plus unused values: the canonical
+    id of a value is the LOWEST index that holds it."""
+    import synth
+    m = synth.torus_mesh(24, 12)
+    out = dict(m)
+    rng = np.random.default_rng(7)
+    for key, idx in (("pos", "idx_pos"), ("uv", "idx_uv"), ("nrm", "idx_nrm")):
+        v = m[key]; n = len(v)
+        rep = np.concatenate([v, v[::-1], v[: n // 2]])                        # value k also lives at 2n-1-k (and n.. for k < n/2)
+        pick = rng.integers(0, 3, size=len(m[idx]))
+        i = m[idx].astype(np.int64)
+        alt = np.where(pick == 0, i, np.where(pick == 1, 2 * n - 1 - i, np.where(i < n // 2, 2 * n + i, i)))
+        out[key] = np.ascontiguousarray(rep); out[idx] = alt.astype(np.uint32)
+    return out
+
+
+def test_hipemu_partitioned_dedup_duplicates_and_overflow_retry(oracle, hipemu_lib, monkeypatch):
+    """Partitioned dedup (hash bins resolved in LDS): duplicated values get the lowest index, like the oracle; with a 4-slot table
+    every bin overflows (GEO_E_DD_OVERFLOW) and the frames are re-encoded through the hash-table kernels: same bytes."""
+    import synth, uvol
+    m = _dup_mesh(); t = synth.torus_mesh()
+    want = [oracle.drc_encode(x["pos"], x["idx_pos"], x["uv"], x["idx_uv"], x["nrm"], x["idx_nrm"]) for x in (m, t)]
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    assert cd.encode_mesh_batch([m, t]) == want
+    monkeypatch.setenv("UVOL_DD_SLOTS", "4")
+    assert cd.encode_mesh_batch([m, t]) == want
+    cd.close()

@@ -58,7 +58,8 @@ struct GeoJob {
   int32_t wrap_lo[2], wrap_hi[2];                                  // [0]=pos, [1]=uv
   uint32_t out_len;
   // ---- workspace ----
-  uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3]; uint32_t n_dup[3];      // n_dup: phase 0 of the dedup saw two equal values
+  uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3]; uint32_t n_dup[3];      // hash-table dedup (worst-case retry): n_dup: phase 0 saw two equal values
+  uint4 *dd_part[3]; uint32_t *dd_cnt[3]; uint32_t dd_nb[3], dd_nblk[3];               // partitioned dedup: {index, words} records by hash bin; counts[bin][tile]
   uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
@@ -94,6 +95,7 @@ struct GeoJob {
 // (geo_encode_batch re-encodes such a frame alone with worst-case sizes)
 #define GEO_E_WS_OVERFLOW (-50)
 #define GEO_E_SLAB_FULL (-51)
+#define GEO_E_DD_OVERFLOW (-52)        // a hash bin of the partitioned dedup holds more distinct values than its LDS table: retried with the hash-table dedup
 // corner codes for the serial walkers: 4 * face + k, so that face = code >> 2 and records are indexed without a division
 __device__ __forceinline__ int code_of_corner(int c) { return c < 0 ? -1 : (((c / 3) << 2) | (c % 3)); }
 __device__ __host__ __forceinline__ uint32_t uvol_blocks_dev(uint32_t n) { return (n + 255u) / 256u; }

@@ -17,6 +17,10 @@
 #include <algorithm>
 
 #define JOB_OR_RETURN GeoJob &J = jobs[blockIdx.y]; if (J.status != 0) return
+// For kernels with barriers: the frame's status is read by ONE thread and the whole workgroup takes the same decision.  Another
+// workgroup of the same frame may fail the frame at any moment; with a per-thread test some waves of a block would leave and
+// the others wait for them at the barrier (the hardware tolerates that, the host emulation of tests/hipemu does not).
+#define JOB_OR_RETURN_UNIFORM GeoJob &J = jobs[blockIdx.y]; { __shared__ int job_st_; if (threadIdx.x == 0) job_st_ = J.status; __syncthreads(); if (job_st_ != 0) return; }
 
 // ------------------------------------------------------------------------------------------------
 // block-level exclusive scan (wave shuffles + LDS), blockDim.x == UVOL_BLOCK
@@ -121,6 +125,138 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dedup(GeoJob *jobs, int which, i
   if (phase == 1) J.status = -20;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2, partitioned form (the default).  The hash table above costs one device-scope atomic on a random 64-byte line per
+// value: memory-side read-modify-writes that do not cache (47 MB of HBM traffic per 100 k-vertex frame for 3.2 MB of values,
+// profiles/r02_n).  Here the values are first partitioned by the top bits of their hash (count -> scan -> scatter of 16-byte
+// {index, words} records: streaming passes, the only atomics are LDS counters), then every bin (~1 k values) is resolved by
+// ONE workgroup in an LDS hash table.  canon[] = lowest index among bitwise-equal values, exactly as before.  A bin with more
+// distinct values than the table holds (hash skew) fails the frame with GEO_E_DD_OVERFLOW; the host re-encodes it with the
+// hash-table kernels.  grid z = attribute (0 pos, 1 uv, 2 normals), y = frame.
+// ------------------------------------------------------------------------------------------------
+#define DD_TILE 1024                         // values per workgroup in the count / scatter passes
+#define DD_MAXBINS 1024
+#define DD_SLOTS 4096                        // LDS hash slots per bin
+struct DdSrc { const uint32_t *data; uint32_t n, nw; };
+__device__ __forceinline__ DdSrc dd_src(const GeoJob &J, int which) {
+  DdSrc S; S.data = (const uint32_t *)(which == 0 ? (const void *)J.pos : (which == 1 ? (const void *)J.uv : (const void *)J.nrm));
+  S.n = S.data ? (which == 0 ? J.n_pos : (which == 1 ? J.n_uv : J.n_nrm)) : 0u; S.nw = which == 1 ? 2u : 3u; return S;
+}
+__device__ __forceinline__ uint64_t dd_hash(const uint32_t w[3], uint32_t nw) {
+  uint64_t h = 1469598103934665603ULL;
+  for (uint32_t k = 0; k < nw; k++) h = g_mix64(h ^ w[k]);
+  return h;
+}
+__device__ __forceinline__ uint32_t dd_bin(uint64_t h, uint32_t nb) { return (uint32_t)(h >> 40) & (nb - 1); }
+__device__ __forceinline__ uint32_t dd_slot(uint64_t h, uint32_t slots) { return (uint32_t)h & (slots - 1); }
+// pass 1: per tile, the number of values per bin; canon[] starts as the identity
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dd_count(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const int which = (int)blockIdx.z; const DdSrc S = dd_src(J, which);
+  const uint32_t nb = J.dd_nb[which], nblk = J.dd_nblk[which];
+  if (blockIdx.x >= nblk) return;
+  __shared__ uint32_t hist[DD_MAXBINS];
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) hist[b] = 0;
+  __syncthreads();
+  for (uint32_t k = 0; k < DD_TILE / UVOL_BLOCK; k++) {
+    const uint32_t i = blockIdx.x * DD_TILE + k * UVOL_BLOCK + threadIdx.x;
+    if (i < S.n) {
+      uint32_t w[3] = { 0, 0, 0 };
+      for (uint32_t q = 0; q < S.nw; q++) w[q] = S.data[(size_t)i * S.nw + q];
+      atomicAdd(&hist[dd_bin(dd_hash(w, S.nw), nb)], 1u);
+      J.canon[which][i] = i;
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) J.dd_cnt[which][(size_t)b * nblk + blockIdx.x] = hist[b];
+}
+// pass 2: exclusive scan of counts[bin][tile] in bin-major order (one workgroup per frame and attribute); [nb * nblk] = n
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dd_scan(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const int which = (int)blockIdx.z;
+  const uint32_t m = J.dd_nb[which] * J.dd_nblk[which];
+  uint32_t *cnt = J.dd_cnt[which];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < m; b0 += UVOL_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < m ? cnt[i] : 0, tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    if (i < m) cnt[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[m] = carry;
+}
+// pass 3: scatter {index, words} into the bins (order inside a bin is arbitrary: the result is a minimum)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dd_scatter(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const int which = (int)blockIdx.z; const DdSrc S = dd_src(J, which);
+  const uint32_t nb = J.dd_nb[which], nblk = J.dd_nblk[which];
+  if (blockIdx.x >= nblk) return;
+  __shared__ uint32_t cur[DD_MAXBINS];
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) cur[b] = J.dd_cnt[which][(size_t)b * nblk + blockIdx.x];
+  __syncthreads();
+  for (uint32_t k = 0; k < DD_TILE / UVOL_BLOCK; k++) {
+    const uint32_t i = blockIdx.x * DD_TILE + k * UVOL_BLOCK + threadIdx.x;
+    if (i < S.n) {
+      uint32_t w[3] = { 0, 0, 0 };
+      for (uint32_t q = 0; q < S.nw; q++) w[q] = S.data[(size_t)i * S.nw + q];
+      const uint32_t pos = atomicAdd(&cur[dd_bin(dd_hash(w, S.nw), nb)], 1u);
+      J.dd_part[which][pos] = make_uint4(i, w[0], w[1], w[2]);
+    }
+  }
+}
+// pass 4: one workgroup per bin: LDS hash table slot -> (record of the first value that claimed it, lowest index of its value)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_dd_resolve(GeoJob *jobs, uint32_t slots) {
+  JOB_OR_RETURN_UNIFORM;
+  const int which = (int)blockIdx.z; const DdSrc S = dd_src(J, which);
+  const uint32_t nb = J.dd_nb[which], nblk = J.dd_nblk[which];
+  if (blockIdx.x >= nb || S.n == 0) return;
+  const uint32_t lo = J.dd_cnt[which][(size_t)blockIdx.x * nblk], hi = J.dd_cnt[which][(size_t)(blockIdx.x + 1) * nblk];
+  const uint4 *part = J.dd_part[which];
+  __shared__ uint32_t t_rec[DD_SLOTS], t_min[DD_SLOTS];
+  __shared__ uint32_t n_ins, any_dup, fail;
+  for (uint32_t s = threadIdx.x; s < slots; s += UVOL_BLOCK) { t_rec[s] = 0; t_min[s] = 0xffffffffu; }
+  if (threadIdx.x == 0) { n_ins = 0; any_dup = 0; fail = 0; }
+  __syncthreads();
+  for (uint32_t e0 = lo; e0 < hi; e0 += UVOL_BLOCK) {
+    const uint32_t e = e0 + threadIdx.x;
+    if (e < hi) {
+      const uint4 r = part[e]; const uint32_t w[3] = { r.y, r.z, r.w };
+      uint32_t s = dd_slot(dd_hash(w, S.nw), slots);
+      for (uint32_t guard = 0;; guard++) {
+        if (guard >= slots) { fail = 1; break; }
+        uint32_t c = t_rec[s];
+        if (c == 0) { const uint32_t old = atomicCAS(&t_rec[s], 0u, e - lo + 1); if (old == 0) { atomicMin(&t_min[s], r.x); atomicAdd(&n_ins, 1u); break; } c = old; }
+        const uint4 o = part[lo + c - 1];
+        if (o.y == r.y && o.z == r.z && o.w == r.w) { atomicMin(&t_min[s], r.x); any_dup = 1; break; }
+        s = (s + 1) & (slots - 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (fail || n_ins > slots - slots / 4) { if (threadIdx.x == 0) J.status = GEO_E_DD_OVERFLOW; return; }
+  if (!any_dup) return;                                   // every value of the bin is unique: canon[] stays the identity
+  for (uint32_t e0 = lo; e0 < hi; e0 += UVOL_BLOCK) {
+    const uint32_t e = e0 + threadIdx.x;
+    if (e < hi) {
+      const uint4 r = part[e]; const uint32_t w[3] = { r.y, r.z, r.w };
+      uint32_t s = dd_slot(dd_hash(w, S.nw), slots);
+      for (uint32_t guard = 0; guard < slots; guard++) {
+        const uint32_t c = t_rec[s];
+        if (c == 0) break;
+        const uint4 o = part[lo + c - 1];
+        if (o.y == r.y && o.z == r.z && o.w == r.w) { if (t_min[s] != r.x) J.canon[which][r.x] = t_min[s]; break; }
+        s = (s + 1) & (slots - 1);
+      }
+    }
+  }
+}
+
 // three ints moved as one 12-byte access
 #ifdef HIPEMU
 struct uvol_s3 { int32_t x, y, z; };
@@ -129,7 +265,7 @@ typedef int32_t uvol_s3 __attribute__((ext_vector_type(3), aligned(4)));
 #endif
 // per input face: canonical ids, keep flag, index validation
 __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
-  JOB_OR_RETURN;
+  JOB_OR_RETURN_UNIFORM;
   uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   uint32_t keep = 0; bool bad = false;
   if (f < J.nf_in) {
@@ -584,7 +720,7 @@ __device__ inline int eb_events_of(const GeoJob &J, uint32_t i, int ev_spl[2], i
   return n;
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_flags(GeoJob *jobs) {
-  JOB_OR_RETURN;
+  JOB_OR_RETURN_UNIFORM;
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   uint32_t n = 0;
   if (i < J.nf) { int a[2], b[2]; n = i < (uint32_t)J.nsym ? (uint32_t)eb_events_of(J, i, a, b) : 0u; J.evcnt[i] = (uint8_t)n; }
@@ -743,7 +879,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_b(GeoJob *jobs) {
 
 // attribute seams (MeshAttributeCornerTable::InitFromAttribute) + seam-bit eligibility
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
-  JOB_OR_RETURN;
+  JOB_OR_RETURN_UNIFORM;
   const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
   int oc[GEO_ILP];
 #pragma unroll
@@ -930,17 +1066,20 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, i
 // waves (less branch serialisation per step), many walkers are packed up to 64 per wave.
 // Results are identical to the wave-per-walker kernels (same traversal, same output arrays).
 // ------------------------------------------------------------------------------------------------
+// `rec` is a typed global pointer (UVOL_G): global_load / global_store with exactly counted waits.  Through generic pointers
+// every access was a flat_* instruction followed by s_waitcnt vmcnt(0) lgkmcnt(0), i.e. each step also waited for its own
+// stores and for the neighbour prefetches it had just issued.
 #define S_REC(code, vi, rc, lc)                                                                                         \
   do {                                                                                                                  \
-    if (R8) { const uint2 q_ = *reinterpret_cast<const uint2 *>(rec + 2 * (size_t)(code)); rec8_dec(q_.x, q_.y, vi, rc, lc); } \
-    else { const int4 q_ = *reinterpret_cast<const int4 *>(rec + 4 * (size_t)(code)); vi = q_.x; rc = q_.y; lc = q_.z; }  \
+    if (R8) { const uvol_u2 q_ = *(UVOL_G(const uvol_u2))(rec + 2 * (size_t)(code)); rec8_dec(q_.x, q_.y, vi, rc, lc); }  \
+    else { const uvol_i4 q_ = *(UVOL_G(const uvol_i4))(rec + 4 * (size_t)(code)); vi = q_.x; rc = q_.y; lc = q_.z; }      \
   } while (0)
 #define S_FLAG(code) (rec[(R8 ? 2 : 4) * (size_t)((code) | 3)])
 // raw prefetch of a neighbour's record + its face flag (decoded only by the branch that moves there)
 #define S_PRE(code, a, b, c, fl)                                                                                        \
   do {                                                                                                                  \
-    if (R8) { const uint2 q_ = *reinterpret_cast<const uint2 *>(rec + 2 * (size_t)(code)); a = q_.x; b = q_.y; c = 0; }    \
-    else { const int4 q_ = *reinterpret_cast<const int4 *>(rec + 4 * (size_t)(code)); a = (uint32_t)q_.x; b = (uint32_t)q_.y; c = (uint32_t)q_.z; } \
+    if (R8) { const uvol_u2 q_ = *(UVOL_G(const uvol_u2))(rec + 2 * (size_t)(code)); a = q_.x; b = q_.y; c = 0; }          \
+    else { const uvol_i4 q_ = *(UVOL_G(const uvol_i4))(rec + 4 * (size_t)(code)); a = (uint32_t)q_.x; b = (uint32_t)q_.y; c = (uint32_t)q_.z; } \
     fl = S_FLAG(code);                                                                                                  \
   } while (0)
 #define S_TAKE(a, b, c, vi, rc, lc) do { if (R8) rec8_dec(a, b, vi, rc, lc); else { vi = (int)(a); rc = (int)(b); lc = (int)(c); } } while (0)
@@ -948,9 +1087,10 @@ __global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, i
 template <bool R8>
 __device__ inline void eb_walk_simt(GeoJob &J) {
   const int nf = (int)J.nf;
-  uint32_t *rec = reinterpret_cast<uint32_t *>(J.rec[0]);
-  uint32_t *vbits = reinterpret_cast<uint32_t *>(J.vvis);
-  int32_t *proc = J.proc, *stack = J.stack, *initc = J.initc; uint8_t *symb = J.symb, *start_bits = J.start_bits;
+  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[0]));
+  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis));
+  UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
+  UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   for (int f0 = 0; f0 < nf && nproc + ninit < nf; f0++) {
@@ -1033,9 +1173,9 @@ __global__ void __launch_bounds__(64) k_eb_walk_simt(GeoJob *jobs, int n, int W)
 template <bool R8>
 __device__ inline void traverse_simt(GeoJob &J, int t) {
   const int nf = (int)J.nf;
-  uint32_t *rec = reinterpret_cast<uint32_t *>(J.rec[1 + t]);
-  uint32_t *vbits = reinterpret_cast<uint32_t *>(J.t_vvis[t]);
-  int32_t *stack = J.t_stack[t], *order = J.order[t];
+  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
+  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
+  UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
   int n = 0, nvis = 0;
   for (int f = 0; f < nf && nvis < nf; f++) {
     if (S_FLAG(4 * f)) continue;
@@ -1593,11 +1733,18 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_rans_recip(GeoJob *jobs) {
   const uint2 rc = g_recip(p);
   S.tab[k] = make_uint4(p | (rc.y << 24), S.cum[k] + (p == 1 ? prec - 1 : 0), rc.x, 0u);
 }
+// 16-byte load through a typed global pointer (HIP's uint4 class cannot be read through an address-space-qualified pointer)
+#ifdef HIPEMU
+__device__ __forceinline__ uint4 g_ld4(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+#else
+typedef uint32_t uvol_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 g_ld4(UVOL_G(const void) p) { const uvol_u4 q = *(UVOL_G(const uvol_u4))p; return make_uint4(q.x, q.y, q.z, q.w); }
+#endif
 struct SByteOut {
-  uint8_t *p; uint32_t w, cap, acc;
+  UVOL_G(uint8_t) p; uint32_t w, cap, acc;                  // typed global pointer: global_store, not flat_store (see the walkers)
   __device__ __forceinline__ void put(uint32_t b) {
     acc |= (b & 255u) << (8 * (w & 3u)); w++;
-    if ((w & 3u) == 0) { if (w <= cap) *reinterpret_cast<uint32_t *>(p + w - 4) = acc; acc = 0; }
+    if ((w & 3u) == 0) { if (w <= cap) *(UVOL_G(uint32_t))(p + w - 4) = acc; acc = 0; }
   }
   __device__ __forceinline__ void flush() { if (w <= cap) for (uint32_t k = w & ~3u; k < w; k++) p[k] = (uint8_t)(acc >> (8 * (k & 3u))); }
 };
@@ -1605,8 +1752,10 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
   const uint32_t n = S.n;
   if (!n) return;
   const uint32_t prec = 1u << S.prec_bits, L = prec * 4;
-  const uint32_t *syms = S.syms; const uint4 *tab = S.tab;
-  SByteOut O; O.p = S.pay + 8; O.w = 0; O.cap = S.pay_cap - 80; O.acc = 0;
+  UVOL_G(const uint32_t) syms = UVOL_TO_G(const uint32_t, S.syms); UVOL_G(const uint4) tab = UVOL_TO_G(const uint4, S.tab);
+#define TAB(i) g_ld4(tab + (i))
+#define SV(i) g_ld4(sv + (i))
+  SByteOut O; O.p = UVOL_TO_G(uint8_t, S.pay + 8); O.w = 0; O.cap = S.pay_cap - 80; O.acc = 0;
   uint32_t st = L;
 #define SR_STEP(E)                                                                     \
   { const uint32_t p_ = (E).x & 0xffffffu, lim_ = p_ << 10;                             \
@@ -1614,29 +1763,37 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
     const uint32_t q_ = (uint32_t)(((unsigned long long)st * (E).z) >> 32) >> ((E).x >> 24); \
     st = st + (E).y + q_ * (prec - p_); }
   uint32_t hi = n;
-  while (hi & 3u) { hi--; const uint4 e = tab[syms[hi]]; SR_STEP(e); }          // the tail: the groups below are 16-byte aligned
+  while (hi & 7u) { hi--; const uint4 e = TAB(syms[hi]); SR_STEP(e); }          // the tail: the groups below are 32-byte aligned
   if (hi) {
-    // two-deep software pipeline over groups of four symbols: while group g is coded, the table entries of group g + 1 are in
+    // software pipeline over groups of eight symbols: while group g is coded, the eight table entries of group g + 1 are in
     // flight (their symbols arrived an iteration earlier) and the symbols of group g + 2 are being fetched - a lane never issues
-    // a load whose address it has to wait for
-    uint4 sy1 = *reinterpret_cast<const uint4 *>(syms + hi - 4);                             // symbols of the current group
-    uint4 sy2 = hi >= 8 ? *reinterpret_cast<const uint4 *>(syms + hi - 8) : sy1;             // ... of the next one
-    uint4 e0 = tab[sy1.w], e1 = tab[sy1.z], e2 = tab[sy1.y], e3 = tab[sy1.x];
+    // a load whose address it has to wait for, and an entry has ~8 symbol steps (> an L2 round trip) to arrive
+    UVOL_G(const uint4) sv = (UVOL_G(const uint4))syms;
+    uint4 s1a = SV(hi / 4 - 1), s1b = SV(hi / 4 - 2);                                        // symbols of the current group (high half first)
+    uint4 s2a = s1a, s2b = s1b;
+    if (hi >= 16) { s2a = SV(hi / 4 - 3); s2b = SV(hi / 4 - 4); }                            // ... of the next one
+    uint4 e[8];
+    e[0] = TAB(s1a.w); e[1] = TAB(s1a.z); e[2] = TAB(s1a.y); e[3] = TAB(s1a.x); e[4] = TAB(s1b.w); e[5] = TAB(s1b.z); e[6] = TAB(s1b.y); e[7] = TAB(s1b.x);
     while (hi) {
-      hi -= 4;
-      const uint4 c0 = e0, c1 = e1, c2 = e2, c3 = e3;
+      hi -= 8;
+      uint4 c[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = e[k];
       if (hi) {
-        e0 = tab[sy2.w]; e1 = tab[sy2.z]; e2 = tab[sy2.y]; e3 = tab[sy2.x];
-        if (hi >= 8) sy2 = *reinterpret_cast<const uint4 *>(syms + hi - 8);
+        e[0] = TAB(s2a.w); e[1] = TAB(s2a.z); e[2] = TAB(s2a.y); e[3] = TAB(s2a.x); e[4] = TAB(s2b.w); e[5] = TAB(s2b.z); e[6] = TAB(s2b.y); e[7] = TAB(s2b.x);
+        if (hi >= 16) { s2a = SV(hi / 4 - 3); s2b = SV(hi / 4 - 4); }
       }
-      SR_STEP(c0); SR_STEP(c1); SR_STEP(c2); SR_STEP(c3);
+#pragma unroll
+      for (int k = 0; k < 8; k++) SR_STEP(c[k]);
     }
   }
+#undef TAB
+#undef SV
 #undef SR_STEP
   uint32_t w = O.w;
   if (w + 4 > O.cap) { J.status = -32; return; }
   O.flush();
-  uint8_t *pay = O.p;
+  uint8_t *pay = S.pay + 8;
   st -= L;
   if (st < (1u << 6)) pay[w++] = (uint8_t)st;
   else if (st < (1u << 14)) { const uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
@@ -1651,23 +1808,40 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
   const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
   uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
   const uint32_t p = 256 - p0;
-  SByteOut O; O.p = B.buf + 8; O.w = 0; O.cap = B.cap - 80; O.acc = 0;
+  SByteOut O; O.p = UVOL_TO_G(uint8_t, B.buf + 8); O.w = 0; O.cap = B.cap - 80; O.acc = 0;
   uint32_t st = 4096;
   const uint2 r1 = g_recip(p), r0 = g_recip(p0);
   const uint32_t a1 = (p == 1 ? 255u : 0u), a0 = p + (p0 == 1 ? 255u : 0u);
   const uint32_t lim1 = 4096u * p, lim0 = 4096u * p0, mu1 = 256u - p, mu0 = 256u - p0;
-  const uint8_t *bits = B.bits;
-  for (uint32_t i = n; i-- > 0;) {
-    const bool one = bits[i] != 0;
-    const uint32_t lim = one ? lim1 : lim0, m = one ? r1.x : r0.x, sh = one ? r1.y : r0.y, add = one ? a1 : a0, mul = one ? mu1 : mu0;
-    if (st >= lim) { O.put(st); st >>= 8; }
-    const uint32_t q = (uint32_t)(((unsigned long long)st * m) >> 32) >> sh;
-    st = st + add + q * mul;
+  UVOL_G(const uint8_t) bits = UVOL_TO_G(const uint8_t, B.bits);
+#define SB_STEP(BYTE)                                                                  \
+  { const bool one = (BYTE) != 0;                                                       \
+    const uint32_t lim = one ? lim1 : lim0, m = one ? r1.x : r0.x, sh = one ? r1.y : r0.y, add = one ? a1 : a0, mul = one ? mu1 : mu0; \
+    if (st >= lim) { O.put(st); st >>= 8; }                                             \
+    const uint32_t q = (uint32_t)(((unsigned long long)st * m) >> 32) >> sh;            \
+    st = st + add + q * mul; }
+  // The flags are fetched 16 at a time, one chunk ahead: a byte load per step sits behind the coder's own stores (the compiler
+  // cannot prove that they do not alias), i.e. one L2 round trip per bit - that, not the arithmetic, set the kernel's time.
+  uint32_t i = n;
+  while (i & 15u) { i--; SB_STEP(bits[i]); }
+  if (i) {
+    UVOL_G(const uint4) bv = (UVOL_G(const uint4))bits;
+    uint4 cur = g_ld4(bv + (i / 16 - 1)), nxt = cur;
+    if (i >= 32) nxt = g_ld4(bv + (i / 16 - 2));
+    while (i) {
+      i -= 16;
+      const uint4 c = cur; cur = nxt;
+      if (i >= 32) nxt = g_ld4(bv + (i / 16 - 2));
+      const uint32_t wv[4] = { c.w, c.z, c.y, c.x };
+#pragma unroll
+      for (int k = 0; k < 4; k++) { SB_STEP(wv[k] >> 24); SB_STEP((wv[k] >> 16) & 255u); SB_STEP((wv[k] >> 8) & 255u); SB_STEP(wv[k] & 255u); }
+    }
   }
+#undef SB_STEP
   uint32_t w = O.w;
   if (w + 3 > O.cap) { J.status = -33; return; }
   O.flush();
-  uint8_t *pay = O.p;
+  uint8_t *pay = B.buf + 8;
   st -= 4096;
   if (st < (1u << 6)) pay[w++] = (uint8_t)st;
   else if (st < (1u << 14)) { const uint32_t v = (1u << 14) + st; pay[w++] = v & 255; pay[w++] = (v >> 8) & 255; }
@@ -1871,11 +2045,15 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   J.ecap = (uint32_t)ecap;
   auto bitlen = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };
 #define CARVE(field, T, count, first, last) items.push_back(WsItem{(size_t)((char *)&(field) - (char *)&J), (size_t)(count) * sizeof(T), (first), (last), 0})
-  // dedup hash tables: live in the first phase only, zeroed group by group right before use (k_dd_clear, geo_dedup_groups)
+  // dedup scratch, live in the first phase only.  Compact layout: the partitioned form (records by hash bin + the counts
+  // matrix); worst-case layout (retries): the hash tables, zeroed right before use (k_dd_clear)
   for (int k = 0; k < 3; k++) {
     const uint32_t n = k == 0 ? J.n_pos : (k == 1 ? J.n_uv : J.n_nrm);
     J.dd_cap[k] = pow2_at_least(2ull * n + 2);
-    CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k], PH_DEDUP, PH_DEDUP);
+    J.dd_nblk[k] = (uint32_t)((n + DD_TILE - 1) / DD_TILE);
+    J.dd_nb[k] = (uint32_t)std::min<uint64_t>(DD_MAXBINS, pow2_at_least(std::max<uint64_t>(1, n / 1024)));
+    if (full) { CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k], PH_DEDUP, PH_DEDUP); }
+    else { CARVE(J.dd_part[k], uint4, (size_t)n + 1, PH_DEDUP, PH_DEDUP); CARVE(J.dd_cnt[k], uint32_t, (size_t)J.dd_nb[k] * J.dd_nblk[k] + 2, PH_DEDUP, PH_DEDUP); }
   }
   // ---- pinned, zero-initialised ----
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
@@ -2184,21 +2362,22 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
                  be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
-    // UVOL_DD_GROUP=<frames> (diagnostic) clears and de-duplicates the batch in groups of that many frames so that a group's hash
-    // tables could stay in the memory-side cache between the clear and the probes; measured: no difference for 8 / 32 / 128 /
-    // all frames per group (device atomics are performed memory-side either way), so the default is one group.
-    static const unsigned dd_env = [] { const char *e = getenv("UVOL_DD_GROUP"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? v : 0); }();
-    const unsigned dd_group = dd_env ? dd_env : N;
-    for (unsigned y0 = 0; y0 < N; y0 += dd_group) {
-      const unsigned Ng = std::min(dd_group, N - y0);
-      GeoJob *gj = dj + y0;
-      LAUNCH(k_dd_clear, dim3(16, Ng, 3), dim3(UVOL_BLOCK), gj);
-      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 0, 0);
-      LAUNCH(k_dedup<2>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 1, 0);
-      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 2, 0);
-      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 0, 1);
-      LAUNCH(k_dedup<2>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 1, 1);
-      LAUNCH(k_dedup<3>, dim3(bv, Ng), dim3(UVOL_BLOCK), gj, 2, 1);
+    if (!full) {
+      // UVOL_DD_SLOTS=<power of two <= 4096> (tests): LDS slots per bin; a small table forces GEO_E_DD_OVERFLOW and the retry
+      uint32_t slots = DD_SLOTS; { const char *e = getenv("UVOL_DD_SLOTS"); const int v = e ? atoi(e) : 0; if (v >= 4 && v <= DD_SLOTS && !(v & (v - 1))) slots = (uint32_t)v; }
+      const unsigned bt = (unsigned)((max_vals + DD_TILE - 1) / DD_TILE), nbm = (unsigned)std::min<uint64_t>(DD_MAXBINS, pow2_at_least(std::max<uint64_t>(1, max_vals / 1024)));
+      LAUNCH(k_dd_count, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dd_scan, dim3(1, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dd_scatter, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dd_resolve, dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
+    } else {
+      LAUNCH(k_dd_clear, dim3(16, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, 0);
+      LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, 0);
+      LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 0);
+      LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, 1);
+      LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, 1);
+      LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 1);
     }
     LAUNCH(k_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_KEEP);
@@ -2326,7 +2505,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
     out_lens[i] = J.out_len;
     if (st == UVOL_OK) { }
-    else if (!full && (J.status == GEO_E_WS_OVERFLOW || J.status == GEO_E_SLAB_FULL)) { retry.push_back(i); st = UVOL_OK; }
+    else if (!full && (J.status == GEO_E_WS_OVERFLOW || J.status == GEO_E_SLAB_FULL || J.status == GEO_E_DD_OVERFLOW)) { retry.push_back(i); st = UVOL_OK; }
     else { ctx->set_error("mesh %d: encode failed (device status %d)", i, J.status); worst = st; }
     if (status) status[i] = st;
   }
