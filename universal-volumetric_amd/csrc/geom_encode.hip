@@ -881,15 +881,24 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_b(GeoJob *jobs) {
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
   JOB_OR_RETURN_UNIFORM;
   const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int oc[GEO_ILP];
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; oc[k] = c < nc ? J.nopp[c] : -1; }
+  // eligibility flags + their per-256-corner sums for k_seam_bits (one barrier: per-wave ballots, then GEO_ILP threads add them)
+  __shared__ uint32_t wcnt[GEO_ILP][UVOL_BLOCK / 64];
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) {
-    const uint32_t c = c0 + k * UVOL_BLOCK; const uint32_t e = (c < nc && oc[k] >= 0 && (uint32_t)oc[k] / 3 > c / 3) ? 1u : 0u;
-    if (c < nc) J.elig[c] = (uint8_t)e;
-    const uint32_t tot = block_sum(e), b = blockIdx.x * GEO_ILP + k;     // block sums of the eligibility flags for k_seam_bits
-    if (threadIdx.x == 0 && b < uvol_blocks_dev(nc)) J.bsum[b] = tot;
+    const uint32_t c = c0 + k * UVOL_BLOCK; const bool e = c < nc && oc[k] >= 0 && (uint32_t)oc[k] / 3 > c / 3;
+    if (c < nc) J.elig[c] = e ? 1 : 0;
+    const unsigned long long m = __ballot(e);
+    if (lane == 0) wcnt[k][wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < GEO_ILP) {
+    uint32_t tot = 0; for (int w = 0; w < UVOL_BLOCK / 64; w++) tot += wcnt[threadIdx.x][w];
+    const uint32_t b = blockIdx.x * GEO_ILP + threadIdx.x;
+    if (b < uvol_blocks_dev(nc)) J.bsum[b] = tot;
   }
   for (int i = 0; i < J.nad; i++) {
     const int32_t *ids = J.att_kind[i] == 0 ? J.nuid : J.nnid;
@@ -899,18 +908,25 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
       const uint32_t c = c0 + k * UVOL_BLOCK; const bool in = c < nc && oc[k] >= 0; const int cc = in ? (int)c : 0, oo = in ? oc[k] : 0;
       a0[k] = ids[g_nxt(cc)]; a1[k] = ids[g_prv(cc)]; b0[k] = ids[g_prv(oo)]; b1[k] = ids[g_nxt(oo)];
     }
+    bool any = false;
 #pragma unroll
     for (int k = 0; k < GEO_ILP; k++) {
       const uint32_t c = c0 + k * UVOL_BLOCK;
       if (c >= nc) continue;
-      uint8_t s = 1;
+      uint8_t sm = 1;
       if (oc[k] >= 0) {
-        s = (a0[k] != b0[k] || a1[k] != b1[k]) ? 1 : 0;
-        if (s) { J.interior_seams[i] = 1; const uint32_t va = (uint32_t)J.bvert[g_nxt(c)], vb = (uint32_t)J.bvert[g_prv(c)];      // both ends of the edge get split
-          atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31)); }
+        sm = (a0[k] != b0[k] || a1[k] != b1[k]) ? 1 : 0;
+        if (sm) {                                                        // both ends of the edge get split
+          any = true;
+          const uint32_t va = (uint32_t)J.bvert[g_nxt(c)], vb = (uint32_t)J.bvert[g_prv(c)];
+          // a vertex on a seam is reached from ~4 corners: test the bit (a stale 0 only costs a redundant atomic) before setting it
+          if (!((J.vseam[i][va >> 5] >> (va & 31)) & 1u)) atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31));
+          if (!((J.vseam[i][vb >> 5] >> (vb & 31)) & 1u)) atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31));
+        }
       }
-      J.seam[i][c] = s;
+      J.seam[i][c] = sm;
     }
+    if (any) J.interior_seams[i] = 1;
   }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
@@ -1731,7 +1747,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_rans_recip(GeoJob *jobs) {
   if (k >= ns) return;
   const uint32_t p = S.probs[k], prec = 1u << S.prec_bits;
   const uint2 rc = g_recip(p);
-  S.tab[k] = make_uint4(p | (rc.y << 24), S.cum[k] + (p == 1 ? prec - 1 : 0), rc.x, 0u);
+  S.tab[k] = make_uint4(p | (rc.y << 24), S.cum[k] + (p == 1 ? prec - 1 : 0), rc.x, prec - p);
 }
 // 16-byte load through a typed global pointer (HIP's uint4 class cannot be read through an address-space-qualified pointer)
 #ifdef HIPEMU
@@ -1741,12 +1757,16 @@ typedef uint32_t uvol_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 g_ld4(UVOL_G(const void) p) { const uvol_u4 q = *(UVOL_G(const uvol_u4))p; return make_uint4(q.x, q.y, q.z, q.w); }
 #endif
 struct SByteOut {
-  UVOL_G(uint8_t) p; uint32_t w, cap, acc;                  // typed global pointer: global_store, not flat_store (see the walkers)
-  __device__ __forceinline__ void put(uint32_t b) {
-    acc |= (b & 255u) << (8 * (w & 3u)); w++;
-    if ((w & 3u) == 0) { if (w <= cap) *(UVOL_G(uint32_t))(p + w - 4) = acc; acc = 0; }
+  UVOL_G(uint8_t) p; uint32_t w, cap, fill; unsigned long long acc;       // typed global pointer: global_store, not flat_store (see the walkers)
+  // append the low k (0..3) bytes of v, least significant first; `w` counts the bytes already stored, `fill` those still in `acc`
+  __device__ __forceinline__ void put_n(uint32_t v, uint32_t k) {
+    const uint32_t m = k == 0 ? 0u : (0xffffffffu >> (32 - 8 * k));
+    acc |= (unsigned long long)(v & m) << (8 * fill);
+    fill += k;
+    if (fill >= 4) { if (w + 4 <= cap) *(UVOL_G(uint32_t))(p + w) = (uint32_t)acc; w += 4; acc >>= 32; fill -= 4; }
   }
-  __device__ __forceinline__ void flush() { if (w <= cap) for (uint32_t k = w & ~3u; k < w; k++) p[k] = (uint8_t)(acc >> (8 * (k & 3u))); }
+  __device__ __forceinline__ uint32_t bytes() const { return w + fill; }
+  __device__ __forceinline__ void flush() { if (w + fill <= cap) for (uint32_t k = 0; k < fill; k++) p[w + k] = (uint8_t)(acc >> (8 * k)); }
 };
 __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
   const uint32_t n = S.n;
@@ -1755,13 +1775,19 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
   UVOL_G(const uint32_t) syms = UVOL_TO_G(const uint32_t, S.syms); UVOL_G(const uint4) tab = UVOL_TO_G(const uint4, S.tab);
 #define TAB(i) g_ld4(tab + (i))
 #define SV(i) g_ld4(sv + (i))
-  SByteOut O; O.p = UVOL_TO_G(uint8_t, S.pay + 8); O.w = 0; O.cap = S.pay_cap - 80; O.acc = 0;
+  SByteOut O; O.p = UVOL_TO_G(uint8_t, S.pay + 8); O.w = 0; O.cap = S.pay_cap - 80; O.acc = 0; O.fill = 0;
   uint32_t st = L;
+// one symbol: renormalise (at most three bytes leave: the state is below 2^(prec_bits + 10) <= 2^30, the limit at least 2^10) without
+// a loop - the number of bytes is three compares, the bytes are the low bytes of the state -, then the exact-reciprocal update
 #define SR_STEP(E)                                                                     \
   { const uint32_t p_ = (E).x & 0xffffffu, lim_ = p_ << 10;                             \
-    while (st >= lim_) { O.put(st); st >>= 8; }                                         \
-    const uint32_t q_ = (uint32_t)(((unsigned long long)st * (E).z) >> 32) >> ((E).x >> 24); \
-    st = st + (E).y + q_ * (prec - p_); }
+    uint32_t s_ = st;                                                                   \
+    const bool c1_ = s_ >= lim_; s_ = c1_ ? s_ >> 8 : s_;                               \
+    const bool c2_ = s_ >= lim_; s_ = c2_ ? s_ >> 8 : s_;                               \
+    const bool c3_ = s_ >= lim_; s_ = c3_ ? s_ >> 8 : s_;                               \
+    O.put_n(st, (uint32_t)c1_ + (uint32_t)c2_ + (uint32_t)c3_);                         \
+    const uint32_t q_ = __umulhi(s_, (E).z) >> ((E).x >> 24);                           \
+    st = s_ + (E).y + q_ * (E).w; }
   uint32_t hi = n;
   while (hi & 7u) { hi--; const uint4 e = TAB(syms[hi]); SR_STEP(e); }          // the tail: the groups below are 32-byte aligned
   if (hi) {
@@ -1790,7 +1816,7 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
 #undef TAB
 #undef SV
 #undef SR_STEP
-  uint32_t w = O.w;
+  uint32_t w = O.bytes();
   if (w + 4 > O.cap) { J.status = -32; return; }
   O.flush();
   uint8_t *pay = S.pay + 8;
@@ -1808,7 +1834,7 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
   const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
   uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
   const uint32_t p = 256 - p0;
-  SByteOut O; O.p = UVOL_TO_G(uint8_t, B.buf + 8); O.w = 0; O.cap = B.cap - 80; O.acc = 0;
+  SByteOut O; O.p = UVOL_TO_G(uint8_t, B.buf + 8); O.w = 0; O.cap = B.cap - 80; O.acc = 0; O.fill = 0;
   uint32_t st = 4096;
   const uint2 r1 = g_recip(p), r0 = g_recip(p0);
   const uint32_t a1 = (p == 1 ? 255u : 0u), a0 = p + (p0 == 1 ? 255u : 0u);
@@ -1817,8 +1843,8 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
 #define SB_STEP(BYTE)                                                                  \
   { const bool one = (BYTE) != 0;                                                       \
     const uint32_t lim = one ? lim1 : lim0, m = one ? r1.x : r0.x, sh = one ? r1.y : r0.y, add = one ? a1 : a0, mul = one ? mu1 : mu0; \
-    if (st >= lim) { O.put(st); st >>= 8; }                                             \
-    const uint32_t q = (uint32_t)(((unsigned long long)st * m) >> 32) >> sh;            \
+    { const bool c_ = st >= lim; O.put_n(st, c_ ? 1u : 0u); st = c_ ? st >> 8 : st; }   \
+    const uint32_t q = __umulhi(st, m) >> sh;                                           \
     st = st + add + q * mul; }
   // The flags are fetched 16 at a time, one chunk ahead: a byte load per step sits behind the coder's own stores (the compiler
   // cannot prove that they do not alias), i.e. one L2 round trip per bit - that, not the arithmetic, set the kernel's time.
@@ -1838,7 +1864,7 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
     }
   }
 #undef SB_STEP
-  uint32_t w = O.w;
+  uint32_t w = O.bytes();
   if (w + 3 > O.cap) { J.status = -33; return; }
   O.flush();
   uint8_t *pay = B.buf + 8;
