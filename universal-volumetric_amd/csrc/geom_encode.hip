@@ -1756,26 +1756,38 @@ __device__ __forceinline__ uint4 g_ld4(const void *p) { return *reinterpret_cast
 typedef uint32_t uvol_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 g_ld4(UVOL_G(const void) p) { const uvol_u4 q = *(UVOL_G(const uvol_u4))p; return make_uint4(q.x, q.y, q.z, q.w); }
 #endif
+// Output of a lane coder.  On gfx950 loads and stores share vmcnt and the compiler has to wait for BOTH kinds (vmcnt(0)) whenever a
+// store is outstanding next to a load it needs, so a loop that stores a few bytes per step and reads its next table entries drains
+// its stores every iteration: ~2 us per group of 8 symbols, 240 ns per symbol, against ~50 ns of arithmetic (measured stream by
+// stream).  The bytes are therefore staged in LDS (lgkmcnt, a different counter) and written out SB_FLUSH dwords at a time.
+#define SB_STRIDE 65                       // dwords of LDS per lane (odd: lanes staging the same slot hit different banks)
+#define SB_FLUSH 48                        // staged dwords that trigger a write-out at the next group boundary (a group adds <= 7)
 struct SByteOut {
-  UVOL_G(uint8_t) p; uint32_t w, cap, fill; unsigned long long acc;       // typed global pointer: global_store, not flat_store (see the walkers)
-  // append the low k (0..3) bytes of v, least significant first; `w` counts the bytes already stored, `fill` those still in `acc`
+  UVOL_G(uint8_t) p; UVOL_L(uint32_t) stg; uint32_t w, cap, fill, nst; unsigned long long acc;
+  __device__ __forceinline__ void init(uint8_t *dst, uint32_t cap_, uint32_t *lds_lane) { p = UVOL_TO_G(uint8_t, dst); stg = UVOL_TO_L(uint32_t, lds_lane); w = 0; cap = cap_; fill = 0; nst = 0; acc = 0; }
+  // append the low k (0..3) bytes of v, least significant first
   __device__ __forceinline__ void put_n(uint32_t v, uint32_t k) {
     const uint32_t m = k == 0 ? 0u : (0xffffffffu >> (32 - 8 * k));
     acc |= (unsigned long long)(v & m) << (8 * fill);
     fill += k;
-    if (fill >= 4) { if (w + 4 <= cap) *(UVOL_G(uint32_t))(p + w) = (uint32_t)acc; w += 4; acc >>= 32; fill -= 4; }
+    if (fill >= 4) { stg[nst] = (uint32_t)acc; nst++; acc >>= 32; fill -= 4; }
   }
-  __device__ __forceinline__ uint32_t bytes() const { return w + fill; }
-  __device__ __forceinline__ void flush() { if (w + fill <= cap) for (uint32_t k = 0; k < fill; k++) p[w + k] = (uint8_t)(acc >> (8 * k)); }
+  __device__ __forceinline__ void write_out() {                        // staged dwords -> global memory; `w` = bytes written so far
+    if (w + 4 * nst <= cap) for (uint32_t j = 0; j < nst; j++) *(UVOL_G(uint32_t))(p + w + 4 * j) = stg[j];
+    w += 4 * nst; nst = 0;
+  }
+  __device__ __forceinline__ void group_end() { if (nst >= SB_FLUSH) write_out(); }
+  __device__ __forceinline__ uint32_t bytes() const { return w + 4 * nst + fill; }
+  __device__ __forceinline__ void flush() { write_out(); if (w + fill <= cap) for (uint32_t k = 0; k < fill; k++) p[w + k] = (uint8_t)(acc >> (8 * k)); }
 };
-__device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
+__device__ inline void rans_encode_lane(GeoJob &J, RansStream &S, uint32_t *lds_lane) {
   const uint32_t n = S.n;
   if (!n) return;
   const uint32_t prec = 1u << S.prec_bits, L = prec * 4;
   UVOL_G(const uint32_t) syms = UVOL_TO_G(const uint32_t, S.syms); UVOL_G(const uint4) tab = UVOL_TO_G(const uint4, S.tab);
 #define TAB(i) g_ld4(tab + (i))
 #define SV(i) g_ld4(sv + (i))
-  SByteOut O; O.p = UVOL_TO_G(uint8_t, S.pay + 8); O.w = 0; O.cap = S.pay_cap - 80; O.acc = 0; O.fill = 0;
+  SByteOut O; O.init(S.pay + 8, S.pay_cap - 80, lds_lane);
   uint32_t st = L;
 // one symbol: renormalise (at most three bytes leave: the state is below 2^(prec_bits + 10) <= 2^30, the limit at least 2^10) without
 // a loop - the number of bytes is three compares, the bytes are the low bytes of the state -, then the exact-reciprocal update
@@ -1789,7 +1801,7 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
     const uint32_t q_ = __umulhi(s_, (E).z) >> ((E).x >> 24);                           \
     st = s_ + (E).y + q_ * (E).w; }
   uint32_t hi = n;
-  while (hi & 7u) { hi--; const uint4 e = TAB(syms[hi]); SR_STEP(e); }          // the tail: the groups below are 32-byte aligned
+  while (hi & 7u) { hi--; const uint4 e = TAB(syms[hi]); SR_STEP(e); O.group_end(); }          // the tail: the groups below are 32-byte aligned
   if (hi) {
     // software pipeline over groups of eight symbols: while group g is coded, the eight table entries of group g + 1 are in
     // flight (their symbols arrived an iteration earlier) and the symbols of group g + 2 are being fetched - a lane never issues
@@ -1811,6 +1823,7 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
       }
 #pragma unroll
       for (int k = 0; k < 8; k++) SR_STEP(c[k]);
+      O.group_end();
     }
   }
 #undef TAB
@@ -1829,12 +1842,12 @@ __device__ inline void rans_encode_lane(GeoJob &J, RansStream &S) {
   g_put_varint(S.pay + 8 - vl, w);
   S.pay_off = 8 - vl; S.pay_len = vl + w;
 }
-__device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
+__device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B, uint32_t *lds_lane) {
   const uint32_t n = B.n; const uint64_t total = n ? n : 1;
   const uint32_t p0raw = (uint32_t)(((double)B.zeros / (double)total) * 256.0 + 0.5);
   uint32_t p0 = p0raw < 255 ? p0raw : 255; if (p0 == 0) p0 = 1;
   const uint32_t p = 256 - p0;
-  SByteOut O; O.p = UVOL_TO_G(uint8_t, B.buf + 8); O.w = 0; O.cap = B.cap - 80; O.acc = 0; O.fill = 0;
+  SByteOut O; O.init(B.buf + 8, B.cap - 80, lds_lane);
   uint32_t st = 4096;
   const uint2 r1 = g_recip(p), r0 = g_recip(p0);
   const uint32_t a1 = (p == 1 ? 255u : 0u), a0 = p + (p0 == 1 ? 255u : 0u);
@@ -1849,7 +1862,7 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
   // The flags are fetched 16 at a time, one chunk ahead: a byte load per step sits behind the coder's own stores (the compiler
   // cannot prove that they do not alias), i.e. one L2 round trip per bit - that, not the arithmetic, set the kernel's time.
   uint32_t i = n;
-  while (i & 15u) { i--; SB_STEP(bits[i]); }
+  while (i & 15u) { i--; SB_STEP(bits[i]); O.group_end(); }
   if (i) {
     UVOL_G(const uint4) bv = (UVOL_G(const uint4))bits;
     uint4 cur = g_ld4(bv + (i / 16 - 1)), nxt = cur;
@@ -1861,6 +1874,7 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
       const uint32_t wv[4] = { c.w, c.z, c.y, c.x };
 #pragma unroll
       for (int k = 0; k < 4; k++) { SB_STEP(wv[k] >> 24); SB_STEP((wv[k] >> 16) & 255u); SB_STEP((wv[k] >> 8) & 255u); SB_STEP(wv[k] & 255u); }
+      O.group_end();
     }
   }
 #undef SB_STEP
@@ -1879,6 +1893,7 @@ __device__ inline void rabs_encode_lane(GeoJob &J, RabsStream &B) {
 }
 // grid (frame blocks, stream); lanes of a wave = the same stream of W consecutive frames
 __global__ void __launch_bounds__(64) k_entropy_simt(GeoJob *jobs, int n, int W) {
+  UVOL_DYN_SMEM(uint32_t, lds);                                         // SB_STRIDE dwords per lane: the coders' output staging
   const int lane = (int)threadIdx.x;
   if (lane >= W) return;
   const int j = (int)blockIdx.x * W + lane;
@@ -1886,7 +1901,7 @@ __global__ void __launch_bounds__(64) k_entropy_simt(GeoJob *jobs, int n, int W)
   GeoJob &J = jobs[j];
   if (J.status != 0) return;
   const int t = (int)blockIdx.y;
-  if (t < GEO_NSTREAM) rans_encode_lane(J, J.rs[t]); else rabs_encode_lane(J, J.rb[t - GEO_NSTREAM]);
+  if (t < GEO_NSTREAM) rans_encode_lane(J, J.rs[t], lds + lane * SB_STRIDE); else rabs_encode_lane(J, J.rb[t - GEO_NSTREAM], lds + lane * SB_STRIDE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2488,9 +2503,13 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     if (ent_wave) LAUNCH(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), dj, uvol_debug() ? 1 : 0);
     else {
       static const int ent_w_env = [] { const char *e = getenv("UVOL_ENTROPY_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
-      const unsigned W = ent_w_env ? (unsigned)ent_w_env : std::min(64u, std::max(1u, (14u * N + 4095u) / 4096u));      // ~4096 waves per launch
+      // lanes per wave: five streams of a frame are long (three attribute symbol streams, two seam-bit streams; ~300 k steps) and a
+      // wave runs as long as its longest lane, so the launch should put at most ONE long wave on a SIMD (1024 of them): waves that
+      // share a SIMD share its issue slots (2160 frames: 172 / 105 / 60 / 64 / 55 / 52 ms with 1 / 2 / 4 / 8 / 16 / 32 lanes per wave)
+      unsigned W = 4; while (W < 64 && 5u * N > 512u * W) W *= 2;
+      if (ent_w_env) W = (unsigned)ent_w_env;
       LAUNCH(k_rans_recip, dim3(uvol_blocks(((size_t)2 << std::max(prm.q_position_attr, std::max(prm.q_texture_attr, prm.q_normal_attr))) + 8), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_entropy_simt, dim3((N + W - 1) / W, GEO_NSTREAM + GEO_NRABS), dim3(64), dj, n, (int)W);
+      LAUNCH_SM(k_entropy_simt, dim3((N + W - 1) / W, GEO_NSTREAM + GEO_NRABS), dim3(64), (size_t)W * SB_STRIDE * 4, dj, n, (int)W);
     }
   }
   {
