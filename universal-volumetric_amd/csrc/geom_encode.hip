@@ -366,13 +366,23 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_edge_match(GeoJob *jobs) {
   for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK, cc = c < nc ? c : 0u; a[k] = (uint32_t)J.cp[g_nxt(cc)]; b[k] = (uint32_t)J.cp[g_prv(cc)]; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) { sa[k] = J.he_start[a[k]]; ea[k] = J.he_cur[a[k]]; sb[k] = J.he_start[b[k]]; eb[k] = J.he_cur[b[k]]; }
+  // the first HE_UNR entries of both buckets are fetched at once (a vertex has ~6 outgoing edges); a loop reads the rest
+  enum { HE_UNR = 8 };
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) {
     const uint32_t c = c0 + k * UVOL_BLOCK;
     if (c >= nc) continue;
+    unsigned long long ua[HE_UNR], ub[HE_UNR];
+#pragma unroll
+    for (int j = 0; j < HE_UNR; j++) { ua[j] = J.he_ent[sa[k] + j < ea[k] ? sa[k] + j : sa[k]]; ub[j] = J.he_ent[sb[k] + j < eb[k] ? sb[k] + j : sb[k]]; }
     uint32_t self = 0xffffffffu, o = 0xffffffffu;
-    for (uint32_t i = sa[k]; i < ea[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == b[k]) { const uint32_t cc = (uint32_t)v; self = cc < self ? cc : self; } }
-    for (uint32_t i = sb[k]; i < eb[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == a[k]) { const uint32_t cc = (uint32_t)v; o = cc < o ? cc : o; } }
+#pragma unroll
+    for (int j = 0; j < HE_UNR; j++) {
+      if (sa[k] + j < ea[k] && (uint32_t)(ua[j] >> 32) == b[k]) { const uint32_t cc = (uint32_t)ua[j]; self = cc < self ? cc : self; }
+      if (sb[k] + j < eb[k] && (uint32_t)(ub[j] >> 32) == a[k]) { const uint32_t cc = (uint32_t)ub[j]; o = cc < o ? cc : o; }
+    }
+    for (uint32_t i = sa[k] + HE_UNR; i < ea[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == b[k]) { const uint32_t cc = (uint32_t)v; self = cc < self ? cc : self; } }
+    for (uint32_t i = sb[k] + HE_UNR; i < eb[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == a[k]) { const uint32_t cc = (uint32_t)v; o = cc < o ? cc : o; } }
     J.opp[c] = (self == c && o != 0xffffffffu) ? (int)o : GEO_INV;
   }
 }
@@ -908,6 +918,14 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
       const uint32_t c = c0 + k * UVOL_BLOCK; const bool in = c < nc && oc[k] >= 0; const int cc = in ? (int)c : 0, oo = in ? oc[k] : 0;
       a0[k] = ids[g_nxt(cc)]; a1[k] = ids[g_prv(cc)]; b0[k] = ids[g_prv(oo)]; b1[k] = ids[g_nxt(oo)];
     }
+    // The rare seam corners must not cost the whole wave a chain of dependent loads (each divergent section was three round
+    // trips, eight sections per thread): the two vertex ids of the edge and their bitmap words are fetched unconditionally for
+    // all corners (near-by / L2-resident data), only the fire-and-forget atomics are conditional.
+    uint32_t va[GEO_ILP], vb[GEO_ILP], wa[GEO_ILP], wb[GEO_ILP];
+#pragma unroll
+    for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK, cc = c < nc ? c : 0u; va[k] = (uint32_t)J.bvert[g_nxt(cc)]; vb[k] = (uint32_t)J.bvert[g_prv(cc)]; }
+#pragma unroll
+    for (int k = 0; k < GEO_ILP; k++) { wa[k] = J.vseam[i][va[k] >> 5]; wb[k] = J.vseam[i][vb[k] >> 5]; }
     bool any = false;
 #pragma unroll
     for (int k = 0; k < GEO_ILP; k++) {
@@ -916,12 +934,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
       uint8_t sm = 1;
       if (oc[k] >= 0) {
         sm = (a0[k] != b0[k] || a1[k] != b1[k]) ? 1 : 0;
-        if (sm) {                                                        // both ends of the edge get split
-          any = true;
-          const uint32_t va = (uint32_t)J.bvert[g_nxt(c)], vb = (uint32_t)J.bvert[g_prv(c)];
-          // a vertex on a seam is reached from ~4 corners: test the bit (a stale 0 only costs a redundant atomic) before setting it
-          if (!((J.vseam[i][va >> 5] >> (va & 31)) & 1u)) atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31));
-          if (!((J.vseam[i][vb >> 5] >> (vb & 31)) & 1u)) atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31));
+        if (sm) {                                                        // both ends of the edge get split; a vertex on a seam is reached
+          any = true;                                                    // from ~4 corners: a bit already seen set needs no atomic
+          if (!((wa[k] >> (va[k] & 31)) & 1u)) atomicOr(&J.vseam[i][va[k] >> 5], 1u << (va[k] & 31));
+          if (!((wb[k] >> (vb[k] & 31)) & 1u)) atomicOr(&J.vseam[i][vb[k] >> 5], 1u << (vb[k] & 31));
         }
       }
       J.seam[i][c] = sm;
@@ -961,13 +977,17 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
   for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? J.bvert[c] : 0; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][(uint32_t)v[k] >> 5];
-  GTab T; T.opp = J.nopp; T.seam = J.seam[i];
+  // left-most corner of its segment <=> the edge to its left is a seam or a boundary <=> seam[next(c)] (k_seams marks boundaries
+  // too); fetched for every corner (a neighbouring byte) so that the rare seam vertices cost no divergent round trip
+  uint8_t sl[GEO_ILP];
+#pragma unroll
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; sl[k] = J.seam[i][g_nxt(c < nc ? c : 0u)]; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) {
     const uint32_t c = c0 + k * UVOL_BLOCK;
     if (c >= nc) continue;
     if (!((w[k] >> ((uint32_t)v[k] & 31)) & 1u)) { J.avert[i][c] = v[k]; continue; }
-    if (gt_swl(T, (int)c) < 0) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
+    if (sl[k]) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
   }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
