@@ -60,6 +60,7 @@ struct GeoJob {
   // ---- workspace ----
   uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3]; uint32_t n_dup[3];      // hash-table dedup (worst-case retry): n_dup: phase 0 saw two equal values
   uint4 *dd_part[3]; uint32_t *dd_cnt[3]; uint32_t dd_nb[3], dd_nblk[3];               // partitioned dedup: {index, words} records by hash bin; counts[bin][tile]
+  uint32_t *he_part, *he_cnt; uint32_t he_vpb, he_nb, he_nblk;      // partitioned bucket build: {from, to, corner} records by vertex range; counts[bin][tile]; vertices per bin (0: atomic build)
   uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)

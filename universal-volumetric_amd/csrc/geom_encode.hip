@@ -350,6 +350,99 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_he_fill(GeoJob *jobs) {
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) if (a[k] != 0xffffffffu) J.he_ent[slot[k]] = ((unsigned long long)b[k] << 32) | (unsigned long long)(c0 + k * UVOL_BLOCK);
 }
+// Partitioned form of the bucket build (the default): the count / fill kernels above post two device-scope atomics per corner
+// (1.2 M per 200 k-face frame, memory-side) and fill the buckets with scattered 8-byte stores (17 MB of write traffic for a
+// 4.8 MB array).  Here the half-edges are partitioned by ranges of `he_vpb` from-vertices (count -> scan -> scatter of 12-byte
+// {from, to, corner} records), then ONE workgroup per range counts, scans and fills its buckets in LDS and writes he_start /
+// he_cur / he_ent for its range contiguously.  Bucket contents are the same sets as before; their order is arbitrary either way.
+#define HE_TILE 2048                        // corners per workgroup in the count / scatter passes
+#define HE_MAXBINS 1024
+#define HE_MAXVPB 4096                      // from-vertices per range (LDS counters)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_hp_count(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const uint32_t nb = J.he_nb, nblk = J.he_nblk, nc = J.nc; uint32_t sh = 9; while ((1u << sh) < J.he_vpb) sh++;
+  if (blockIdx.x >= nblk) return;
+  __shared__ uint32_t hist[HE_MAXBINS];
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) hist[b] = 0;
+  __syncthreads();
+  uint32_t a[HE_TILE / UVOL_BLOCK];
+#pragma unroll
+  for (int k = 0; k < HE_TILE / UVOL_BLOCK; k++) { const uint32_t c = blockIdx.x * HE_TILE + k * UVOL_BLOCK + threadIdx.x; a[k] = c < nc ? (uint32_t)J.cp[g_nxt(c)] : 0xffffffffu; }
+#pragma unroll
+  for (int k = 0; k < HE_TILE / UVOL_BLOCK; k++) if (a[k] != 0xffffffffu) atomicAdd(&hist[a[k] >> sh], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) J.he_cnt[(size_t)b * nblk + blockIdx.x] = hist[b];
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_hp_scan(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const uint32_t m = J.he_nb * J.he_nblk;
+  uint32_t *cnt = J.he_cnt;
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < m; b0 += UVOL_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < m ? cnt[i] : 0, tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    if (i < m) cnt[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[m] = carry;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_hp_scatter(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const uint32_t nb = J.he_nb, nblk = J.he_nblk, nc = J.nc; uint32_t sh = 9; while ((1u << sh) < J.he_vpb) sh++;
+  if (blockIdx.x >= nblk) return;
+  __shared__ uint32_t cur[HE_MAXBINS];
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) cur[b] = J.he_cnt[(size_t)b * nblk + blockIdx.x];
+  __syncthreads();
+  uint32_t a[HE_TILE / UVOL_BLOCK], bb[HE_TILE / UVOL_BLOCK];
+#pragma unroll
+  for (int k = 0; k < HE_TILE / UVOL_BLOCK; k++) {
+    const uint32_t c = blockIdx.x * HE_TILE + k * UVOL_BLOCK + threadIdx.x; const bool in = c < nc;
+    a[k] = in ? (uint32_t)J.cp[g_nxt(c)] : 0xffffffffu; bb[k] = in ? (uint32_t)J.cp[g_prv(c)] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < HE_TILE / UVOL_BLOCK; k++) {
+    if (a[k] == 0xffffffffu) continue;
+    const uint32_t pos = atomicAdd(&cur[a[k] >> sh], 1u);
+    uvol_s3 r; r.x = (int32_t)a[k]; r.y = (int32_t)bb[k]; r.z = (int32_t)(blockIdx.x * HE_TILE + k * UVOL_BLOCK + threadIdx.x);
+    *reinterpret_cast<uvol_s3 *>(J.he_part + 3 * (size_t)pos) = r;
+  }
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_hp_build(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const uint32_t nb = J.he_nb, nblk = J.he_nblk, vpb = J.he_vpb;
+  if (blockIdx.x >= nb) return;
+  const uint32_t lo = J.he_cnt[(size_t)blockIdx.x * nblk], hi = J.he_cnt[(size_t)(blockIdx.x + 1) * nblk];
+  const uint32_t v0 = blockIdx.x * vpb, nv = v0 < J.n_pos ? (J.n_pos - v0 < vpb ? J.n_pos - v0 : vpb) : 0u;
+  __shared__ uint32_t cv[HE_MAXVPB];
+  __shared__ uint32_t carry;
+  for (uint32_t j = threadIdx.x; j < vpb; j += UVOL_BLOCK) cv[j] = 0;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += UVOL_BLOCK) atomicAdd(&cv[J.he_part[3 * (size_t)e] - v0], 1u);
+  __syncthreads();
+  for (uint32_t j0 = 0; j0 < vpb; j0 += UVOL_BLOCK) {                    // exclusive scan in place; bucket bounds for the range
+    const uint32_t j = j0 + threadIdx.x;
+    uint32_t v = cv[j], tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    cv[j] = c + ex;
+    if (j < nv) { J.he_start[v0 + j] = lo + c + ex; J.he_cur[v0 + j] = lo + c + ex + v; }
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += UVOL_BLOCK) {
+    const uvol_s3 r = *reinterpret_cast<const uvol_s3 *>(J.he_part + 3 * (size_t)e);
+    const uint32_t slot = lo + atomicAdd(&cv[(uint32_t)r.x - v0], 1u);
+    J.he_ent[slot] = ((unsigned long long)(uint32_t)r.y << 32) | (unsigned long long)(uint32_t)r.z;
+  }
+}
 // lowest corner on the directed edge (from -> to), or -1; the order inside a bucket is arbitrary, the minimum is not
 __device__ __forceinline__ int he_find(const GeoJob &J, uint32_t from, uint32_t to) {
   const uint32_t s = J.he_start[from], e = J.he_cur[from];
@@ -2123,6 +2216,12 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   CARVE(J.keep, uint8_t, nfi + 1, PH_FACES, PH_FACES);
   CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_RENUM);
   CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_FANS0); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_FANS0);      // k_vert0 walks the buckets
+  { // partitioned bucket build (compact layout, ranges of <= HE_MAXVPB vertices): records + counts matrix, live in PH_CT only
+    uint32_t vpb = 512; while ((uint64_t)vpb * HE_MAXBINS < (uint64_t)J.n_pos) vpb *= 2;
+    J.he_vpb = (!full && vpb <= HE_MAXVPB && J.n_pos > 0) ? vpb : 0u;
+    J.he_nb = J.he_vpb ? (J.n_pos + vpb - 1) / vpb : 0u; J.he_nblk = J.he_vpb ? (uint32_t)((nc + HE_TILE - 1) / HE_TILE) : 0u;
+    if (J.he_vpb) { CARVE(J.he_part, uint32_t, 3 * nc + 4, PH_CT, PH_CT); CARVE(J.he_cnt, uint32_t, (size_t)J.he_nb * J.he_nblk + 2, PH_CT, PH_CT); }
+  }
   CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_PRED);                     // events / valence replay (auxiliary stream) read it until the join
   CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_PRED);
   // ---- K4 ----
@@ -2351,7 +2450,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   G->hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
-  uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0; uint64_t algo_in = 0;
+  uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0, he_nb_max = 0; bool he_part_all = true; uint64_t algo_in = 0;
   for (int i = 0; i < n; i++) max_nfi = std::max(max_nfi, meshes[i].n_faces);
   const int r8 = geo_rec8(max_nfi) ? 1 : 0;
   for (int i = 0; i < n; i++) {
@@ -2372,6 +2471,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     const size_t oc = full ? caps[i] : std::min<size_t>(caps[i], 32768 + 8 * (size_t)m.n_faces);
     out_total += (oc + 255) & ~(size_t)255; J.out_cap = (uint32_t)std::min<size_t>(caps[i], 0xffffffffu);
     max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm))); max_ecap = std::max(max_ecap, J.ecap);
+    he_nb_max = std::max(he_nb_max, J.he_nb); he_part_all = he_part_all && J.he_vpb != 0;
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
   int rc;
@@ -2436,9 +2536,17 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k3_corner_table", (uint64_t)n * 0 + (uint64_t)3 * max_nfi * 4 * 3);
-    LAUNCH(k_he_count, dim3(bci, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_he_scan, dim3(1, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_he_fill, dim3(bci, N), dim3(UVOL_BLOCK), dj);
+    if (he_part_all) {
+      const unsigned bt = (unsigned)(((size_t)3 * max_nfi + HE_TILE - 1) / HE_TILE);
+      LAUNCH(k_hp_count, dim3(bt, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_hp_scan, dim3(1, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_hp_scatter, dim3(bt, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_hp_build, dim3(he_nb_max, N), dim3(UVOL_BLOCK), dj);
+    } else {
+      LAUNCH(k_he_count, dim3(bci, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_he_scan, dim3(1, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_he_fill, dim3(bci, N), dim3(UVOL_BLOCK), dj);
+    }
     LAUNCH(k_edge_match, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
   }

@@ -1111,7 +1111,8 @@ static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsign
 }
 
 // selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
-static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < 256u ? J.Kmax_s : 256u; }   // leaves per pass: 17 KiB of LDS, placeable next to the geometry walkers' bitmaps
+static inline uint32_t sel_lcap_max() { static const uint32_t v = [] { const char *e = getenv("UVOL_SEL_LCAP"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 16 && x <= 768 ? x : 256); }(); return v; }
+static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < sel_lcap_max() ? J.Kmax_s : sel_lcap_max(); }   // leaves per pass: 17 KiB of LDS, placeable next to the geometry walkers' bitmaps
 static inline unsigned sel_stat_blocks(const TexJob &J, unsigned nseg) { return std::max<unsigned>(std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))), (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }   // >= NB / SEL_STATS_ITEMS: the 16-bit partial sums
 static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force, int round = -1) {
   // round r of the tree build has <= 2^r leaves: reserve LDS for those only (leaves past the cap would still be counted, through
