@@ -8,7 +8,7 @@ O=gpurun_out/$TAG; mkdir -p $O
 # synchronised), which shows the kernel a hanging pass stopped in
 for H in ${PMC_HALVES:-geo tex}; do for C in FETCH_SIZE WRITE_SIZE; do
   UVOL_DEBUG=${PMC_DEBUG:-0} timeout ${PMC_TIMEOUT:-420} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p_${H}_$C -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --only $H > /dev/null 2> $O/pmc_${H}_$C.err
-  grep '^\[uvol\]' $O/pmc_${H}_$C.err | tail -3 > $O/pmc_${H}_$C.last; grep -v '^\[uvol\]\|amdgpu.ids' $O/pmc_${H}_$C.err >> $O/pmc.err; rm -f $O/pmc_${H}_$C.err
+  grep '^\[uvol\]' $O/pmc_${H}_$C.err | tail -3 > $O/pmc_${H}_$C.last; grep -v '^\[uvol\]\|amdgpu.ids' $O/pmc_${H}_$C.err >> $O/pmc.err; mv $O/pmc_${H}_$C.err $O/pmc_${H}_$C.errfull; tail -c 3000 $O/pmc_${H}_$C.errfull > $O/pmc_${H}_$C.tail; rm -f $O/pmc_${H}_$C.errfull
 done; done
 d() { dirname $(find $O/p_$1 -name bench_counter_collection.csv | head -1); }
 : > $O/pmc.log

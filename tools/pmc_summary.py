@@ -8,7 +8,7 @@ import collections, csv, json, sys
 fd, wd, outp = sys.argv[1], sys.argv[2], sys.argv[4]
 frames = int(sys.argv[3].split(':')[0]); frames_tex = int(sys.argv[3].split(':')[1]) if ':' in sys.argv[3] else frames
 GROUPS = {"geo.k4_eb_walk": ["k_eb_walk"], "geo.k5_traverse": ["k_traverse"], "geo.k4_eb_valence": ["k_eb_valence"], "geo.k7_entropy_encode": ["k_entropy"],
-          "geo.k2_dedup": ["k_dedup", "k_faces", "k_compact_faces"], "geo.k3_corner_table": ["k_he_", "k_edge_match", "k_vert0"],
+          "geo.k2_dedup": ["k_dedup", "k_dd_", "k_faces", "k_compact_faces"], "geo.k3_corner_table": ["k_he_", "k_hp_", "k_edge_match", "k_vert0"],
           "geo.k4b_renumber_seams": ["k_renumber", "k_seams", "k_seam_bits", "k_aseg"],
           "tex.k12_sel_tokens": ["k_sel_tokens"], "tex.k9_endpoint_fit": ["k_tex_fit"], "tex.k10_selector_codebook": ["k_sel_stats", "k_sel_assign", "k_sel_centroids", "k_sel_used", "k_vq_apply<16>", "k_vq_decide<16>", "k_vq_zero<16>", "k_copy_skipped"]}
 def load(d, c):
