@@ -73,7 +73,7 @@ struct GeoJob {
   uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // per vertex id: on a boundary, ring size; size of the id space per table (encoder: only vopen_d[0])
   uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
   uint8_t *start_bits;
-  int32_t *old_of_new, *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert;
+  int32_t *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert;
   uint8_t *seam[2]; uint8_t *elig; uint8_t *seam_bits[2];
   int32_t *avert[2];
   int32_t *order[3], *v2d[3]; uint8_t *t_vvis[3]; int32_t *t_stack[3];

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_sums(GeoJob *jobs, int sel)
   if (threadIdx.x == 0) bsum[nblocks] = carry;
 }
 
-// Corners per thread in the per-corner gather kernels (see k_renumber_b): they are latency-bound at full occupancy, so a
+// Corners per thread in the per-corner gather kernels (k_edge_match, k_aseg_a/b): they are latency-bound at full occupancy, so a
 // thread issues every level of its dependent loads for GEO_ILP corners (one block stride apart: coalesced) before using any.
 #define GEO_ILP 4
 // ------------------------------------------------------------------------------------------------
@@ -942,91 +942,75 @@ __global__ void __launch_bounds__(64) k_eb_ctx(GeoJob *jobs) {
 }
 
 // renumber into decoder order (decoder corner 3f+k <-> rot^k(processed corner f))
+__device__ __forceinline__ int renum_first_corner(const GeoJob &J, uint32_t f) { return (int)f < J.nsym ? J.proc[J.nsym - 1 - (int)f] : J.initc[(int)f - J.nsym]; }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_a(GeoJob *jobs) {
   JOB_OR_RETURN;
   uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (f >= J.nf) return;
-  int c = (int)f < J.nsym ? J.proc[J.nsym - 1 - (int)f] : J.initc[(int)f - J.nsym];
-  int o[3] = { c, g_nxt(c), g_prv(c) };
-  for (int k = 0; k < 3; k++) { J.old_of_new[3 * f + k] = o[k]; J.new_of_old[o[k]] = (int)(3 * f + k); }
+  const int c = renum_first_corner(J, f);
+  const int o[3] = { c, g_nxt(c), g_prv(c) };
+  for (int k = 0; k < 3; k++) J.new_of_old[o[k]] = (int)(3 * f + k);
 }
-// The per-corner gather kernels below are latency-bound at full occupancy (three or four dependent loads per thread, ~2 us
-// each under load: 512 k resident threads / 6 us = what was measured), so every thread handles GEO_ILP corners, one block
-// stride apart (accesses stay coalesced), and issues each level of its loads for all of them before it uses any.
-__global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_b(GeoJob *jobs) {
-  JOB_OR_RETURN;
-  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
-  int o[GEO_ILP], oo[GEO_ILP], p[GEO_ILP], u[GEO_ILP], n[GEO_ILP], v[GEO_ILP];
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; o[k] = c < nc ? J.old_of_new[c] : 0; }
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { oo[k] = J.opp[o[k]]; p[k] = J.cp[o[k]]; u[k] = J.cu[o[k]]; n[k] = J.cn[o[k]]; v[k] = J.vert[o[k]]; }
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) oo[k] = oo[k] < 0 ? GEO_INV : J.new_of_old[oo[k]];
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) {
-    const uint32_t c = c0 + k * UVOL_BLOCK;
-    if (c < nc) { J.nopp[c] = oo[k]; J.npid[c] = p[k]; J.nuid[c] = u[k]; J.nnid[c] = n[k]; J.bvert[c] = v[k]; }   // the same vertices under the decoder's corner numbering
-  }
-}
-
-// attribute seams (MeshAttributeCornerTable::InitFromAttribute) + seam-bit eligibility
-__global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
+// One thread per NEW face: the renumbered tables (opposite corners, value ids, vertices under the decoder's corner numbering),
+// the attribute seams (MeshAttributeCornerTable::InitFromAttribute) with the seam-bit eligibility flags and their block sums,
+// and the 'a seam touches this vertex' bits.  The renumbering maps whole faces (rotated), so everything a corner needs from
+// its own face is in the thread's registers (three 12-byte loads per array from the OLD face) and the ids across an edge
+// come from the old face of the opposite corner - 20 loads per face where the per-corner k_renumber_b + k_seams pair issued 60.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_seams(GeoJob *jobs) {
   JOB_OR_RETURN_UNIFORM;
-  const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int oc[GEO_ILP];
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; oc[k] = c < nc ? J.nopp[c] : -1; }
-  // eligibility flags + their per-256-corner sums for k_seam_bits (one barrier: per-wave ballots, then GEO_ILP threads add them)
-  __shared__ uint32_t wcnt[GEO_ILP][UVOL_BLOCK / 64];
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) {
-    const uint32_t c = c0 + k * UVOL_BLOCK; const bool e = c < nc && oc[k] >= 0 && (uint32_t)oc[k] / 3 > c / 3;
-    if (c < nc) J.elig[c] = e ? 1 : 0;
-    const unsigned long long m = __ballot(e);
-    if (lane == 0) wcnt[k][wave] = (uint32_t)__popcll(m);
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x, nf = J.nf;
+  const bool in = f < nf;
+  __shared__ uint32_t ecnt[3];                                         // eligible corners per 256-corner block (three per 256 faces)
+  if (threadIdx.x < 3) ecnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (in) {
+    const int c0 = renum_first_corner(J, f);
+    const int fo = 3 * (c0 / 3), r0 = c0 - fo;                          // old face, rotation
+    int opp_[3], P[3], U[3], Nn[3], V[3];
+    { const uvol_s3 a = *reinterpret_cast<const uvol_s3 *>(J.opp + fo), b = *reinterpret_cast<const uvol_s3 *>(J.cp + fo), c = *reinterpret_cast<const uvol_s3 *>(J.cu + fo),
+                    d = *reinterpret_cast<const uvol_s3 *>(J.cn + fo), e = *reinterpret_cast<const uvol_s3 *>(J.vert + fo);
+      const int ao[3] = { a.x, a.y, a.z }, bo[3] = { b.x, b.y, b.z }, co[3] = { c.x, c.y, c.z }, dn[3] = { d.x, d.y, d.z }, ev[3] = { e.x, e.y, e.z };
+      for (int k = 0; k < 3; k++) { const int j = (r0 + k) % 3; opp_[k] = ao[j]; P[k] = bo[j]; U[k] = co[j]; Nn[k] = dn[j]; V[k] = ev[j]; } }
+    int no[3];
+    for (int k = 0; k < 3; k++) no[k] = opp_[k] < 0 ? GEO_INV : J.new_of_old[opp_[k]];
+    // ids across each edge: the two other corners of the opposite corner's OLD face
+    int bu[3][2], bn[3][2];
+    for (int k = 0; k < 3; k++) {
+      const int oo = opp_[k] < 0 ? 0 : opp_[k];
+      bu[k][0] = J.cu[g_prv(oo)]; bu[k][1] = J.cu[g_nxt(oo)]; bn[k][0] = J.cn[g_prv(oo)]; bn[k][1] = J.cn[g_nxt(oo)];
+    }
+    { uvol_s3 w; w.x = no[0]; w.y = no[1]; w.z = no[2]; *reinterpret_cast<uvol_s3 *>(J.nopp + 3 * (size_t)f) = w;
+      w.x = P[0]; w.y = P[1]; w.z = P[2]; *reinterpret_cast<uvol_s3 *>(J.npid + 3 * (size_t)f) = w;
+      w.x = U[0]; w.y = U[1]; w.z = U[2]; *reinterpret_cast<uvol_s3 *>(J.nuid + 3 * (size_t)f) = w;
+      w.x = Nn[0]; w.y = Nn[1]; w.z = Nn[2]; *reinterpret_cast<uvol_s3 *>(J.nnid + 3 * (size_t)f) = w;
+      w.x = V[0]; w.y = V[1]; w.z = V[2]; *reinterpret_cast<uvol_s3 *>(J.bvert + 3 * (size_t)f) = w; }
+    for (int k = 0; k < 3; k++) {
+      const uint32_t c = 3 * f + k; const bool e = no[k] >= 0 && (uint32_t)no[k] / 3 > f;
+      J.elig[c] = e ? 1 : 0;
+      if (e) atomicAdd(&ecnt[(3 * threadIdx.x + k) >> 8], 1u);
+    }
+    for (int i = 0; i < J.nad; i++) {
+      const bool uvk = J.att_kind[i] == 0;
+      bool any = false;
+      for (int k = 0; k < 3; k++) {
+        uint8_t sm = 1;
+        if (opp_[k] >= 0) {
+          const int a0 = uvk ? U[(k + 1) % 3] : Nn[(k + 1) % 3], a1 = uvk ? U[(k + 2) % 3] : Nn[(k + 2) % 3];
+          const int b0 = uvk ? bu[k][0] : bn[k][0], b1 = uvk ? bu[k][1] : bn[k][1];
+          sm = (a0 != b0 || a1 != b1) ? 1 : 0;
+          if (sm) {                                                      // both ends of the edge get split
+            any = true;
+            const uint32_t va = (uint32_t)V[(k + 1) % 3], vb = (uint32_t)V[(k + 2) % 3];
+            atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31));
+          }
+        }
+        J.seam[i][3 * (size_t)f + k] = sm;
+      }
+      if (any) J.interior_seams[i] = 1;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < GEO_ILP) {
-    uint32_t tot = 0; for (int w = 0; w < UVOL_BLOCK / 64; w++) tot += wcnt[threadIdx.x][w];
-    const uint32_t b = blockIdx.x * GEO_ILP + threadIdx.x;
-    if (b < uvol_blocks_dev(nc)) J.bsum[b] = tot;
-  }
-  for (int i = 0; i < J.nad; i++) {
-    const int32_t *ids = J.att_kind[i] == 0 ? J.nuid : J.nnid;
-    int a0[GEO_ILP], a1[GEO_ILP], b0[GEO_ILP], b1[GEO_ILP];
-#pragma unroll
-    for (int k = 0; k < GEO_ILP; k++) {
-      const uint32_t c = c0 + k * UVOL_BLOCK; const bool in = c < nc && oc[k] >= 0; const int cc = in ? (int)c : 0, oo = in ? oc[k] : 0;
-      a0[k] = ids[g_nxt(cc)]; a1[k] = ids[g_prv(cc)]; b0[k] = ids[g_prv(oo)]; b1[k] = ids[g_nxt(oo)];
-    }
-    // The rare seam corners must not cost the whole wave a chain of dependent loads (each divergent section was three round
-    // trips, eight sections per thread): the two vertex ids of the edge and their bitmap words are fetched unconditionally for
-    // all corners (near-by / L2-resident data), only the fire-and-forget atomics are conditional.
-    uint32_t va[GEO_ILP], vb[GEO_ILP], wa[GEO_ILP], wb[GEO_ILP];
-#pragma unroll
-    for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK, cc = c < nc ? c : 0u; va[k] = (uint32_t)J.bvert[g_nxt(cc)]; vb[k] = (uint32_t)J.bvert[g_prv(cc)]; }
-#pragma unroll
-    for (int k = 0; k < GEO_ILP; k++) { wa[k] = J.vseam[i][va[k] >> 5]; wb[k] = J.vseam[i][vb[k] >> 5]; }
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < GEO_ILP; k++) {
-      const uint32_t c = c0 + k * UVOL_BLOCK;
-      if (c >= nc) continue;
-      uint8_t sm = 1;
-      if (oc[k] >= 0) {
-        sm = (a0[k] != b0[k] || a1[k] != b1[k]) ? 1 : 0;
-        if (sm) {                                                        // both ends of the edge get split; a vertex on a seam is reached
-          any = true;                                                    // from ~4 corners: a bit already seen set needs no atomic
-          if (!((wa[k] >> (va[k] & 31)) & 1u)) atomicOr(&J.vseam[i][va[k] >> 5], 1u << (va[k] & 31));
-          if (!((wb[k] >> (vb[k] & 31)) & 1u)) atomicOr(&J.vseam[i][vb[k] >> 5], 1u << (vb[k] & 31));
-        }
-      }
-      J.seam[i][c] = sm;
-    }
-    if (any) J.interior_seams[i] = 1;
-  }
+  if (threadIdx.x < 3) { const uint32_t b = 3 * blockIdx.x + threadIdx.x; if (b < uvol_blocks_dev(J.nc)) J.bsum[b] = ecnt[threadIdx.x]; }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
@@ -2238,14 +2222,14 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, PH_PRED); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, PH_PRED); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, PH_PRED);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1, PH_RENUM, PH_ENT);
   // ---- renumbering, seams ----
-  CARVE(J.old_of_new, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
+  CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
   CARVE(J.npid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nuid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nnid, int32_t, nc + 3, PH_RENUM, PH_QUANT);
   CARVE(J.bvert, int32_t, nc + 3, PH_RENUM, PH_PRED);
   for (int i = 0; i < 2; i++) {
-    CARVE(J.seam[i], uint8_t, nc + 3, PH_SEAMS, PH_PRED); CARVE(J.seam_bits[i], uint8_t, nc + 3, PH_SEAMS, PH_ENT);
+    CARVE(J.seam[i], uint8_t, nc + 3, PH_RENUM, PH_PRED); CARVE(J.seam_bits[i], uint8_t, nc + 3, PH_SEAMS, PH_ENT);
     CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED);
   }
-  CARVE(J.elig, uint8_t, nc + 3, PH_SEAMS, PH_SEAMS);
+  CARVE(J.elig, uint8_t, nc + 3, PH_RENUM, PH_SEAMS);
   // ---- K5, K1, K6 ----
   for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, ecap, PH_TRAV, PH_PRED); CARVE(J.v2d[t], int32_t, ecap, PH_V2D, PH_PRED); CARVE(J.t_stack[t], int32_t, nfi + 2, PH_TRAV, PH_TRAV); }
   CARVE(J.P, int32_t, 3 * ecap, PH_QUANT, PH_PRED); CARVE(J.U, int32_t, 2 * ecap, PH_QUANT, PH_PRED); CARVE(J.O, int32_t, 2 * ecap, PH_QUANT, PH_PRED);
@@ -2575,8 +2559,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   {
     uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_renumber_b, dim3(bci, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_seams, dim3(bci, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_renumber_seams, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
     LAUNCH(k_seam_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_aseg_a, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
