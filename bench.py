@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
     ap.add_argument("--geo-priority", type=int, default=0, help="DIAGNOSTIC: geometry contexts on high-priority streams too")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
+    ap.add_argument("--tex-delay-ms", type=float, default=0.0, help="DIAGNOSTIC: the texture streams start each pass (--lockstep) / their first pass this long after the geometry streams")
     ap.add_argument("--geo-stagger-ms", type=float, default=0.0, help="one-time start delay of geometry stream g: g * this")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
     ap.add_argument("--cu-split", type=int, default=0, help="16*G+T: CU residue masks (mod 4) for the geometry / texture streams, e.g. 0x7*16+0x8 = 120")
@@ -155,6 +156,11 @@ def main():
             except BaseException as e:          # a failed stream must fail the whole bench, not shrink the work silently
                 errors.append(e)
 
+        def loop1(fn, arg, delay):
+            if delay > 0:
+                time.sleep(delay)
+            fn(arg)
+
         def loop(fn, arg, delay):
             if delay > 0:
                 time.sleep(delay)
@@ -163,14 +169,14 @@ def main():
         if args.lockstep:
             for _ in range(k):
                 th = [threading.Thread(target=guarded, args=(run_geo, gi)) for gi in range(GS) if args.only != "tex"] + \
-                     [threading.Thread(target=guarded, args=(run_tex, ti)) for ti in range(len(texs)) if args.only != "geo"]
+                     [threading.Thread(target=guarded, args=(loop1, run_tex, ti, args.tex_delay_ms * 1e-3)) for ti in range(len(texs)) if args.only != "geo"]
                 for t in th:
                     t.start()
                 for t in th:
                     t.join()
         else:
             th = [threading.Thread(target=guarded, args=(loop, run_geo, gi, gi * args.geo_stagger_ms * 1e-3)) for gi in range(GS) if args.only != "tex"] + \
-                 [threading.Thread(target=guarded, args=(loop, run_tex, ti, 0.0)) for ti in range(len(texs)) if args.only != "geo"]
+                 [threading.Thread(target=guarded, args=(loop, run_tex, ti, args.tex_delay_ms * 1e-3)) for ti in range(len(texs)) if args.only != "geo"]
             for t in th:
                 t.start()
             for t in th:

@@ -2206,20 +2206,20 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
     J.he_nb = J.he_vpb ? (J.n_pos + vpb - 1) / vpb : 0u; J.he_nblk = J.he_vpb ? (uint32_t)((nc + HE_TILE - 1) / HE_TILE) : 0u;
     if (J.he_vpb) { CARVE(J.he_part, uint32_t, 3 * nc + 4, PH_CT, PH_CT); CARVE(J.he_cnt, uint32_t, (size_t)J.he_nb * J.he_nblk + 2, PH_CT, PH_CT); }
   }
-  CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_PRED);                     // events / valence replay (auxiliary stream) read it until the join
-  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_PRED);
+  CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_SEAMS);                     // events / valence replay (auxiliary stream) read it until the join
+  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_SEAMS);
   // ---- K4 ----
   const size_t rec_bytes = (r8 ? 32 : 64) * (nfi + 1);
   CARVE(J.rec[0], uint8_t, rec_bytes, PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
   for (int w = 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
-  CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_PRED);
-  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, PH_PRED);
-  CARVE(J.proc, int32_t, nfi + 1, PH_WALK, PH_PRED); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, PH_PRED);
+  CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_SEAMS);
+  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, PH_SEAMS);
+  CARVE(J.proc, int32_t, nfi + 1, PH_WALK, PH_SEAMS); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, PH_SEAMS);
   CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_RENUM); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
   // auxiliary stream (forked after PH_FTIME, joined before PH_HIST)
-  CARVE(J.evcnt, uint8_t, nfi + 1, PH_RENUM, PH_PRED);
+  CARVE(J.evcnt, uint8_t, nfi + 1, PH_RENUM, PH_SEAMS);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_spl, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT);
-  CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, PH_PRED); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, PH_PRED); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, PH_PRED);
+  CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, PH_SEAMS); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, PH_SEAMS); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, PH_SEAMS);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1, PH_RENUM, PH_ENT);
   // ---- renumbering, seams ----
   CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
@@ -2565,6 +2565,11 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_aseg_a, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_aseg_b, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
   }
+  // The auxiliary stream (events / valence replay / context scatter, ~90 ms per 2160 frames) is joined HERE, not before the
+  // entropy stage: it then overlaps the renumber / seams group only (about as long), but everything it reads (old-order
+  // opposite corners and vertices, the symbol sequence, the valence scratch: 11.6 MB per frame) is dead before the three record
+  // tables of the attribute traversals are written and shares their addresses - the workspace peak drops from 63 to 52 MB.
+  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
     LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, r8);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
@@ -2591,7 +2596,6 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_ori_bits, dim3(be, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_pred_nrm, dim3(be, N), dim3(UVOL_BLOCK), dj);
   }
-  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
     uvol_ctx::Scope sc0(ctx, "geo.k7_hist_tables", 0);
     LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi, 16 * UVOL_BLOCK), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
