@@ -8,7 +8,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o ben
 cp $(find $O/kt -name bench_kernel_stats.csv | head -1) $O/kernel_stats.csv
 # HBM traffic of every kernel: tools/pmc_pack.sh (own processes per half)
 rm -rf $O/kt
-PMC_DEBUG=1 PMC_TIMEOUT=400 bash tools/pmc_pack.sh $TAG      # UVOL_DEBUG=1: with counters armed the serialised kernels deadlock on cross-stream event waits unless every launch is synchronised
+PMC_TIMEOUT=100 bash tools/pmc_pack.sh $TAG
 python tools/uastc_timing.py 24 > $O/uastc_timing.json 2>> $O/bench.err
 python tools/dec_timing.py 96 > $O/dec_timing.json 2>> $O/bench.err
 python tools/gdec_timing.py 480 > $O/gdec_timing.json 2>> $O/bench.err
