@@ -220,3 +220,29 @@ def shuffle_mesh(m, seed=0):
         out[val] = np.ascontiguousarray(a[vperm])
         out[idx] = np.ascontiguousarray(inv[np.asarray(m[idx]).reshape(nf, 3)[fperm]].astype(np.uint32).reshape(-1))
     return out
+
+
+def random_soup_mesh(seed, n_pos=40, n_faces=120, dup_frac=0.3, with_uv=True, with_nrm=True):
+    """Seeded adversarial triangle soup: faces drawn at random over few positions (non-manifold edges and vertices, duplicate and
+    flipped faces, isolated components), a fraction of the value arrays duplicated bit for bit under other indices, degenerate
+    faces (repeated index, or two indices whose values are equal), unused values, random per-corner uv / normal indices."""
+    rng = np.random.default_rng(seed)
+    def values(n, d):
+        v = rng.random((n, d)).astype(np.float32)
+        k = int(n * dup_frac)
+        if k:
+            v[rng.integers(0, n, size=k)] = v[rng.integers(0, n, size=k)]          # bitwise duplicates
+        return v
+    pos = values(n_pos, 3)
+    idx = rng.integers(0, n_pos, size=(n_faces, 3)).astype(np.uint32)
+    # stitch some proper fans in so that there are interior edges as well
+    for f in range(0, n_faces - 2, 3):
+        a, b, c, d = rng.choice(n_pos, size=4, replace=False)
+        idx[f] = (a, b, c); idx[f + 1] = (a, c, d)
+    m = dict(pos=pos, idx_pos=idx.reshape(-1))
+    if with_uv:
+        uv = values(max(3, n_pos + 7), 2); m["uv"] = uv; m["idx_uv"] = rng.integers(0, len(uv), size=3 * n_faces).astype(np.uint32)
+    if with_nrm:
+        nr = values(max(3, n_pos // 2), 3) - 0.5; nr /= np.maximum(1e-6, np.linalg.norm(nr, axis=1, keepdims=True)); nr = nr.astype(np.float32)
+        m["nrm"] = nr; m["idx_nrm"] = rng.integers(0, len(nr), size=3 * n_faces).astype(np.uint32)
+    return m
