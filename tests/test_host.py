@@ -141,3 +141,33 @@ def test_obj_and_png_ingest(H, tmp_path):
         assert H.uvolh_read_png(str(q).encode(), wh, buf.ctypes.data_as(C.POINTER(C.c_ubyte)), buf.nbytes) == 0
         want = np.array(Image.fromarray(arr, mode).convert("RGBA"))
         assert (wh[0], wh[1]) == (arr.shape[1], arr.shape[0]) and np.array_equal(buf, want)
+
+
+def test_obj_number_parser_equals_strtof(H, tmp_path):
+    """read_obj parses decimals itself (strtof is ~10x slower); the result must be strtof's, bit for bit: plain decimals of every
+    length, exponents, signs, leading / trailing dots, values next to float rounding boundaries, subnormals, overflow, long digit strings."""
+    import ctypes.util
+    libc = C.CDLL(ctypes.util.find_library("c")); libc.strtof.restype = C.c_float; libc.strtof.argtypes = [C.c_char_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    toks = []
+    for k in range(3000):
+        x = float(rng.standard_normal()) * 10.0 ** int(rng.integers(-12, 12))
+        toks += ["%r" % x, "%.6f" % x, "%.3g" % x, "%.9g" % x, "%.17g" % x, "%e" % x]
+    f32 = rng.integers(0, 2 ** 31 - 2 ** 23, size=2000, dtype=np.int64).astype(np.uint32).view(np.float32)      # finite floats incl. subnormals
+    for v in f32:
+        d = float(v); nx = float(np.nextafter(v, np.float32(np.inf)))
+        toks += ["%.9g" % d, "%.17g" % ((d + nx) / 2), "%.20g" % ((d + nx) / 2), "%.12g" % ((d + nx) / 2)]   # the midpoints: rounding boundaries
+    toks += ["0", "-0", "-0.0", "+1.5", ".5", "5.", "-.25", "1e-40", "1e-46", "3.4028235e38", "3.5e38", "1e39", "-1e39", "123456789012345678901234567890",
+             "0.000000000000000000000000000000000000001", "1.00000005960464477539062500000000000001", "16777217", "16777217.0000000001", "9007199254740993", "1e22", "1e23", "8.5e-23"]
+    toks = toks[: 3 * (len(toks) // 3)]
+    p = tmp_path / "n.obj"
+    with open(p, "w") as f:
+        for i in range(0, len(toks), 3):
+            f.write("v %s %s %s\n" % tuple(toks[i:i + 3]))
+        f.write("f 1 2 3\n")
+    H.uvolh_read_obj_positions.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
+    got = np.zeros(len(toks), np.float32)
+    assert H.uvolh_read_obj_positions(str(p).encode(), got.ctypes.data_as(C.POINTER(C.c_float)), got.size) == len(toks) // 3
+    want = np.array([libc.strtof(t.encode(), None) for t in toks], np.float32)
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert len(bad) == 0, [(toks[i], got[i], want[i]) for i in bad[:5]]
