@@ -2463,6 +2463,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   if ((rc = uvol_ensure(ctx, G->jobs, sizeof(GeoJob) * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, G->outs, out_total))) return rc;
   if (!on_device && (rc = uvol_ensure(ctx, G->inputs, in_total))) return rc;
+  std::vector<UvolUpItem> ups; if (!on_device) ups.reserve((size_t)n * 6);
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     uint8_t *base = (uint8_t *)G->slab.p + ws_off[i];
@@ -2472,8 +2473,8 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
     else {
       uint8_t *ib = (uint8_t *)G->inputs.p + in_off[i]; size_t o = 0;
-      auto up = [&](const void *src, size_t bytes) -> const void * {
-        void *d = ib + o; (void)hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream); o += (bytes + 255) / 256 * 256; return d; };
+      auto up = [&](const void *src, size_t bytes) -> const void * {                 // queued: ONE staged upload for the whole batch below
+        void *d = ib + o; if (bytes) ups.push_back(UvolUpItem{ in_off[i] + o, src, bytes }); o += (bytes + 255) / 256 * 256; return d; };
       J.pos = (const float *)up(m.pos, (size_t)m.n_pos * 12);
       J.uv = J.has_uv ? (const float *)up(m.uv, (size_t)m.n_uv * 8) : nullptr;
       J.nrm = J.has_nrm ? (const float *)up(m.nrm, (size_t)m.n_nrm * 12) : nullptr;
@@ -2489,6 +2490,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     J.rb[0].bits = J.start_bits; J.rb[1].bits = J.seam_bits[0]; J.rb[2].bits = J.seam_bits[1]; J.rb[3].bits = J.ori_bits; J.rb[4].bits = J.flips;
     // rabs slot 1/2 follow the attribute-data slot; slot 3 = uv orientations, slot 4 = normal flips
   }
+  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)G->inputs.p, ups); if (rcu != UVOL_OK) return rcu; }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->jobs.p, G->hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   GeoJob *dj = (GeoJob *)G->jobs.p;
   const unsigned N = (unsigned)n;

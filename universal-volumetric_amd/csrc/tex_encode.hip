@@ -1152,6 +1152,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   if ((rc = uvol_ensure(ctx, T->job, sizeof(TexJob) * (size_t)n_seg))) return rc;
   if (!on_device && (rc = uvol_ensure(ctx, T->layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
   T->hjobs.assign((size_t)n_seg, J0);
+  std::vector<UvolUpItem> ups;                                           // host layers: one staged upload for the whole batch
   for (int s = 0; s < n_seg; s++) {
     TexJob &J = T->hjobs[s];
     uint8_t *base = (uint8_t *)T->slab.p + ws * (size_t)s;
@@ -1160,9 +1161,10 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     for (int l = 0; l < n_layers; l++) {
       const uint8_t *src = rgba[(size_t)s * n_layers + l];
       if (on_device) J.layer[l] = src;
-      else { uint8_t *d = (uint8_t *)T->layers.p + lbytes * ((size_t)s * n_layers + l); UVOL_HIP_CHECK(ctx, hipMemcpyAsync(d, src, lbytes, hipMemcpyHostToDevice, ctx->stream)); J.layer[l] = d; }
+      else { uint8_t *d = (uint8_t *)T->layers.p + lbytes * ((size_t)s * n_layers + l); ups.push_back(UvolUpItem{ lbytes * ((size_t)s * n_layers + l), src, lbytes }); J.layer[l] = d; }
     }
   }
+  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)T->layers.p, ups); if (rcu != UVOL_OK) return rcu; }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->job.p, T->hjobs.data(), sizeof(TexJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
   TexJob *dj = (TexJob *)T->job.p;
   const TexJob &J = J0;

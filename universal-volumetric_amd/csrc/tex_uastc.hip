@@ -546,15 +546,17 @@ int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
   if ((rc = uvol_ensure(ctx, U->blocks, seg_bytes * (size_t)n_seg))) return rc;
   if (!on_device && (rc = uvol_ensure(ctx, U->layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
   U->hjobs.assign((size_t)n_seg, UastcJob{});
+  std::vector<UvolUpItem> ups;
   for (int s = 0; s < n_seg; s++) {
     UastcJob &J = U->hjobs[s]; J.W = W; J.H = H; J.L = (uint32_t)n_layers; J.bx = bx; J.by = by; J.yflip = ctx->prm.y_flip ? 1 : 0;
     for (int l = 0; l < n_layers; l++) {
       const uint8_t *src = rgba[(size_t)s * n_layers + l];
       if (on_device) J.layer[l] = src;
-      else { uint8_t *d = (uint8_t *)U->layers.p + lbytes * ((size_t)s * n_layers + l); UVOL_HIP_CHECK(ctx, hipMemcpyAsync(d, src, lbytes, hipMemcpyHostToDevice, ctx->stream)); J.layer[l] = d; }
+      else { uint8_t *d = (uint8_t *)U->layers.p + lbytes * ((size_t)s * n_layers + l); ups.push_back(UvolUpItem{ lbytes * ((size_t)s * n_layers + l), src, lbytes }); J.layer[l] = d; }
       J.out[l] = (uint8_t *)U->blocks.p + seg_bytes * (size_t)s + nb * 16 * (size_t)l;
     }
   }
+  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)U->layers.p, ups); if (rcu != UVOL_OK) return rcu; }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
   { uvol_ctx::Scope sc(ctx, "tex.uastc_encode", (uint64_t)(lbytes + nb * 16) * n_layers * (uint64_t)n_seg);
     hipLaunchKernelGGL(k_uastc_encode, dim3(uvol_blocks(nb), (unsigned)n_layers, (unsigned)n_seg), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p); }
