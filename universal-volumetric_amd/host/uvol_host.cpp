@@ -236,12 +236,13 @@ static inline bool fast_float(const char *&q, const char *le, float &out) {
   if (!(std::fabs(f) >= 1.17549435e-38f) && mant != 0) return false;       // subnormal floats round differently: strtof
   out = neg ? -f : f; q = p; return true;
 }
-bool read_obj(const std::string &path, ObjMesh &m, std::string &err) {
-  std::vector<uint8_t> d; if (!read_file(path, d)) { err = "cannot read " + path; return false; }
-  m = ObjMesh();
+bool read_obj(const std::string &path, ObjMesh &m, std::string &err, IngestScratch *scratch) {
+  IngestScratch local; IngestScratch &S = scratch ? *scratch : local;
+  std::vector<uint8_t> &d = S.file; if (!read_file(path, d)) { err = "cannot read " + path; return false; }
+  m.pos.clear(); m.uv.clear(); m.nrm.clear(); m.idx_pos.clear(); m.idx_uv.clear(); m.idx_nrm.clear();      // capacity is kept
   const char *p = (const char *)d.data(), *e = p + d.size();
   bool has_uv = true, has_n = true; long nfaces = 0;
-  std::vector<long> fv, ft, fn;
+  std::vector<long> &fv = S.fv, &ft = S.ft, &fn = S.fn;
   { // one cheap pass over the line starts so that every array is allocated once (a 100 k-vertex frame grew ~25 MB of vectors by
     // doubling, on 64 ingest threads at a time)
     size_t nv = 0, nt = 0, nn = 0, nfl = 0;
@@ -321,12 +322,13 @@ static bool inflate_zlib_stream(const uint8_t *in, size_t in_len, uint8_t *out, 
 }
 
 // ------------------------------------------------------------------ PNG (8/16-bit, colour types 0/2/3/4/6, non-interlaced) via zlib
-bool read_png(const std::string &path, Image &img, std::string &err) {
-  std::vector<uint8_t> d; if (!read_file(path, d)) { err = "cannot read " + path; return false; }
+bool read_png(const std::string &path, Image &img, std::string &err, IngestScratch *scratch) {
+  IngestScratch local; IngestScratch &S = scratch ? *scratch : local;
+  std::vector<uint8_t> &d = S.file; if (!read_file(path, d)) { err = "cannot read " + path; return false; }
   static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
   if (d.size() < 33 || std::memcmp(d.data(), sig, 8)) { err = path + ": not a PNG"; return false; }
   auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
-  uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0; std::vector<uint8_t> idat, plte, trns;
+  uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0; std::vector<uint8_t> &idat = S.idat, plte, trns; idat.clear();
   for (size_t o = 8; o + 12 <= d.size();) {
     uint32_t len = be32(o); if (o + 12 + len > d.size()) break;
     const char *t = (const char *)&d[o + 4]; const uint8_t *body = &d[o + 8];
@@ -341,11 +343,11 @@ bool read_png(const std::string &path, Image &img, std::string &err) {
   if (!w || !h || interlace || (depth != 8 && depth != 16) || (ctype != 0 && ctype != 2 && ctype != 3 && ctype != 4 && ctype != 6) || (ctype == 3 && depth != 8)) { err = path + ": unsupported PNG variant"; return false; }
   const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4, bpp = ch * depth / 8;
   const size_t stride = (size_t)w * bpp;
-  std::vector<uint8_t> raw((stride + 1) * h);
+  std::vector<uint8_t> &raw = S.raw; raw.resize((stride + 1) * h);
   if (!inflate_zlib_stream(idat.data(), idat.size(), raw.data(), raw.size())) { err = path + ": zlib inflate failed"; return false; }
   // rows are un-filtered IN PLACE in the inflated buffer (the previous row is the one just done), one tight loop per filter type
   // instead of a switch per byte
-  std::vector<uint8_t> zero(stride, 0);
+  std::vector<uint8_t> &zero = S.zero; zero.assign(stride, 0);
   img.w = w; img.h = h; img.rgba.resize((size_t)w * h * 4);
   for (uint32_t y = 0; y < h; y++) {
     uint8_t *r = &raw[(stride + 1) * y]; const int ft = r[0]; r++;

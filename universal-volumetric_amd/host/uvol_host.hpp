@@ -48,9 +48,14 @@ std::string config_template();                                          // `crea
 
 // ---- ingest ----
 struct ObjMesh { std::vector<float> pos, uv, nrm; std::vector<uint32_t> idx_pos, idx_uv, idx_nrm; };
-bool read_obj(const std::string &path, ObjMesh &m, std::string &err);
+// Buffers an ingest worker keeps between files.  A 100 k-vertex OBJ + a 2048^2 PNG need ~70 MB of temporaries; allocated afresh
+// per file they are ~70 MB of new pages to fault in per frame, and 128 ingest threads of one process faulting at once serialise
+// on the address-space lock (a file took 300 ms instead of 43).  read_obj / read_png also REUSE the capacity of the ObjMesh /
+// Image they are given, so a caller that recycles its batch objects allocates nothing in the steady state.
+struct IngestScratch { std::vector<uint8_t> file, idat, raw, zero; std::vector<long> fv, ft, fn; };
+bool read_obj(const std::string &path, ObjMesh &m, std::string &err, IngestScratch *scratch = nullptr);
 struct Image { uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; };
-bool read_png(const std::string &path, Image &img, std::string &err);
+bool read_png(const std::string &path, Image &img, std::string &err, IngestScratch *scratch = nullptr);
 bool write_file(const std::string &path, const void *data, size_t n);
 bool read_file(const std::string &path, std::vector<uint8_t> &data);
 std::vector<std::string> list_dir(const std::string &dir);

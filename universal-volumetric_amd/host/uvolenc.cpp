@@ -30,17 +30,21 @@ using namespace uvolh;
 
 static std::string dirname_of(const std::string &p) { size_t k = p.find_last_of('/'); return k == std::string::npos ? "" : p.substr(0, k); }
 static std::string basename_of(const std::string &p) { size_t k = p.find_last_of('/'); return k == std::string::npos ? p : p.substr(k + 1); }
+static bool g_timing = false;      // UVOL_TIMING=1: per-batch stage times on stderr
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static std::string join(const std::string &a, const std::string &b) { if (a.empty()) return b; if (!b.empty() && b[0] == '/') return b; return a + "/" + b; }
 
 // fn(k) for k in [0, n) on up to nthreads host threads (ingest: OBJ text parsing / PNG inflate; egress: file writes)
-static void parallel_for(size_t n, int nthreads, const std::function<void(size_t)> &fn) {
+// (fn also gets the index of the worker that runs it: the workers' scratch buffers outlive the call)
+static void parallel_for_w(size_t n, int nthreads, const std::function<void(size_t, size_t)> &fn) {
   const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), n));
-  if (nt <= 1) { for (size_t k = 0; k < n; k++) fn(k); return; }
+  if (nt <= 1) { for (size_t k = 0; k < n; k++) fn(k, 0); return; }
   std::atomic<size_t> next{0};
   std::vector<std::thread> th;
-  for (size_t t = 0; t < nt; t++) th.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(k); });
+  for (size_t t = 0; t < nt; t++) th.emplace_back([&, t] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(k, t); });
   for (auto &t : th) t.join();
 }
+static void parallel_for(size_t n, int nthreads, const std::function<void(size_t)> &fn) { parallel_for_w(n, nthreads, [&](size_t k, size_t) { fn(k); }); }
 
 int main(int argc, char **argv) {
   if (argc < 2) { std::printf("❌ Invalid number of arguments. Please supply project-config.json as argument\n"); return 1; }
@@ -50,6 +54,7 @@ int main(int argc, char **argv) {
     std::printf("✅ Written template object to project-config-template.json\n"); return 0;
   }
   const auto t_start = std::chrono::steady_clock::now();
+  { const char *e = std::getenv("UVOL_TIMING"); g_timing = e && *e == '1'; }
   int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
@@ -110,37 +115,49 @@ int main(int argc, char **argv) {
     // Segment-aligned blocks of frames per GPU (shard_plan): rank g gets the frames of ITS texture segments, so a
     // GPU's geometry and texture outputs cover the same time span; each GPU encodes batches of frames_per_batch frames.  The OBJ text
     // of batch b+1 is parsed by the ingest threads while the GPU encodes batch b, .drc files are written in parallel.
-    struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; };
+    // Two batch objects per GPU are recycled (the one being loaded, the one being encoded): their meshes, the ingest workers' scratch
+    // buffers and the output buffers keep their capacity, so after the first two batches the stage allocates nothing.
+    struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; std::vector<std::unique_ptr<uint8_t[]>> outs; std::vector<size_t> ocap; };
     for (int g = 0; g < n_gpus; g++) geo_threads.emplace_back([&, g] {
       const std::vector<std::string> &files = obj_files;
       const ShardPlan sp = shard_plan((long)files.size(), B, n_gpus, g);
       const size_t lo = (size_t)sp.first_frame, hi = lo + (size_t)sp.n_frames;
-      auto load = [&](size_t b0) {
-        auto Bt = std::make_shared<GeoBatch>(); Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; Bt->ms.resize(Bt->nb);
+      std::shared_ptr<GeoBatch> pool[2] = { std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>() }; size_t n_loads = 0;
+      std::vector<IngestScratch> scratch((size_t)std::max(1, ingest_threads));
+      auto load = [&](size_t b0, size_t slot) {
+        std::shared_ptr<GeoBatch> Bt = pool[slot]; Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; Bt->bad = -1; Bt->err.clear();
+        if (Bt->ms.size() < Bt->nb) Bt->ms.resize(Bt->nb);
         std::mutex mu;
-        parallel_for(Bt->nb, ingest_threads, [&](size_t k) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), Bt->ms[k], e)) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = e; } } });
+        const double tl0 = now_ms();
+        parallel_for_w(Bt->nb, ingest_threads, [&](size_t k, size_t w) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), Bt->ms[k], e, &scratch[w])) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = e; } } });
+        if (g_timing && Bt->nb) std::fprintf(stderr, "[uvolenc-timing] geo load  b0=%zu n=%zu %.0f ms\n", b0, Bt->nb, now_ms() - tl0);
         return Bt;
       };
-      std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo);
+      std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) & 1);
       for (size_t b0 = lo; b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
+        const double tw0 = now_ms();
         std::shared_ptr<GeoBatch> Bt = nextb.get();
-        nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch);
+        const double tw1 = now_ms();
+        nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch, (n_loads++) & 1);      // the other object: the previous batch is done with it
         const size_t nb = Bt->nb;
         if (Bt->bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)Bt->bad].c_str(), Bt->err.c_str()); geo_failed = (int)(b0 + (size_t)Bt->bad); break; }
-        std::vector<uvol_mesh> um(nb); std::vector<std::unique_ptr<uint8_t[]>> outs(nb);
+        std::vector<uvol_mesh> um(nb); std::vector<std::unique_ptr<uint8_t[]>> &outs = Bt->outs; if (outs.size() < nb) { outs.resize(nb); Bt->ocap.resize(nb, 0); }
         std::vector<uint8_t *> op(nb); std::vector<size_t> caps(nb), lens(nb); std::vector<int> st(nb);
         for (size_t k = 0; k < nb; k++) {
           const ObjMesh &o = Bt->ms[k]; uvol_mesh &m = um[k]; std::memset(&m, 0, sizeof m);
           m.pos = o.pos.data(); m.n_pos = (uint32_t)o.pos.size() / 3; m.idx_pos = o.idx_pos.data(); m.n_faces = (uint32_t)o.idx_pos.size() / 3;
           if (!o.uv.empty()) { m.uv = o.uv.data(); m.n_uv = (uint32_t)o.uv.size() / 2; m.idx_uv = o.idx_uv.data(); }
           if (!o.nrm.empty()) { m.nrm = o.nrm.data(); m.n_nrm = (uint32_t)o.nrm.size() / 3; m.idx_nrm = o.idx_nrm.data(); }
-          caps[k] = uvol_mesh_bound(&m); outs[k].reset(new uint8_t[caps[k]]); op[k] = outs[k].get();          // (not zero-filled: the bound is a worst case)
+          caps[k] = uvol_mesh_bound(&m); if (Bt->ocap[k] < caps[k]) { outs[k].reset(new uint8_t[caps[k]]); Bt->ocap[k] = caps[k]; } op[k] = outs[k].get();   // (not zero-filled: the bound is a worst case)
         }
+        const double te0 = now_ms();
         if (uvol_encode_mesh_batch(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data()) != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); geo_failed = (int)b0; break; }
         for (size_t k = 0; k < nb; k++) if (st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); geo_failed = (int)(b0 + k); break; }   // scripts/Encoder.py:263-266
         if (geo_failed >= 0) break;
+        const double te1 = now_ms();
         std::atomic<int> wbad{-1};
         parallel_for(nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, b0 + k); if (!write_file(join(geo_dir, name), outs[k].get(), lens[k])) wbad = (int)(b0 + k); });
+        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] geo batch b0=%zu: waited for load %.0f ms, prepare %.0f, encode %.0f, write %.0f\n", b0, tw1 - tw0, te0 - tw1, te1 - te0, now_ms() - te1);
         if (wbad >= 0) { geo_failed = wbad.load(); break; }
       }
       if (nextb.valid()) nextb.wait();
@@ -161,28 +178,37 @@ int main(int argc, char **argv) {
     // through the batched entry point (one launch per stage for all of them); PNGs of the next call are inflated by the
     // ingest threads meanwhile.  A short last segment (fewer layers) is encoded on its own.
     const int segs_per_call = std::max(1, frames_per_batch / std::max(1, cfg.ktx2_batch_size));
-    struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::string err; int bad = -1; };
+    struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::vector<std::vector<Image>> spare; std::string err; int bad = -1; };
     for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
       const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;       // = shard_plan's segment block
-      auto load = [&](size_t s0) {
-        auto T = std::make_shared<TexBatch>(); T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->imgs.resize(T->ns);
-        for (auto &v : T->imgs) v.resize((size_t)B);
+      std::shared_ptr<TexBatch> pool[2] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
+      std::vector<IngestScratch> scratch((size_t)std::max(1, ingest_threads));
+      auto load = [&](size_t s0, size_t slot) {
+        std::shared_ptr<TexBatch> T = pool[slot]; T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->bad = -1; T->err.clear();
+        // recycled Image objects keep their 16.8 MB pixel buffers (a short last segment shrinks imgs[s]; the layers come back from `spare`)
+        for (auto &v : T->imgs) for (auto &im : v) { T->spare.emplace_back(); T->spare.back().push_back(std::move(im)); }
+        T->imgs.clear(); T->imgs.resize(T->ns);
+        for (auto &v : T->imgs) { v.resize((size_t)B); for (auto &im : v) if (!T->spare.empty()) { im = std::move(T->spare.back()[0]); T->spare.pop_back(); } }
+        const double tl0 = now_ms();
         std::mutex mu; std::vector<std::vector<uint8_t>> present(T->ns, std::vector<uint8_t>((size_t)B, 0));
-        parallel_for(T->ns * (size_t)B, ingest_threads, [&](size_t j) {
+        parallel_for_w(T->ns * (size_t)B, ingest_threads, [&](size_t j, size_t wk) {
           const size_t s = j / (size_t)B; const int k = (int)(j % (size_t)B);
           char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s0 + s] + k));
           std::string e;
-          if (read_png(path, T->imgs[s][(size_t)k], e)) present[s][(size_t)k] = 1;
+          if (read_png(path, T->imgs[s][(size_t)k], e, &scratch[wk])) present[s][(size_t)k] = 1;
           else if (k == 0 || starts[s0 + s] + k < cfg.ktx2_file_count) { std::lock_guard<std::mutex> l(mu); if (T->bad < 0 || (int)s < T->bad) { T->bad = (int)s; T->err = e; } }
         });
         for (size_t s = 0; s < T->ns; s++) { size_t n = 0; while (n < (size_t)B && present[s][n]) n++; T->imgs[s].resize(n); }   // layers of a short last segment
+        if (g_timing && T->ns) std::fprintf(stderr, "[uvolenc-timing] tex load  s0=%zu n=%zu segments %.0f ms\n", s0, T->ns, now_ms() - tl0);
         return T;
       };
       auto fail = [&](int first, const char *why) { std::printf("Failed to compress images with indices: [%d, %d]\n%s\n", first, first + B, why); tex_failed = first; };   // :293-298
-      std::future<std::shared_ptr<TexBatch>> nextb = std::async(std::launch::async, load, lo);
+      std::future<std::shared_ptr<TexBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) & 1);
       for (size_t s0 = lo; s0 < hi && tex_failed < 0; s0 += (size_t)segs_per_call) {
+        const double tw0 = now_ms();
         std::shared_ptr<TexBatch> T = nextb.get();
-        nextb = std::async(std::launch::async, load, s0 + (size_t)segs_per_call);
+        const double tw1 = now_ms();
+        nextb = std::async(std::launch::async, load, s0 + (size_t)segs_per_call, (n_loads++) & 1);
         if (T->bad >= 0) { fail(starts[s0 + (size_t)T->bad], T->err.c_str()); break; }
         const uint32_t w = T->imgs[0][0].w, h = T->imgs[0][0].h; bool same = true;
         for (auto &seg : T->imgs) for (auto &im : seg) if (im.w != w || im.h != h) same = false;
@@ -202,6 +228,7 @@ int main(int argc, char **argv) {
           const size_t cap = uvol_texture_bound(w, h, (int)ptrs.size()); outs[s].reset(new uint8_t[cap]);
           if (uvol_encode_texture_segment(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].get(), cap, &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
         }
+        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] tex batch s0=%zu: waited for load %.0f ms, encode (+prepare) %.0f\n", s0, tw1 - tw0, now_ms() - tw1);
         if (tex_failed >= 0) break;
         std::atomic<int> wbad{-1};
         parallel_for(T->ns, ingest_threads, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].get(), lens[s])) wbad = starts[s0 + s]; });
