@@ -36,13 +36,19 @@ obj_mb = os.path.getsize(os.path.join(root, "OBJ", "frame_00000.obj")) / 1e6; pn
 cfg = {"name": "e2e", "OBJFilesPath": os.path.join(root, "OBJ", "frame_#####.obj"), "ImagesPath": os.path.join(root, "PNG", "export_#####.png"),
        "KTX2_FIRST_FILE": 0, "KTX2_FILE_COUNT": n, "KTX2_BATCH_SIZE": 5, "GEOMETRY_FRAME_RATE": 30, "TEXTURE_FRAME_RATE": 30, "OutputDirectory": os.path.join(root, "out")}
 json.dump(cfg, open(os.path.join(root, "project-config.json"), "w"))
-threads = str(min(64, max(4, (os.cpu_count() or 8) // 2)))
-cmd = [os.path.join(ROOT, "universal-volumetric_amd", "bin", "uvolenc"), os.path.join(root, "project-config.json"), "--batch-frames", str(min(n, 240)), "--ingest-threads", threads] + extra
+def quota_cpus():                          # what uvolenc's own default is based on (cgroup v2 quota, else the hardware threads)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return os.cpu_count() if q == "max" else max(1, min(os.cpu_count(), -(-int(q) // int(per))))
+    except Exception:
+        return os.cpu_count() or 8
+threads = "default"
+cmd = [os.path.join(ROOT, "universal-volumetric_amd", "bin", "uvolenc"), os.path.join(root, "project-config.json")] + (["--batch-frames", str(min(n, 120))] if "--batch-frames" not in extra else []) + extra
 t = time.perf_counter(); r = subprocess.run(cmd, cwd=root, capture_output=True, text=True); wall = time.perf_counter() - t
 m = re.search(r"encode phase ([0-9.]+) s, ([0-9.]+) frames/s", r.stdout)
 out_dir = os.path.join(root, "out")
 print(json.dumps({"what": "uvolenc end to end: %d OBJ (%.1f MB text each) + %d PNG (%.1f MB each) files -> .drc / .ktx2 / uvol.json on disk" % (n, obj_mb, n, png_mb),
-                  "rc": r.returncode, "frames": n, "ingest_threads_per_stage": int(threads), "host_cores": os.cpu_count(), "args": extra,
+                  "rc": r.returncode, "frames": n, "ingest_threads_per_stage": threads, "host_hw_threads": os.cpu_count(), "host_cpus_usable": quota_cpus(), "args": extra,
                   "encode_phase_s": float(m.group(1)) if m else None, "frames_per_s_encode_phase": float(m.group(2)) if m else None,
                   "frames_per_s_process_wall": n / wall, "generate_inputs_s": t_gen,
                   "drc_files": len(os.listdir(os.path.join(out_dir, "geometry_draco"))) if r.returncode == 0 else 0,

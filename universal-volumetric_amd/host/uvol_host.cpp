@@ -11,6 +11,7 @@
 #include <fstream>
 #include <sstream>
 #include <sys/stat.h>
+#include <thread>
 #include <zlib.h>
 
 namespace uvolh {
@@ -186,6 +187,18 @@ std::string config_template() {                                          // scri
 
 // ------------------------------------------------------------------ files
 bool write_file(const std::string &path, const void *data, size_t n) { FILE *f = std::fopen(path.c_str(), "wb"); if (!f) return false; bool ok = std::fwrite(data, 1, n, f) == n; std::fclose(f); return ok; }
+unsigned effective_cpus() {
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64] = {0}; long long period = 0;
+    if (std::fscanf(f, "%63s %lld", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) {
+      const long long quota = std::atoll(a);
+      if (quota > 0) hw = (unsigned)std::max<long long>(1, std::min<long long>(hw, (quota + period - 1) / period));
+    }
+    std::fclose(f);
+  }
+  return hw;
+}
 bool read_file(const std::string &path, std::vector<uint8_t> &d) {
   FILE *f = std::fopen(path.c_str(), "rb"); if (!f) return false;
   std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);

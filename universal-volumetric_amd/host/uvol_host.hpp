@@ -56,6 +56,9 @@ struct IngestScratch { std::vector<uint8_t> file, idat, raw, zero; std::vector<l
 bool read_obj(const std::string &path, ObjMesh &m, std::string &err, IngestScratch *scratch = nullptr);
 struct Image { uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; };
 bool read_png(const std::string &path, Image &img, std::string &err, IngestScratch *scratch = nullptr);
+// CPUs this process may actually use: the cgroup v2 quota (cpu.max) when there is one, else the hardware thread count.  A container
+// that sees 256 hardware threads under a 16-CPU quota gets SLOWER with more than ~16 runnable threads (measured: DESIGN section 6).
+unsigned effective_cpus();
 bool write_file(const std::string &path, const void *data, size_t n);
 bool read_file(const std::string &path, std::vector<uint8_t> &data);
 std::vector<std::string> list_dir(const std::string &dir);

@@ -92,7 +92,9 @@ int main(int argc, char **argv) {
   // one geometry and one texture context (= HIP stream) per GPU: the two stages of a GPU run side by side
   std::vector<uvol_ctx *> ctxs((size_t)n_gpus, nullptr), tctxs((size_t)n_gpus, nullptr);
   for (int g = 0; g < n_gpus; g++) if (uvol_ctx_create(device0 + g, &prm, &ctxs[g]) != UVOL_OK || uvol_ctx_create(device0 + g, &prm, &tctxs[g]) != UVOL_OK) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
-  if (ingest_threads <= 0) ingest_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency() / (2u * (unsigned)n_gpus)));
+  // default: the CPUs this process may use (cgroup quota aware) shared by the two stages of every GPU.  Measured under a 16-CPU
+  // quota (960 frames): 177 / 182 / 179 / 173 / 134 frames/s with 8 / 12 / 16 / 24 / 64 threads per stage
+  if (ingest_threads <= 0) ingest_threads = (int)std::max(1u, std::min(48u, effective_cpus() / (2u * (unsigned)n_gpus)));
 
   std::printf("🎯 Dealing with Geomety data\n");
   if (!cfg.abc_file_path.empty()) { std::printf("❌ ABCFilePath needs Blender (bpy); export OBJ files and use OBJFilesPath\n"); return 1; }
