@@ -171,3 +171,58 @@ def test_obj_number_parser_equals_strtof(H, tmp_path):
     want = np.array([libc.strtof(t.encode(), None) for t in toks], np.float32)
     bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
     assert len(bad) == 0, [(toks[i], got[i], want[i]) for i in bad[:5]]
+
+
+def test_png_filters_modes_and_both_inflaters(tmp_path):
+    """read_png un-filters rows in place with one loop per filter type and inflates through libdeflate when the shared library is there,
+    else zlib: every PNG filter type (rows written by hand), 8- and 16-bit, grey / grey+alpha / RGB / RGBA / palette with tRNS, and both
+    inflaters (UVOL_NO_LIBDEFLATE=1 in a child process: the choice is made once per process) must give PIL's pixels."""
+    import struct, subprocess, sys, zlib
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    h, w = 37, 53
+    base = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] + rng.integers(0, 9, (h, w, 4))).astype(np.uint8)      # smooth + noise: all filters pay
+
+    def png_with_filters(arr):                                           # arr [h, w, c] uint8; row y uses filter y % 5
+        hh, ww, c = arr.shape; raw = bytearray(); prev = np.zeros(ww * c, np.int32)
+        for y in range(hh):
+            cur = arr[y].reshape(-1).astype(np.int32); ft = y % 5
+            a = np.concatenate([np.zeros(c, np.int32), cur[:-c]]); b = prev; cc = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+            if ft == 0: f = cur
+            elif ft == 1: f = cur - a
+            elif ft == 2: f = cur - b
+            elif ft == 3: f = cur - (a + b) // 2
+            else:
+                p = a + b - cc; pa, pb, pc = abs(p - a), abs(p - b), abs(p - cc)
+                f = cur - np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, cc))
+            raw.append(ft); raw += bytes((f & 255).astype(np.uint8)); prev = cur
+        def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+        ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+        z = zlib.compress(bytes(raw), 6)
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", ww, hh, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+    files = []
+    for c in (1, 2, 3, 4):
+        p = tmp_path / ("filters%d.png" % c); p.write_bytes(png_with_filters(base[..., :c].copy())); files.append(p)
+    for name, im in (("rgb16", Image.fromarray(rng.integers(0, 65536, (9, 11)).astype(np.uint16))),
+                     ("pal", Image.fromarray(rng.integers(0, 256, (12, 13, 3), dtype=np.uint8), "RGB").quantize(17)),
+                     ("la", Image.fromarray(rng.integers(0, 256, (8, 7, 2), dtype=np.uint8), "LA"))):
+        p = tmp_path / (name + ".png")
+        if name == "pal": im.save(p, transparency=3)
+        else: im.save(p)
+        files.append(p)
+    prog = (
+        "import sys, ctypes as C, numpy as np\n"
+        "from PIL import Image\n"
+        "H = C.CDLL(sys.argv[1])\n"
+        "for f in sys.argv[2:]:\n"
+        "    want = np.array(Image.open(f).convert('RGBA')) if Image.open(f).mode != 'I;16' else None\n"
+        "    im = Image.open(f); wh = (C.c_uint * 2)(); buf = np.zeros((im.size[1], im.size[0], 4), np.uint8)\n"
+        "    assert H.uvolh_read_png(f.encode(), wh, buf.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_size_t(buf.nbytes)) == 0, f\n"
+        "    if want is None:\n"
+        "        g = (np.array(im) >> 8).astype(np.uint8); want = np.stack([g, g, g, np.full_like(g, 255)], -1)\n"
+        "    assert (wh[0], wh[1]) == im.size and np.array_equal(buf, want), f\n"
+        "print('ok')\n")
+    lib = os.path.join(ROOT, "universal-volumetric_amd", "libuvolhost.so")
+    for env_extra in ({}, {"UVOL_NO_LIBDEFLATE": "1"}):
+        out = subprocess.run([sys.executable, "-c", prog, lib] + [str(f) for f in files], env=dict(os.environ, **env_extra), capture_output=True, text=True)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
