@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -222,6 +225,20 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
 // and each chunk goes over in one DMA at link speed while the threads fill the other buffer.
 // ------------------------------------------------------------------------------------------------
 struct UvolUpItem { size_t dev_off; const void *src; size_t bytes; };     // sorted by dev_off, non-overlapping
+// Contexts of one process share the host link.  When a geometry and a texture context upload at the same time (uvolenc, the
+// PCIe-inclusive bench variant) each gets half of it and BOTH encoders start late; chunks are therefore issued shortest-
+// remaining-upload first, so the smaller batch (the meshes) is on the device - and being encoded - while the larger one goes over.
+struct UvolUpSched {
+  std::mutex m; std::condition_variable cv; std::map<uint64_t, size_t> rem; uint64_t next_id = 1;
+  uint64_t enter(size_t total) { std::lock_guard<std::mutex> l(m); const uint64_t id = next_id++; rem[id] = total; return id; }
+  void turn(uint64_t id) {                                   // blocks until `id` has the least bytes left (ties: the older one)
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { const size_t mine = rem[id]; for (auto &kv : rem) if (kv.first != id && (kv.second < mine || (kv.second == mine && kv.first < id))) return false; return true; });
+  }
+  void progress(uint64_t id, size_t bytes) { { std::lock_guard<std::mutex> l(m); size_t &r = rem[id]; r = r > bytes ? r - bytes : 0; } cv.notify_all(); }
+  void leave(uint64_t id) { { std::lock_guard<std::mutex> l(m); rem.erase(id); } cv.notify_all(); }
+};
+inline UvolUpSched g_uvol_up_sched;
 static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std::vector<UvolUpItem> &items) {
   if (items.empty()) return UVOL_OK;
   const size_t total = items.back().dev_off + items.back().bytes;
@@ -235,8 +252,11 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
     ctx->up_cap = CH;
   }
   size_t first = 0; int buf = 0; bool used[2] = { false, false };
+  const uint64_t sid = g_uvol_up_sched.enter(total);
+  struct Leave { uint64_t id; ~Leave() { g_uvol_up_sched.leave(id); } } leave_{ sid };
   for (size_t c0 = 0; c0 < total; c0 += CH, buf ^= 1) {
     const size_t c1 = std::min(total, c0 + CH);
+    g_uvol_up_sched.turn(sid);
     if (used[buf]) UVOL_HIP_CHECK(ctx, hipEventSynchronize(ctx->up_ev[buf]));       // the DMA that last read this buffer is done
     while (first < items.size() && items[first].dev_off + items[first].bytes <= c0) first++;
     size_t last = first; while (last < items.size() && items[last].dev_off < c1) last++;
@@ -263,6 +283,7 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
     UVOL_HIP_CHECK(ctx, hipMemcpyAsync(dev_base + c0, pin, c1 - c0, hipMemcpyHostToDevice, ctx->stream));
     UVOL_HIP_CHECK(ctx, hipEventRecord(ctx->up_ev[buf], ctx->stream));
     used[buf] = true;
+    g_uvol_up_sched.progress(sid, c1 - c0);
   }
   return UVOL_OK;
 }
