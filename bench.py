@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--tex-delay-ms", type=float, default=0.0, help="DIAGNOSTIC: the texture streams start each pass (--lockstep) / their first pass this long after the geometry streams")
     ap.add_argument("--geo-stagger-ms", type=float, default=0.0, help="one-time start delay of geometry stream g: g * this")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
+    ap.add_argument("--tex-cu", default="", help="MOD:MASKHEX: texture streams restricted to the CUs with (index mod MOD) in MASK; the geometry streams keep all CUs")
     ap.add_argument("--cu-split", type=int, default=0, help="16*G+T: CU residue masks (mod 4) for the geometry / texture streams, e.g. 0x7*16+0x8 = 120")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     args = ap.parse_args()
@@ -121,6 +122,8 @@ def main():
         gcfg.update(stream_priority=1)
     if args.traverse_vbits_l2 == 1:
         gcfg.update(traverse_vbits_l2=1)
+    if args.tex_cu:            # --tex-cu MOD:MASK: the texture streams only run on CUs whose index modulo MOD has its bit set in MASK (hex)
+        m_, r_ = args.tex_cu.split(":"); tcfg.update(cu_mod=int(m_), cu_residues=int(r_, 16))
     if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)
         gcfg.update(cu_mod=4, cu_residues=int(args.cu_split) // 16); tcfg.update(cu_mod=4, cu_residues=int(args.cu_split) % 16)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]
