@@ -1,4 +1,4 @@
-# tools/exp_simt.sh — round 2 experiment: wave-per-walker (LDS bitmaps) vs lane-per-walker (UVOL_SIMT_W) geometry walkers
+# tools/experiments/exp_simt.sh — round 2 experiment: wave-per-walker (LDS bitmaps) vs lane-per-walker (UVOL_SIMT_W) geometry walkers
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r02_a; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 UVOL_SIMT_W=4 python -m pytest tests/test_gpu_geom.py -m gpu -x -q > $O/pytest_simt.log 2>&1; echo "pytest rc $?" >> $O/pytest_simt.log
