@@ -95,6 +95,13 @@
 #define UVOL_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
 
+// occupancy target of a kernel (waves per SIMD): an attribute hipcc understands, nothing in the tests/hipemu build
+#ifdef HIPEMU
+#define UVOL_WAVES_PER_EU(n)
+#else
+#define UVOL_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
 // dynamic LDS: `extern __shared__` on the GPU, the shim's per-workgroup buffer in the tests/hipemu build
 #ifdef HIPEMU
 #define UVOL_DYN_SMEM(T, name) T *name = reinterpret_cast<T *>(hipemu_dyn_smem)
