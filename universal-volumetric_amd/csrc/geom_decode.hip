@@ -726,6 +726,7 @@ extern "C" int uvol_drc_info(const uint8_t *drc, size_t len, uint32_t *n_faces, 
 
 // geom_encode.hip: k_pack_faces + k_traverse + k_v2d over tables 1..3 of a GeoJob array (the encoder's own sequencing kernels)
 int geo_run_traversals(uvol_ctx *ctx, GeoJob *gj, int n, uint32_t max_nfi, uint32_t max_vals);
+bool geo_records8(uint32_t max_nfi);
 
 #define GLAUNCH(k, grid, block, shmem, ...)                                                      \
   do {                                                                                           \
@@ -736,7 +737,7 @@ int geo_run_traversals(uvol_ctx *ctx, GeoJob *gj, int n, uint32_t max_nfi, uint3
 
 // workspace of one frame (base == nullptr: size only); also wires the GeoJob view the shared traversal kernels read:
 // table 1 = base corner table, 2 / 3 = attribute tables 0 / 1
-static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base) {
+static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base, bool r8) {
   size_t o = 0;
   auto take = [&](size_t bytes) -> uint8_t * { uint8_t *p = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return p; };
   const size_t nf = (size_t)J.nf, nc = 3 * nf, maxv = (size_t)J.nev + nf + 8;          // nsplit <= nf
@@ -757,7 +758,7 @@ static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base) {
   G.status = 0; G.nf = (uint32_t)nf; G.nc = (uint32_t)nc; G.nad = 2; G.nverts = 0xffffffffu; G.ecap = (uint32_t)(nc + 3);
   G.nopp = J.opp; G.bvert = J.c2v; G.avert[0] = J.t_c2v[0]; G.avert[1] = J.t_c2v[1]; G.seam[0] = J.edge_seam[0]; G.seam[1] = J.edge_seam[1];
   G.vopen_d[1] = J.vopen[0]; G.vopen_d[2] = J.vopen[1]; G.vopen_d[3] = J.vopen[2];
-  for (int k = 1; k < 4; k++) G.rec[k] = (int32_t *)take(64 * (nf + 1));
+  for (int k = 1; k < 4; k++) G.rec[k] = (int32_t *)take((r8 ? 32 : 64) * (nf + 1));     // 8- or 16-byte corner records, decided per batch (geo_records8)
   for (int k = 0; k < 3; k++) { G.order[k] = (int32_t *)take(4 * (nc + 3)); G.v2d[k] = (int32_t *)take(4 * (nc + 3)); G.t_stack[k] = (int32_t *)take(4 * (nf + 2)); G.t_vvis[k] = take(nc + 64); }
   return o;
 }
@@ -769,6 +770,8 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   std::vector<size_t> foff((size_t)n), woff((size_t)n), ooff((size_t)n);
   size_t ftot = 0, wtot = 0, otot = 0; uint32_t max_nf = 0, max_nev = 0;
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  bool r8 = true;                                                        // record format of the batch: every frame's face count must allow 8-byte records
+  { uint32_t mf = 0; for (int i = 0; i < n; i++) { uint32_t nev = 0, nf = 0; if (gdec_header(files[i], lens[i], &nev, &nf)) mf = std::max(mf, nf); } r8 = geo_records8(mf); }
   for (int i = 0; i < n; i++) {
     uint32_t nev = 0, nf = 0;
     if (!gdec_header(files[i], lens[i], &nev, &nf)) { ctx->set_error("frame %d: not a Draco 2.2 edgebreaker mesh", i); return UVOL_E_INVALID; }
@@ -776,7 +779,7 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
     GeoDecJob &J = T->hjobs[i]; J.nf = (int32_t)nf; J.nev = (int32_t)nev; J.file_len = (uint32_t)lens[i];
     max_nf = std::max(max_nf, nf); max_nev = std::max(max_nev, nev);
     foff[i] = ftot; ftot += a256(lens[i] + 16);
-    GeoJob gtmp{}; const size_t w = gdec_carve(J, gtmp, nullptr);
+    GeoJob gtmp{}; const size_t w = gdec_carve(J, gtmp, nullptr, r8);
     woff[i] = wtot; wtot += a256(w);
     { const size_t nc = 3 * (size_t)nf; ooff[i] = otot; otot += 3 * (a256(4 * 3 * nc) + a256(4 * nc)); }
   }
@@ -792,7 +795,7 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
     uint8_t *fd = (uint8_t *)T->files.p + foff[i];
     UVOL_HIP_CHECK(ctx, hipMemcpyAsync(fd, files[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
     J.file = fd; J.status = 0;
-    (void)gdec_carve(J, G, (uint8_t *)T->slab.p + woff[i]);
+    (void)gdec_carve(J, G, (uint8_t *)T->slab.p + woff[i], r8);
     const size_t nc = 3 * (size_t)J.nf;
     uint8_t *ob = (uint8_t *)T->outs.p + ooff[i]; size_t oo = 0;
     for (int k = 0; k < 3; k++) { J.o_val[k] = (float *)(ob + oo); oo += a256(4 * 3 * nc); J.o_idx[k] = (uint32_t *)(ob + oo); oo += a256(4 * nc); }

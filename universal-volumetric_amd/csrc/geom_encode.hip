@@ -2382,6 +2382,7 @@ static inline bool geo_rec8(uint32_t max_nfi) {
   static const bool force16 = [] { const char *e = getenv("UVOL_REC16"); return e && *e == '1'; }();
   return !force16 && 4ull * max_nfi < (1ull << 20);
 }
+bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi); }          // the decode path sizes its record tables with the same rule
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) { const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
