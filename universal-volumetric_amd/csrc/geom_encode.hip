@@ -670,12 +670,36 @@ template <> struct RecOps<true> {
   static __device__ __forceinline__ void take(const Pre &p, int &vi, int &rc, int &lc) { const uint32_t lo = (uint32_t)UVOL_READFIRST(p.x), hi = (uint32_t)UVOL_READFIRST(p.y); rec8_dec(lo, hi, vi, rc, lc); }
 };
 
+// Output staging of the one-lane LDS walkers.  gfx950 has ONE counter (vmcnt) for loads and stores and the compiler treats a queue
+// that holds both as unordered: with a store outstanding, the wait for the record the next step needs becomes vmcnt(0) and also
+// waits for the acknowledgement of the proc[] / symb[] (order[]) stores issued a moment ago - a second memory round trip per face
+// on top of the record load.  The walkers therefore write their output streams to LDS (lgkmcnt) and flush WALK_STG entries at a
+// time with 16-byte stores: one store acknowledgement per WALK_STG faces instead of one per face.
+#define WALK_STG 256                                    // staged entries (multiple of 16)
+#define WALK_STG_DWORDS (WALK_STG + WALK_STG / 4)       // int32 entries + one byte per entry
+struct WalkStage {
+  UVOL_L(int32_t) w; UVOL_L(uint8_t) b;
+  __device__ __forceinline__ void init(UVOL_L(uint32_t) lds) { w = (UVOL_L(int32_t))lds; b = (UVOL_L(uint8_t))(lds + WALK_STG); }
+  // entries [n - WALK_STG, n) of the streams leave when n reaches a multiple of WALK_STG (16-byte aligned: arrays are 256-byte aligned)
+  __device__ __forceinline__ void flush_words(UVOL_G(int32_t) dst, int n) {
+    UVOL_G(uvol_i4) d = (UVOL_G(uvol_i4))(dst + (n - WALK_STG)); UVOL_L(const uvol_i4) s = (UVOL_L(const uvol_i4))w;
+#pragma unroll 8
+    for (int i = 0; i < WALK_STG / 4; i++) d[i] = s[i];
+  }
+  __device__ __forceinline__ void flush_bytes(UVOL_G(uint8_t) dst, int n) {
+    UVOL_G(uvol_i4) d = (UVOL_G(uvol_i4))(dst + (n - WALK_STG)); UVOL_L(const uvol_i4) s = (UVOL_L(const uvol_i4))b;
+#pragma unroll 8
+    for (int i = 0; i < WALK_STG / 16; i++) d[i] = s[i];
+  }
+  __device__ __forceinline__ void tail_words(UVOL_G(int32_t) dst, int n) { for (int i = n & ~(WALK_STG - 1); i < n; i++) dst[i] = w[i & (WALK_STG - 1)]; }
+  __device__ __forceinline__ void tail_bytes(UVOL_G(uint8_t) dst, int n) { for (int i = n & ~(WALK_STG - 1); i < n; i++) dst[i] = b[i & (WALK_STG - 1)]; }
+};
 // Edgebreaker walk, one lane per frame: typed pointers (global_* / ds_* instructions, exactly counted waits), no scatter
 // stores (face_time is rebuilt from proc[] by k_face_time).  Per face: ONE 8- or 16-byte record read from HBM — the dependent
 // access that bounds the walk —, one sequential proc/symb store pair, a fire-and-forget ds_or for the face bit and one
 // LDS round trip for the vertex / neighbour bits.  Corners are carried as codes (4 * face + k).
 template <bool R8, typename FB, typename VB>
-__device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
+__device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits, UVOL_L(uint32_t) stg_lds) {
   typedef RecOps<R8> RO;
   const int nf = (int)J.nf;
   const typename RO::Ptr rec = RO::ptr(J.rec[0]);
@@ -683,7 +707,9 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
   UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
   const int dz = UVOL_LANE_ZERO();
+  WalkStage stg; stg.init(stg_lds);
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
+#define W_EMIT(SYM) do { stg.b[nproc & (WALK_STG - 1)] = (uint8_t)(SYM); nproc++; if ((nproc & (WALK_STG - 1)) == 0) { stg.flush_words(proc, nproc); stg.flush_bytes(symb, nproc); } } while (0)
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
   for (int f0 = 0; f0 < nf; f0++) {
     // component starts: fully visited words of the face bitmap are skipped 32 faces at a time
@@ -727,7 +753,7 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
         const int face = x >> 2;
         // both records this step can move to are requested now and taken (readfirstlane) only by the branch that goes there
         const typename RO::Pre pR = RO::pre(rec, (rcn < 0 ? x : rcn) + dz), pL = RO::pre(rec, (lcn < 0 ? x : lcn) + dz);
-        proc[nproc] = 3 * face + (x & 3);
+        stg.w[nproc & (WALK_STG - 1)] = 3 * face + (x & 3);
         pbit_set(fbits, face);
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
@@ -737,12 +763,11 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
 #define W_GO_L() do { x = lcn; RO::take(pL, vi, rcn, lcn); } while (0)
         if (!((vw_ >> (v & 31)) & 1u)) {
           pbit_set(vbits, v);
-          if (!(vi & 1)) { symb[nproc] = T_C; nproc++; W_GO_R(); continue; }
+          if (!(vi & 1)) { W_EMIT(T_C); W_GO_R(); continue; }
         }
         const bool rvis = ((rw_ >> ((rcn >> 2) & 31)) & 1u) != 0, lvis = ((lw_ >> ((lcn >> 2) & 31)) & 1u) != 0;
         const int sym = rvis ? (lvis ? T_E : T_R) : (lvis ? T_L : T_S);
-        symb[nproc] = (uint8_t)sym;
-        nproc++;
+        W_EMIT(sym);
         if (sym == T_E) { sp--; break; }
         if (sym == T_R) { W_GO_L(); continue; }
         if (sym == T_L) { W_GO_R(); continue; }
@@ -755,6 +780,8 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
       }
     }
   }
+#undef W_EMIT
+  stg.tail_words(proc, nproc); stg.tail_bytes(symb, nproc);
   J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
   if (nproc + ninit != nf) J.status = -10;
   J.rb[0].n = (uint32_t)nstart;
@@ -762,23 +789,186 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits) {
   J.rb[0].zeros = z;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cooperative-lane forms of the LDS walkers (the default whenever the bitmaps are in LDS).  A one-lane walk is bound by
+// instruction issue, not by memory: a single wave issues about one instruction per 5 cycles, and a step of eb_walk_lane0 is
+// ~100 instructions (two address computations and loads, three LDS reads behind branches, lane elections around the LDS
+// atomics, scalar bookkeeping) = ~210 ns on top of the ~160 ns its dependent load costs (tools/latbench/seqbench).  Here the
+// per-candidate work of a step is ONE vector instruction each: lane 0 handles the right neighbour, lane 1 the left one, every
+// other lane the tip vertex - one load fetches both neighbours' records, one ds_read their two face-visited words and the
+// vertex-visited word, one ballot turns the three tests into a scalar mask; the record the walk moves to is picked with
+// v_readlane (lane select in an SGPR), so the step has no divergent branch and ~45 instructions.  The current face's bit is set with
+// a plain LDS write (its word is known: a candidate lane read it one step earlier, or the pop test just did), outputs are staged in
+// LDS (WalkStage) and flushed by all 64 lanes.  A second wave of the workgroup reads the walker's position from LDS and touches
+// the 128-byte lines of the record table around it, so that the walker's loads hit in this CU's L1 / this XCD's L2 instead of
+// paying an HBM miss per new line (seqbench: 157 -> 96 ns per dependent load on a strip-ordered table).
+// Results are identical to eb_walk_lane0 / traverse_lane0 (same traversal, same output arrays).
+// ------------------------------------------------------------------------------------------------
+#define WALK_PUB_DWORDS 8                                // [0] walker position (corner code), [1] done flag
+#define WALK_PF_LINES 64                                 // 128-byte lines the helper wave keeps touched around the walker
+template <bool R8> struct CoopRec;
+template <> struct CoopRec<true> {
+  // two v_readlane, then scalar 64-bit shifts (written with 32-bit pieces the compiler moved the funnel shift back to the VALU)
+  static __device__ __forceinline__ void take(const uvol_u2 &p, int sel, int &vi, int &rc, int &lc) {
+    const unsigned long long q = ((unsigned long long)UVOL_READLANE(p.y, sel) << 32) | (unsigned long long)UVOL_READLANE(p.x, sel);
+    vi = (int)((uint32_t)q & 0x1fffffu); rc = (int)((long long)(q << 22) >> 43); lc = (int)((long long)(q << 1) >> 43);
+  }
+};
+template <> struct CoopRec<false> {
+  static __device__ __forceinline__ void take(const uvol_i3 &p, int sel, int &vi, int &rc, int &lc) { vi = (int)UVOL_READLANE(p.x, sel); rc = (int)UVOL_READLANE(p.y, sel); lc = (int)UVOL_READLANE(p.z, sel); }
+};
+// record of `code` as wave-uniform scalars (every lane loads the same address: one request)
+template <bool R8> __device__ __forceinline__ void coop_get(typename RecOps<R8>::Ptr rec, int code, int &vi, int &rc, int &lc) {
+  int a, b, c; RecOps<R8>::get(rec, code, a, b, c); vi = UVOL_READFIRST(a); rc = UVOL_READFIRST(b); lc = UVOL_READFIRST(c);
+}
+// helper wave: keeps WALK_PF_LINES lines of the record table around the walker's published position touched
+__device__ __forceinline__ void walk_prefetch_wave(const int32_t *rec_base, uint32_t rec_bytes, UVOL_L(uint32_t) pub, int shift /* corner code -> 128-byte line */) {
+#ifndef HIPEMU
+  const int lane = (int)(threadIdx.x & 63), nlines = (int)(rec_bytes >> 7);
+  UVOL_G(const uint32_t) r = UVOL_TO_G(const uint32_t, reinterpret_cast<const uint32_t *>(rec_base));
+  int base = -(1 << 30); uint32_t acc = 0;
+  while (!__hip_atomic_load(&pub[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+    const int c = (int)__hip_atomic_load(&pub[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> shift;
+    if (c < base + WALK_PF_LINES / 4 || c >= base + (3 * WALK_PF_LINES) / 4) {
+      base = c - WALK_PF_LINES / 4;
+      const int line = base + lane;
+      if (line >= 0 && line < nlines) acc += r[32 * (size_t)line];
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (acc == 0x9e3779b9u) pub[2] = acc;               // keeps the loads alive
+#endif
+}
+
+template <bool R8>
+__device__ __forceinline__ void eb_walk_coop(GeoJob &J, UVOL_L(uint32_t) lds, uint32_t fw, UVOL_L(uint32_t) pub, int pf) {
+  typedef RecOps<R8> RO;
+  const int lane = (int)(threadIdx.x & 63);
+  const bool cl = lane < 2;                              // candidate lanes: 0 = right neighbour, 1 = left neighbour; the others: tip vertex
+  const int nf = (int)J.nf;
+  const typename RO::Ptr rec = RO::ptr(J.rec[0]);
+  UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack);
+  UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
+  UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
+  UVOL_L(uint32_t) dummy = pub + 4 + (lane & 1);         // where the candidate lanes put the word the vertex lanes write back
+  uint32_t pv = 0, sv = 0;                               // output staging: lane k = entry (nproc & ~63) + k of proc[] / symb[]
+  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
+#define C_FWORD(k) ((uint32_t)UVOL_BCAST0(lds[k]))
+  for (int f0 = 0; f0 < nf; f0++) {
+    if ((f0 & 31) == 0) { while (f0 + 32 <= nf && C_FWORD(f0 >> 5) == 0xffffffffu) f0 += 32; if (f0 >= nf) break; }
+    if ((C_FWORD(f0 >> 5) >> (f0 & 31)) & 1u) continue;
+    int v0[3], r0_[3], l0_[3];
+    for (int k = 0; k < 3; k++) coop_get<R8>(rec, 4 * f0 + k, v0[k], r0_[k], l0_[k]);
+    const int o0[3] = { r0_[2], r0_[0], r0_[1] };
+    int interior = 1, start = 4 * f0;
+    for (int k = 0; k < 3; k++) {
+      if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
+      if (v0[k] & 1) {
+        int ci = 4 * f0 + k, rc = ci;
+        while (rc >= 0) { ci = rc; int v_, r_, o; coop_get<R8>(rec, rc, v_, r_, o); rc = o < 0 ? -1 : code_prv(o); }
+        interior = 0; start = code_prv(ci); break;
+      }
+    }
+    if (lane == 0) start_bits[nstart] = (uint8_t)interior;
+    nstart++;
+    int from;
+    if (interior) {
+      for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; lds[fw + (v >> 5)] = (uint32_t)UVOL_BCAST0(lds[fw + (v >> 5)]) | (1u << (v & 31)); }
+      lds[f0 >> 5] = C_FWORD(f0 >> 5) | (1u << (f0 & 31));
+      if (lane == 0) initc[ninit] = 3 * f0 + 1;
+      ninit++;
+      from = o0[1];
+      if (from < 0 || ((C_FWORD(from >> 7) >> ((from >> 2) & 31)) & 1u)) continue;
+    } else from = start;
+    int sp = 0;
+    if (lane == 0) stack[sp] = from;
+    sp++;
+    int top = from; bool top_known = true;
+    while (sp > 0) {
+      int x;
+      if (top_known) x = top; else { UVOL_WAVE_FENCE(); x = UVOL_BCAST0(stack[sp - 1]); }     // lane 0's own earlier store
+      top_known = false;
+      if (x < 0) { sp--; continue; }
+      uint32_t xw = C_FWORD(x >> 7);                     // face-visited word of x's face
+      if ((xw >> ((x >> 2) & 31)) & 1u) { sp--; continue; }
+      int vi, rcn, lcn;
+      coop_get<R8>(rec, x, vi, rcn, lcn);
+      // One step = straight-line code with ONE taken branch (the back edge): a lone wave pays ~40 cycles of instruction fetch per
+      // taken branch, so the common symbols (C, R, L) are resolved with scalar selects; S / E (a few % of the steps) and the
+      // write-out of the staged outputs (every 64th step) leave the line.
+      for (;;) {
+        const int face = x >> 2;
+        const int cand = lane == 0 ? rcn : lcn; const bool cvalid = cand >= 0;
+        const int ccode = cvalid ? cand : x;
+        const typename RO::Pre pre = RO::pre(rec, ccode);                        // lanes 0 / 1: the two records this step can move to
+        if (pf) pub[0] = (uint32_t)x;                                            // for the prefetch wave
+        lds[face >> 5] = xw | (1u << (face & 31));                               // face visited (plain write: xw is current)
+        pv = UVOL_WRITELANE(3 * face + (x & 3), nproc & 63, pv);
+        const int v = vi >> 1;
+        const uint32_t widx = cl ? (uint32_t)ccode >> 7 : fw + (uint32_t)(v >> 5);
+        const uint32_t sh = cl ? ((uint32_t)cand >> 2) & 31u : (uint32_t)v & 31u;
+        const uint32_t word = lds[widx];
+        const bool hit = ((word >> sh) & 1u) != 0 || (cl && !cvalid);
+        const uint32_t m = (uint32_t)__ballot(hit) & 7u;                         // bit 0: right visited, 1: left visited, 2: tip vertex visited
+        (cl ? dummy : lds + widx)[0] = word | (1u << sh);                        // the tip's bit (already set when it was visited)
+        const bool ccase = (((m >> 2) | (uint32_t)vi) & 1u) == 0;                // tip unvisited and not on a boundary: C
+        const uint32_t sym = ccase ? 0u : 1u + (m & 2u) + ((m & 1u) << 2);       // S = 1, L = 3 (left visited), R = 5 (right visited), E = 7
+        sv = UVOL_WRITELANE(sym, nproc & 63, sv);
+        nproc++;
+        if (__builtin_expect((nproc & 63) == 0, 0)) { proc[nproc - 64 + lane] = (int32_t)pv; symb[nproc - 64 + lane] = (uint8_t)sv; }
+        if (__builtin_expect((0x82u >> sym) & 1u, 0)) {                            // E (7) or S (1): the run of C / R / L steps ends
+          if (sym == 7u) { sp--; break; }
+          nsplit++;
+          if (lane == 0) { stack[sp - 1] = lcn; stack[sp] = rcn; }
+          sp++; top = rcn; top_known = true;
+          break;
+        }
+        const int sel = (int)(sym >> 2);                                          // R (5): the walk goes left; C (0) and L (3): right
+        x = sel ? lcn : rcn;
+        xw = UVOL_READLANE(word, sel);
+        CoopRec<R8>::take(pre, sel, vi, rcn, lcn);
+      }
+    }
+  }
+  if (lane < (nproc & 63)) { proc[(nproc & ~63) + lane] = (int32_t)pv; symb[(nproc & ~63) + lane] = (uint8_t)sv; }
+  if (lane == 0) {
+    J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
+    if (nproc + ninit != nf) J.status = -10;
+    J.rb[0].n = (uint32_t)nstart;
+    UVOL_WAVE_FENCE();
+    uint32_t z = 0; for (int i = 0; i < nstart; i++) z += J.start_bits[i] == 0;
+    J.rb[0].zeros = z;
+  }
+}
+#undef C_FWORD
+
 // LDS: [face bits, fw words][vertex bits, vcap_words]; vcap_words is sized by the host from the input attribute counts and
 // the LDS slot (a table with more vertices keeps its vertex bitmap in global memory).  A mesh whose face bitmap does not fit
 // LDS is walked by the lane-per-walker kernels below (nothing in LDS).
 template <bool R8>
-__global__ void __launch_bounds__(64) k_eb_walk(GeoJob *jobs, int vcap_words) {
+__global__ void __launch_bounds__(128) k_eb_walk(GeoJob *jobs, int vcap_words, int pf) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
-  const uint32_t lane = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool ok = J.status == 0;
   const uint32_t fw = ((uint32_t)J.nf + 31) / 32, vw = (J.nverts_t[0] + 31) / 32, vcw = (uint32_t)vcap_words;
   const bool v_in_lds = vw <= vcw;
-  if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0;
+  const uint32_t stg_off = (fw + vcw + 3u) & ~3u;          // WALK_STG_DWORDS of output staging + WALK_PUB_DWORDS behind the bitmaps
+  if (ok) for (uint32_t k = tid; k < fw + vcw; k += 128) lds[k] = 0;
+  if (tid < WALK_PUB_DWORDS) lds[stg_off + WALK_STG_DWORDS + tid] = 0;
   __syncthreads();
-  if (!ok || lane != 0) return;
-  if (v_in_lds) eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-  else eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)));
+  if (!ok) return;
+  UVOL_L(uint32_t) stg = UVOL_TO_L(uint32_t, lds) + stg_off; UVOL_L(uint32_t) pub = stg + WALK_STG_DWORDS;
+  if (v_in_lds) {
+    if (wave == 1) { if (pf) walk_prefetch_wave(J.rec[0], (uint32_t)((R8 ? 32 : 64) * (size_t)J.nf), pub, R8 ? 4 : 3); return; }
+    eb_walk_coop<R8>(J, UVOL_TO_L(uint32_t, lds), fw, pub, pf);
+    pub[1] = 1u;
+    return;
+  }
+  if (tid != 0) return;
+  eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)), stg);
 }
 
 // face_time[f] = index of the symbol that encoded face f (-1 for the faces that only start a component): the inverse
@@ -1085,13 +1275,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
 // (v2d[], its inverse, is rebuilt by k_v2d).  Same structure as eb_walk_lane0.
 // ------------------------------------------------------------------------------------------------
 template <bool R8, typename FB, typename VB>
-__device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vbits) {
+__device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vbits, UVOL_L(uint32_t) stg_lds) {
   typedef RecOps<R8> RO;
   const int nf = (int)J.nf;
   const typename RO::Ptr rec = RO::ptr(J.rec[1 + t]);
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
   const int dz = UVOL_LANE_ZERO();
+  WalkStage stg; stg.init(stg_lds);
   int n = 0;
+#define T_EMIT(C) do { stg.w[n & (WALK_STG - 1)] = (C); n++; if ((n & (WALK_STG - 1)) == 0) stg.flush_words(order, n); } while (0)
   for (int f = 0; f < nf; f++) {
     if ((f & 31) == 0) { while (f + 32 <= nf && pword(fbits, f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; }
     if (pbit_get(fbits, f)) continue;
@@ -1100,8 +1292,8 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
     sp++;
     int top = x; bool top_known = true;
     { int vn, vp, r_, l_; RO::get(rec, x + 1, vn, r_, l_); RO::get(rec, x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
-      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); order[n] = 3 * f + 1; n++; }
-      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); order[n] = 3 * f + 2; n++; } }
+      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); T_EMIT(3 * f + 1); }
+      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); T_EMIT(3 * f + 2); } }
     while (sp > 0) {
       x = top_known ? top : stack[sp - 1];
       top_known = false;
@@ -1120,7 +1312,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
 #define T_GO_R() do { x = rc; RO::take(pR, vi, rc, lc); } while (0)
 #define T_GO_L() do { x = lc; RO::take(pL, vi, rc, lc); } while (0)
         if (!((vw_ >> (v & 31)) & 1u)) {
-          pbit_set(vbits, v); order[n] = 3 * face + (x & 3); n++;
+          pbit_set(vbits, v); T_EMIT(3 * face + (x & 3));
           if (!(vi & 1)) { T_GO_R(); continue; }
         }
         const bool rvis = ((rw_ >> ((rc >> 2) & 31)) & 1u) != 0, lvis = ((lw_ >> ((lc >> 2) & 31)) & 1u) != 0;
@@ -1131,32 +1323,114 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
       }
     }
   }
+#undef T_EMIT
+  stg.tail_words(order, n);
   J.ne[t] = (uint32_t)n;
   if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
 
+
+// cooperative-lane form of traverse_lane0 (see eb_walk_coop): same traversal, same order[] stream
 template <bool R8>
-__global__ void __launch_bounds__(64) k_traverse(GeoJob *jobs, int vcap_words, int dbg) {
+__device__ __forceinline__ void traverse_coop(GeoJob &J, int t, UVOL_L(uint32_t) lds, uint32_t fw, UVOL_L(uint32_t) pub, int pf) {
+  typedef RecOps<R8> RO;
+  const int lane = (int)(threadIdx.x & 63);
+  const bool cl = lane < 2;
+  const int nf = (int)J.nf;
+  const typename RO::Ptr rec = RO::ptr(J.rec[1 + t]);
+  UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  UVOL_L(uint32_t) dummy = pub + 4 + (lane & 1);
+  uint32_t ov = 0;                                       // staged order[] entries: lane k = entry (n & ~63) + k
+  int n = 0;
+#define C_FWORD(k) ((uint32_t)UVOL_BCAST0(lds[k]))
+#define C_EMIT(C) do { ov = UVOL_WRITELANE((C), n & 63, ov); n++; if ((n & 63) == 0) order[n - 64 + lane] = (int32_t)ov; } while (0)
+  for (int f = 0; f < nf; f++) {
+    if ((f & 31) == 0) { while (f + 32 <= nf && C_FWORD(f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; }
+    if ((C_FWORD(f >> 5) >> (f & 31)) & 1u) continue;
+    int x = 4 * f, sp = 0;
+    if (lane == 0) stack[sp] = x;
+    sp++;
+    int top = x; bool top_known = true;
+    { int vn, vp, r_, l_; coop_get<R8>(rec, x + 1, vn, r_, l_); coop_get<R8>(rec, x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
+      uint32_t w = (uint32_t)UVOL_BCAST0(lds[fw + (vn >> 5)]);
+      if (!((w >> (vn & 31)) & 1u)) { lds[fw + (vn >> 5)] = w | (1u << (vn & 31)); C_EMIT(3 * f + 1); }
+      w = (uint32_t)UVOL_BCAST0(lds[fw + (vp >> 5)]);
+      if (!((w >> (vp & 31)) & 1u)) { lds[fw + (vp >> 5)] = w | (1u << (vp & 31)); C_EMIT(3 * f + 2); } }
+    while (sp > 0) {
+      if (top_known) x = top; else { UVOL_WAVE_FENCE(); x = UVOL_BCAST0(stack[sp - 1]); }
+      top_known = false;
+      if (x < 0) { sp--; continue; }
+      uint32_t xw = C_FWORD(x >> 7);
+      if ((xw >> ((x >> 2) & 31)) & 1u) { sp--; continue; }
+      int vi, rc, lc;
+      coop_get<R8>(rec, x, vi, rc, lc);
+      for (;;) {                                          // straight-line step, see eb_walk_coop
+        const int face = x >> 2;
+        const int cand = lane == 0 ? rc : lc; const bool cvalid = cand >= 0;
+        const int ccode = cvalid ? cand : x;
+        const typename RO::Pre pre = RO::pre(rec, ccode);
+        if (pf) pub[0] = (uint32_t)x;
+        lds[face >> 5] = xw | (1u << (face & 31));
+        const int v = vi >> 1;
+        const uint32_t widx = cl ? (uint32_t)ccode >> 7 : fw + (uint32_t)(v >> 5);
+        const uint32_t sh = cl ? ((uint32_t)cand >> 2) & 31u : (uint32_t)v & 31u;
+        const uint32_t word = lds[widx];
+        const bool hit = ((word >> sh) & 1u) != 0 || (cl && !cvalid);
+        const uint32_t m = (uint32_t)__ballot(hit) & 7u;
+        (cl ? dummy : lds + widx)[0] = word | (1u << sh);
+        // a vertex seen for the first time takes the next place in the order (the slot is simply overwritten otherwise)
+        ov = UVOL_WRITELANE(3 * face + (x & 3), n & 63, ov);
+        const int fresh = (int)((m >> 2) & 1u) ^ 1;
+        n += fresh;
+        if (__builtin_expect(fresh && (n & 63) == 0, 0)) order[n - 64 + lane] = (int32_t)ov;
+        const bool ccase = (((m >> 2) | (uint32_t)vi) & 1u) == 0;
+        const uint32_t k = ccase ? 0u : 1u + (m & 3u);   // 0: go right (new interior vertex); 1: fork; 2: right visited -> left; 3: left visited -> right; 4: dead end
+        if (__builtin_expect((0x12u >> k) & 1u, 0)) {                              // fork (1) or dead end (4)
+          if (k == 4u) { sp--; break; }
+          if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; }
+          sp++; top = rc; top_known = true; break;
+        }
+        const int sel = k == 2u ? 1 : 0;
+        x = sel ? lc : rc;
+        xw = UVOL_READLANE(word, sel);
+        CoopRec<R8>::take(pre, sel, vi, rc, lc);
+      }
+    }
+  }
+#undef C_EMIT
+#undef C_FWORD
+  if (lane < (n & 63)) order[(n & ~63) + lane] = (int32_t)ov;
+  if (lane == 0) {
+    J.ne[t] = (uint32_t)n;
+    if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;
+  }
+}
+
+template <bool R8>
+__global__ void __launch_bounds__(128) k_traverse(GeoJob *jobs, int vcap_words, int dbg) {
   GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.x;
   UVOL_SERIAL_PRIO();
   UVOL_DYN_SMEM(uint32_t, lds);
-  const uint32_t lane = threadIdx.x;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
   const int ai = t > 0 ? t - 1 : 0;
   const bool ok = J.status == 0 && !(t > 0 && (ai >= J.nad || !J.interior_seams[ai]));
   const uint32_t fw = ((uint32_t)J.nf + 31) / 32, vw = (J.nverts_t[1 + t] + 31) / 32, vcw = (uint32_t)vcap_words;
   const bool v_in_lds = vw <= vcw;
-  if (ok) for (uint32_t k = lane; k < fw + vcw; k += 64) lds[k] = 0;
+  const uint32_t stg_off = (fw + vcw + 3u) & ~3u;
+  if (ok) for (uint32_t k = tid; k < fw + vcw; k += 128) lds[k] = 0;
+  if (tid < WALK_PUB_DWORDS) lds[stg_off + WALK_STG_DWORDS + tid] = 0;
   __syncthreads();
-  if (!ok || lane != 0) return;
-#ifndef HIPEMU
-  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
-#endif
-  if (v_in_lds) traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_L(uint32_t, lds) + fw);
-  else traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])));
-#ifndef HIPEMU
-  if (dbg && blockIdx.y == 0) printf("[traverse] table %d: faces=%d verts=%u v_in_lds=%d  %.3f ms\n", t, (int)J.nf, J.ne[t], (int)v_in_lds, (double)(wall_clock64() - t_begin) * 1e-5);
-#endif
+  if (!ok) return;
+  UVOL_L(uint32_t) stg = UVOL_TO_L(uint32_t, lds) + stg_off; UVOL_L(uint32_t) pub = stg + WALK_STG_DWORDS;
+  if (v_in_lds) {
+    if (wave == 1) { if (dbg & 2) walk_prefetch_wave(J.rec[1 + t], (uint32_t)((R8 ? 32 : 64) * (size_t)J.nf), pub, R8 ? 4 : 3); return; }
+    traverse_coop<R8>(J, t, UVOL_TO_L(uint32_t, lds), fw, pub, dbg & 2);
+    pub[1] = 1u;
+    return;
+  }
+  if (tid != 0) return;
+  traverse_lane0<R8>(J, t, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t])), stg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2354,6 +2628,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_clear(GeoJob *jobs) {
 // UVOL_SIMT_W=<1..64> forces the SIMT form with that many lanes per wave, UVOL_WALK_FORCE=global its one-lane-per-wave form
 // (what a mesh too large for LDS gets), UVOL_WALK_FORCE=vglobal LDS walkers with their vertex bitmap in global memory (tests).
 struct WalkPlan { int simt_w; size_t lds; int vcw; };
+static inline int geo_walk_pf() { static const int v = [] { const char *e = getenv("UVOL_WALK_PF"); return (e && *e == '0') ? 0 : 1; }(); return v; }     // UVOL_WALK_PF=0 (diagnostic): LDS walkers without their prefetch wave
 static inline int geo_simt_env() { static const int w = [] { const char *e = getenv("UVOL_SIMT_W"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return w; }
 static WalkPlan walk_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t n_walkers, bool vertex_bits_global = false) {
   WalkPlan P{0, 0, 0};
@@ -2361,14 +2636,14 @@ static WalkPlan walk_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals
   // Vertex bitmap capacity.  At least the largest attribute array of the batch + 6 % (vertices split at seams and
   // non-manifold fans; a table that still exceeds it keeps its vertex bitmap in global memory); then rounded UP to
   // whatever fits the same number of walkers per CU, so the slack of the LDS slot is not wasted.
-  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4;
+  const size_t lds_cu = 150 * 1024 /* what several workgroups can share of a CU's 160 KiB (measured: 3 x 53 KiB does not fit) */, fw_bytes = walk_fw * 4 + (WALK_STG_DWORDS + WALK_PUB_DWORDS) * 4 + 16 /* + output staging, position word */;
   const size_t v_min_bytes = std::min<size_t>((((size_t)max_vals + max_vals / 16 + 31) / 32 + 2) * 4, ((3 * (size_t)max_nfi + 31) / 32) * 4);
   static const int walk_force = [] { const char *e = getenv("UVOL_WALK_FORCE"); return !e ? 0 : (!strcmp(e, "vglobal") ? 1 : (!strcmp(e, "global") ? 2 : 0)); }();
   const bool vglobal = walk_force == 1 || vertex_bits_global;
   size_t per_cu = lds_cu / (fw_bytes + (vglobal ? 4 : v_min_bytes)); if (per_cu < 1) per_cu = 1;
   const size_t slot = (lds_cu / per_cu) & ~(size_t)1023;
   const size_t walk_vcw = vglobal ? 1 : (slot > fw_bytes + v_min_bytes ? (slot - fw_bytes) / 4 : v_min_bytes / 4);
-  P.lds = ((walk_fw + walk_vcw + 3) & ~(size_t)3) * 4; P.vcw = (int)walk_vcw;
+  P.lds = (((walk_fw + walk_vcw + 3) & ~(size_t)3) + WALK_STG_DWORDS + WALK_PUB_DWORDS) * 4; P.vcw = (int)walk_vcw;
   const bool lds_fits = P.lds <= G->max_lds;
   if (geo_simt_env() > 0) P.simt_w = geo_simt_env();
   else if (walk_force == 2 || !lds_fits) P.simt_w = 1;
@@ -2386,8 +2661,8 @@ bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi); }          // th
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) { const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
-  else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(64), P.lds, dj, P.vcw, uvol_debug() ? 1 : 0);
-  else LAUNCH_SM((k_traverse<false>), dim3(3, N), dim3(64), P.lds, dj, P.vcw, uvol_debug() ? 1 : 0);
+  else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
+  else LAUNCH_SM((k_traverse<false>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
 }
 // attribute sequencing of a prepared GeoJob array (tables 1..3): corner records, DepthFirstTraverser, inverse maps.
 // Shared with the decode path (geom_decode.hip), which fills the same job fields from a decoded corner table.
@@ -2542,8 +2817,8 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, r8);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) { const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W; if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
-    else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(64), wp_walk.lds, dj, wp_walk.vcw);
-    else LAUNCH_SM((k_eb_walk<false>), dim3(N), dim3(64), wp_walk.lds, dj, wp_walk.vcw);
+    else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());
+    else LAUNCH_SM((k_eb_walk<false>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside

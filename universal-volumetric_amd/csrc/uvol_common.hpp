@@ -24,6 +24,9 @@
 #else
 #define UVOL_READLANE(v, l) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(l)))
 #endif
+// the wave-uniform `val` into lane `l` (uniform) of a per-lane register, the other lanes keep `old` (v_cmp + v_cndmask; this
+// toolchain has no v_writelane builtin)
+#define UVOL_WRITELANE(val, l, old) ((int)(threadIdx.x & 63) == (int)(l) ? (uint32_t)(val) : (uint32_t)(old))
 
 // intra-wave ordering point between lane 0's stores and the other lanes' loads: lock-step on the GPU (plus a
 // compiler barrier); a real rendezvous in the shim, where lanes are fibers that run ahead of each other
@@ -87,10 +90,14 @@
 #ifdef HIPEMU
 #define UVOL_LANE_ZERO() 0
 #define UVOL_READFIRST(v) (v)
+#define UVOL_BCAST0(v) (__shfl((v), 0))
 #define UVOL_OPAQUE(v) ((void)0)
 #else
 #define UVOL_LANE_ZERO() ((int)__builtin_amdgcn_mbcnt_lo(~0u, 0u))
 #define UVOL_READFIRST(v) (__builtin_amdgcn_readfirstlane((int)(v)))
+// lane 0's value in every lane of a FULLY active wave (the cooperative walkers): readfirstlane on the GPU; in the shim a real
+// exchange, which also is the rendezvous that keeps its free-running lanes from acting on LDS words a faster lane already changed
+#define UVOL_BCAST0(v) (__builtin_amdgcn_readfirstlane((int)(v)))
 // empty asm the optimiser cannot look through: stops it re-associating across `v` (emits no instruction)
 #define UVOL_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif

@@ -43,7 +43,7 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
 
 
 def load(path=None):
-    path = path or DEFAULT_LIB
+    path = path or os.environ.get("UVOL_LIB") or DEFAULT_LIB      # UVOL_LIB: diagnostic builds of the same HIP library (tools/)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950); no CPU fallback exists")
     L = C.CDLL(path)
