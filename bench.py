@@ -8,11 +8,15 @@ texture segments (one batched `uvol_encode_texture_segments_dev` call = that man
 scripts/Encoder.py:279-298), geometry and texture on two HIP streams of the same GPU.  The timed
 region ends when every .drc / .ktx2 byte is in host memory.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W                      # weak scaling: every rank encodes --frames-per-step frames
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --total-frames 1200 ...                    # STRONG scaling (BASELINE configs[3]): ONE job of that many
+                                                                      # frames, split over the ranks by shard.plan; a step = the job
 
-Frames shard one-per-GPU-batch (weak scaling: per-GPU work fixed); the only collective is the final
-32-byte-per-rank manifest gather, over RCCL.
+The only collective is the final 32-byte-per-rank manifest gather, over RCCL.
+On one GPU the line also carries `variants` (never `value`): the same path on the SURVEY §8(d) boundary (host buffers), as small
+jobs (150 / 300 / 1200 frames -> the 8-GPU projection of configs[3]), on a scan-like storage order, and the decode path
+(configs[4]); `--no-variants` skips them.
 """
 import argparse
 import ctypes as C
@@ -27,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 I8_PEAK_TOPS = 3944.0        # dense i8 MFMA (16x16x64), MI355X_MICROARCH.md
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 
 
 def main():
@@ -35,32 +39,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=2160, help="frames in flight per step (per GPU); a frame holds ~75 MB of geometry workspace + 27 MB of inputs")
+    ap.add_argument("--frames-per-step", type=int, default=2160, help="frames in flight per step (per GPU); a frame holds ~55 MB of geometry workspace + 27 MB of inputs")
+    ap.add_argument("--total-frames", type=int, default=0, help="STRONG scaling: one job of this many frames split over the ranks (shard.plan, whole texture segments per rank); "
+                                                                "a step is the whole job.  BASELINE configs[3]: --total-frames 1200 --gpus 8")
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
     ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames whose content is cycled")
-    ap.add_argument("--shared-inputs", action="store_true", help="DIAGNOSTIC: all frames read the same --distinct input buffers / one texture segment (as before r01_k)")
+    ap.add_argument("--shared-inputs", action="store_true", help="DIAGNOSTIC: all frames read the same --distinct input buffers / one texture segment")
     ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--mesh-order", choices=["lattice", "shuffled"], default="lattice", help="DIAGNOSTIC 'shuffled': seeded permutation of faces and values (scan-like storage order, no cache-line locality between consecutive faces)")
     ap.add_argument("--tex-streams", type=int, default=1, help="texture contexts (HIP streams) fed by host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the workload variants reported next to the headline on one GPU")
     ap.add_argument("--traverse-vbits-l2", type=int, default=0, help="LDS walkers (small batches): 1 = attribute traversers keep their vertex bitmap in L2")
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
-    ap.add_argument("--geo-priority", type=int, default=0, help="DIAGNOSTIC: geometry contexts on high-priority streams too")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
-    ap.add_argument("--tex-delay-ms", type=float, default=0.0, help="DIAGNOSTIC: the texture streams start each pass (--lockstep) / their first pass this long after the geometry streams")
-    ap.add_argument("--geo-stagger-ms", type=float, default=0.0, help="one-time start delay of geometry stream g: g * this")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
-    ap.add_argument("--tex-cu", default="", help="MOD:MASKHEX: texture streams restricted to the CUs with (index mod MOD) in MASK; the geometry streams keep all CUs")
-    ap.add_argument("--cu-split", type=int, default=0, help="16*G+T: CU residue masks (mod 4) for the geometry / texture streams, e.g. 0x7*16+0x8 = 120")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    import uvol, synth
+    import uvol, synth, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -75,10 +77,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    F = args.frames_per_step
     B = args.batch
-    assert F % B == 0
-    nseg = F // B
+    strong = args.total_frames > 0
+    if strong:                     # this rank's block of the ONE job (contiguous whole segments, SURVEY 8e / scripts/Encoder.py:103-154 accounting)
+        f_lo, F, s_lo, nseg = shard.plan(args.total_frames, B, world, rank)
+        assert args.total_frames % B == 0, "--total-frames must be a multiple of KTX2_BATCH_SIZE in the bench"
+    else:
+        F = args.frames_per_step
+        assert F % B == 0
+        nseg = F // B
+    variants_on = world == 1 and not args.no_variants and not args.only and not args.host_inputs and not strong and args.mesh_order == "lattice"
+    F_alloc = max(F, 1)
 
     # ---- synthetic frames (seeded), uploaded once; inputs are resident in HBM when timing starts ----
     meshes_h = [synth.sphere_mesh(args.segs, args.rings, frame=k, seed=k) for k in range(args.distinct)]
@@ -91,10 +100,11 @@ def main():
     # every frame of the step has its OWN input buffers in HBM (content cycles through the --distinct synthetic frames): no
     # frame finds its inputs in a cache because another frame of the batch read the same addresses
     base_t = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in m.items()} for m in meshes_h]
-    for i in range(F if not args.shared_inputs else args.distinct):
+    frame_t = []
+    for i in range(F_alloc if not args.shared_inputs else args.distinct):
         m = meshes_h[i % args.distinct]
         t = base_t[i % args.distinct] if i < args.distinct else {k: v.clone() for k, v in base_t[i % args.distinct].items()}
-        keep.append(t)
+        frame_t.append(t)
         mm = uvol.Mesh()
         mm.pos = t["pos"].data_ptr(); mm.n_pos = len(m["pos"]); mm.uv = t["uv"].data_ptr(); mm.n_uv = len(m["uv"])
         mm.nrm = t["nrm"].data_ptr(); mm.n_nrm = len(m["nrm"])
@@ -105,7 +115,7 @@ def main():
     tex_ptrs = [t.data_ptr() for t in tex_d]
     # texture segments: own buffers AND own content per segment (the base segment shifted by whole 4x4 blocks along x)
     tex_seg_ptrs = []
-    for s_ in range(nseg):
+    for s_ in range(max(nseg, 1)):
         if args.shared_inputs or s_ == 0:
             tex_seg_ptrs += tex_ptrs
         else:
@@ -113,106 +123,109 @@ def main():
             keep.append(seg); tex_seg_ptrs += [t.data_ptr() for t in seg]
     torch.cuda.synchronize()
 
-    cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=F)
+    cfg = dict(Q_POSITION_ATTR=11, Q_TEXTURE_ATTR=10, Q_NORMAL_ATTR=8, DRACO_COMPRESSION_LEVEL=7, KTX2_BATCH_SIZE=B, max_batch=max(F_alloc, 1))
     gcfg, tcfg = dict(cfg), dict(cfg)
     GS = max(1, args.geo_streams)
     if args.tex_priority:
         tcfg.update(stream_priority=1)
-    if args.geo_priority:
-        gcfg.update(stream_priority=1)
     if args.traverse_vbits_l2 == 1:
         gcfg.update(traverse_vbits_l2=1)
-    if args.tex_cu:            # --tex-cu MOD:MASK: the texture streams only run on CUs whose index modulo MOD has its bit set in MASK (hex)
-        m_, r_ = args.tex_cu.split(":"); tcfg.update(cu_mod=int(m_), cu_residues=int(r_, 16))
-    if args.cu_split:          # --cu-split GT: geometry on residues G (bitmask) of every 4 CUs, texture on residues T (hipExtStreamCreateWithCUMask)
-        gcfg.update(cu_mod=4, cu_residues=int(args.cu_split) // 16); tcfg.update(cu_mod=4, cu_residues=int(args.cu_split) % 16)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]
     texs = [uvol.Codec(device=local_rank, **tcfg) for _ in range(max(1, args.tex_streams))]
     out = {}
 
-    host_frames = [meshes_h[i % args.distinct] for i in range(F)]
+    class Job:
+        """One pass over the first n frames / n // B segments of the resident inputs (n = F for the headline; the variants run
+        smaller jobs on the same contexts and buffers)."""
+        def __init__(self, n, host=False, only=args.only):
+            self.n, self.nseg, self.host, self.only = n, n // B, host, only
+            self.gsl = [(gi * n // GS, (gi + 1) * n // GS) for gi in range(GS)]
+            nd = len(dev_meshes)
+            self.gb = [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
+            self.hf = [meshes_h[i % args.distinct] for i in range(n)] if host else None
 
-    gsl = [(gi * F // GS, (gi + 1) * F // GS) for gi in range(GS)]
-    gbatches = [(uvol.Mesh * (b - a))(*[dev_meshes[i % len(dev_meshes)] for i in range(a, b)]) for a, b in gsl]
+        def run_geo(self, gi):
+            a, b = self.gsl[gi]
+            if b > a:
+                out["drc_%d" % gi] = geos[gi].encode_mesh_batch(self.hf[a:b]) if self.host else geos[gi].encode_mesh_batch_dev(self.gb[gi], views=True)
+            else:
+                out["drc_%d" % gi] = []
 
-    def run_geo(gi):
-        a, b = gsl[gi]
-        out["drc_%d" % gi] = geos[gi].encode_mesh_batch(host_frames[a:b]) if args.host_inputs else geos[gi].encode_mesh_batch_dev(gbatches[gi], views=True)
+        def run_tex(self, ti):
+            segs = range(ti, self.nseg, len(texs))           # segments of this step handled by texture context ti, ONE batched call
+            if not len(segs):
+                out["ktx2_%d" % ti] = []
+            elif self.host:
+                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([tex_h] * len(segs))
+            else:
+                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev([p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]], B, args.tex_size, args.tex_size)
 
-    def run_tex(ti):
-        mine = len(range(ti, nseg, len(texs)))            # segments of this step handled by texture context ti, ONE batched call
-        if args.host_inputs:
-            out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([tex_h] * mine) if mine else []
-        else:
-            segs = range(ti, nseg, len(texs))
-            out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev([p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]], B, args.tex_size, args.tex_size) if mine else []
+        def steps(self, k):
+            """k passes.  Every stream (geometry sub-batch / texture share) runs its k passes back to back on its own host
+            thread; with --lockstep all streams meet at a barrier after every pass instead."""
+            errors = []
 
-    def steps(k):
-        """k passes over the batch.  Every stream (geometry sub-batch / texture share) runs its k passes back to back on its
-        own host thread; with --lockstep all streams meet at a barrier after every pass instead.  --geo-stagger-ms delays
-        geometry stream g by g * that much once, so that the streams' serial phases interleave instead of colliding."""
-        errors = []
+            def guarded(fn, *a):
+                try:
+                    fn(*a)
+                except BaseException as e:          # a failed stream must fail the whole bench, not shrink the work silently
+                    errors.append(e)
 
-        def guarded(fn, *a):
-            try:
-                fn(*a)
-            except BaseException as e:          # a failed stream must fail the whole bench, not shrink the work silently
-                errors.append(e)
+            def loop(fn, arg, kk):
+                for _ in range(kk):
+                    fn(arg)
+            rounds = [(1, k)] if not args.lockstep else [(k, 1)]
+            for reps, kk in rounds:
+                for _ in range(reps):
+                    th = [threading.Thread(target=guarded, args=(loop, self.run_geo, gi, kk)) for gi in range(GS) if self.only != "tex"] + \
+                         [threading.Thread(target=guarded, args=(loop, self.run_tex, ti, kk)) for ti in range(len(texs)) if self.only != "geo"]
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+            if errors:
+                raise errors[0]
+            out["ktx2"] = [k_ for ti in range(len(texs)) for k_ in out.get("ktx2_%d" % ti, [])]
+            out["drc"] = [k_ for gi in range(GS) for k_ in out.get("drc_%d" % gi, [])]
+            if self.only != "tex" and (len(out["drc"]) != self.n or not all(len(d_) for d_ in out["drc"])):
+                raise RuntimeError("bench: %d of %d geometry frames encoded" % (len(out["drc"]), self.n))
+            if self.only != "geo" and (len(out["ktx2"]) != self.nseg or not all(len(k_) for k_ in out["ktx2"])):
+                raise RuntimeError("bench: %d of %d texture segments encoded" % (len(out["ktx2"]), self.nseg))
 
-        def loop1(fn, arg, delay):
-            if delay > 0:
-                time.sleep(delay)
-            fn(arg)
+        def timed(self, k, w=1):
+            """frames/s of k passes after w warm-up passes (single GPU, used by the variants)."""
+            if w:
+                self.steps(w)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            self.steps(k)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t
+            return {"frames_per_s": self.n * k / dt, "ms_per_pass": 1000.0 * dt / k, "frames": self.n, "passes": k}
 
-        def loop(fn, arg, delay):
-            if delay > 0:
-                time.sleep(delay)
-            for _ in range(k):
-                fn(arg)
-        if args.lockstep:
-            for _ in range(k):
-                th = [threading.Thread(target=guarded, args=(run_geo, gi)) for gi in range(GS) if args.only != "tex"] + \
-                     [threading.Thread(target=guarded, args=(loop1, run_tex, ti, args.tex_delay_ms * 1e-3)) for ti in range(len(texs)) if args.only != "geo"]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-        else:
-            th = [threading.Thread(target=guarded, args=(loop, run_geo, gi, gi * args.geo_stagger_ms * 1e-3)) for gi in range(GS) if args.only != "tex"] + \
-                 [threading.Thread(target=guarded, args=(loop, run_tex, ti, args.tex_delay_ms * 1e-3)) for ti in range(len(texs)) if args.only != "geo"]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        if errors:
-            raise errors[0]
-        out["ktx2"] = [k_ for ti in range(len(texs)) for k_ in out.get("ktx2_%d" % ti, [])]
-        out["drc"] = [k_ for gi in range(GS) for k_ in out.get("drc_%d" % gi, [])]
-        if args.only != "tex" and (len(out["drc"]) != F or not all(len(d_) for d_ in out["drc"])):
-            raise RuntimeError("bench: %d of %d geometry frames encoded" % (len(out["drc"]), F))
-        if args.only != "geo" and (len(out["ktx2"]) != nseg or not all(len(k_) for k_ in out["ktx2"])):
-            raise RuntimeError("bench: %d of %d texture segments encoded" % (len(out["ktx2"]), nseg))
+    def set_profiling(on):
+        for c in geos + texs:
+            c.profile(on)
+            if on:
+                c.profile_reset()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    main_job = Job(F, host=args.host_inputs)
     if args.warmup:
-        steps(args.warmup)
-    for g in geos:
-        g.profile(True); g.profile_reset()
-    for t in texs:
-        t.profile(True); t.profile_reset()
+        main_job.steps(args.warmup)
+    set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    steps(args.steps)
+    main_job.steps(args.steps)
     # manifest gather (SURVEY §8e): {frames, segments, layers in last segment, bytes} per rank
-    import shard
     nbytes = sum(len(x) for x in out["drc"]) + sum(len(x) for x in out["ktx2"])
     table = shard.gather_counts(F * args.steps, nseg * args.steps, B, nbytes, device=dev)      # RCCL all_gather when world > 1
     total_frames, total_segs, total_tex_frames, _ = shard.totals(table, B)
     assert total_frames == total_tex_frames or args.only                                                   # check_total_frames (Encoder.py:135)
+    if strong:
+        assert total_frames == args.total_frames * args.steps, (total_frames, args.total_frames)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -221,35 +234,35 @@ def main():
         dt = float(tt[0])
 
     if rank == 0:
-        drc_len = sum(len(x) for x in out["drc"]) / F
-        ktx_len = sum(len(x) for x in out["ktx2"]) / F
+        drc_len = sum(len(x) for x in out["drc"]) / max(F, 1)
+        ktx_len = sum(len(x) for x in out["ktx2"]) / max(F, 1)
         algo_per_frame = 32.0 * V + 12.0 * Fc + 4.0 * args.tex_size ** 2 + drc_len + ktx_len
-        groups = []
         tg = {}
         for t in geos + texs:
             for g in t.profile_report():
                 a = tg.setdefault(g["name"], dict(name=g["name"], launches=0, total_ms=0.0, algo_bytes=0))
                 a["launches"] += g["launches"]; a["total_ms"] += g["total_ms"]; a["algo_bytes"] += g["algo_bytes"]
-        groups += list(tg.values())
-        groups.sort(key=lambda g: -g["total_ms"])
+        groups = sorted(tg.values(), key=lambda g: -g["total_ms"])
         mfma_grp = tg.get("tex.k10_sel_assign")                   # sub-scope of tex.k10_selector_codebook; its work field counts integer ops, not bytes
         # dominant kernel: the longest group of the CRITICAL PATH, i.e. of the geometry stream (its groups sum to ~95 % of a step;
-        # the texture stream runs beside it and is idle a third of the time) - the texture selector-codebook group is about as
-        # long but is ~140 launches of ten kernels, not a kernel.  With --only tex the longest texture group stands in.
+        # the texture stream runs beside it and is idle a third of the time).  With --only tex the longest texture group stands in.
         cand = [g for g in groups if g["name"].startswith("geo.")] or [g for g in groups if g["name"] != "tex.k10_sel_assign"]
         dom = cand[0]
-        units = F // GS if dom["name"].startswith("geo.") else F // len(texs)          # frames one launch of that group processes
+        units = max(F // GS, 1) if dom["name"].startswith("geo.") else max(F // len(texs), 1)          # frames one launch of that group processes
         avg_ms = dom["total_ms"] / max(1, dom["launches"])
         achieved = algo_per_frame * units / (avg_ms * 1e-3) / 1e9
+        workload = ("BASELINE configs[3] shape: ONE job of %d frames split over %d rank(s) by whole texture segments (rank 0: %d frames)" % (args.total_frames, world, F)) if strong else \
+                   ("BASELINE configs[2] shape, %d frames per step" % F)
         res = {
             "metric": "frames/s encode, 100k-vert mesh + 2048^2 texture",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else "") + (" DIAGNOSTIC %s only" % args.only if args.only else ""),
-            "config": {"workload": "BASELINE configs[2] shape: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, "
-                                   "%d frames per step, qp11/qt10/qn8/cl7; %s%s" % (V, Fc, args.tex_size, args.tex_size, B, F, "DIAGNOSTIC shuffled face / value order; " if args.mesh_order == "shuffled" else "",
-                                   "DIAGNOSTIC shared input buffers" if args.shared_inputs else "every frame / segment reads its own input buffers in HBM"),
-                       "frames_per_step": F, "ktx2_batch_size": B, "parallelism": "frames sharded per GPU; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
+            "config": {"workload": "%s: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, qp11/qt10/qn8/cl7; %s%s"
+                                   % (workload, V, Fc, args.tex_size, args.tex_size, B, "DIAGNOSTIC shuffled face / value order; " if args.mesh_order == "shuffled" else "",
+                                      "DIAGNOSTIC shared input buffers" if args.shared_inputs else "every frame / segment reads its own input buffers in HBM"),
+                       "frames_per_step": F if not strong else args.total_frames, "ktx2_batch_size": B,
+                       "parallelism": "frames sharded per GPU in blocks of whole segments; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
                        "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len, "mesh_order": args.mesh_order,
                        "geometry_workspace_bytes_per_frame": geos[0].mesh_workspace(**meshes_h[0])},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -259,22 +272,87 @@ def main():
             "kernel_groups_ms_per_step": {g["name"]: g["total_ms"] / args.steps for g in groups},
         }
         if mfma_grp and mfma_grp["total_ms"] > 0:
-            # the one contraction on the path (exact i8 nearest-codeword search) against the dense i8
+            # the one contraction on the path (exact i8 nearest-codeword search, DESIGN.md section 5 step 6) against the dense i8
             # matrix-core rate of MI355X_MICROARCH.md (16x16x64: >= 3944 TOP/s); secondary to `roofline`, which stays the dominant kernel
             tops = mfma_grp["algo_bytes"] / (mfma_grp["total_ms"] * 1e-3) / 1e12
             res["roofline_mfma"] = {"bound": "mfma", "kernel": "tex.k10_sel_assign", "achieved": tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s",
                                     "frac": tops / I8_PEAK_TOPS, "avg_launch_ms": mfma_grp["total_ms"] / max(1, mfma_grp["launches"]),
                                     "ops_per_launch": mfma_grp["algo_bytes"] / max(1, mfma_grp["launches"]), "dtype": "i8 x i8 -> i32"}
-        res["quality"] = quality_gates(geos[0], texs[0], out, meshes_h[0], tex_h, B) if not args.only else None
+        res["quality"] = quality_gates(geos[0], texs[0], out, meshes_h[0], tex_h, B) if not args.only and F else None
+        if variants_on:
+            try:
+                res["variants"] = run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, res["ms_per_step"], F, B, V, Fc, local_rank)
+            except Exception as e:                                   # the headline stands on its own
+                res["variants"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
         print(json.dumps(res))
-    for g in geos:
-        g.close()
-    for t in texs:
-        t.close()
+    for c in geos + texs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, ms_step, F, B, V, Fc, local_rank):
+    """The same path on other boundaries / job sizes / storage orders, each a few passes (about 25 s in all), reported NEXT TO the
+    headline: what a user of the reference sees depends on where the inputs are and how large the job is (VERDICT r2 #3)."""
+    import numpy as np
+    import torch
+    import uvol, synth
+    v = {}
+    # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
+    set_profiling(False)
+    r = Job(F).timed(2, 0)
+    v["events_off"] = dict(r, note="headline workload without the per-group hipEvent brackets; ms_per_step with them: %.1f" % ms_step,
+                           events_cost_frac=ms_step / r["ms_per_pass"] - 1.0)
+    # (1) small jobs (latency-bound: the serial walks of a frame do not shrink with the batch) and the 8-GPU projection of
+    #     BASELINE configs[3] (1200 frames, 150 per GPU): 8 x rate(150-frame job) / rate(1200-frame job on one GPU)
+    for n in (150, 300, 1200):
+        if n <= F:
+            v["job_%d" % n] = Job(n).timed(3, 1)
+    if "job_150" in v and "job_1200" in v:
+        v["projected_8gpu_speedup_configs3"] = {"value": 8.0 * v["job_150"]["frames_per_s"] / v["job_1200"]["frames_per_s"],
+                                                "how": "8 x frames/s of the 150-frame share of one GPU / frames/s of the whole 1200-frame job on one GPU; "
+                                                       "the manifest gather (32 bytes per rank) is not modelled"}
+    # (2) scan-like storage order: the resident input buffers are overwritten with a seeded permutation of faces and values
+    sh = [synth.shuffle_mesh(m, seed=100 + k) for k, m in enumerate(meshes_h)]
+    for i, t in enumerate(frame_t):
+        for key, val in sh[i % len(sh)].items():
+            t[key].copy_(torch.from_numpy(np.ascontiguousarray(val)), non_blocking=False)
+    torch.cuda.synchronize()
+    v["shuffled_order"] = dict(Job(F).timed(2, 1), note="same surfaces, faces and value arrays in a seeded random order (no locality between consecutive faces)")
+    # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
+    frame_t.clear(); keep.clear()
+    torch.cuda.empty_cache()
+    nh = min(F, 1080)
+    v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
+    # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
+    drc = [bytes(x) for x in out["drc"][:480]]; ktx = list(out["ktx2"][:192])
+    for c in geos + texs:
+        c.close()
+    del geos[:]; del texs[:]
+    torch.cuda.empty_cache()
+    try:
+        d = uvol.Codec(device=local_rank, max_batch=len(drc))
+        d.decode_mesh_batch(drc[:8], fetch=False)
+        d.decode_mesh_batch(drc, fetch=False)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        d.decode_mesh_batch(drc, fetch=False)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        v["decode_mesh"] = {"frames_per_s": len(drc) / dt, "frames": len(drc), "ms": 1000.0 * dt, "note": ".drc -> de-quantised attribute arrays + per-corner indices, results left in HBM"}
+        size = args.tex_size
+        bufs = torch.empty((len(ktx), B, size, size, 4), dtype=torch.uint8, device=dev)
+        ptrs = [bufs[s, l].data_ptr() for s in range(len(ktx)) for l in range(B)]
+        d.decode_texture_segments_dev(ktx[:2], ptrs[:2 * B], size * size * 4)
+        d.decode_texture_segments_dev(ktx, ptrs, size * size * 4)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        d.decode_texture_segments_dev(ktx, ptrs, size * size * 4)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        v["decode_texture"] = {"frames_per_s": len(ktx) * B / dt, "segments": len(ktx), "ms": 1000.0 * dt, "note": "ETC1S .ktx2 -> RGBA32 layers in HBM"}
+        d.close()
+    except Exception as e:
+        v["decode_error"] = repr(e)
+    return v
 
 
 def quality_gates(geo, tex, out, mesh0, tex0, B):
@@ -303,12 +381,14 @@ def quality_gates(geo, tex, out, mesh0, tex0, B):
 def pmc_traffic(group, units):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are
     collected in their own runs, profiles/<PMC_FILE> records the per-frame figure and how it was corrected)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-        e = t["kernels"].get(group)
-        return None if e is None else e["hbm_bytes_per_frame"] * units
-    except Exception:
-        return None
+    for f in (PMC_FILE, "r02_pmc_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", f)))
+            e = t["kernels"].get(group)
+            return None if e is None else e["hbm_bytes_per_frame"] * units
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(mesh, tex, B):

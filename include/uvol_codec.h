@@ -131,7 +131,9 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
  * uploads the layers as one sampler2DArray).  Input: BasisLZ/ETC1S .ktx2 files as uvol_encode_texture_segment[s] or
  * `basisu -ktx2 -tex_type video` write them (no alpha slices, one mip level), or the UASTC .ktx2 files this codec writes with
  * uvol_params.uastc (told apart by the DFD colour model).  Output: RGBA8, rows in stored order. */
-/* host-only: container dimensions of one file (UVOL_E_INVALID if it is not a KTX2/BasisLZ file this decoder handles) */
+/* host-only: container dimensions of one file (UVOL_E_INVALID if it is not a KTX2/BasisLZ file this decoder handles;
+ * UVOL_E_UNSUPPORTED for a UASTC file whose level data are Zstandard-supercompressed - the default of stock `basisu -uastc -ktx2`;
+ * this library has no Zstandard and reads supercompressionScheme 0 only, i.e. `basisu -uastc -ktx2 -ktx2_no_zstandard`) */
 int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, uint32_t *height, uint32_t *layers);
 /* n_segments files of one width / height / layer count; rgba[s * layers + l] receives width*height*4 bytes
  * (layer_cap = size of each buffer).  One kernel launch per stage for the whole batch. */

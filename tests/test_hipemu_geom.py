@@ -63,7 +63,8 @@ def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
 def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
     """Visited bitmaps in LDS (default, covered above), vertex bitmap in global memory (a table with more vertices than
     the LDS slot), nothing in LDS (mesh too large for LDS: the lane-per-walker kernels, one lane per wave), "simtN": the
-    lane-per-walker kernels with N lanes per wave (what large batches use): same bytes.  "rec16": the 16-byte corner records
+    lane-per-walker kernels with N lanes per wave and the lane-per-stream entropy coder (what large batches use; small ones get the
+    cooperative LDS walkers and the wave-per-stream coder, covered above): same bytes.  "rec16": the 16-byte corner records
     that batches with >= 2^18 faces per mesh use instead of the packed 8-byte ones (UVOL_REC16=1).  The switches are read
     once per process, hence the fresh interpreter."""
     import subprocess, sys, os
@@ -77,9 +78,26 @@ def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
-    env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:]) if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
+    env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="8") if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_hipemu_vertex_ids_beyond_the_8_byte_record_field(oracle, hipemu_lib):
+    """vertex ids are position-based and not bounded by the face count.  A 1920-face torus one of whose referenced
+    positions has index 2^20 + 5 must not be packed into the 21-bit fields of the 8-byte corner records: same bytes as the oracle."""
+    import synth, uvol
+    m = synth.torus_mesh()
+    n = (1 << 20) + 6
+    pos = np.zeros((n, 3), np.float32); pos[:len(m["pos"])] = m["pos"]
+    idx = m["idx_pos"].copy()
+    old = int(idx[7]); pos[n - 1] = pos[old]; pos[old] = (9.0, 9.0, 9.0)        # the vertex moves to the far end of the array
+    idx[idx == old] = n - 1
+    f = dict(m, pos=pos, idx_pos=idx)
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    got = cd.encode_mesh_batch([f])[0]
+    cd.close()
+    assert got == oracle.drc_encode(f["pos"], f["idx_pos"], f["uv"], f["idx_uv"], f["nrm"], f["idx_nrm"])
 
 
 def _check_decoded(oracle, data, got):

@@ -2422,6 +2422,11 @@ void geo_destroy(uvol_ctx *ctx) {
   delete g; ctx->geo = nullptr;
 }
 
+// entry capacity of a frame's per-vertex arrays = size of its vertex id space (ws_collect sizes them with it; geo_rec8 bounds the record fields with it)
+static inline uint64_t geo_ecap(uint32_t n_pos, uint32_t n_uv, uint32_t n_nrm, uint32_t nf, bool full) {
+  const uint64_t vmax = std::max<uint64_t>(n_pos, std::max<uint64_t>(n_uv, n_nrm)), nc = 3ull * nf;
+  return full ? vmax + 2 * nc + 3 : std::min(vmax + 2 * nc + 3, vmax + vmax / 2 + 4096);
+}
 namespace {
 inline uint32_t pow2_at_least(uint64_t v) { uint32_t c = 16; while (c < v) c <<= 1; return c; }
 
@@ -2443,7 +2448,7 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   const size_t nfi = J.nf_in, nc = 3 * nfi;
   const size_t vmax = std::max<size_t>(J.n_pos, std::max<size_t>(J.n_uv, J.n_nrm));
   // vertex ids are position ids + one id per further fan of a non-manifold position + (attribute tables) one per seam segment
-  const size_t ecap = full ? vmax + 2 * nc + 3 : std::min(vmax + 2 * nc + 3, vmax + vmax / 2 + 4096);
+  const size_t ecap = (size_t)geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, full);
   J.ecap = (uint32_t)ecap;
   auto bitlen = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };
 #define CARVE(field, T, count, first, last) items.push_back(WsItem{(size_t)((char *)&(field) - (char *)&J), (size_t)(count) * sizeof(T), (first), (last), 0})
@@ -2651,13 +2656,15 @@ static WalkPlan walk_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals
   return P;
 }
 // 8-byte corner records (RecOps<true>): every corner code (< 4 * faces, signed field: 20 bits + sign) and every
-// vertex id << 1 | open (< 6 * faces, unsigned 21-bit field) of the batch must fit, i.e. faces < 2^18; UVOL_REC16=1 (tests)
-// forces the 16-byte format
-static inline bool geo_rec8(uint32_t max_nfi) {
+// vertex id << 1 | open (unsigned 21-bit field) of the batch must fit: faces < 2^18 AND the vertex id space below 2^20.  Ids are
+// position-based (n_pos + extra fans + seam segments, bounded by the workspace's entry capacity `ecap`), NOT bounded by the
+// face count: a 2000-face mesh that references position 2^20 + 5 needs the 16-byte format.  UVOL_REC16=1 (tests) forces it.
+static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
   static const bool force16 = [] { const char *e = getenv("UVOL_REC16"); return e && *e == '1'; }();
-  return !force16 && 4ull * max_nfi < (1ull << 20);
+  return !force16 && 4ull * max_nfi < (1ull << 20) && max_ids < (1ull << 20);
 }
-bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi); }          // the decode path sizes its record tables with the same rule
+// the decode path sizes its record tables with the same rule; its vertex ids are dense (< 3 * faces)
+bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) { const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
@@ -2670,7 +2677,7 @@ int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint3
   GeoState *G = ctx->geo;
   const unsigned N = (unsigned)n, bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi);
   const WalkPlan P = walk_plan(G, max_nfi, max_vals, (size_t)3 * N);
-  const int r8 = geo_rec8(max_nfi) ? 1 : 0;
+  const int r8 = geo_records8(max_nfi) ? 1 : 0;
   for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w, r8);
   launch_traversals(ctx, dj, n, P, r8);
   LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
@@ -2683,7 +2690,7 @@ extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   GeoJob J{}; J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
   J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
   WsPlan P; std::vector<WsItem> items;
-  return layout_job(J, nullptr, false, geo_rec8(m->n_faces), P, items) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
+  return layout_job(J, nullptr, false, geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)), P, items) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
 }
 static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                                  uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full);
@@ -2711,8 +2718,12 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
   uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0, he_nb_max = 0; bool he_part_all = true; uint64_t algo_in = 0;
-  for (int i = 0; i < n; i++) max_nfi = std::max(max_nfi, meshes[i].n_faces);
-  const int r8 = geo_rec8(max_nfi) ? 1 : 0;
+  uint64_t max_ids = 0;
+  for (int i = 0; i < n; i++) {
+    const uvol_mesh &m = meshes[i]; max_nfi = std::max(max_nfi, m.n_faces);
+    max_ids = std::max(max_ids, geo_ecap(m.n_pos, (m.uv && m.idx_uv) ? m.n_uv : 0, (m.nrm && m.idx_nrm) ? m.n_nrm : 0, m.n_faces, full));
+  }
+  const int r8 = geo_rec8(max_nfi, max_ids) ? 1 : 0;
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
@@ -2881,11 +2892,15 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k7_entropy_encode", 0);
-    // UVOL_ENTROPY_WAVE=1 (tests / diagnostic): the wave-per-stream kernel
-    static const bool ent_wave = [] { const char *e = getenv("UVOL_ENTROPY_WAVE"); return e && *e == '1'; }();
+    // Wave-per-stream coder (state recurrence on the scalar unit, ~90 ns per symbol) while all 14 x N one-wave workgroups are resident
+    // at once (8 KiB of LDS each: 20 per CU); beyond that the lane-per-stream coder, which is slower per stream (~175 ns per symbol)
+    // but runs every stream of the batch concurrently (300 frames: 28 vs 72 ms; 2160 frames: 53 ms with lanes).
+    // UVOL_ENTROPY_WAVE=1 / 0 (tests / diagnostic) forces one form.
+    static const int ent_env = [] { const char *e = getenv("UVOL_ENTROPY_WAVE"); return !e ? -1 : (*e == '1' ? 1 : 0); }();
+    static const int ent_w_env = [] { const char *e = getenv("UVOL_ENTROPY_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // lanes per wave of the lane form (implies it)
+    const bool ent_wave = ent_env >= 0 ? ent_env == 1 : (ent_w_env == 0 && (size_t)(GEO_NSTREAM + GEO_NRABS) * N <= (size_t)20 * G->num_cu);
     if (ent_wave) LAUNCH(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), dj, uvol_debug() ? 1 : 0);
     else {
-      static const int ent_w_env = [] { const char *e = getenv("UVOL_ENTROPY_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
       // lanes per wave: five streams of a frame are long (three attribute symbol streams, two seam-bit streams; ~300 k steps) and a
       // wave runs as long as its longest lane, so the launch should put at most ONE long wave on a SIMD (1024 of them): waves that
       // share a SIMD share its issue slots (2160 frames: 172 / 105 / 60 / 64 / 55 / 52 ms with 1 / 2 / 4 / 8 / 16 / 32 lanes per wave)

@@ -471,7 +471,9 @@ static int tdec_parse(const uint8_t *b, size_t n, TexDecJob &J) {
 extern "C" int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, uint32_t *height, uint32_t *layers) {
   TexDecJob J; memset(&J, 0, sizeof J);
   { uint32_t w, h, l; uint64_t lo;                    // UASTC files of this codec (tex_uastc.hip)
-    if (uastc_ktx2_probe(ktx2, len, &w, &h, &l, &lo) == 0) { if (width) *width = w; if (height) *height = h; if (layers) *layers = l; return UVOL_OK; } }
+    const int pr = uastc_ktx2_probe(ktx2, len, &w, &h, &l, &lo);
+    if (pr == 0) { if (width) *width = w; if (height) *height = h; if (layers) *layers = l; return UVOL_OK; }
+    if (pr == UASTC_PROBE_SUPERCOMPRESSED) return UVOL_E_UNSUPPORTED; }          // Zstandard-supercompressed UASTC: recognised, not decoded
   if (tdec_parse(ktx2, len, J)) return UVOL_E_INVALID;
   if (width) *width = J.width; if (height) *height = J.height; if (layers) *layers = J.layers;
   return UVOL_OK;

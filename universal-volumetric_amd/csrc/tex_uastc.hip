@@ -524,9 +524,12 @@ int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint3
   static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
   if (!b || n < 104 + 44 || n > 0xffffffffull * 16 || memcmp(b, ident, 12)) return -1;
   uint32_t u[9]; memcpy(u, b + 12, 36);
-  if (u[0] != 0 || u[8] != 0 || u[7] != 1 || u[6] != 1 || !u[2] || !u[3] || u[2] > 16384 || u[3] > 16384) return -2;
   uint32_t dfd_off, dfd_len; memcpy(&dfd_off, b + 48, 4); memcpy(&dfd_len, b + 52, 4);
-  if (dfd_len < 44 || dfd_off > n || dfd_len > n - dfd_off || b[dfd_off + 12] != 166) return -3;
+  const bool model_uastc = dfd_len >= 44 && dfd_off <= n && dfd_len <= n - dfd_off && b[dfd_off + 12] == 166;
+  // stock `basisu -uastc -ktx2` writes Zstandard-supercompressed level data (scheme 2) by default: recognised, not decoded (no Zstd here)
+  if (model_uastc && u[0] == 0 && u[8] != 0) return UASTC_PROBE_SUPERCOMPRESSED;
+  if (u[0] != 0 || u[8] != 0 || u[7] != 1 || u[6] != 1 || !u[2] || !u[3] || u[2] > 16384 || u[3] > 16384) return -2;
+  if (!model_uastc) return -3;
   uint64_t lo, ll; memcpy(&lo, b + 80, 8); memcpy(&ll, b + 88, 8);
   const uint32_t layers = u[5] ? u[5] : 1;
   if (layers > 64) return -4;

@@ -153,6 +153,9 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
 // UASTC and ETC1S files are told apart by the container (DFD colour model 166 vs 163)
 static bool is_uastc(const uint8_t *const *ktx2, const size_t *lens) { uint32_t w, h, l; uint64_t lo; return uastc_ktx2_probe(ktx2[0], lens[0], &w, &h, &l, &lo) == 0; }
 static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool dev, int target) {
+  { uint32_t w, h, l; uint64_t lo;
+    if (uastc_ktx2_probe(ktx2[0], lens[0], &w, &h, &l, &lo) == UASTC_PROBE_SUPERCOMPRESSED) {
+      ctx->set_error("Zstandard-supercompressed UASTC (supercompressionScheme != 0, the default of `basisu -uastc -ktx2`) is not supported: write the file with -ktx2_no_zstandard"); return UVOL_E_UNSUPPORTED; } }
   if (is_uastc(ktx2, lens)) {
     if (target != 0 && target != 3) { ctx->set_error("UASTC sources transcode to RGBA32 or ASTC 4x4 here"); return UVOL_E_UNSUPPORTED; }
     return tex_uastc_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);

@@ -159,7 +159,7 @@ struct uvol_ctx {
   TexDecState *texdec = nullptr;
   GeoDecState *geodec = nullptr;
   UastcState *uastc = nullptr;
-  uint8_t *up_pin[2] = { nullptr, nullptr }; size_t up_cap = 0; hipEvent_t up_ev[2] = { nullptr, nullptr };   // staged uploads (uvol_upload_staged)
+  uint8_t *up_pin[2] = { nullptr, nullptr }; size_t up_cap = 0; hipEvent_t up_ev[2] = { nullptr, nullptr }; bool up_rec[2] = { false, false };   // staged uploads (uvol_upload_staged); up_rec: a DMA out of that buffer may still be in flight
 
   void set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(err, sizeof(err), fmt, ap); va_end(ap);
@@ -220,6 +220,7 @@ void texdec_destroy(uvol_ctx *ctx);
 int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target);
 int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);
+#define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */
 int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L, uint64_t *lvl_off);
 int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
                               bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens);
@@ -239,20 +240,45 @@ int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, 
 // and each chunk goes over in one DMA at link speed while the threads fill the other buffer.
 // ------------------------------------------------------------------------------------------------
 struct UvolUpItem { size_t dev_off; const void *src; size_t bytes; };     // sorted by dev_off, non-overlapping
-// Contexts of one process share the host link.  When a geometry and a texture context upload at the same time (uvolenc, the
-// PCIe-inclusive bench variant) each gets half of it and BOTH encoders start late; chunks are therefore issued shortest-
-// remaining-upload first, so the smaller batch (the meshes) is on the device - and being encoded - while the larger one goes over.
+// Contexts of one process that drive the SAME device share its host link.  When a geometry and a texture context upload at the
+// same time (uvolenc, the PCIe-inclusive bench variant) each gets half of it and BOTH encoders start late; chunks are therefore
+// issued shortest-remaining-upload first, so the smaller batch (the meshes) is on the device - and being encoded - while the
+// larger one goes over.  One gate PER DEVICE: uploads to different GPUs travel on different links and never wait for each other
+// (`uvolenc --gpus N` runs 2 contexts per GPU in one process).  A context that has been passed over UP_MAX_SKIPS times goes next
+// whatever its size, so a stream of small uploads cannot starve a large one.
 struct UvolUpSched {
-  std::mutex m; std::condition_variable cv; std::map<uint64_t, size_t> rem; uint64_t next_id = 1;
-  uint64_t enter(size_t total) { std::lock_guard<std::mutex> l(m); const uint64_t id = next_id++; rem[id] = total; return id; }
-  void turn(uint64_t id) {                                   // blocks until `id` has the least bytes left (ties: the older one)
+  enum { UP_MAX_SKIPS = 64 };
+  struct Ent { size_t rem; unsigned skipped; };
+  std::mutex m; std::condition_variable cv; std::map<uint64_t, Ent> rem; uint64_t next_id = 1;
+  uint64_t enter(size_t total) { std::lock_guard<std::mutex> l(m); const uint64_t id = next_id++; rem[id] = Ent{ total, 0 }; return id; }
+  // blocks until `id` has the least bytes left (ties: the older one), or has waited through UP_MAX_SKIPS chunks of others
+  void turn(uint64_t id) {
     std::unique_lock<std::mutex> l(m);
-    cv.wait(l, [&] { const size_t mine = rem[id]; for (auto &kv : rem) if (kv.first != id && (kv.second < mine || (kv.second == mine && kv.first < id))) return false; return true; });
+    cv.wait(l, [&] {
+      const Ent &me = rem[id];
+      if (me.skipped >= UP_MAX_SKIPS) { for (auto &kv : rem) if (kv.first < id && kv.second.skipped >= UP_MAX_SKIPS) return false; return true; }
+      for (auto &kv : rem) if (kv.first != id && (kv.second.skipped >= UP_MAX_SKIPS || kv.second.rem < me.rem || (kv.second.rem == me.rem && kv.first < id))) return false;
+      return true; });
   }
-  void progress(uint64_t id, size_t bytes) { { std::lock_guard<std::mutex> l(m); size_t &r = rem[id]; r = r > bytes ? r - bytes : 0; } cv.notify_all(); }
+  void progress(uint64_t id, size_t bytes) {
+    { std::lock_guard<std::mutex> l(m); Ent &r = rem[id]; r.rem = r.rem > bytes ? r.rem - bytes : 0; r.skipped = 0; for (auto &kv : rem) if (kv.first != id) kv.second.skipped++; }
+    cv.notify_all();
+  }
   void leave(uint64_t id) { { std::lock_guard<std::mutex> l(m); rem.erase(id); } cv.notify_all(); }
 };
-inline UvolUpSched g_uvol_up_sched;
+inline UvolUpSched &uvol_up_sched(int device) {
+  static std::mutex m; static std::map<int, UvolUpSched *> by_dev;
+  std::lock_guard<std::mutex> l(m);
+  UvolUpSched *&s = by_dev[device]; if (!s) s = new UvolUpSched();      // lives as long as the process (contexts come and go)
+  return *s;
+}
+// host threads one upload may use for its memcpy into the pinned buffers: 8 when the process drives one device, fewer per upload
+// when it drives several (`uvolenc --gpus 8`: 16 contexts), so that the copies do not oversubscribe the host
+inline int uvol_up_threads() {
+  static const int hw = [] { const unsigned h = std::thread::hardware_concurrency(); return (int)(h ? h : 8); }();
+  int ndev = 1; (void)hipGetDeviceCount(&ndev); if (ndev < 1) ndev = 1;
+  return std::max(2, std::min(8, hw / (2 * ndev)));
+}
 static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std::vector<UvolUpItem> &items) {
   if (items.empty()) return UVOL_OK;
   const size_t total = items.back().dev_off + items.back().bytes;
@@ -261,17 +287,27 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
     for (const UvolUpItem &it : items) if (it.bytes) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(dev_base + it.dev_off, it.src, it.bytes, hipMemcpyHostToDevice, ctx->stream));
     return UVOL_OK;
   }
-  if (!ctx->up_pin[0]) {
-    for (int k = 0; k < 2; k++) { UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&ctx->up_pin[k], CH, hipHostMallocDefault)); UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming)); }
+  if (!ctx->up_pin[0]) {                                                    // both buffers and both events, or nothing: published only when all four exist
+    uint8_t *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; k++) { e = hipHostMalloc((void **)&pin[k], CH, hipHostMallocDefault); if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); }
+    if (e != hipSuccess) {
+      for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+      ctx->set_error("staged upload: pinned buffers: %s", hipGetErrorString(e)); return UVOL_E_HIP;
+    }
+    for (int k = 0; k < 2; k++) { ctx->up_pin[k] = pin[k]; ctx->up_ev[k] = ev[k]; ctx->up_rec[k] = false; }
     ctx->up_cap = CH;
   }
-  size_t first = 0; int buf = 0; bool used[2] = { false, false };
-  const uint64_t sid = g_uvol_up_sched.enter(total);
-  struct Leave { uint64_t id; ~Leave() { g_uvol_up_sched.leave(id); } } leave_{ sid };
+  // a previous call may have returned early (an error after its DMAs were queued): nothing is copied into a pinned buffer a DMA still reads
+  for (int k = 0; k < 2; k++) if (ctx->up_rec[k]) { UVOL_HIP_CHECK(ctx, hipEventSynchronize(ctx->up_ev[k])); ctx->up_rec[k] = false; }
+  size_t first = 0; int buf = 0;
+  UvolUpSched &sched = uvol_up_sched(ctx->device);
+  const uint64_t sid = sched.enter(total);
+  struct Leave { UvolUpSched &s; uint64_t id; ~Leave() { s.leave(id); } } leave_{ sched, sid };
+  const int nt = uvol_up_threads();
   for (size_t c0 = 0; c0 < total; c0 += CH, buf ^= 1) {
     const size_t c1 = std::min(total, c0 + CH);
-    g_uvol_up_sched.turn(sid);
-    if (used[buf]) UVOL_HIP_CHECK(ctx, hipEventSynchronize(ctx->up_ev[buf]));       // the DMA that last read this buffer is done
+    sched.turn(sid);
+    if (ctx->up_rec[buf]) { UVOL_HIP_CHECK(ctx, hipEventSynchronize(ctx->up_ev[buf])); ctx->up_rec[buf] = false; }      // the DMA that last read this buffer is done
     while (first < items.size() && items[first].dev_off + items[first].bytes <= c0) first++;
     size_t last = first; while (last < items.size() && items[last].dev_off < c1) last++;
     uint8_t *pin = ctx->up_pin[buf];
@@ -282,9 +318,9 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
         if (hi > lo) memcpy(pin + (lo - c0), (const uint8_t *)it.src + (lo - it.dev_off), hi - lo);
       } };
     const size_t ni = last - first;
-    if (ni >= 8) { const int nt = 8; std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work, first + ni * t / nt, first + ni * (t + 1) / nt); for (auto &x : th) x.join(); }
+    if (ni >= 8) { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work, first + ni * t / nt, first + ni * (t + 1) / nt); for (auto &x : th) x.join(); }
     else if (ni >= 1) {                                                       // few large items (image layers): split each across the threads
-      const int nt = 8; std::vector<std::thread> th;
+      std::vector<std::thread> th;
       for (int t = 0; t < nt; t++) th.emplace_back([&, t]() {
         for (size_t i = first; i < last; i++) {
           const UvolUpItem &it = items[i];
@@ -296,8 +332,8 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
     }
     UVOL_HIP_CHECK(ctx, hipMemcpyAsync(dev_base + c0, pin, c1 - c0, hipMemcpyHostToDevice, ctx->stream));
     UVOL_HIP_CHECK(ctx, hipEventRecord(ctx->up_ev[buf], ctx->stream));
-    used[buf] = true;
-    g_uvol_up_sched.progress(sid, c1 - c0);
+    ctx->up_rec[buf] = true;
+    sched.progress(sid, c1 - c0);
   }
   return UVOL_OK;
 }

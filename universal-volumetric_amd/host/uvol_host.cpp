@@ -270,7 +270,13 @@ bool read_obj(const std::string &path, ObjMesh &m, std::string &err, IngestScrat
   auto num = [&](const char *&q, const char *le, float &o) {
     skip_sp(q);
     if (fast_float(q, le, o)) return true;
-    char *end; o = std::strtof(q, &end); bool ok = end != q; q = end; return ok; };
+    // the unusual numbers go to strtof - on a NUL-terminated copy of the token, bounded by the line end: the file buffer is not
+    // terminated, and strtof skips leading white space INCLUDING '\n' (a `v 1 2` line would take its third value from the next line)
+    if (q >= le) return false;
+    char tok[96]; size_t nt = 0;
+    while (q + nt < le && nt + 1 < sizeof(tok) && q[nt] != ' ' && q[nt] != '\t' && q[nt] != '\r' && q[nt] != '\n') { tok[nt] = q[nt]; nt++; }
+    tok[nt] = 0;
+    char *end; o = std::strtof(tok, &end); const bool ok = end != tok; q += ok ? (size_t)(end - tok) : 0; return ok; };
   auto integer = [&](const char *&q, const char *le, long &o) {                 // optional sign + digits (what strtol accepts here)
     const char *s0 = q; bool neg = false; if (q < le && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
     const char *d0 = q; long v = 0; while (q < le && *q >= '0' && *q <= '9') { if (v < (1l << 40)) v = v * 10 + (*q - '0'); q++; }
