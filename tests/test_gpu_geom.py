@@ -99,8 +99,9 @@ def test_gpu_walker_bitmap_placements(oracle):
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
     # rec16: 16-byte corner records (meshes with >= 2^18 faces); simtN: lane-per-walker kernels, N lanes per wave (large batches);
     # entwave: the wave-per-stream entropy coder instead of the lane-per-stream one
-    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "entwave"):
-        env = dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
+    # relabel: the locality relabelling forced on for these coherently stored meshes (per frame it is decided on the device)
+    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "entwave", "relabel", "relabel_simt"):
+        env = dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="5") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (force, r.stdout[-500:], r.stderr[-1500:])
 
@@ -250,3 +251,24 @@ def test_gpu_random_soups_and_shuffled_order_match_oracle(oracle, gpu_codec):
     got = gpu_codec.encode_mesh_batch(frames)
     for m, g in zip(frames, got):
         assert g == oracle.drc_encode(m["pos"], m["idx_pos"], m.get("uv"), m.get("idx_uv"), m.get("nrm"), m.get("idx_nrm"))
+
+
+def test_gpu_storage_order_does_not_change_the_bytes(oracle):
+    """a surface stored in lattice order and the same surface in a scan-like (shuffled) order both give the oracle's
+    bytes at the bench's frame size - with the locality relabelling decided per frame (default: the lattice frame skips it, the
+    shuffled one gets it), forced on and switched off, through the LDS walkers and the lane-per-walker kernels."""
+    import subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import synth, uvol\nimport oracle as o\n"
+        "o.lib(); c = uvol.Codec(device=0)\n"
+        "a = synth.sphere_mesh(frame=1, seed=1); b = synth.shuffle_mesh(a, seed=7); t = synth.shuffle_mesh(synth.torus_mesh(), seed=2)\n"
+        "frames = [a, b, t, synth.shuffle_mesh(synth.grid_mesh(), seed=4)]\n"
+        "res = c.encode_mesh_batch(frames)\n"
+        "for f, r in zip(frames, res):\n"
+        "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
+    for env in (dict(), dict(UVOL_RELABEL="1"), dict(UVOL_RELABEL="0"), dict(UVOL_SIMT_W="16"), dict(UVOL_RELABEL="1", UVOL_SIMT_W="3")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])

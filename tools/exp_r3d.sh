@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r3d; rm -rf $O; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_geom.py tests/test_gpu_cli.py -x -q -m gpu > $O/pytest_geom.log 2>&1; tail -2 $O/pytest_geom.log
+for ord in lattice shuffled; do
+  timeout 600 python bench.py --no-cpu-baseline --no-variants --steps 2 --warmup 1 --only geo --mesh-order $ord > $O/geo_${ord}.json 2>> $O/err.log
+  timeout 600 python bench.py --no-cpu-baseline --no-variants --steps 2 --warmup 1 --mesh-order $ord > $O/full_${ord}.json 2>> $O/err.log
+done
+tail -3 $O/err.log
+for f in $O/*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); g=d["kernel_groups_ms_per_step"]
+    print(sys.argv[1].split('/')[-1], round(d["value"],1), "fps", round(d["ms_per_step"],1), "ms |", " ".join("%s=%.1f"%(k.split('.')[1],v) for k,v in sorted(g.items(), key=lambda x:-x[1])[:10]))
+except Exception as e: print(sys.argv[1], "ERR", e)
+PY
+done

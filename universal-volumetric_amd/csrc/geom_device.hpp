@@ -60,6 +60,17 @@ struct GeoJob {
   // ---- workspace ----
   uint32_t *dd_tab[3]; uint32_t dd_cap[3]; uint32_t *canon[3]; uint32_t n_dup[3];      // hash-table dedup (worst-case retry): n_dup: phase 0 saw two equal values
   uint4 *dd_part[3]; uint32_t *dd_cnt[3]; uint32_t dd_nb[3], dd_nblk[3];               // partitioned dedup: {index, words} records by hash bin; counts[bin][tile]
+  // locality relabelling (k_ms_*): positions get new ids in Morton order of their quantised coordinates, faces are stored in the
+  // order of their lowest new vertex id.  Ids and storage order are identities only - the bitstream is the one the input order
+  // gives (component starts and non-manifold tie-breaks still follow the ORIGINAL face order through forig / s_of_o).
+  int32_t relabel;                         // 1: on for this frame
+  uint32_t *ms_key[2];                     // [0] Morton key per position; [1] per input face: lowest new vertex id (~0u: dropped face)
+  uint2 *ms_part; uint32_t *ms_cnt;        // {key, index} records by bin; counts[bin][tile]
+  uint32_t ms_nb[2], ms_nblk[2], ms_sh[2]; // bins, tiles, bin = key >> sh
+  uint32_t *prank;                         // position -> new id
+  float *pos_s;                            // positions in new-id order
+  uint32_t *fperm, *cidx;                  // sorted slot -> input face; input face -> its index among the kept faces (original order)
+  int32_t *forig, *s_of_o;                 // stored face -> original kept-face index, and back
   uint32_t *he_part, *he_cnt; uint32_t he_vpb, he_nb, he_nblk;      // partitioned bucket build: {from, to, corner} records by vertex range; counts[bin][tile]; vertices per bin (0: atomic build)
   uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)

@@ -263,6 +263,187 @@ struct uvol_s3 { int32_t x, y, z; };
 #else
 typedef int32_t uvol_s3 __attribute__((ext_vector_type(3), aligned(4)));
 #endif
+// ------------------------------------------------------------------------------------------------
+// Locality relabelling.  The serial walkers pay one dependent memory access per face, and what that access costs is decided by
+// where the neighbouring face's record lies: in a file whose faces / vertices are stored in scan order (no relation between
+// index and place on the surface) every step is an HBM miss and the gather kernels lose their coalescing - 2.3x for the whole
+// path (profiles/r02_*_variant_shuffled_order).  So the frame is relabelled first: positions get new ids in Morton order of
+// their coordinates (10 bits per axis over the bounding box), faces are stored in the order of their lowest new vertex id.
+// Neither the ids nor the storage order reach the bitstream: vertex ids are identities, the renumbering into decoder order
+// follows the walk, and the two places that DO depend on the input's face order - which unvisited face starts the next
+// component, and which corner wins a non-manifold edge - keep using the original order through forig[] / s_of_o[].  The .drc
+// is byte-identical with and without the relabelling (tests: shuffled and lattice storage of one surface both match the oracle).
+// It is not a full sort and does not need to be: keys are binned by their top bits (count -> scan -> scatter of 8-byte records,
+// LDS counters only), then one workgroup per bin orders its records by the next 11 bits with an LDS histogram; entries with
+// equal prefixes stay in arbitrary order (the new ids are a performance hint, any bijection is correct).
+// ------------------------------------------------------------------------------------------------
+#define MS_TILE 2048
+#define MS_MAXBINS 1024
+#define MS_SUB 2048
+__device__ __forceinline__ uint32_t ms_spread10(uint32_t x) {
+  x &= 0x3ffu; x = (x | (x << 16)) & 0x030000ffu; x = (x | (x << 8)) & 0x0300f00fu; x = (x | (x << 4)) & 0x030c30c3u; x = (x | (x << 2)) & 0x09249249u; return x;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_ms_key_pos(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  if (!J.relabel) return;
+  const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (i >= J.n_pos) return;
+  uint32_t key = 0;
+  for (int k = 0; k < 3; k++) {
+    const float lo = g_float_unorder(J.pos_min_u[k]), hi = g_float_unorder(J.pos_max_u[k]), r = hi - lo;
+    const float t = r > 0.f ? (J.pos[3 * (size_t)i + k] - lo) * (1023.0f / r) : 0.f;
+    const uint32_t q = t >= 1023.f ? 1023u : (t > 0.f ? (uint32_t)t : 0u);                 // NaN -> 0
+    key |= ms_spread10(q) << k;
+  }
+  J.ms_key[0][i] = key;
+}
+// Is the frame stored coherently already (consecutive faces adjacent on the surface, the vertices of a face close in index: a
+// lattice, a strip-ordered export, a file that went through a vertex-cache optimiser)?  Then the relabelling would only cost its
+// passes (+8 % on the lattice bench) and is skipped for this frame.  relabel: 2 = decide here, 1 = forced on, 0 = off.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_coherence(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  const bool on = J.status == 0 && J.relabel == 2;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  uint32_t share = 0, tight = 0;
+  if (on && f > 0 && f < J.nf_in) {
+    const uint32_t a0 = J.ipos[3 * f], a1 = J.ipos[3 * f + 1], a2 = J.ipos[3 * f + 2], b0 = J.ipos[3 * f - 3], b1 = J.ipos[3 * f - 2], b2 = J.ipos[3 * f - 1];
+    share = (a0 == b0 || a0 == b1 || a0 == b2 || a1 == b0 || a1 == b1 || a1 == b2 || a2 == b0 || a2 == b1 || a2 == b2) ? 1u : 0u;
+    const uint32_t mx = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2), mn = a0 < a1 ? (a0 < a2 ? a0 : a2) : (a1 < a2 ? a1 : a2);
+    tight = (mx - mn) <= J.n_pos / 16u + 64u ? 1u : 0u;
+  }
+  const uint32_t s1 = block_sum(share), s2 = block_sum(tight);
+  if (threadIdx.x == 0 && on) { if (s1) atomicAdd(&J.ms_nb[1], s1); if (s2) atomicAdd(&J.ms_nblk[1], s2); }     // (the two fields are set for good by k_relabel_decide)
+}
+__global__ void __launch_bounds__(64) k_relabel_decide(GeoJob *jobs, int n) {
+  const int j = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (j >= n) return;
+  GeoJob &J = jobs[j];
+  if (J.relabel == 2) {
+    const uint64_t nf = J.nf_in, share = J.ms_nb[1], tight = J.ms_nblk[1];
+    J.relabel = (share * 100 >= nf * 60 && tight * 100 >= nf * 90) ? 0 : 1;
+  }
+  uint32_t kb = 0; { uint32_t v = J.n_pos ? J.n_pos - 1 : 0; while (v) { kb++; v >>= 1; } }
+  J.ms_sh[1] = kb > 10 ? kb - 10 : 0; J.ms_nb[1] = ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1; J.ms_nblk[1] = (J.nf_in + MS_TILE - 1) / MS_TILE;
+}
+__device__ __forceinline__ uint32_t ms_count_of(const GeoJob &J, int which) { return which == 0 ? J.n_pos : J.nf_in; }
+__global__ void __launch_bounds__(UVOL_BLOCK) k_ms_count(GeoJob *jobs, int which) {
+  JOB_OR_RETURN_UNIFORM;
+  if (!J.relabel) return;
+  const uint32_t nb = J.ms_nb[which], nblk = J.ms_nblk[which], sh = J.ms_sh[which], n = ms_count_of(J, which);
+  if (blockIdx.x >= nblk) return;
+  __shared__ uint32_t hist[MS_MAXBINS];
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) hist[b] = 0;
+  __syncthreads();
+  const uint32_t *key = J.ms_key[which];
+  for (uint32_t k = 0; k < MS_TILE / UVOL_BLOCK; k++) {
+    const uint32_t i = blockIdx.x * MS_TILE + k * UVOL_BLOCK + threadIdx.x;
+    if (i < n) { const uint32_t kk = key[i]; if (kk != 0xffffffffu) atomicAdd(&hist[kk >> sh], 1u); }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) J.ms_cnt[(size_t)b * nblk + blockIdx.x] = hist[b];
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_ms_scan(GeoJob *jobs, int which) {
+  JOB_OR_RETURN_UNIFORM;
+  if (!J.relabel) return;
+  const uint32_t m = J.ms_nb[which] * J.ms_nblk[which];
+  uint32_t *cnt = J.ms_cnt;
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < m; b0 += UVOL_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < m ? cnt[i] : 0, tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    if (i < m) cnt[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[m] = carry;
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_ms_scatter(GeoJob *jobs, int which) {
+  JOB_OR_RETURN_UNIFORM;
+  if (!J.relabel) return;
+  const uint32_t nb = J.ms_nb[which], nblk = J.ms_nblk[which], sh = J.ms_sh[which], n = ms_count_of(J, which);
+  if (blockIdx.x >= nblk) return;
+  __shared__ uint32_t cur[MS_MAXBINS];
+  for (uint32_t b = threadIdx.x; b < nb; b += UVOL_BLOCK) cur[b] = J.ms_cnt[(size_t)b * nblk + blockIdx.x];
+  __syncthreads();
+  const uint32_t *key = J.ms_key[which];
+  for (uint32_t k = 0; k < MS_TILE / UVOL_BLOCK; k++) {
+    const uint32_t i = blockIdx.x * MS_TILE + k * UVOL_BLOCK + threadIdx.x;
+    if (i < n) { const uint32_t kk = key[i]; if (kk != 0xffffffffu) { const uint32_t pos = atomicAdd(&cur[kk >> sh], 1u); J.ms_part[pos] = make_uint2(kk, i); } }
+  }
+}
+// one workgroup per bin: order the bin's records by the next (up to) 11 key bits and hand out the final slots
+__global__ void __launch_bounds__(UVOL_BLOCK) k_ms_place(GeoJob *jobs, int which) {
+  JOB_OR_RETURN_UNIFORM;
+  if (!J.relabel) return;
+  const uint32_t nb = J.ms_nb[which], nblk = J.ms_nblk[which], sh = J.ms_sh[which];
+  if (blockIdx.x >= nb) return;
+  const uint32_t lo = J.ms_cnt[(size_t)blockIdx.x * nblk], hi = J.ms_cnt[(size_t)(blockIdx.x + 1) * nblk];
+  const uint32_t sh2 = sh > 11u ? sh - 11u : 0u, smask = (1u << (sh - sh2)) - 1u;          // sub-key = key bits [sh2, sh)
+  __shared__ uint32_t sub[MS_SUB];
+  __shared__ uint32_t carry;
+  for (uint32_t j = threadIdx.x; j < MS_SUB; j += UVOL_BLOCK) sub[j] = 0;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const uint2 *part = J.ms_part;
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += UVOL_BLOCK) atomicAdd(&sub[(part[e].x >> sh2) & smask], 1u);
+  __syncthreads();
+  for (uint32_t j0 = 0; j0 < MS_SUB; j0 += UVOL_BLOCK) {
+    const uint32_t j = j0 + threadIdx.x;
+    uint32_t v = sub[j], tot;
+    const uint32_t ex = block_excl_scan(v, &tot);
+    const uint32_t c = carry;
+    sub[j] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += UVOL_BLOCK) {
+    const uint2 r = part[e];
+    const uint32_t slot = lo + atomicAdd(&sub[(r.x >> sh2) & smask], 1u);
+    if (which == 0) {
+      J.prank[r.y] = slot;
+      const float *src = J.pos + 3 * (size_t)r.y; float *dst = J.pos_s + 3 * (size_t)slot;
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    } else J.fperm[slot] = r.y;
+  }
+}
+// per kept input face: its index among the kept faces in input order (the face numbering Draco's semantics refer to)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_face_cidx(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  if (!J.relabel) return;                                  // block-uniform
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const bool live = J.status == 0 && f < J.nf_in;
+  uint32_t v = live ? J.keep[f] : 0, tot;
+  const uint32_t pos = block_excl_scan(v, &tot) + (blockIdx.x <= uvol_blocks_dev(J.nf_in) ? J.bsum[blockIdx.x] : 0);
+  if (live && v) J.cidx[f] = pos;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
+    const uint32_t nf = J.bsum[uvol_blocks_dev(J.nf_in)];
+    J.nf = nf; J.nc = 3 * nf;
+    if (nf == 0) J.status = -3;
+  }
+}
+// stored face s <- input face fperm[s]: canonical ids (positions in their new numbering) and the maps to / from the original order
+__global__ void __launch_bounds__(UVOL_BLOCK) k_relabel_faces(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  if (!J.relabel) return;
+  const uint32_t s = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (s >= J.nf) return;
+  const uint32_t f = J.fperm[s];
+  uvol_s3 a, b, c;
+  a.x = (int32_t)J.prank[J.canon[0][J.ipos[3 * f]]]; a.y = (int32_t)J.prank[J.canon[0][J.ipos[3 * f + 1]]]; a.z = (int32_t)J.prank[J.canon[0][J.ipos[3 * f + 2]]];
+  b.x = b.y = b.z = 0; c.x = c.y = c.z = 0;
+  if (J.has_uv) { b.x = (int32_t)J.canon[1][J.iuv[3 * f]]; b.y = (int32_t)J.canon[1][J.iuv[3 * f + 1]]; b.z = (int32_t)J.canon[1][J.iuv[3 * f + 2]]; }
+  if (J.has_nrm) { c.x = (int32_t)J.canon[2][J.inrm[3 * f]]; c.y = (int32_t)J.canon[2][J.inrm[3 * f + 1]]; c.z = (int32_t)J.canon[2][J.inrm[3 * f + 2]]; }
+  *reinterpret_cast<uvol_s3 *>(J.cp + 3 * (size_t)s) = a; *reinterpret_cast<uvol_s3 *>(J.cu + 3 * (size_t)s) = b; *reinterpret_cast<uvol_s3 *>(J.cn + 3 * (size_t)s) = c;
+  const uint32_t co = J.cidx[f];
+  J.forig[s] = (int32_t)co; J.s_of_o[co] = (int32_t)s;
+}
+
 // per input face: canonical ids, keep flag, index validation
 __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
   JOB_OR_RETURN_UNIFORM;
@@ -278,6 +459,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
     }
     keep = (a[0] != a[1] && a[1] != a[2] && a[0] != a[2]) ? 1u : 0u;
     J.keep[f] = (uint8_t)keep;
+    if (J.relabel) {                                                     // sort key of the face: its lowest NEW vertex id (dropped faces are left out)
+      uint32_t k0 = 0xffffffffu;
+      if (keep && !bad) { const uint32_t r0 = J.prank[a[0]], r1 = J.prank[a[1]], r2 = J.prank[a[2]]; k0 = r0 < r1 ? r0 : r1; k0 = r2 < k0 ? r2 : k0; }
+      J.ms_key[1][f] = k0;
+    }
   }
   const uint32_t tot = block_sum(keep);                                  // block sums of the keep flags (was a k_scan_blocks pass)
   if (threadIdx.x == 0 && blockIdx.x < uvol_blocks_dev(J.nf_in)) J.bsum[blockIdx.x] = tot;
@@ -285,6 +471,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
+  if (J.relabel) return;                                   // block-uniform: k_face_cidx + k_relabel_faces store the faces instead
   uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   bool live = J.status == 0 && f < J.nf_in;
   uint32_t v = live ? J.keep[f] : 0, tot;
@@ -464,8 +651,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_edge_match(GeoJob *jobs) {
     const uint32_t c = c0 + k * UVOL_BLOCK;
     if (c >= nc) continue;
     uint32_t self = 0xffffffffu, o = 0xffffffffu;      // (fetching the first eight entries of both buckets at once was slower: 24 vs 20 ms)
-    for (uint32_t i = sa[k]; i < ea[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == b[k]) { const uint32_t cc = (uint32_t)v; self = cc < self ? cc : self; } }
-    for (uint32_t i = sb[k]; i < eb[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == a[k]) { const uint32_t cc = (uint32_t)v; o = cc < o ? cc : o; } }
+    // "lowest corner" means lowest in the ORIGINAL face order: only looked up when an edge has several corners (non-manifold)
+    const bool rl = J.relabel != 0;
+#define EM_LOWER(x, y) (rl ? (3u * (uint32_t)J.forig[(x) / 3u] + (x) % 3u < 3u * (uint32_t)J.forig[(y) / 3u] + (y) % 3u) : ((x) < (y)))
+    for (uint32_t i = sa[k]; i < ea[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == b[k]) { const uint32_t cc = (uint32_t)v; if (self == 0xffffffffu || EM_LOWER(cc, self)) self = cc; } }
+    for (uint32_t i = sb[k]; i < eb[k]; i++) { const unsigned long long v = J.he_ent[i]; if ((uint32_t)(v >> 32) == a[k]) { const uint32_t cc = (uint32_t)v; if (o == 0xffffffffu || EM_LOWER(cc, o)) o = cc; } }
+#undef EM_LOWER
     J.opp[c] = (self == c && o != 0xffffffffu) ? (int)o : GEO_INV;
   }
 }
@@ -711,9 +902,13 @@ __device__ __forceinline__ void eb_walk_lane0(GeoJob &J, FB fbits, VB vbits, UVO
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
 #define W_EMIT(SYM) do { stg.b[nproc & (WALK_STG - 1)] = (uint8_t)(SYM); nproc++; if ((nproc & (WALK_STG - 1)) == 0) { stg.flush_words(proc, nproc); stg.flush_bytes(symb, nproc); } } while (0)
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
-  for (int f0 = 0; f0 < nf; f0++) {
-    // component starts: fully visited words of the face bitmap are skipped 32 faces at a time
-    if ((f0 & 31) == 0) { while (f0 + 32 <= nf && pword(fbits, f0 >> 5) == 0xffffffffu) f0 += 32; if (f0 >= nf) break; }
+  const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
+  for (int fo = 0; fo < nf; fo++) {
+    // component starts, in the ORIGINAL face order (a relabelled frame maps it to the stored face); fully visited words of the
+    // face bitmap are skipped 32 faces at a time where stored order = original order
+    int f0 = fo;
+    if (rl) { if (nproc + ninit >= nf) break; f0 = s_of_o[fo]; }
+    else if ((fo & 31) == 0) { while (fo + 32 <= nf && pword(fbits, fo >> 5) == 0xffffffffu) fo += 32; if (fo >= nf) break; f0 = fo; }
     if (pbit_get(fbits, f0)) continue;
     int v0[3], r0_[3], l0_[3];
     for (int k = 0; k < 3; k++) RO::get(rec, 4 * f0 + k, v0[k], r0_[k], l0_[k]);
@@ -855,8 +1050,11 @@ __device__ __forceinline__ void eb_walk_coop(GeoJob &J, UVOL_L(uint32_t) lds, ui
   uint32_t pv = 0, sv = 0;                               // output staging: lane k = entry (nproc & ~63) + k of proc[] / symb[]
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
 #define C_FWORD(k) ((uint32_t)UVOL_BCAST0(lds[k]))
-  for (int f0 = 0; f0 < nf; f0++) {
-    if ((f0 & 31) == 0) { while (f0 + 32 <= nf && C_FWORD(f0 >> 5) == 0xffffffffu) f0 += 32; if (f0 >= nf) break; }
+  const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
+  for (int fo = 0; fo < nf; fo++) {
+    int f0 = fo;                                         // component starts follow the ORIGINAL face order (see eb_walk_lane0)
+    if (rl) { if (nproc + ninit >= nf) break; f0 = UVOL_READFIRST(s_of_o[fo]); }
+    else if ((fo & 31) == 0) { while (fo + 32 <= nf && C_FWORD(fo >> 5) == 0xffffffffu) fo += 32; if (fo >= nf) break; f0 = fo; }
     if ((C_FWORD(f0 >> 5) >> (f0 & 31)) & 1u) continue;
     int v0[3], r0_[3], l0_[3];
     for (int k = 0; k < 3; k++) coop_get<R8>(rec, 4 * f0 + k, v0[k], r0_[k], l0_[k]);
@@ -1461,6 +1659,12 @@ __global__ void __launch_bounds__(128) k_traverse(GeoJob *jobs, int vcap_words, 
   } while (0)
 #define S_TAKE(a, b, c, vi, rc, lc) do { if (R8) rec8_dec(a, b, vi, rc, lc); else { vi = (int)(a); rc = (int)(b); lc = (int)(c); } } while (0)
 
+// One step of a lane is the SAME straight-line code whatever its symbol (C / R / L / S differ only in predicated selects and
+// two predicated stack stores), so the lanes of a wave do not serialise on their symbols: frames of a real sequence have
+// different connectivity and walk different paths, and the earlier branch-per-symbol form ran 3 - 4 x slower on them than on
+// the bench's lattice frames, whose walkers happen to move in lock step (tools/exp_r3e: 450 vs 136 ms per 2160 frames, equal
+// with one lane per wave).  Only the rare events leave the line: a dead end (E: pop the stack, a dependent load) and the search
+// for the next component.  The S symbol is "go right and push the left neighbour": its record is already prefetched.
 template <bool R8>
 __device__ inline void eb_walk_simt(GeoJob &J) {
   const int nf = (int)J.nf;
@@ -1468,66 +1672,72 @@ __device__ inline void eb_walk_simt(GeoJob &J) {
   UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis));
   UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
   UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
+  const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
-  enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
-  for (int f0 = 0; f0 < nf && nproc + ninit < nf; f0++) {
-    if (S_FLAG(4 * f0)) continue;
-    int v0[3], r0_[3], l0_[3];
-    for (int k = 0; k < 3; k++) S_REC(4 * f0 + k, v0[k], r0_[k], l0_[k]);
-    const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
-    int interior = 1, start = 4 * f0;
-    for (int k = 0; k < 3; k++) {
-      if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
-      if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
-        int ci = 4 * f0 + k, rc = ci;
-        while (rc >= 0) { ci = rc; int v_, r_, l_; S_REC(rc, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
-        interior = 0; start = code_prv(ci); break;
-      }
-    }
-    start_bits[nstart] = (uint8_t)interior;
-    nstart++;
-    int from;
-    if (interior) {
-      for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = vbits[v >> 5]; vbits[v >> 5] = w | (1u << (v & 31)); }
-      S_FLAG(4 * f0) = 1u;
-      initc[ninit] = 3 * f0 + 1;
-      ninit++;
-      from = o0[1];
-      if (from < 0 || S_FLAG(from)) continue;
-    } else from = start;
-    int sp = 0;
-    stack[sp] = from;
-    sp++;
-    while (sp > 0) {
-      int x = stack[sp - 1];
-      if (x < 0 || S_FLAG(x)) { sp--; continue; }
-      int vi, rcn, lcn;
-      S_REC(x, vi, rcn, lcn);
+  int fo = 0, sp = 0, x = -1, vi = 0, rcn = -1, lcn = -1;
+  for (;;) {
+    if (x < 0) {                                          // rare: a corner to go on from - the stack, else the next component
+      bool finished = false;
       for (;;) {
-        const int face = x >> 2;
-        S_FLAG(x) = 1u;
-        uint32_t ra, rb, rc_, rfl, la, lb, lc_, lfl;
-        S_PRE(rcn < 0 ? x : rcn, ra, rb, rc_, rfl);
-        S_PRE(lcn < 0 ? x : lcn, la, lb, lc_, lfl);
-        proc[nproc] = 3 * face + (x & 3);
-        const int v = vi >> 1;
-        const uint32_t vw = vbits[v >> 5];
-        if (!((vw >> (v & 31)) & 1u)) {
-          vbits[v >> 5] = vw | (1u << (v & 31));
-          if (!(vi & 1)) { symb[nproc] = T_C; nproc++; x = rcn; S_TAKE(ra, rb, rc_, vi, rcn, lcn); continue; }
+        if (sp > 0) {
+          const int c = stack[sp - 1];
+          if (c < 0 || S_FLAG(c)) { sp--; continue; }
+          x = c; S_REC(x, vi, rcn, lcn);
+          break;
         }
-        const bool rvis = rcn < 0 || rfl != 0, lvis = lcn < 0 || lfl != 0;
-        const int sym = rvis ? (lvis ? T_E : T_R) : (lvis ? T_L : T_S);
-        symb[nproc] = (uint8_t)sym;
-        nproc++;
-        if (sym == T_E) { sp--; break; }
-        if (sym == T_R) { x = lcn; S_TAKE(la, lb, lc_, vi, rcn, lcn); continue; }
-        if (sym == T_L) { x = rcn; S_TAKE(ra, rb, rc_, vi, rcn, lcn); continue; }
-        nsplit++;
-        stack[sp - 1] = lcn; stack[sp] = rcn;
-        sp++;
-        break;
+        if (fo >= nf || nproc + ninit >= nf) { finished = true; break; }
+        const int f0 = rl ? s_of_o[fo] : fo;             // component starts follow the ORIGINAL face order
+        fo++;
+        if (S_FLAG(4 * f0)) continue;
+        int v0[3], r0_[3], l0_[3];
+        for (int k = 0; k < 3; k++) S_REC(4 * f0 + k, v0[k], r0_[k], l0_[k]);
+        const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
+        int interior = 1, start = 4 * f0;
+        for (int k = 0; k < 3; k++) {
+          if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
+          if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
+            int ci = 4 * f0 + k, rc = ci;
+            while (rc >= 0) { ci = rc; int v_, r_, l_; S_REC(rc, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
+            interior = 0; start = code_prv(ci); break;
+          }
+        }
+        start_bits[nstart] = (uint8_t)interior;
+        nstart++;
+        int from;
+        if (interior) {
+          for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = vbits[v >> 5]; vbits[v >> 5] = w | (1u << (v & 31)); }
+          S_FLAG(4 * f0) = 1u;
+          initc[ninit] = 3 * f0 + 1;
+          ninit++;
+          from = o0[1];
+          if (from < 0 || S_FLAG(from)) continue;
+        } else from = start;
+        stack[0] = from; sp = 1;
       }
+      if (finished) break;
+    }
+    // ---- the common step ----
+    S_FLAG(x) = 1u;
+    uint32_t ra, rb, rc_, rfl, la, lb, lc_, lfl;
+    S_PRE(rcn < 0 ? x : rcn, ra, rb, rc_, rfl);
+    S_PRE(lcn < 0 ? x : lcn, la, lb, lc_, lfl);
+    proc[nproc] = 3 * (x >> 2) + (x & 3);
+    const int v = vi >> 1;
+    const uint32_t vw = vbits[v >> 5];
+    vbits[v >> 5] = vw | (1u << (v & 31));                                  // (already set when the tip was visited)
+    const uint32_t vvis = (vw >> (v & 31)) & 1u;
+    const uint32_t rvis = (rcn < 0 || rfl != 0) ? 1u : 0u, lvis = (lcn < 0 || lfl != 0) ? 1u : 0u;
+    const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;                    // tip unvisited and not on a boundary
+    const uint32_t sym = ccase ? 0u : 1u + 2u * lvis + 4u * rvis;           // C 0, S 1, L 3, R 5, E 7
+    symb[nproc] = (uint8_t)sym;
+    nproc++;
+    if (sym == 1u) { stack[sp - 1] = lcn; stack[sp] = rcn; sp++; nsplit++; }   // S: the left neighbour waits on the stack, the walk goes right
+    if (sym == 7u) { sp--; x = -1; }
+    else {
+      const bool go_l = sym == 5u;
+      x = go_l ? lcn : rcn;
+      const uint32_t qa = go_l ? la : ra, qb = go_l ? lb : rb, qc = go_l ? lc_ : rc_;
+      S_TAKE(qa, qb, qc, vi, rcn, lcn);
     }
   }
   J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
@@ -1547,45 +1757,56 @@ __global__ void __launch_bounds__(64) k_eb_walk_simt(GeoJob *jobs, int n, int W)
   eb_walk_simt<R8>(J);
 }
 
+// attribute sequencing with the same straight-line step (see eb_walk_simt)
 template <bool R8>
 __device__ inline void traverse_simt(GeoJob &J, int t) {
   const int nf = (int)J.nf;
   UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
   UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
-  int n = 0, nvis = 0;
-  for (int f = 0; f < nf && nvis < nf; f++) {
-    if (S_FLAG(4 * f)) continue;
-    int x = 4 * f, sp = 0;
-    stack[sp] = x;
-    sp++;
-    { int vn, vp, r_, l_; S_REC(x + 1, vn, r_, l_); S_REC(x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
-      uint32_t w = vbits[vn >> 5];
-      if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f + 1; n++; }
-      w = vbits[vp >> 5];
-      if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f + 2; n++; } }
-    while (sp > 0) {
-      x = stack[sp - 1];
-      if (x < 0 || S_FLAG(x)) { sp--; continue; }
-      int vi, rc, lc;
-      S_REC(x, vi, rc, lc);
+  int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
+  for (;;) {
+    if (x < 0) {                                          // rare: the stack, else the next unvisited face starts a component
+      bool finished = false;
       for (;;) {
-        const int face = x >> 2;
-        S_FLAG(x) = 1u;
-        nvis++;
-        uint32_t ra, rb, rc_, rfl, la, lb, lc_, lfl;
-        S_PRE(rc < 0 ? x : rc, ra, rb, rc_, rfl);
-        S_PRE(lc < 0 ? x : lc, la, lb, lc_, lfl);
-        const int v = vi >> 1;
-        const uint32_t vw = vbits[v >> 5];
-        if (!((vw >> (v & 31)) & 1u)) {
-          vbits[v >> 5] = vw | (1u << (v & 31)); order[n] = 3 * face + (x & 3); n++;
-          if (!(vi & 1)) { x = rc; S_TAKE(ra, rb, rc_, vi, rc, lc); continue; }
+        if (sp > 0) {
+          const int c = stack[sp - 1];
+          if (c < 0 || S_FLAG(c)) { sp--; continue; }
+          x = c; S_REC(x, vi, rc, lc);
+          break;
         }
-        const bool rvis = rc < 0 || rfl != 0, lvis = lc < 0 || lfl != 0;
-        if (rvis) { if (lvis) { sp--; break; } x = lc; S_TAKE(la, lb, lc_, vi, rc, lc); }
-        else { if (lvis) { x = rc; S_TAKE(ra, rb, rc_, vi, rc, lc); } else { stack[sp - 1] = lc; stack[sp] = rc; sp++; break; } }
+        if (f >= nf || nvis >= nf) { finished = true; break; }
+        const int f0 = f; f++;
+        if (S_FLAG(4 * f0)) continue;
+        stack[0] = 4 * f0; sp = 1;
+        int vn, vp, r_, l_; S_REC(4 * f0 + 1, vn, r_, l_); S_REC(4 * f0 + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
+        uint32_t w = vbits[vn >> 5];
+        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f0 + 1; n++; }
+        w = vbits[vp >> 5];
+        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f0 + 2; n++; }
       }
+      if (finished) break;
+    }
+    S_FLAG(x) = 1u;
+    nvis++;
+    uint32_t ra, rb, rc_, rfl, la, lb, lc_, lfl;
+    S_PRE(rc < 0 ? x : rc, ra, rb, rc_, rfl);
+    S_PRE(lc < 0 ? x : lc, la, lb, lc_, lfl);
+    const int v = vi >> 1;
+    const uint32_t vw = vbits[v >> 5];
+    vbits[v >> 5] = vw | (1u << (v & 31));
+    const uint32_t vvis = (vw >> (v & 31)) & 1u;
+    if (!vvis) { order[n] = 3 * (x >> 2) + (x & 3); n++; }                  // a vertex seen for the first time takes the next place
+    const uint32_t rvis = (rc < 0 || rfl != 0) ? 1u : 0u, lvis = (lc < 0 || lfl != 0) ? 1u : 0u;
+    const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;
+    const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
+    if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; }
+    if (k == 4u) { sp--; x = -1; }
+    else {
+      const bool go_l = k == 2u;
+      x = go_l ? lc : rc;
+      const uint32_t qa = go_l ? la : ra, qb = go_l ? lb : rb, qc = go_l ? lc_ : rc_;
+      S_TAKE(qa, qb, qc, vi, rc, lc);
     }
   }
   J.ne[t] = (uint32_t)n;
@@ -1669,7 +1890,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_quantize(GeoJob *jobs) {
   if (a == 0) {
     if (p < J.ne[0]) {
       const float range = quant_range(J.pos_min_u, J.pos_max_u, 3), inv = (float)((1u << J.qp) - 1) / range;
-      const float *v = J.pos + 3 * (size_t)J.npid[J.order[0][p]];
+      const float *v = (J.relabel ? J.pos_s : J.pos) + 3 * (size_t)J.npid[J.order[0][p]];
       for (int k = 0; k < 3; k++) { float t = v[k] - g_float_unorder(J.pos_min_u[k]); t = t * inv; int q = (int)floorf(t + 0.5f); J.P[3 * p + k] = q; lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
       have = true;
     }
@@ -2462,6 +2683,21 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
     if (full) { CARVE(J.dd_tab[k], uint32_t, J.dd_cap[k], PH_DEDUP, PH_DEDUP); }
     else { CARVE(J.dd_part[k], uint4, (size_t)n + 1, PH_DEDUP, PH_DEDUP); CARVE(J.dd_cnt[k], uint32_t, (size_t)J.dd_nb[k] * J.dd_nblk[k] + 2, PH_DEDUP, PH_DEDUP); }
   }
+  // locality relabelling (k_ms_*): keys, {key, index} records, counts matrices; new position ids / positions in that order; face maps
+  if (J.relabel) {
+    const size_t nmax = std::max<size_t>(J.n_pos, nfi);
+    auto bits_of = [&](uint64_t v) { uint32_t b = 0; while (v) { b++; v >>= 1; } return b; };
+    J.ms_sh[0] = 20; J.ms_nb[0] = MS_MAXBINS; J.ms_nblk[0] = (uint32_t)((J.n_pos + MS_TILE - 1) / MS_TILE);                  // 30-bit Morton keys: bin = top 10 bits
+    { const uint32_t kb = bits_of(J.n_pos ? J.n_pos - 1 : 0); J.ms_sh[1] = kb > 10 ? kb - 10 : 0; }
+    J.ms_nb[1] = 0; J.ms_nblk[1] = 0;                      // k_coherence counts in them, k_relabel_decide then sets bins / tiles of the face sort
+    const uint32_t ms_nblk1 = (uint32_t)((nfi + MS_TILE - 1) / MS_TILE);
+    CARVE(J.ms_key[0], uint32_t, (size_t)J.n_pos + 1, PH_DEDUP, PH_DEDUP); CARVE(J.ms_key[1], uint32_t, nfi + 1, PH_FACES, PH_FACES);
+    CARVE(J.ms_part, uint2, nmax + 1, PH_DEDUP, PH_FACES);
+    CARVE(J.ms_cnt, uint32_t, (size_t)MS_MAXBINS * std::max(J.ms_nblk[0], ms_nblk1) + 2, PH_DEDUP, PH_FACES);
+    CARVE(J.prank, uint32_t, (size_t)J.n_pos + 1, PH_DEDUP, PH_FACES); CARVE(J.pos_s, float, 3 * (size_t)J.n_pos + 3, PH_DEDUP, PH_QUANT);
+    CARVE(J.fperm, uint32_t, nfi + 1, PH_FACES, PH_FACES); CARVE(J.cidx, uint32_t, nfi + 1, PH_FACES, PH_FACES);
+    CARVE(J.forig, int32_t, nfi + 1, PH_FACES, PH_CT); CARVE(J.s_of_o, int32_t, nfi + 1, PH_FACES, PH_WALK);
+  }
   // ---- pinned, zero-initialised ----
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
@@ -2572,7 +2808,7 @@ void ws_place(std::vector<WsItem> &items, WsPlan &P) {
 // of jobs with the same dimensions (a sequence's frames usually are).
 size_t layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlan &P, std::vector<WsItem> &items) {
   ws_collect(J, full, r8, items);
-  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25), items.size() };
+  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26), items.size() };
   if (key != P.key) { ws_place(items, P); P.key = key; }
   if (base) for (size_t i = 0; i < items.size(); i++) *reinterpret_cast<uint8_t **>((char *)&J + items[i].slot) = base + P.offs[i];
   return P.total;
@@ -2633,6 +2869,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_clear(GeoJob *jobs) {
 // UVOL_SIMT_W=<1..64> forces the SIMT form with that many lanes per wave, UVOL_WALK_FORCE=global its one-lane-per-wave form
 // (what a mesh too large for LDS gets), UVOL_WALK_FORCE=vglobal LDS walkers with their vertex bitmap in global memory (tests).
 struct WalkPlan { int simt_w; size_t lds; int vcw; };
+// locality relabelling: 2 = per frame, decided on the device (k_coherence: frames stored coherently skip it); UVOL_RELABEL=1 / 0 (tests, diagnostic) force it on / off
+static inline int geo_relabel_mode() { static const int v = [] { const char *e = getenv("UVOL_RELABEL"); return !e ? 2 : (*e == '0' ? 0 : (*e == '1' ? 1 : 2)); }(); return v; }
+static inline bool geo_relabel_on() { return geo_relabel_mode() != 0; }
 static inline int geo_walk_pf() { static const int v = [] { const char *e = getenv("UVOL_WALK_PF"); return (e && *e == '0') ? 0 : 1; }(); return v; }     // UVOL_WALK_PF=0 (diagnostic): LDS walkers without their prefetch wave
 static inline int geo_simt_env() { static const int w = [] { const char *e = getenv("UVOL_SIMT_W"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }(); return w; }
 static WalkPlan walk_plan(const GeoState *G, uint32_t max_nfi, uint32_t max_vals, size_t n_walkers, bool vertex_bits_global = false) {
@@ -2687,7 +2926,7 @@ int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint3
 // device workspace one frame of these dimensions holds while it is in flight (compact layout + its share of the packed output area)
 extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   if (!ctx || !m || !m->n_faces) return 0;
-  GeoJob J{}; J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
+  GeoJob J{}; J.relabel = geo_relabel_mode(); J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
   J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
   WsPlan P; std::vector<WsItem> items;
   return layout_job(J, nullptr, false, geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)), P, items) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
@@ -2727,7 +2966,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
-    J.n_pos = m.n_pos; J.nf_in = m.n_faces;
+    J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = geo_relabel_mode();
     J.has_uv = (m.uv && m.idx_uv && m.n_uv) ? 1 : 0; J.has_nrm = (m.nrm && m.idx_nrm && m.n_nrm) ? 1 : 0;
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
@@ -2784,6 +3023,9 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
                  be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
+  const bool relabel = geo_relabel_on();
+  // bounding boxes first: the relabelling's Morton keys are taken over them (k_quantize uses them much later)
+  LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
     if (!full) {
@@ -2803,9 +3045,27 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
       LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, 1);
       LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 1);
     }
+    const unsigned mt0 = (unsigned)((max_vals + MS_TILE - 1) / MS_TILE), mt1 = (unsigned)(((size_t)max_nfi + MS_TILE - 1) / MS_TILE);
+    if (relabel) {                                           // new position ids (Morton order) and the positions in that order
+      LAUNCH(k_coherence, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_relabel_decide, dim3((N + 63) / 64), dim3(64), dj, n);
+      LAUNCH(k_ms_key_pos, dim3(bv, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_ms_count, dim3(mt0, N), dim3(UVOL_BLOCK), dj, 0);
+      LAUNCH(k_ms_scan, dim3(1, N), dim3(UVOL_BLOCK), dj, 0);
+      LAUNCH(k_ms_scatter, dim3(mt0, N), dim3(UVOL_BLOCK), dj, 0);
+      LAUNCH(k_ms_place, dim3(MS_MAXBINS, N), dim3(UVOL_BLOCK), dj, 0);
+    }
     LAUNCH(k_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_KEEP);
-    LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    if (relabel) {                                           // faces stored in the order of their lowest new vertex id
+      LAUNCH(k_face_cidx, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_ms_count, dim3(mt1, N), dim3(UVOL_BLOCK), dj, 1);
+      LAUNCH(k_ms_scan, dim3(1, N), dim3(UVOL_BLOCK), dj, 1);
+      LAUNCH(k_ms_scatter, dim3(mt1, N), dim3(UVOL_BLOCK), dj, 1);
+      LAUNCH(k_ms_place, dim3(MS_MAXBINS, N), dim3(UVOL_BLOCK), dj, 1);
+      LAUNCH(k_relabel_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    }
+    LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);       // the frames that are not relabelled (decided per frame on the device)
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k3_corner_table", (uint64_t)n * 0 + (uint64_t)3 * max_nfi * 4 * 3);
@@ -2871,7 +3131,6 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
-    LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_quantize, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
   }
   {
