@@ -75,11 +75,11 @@ def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
         "import synth, uvol\nimport oracle as o\n"
         "o.lib(); c = uvol.Codec(lib_path=%r)\n"
         "frames = [synth.torus_mesh(), synth.sphere_mesh(40, 21, charts=(5, 4)), synth.grid_mesh()]\n"
-        "frames += [synth.shuffle_mesh(frames[1], seed=3)] + list(synth.edge_case_meshes().values()) + [synth.random_soup_mesh(5), synth.random_soup_mesh(6, 60, 300)]\n"
+        "if %r: frames += [synth.shuffle_mesh(frames[1], seed=3)] + list(synth.edge_case_meshes().values()) + [synth.random_soup_mesh(5), synth.random_soup_mesh(6, 60, 300)]\n"
         "for f, r in zip(frames, c.encode_mesh_batch(frames)):\n"
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
-    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib, force.startswith("relabel"))
     env = dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="7") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="8") if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -272,7 +272,7 @@ typedef int32_t uvol_s3 __attribute__((ext_vector_type(3), aligned(4)));
 // Neither the ids nor the storage order reach the bitstream: vertex ids are identities, the renumbering into decoder order
 // follows the walk, and the two places that DO depend on the input's face order - which unvisited face starts the next
 // component, and which corner wins a non-manifold edge - keep using the original order through forig[] / s_of_o[].  The .drc
-// is byte-identical with and without the relabelling (tests: shuffled and lattice storage of one surface both match the oracle).
+// is byte-identical with and without the relabelling (tests: shuffled and lattice storage of one surface give the same bytes).
 // It is not a full sort and does not need to be: keys are binned by their top bits (count -> scan -> scatter of 8-byte records,
 // LDS counters only), then one workgroup per bin orders its records by the next 11 bits with an LDS histogram; entries with
 // equal prefixes stay in arbitrary order (the new ids are a performance hint, any bijection is correct).
@@ -322,8 +322,7 @@ __global__ void __launch_bounds__(64) k_relabel_decide(GeoJob *jobs, int n) {
     const uint64_t nf = J.nf_in, share = J.ms_nb[1], tight = J.ms_nblk[1];
     J.relabel = (share * 100 >= nf * 60 && tight * 100 >= nf * 90) ? 0 : 1;
   }
-  uint32_t kb = 0; { uint32_t v = J.n_pos ? J.n_pos - 1 : 0; while (v) { kb++; v >>= 1; } }
-  J.ms_sh[1] = kb > 10 ? kb - 10 : 0; J.ms_nb[1] = ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1; J.ms_nblk[1] = (J.nf_in + MS_TILE - 1) / MS_TILE;
+  J.ms_nb[1] = ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1; J.ms_nblk[1] = (J.nf_in + MS_TILE - 1) / MS_TILE;
 }
 __device__ __forceinline__ uint32_t ms_count_of(const GeoJob &J, int which) { return which == 0 ? J.n_pos : J.nf_in; }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_ms_count(GeoJob *jobs, int which) {
@@ -2687,8 +2686,10 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   if (J.relabel) {
     const size_t nmax = std::max<size_t>(J.n_pos, nfi);
     auto bits_of = [&](uint64_t v) { uint32_t b = 0; while (v) { b++; v >>= 1; } return b; };
-    J.ms_sh[0] = 20; J.ms_nb[0] = MS_MAXBINS; J.ms_nblk[0] = (uint32_t)((J.n_pos + MS_TILE - 1) / MS_TILE);                  // 30-bit Morton keys: bin = top 10 bits
-    { const uint32_t kb = bits_of(J.n_pos ? J.n_pos - 1 : 0); J.ms_sh[1] = kb > 10 ? kb - 10 : 0; }
+    // bins of the first level: ~512 keys each, at most MS_MAXBINS (30-bit Morton keys / ids below n_pos: bin = the key's top bits)
+    const uint32_t lb0 = std::min<uint32_t>(10, bits_of(J.n_pos / 512)), lb1 = std::min<uint32_t>(10, bits_of(nfi / 512));
+    J.ms_sh[0] = 30 - lb0; J.ms_nb[0] = 1u << lb0; J.ms_nblk[0] = (uint32_t)((J.n_pos + MS_TILE - 1) / MS_TILE);
+    { const uint32_t kb = bits_of(J.n_pos ? J.n_pos - 1 : 0); J.ms_sh[1] = kb > lb1 ? kb - lb1 : 0; }
     J.ms_nb[1] = 0; J.ms_nblk[1] = 0;                      // k_coherence counts in them, k_relabel_decide then sets bins / tiles of the face sort
     const uint32_t ms_nblk1 = (uint32_t)((nfi + MS_TILE - 1) / MS_TILE);
     CARVE(J.ms_key[0], uint32_t, (size_t)J.n_pos + 1, PH_DEDUP, PH_DEDUP); CARVE(J.ms_key[1], uint32_t, nfi + 1, PH_FACES, PH_FACES);
@@ -2956,7 +2957,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   G->hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
-  uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0, he_nb_max = 0; bool he_part_all = true; uint64_t algo_in = 0;
+  uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0, he_nb_max = 0, ms_nb_max = 1; bool he_part_all = true; uint64_t algo_in = 0;
   uint64_t max_ids = 0;
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; max_nfi = std::max(max_nfi, m.n_faces);
@@ -2982,6 +2983,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     out_total += (oc + 255) & ~(size_t)255; J.out_cap = (uint32_t)std::min<size_t>(caps[i], 0xffffffffu);
     max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm))); max_ecap = std::max(max_ecap, J.ecap);
     he_nb_max = std::max(he_nb_max, J.he_nb); he_part_all = he_part_all && J.he_vpb != 0;
+    if (J.relabel) ms_nb_max = std::max(ms_nb_max, std::max(J.ms_nb[0], ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1));
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
   int rc;
@@ -3053,7 +3055,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
       LAUNCH(k_ms_count, dim3(mt0, N), dim3(UVOL_BLOCK), dj, 0);
       LAUNCH(k_ms_scan, dim3(1, N), dim3(UVOL_BLOCK), dj, 0);
       LAUNCH(k_ms_scatter, dim3(mt0, N), dim3(UVOL_BLOCK), dj, 0);
-      LAUNCH(k_ms_place, dim3(MS_MAXBINS, N), dim3(UVOL_BLOCK), dj, 0);
+      LAUNCH(k_ms_place, dim3(ms_nb_max, N), dim3(UVOL_BLOCK), dj, 0);
     }
     LAUNCH(k_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_KEEP);
@@ -3062,7 +3064,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
       LAUNCH(k_ms_count, dim3(mt1, N), dim3(UVOL_BLOCK), dj, 1);
       LAUNCH(k_ms_scan, dim3(1, N), dim3(UVOL_BLOCK), dj, 1);
       LAUNCH(k_ms_scatter, dim3(mt1, N), dim3(UVOL_BLOCK), dj, 1);
-      LAUNCH(k_ms_place, dim3(MS_MAXBINS, N), dim3(UVOL_BLOCK), dj, 1);
+      LAUNCH(k_ms_place, dim3(ms_nb_max, N), dim3(UVOL_BLOCK), dj, 1);
       LAUNCH(k_relabel_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     }
     LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);       // the frames that are not relabelled (decided per frame on the device)
