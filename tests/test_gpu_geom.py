@@ -272,3 +272,56 @@ def test_gpu_storage_order_does_not_change_the_bytes(oracle):
     for env in (dict(), dict(UVOL_RELABEL="1"), dict(UVOL_RELABEL="0"), dict(UVOL_SIMT_W="16"), dict(UVOL_RELABEL="1", UVOL_SIMT_W="3")):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_gpu_mesh_decoder_survives_corrupt_input(oracle):
+    """Bit flips, truncation and overwritten words in .drc files ON THE DEVICE, with UVOL_DEBUG=1 (every launch synchronised, a fault
+    is attributed to its kernel): a decoded result or a clean error, never a fault, and the context still encodes afterwards."""
+    import subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, synth, uvol\nimport oracle as o\n"
+        "o.lib(); cd = uvol.Codec(device=0)\n"
+        "bases = []\n"
+        "for m in (synth.torus_mesh(), synth.grid_mesh(), synth.sphere_mesh(40, 21, charts=(5, 4))):\n"
+        "    bases.append((m, o.drc_encode(m['pos'], m['idx_pos'], m['uv'], m['idx_uv'], m['nrm'], m['idx_nrm'])))\n"
+        "rng = np.random.default_rng(11); rej = 0; okc = 0\n"
+        "for it in range(60):\n"
+        "    base = bases[it %% 3][1]; b = bytearray(base); mode = (it // 3) %% 3\n"
+        "    if mode == 0:\n"
+        "        for _ in range(int(rng.integers(1, 4))): b[int(rng.integers(11, len(b)))] ^= 1 << int(rng.integers(0, 8))\n"
+        "    elif mode == 1: b = b[:int(rng.integers(12, len(b)))]\n"
+        "    else:\n"
+        "        i = int(rng.integers(12, len(b) - 4)); b[i:i + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))\n"
+        "    try:\n"
+        "        cd.decode_mesh_batch([bytes(b), base]); okc += 1\n"
+        "    except uvol.UvolError: rej += 1\n"
+        "assert rej > 0\n"
+        "m, base = bases[0]\n"
+        "assert cd.encode_mesh(**m) == base\n"
+        "print('ok', rej, okc)\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_DEBUG="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout and "FAILED" not in r.stderr, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_gpu_256_full_size_frames_in_one_batch(oracle, gpu_codec):
+    """the regime the bench runs in - hundreds of 100k-vertex frames in ONE call (lifetime-shared workspaces, the
+    lane-per-walker kernels chosen by the batch size, not by an environment switch) - against the oracle's bytes for a sample of the
+    frames, lattice and scan-like storage orders mixed in one batch; every other frame must equal the sampled frame of its content."""
+    import synth
+    base = [synth.sphere_mesh(frame=k, seed=k) for k in range(4)]
+    base += [synth.shuffle_mesh(base[1], seed=9), synth.shuffle_mesh(base[2], seed=10)]
+    n = 264
+    frames = [base[i % len(base)] for i in range(n)]
+    res = gpu_codec.encode_mesh_batch(frames)
+    want = {}
+    for i in (0, 1, 4, 5, 130, 263):
+        k = i % len(base); f = base[k]
+        want[k] = want.get(k) or oracle.drc_encode(f["pos"], f["idx_pos"], f["uv"], f["idx_uv"], f["nrm"], f["idx_nrm"])
+        assert res[i] == want[k], i
+    first = {}
+    for i, r in enumerate(res):
+        k = i % len(base)
+        first.setdefault(k, r)
+        assert r == first[k], (i, k)
