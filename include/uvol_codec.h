@@ -13,6 +13,8 @@
  *
  * Threading: a ctx is bound to one GPU and one HIP stream; it is NOT thread-safe.  Different
  * ctxs may be used from different threads / processes (one process per GPU in bench.py).
+ * Every batched encode entry point also has an enqueue form (`*_async`): it returns at once, the work runs in call order on the
+ * context, and uvol_sync(ctx) completes it (SURVEY 8b "Threading").
  * There is NO CPU fallback: uvol_ctx_create fails with UVOL_E_NODEVICE when no gfx950 GPU is present.
  */
 #ifndef UVOL_CODEC_H
@@ -70,6 +72,7 @@ int  uvol_device_count(void);
 int  uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out);
 void uvol_ctx_destroy(uvol_ctx *ctx);
 const char *uvol_last_error(const uvol_ctx *ctx);
+/* completes everything enqueued on ctx (uvol_*_async calls and the stream); returns the first error among the enqueued calls */
 int  uvol_sync(uvol_ctx *ctx);
 
 /* One frame of OBJ-shaped geometry: separate value arrays + per-corner index triplets
@@ -104,6 +107,16 @@ int uvol_encode_mesh_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
 int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
                                uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
 
+/* Enqueue forms.  The call returns as soon as its arguments are recorded (the `meshes`, `outs` and `caps` ARRAYS are copied);
+ * the frames' input arrays, the output buffers and `out_lens` / `status` belong to the call until uvol_sync(ctx) returns, which
+ * reports the first failing call (its message through uvol_last_error).  Calls enqueued on one ctx run in order; a blocking entry
+ * point on the same ctx waits for them first.  A host driver overlaps its own work - parsing the next batch, writing the previous
+ * one - with the GPU this way without owning a thread per context (host/uvolenc.cpp does). */
+int uvol_encode_mesh_batch_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
+                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+int uvol_encode_mesh_batch_dev_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
+                                     uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+
 /* Replaces one `basisu -ktx2 -tex_type video` process (scripts/Encoder.py:290-292):
  * n_layers RGBA8 images (width*height*4 bytes each, top row first as a PNG decoder yields them)
  * -> one ETC1S/BasisLZ .ktx2 with n_layers array layers (layer 0 I-frame, others P-frames). */
@@ -124,6 +137,14 @@ int uvol_encode_texture_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int 
 int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers,
                                      uint32_t width, uint32_t height,
                                      uint8_t *const *outs, const size_t *caps, size_t *out_lens);
+
+/* enqueue forms of the two batched texture entry points (same contract as uvol_encode_mesh_batch_async) */
+int uvol_encode_texture_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers,
+                                       uint32_t width, uint32_t height,
+                                       uint8_t *const *outs, const size_t *caps, size_t *out_lens);
+int uvol_encode_texture_segments_dev_async(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers,
+                                           uint32_t width, uint32_t height,
+                                           uint8_t *const *outs, const size_t *caps, size_t *out_lens);
 
 /* ---- decode path, texture half ----
  * Replaces, for the RGBA32 target, what the stock player does per .ktx2 segment: KTX2Loader parses the container and

@@ -325,3 +325,16 @@ def test_gpu_256_full_size_frames_in_one_batch(oracle, gpu_codec):
         k = i % len(base)
         first.setdefault(k, r)
         assert r == first[k], (i, k)
+
+
+def test_gpu_enqueue_form_of_the_abi(oracle, gpu_codec):
+    """uvol_encode_mesh_batch_async / uvol_encode_texture_segments_async + uvol_sync on the device: several calls enqueued back to
+    back, results equal to the blocking entry points' (and the oracle's), a failing frame fails alone."""
+    import synth
+    a, b = synth.sphere_mesh(120, 61, charts=(12, 6), frame=3), synth.grid_mesh()
+    bad = dict(b, idx_pos=b["idx_pos"].copy()); bad["idx_pos"][5] = 10 ** 6
+    tex = synth.texture_sequence(2, size=64, seed=1)
+    gpu_codec.start_mesh_batch([a, b]); gpu_codec.start_mesh_batch([b, bad, a]); gpu_codec.start_texture_segments([tex, tex])
+    r = gpu_codec.finish()
+    ea, eb = _oracle_bytes(oracle, a), _oracle_bytes(oracle, b)
+    assert r[0] == [ea, eb] and r[1] == [eb, None, ea] and r[2] == [oracle.ktx2_encode(tex)] * 2

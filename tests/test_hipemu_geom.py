@@ -102,6 +102,32 @@ def test_hipemu_vertex_ids_beyond_the_8_byte_record_field(oracle, hipemu_lib):
     assert got == oracle.drc_encode(f["pos"], f["idx_pos"], f["uv"], f["idx_uv"], f["nrm"], f["idx_nrm"])
 
 
+def test_hipemu_enqueue_form_of_the_abi(oracle, hipemu_lib):
+    """SURVEY 8(b) "Threading": uvol_*_async record a call and return, uvol_sync completes them in order.  Two geometry batches and
+    a texture call enqueued back to back give the bytes of the blocking entry points; a frame that fails (bad index) fails alone;
+    a call that fails as a whole (quantisation bits out of range) is reported by uvol_sync, once; a blocking call on a context with
+    queued work runs after it."""
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    a, b = synth.torus_mesh(16, 8), synth.grid_mesh()
+    bad = dict(a, idx_pos=a["idx_pos"].copy()); bad["idx_pos"][5] = 10 ** 6
+    tex = synth.texture_sequence(2, size=32, seed=1)
+    enc = lambda f: oracle.drc_encode(f["pos"], f["idx_pos"], f["uv"], f["idx_uv"], f["nrm"], f["idx_nrm"])
+    cd.start_mesh_batch([a, b]); cd.start_mesh_batch([b, bad, a]); cd.start_texture_segments([tex])
+    r = cd.finish()
+    assert r[0] == [enc(a), enc(b)] and r[1] == [enc(b), None, enc(a)] and r[2] == [oracle.ktx2_encode(tex)]
+    cd.start_mesh_batch([a])
+    assert cd.encode_mesh(**b) == enc(b)                      # blocking call: after the queued one
+    assert cd.finish() == [[enc(a)]]
+    cd.close()
+    c2 = uvol.Codec(lib_path=hipemu_lib, Q_POSITION_ATTR=30)
+    c2.start_mesh_batch([a])
+    with pytest.raises(uvol.UvolError):
+        c2.finish()
+    assert c2.finish() == []                                   # the error was reported once
+    c2.close()
+
+
 def _check_decoded(oracle, data, got):
     """HIP decode result against the oracle decoder: entry values (de-quantised floats, bit-exact) and per-corner indices."""
     want = oracle.drc_decode(data)

@@ -32,6 +32,56 @@ hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
   return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Enqueue form of the ABI (SURVEY 8(b) "Threading": ABI calls enqueue on the ctx, uvol_sync(ctx) completes).  A call returns as
+// soon as its arguments are recorded; the work runs on the context's worker thread in call order, through the same code as the
+// blocking entry points.  Input arrays, output buffers and the out_lens / status arrays belong to the call until uvol_sync(ctx)
+// returns; the pointer / capacity ARRAYS themselves are copied.  The first failing call's return code and message are kept and
+// returned by uvol_sync (then cleared).  A blocking entry point on a context with queued work waits for it first.
+// ------------------------------------------------------------------------------------------------
+static void async_worker(uvol_ctx *ctx) {
+  uvol_ctx::AsyncQ *A = ctx->async;
+  std::unique_lock<std::mutex> l(A->m);
+  for (;;) {
+    A->cv_work.wait(l, [&] { return A->stop || !A->q.empty(); });
+    if (A->q.empty()) { if (A->stop) return; continue; }
+    std::function<int()> f = std::move(A->q.front()); A->q.pop_front(); A->busy = true;
+    l.unlock();
+    const int rc = f();
+    l.lock();
+    if (rc != UVOL_OK && A->first_err == UVOL_OK) { A->first_err = rc; snprintf(A->err, sizeof A->err, "%s", ctx->err); }
+    A->busy = false;
+    if (A->q.empty()) A->cv_idle.notify_all();
+  }
+}
+static int async_push(uvol_ctx *ctx, std::function<int()> f) {
+  if (!ctx->async) { ctx->async = new (std::nothrow) uvol_ctx::AsyncQ(); if (!ctx->async) return UVOL_E_HIP; ctx->async->th = std::thread(async_worker, ctx); }
+  { std::lock_guard<std::mutex> l(ctx->async->m); ctx->async->q.push_back(std::move(f)); }
+  ctx->async->cv_work.notify_one();
+  return UVOL_OK;
+}
+// waits for the queued calls; returns (and clears) the first error among them
+static int async_drain(uvol_ctx *ctx, bool take_error = true) {
+  if (!ctx->async) return UVOL_OK;
+  uvol_ctx::AsyncQ *A = ctx->async;
+  std::unique_lock<std::mutex> l(A->m);
+  A->cv_idle.wait(l, [&] { return A->q.empty() && !A->busy; });
+  if (!take_error) return UVOL_OK;
+  const int rc = A->first_err;
+  if (rc != UVOL_OK) { snprintf(ctx->err, sizeof ctx->err, "%s", A->err); A->first_err = UVOL_OK; A->err[0] = 0; }
+  return rc;
+}
+// a blocking entry point on a context with queued work: the queued calls go first (their error, if any, stays for uvol_sync)
+#define UVOL_AFTER_ASYNC(ctx) do { if ((ctx) && (ctx)->async) (void)async_drain((ctx), false); } while (0)
+static void async_shutdown(uvol_ctx *ctx) {
+  if (!ctx->async) return;
+  (void)async_drain(ctx);
+  { std::lock_guard<std::mutex> l(ctx->async->m); ctx->async->stop = true; }
+  ctx->async->cv_work.notify_all();
+  if (ctx->async->th.joinable()) ctx->async->th.join();
+  delete ctx->async; ctx->async = nullptr;
+}
+
 extern "C" {
 
 void uvol_params_default(uvol_params *p) {
@@ -70,6 +120,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
 
 void uvol_ctx_destroy(uvol_ctx *ctx) {
   if (!ctx) return;
+  async_shutdown(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
@@ -84,9 +135,11 @@ const char *uvol_last_error(const uvol_ctx *ctx) { return ctx ? ctx->err : "null
 
 int uvol_sync(uvol_ctx *ctx) {
   if (!ctx) return UVOL_E_INVALID;
+  const int arc = async_drain(ctx);                        // every call enqueued with uvol_*_async has completed; first error among them
+  (void)hipSetDevice(ctx->device);
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
-  return UVOL_OK;
+  return arc;
 }
 
 static int encode_batch_common(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool dev,
@@ -103,6 +156,7 @@ static int encode_batch_common(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bo
 }
 
 int uvol_encode_mesh(uvol_ctx *ctx, const uvol_mesh *mesh, uint8_t *out, size_t cap, size_t *out_len) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !mesh || !out || !out_len) return UVOL_E_INVALID;
   int st = 0;
   int rc = encode_batch_common(ctx, mesh, 1, false, &out, &cap, out_len, &st);
@@ -111,16 +165,19 @@ int uvol_encode_mesh(uvol_ctx *ctx, const uvol_mesh *mesh, uint8_t *out, size_t 
 
 int uvol_encode_mesh_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps,
                            size_t *out_lens, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
   return encode_batch_common(ctx, meshes, n, false, outs, caps, out_lens, status);
 }
 
 int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps,
                                size_t *out_lens, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
   return encode_batch_common(ctx, meshes, n, true, outs, caps, out_lens, status);
 }
 
 int uvol_encode_texture_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t width, uint32_t height,
                                 uint8_t *out, size_t cap, size_t *out_len) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !rgba || n_layers <= 0 || !out || !out_len || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba, 1, n_layers, width, height, false, &out, &cap, out_len);
@@ -129,6 +186,7 @@ int uvol_encode_texture_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n
 
 int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_layers, uint32_t width, uint32_t height,
                                     uint8_t *out, size_t cap, size_t *out_len) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !rgba_dev || n_layers <= 0 || !out || !out_len || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba_dev, 1, n_layers, width, height, true, &out, &cap, out_len);
@@ -137,6 +195,7 @@ int uvol_encode_texture_segment_dev(uvol_ctx *ctx, const uint8_t *const *rgba_de
 
 int uvol_encode_texture_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height,
                                  uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !rgba || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba, n_segments, n_layers, width, height, false, outs, caps, out_lens);
@@ -144,10 +203,42 @@ int uvol_encode_texture_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int 
 }
 int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers, uint32_t width, uint32_t height,
                                      uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !rgba_dev || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
   return tex_encode_segments(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
+}
+
+// ---- enqueue forms (see the block comment above async_worker) ----
+static int mesh_batch_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool dev, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  if (!ctx || !meshes || n < 0 || !outs || !caps || !out_lens) return UVOL_E_INVALID;
+  std::vector<uvol_mesh> m(meshes, meshes + n); std::vector<uint8_t *> o(outs, outs + n); std::vector<size_t> c(caps, caps + n);
+  return async_push(ctx, [ctx, m = std::move(m), o = std::move(o), c = std::move(c), n, dev, out_lens, status]() {
+    return encode_batch_common(ctx, m.data(), n, dev, o.data(), c.data(), out_lens, status); });
+}
+int uvol_encode_mesh_batch_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  return mesh_batch_async(ctx, meshes, n, false, outs, caps, out_lens, status);
+}
+int uvol_encode_mesh_batch_dev_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  return mesh_batch_async(ctx, meshes, n, true, outs, caps, out_lens, status);
+}
+static int tex_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height, bool dev,
+                              uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  if (!ctx || !rgba || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
+  std::vector<const uint8_t *> r(rgba, rgba + (size_t)n_segments * n_layers); std::vector<uint8_t *> o(outs, outs + n_segments); std::vector<size_t> c(caps, caps + n_segments);
+  return async_push(ctx, [ctx, r = std::move(r), o = std::move(o), c = std::move(c), n_segments, n_layers, width, height, dev, out_lens]() {
+    (void)hipSetDevice(ctx->device);
+    if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens);
+    return tex_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens); });
+}
+int uvol_encode_texture_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height,
+                                       uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  return tex_segments_async(ctx, rgba, n_segments, n_layers, width, height, false, outs, caps, out_lens);
+}
+int uvol_encode_texture_segments_dev_async(uvol_ctx *ctx, const uint8_t *const *rgba_dev, int n_segments, int n_layers, uint32_t width, uint32_t height,
+                                           uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  return tex_segments_async(ctx, rgba_dev, n_segments, n_layers, width, height, true, outs, caps, out_lens);
 }
 
 // UASTC and ETC1S files are told apart by the container (DFD colour model 166 vs 163)
@@ -164,34 +255,40 @@ static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size
   return tex_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);
 }
 int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba, size_t layer_cap) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return decode_dispatch(ctx, ktx2, lens, n_segments, rgba, layer_cap, false, 0);
 }
 int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba_dev, size_t layer_cap) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !rgba_dev) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return decode_dispatch(ctx, ktx2, lens, n_segments, rgba_dev, layer_cap, true, 0);
 }
 int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 1);
 }
 
 int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 2);
 }
 
 int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 3);
 }
 
 int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !drc || !lens || n < 0 || !out) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   const int mb = ctx->prm.max_batch;

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -159,6 +161,10 @@ struct uvol_ctx {
   TexDecState *texdec = nullptr;
   GeoDecState *geodec = nullptr;
   UastcState *uastc = nullptr;
+  // enqueue form of the ABI (uvol_*_async + uvol_sync): calls run in order on this context's worker thread
+  struct AsyncQ {
+    std::mutex m; std::condition_variable cv_work, cv_idle; std::deque<std::function<int()>> q; std::thread th; bool busy = false, stop = false; int first_err = 0; char err[512] = {0};
+  } *async = nullptr;
   uint8_t *up_pin[2] = { nullptr, nullptr }; size_t up_cap = 0; hipEvent_t up_ev[2] = { nullptr, nullptr }; bool up_rec[2] = { false, false };   // staged uploads (uvol_upload_staged); up_rec: a DMA out of that buffer may still be in flight
 
   void set_error(const char *fmt, ...) {

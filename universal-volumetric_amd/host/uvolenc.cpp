@@ -136,11 +136,22 @@ int main(int argc, char **argv) {
         return Bt;
       };
       std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) & 1);
+      // The GPU call is ENQUEUED (uvol_encode_mesh_batch_async): while the device encodes batch b this thread writes the .drc files of
+      // batch b - 1 (and the ingest threads parse batch b + 1), then uvol_sync completes batch b.  A batch object's output buffers are
+      // next written by the encode of batch b + 2, after its files are on disk.
+      struct Written { std::vector<std::unique_ptr<uint8_t[]>> *outs = nullptr; std::vector<size_t> lens; size_t b0 = 0, nb = 0; } prev;
+      auto write_prev = [&]() {
+        if (!prev.outs || !prev.nb) return;
+        std::atomic<int> wbad{-1};
+        parallel_for(prev.nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, prev.b0 + k); if (!write_file(join(geo_dir, name), (*prev.outs)[k].get(), prev.lens[k])) wbad = (int)(prev.b0 + k); });
+        prev.nb = 0;
+        if (wbad >= 0) geo_failed = wbad.load();
+      };
       for (size_t b0 = lo; b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
         const double tw0 = now_ms();
         std::shared_ptr<GeoBatch> Bt = nextb.get();
         const double tw1 = now_ms();
-        nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch, (n_loads++) & 1);      // the other object: the previous batch is done with it
+        nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch, (n_loads++) & 1);      // the other object: the previous batch is done with its meshes
         const size_t nb = Bt->nb;
         if (Bt->bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)Bt->bad].c_str(), Bt->err.c_str()); geo_failed = (int)(b0 + (size_t)Bt->bad); break; }
         std::vector<uvol_mesh> um(nb); std::vector<std::unique_ptr<uint8_t[]>> &outs = Bt->outs; if (outs.size() < nb) { outs.resize(nb); Bt->ocap.resize(nb, 0); }
@@ -153,15 +164,17 @@ int main(int argc, char **argv) {
           caps[k] = uvol_mesh_bound(&m); if (Bt->ocap[k] < caps[k]) { outs[k].reset(new uint8_t[caps[k]]); Bt->ocap[k] = caps[k]; } op[k] = outs[k].get();   // (not zero-filled: the bound is a worst case)
         }
         const double te0 = now_ms();
-        if (uvol_encode_mesh_batch(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data()) != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); geo_failed = (int)b0; break; }
+        int rc = uvol_encode_mesh_batch_async(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data());
+        write_prev();                                                                  // the previous batch's files, while the GPU works
+        const double te1 = now_ms();
+        if (rc == UVOL_OK) rc = uvol_sync(ctxs[g]);
+        if (rc != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); geo_failed = (int)b0; break; }
         for (size_t k = 0; k < nb; k++) if (st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); geo_failed = (int)(b0 + k); break; }   // scripts/Encoder.py:263-266
         if (geo_failed >= 0) break;
-        const double te1 = now_ms();
-        std::atomic<int> wbad{-1};
-        parallel_for(nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, b0 + k); if (!write_file(join(geo_dir, name), outs[k].get(), lens[k])) wbad = (int)(b0 + k); });
-        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] geo batch b0=%zu: waited for load %.0f ms, prepare %.0f, encode %.0f, write %.0f\n", b0, tw1 - tw0, te0 - tw1, te1 - te0, now_ms() - te1);
-        if (wbad >= 0) { geo_failed = wbad.load(); break; }
+        prev.outs = &outs; prev.lens = lens; prev.b0 = b0; prev.nb = nb;
+        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] geo batch b0=%zu: waited for load %.0f ms, prepare %.0f, write of the previous batch (GPU busy) %.0f, waited for the GPU %.0f\n", b0, tw1 - tw0, te0 - tw1, te1 - te0, now_ms() - te1);
       }
+      if (geo_failed < 0) write_prev();
       if (nextb.valid()) nextb.wait();
     });
   }

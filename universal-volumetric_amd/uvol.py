@@ -36,7 +36,7 @@ class Mesh(C.Structure):
 
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
-           "uvol_encode_mesh_batch_dev", "uvol_texture_bound", "uvol_encode_texture_segment",
+           "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
@@ -55,14 +55,14 @@ def load(path=None):
     L.uvol_mesh_bound.argtypes = [C.POINTER(Mesh)]; L.uvol_mesh_bound.restype = C.c_size_t
     L.uvol_mesh_workspace.argtypes = [C.c_void_p, C.POINTER(Mesh)]; L.uvol_mesh_workspace.restype = C.c_size_t
     L.uvol_encode_mesh.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
-    for nm in ("uvol_encode_mesh_batch", "uvol_encode_mesh_batch_dev"):
+    for nm in ("uvol_encode_mesh_batch", "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.uvol_texture_bound.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.uvol_texture_bound.restype = C.c_size_t
     for nm in ("uvol_encode_texture_segment", "uvol_encode_texture_segment_dev"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_size_t)]
-    for nm in ("uvol_encode_texture_segments", "uvol_encode_texture_segments_dev"):
+    for nm in ("uvol_encode_texture_segments", "uvol_encode_texture_segments_dev", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async"):
         getattr(L, nm).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.uvol_ktx2_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -155,6 +155,46 @@ class Codec:
         """meshes: ctypes array of Mesh holding DEVICE pointers (inputs resident in HBM).  views=True: numpy views of this
         codec's output buffers instead of `bytes` copies (valid until the next call; no 250 KB copy per frame in Python)."""
         return self._run_batch(self.L.uvol_encode_mesh_batch_dev, meshes, len(meshes), raise_on_error, views)
+
+    # ---- enqueue form (uvol_*_async + uvol_sync): start_* record a call, finish() completes all of them in order ----
+    def start_mesh_batch(self, frames):
+        """Enqueues uvol_encode_mesh_batch_async for host frames; the result arrives with finish()."""
+        n = len(frames)
+        meshes = (Mesh * n)(); keep = []
+        for i, f in enumerate(frames):
+            m, k = self._mesh_host(**f); meshes[i] = m; keep.append(k)
+        caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)(); bufs = []
+        for i in range(n):
+            cap = self.L.uvol_mesh_bound(C.byref(meshes[i])); bufs.append(np.empty(cap, dtype=np.uint8)); caps[i] = cap; outs[i] = bufs[i].ctypes.data
+        rc = self.L.uvol_encode_mesh_batch_async(self.h, meshes, n, outs, caps, lens, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_mesh_batch_async rc={rc}: {self.error()}")
+        self._pending = getattr(self, "_pending", []) + [("mesh", n, bufs, lens, st, keep, meshes)]
+
+    def start_texture_segments(self, segments):
+        """Enqueues uvol_encode_texture_segments_async for host segments."""
+        arrs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in seg] for seg in segments]
+        h, w = arrs[0][0].shape[:2]; nl = len(arrs[0]); nseg = len(arrs)
+        flat = [a for seg in arrs for a in seg]
+        ptrs = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
+        cap = self.L.uvol_texture_bound(w, h, nl)
+        bufs = [np.empty(cap, dtype=np.uint8) for _ in range(nseg)]
+        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
+        rc = self.L.uvol_encode_texture_segments_async(self.h, ptrs, nseg, nl, w, h, outs, caps, lens)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_texture_segments_async rc={rc}: {self.error()}")
+        self._pending = getattr(self, "_pending", []) + [("tex", nseg, bufs, lens, None, flat, ptrs)]
+
+    def finish(self):
+        """uvol_sync: completes every enqueued call; returns their results in call order (meshes: None for a failed frame)."""
+        rc = self.L.uvol_sync(self.h)
+        pend, self._pending = getattr(self, "_pending", []), []
+        if rc != UVOL_OK:
+            raise UvolError(f"uvol_sync rc={rc}: {self.error()}")
+        res = []
+        for kind, n, bufs, lens, st, _, _ in pend:
+            res.append([(bufs[i][:lens[i]].tobytes() if (st is None or st[i] == UVOL_OK) else None) for i in range(n)])
+        return res
 
     def _run_batch(self, fn, meshes, n, raise_on_error, views=False):
         caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)()
