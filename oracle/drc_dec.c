@@ -23,16 +23,106 @@ void drc_mesh_free(drc_mesh *m) {
   memset(m, 0, sizeof(*m));
 }
 
+
+/* wrap / octahedron helpers of the attribute loops below are in drc_internal.h */
+
+/* Sequential connectivity (encoder_method 0, MeshSequentialDecoder): restated from the published bitstream description, exercised
+ * by no reference fixture; pinned by the round trip with drc_enc.c (method 2).  One attributes decoder, every attribute has one
+ * entry per point, decoded in point order with the DIFFERENCE predictor (or none). */
+static int drc_decode_sequential(const uint8_t *b, size_t n, drc_mesh *m) {
+  rdr R = { b, n, 11, 0 }, *r = &R;
+  int rc = 0;
+  const int nf = (int)r_varint(r), np = (int)r_varint(r), cm = r_u8(r);
+  if (r->err || nf <= 0 || np <= 0 || nf > (1 << 28) || np > (1 << 28)) return -6;
+  m->method = 0; m->traversal = cm; m->nf = nf; m->npoints = np; m->nev = np;
+  int32_t *faces = (int32_t *)malloc(4 * 3 * (size_t)nf);
+  if (cm == 0) {                                       /* compressed indices: signed differences to the previous index, as symbols */
+    uint32_t *sy = (uint32_t *)malloc(4 * 3 * (size_t)nf + 4);
+    if (orc_decode_symbols_nc(b, n, &r->o, 3 * (uint32_t)nf, 1, sy, NULL)) rc = -8;
+    int32_t last = 0;
+    for (int i = 0; i < 3 * nf && !rc; i++) { int32_t d = (int32_t)(sy[i] >> 1); if (sy[i] & 1) d = -d; last += d; faces[i] = last; }
+    free(sy);
+  } else if (cm == 1) {
+    for (int i = 0; i < 3 * nf; i++) {
+      if (np < 256) faces[i] = r_u8(r);
+      else if (np < (1 << 16)) { uint32_t lo = r_u8(r), hi = r_u8(r); faces[i] = (int32_t)(lo | (hi << 8)); }
+      else if (np < (1 << 21)) faces[i] = (int32_t)r_varint(r);
+      else faces[i] = r_i32(r);
+    }
+  } else rc = -5;
+  if (r->err) rc = -8;
+  for (int i = 0; i < 3 * nf && !rc; i++) if (faces[i] < 0 || faces[i] >= np) rc = -19;
+  m->conn_end = r->o;
+  if (rc) { free(faces); return rc; }
+  const int ndec = r_u8(r); if (r->err || ndec != 1) { free(faces); return -20; }
+  const int natt = (int)r_varint(r); if (r->err || natt < 1 || natt > 8) { free(faces); return -22; }
+  for (int d = 0; d < natt; d++) { drc_att *A = &m->att[d]; A->att_type = r_u8(r); A->data_type = r_u8(r); A->ncomp = r_u8(r); (void)r_u8(r); A->unique_id = (int)r_varint(r); A->att_data_id = -1; A->dec_type = 0; }
+  for (int d = 0; d < natt; d++) m->att[d].seq_type = r_u8(r);
+  m->natt = natt; m->hdr_end = r->o;
+  if (r->err) { free(faces); m->natt = 0; return -22; }
+  for (int d = 0; d < natt && !rc; d++) {
+    drc_att *A = &m->att[d];
+    A->n = np; A->sec_begin = r->o;
+    A->pred_method = (int8_t)r_u8(r);
+    if (A->pred_method != -2) A->transform = (int8_t)r_u8(r);
+    const int compressed = r_u8(r);
+    const int nc = (A->seq_type == 3) ? 2 : A->ncomp; A->ncomp_port = nc;
+    if (nc < 1 || nc > 4 || (A->seq_type != 1 && A->seq_type != 2 && A->seq_type != 3)) { rc = -24; break; }
+    uint32_t *syms = (uint32_t *)malloc(4 * ((size_t)np * nc + 1));
+    int32_t *out = (int32_t *)calloc((size_t)np * nc + 1, sizeof(int32_t));
+    A->vals = out;
+    A->corner_to_entry = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)nf);
+    memcpy(A->corner_to_entry, faces, sizeof(int32_t) * 3 * (size_t)nf);
+    A->sym_begin = r->o;
+    if (compressed == 1) { if (orc_decode_symbols_nc(b, n, &r->o, (uint32_t)(np * nc), nc, syms, NULL)) rc = -25; }
+    else if (compressed == 0) {                        /* raw values: byte width, then little-endian values */
+      const int nb = r_u8(r); if (nb < 1 || nb > 4) rc = -25;
+      for (int i = 0; i < np * nc && !rc; i++) { uint32_t v = 0; for (int k = 0; k < nb; k++) v |= (uint32_t)r_u8(r) << (8 * k); syms[i] = v; }
+    } else rc = -24;
+    A->sym_end = r->o;
+    if (!rc && A->pred_method == -2) { for (int i = 0; i < np * nc; i++) out[i] = sgn_sym(syms[i]); }
+    else if (!rc && A->pred_method == 0 && A->transform == 1) {
+      const int32_t lo = r_i32(r), hi = r_i32(r);
+      for (int p = 0; p < np; p++) for (int k = 0; k < nc; k++) out[p * nc + k] = wrap_orig(p ? out[(p - 1) * nc + k] : 0, sgn_sym(syms[p * nc + k]), lo, hi);
+    } else if (!rc && A->pred_method == 0 && A->transform == 3 && nc == 2) {
+      const int32_t maxq = r_i32(r), cen = r_i32(r);
+      int q = 0; while ((1 << q) - 1 < maxq) q++;
+      octb ot; oct_init(&ot, q);
+      if (ot.MAXQ != maxq || ot.CEN != cen) rc = -30;
+      for (int p = 0; p < np && !rc; p++) {
+        const int32_t zero[2] = {0, 0}; int32_t corr[2] = { (int32_t)syms[2 * p], (int32_t)syms[2 * p + 1] };
+        oct_orig_value(&ot, p ? out + 2 * (p - 1) : zero, corr, out + 2 * p);
+      }
+    } else if (!rc) rc = -31;
+    A->sec_end = r->o;
+    free(syms);
+    if (r->err) rc = -32;
+  }
+  for (int d = 0; d < natt && !rc; d++) {              /* data needed by the portable transforms, attribute by attribute */
+    drc_att *A = &m->att[d];
+    if (A->seq_type == 2) { for (int k = 0; k < A->ncomp && k < 4; k++) A->minv[k] = r_f32(r); A->range = r_f32(r); A->qbits = r_u8(r); }
+    else if (A->seq_type == 3) A->qbits = r_u8(r);
+    if (r->err) rc = -32;
+  }
+  free(faces);
+  m->total = n; m->leftover = n - r->o;
+  if (rc) { m->natt = 8; drc_mesh_free(m); }
+  return rc;
+}
+
 int drc_decode(const uint8_t *b, size_t n, drc_mesh *m) {
   memset(m, 0, sizeof(*m));
   if (n < 11 || memcmp(b, "DRACO", 5)) return -1;
   m->major = b[5]; m->minor = b[6];
-  if (b[7] != 1 || b[8] != 1) return -2;               /* TRIANGULAR_MESH, EDGEBREAKER */
+  if (b[7] != 1 || b[8] > 1) return -2;                /* TRIANGULAR_MESH; SEQUENTIAL (0) or EDGEBREAKER (1) */
   if (m->major != 2 || m->minor != 2) return -3;
   if ((b[9] | (b[10] << 8)) != 0) return -4;           /* no metadata */
+  if (b[8] == 0) return drc_decode_sequential(b, n, m);
+  m->method = 1;
   rdr R = { b, n, 11, 0 }, *r = &R;
   int rc = 0;
-  int tt = r_u8(r); if (tt != 2) return -5;            /* VALENCE traversal */
+  int tt = r_u8(r); if (tt != 2 && tt != 0) return -5; /* VALENCE (2) or STANDARD (0) traversal */
+  m->traversal = tt;
   int nev = (int)r_varint(r), nf = (int)r_varint(r), nad = r_u8(r);
   int nsym = (int)r_varint(r), nsplit = (int)r_varint(r), nts = (int)r_varint(r);
   if (r->err || nf <= 0 || nad > 7 || nsym > nf || nts > nf) return -6;
@@ -43,11 +133,14 @@ int drc_decode(const uint8_t *b, size_t n, drc_mesh *m) {
     if (r->o + (size_t)(nts + 7) / 8 > n) r->err = 1;
     else { for (int i = 0; i < nts; i++) sp_edge[i] = (b[r->o + (i >> 3)] >> (i & 7)) & 1; if (nts > 0) r->o += (size_t)(nts + 7) / 8; } }
   orc_rabs_dec start_faces, seams[8];
+  const uint8_t *sbits = NULL; size_t sbit = 0, sbit_n = 0;      /* standard traversal: the symbols as a size-prefixed LSB-first bit sequence */
+  if (tt == 0) { const size_t nb = r_varint(r); if (r->err || r->o + nb > n) { rc = -7; goto fail0; } sbits = b + r->o; sbit_n = 8 * nb; r->o += nb; }
   if (r->err || orc_rabs_open(&start_faces, b, n, r->o)) { rc = -7; goto fail0; }
   r->o = start_faces.end;
   for (int i = 0; i < nad; i++) { if (orc_rabs_open(&seams[i], b, n, r->o)) { rc = -7; goto fail0; } r->o = seams[i].end; }
   uint32_t *ctx[6] = {0}; int cnt[6];
-  for (int i = 0; i < 6; i++) {
+  for (int i = 0; i < 6; i++) cnt[i] = 0;
+  for (int i = 0; i < 6 && tt == 2; i++) {
     int cn = (int)r_varint(r); cnt[i] = cn; m->ctx_n[i] = cn;
     if (r->err || cn < 0 || cn > nf) { rc = -8; goto fail1; }
     if (cn > 0) { ctx[i] = (uint32_t *)malloc(4 * (size_t)cn); if (orc_decode_symbols(b, n, &r->o, (uint32_t)cn, ctx[i], NULL)) { rc = -8; goto fail1; } }
@@ -68,7 +161,12 @@ int drc_decode(const uint8_t *b, size_t n, drc_mesh *m) {
 #define ADDV() (nv < maxv ? (lm[nv] = ORC_INV, nv++) : (rc = -9, 0))
     for (int sid = 0; sid < nsym && !rc; sid++) {
       int face = nfaces++, check = 0, sym;
-      if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } uint32_t s = ctx[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
+      if (tt == 0) {                                    /* 1 bit: C; else two more bits: S 1, L 3, R 5, E 7 */
+        if (sbit + 1 > sbit_n) { rc = -10; break; }
+        sym = (sbits[sbit >> 3] >> (sbit & 7)) & 1; sbit++;
+        if (sym) { if (sbit + 2 > sbit_n) { rc = -10; break; } for (int k = 0; k < 2; k++, sbit++) sym |= ((sbits[sbit >> 3] >> (sbit & 7)) & 1) << (1 + k); }
+      }
+      else if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } uint32_t s = ctx[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
       else sym = 7;
       int corner = 3 * face;
       if (sym == 0) {                                   /* C */

@@ -116,6 +116,96 @@ static void oct_corr(const octb *t, const int32_t orig_[2], const int32_t pred_[
   if (corr[1] < 0) corr[1] += t->MAXQ;
 }
 
+/* ---------------- sequential connectivity (MESH_SEQUENTIAL_ENCODING, what stock `draco_encoder -cl 0` selects) ----------------
+ * Restated from the published bitstream description (MeshSequentialEncoder / SequentialAttributeEncodersController): no reference
+ * fixture uses it, so it is pinned only by the round trip through drc_dec.c.  Points = the distinct (position, uv, normal) value
+ * triples in order of first appearance over the corners (every face is kept, also degenerate ones); connectivity = the point index
+ * of every corner, stored raw in the smallest type; ONE attribute decoder holds all attributes, each coded per point in point order
+ * with the DIFFERENCE predictor (previous point's value; zeros for the first) through the wrap / canonicalised-octahedron
+ * transform and the RAW rANS scheme; the de-quantisation parameters of all attributes follow the values of all attributes. */
+static int drc_encode_sequential(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out) {
+  const int qp = prm->qp, qt = prm->qt, qn = prm->qn;
+  const int has_uv = in->uv && in->n_uv && in->idx_uv, has_nrm = in->nrm && in->n_nrm && in->idx_nrm;
+  const uint32_t nf = in->nf, nc = 3 * nf;
+  if (nf == 0) return -3;
+  uint32_t *canon_p = (uint32_t *)malloc(4 * (size_t)(in->n_pos + 1)), *canon_u = NULL, *canon_n = NULL;
+  dedup_values(in->pos, in->n_pos, 12, canon_p);
+  if (has_uv) { canon_u = (uint32_t *)malloc(4 * (size_t)(in->n_uv + 1)); dedup_values(in->uv, in->n_uv, 8, canon_u); }
+  if (has_nrm) { canon_n = (uint32_t *)malloc(4 * (size_t)(in->n_nrm + 1)); dedup_values(in->nrm, in->n_nrm, 12, canon_n); }
+  /* points: first corner of every distinct (p, u, n) triple, two 64-bit map levels */
+  int32_t *pu = (int32_t *)malloc(4 * (size_t)nc), *pid = (int32_t *)malloc(4 * (size_t)nc), *first = (int32_t *)malloc(4 * (size_t)nc);
+  { emap E; emap_init(&E, nc);
+    for (uint32_t c = 0; c < nc; c++) emap_put_min(&E, ((uint64_t)canon_p[in->idx_pos[c]] << 32) | (has_uv ? canon_u[in->idx_uv[c]] : 0u), (int32_t)c);
+    for (uint32_t c = 0; c < nc; c++) pu[c] = emap_get(&E, ((uint64_t)canon_p[in->idx_pos[c]] << 32) | (has_uv ? canon_u[in->idx_uv[c]] : 0u));
+    free(E.key); free(E.val);
+    emap_init(&E, nc);
+    for (uint32_t c = 0; c < nc; c++) emap_put_min(&E, ((uint64_t)(uint32_t)pu[c] << 32) | (has_nrm ? canon_n[in->idx_nrm[c]] : 0u), (int32_t)c);
+    for (uint32_t c = 0; c < nc; c++) first[c] = emap_get(&E, ((uint64_t)(uint32_t)pu[c] << 32) | (has_nrm ? canon_n[in->idx_nrm[c]] : 0u));
+    free(E.key); free(E.val); }
+  uint32_t np = 0; int32_t *corner_of_point = (int32_t *)malloc(4 * (size_t)nc);
+  for (uint32_t c = 0; c < nc; c++) if (first[c] == (int32_t)c) { corner_of_point[np] = (int32_t)c; pid[c] = (int32_t)np++; }
+  for (uint32_t c = 0; c < nc; c++) pid[c] = pid[first[c]];
+  ob_bytes(out, "DRACO", 5); ob_u8(out, 2); ob_u8(out, 2); ob_u8(out, 1); ob_u8(out, 0); ob_u16(out, 0);
+  ob_varint(out, nf); ob_varint(out, np); ob_u8(out, 1);                       /* connectivity_method 1: indices stored directly */
+  for (uint32_t c = 0; c < nc; c++) {
+    const uint32_t v = (uint32_t)pid[c];
+    if (np < 256) ob_u8(out, (uint8_t)v); else if (np < (1u << 16)) ob_u16(out, (uint16_t)v); else if (np < (1u << 21)) ob_varint(out, v); else ob_i32(out, (int32_t)v);
+  }
+  const int natt = 1 + has_uv + has_nrm;
+  ob_u8(out, 1);                                                               /* one attributes decoder */
+  ob_varint(out, (uint64_t)natt);
+  ob_u8(out, 0); ob_u8(out, 9); ob_u8(out, 3); ob_u8(out, 0); ob_varint(out, 0);
+  { int id = 1;
+    if (has_uv) { ob_u8(out, 3); ob_u8(out, 9); ob_u8(out, 2); ob_u8(out, 0); ob_varint(out, (uint64_t)id++); }
+    if (has_nrm) { ob_u8(out, 1); ob_u8(out, 9); ob_u8(out, 3); ob_u8(out, 0); ob_varint(out, (uint64_t)id++); } }
+  ob_u8(out, 2); if (has_uv) ob_u8(out, 2); if (has_nrm) ob_u8(out, 3);        /* sequential encoder types: quantization, quantization, normals */
+  /* ---- portable values of every attribute ---- */
+  float pmin[3], prange, umin[2] = {0, 0}, urange = 1.f;
+  for (int a = 0; a < 2; a++) {
+    if (a == 1 && !has_uv) continue;
+    const int ncomp = a == 0 ? 3 : 2, q = a == 0 ? qp : qt;
+    const float *src = a == 0 ? in->pos : in->uv; const uint32_t nval = a == 0 ? in->n_pos : in->n_uv;
+    const uint32_t *canon = a == 0 ? canon_p : canon_u, *idx = a == 0 ? in->idx_pos : in->idx_uv;
+    float mn[3], mx[3], range;
+    for (int k = 0; k < ncomp; k++) { mn[k] = src[k]; mx[k] = src[k]; }
+    for (uint32_t i = 1; i < nval; i++) for (int k = 0; k < ncomp; k++) { const float v = src[(size_t)ncomp * i + k]; if (v < mn[k]) mn[k] = v; if (v > mx[k]) mx[k] = v; }
+    range = mx[0] - mn[0]; for (int k = 1; k < ncomp; k++) { const float d = mx[k] - mn[k]; if (d > range) range = d; }
+    if (range == 0.f) range = 1.f;
+    if (a == 0) { memcpy(pmin, mn, 12); prange = range; } else { memcpy(umin, mn, 8); urange = range; }
+    const float inv = (float)((1u << q) - 1) / range;
+    int32_t *Q = (int32_t *)malloc(4 * (size_t)ncomp * np + 4);
+    for (uint32_t p = 0; p < np; p++) { const float *v = src + (size_t)ncomp * canon[idx[corner_of_point[p]]]; for (int k = 0; k < ncomp; k++) { float t = v[k] - mn[k]; t = t * inv; Q[(size_t)ncomp * p + k] = (int32_t)floorf(t + 0.5f); } }
+    wrapt W; wrap_init(&W, Q, (size_t)ncomp * np);
+    uint32_t *syms = (uint32_t *)malloc(4 * (size_t)ncomp * np + 4);
+    for (uint32_t p = 0; p < np; p++) for (int k = 0; k < ncomp; k++) syms[(size_t)ncomp * p + k] = sym_of(wrap_corr(&W, Q[(size_t)ncomp * p + k], p ? (int64_t)Q[(size_t)ncomp * (p - 1) + k] : 0));
+    ob_u8(out, 0); ob_u8(out, 1); ob_u8(out, 1);                               /* PREDICTION_DIFFERENCE, wrap transform, compressed */
+    orc_encode_symbols(syms, (uint32_t)ncomp * np, out);
+    ob_i32(out, W.lo); ob_i32(out, W.hi);
+    free(Q); free(syms);
+  }
+  if (has_nrm) {
+    octb ot; oct_init(&ot, qn);
+    int32_t *O = (int32_t *)malloc(8 * (size_t)np + 8); uint32_t *syms = (uint32_t *)malloc(8 * (size_t)np + 8);
+    for (uint32_t p = 0; p < np; p++) float_to_oct(&ot, in->nrm + 3 * (size_t)canon_n[in->idx_nrm[corner_of_point[p]]], &O[2 * p], &O[2 * p + 1]);
+    for (uint32_t p = 0; p < np; p++) {
+      const int32_t zero[2] = {0, 0}; int32_t corr[2];
+      oct_corr(&ot, O + 2 * (size_t)p, p ? O + 2 * (size_t)(p - 1) : zero, corr);
+      syms[2 * p] = (uint32_t)corr[0]; syms[2 * p + 1] = (uint32_t)corr[1];
+    }
+    ob_u8(out, 0); ob_u8(out, 3); ob_u8(out, 1);                               /* PREDICTION_DIFFERENCE, canonicalised octahedron transform */
+    orc_encode_symbols(syms, 2 * np, out);
+    ob_i32(out, ot.MAXQ); ob_i32(out, ot.CEN);
+    free(O); free(syms);
+  }
+  /* ---- data needed by the portable transforms, attribute by attribute ---- */
+  for (int k = 0; k < 3; k++) ob_f32(out, pmin[k]);
+  ob_f32(out, prange); ob_u8(out, (uint8_t)qp);
+  if (has_uv) { ob_f32(out, umin[0]); ob_f32(out, umin[1]); ob_f32(out, urange); ob_u8(out, (uint8_t)qt); }
+  if (has_nrm) ob_u8(out, (uint8_t)qn);
+  free(canon_p); free(canon_u); free(canon_n); free(pu); free(pid); free(first); free(corner_of_point);
+  return 0;
+}
+
 int drc_encode(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out) {
   const int qp = prm->qp, qt = prm->qt, qn = prm->qn;
   if (qp < 1 || qp > 16 || qt < 1 || qt > 16 || qn < 2 || qn > 16) return -1;
@@ -126,6 +216,7 @@ int drc_encode(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out)
     if (has_uv && in->idx_uv[c] >= in->n_uv) return -2;
     if (has_nrm && in->idx_nrm[c] >= in->n_nrm) return -2;
   }
+  if (prm->method == 2) return drc_encode_sequential(in, prm, out);
   /* K2: value dedup (bitwise) */
   uint32_t *canon_p = (uint32_t *)malloc(4 * (size_t)(in->n_pos + 1)), *canon_u = NULL, *canon_n = NULL;
   dedup_values(in->pos, in->n_pos, 12, canon_p);
@@ -168,6 +259,7 @@ int drc_encode(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out)
   int32_t *f2split = (int32_t *)malloc(4 * (size_t)nf); for (int i = 0; i < nf; i++) f2split[i] = -1;
   ivec proc = {0}, initc = {0}, stack = {0}, ev_src = {0}, ev_spl = {0}, ev_edge = {0};
   ivec ctxs[6]; memset(ctxs, 0, sizeof(ctxs));
+  ivec symseq = {0};                               /* the symbols in encoding order (the standard traversal stores them as bits) */
   bvec start_bits = {0};
   int last_sym_id = -1, nsplit = 0, prev_symbol = -1;
   enum { T_C = 0, T_S = 1, T_L = 3, T_R = 5, T_E = 7 };
@@ -192,6 +284,7 @@ int drc_encode(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out)
       case T_E: vval[c2vm[last_corner]] -= 2; vval[c2vm[nx_]] -= 2; vval[c2vm[pv_]] -= 2; break; \
     } \
     if (prev_symbol != -1) { int cv = active_valence < 2 ? 2 : (active_valence > 7 ? 7 : active_valence); iv_push(&ctxs[cv - 2], topo2id[prev_symbol]); } \
+    iv_push(&symseq, (symbol)); \
     prev_symbol = (symbol); } while (0)
 #define CHECK_SPLIT(src_edge, nb_face) do { int sid_ = f2split[nb_face]; if (sid_ != -1) { iv_push(&ev_src, last_sym_id); iv_push(&ev_spl, sid_); iv_push(&ev_edge, (src_edge)); } } while (0)
 
@@ -283,16 +376,27 @@ int drc_encode(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out)
 
   /* ---------------- connectivity section ---------------- */
   ob_bytes(out, "DRACO", 5); ob_u8(out, 2); ob_u8(out, 2); ob_u8(out, 1); ob_u8(out, 1); ob_u16(out, 0);
-  ob_u8(out, 2);                                   /* MESH_EDGEBREAKER_VALENCE_ENCODING */
+  ob_u8(out, prm->method == 1 ? 0 : 2);            /* traversal: MESH_EDGEBREAKER_STANDARD_ENCODING (0) / _VALENCE_ENCODING (2) */
   ob_varint(out, (uint64_t)nverts); ob_varint(out, (uint64_t)nf); ob_u8(out, (uint8_t)nad);
   ob_varint(out, (uint64_t)nsym); ob_varint(out, (uint64_t)nsplit);
   ob_varint(out, (uint64_t)ev_src.n);
   { int last = 0;
     for (int i = 0; i < ev_src.n; i++) { ob_varint(out, (uint64_t)(ev_src.p[i] - last)); ob_varint(out, (uint64_t)(ev_src.p[i] - ev_spl.p[i])); last = ev_src.p[i]; }
     if (ev_src.n > 0) { int nb = (ev_src.n + 7) / 8; for (int j = 0; j < nb; j++) { uint8_t v = 0; for (int k = 0; k < 8 && 8 * j + k < ev_src.n; k++) v |= (uint8_t)((ev_edge.p[8 * j + k] & 1) << k); ob_u8(out, v); } } }
-  orc_rabs_encode(start_bits.p, start_bits.n, out);
-  for (int i = 0; i < nad; i++) orc_rabs_encode(seam_bits[i].p, seam_bits[i].n, out);
-  for (int i = 0; i < 6; i++) { ob_varint(out, (uint64_t)ctxs[i].n); if (ctxs[i].n > 0) orc_encode_symbols((const uint32_t *)ctxs[i].p, (uint32_t)ctxs[i].n, out); }
+  if (prm->method == 1) {
+    /* standard traversal (MeshEdgebreakerTraversalEncoder::Done): the symbols, last first, as bit patterns C = 0 (1 bit), S / L / R / E =
+     * 1 / 3 / 5 / 7 (3 bits), LSB first, in a size-prefixed bit sequence; then the start-face and seam bit streams */
+    size_t nbits = 0; for (int i = 0; i < symseq.n; i++) nbits += symseq.p[i] == 0 ? 1 : 3;
+    const size_t nbytes = (nbits + 7) / 8; uint8_t *bits = (uint8_t *)calloc(nbytes + 1, 1); size_t bo = 0;
+    for (int i = symseq.n - 1; i >= 0; i--) { const int sy = symseq.p[i], len = sy == 0 ? 1 : 3; for (int k = 0; k < len; k++, bo++) if ((sy >> k) & 1) bits[bo >> 3] |= (uint8_t)(1u << (bo & 7)); }
+    ob_varint(out, (uint64_t)nbytes); ob_bytes(out, bits, nbytes); free(bits);
+    orc_rabs_encode(start_bits.p, start_bits.n, out);
+    for (int i = 0; i < nad; i++) orc_rabs_encode(seam_bits[i].p, seam_bits[i].n, out);
+  } else {
+    orc_rabs_encode(start_bits.p, start_bits.n, out);
+    for (int i = 0; i < nad; i++) orc_rabs_encode(seam_bits[i].p, seam_bits[i].n, out);
+    for (int i = 0; i < 6; i++) { ob_varint(out, (uint64_t)ctxs[i].n); if (ctxs[i].n > 0) orc_encode_symbols((const uint32_t *)ctxs[i].p, (uint32_t)ctxs[i].n, out); }
+  }
 
   /* ---------------- attribute decoder headers ---------------- */
   const int ndec = 1 + nad;

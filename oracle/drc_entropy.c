@@ -37,11 +37,45 @@ static int ans_read_init(const uint8_t *buf, size_t n, size_t *off, uint32_t *st
   *st += L; return 0;
 }
 
-int orc_decode_symbols(const uint8_t *b, size_t n, size_t *o, uint32_t nvals, uint32_t *out, orc_sym_info *info) {
-  if (*o + 2 > n) return -1;
+/* rANS table + payload of one RAnsSymbolDecoder<bl>: the RAW scheme's symbols, or the TAGGED scheme's bit-length tags (bl = 5) */
+static int rans_section(const uint8_t *b, size_t n, size_t *o, int bl, uint32_t nvals, uint32_t *out, orc_sym_info *info, int scheme);
+
+int orc_decode_symbols(const uint8_t *b, size_t n, size_t *o, uint32_t nvals, uint32_t *out, orc_sym_info *info) { return orc_decode_symbols_nc(b, n, o, nvals, 1, out, info); }
+
+int orc_decode_symbols_nc(const uint8_t *b, size_t n, size_t *o, uint32_t nvals, int ncomp, uint32_t *out, orc_sym_info *info) {
+  if (*o + 1 > n) return -1;
   int scheme = b[(*o)++];
-  if (scheme != 1) return -2;                      /* only RAW occurs in the fixtures */
+  if (scheme == 0) {
+    /* TAGGED scheme (DecodeTaggedSymbols; no reference fixture uses it - restated from the published bitstream description, pinned only by
+     * the round trip through this file's own writer in the tests): one rANS-coded tag per group of ncomp values = their bit length
+     * (alphabet 0..32, RAnsSymbolDecoder<5>: 12-bit precision), then the values as raw LSB-first bit fields of that length */
+    if (ncomp < 1) return -1;
+    const uint32_t ntags = nvals / (uint32_t)ncomp;
+    uint32_t *tags = (uint32_t *)malloc(4 * ((size_t)ntags + 1));
+    int rc = rans_section(b, n, o, 5, ntags, tags, info, 0);
+    if (!rc) {
+      size_t bit = 0; const uint8_t *p = b + *o; const size_t avail = (n - *o) * 8;
+      for (uint32_t t = 0; t < ntags && !rc; t++) {
+        const uint32_t len = tags[t]; if (len > 32) { rc = -7; break; }
+        for (int c = 0; c < ncomp; c++) {
+          uint32_t v = 0;
+          if (bit + len > avail) { rc = -1; break; }
+          for (uint32_t k = 0; k < len; k++, bit++) v |= (uint32_t)((p[bit >> 3] >> (bit & 7)) & 1) << k;
+          out[(size_t)t * ncomp + c] = v;
+        }
+      }
+      *o += (bit + 7) / 8;
+    }
+    free(tags);
+    return rc;
+  }
+  if (scheme != 1) return -2;
+  if (*o + 1 > n) return -1;
   int bl = b[(*o)++];
+  return rans_section(b, n, o, bl, nvals, out, info, 1);
+}
+
+static int rans_section(const uint8_t *b, size_t n, size_t *o, int bl, uint32_t nvals, uint32_t *out, orc_sym_info *info, int scheme) {
   int prec_bits = (3 * bl) / 2; if (prec_bits < 12) prec_bits = 12; if (prec_bits > 20) prec_bits = 20;
   uint32_t prec = 1u << prec_bits, L = prec * 4;
   uint64_t ns; if (rd_varint(b, n, o, &ns)) return -1;

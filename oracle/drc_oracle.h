@@ -15,6 +15,8 @@ extern "C" {
 /* Decode a DecodeSymbols() section starting at b[*o]; returns 0 ok. out must hold nvals. */
 typedef struct { int scheme, bl, prec_bits, alphabet, unique, left; uint32_t final_state, base; size_t payload; } orc_sym_info;
 int orc_decode_symbols(const uint8_t *b, size_t n, size_t *o, uint32_t nvals, uint32_t *out, orc_sym_info *info);
+/* the same for nvals values in groups of ncomp (the TAGGED scheme codes one bit-length tag per group); RAW ignores ncomp */
+int orc_decode_symbols_nc(const uint8_t *b, size_t n, size_t *o, uint32_t nvals, int ncomp, uint32_t *out, orc_sym_info *info);
 /* Encode symbols with the RAW rANS scheme exactly as draco's EncodeSymbols(RAW). */
 void orc_encode_symbols(const uint32_t *syms, uint32_t nvals, orc_buf *out);
 
@@ -45,13 +47,15 @@ typedef struct {
 
 typedef struct {
   int major, minor, nf, nev, nad, nsym, nsplit, nts, nverts_alloc;
-  int32_t *opp, *c2v;            /* 3*nf */
+  int32_t *opp, *c2v;            /* 3*nf (NULL for sequential connectivity) */
   int ctx_n[6];
   int n_interior_start;
   size_t conn_end, hdr_end, total;
   int natt;
   drc_att att[8];
   size_t leftover;
+  int method, traversal;         /* encoder_method 1 edgebreaker / 0 sequential; edgebreaker traversal 2 valence / 0 standard; sequential: connectivity method 0 compressed / 1 raw */
+  int npoints;                   /* sequential: number of points (= entries of every attribute) */
 } drc_mesh;
 
 /* returns 0 on success, negative error code otherwise */
@@ -63,6 +67,8 @@ void drc_dequant(const drc_mesh *m, int a, float *out);
 /* ---------- encoder restatement ---------- */
 typedef struct {
   int qp, qt, qn;     /* quantization bits, defaults 11/10/8 (scripts/Encoder.py:171-173) */
+  int method;         /* tool set: 0 = valence edgebreaker (draco_encoder -cl 7, the reference's default), 1 = edgebreaker with the STANDARD traversal
+                         (symbols bit-coded, what stock levels 1..5 write), 2 = SEQUENTIAL connectivity + difference prediction (stock level 0) */
 } drc_enc_params;
 
 /* OBJ-style input: separate value arrays + per-corner indices. uv/nrm may be NULL (with n=0). */

@@ -46,11 +46,11 @@ class DrcMesh(C.Structure):
                 ("opp", C.POINTER(C.c_int32)), ("c2v", C.POINTER(C.c_int32)),
                 ("ctx_n", C.c_int * 6), ("n_interior_start", C.c_int),
                 ("conn_end", C.c_size_t), ("hdr_end", C.c_size_t), ("total", C.c_size_t),
-                ("natt", C.c_int), ("att", DrcAtt * 8), ("leftover", C.c_size_t)]
+                ("natt", C.c_int), ("att", DrcAtt * 8), ("leftover", C.c_size_t), ("method", C.c_int), ("traversal", C.c_int), ("npoints", C.c_int)]
 
 
 class DrcEncParams(C.Structure):
-    _fields_ = [("qp", C.c_int), ("qt", C.c_int), ("qn", C.c_int)]
+    _fields_ = [("qp", C.c_int), ("qt", C.c_int), ("qn", C.c_int), ("method", C.c_int)]
 
 
 class DrcEncInput(C.Structure):
@@ -102,8 +102,9 @@ class DecodedMesh:
         self.ctx_n = list(m.ctx_n)
         self.n_interior_start = m.n_interior_start
         self.conn_end, self.hdr_end, self.leftover = m.conn_end, m.hdr_end, m.leftover
-        self.opp = np.ctypeslib.as_array(m.opp, (3 * nf,)).copy()
-        self.c2v = np.ctypeslib.as_array(m.c2v, (3 * nf,)).copy()
+        self.method, self.traversal, self.npoints = m.method, m.traversal, m.npoints     # 1 edgebreaker / 0 sequential connectivity
+        self.opp = np.ctypeslib.as_array(m.opp, (3 * nf,)).copy() if m.opp else None
+        self.c2v = np.ctypeslib.as_array(m.c2v, (3 * nf,)).copy() if m.c2v else None
         self.atts = []
         for i in range(m.natt):
             a = m.att[i]
@@ -167,7 +168,8 @@ def rabs_encode(bits) -> bytes:
     return _take(buf)
 
 
-def drc_encode(pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None, qp=11, qt=10, qn=8) -> bytes:
+def drc_encode(pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None, qp=11, qt=10, qn=8, method=0) -> bytes:
+    """method: 0 valence edgebreaker (`draco_encoder -cl 7`), 1 edgebreaker with the standard traversal, 2 sequential connectivity."""
     pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
     idx_pos = np.ascontiguousarray(idx_pos, dtype=np.uint32).reshape(-1)
     inp = DrcEncInput()
@@ -186,7 +188,7 @@ def drc_encode(pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None, qp=11
         idx_nrm = np.ascontiguousarray(idx_nrm, dtype=np.uint32).reshape(-1)
         keep += [nrm, idx_nrm]
         inp.nrm = nrm.ctypes.data_as(fp); inp.n_nrm = len(nrm); inp.idx_nrm = idx_nrm.ctypes.data_as(up)
-    prm = DrcEncParams(qp, qt, qn)
+    prm = DrcEncParams(qp, qt, qn, method)
     buf = OrcBuf()
     rc = lib().drc_encode(C.byref(inp), C.byref(prm), C.byref(buf))
     if rc:

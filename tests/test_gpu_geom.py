@@ -338,3 +338,20 @@ def test_gpu_enqueue_form_of_the_abi(oracle, gpu_codec):
     r = gpu_codec.finish()
     ea, eb = _oracle_bytes(oracle, a), _oracle_bytes(oracle, b)
     assert r[0] == [ea, eb] and r[1] == [eb, None, ea] and r[2] == [oracle.ktx2_encode(tex)] * 2
+
+
+def test_gpu_decoder_reads_the_other_draco_tool_sets(oracle, gpu_codec):
+    """streams with the STANDARD edgebreaker traversal (stock compression levels 1..5) and with SEQUENTIAL connectivity
+    (level 0) decode on the device to exactly what the CPU restatement decodes - at test sizes and at 100k vertices -,
+    mixed with valence-edgebreaker files in one batch."""
+    import synth
+    ms = [synth.torus_mesh(), synth.grid_mesh(), synth.sphere_mesh(frame=2, seed=2)]
+    files = []
+    for f in ms:
+        for method in (0, 1, 2):
+            files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f["uv"], f["idx_uv"], f["nrm"], f["idx_nrm"], method=method))
+    t = ms[0]
+    files.append(oracle.drc_encode(t["pos"], t["idx_pos"], method=2))
+    from test_hipemu_geom import _check_decoded
+    for data, got in zip(files, gpu_codec.decode_mesh_batch(files)):
+        _check_decoded(oracle, data, got)

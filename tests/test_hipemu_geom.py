@@ -152,6 +152,11 @@ def test_hipemu_mesh_decode_matches_oracle(oracle, hipemu_lib):
     ms = [m for _, m in _meshes()]
     bare = dict(pos=ms[2]["pos"], idx_pos=ms[2]["idx_pos"])
     files = [oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm")) for f in ms + [bare]]
+    # the other Draco tool sets the stock player's decoder reads (src/lib/DRACOLoader.js:470-554): edgebreaker with the STANDARD
+    # traversal (stock levels 1..5) and SEQUENTIAL connectivity (level 0), written by the restatement's encoder options
+    for f in ms[:3] + [bare]:
+        for method in (1, 2):
+            files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), method=method))
     files += [open(os.path.join(GOLDEN, n), "rb").read() for n in ("00000.drc", "00075.drc")]
     for data, got in zip(files, cd.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)

@@ -143,3 +143,20 @@ def test_encoder_other_quantisation_bits(oracle, qp, qt, qn):
     e = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=qp, qt=qt, qn=qn)
     d = check_roundtrip(oracle, m, e, qp=qp, qt=qt)
     assert [a["qbits"] for a in d.atts] == [qp, qt, qn]
+
+
+def test_encoder_tool_set_options_round_trip(oracle):
+    """The restatement's other tool sets - edgebreaker with the STANDARD traversal (method 1) and SEQUENTIAL connectivity with the
+    difference predictor (method 2) - have no reference fixture; they are pinned by the round trip through the decoder:
+    same triangles, positions within half a step; the standard traversal decodes to the very arrays of the valence stream."""
+    import synth
+    from helpers import check_roundtrip
+    for m in (synth.torus_mesh(), synth.grid_mesh(), synth.sphere_mesh(60, 31, charts=(6, 5))):
+        a = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"])
+        b = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], method=1)
+        c = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], method=2)
+        da, db, dc = check_roundtrip(oracle, m, a), check_roundtrip(oracle, m, b), check_roundtrip(oracle, m, c)
+        assert (db.method, db.traversal, dc.method) == (1, 0, 0) and dc.opp is None
+        for x, y in zip(da.atts, db.atts):
+            assert np.array_equal(x["vals"], y["vals"]) and np.array_equal(x["corner_to_entry"], y["corner_to_entry"])
+        assert all(a_["n"] == dc.npoints for a_ in dc.atts)

@@ -34,6 +34,9 @@ struct GDAtt {
 };
 struct GeoDecJob {
   const uint8_t *file; uint32_t file_len; int32_t status;
+  int32_t method, traversal;     // encoder_method: 1 edgebreaker (traversal 2 valence / 0 standard), 0 sequential (traversal = connectivity method: 0 compressed / 1 raw)
+  uint32_t symbits_off, symbits_n;   // standard traversal: the symbols as an LSB-first bit sequence (byte offset, bits)
+  uint32_t seq_idx_off, seq_idx_w;   // sequential, raw indices: byte offset; bytes per index (1, 2, 4) or 0 = varints
   int32_t nev, nf, nad, nsym, nsplit, nts, ndec, nv, n_interior_start;
   uint32_t ts_off, ts_bits_off;  // topology split events: varint pairs, then packed source-edge bits
   GDRabs rb_start, rb_seam[GD_MAXAD];
@@ -73,17 +76,67 @@ __device__ inline void gr_rans(GRd &r, GDRans &S, uint32_t nvals) {
   S.pay_len = gr_varint(r); S.pay_off = r.o; if (r.o + S.pay_len > r.n) r.err = 1; else r.o += S.pay_len;
 }
 
+// ---- sequential connectivity (encoder_method 0; what stock `draco_encoder -cl 0` writes): header, index section, ONE attributes
+// decoder with every attribute coded per point in point order (DIFFERENCE predictor or none), transform data of all attributes
+// at the end.  Restated from the published bitstream description; no reference fixture uses it. ----
+__device__ inline void gd_index_sequential(GeoDecJob &J, GRd &r) {
+  const uint32_t n = r.n;
+  const int nf = (int)gr_varint(r), np = (int)gr_varint(r), cm = (int)gr_u8(r);
+  if (r.err || nf <= 0 || nf != J.nf || np <= 0 || np != J.nev || (cm != 0 && cm != 1)) { J.status = -6; return; }
+  J.traversal = cm; J.nad = 0; J.nsym = 0; J.nsplit = 0; J.nts = 0; J.nv = np;
+  for (int i = 0; i < GD_NRS; i++) { J.rs[i].present = 0; J.rs[i].nvals = 0; }
+  if (cm == 1) {
+    J.seq_idx_off = r.o;
+    if (np < 256) J.seq_idx_w = 1; else if (np < (1 << 16)) J.seq_idx_w = 2; else if (np < (1 << 21)) J.seq_idx_w = 0; else J.seq_idx_w = 4;
+    if (J.seq_idx_w) { const uint64_t bytes = 3ull * (uint64_t)nf * J.seq_idx_w; if (r.o + bytes > n) { J.status = -8; return; } r.o += (uint32_t)bytes; }
+    else { for (int i = 0; i < 3 * nf && !r.err; i++) (void)gr_varint(r); }
+  } else gr_rans(r, J.rs[GD_NRS - 1], 3u * (uint32_t)nf);       // index differences as symbols: the last attribute slot's tables (large alphabet)
+  if (r.err) { J.status = r.err == 2 ? -25 : -8; return; }
+  if (gr_u8(r) != 1) { J.status = -20; return; }
+  const int natt = (int)gr_varint(r);
+  if (r.err || natt < 1 || natt > GD_MAXDEC || (cm == 0 && natt > GD_MAXDEC - 1)) { J.status = -20; return; }
+  J.ndec = natt;
+  for (int d = 0; d < natt; d++) { GDAtt &A = J.att[d]; A.att_data_id = -1; A.dec_type = 0; A.table = 0; A.att_type = (int)gr_u8(r); A.data_type = (int)gr_u8(r); A.ncomp = (int)gr_u8(r); (void)gr_u8(r); A.unique_id = (int)gr_varint(r); }
+  for (int d = 0; d < natt; d++) J.att[d].seq_type = (int)gr_u8(r);
+  if (r.err) { J.status = -22; return; }
+  for (int d = 0; d < natt; d++) {
+    GDAtt &A = J.att[d];
+    A.pred_method = (int8_t)gr_u8(r); A.transform = 0;
+    if (A.pred_method != -2) A.transform = (int8_t)gr_u8(r);
+    if (gr_u8(r) != 1) { J.status = -24; return; }               // raw (uncompressed) values are not read here
+    A.nc = A.seq_type == 3 ? 2 : A.ncomp;
+    if (A.nc < 1 || A.nc > 4 || A.seq_type < 1 || A.seq_type > 3) { J.status = -24; return; }
+    gr_rans(r, J.rs[6 + d], (uint32_t)np * (uint32_t)A.nc);
+    A.aux.present = 0; A.n_orient = 0;
+    if (A.pred_method == -2) { }
+    else if (A.pred_method == 0 && A.transform == 1) { A.lo = gr_i32(r); A.hi = gr_i32(r); }
+    else if (A.pred_method == 0 && A.transform == 3 && A.nc == 2) { A.maxq = gr_i32(r); A.cen = gr_i32(r); }
+    else { J.status = -31; return; }
+    if (r.err) { J.status = r.err == 2 ? -25 : -32; return; }
+  }
+  for (int d = 0; d < natt; d++) {
+    GDAtt &A = J.att[d];
+    if (A.seq_type == 2) { for (int k = 0; k < A.ncomp && k < 4; k++) A.minv[k] = gr_f32(r); A.range = gr_f32(r); A.qbits = (int)gr_u8(r); }
+    else if (A.seq_type == 3) A.qbits = (int)gr_u8(r);
+  }
+  if (r.err) { J.status = -32; return; }
+  if (r.o != n) { J.status = -33; return; }
+}
+
 // ---- K1: index every section of the file ----
 __global__ void __launch_bounds__(64) k_gdec_index(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.x];
   if (threadIdx.x != 0 || J.status != 0) return;
   const uint8_t *b = J.file; const uint32_t n = J.file_len;
   if (n < 11 || b[0] != 'D' || b[1] != 'R' || b[2] != 'A' || b[3] != 'C' || b[4] != 'O') { J.status = -1; return; }
-  if (b[7] != 1 || b[8] != 1) { J.status = -2; return; }
+  if (b[7] != 1 || b[8] > 1) { J.status = -2; return; }
   if (b[5] != 2 || b[6] != 2) { J.status = -3; return; }
   if ((b[9] | (b[10] << 8)) != 0) { J.status = -4; return; }
   GRd r; r.b = b; r.n = n; r.o = 11; r.err = 0;
-  if (gr_u8(r) != 2) { J.status = -5; return; }
+  J.method = b[8];
+  if (J.method == 0) { gd_index_sequential(J, r); return; }
+  J.traversal = (int)gr_u8(r);
+  if (J.traversal != 2 && J.traversal != 0) { J.status = -5; return; }
   const int nev = (int)gr_varint(r), nf = (int)gr_varint(r), nad = (int)gr_u8(r), nsym = (int)gr_varint(r), nsplit = (int)gr_varint(r), nts = (int)gr_varint(r);
   // every count comes from an untrusted varint: the slab is carved for nev + nf + 8 vertices (gdec_carve), so a vertex-split
   // count above nf (one split needs one S symbol, one symbol per face) would let k_gdec_conn write past it
@@ -92,9 +145,14 @@ __global__ void __launch_bounds__(64) k_gdec_index(GeoDecJob *jobs) {
   { int last = 0; for (int i = 0; i < nts; i++) { const int d = (int)gr_varint(r), src = d + last, d2 = (int)gr_varint(r); J.sp_src[i] = src; J.sp_spl[i] = src - d2; last = src; }
     if (r.o + (uint32_t)(nts + 7) / 8 > n) r.err = 1;
     else { for (int i = 0; i < nts; i++) J.sp_edge[i] = (b[r.o + (i >> 3)] >> (i & 7)) & 1; if (nts > 0) r.o += (uint32_t)(nts + 7) / 8; } }
+  if (J.traversal == 0) {                              // standard traversal: size-prefixed bit sequence of the symbols, then start faces and seams
+    const uint32_t nb = gr_varint(r); if (r.err || r.o + nb > n || nb > (1u << 28)) { J.status = -8; return; }
+    J.symbits_off = r.o; J.symbits_n = 8u * nb; r.o += nb;
+  }
   gr_rabs(r, J.rb_start);
   for (int i = 0; i < nad; i++) gr_rabs(r, J.rb_seam[i]);
-  for (int i = 0; i < 6; i++) { const uint32_t cn = gr_varint(r); if (cn > (uint32_t)nf) r.err = 1; J.rs[i].present = 0; J.rs[i].nvals = cn; if (cn > 0 && !r.err) gr_rans(r, J.rs[i], cn); }
+  for (int i = 0; i < 6; i++) { J.rs[i].present = 0; J.rs[i].nvals = 0; }
+  for (int i = 0; i < 6 && J.traversal == 2; i++) { const uint32_t cn = gr_varint(r); if (cn > (uint32_t)nf) r.err = 1; J.rs[i].nvals = cn; if (cn > 0 && !r.err) gr_rans(r, J.rs[i], cn); }
   if (r.err) { J.status = -8; return; }
   // attribute decoder headers (A.4)
   const int ndec = (int)gr_u8(r); if (r.err || ndec < 1 || ndec > GD_MAXDEC) { J.status = -20; return; }
@@ -207,8 +265,9 @@ __device__ __forceinline__ int gd_rabs_bit(GDBit &R) {
 // ---- K3: connectivity, one lane per frame ----
 __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.x];
-  if (threadIdx.x != 0 || J.status != 0) return;
+  if (threadIdx.x != 0 || J.status != 0 || J.method == 0) return;
   const int nf = J.nf, nsym = J.nsym, nts = J.nts, maxv = J.nev + J.nsplit + 3;
+  const bool std_trav = J.traversal == 0; const uint8_t *sbits = J.file + J.symbits_off; uint32_t sbit = 0; const uint32_t sbit_n = J.symbits_n;
   UVOL_G(int32_t) opp = UVOL_TO_G(int32_t, J.opp); UVOL_G(int32_t) c2v = UVOL_TO_G(int32_t, J.c2v); UVOL_G(int32_t) lm = UVOL_TO_G(int32_t, J.lm);
   UVOL_G(int32_t) val = UVOL_TO_G(int32_t, J.val); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) tsac = UVOL_TO_G(int32_t, J.tsac);
   UVOL_G(const uint32_t) ctxs[6]; for (int i = 0; i < 6; i++) ctxs[i] = UVOL_TO_G(const uint32_t, J.rs[i].out);
@@ -224,7 +283,12 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
 #define GD_BADC(c) ((unsigned)(c) >= (unsigned)(3 * nf))
   for (int sid = 0; sid < nsym && !rc; sid++) {
     const int face = nfaces++; int check = 0, sym;
-    if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = ctxs[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
+    if (std_trav) {                                     // 1 bit: C; else two more bits: S 1, L 3, R 5, E 7
+      if (sbit + 1 > sbit_n) { rc = -10; break; }
+      sym = (sbits[sbit >> 3] >> (sbit & 7)) & 1; sbit++;
+      if (sym) { if (sbit + 2 > sbit_n) { rc = -10; break; } for (int k = 0; k < 2; k++, sbit++) sym |= ((sbits[sbit >> 3] >> (sbit & 7)) & 1) << (1 + k); }
+    }
+    else if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = ctxs[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
     else sym = 7;
     const int corner = 3 * face;
     if (sym == 0) {
@@ -320,7 +384,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
 __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_validate(GeoDecJob *jobs, int what) {
   GeoDecJob &J = jobs[blockIdx.y];
   const int c = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x), nc = 3 * J.nf;
-  if (J.status != 0 || c >= nc) return;
+  if (J.status != 0 || c >= nc || J.method == 0) return;
   if (what == 0) {
     const int v = J.c2v[c], o = J.opp[c];
     bool bad = (unsigned)v >= (unsigned)J.nv || o < GEO_INV || o >= nc || (o >= 0 && J.opp[o] != c);
@@ -336,7 +400,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_validate(GeoDecJob *jobs, i
 // part —, (c) ballot-ranked assignment of the bits to both corners of each edge, 64 corners at a time. ----
 __global__ void __launch_bounds__(64) k_gdec_seams(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.x];
-  if (J.status != 0) return;
+  if (J.status != 0 || J.method == 0) return;
   const uint32_t lane = threadIdx.x;
   const int nc = 3 * J.nf, nad = J.nad; const int32_t *opp = J.opp;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -382,7 +446,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_vseam(GeoDecJob *jobs) {
 __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_atttab(GeoDecJob *jobs, int pass) {
   GeoDecJob &J = jobs[blockIdx.y];
   const int i = blockIdx.z, v = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
-  if (J.status != 0 || i >= J.nad || v >= J.nv) return;
+  if (J.status != 0 || i >= J.nad || v >= J.nv || J.method == 0) return;
   const int32_t *opp = J.opp; const uint8_t *es = J.edge_seam[i];
   const uint8_t *vseam = J.vseam + (size_t)i * ((size_t)J.nev + J.nf + 72);
   int32_t *cntp = J.t_cnt + (size_t)i * ((size_t)J.nev + J.nf + 72);
@@ -422,6 +486,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_open(GeoDecJob *jobs, GeoJo
   GeoDecJob &J = jobs[blockIdx.y];
   GeoJob &G = gj[blockIdx.y];
   const int t = blockIdx.z;                                  // 0 base, 1 + i attribute table
+  if (blockIdx.x == 0 && threadIdx.x == 0 && t == 0 && J.method == 0) {      // sequential connectivity: nothing for the traversal kernels to do
+    G.status = J.status; G.nf = 0; G.nc = 0; G.nad = 0; G.nverts = 0xffffffffu; G.interior_seams[0] = G.interior_seams[1] = 0;
+    for (int k = 0; k < 4; k++) G.nverts_t[k] = 0;
+  }
+  if (J.method == 0) return;
   if (blockIdx.x == 0 && threadIdx.x == 0 && t == 0) {
     G.status = J.status; G.nf = (uint32_t)J.nf; G.nc = 3u * (uint32_t)J.nf; G.nad = J.nad > 2 ? 2 : J.nad; G.nverts = 0xffffffffu;
     G.nverts_t[1] = (uint32_t)J.nv;
@@ -591,7 +660,15 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
   // would wait for the previous store's acknowledgement (see uvol_common.hpp)
   UVOL_G(const uint32_t) syms = UVOL_TO_G(const uint32_t, J.rs[6 + d].out); UVOL_G(int32_t) out = UVOL_TO_G(int32_t, A.vals);
   int pdec = -1; for (int k = 0; k < J.ndec; k++) if (J.att[k].att_type == 0 && J.att[k].att_data_id == -1) pdec = k;
-  if (A.pred_method == 1 || A.pred_method == 0) {
+  if (A.pred_method == -2) { for (int i = 0; i < ne * nc; i++) out[i] = gd_sgn(syms[i]); }          // no prediction (sequential streams)
+  else if (A.pred_method == 0 && A.transform == 3) {                                                // DIFFERENCE through the canonicalised octahedron (sequential normals)
+    int q = 0; while ((1 << q) - 1 < A.maxq) q++;
+    const GOct ot = g_oct(q);
+    if (ot.MAXQ != A.maxq || ot.CEN != A.cen || nc != 2) { J.status = -30; return; }
+    int prev[2] = { 0, 0 };
+    for (int p = 0; p < ne; p++) { const int corr[2] = { (int)syms[2 * p], (int)syms[2 * p + 1] }; int32_t o2[2]; gd_oct_orig(ot, prev, corr, o2); out[2 * p] = o2[0]; out[2 * p + 1] = o2[1]; prev[0] = o2[0]; prev[1] = o2[1]; }
+  }
+  else if (A.pred_method == 1 || A.pred_method == 0) {
     const int32_t lo = A.lo, hi = A.hi;
     UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)9 * J.nf + 64));
     // component count as a template parameter: the per-component arrays must stay in registers (a run-time bound sends
@@ -644,6 +721,22 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
   }
 }
 
+// sequential connectivity: the point index of every corner -> c2v[] (one wave per frame; varint- and difference-coded indices by lane 0)
+__global__ void __launch_bounds__(64) k_gdec_seq_conn(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.x];
+  if (J.status != 0 || J.method != 0) return;
+  const int nc = 3 * J.nf, np = J.nv; const uint32_t lane = threadIdx.x;
+  bool bad = false;
+  if (J.traversal == 1 && J.seq_idx_w) {
+    const uint8_t *p = J.file + J.seq_idx_off; const uint32_t w = J.seq_idx_w;
+    for (int i = (int)lane; i < nc; i += 64) { uint32_t v = 0; for (uint32_t k = 0; k < w; k++) v |= (uint32_t)p[(size_t)i * w + k] << (8 * k); if (v >= (uint32_t)np) bad = true; J.c2v[i] = (int32_t)v; }
+  } else if (lane == 0) {
+    if (J.traversal == 1) { GRd r; r.b = J.file; r.n = J.file_len; r.o = J.seq_idx_off; r.err = 0; for (int i = 0; i < nc; i++) { const uint32_t v = gr_varint(r); if (v >= (uint32_t)np) bad = true; J.c2v[i] = (int32_t)v; } if (r.err) bad = true; }
+    else { const uint32_t *sy = J.rs[GD_NRS - 1].out; int32_t last = 0; for (int i = 0; i < nc; i++) { int32_t d = (int32_t)(sy[i] >> 1); if (sy[i] & 1) d = -d; last += d; if ((uint32_t)last >= (uint32_t)np) bad = true; J.c2v[i] = last; } }
+  }
+  if (bad) J.status = -19;
+}
+
 // flip bits of the normal decoders: the only sequential part of the geometric-normal scheme (one lane per decoder)
 __global__ void __launch_bounds__(64) k_gdec_flips(GeoDecJob *jobs, GeoJob *gj) {
   GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
@@ -666,6 +759,7 @@ __global__ void __launch_bounds__(64) k_gdec_counts(GeoDecJob *jobs, GeoJob *gj)
   if (threadIdx.x != 0) return;
   if (G.status != 0 && J.status == 0) J.status = G.status;
   if (J.status != 0) return;
+  if (J.method == 0) { G.ne[0] = (uint32_t)J.nv; return; }                   // sequential: one entry per point, the value counts were known at once
   for (int d = 0; d < J.ndec; d++) J.rs[6 + d].nvals = G.ne[J.att[d].table] * (uint32_t)J.att[d].nc;
 }
 
@@ -681,7 +775,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_finish(GeoDecJob *jobs, Geo
   const GDAtt &A = J.att[d];
   const int t = A.table; const uint32_t ne = G.ne[t];
   if (i == 0) { J.o_n[which] = ne; J.o_dec[which] = d; }
-  if (i < 3u * (uint32_t)J.nf && J.o_idx[which]) { const int32_t *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1]; J.o_idx[which][i] = (uint32_t)G.v2d[t][xc2v[i]]; }
+  if (i < 3u * (uint32_t)J.nf && J.o_idx[which]) { const int32_t *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1]; J.o_idx[which][i] = J.method == 0 ? (uint32_t)J.c2v[i] : (uint32_t)G.v2d[t][xc2v[i]]; }
   if (i >= ne || !J.o_val[which]) return;
   float *o = J.o_val[which];
   if (A.seq_type == 2) {
@@ -710,9 +804,10 @@ void geodec_destroy(uvol_ctx *ctx) {
 }
 
 static bool gdec_header(const uint8_t *b, size_t n, uint32_t *nev, uint32_t *nf) {
-  if (!b || n < 16 || memcmp(b, "DRACO", 5)) return false;
-  size_t o = 12; uint32_t v[2];
+  if (!b || n < 16 || memcmp(b, "DRACO", 5) || b[8] > 1) return false;
+  size_t o = b[8] == 0 ? 11 : 12; uint32_t v[2];                          // sequential: faces, points; edgebreaker: traversal byte, vertices, faces
   for (int k = 0; k < 2; k++) { uint64_t r = 0; int s = 0; for (;;) { if (o >= n || s > 35) return false; const uint8_t c = b[o++]; r |= (uint64_t)(c & 0x7f) << s; s += 7; if (c < 0x80) break; } v[k] = (uint32_t)r; }
+  if (b[8] == 0) { const uint32_t t = v[0]; v[0] = v[1]; v[1] = t; if (v[0] == 0 || v[0] > 3 * v[1]) return false; }
   *nev = v[0]; *nf = v[1];
   return v[1] > 0 && v[1] <= (1u << 26) && v[0] <= 3 * v[1] + 8 && (uint64_t)v[1] <= 16ull * n;      // a face costs > 1/16 byte
 }
@@ -818,7 +913,8 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
     if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) return rc;
     GLAUNCH(k_gdec_counts, dim3(N), dim3(64), 0, dj, gj); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(GD_MAXDEC, N), dim3(64), 0, dj, 6, GD_MAXDEC); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(GD_MAXDEC, N), dim3(64), 0, dj, 6, GD_MAXDEC);
+    GLAUNCH(k_gdec_seq_conn, dim3(N), dim3(64), 0, dj); }                  // frames with sequential connectivity: their index section
   { uvol_ctx::Scope sc(ctx, "geodec.k7_predict", 0);
     GLAUNCH(k_gdec_pgram, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
     GLAUNCH(k_gdec_flips, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj);
