@@ -45,7 +45,8 @@ typedef struct uvol_params {
   int32_t q_texture_attr;           /* Q_TEXTURE_ATTR,          default 10 */
   int32_t q_normal_attr;            /* Q_NORMAL_ATTR,           default 8  */
   int32_t q_generic_attr;           /* Q_GENERIC_ATTR,          default 8 (accepted, unused: no generic attribute on this ABI) */
-  int32_t draco_compression_level;  /* DRACO_COMPRESSION_LEVEL 0..10, default 7 (every level is encoded with the cl 7 tool set: the level is not part of the bitstream) */
+  int32_t draco_compression_level;  /* DRACO_COMPRESSION_LEVEL 0..10, default 7.  0 = sequential connectivity + difference predictor (stock draco_encoder's choice at
+                                       this level); 1..10 are encoded with the level-7 tool set (valence edgebreaker; the level itself is not part of the bitstream) */
   int32_t ktx2_batch_size;          /* KTX2_BATCH_SIZE (mandatory in the reference) = layers per .ktx2 */
   int32_t etc1s_quality;            /* basisu -q equivalent, 1..255, default 128 (Encoder.py passes none) */
   int32_t y_flip;                   /* basisu -y_flip (Encoder.py:290 always passes it), default 1 */

@@ -63,7 +63,7 @@ def test_argv_shims_with_reference_command_lines(oracle, tmp_path):
 
 def test_uvolenc_targets_uastc_and_shims_flags(oracle, tmp_path):
     """On the GPU: `--targets ktx2,etc2` (raw ETC2 target + two-target manifest), `--uastc`, and the documented flag ranges of the
-    shims (`-cl` 0..10 encoded with the cl 7 tool set, `-uastc`)."""
+    shims (`-cl` 1..10 encoded with the cl 7 tool set, `-cl 0` with sequential connectivity, `-uastc`)."""
     import numpy as np
     import cli_helpers, helpers, player_urls
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "universal-volumetric_amd"), "all"])
@@ -87,10 +87,11 @@ def test_uvolenc_targets_uastc_and_shims_flags(oracle, tmp_path):
     # shims: every documented compression level, and -uastc
     obj = os.path.join(str(tmp_path), "OBJ", "frame_00001.obj"); m = meshes[1]
     want = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=14, qt=12, qn=10)
-    for cl in (0, 5, 10):
+    want0 = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"], qp=14, qt=12, qn=10, method=2)
+    for cl in (0, 5, 10):                     # level 0 = sequential connectivity (stock draco_encoder's choice), the others the level-7 tool set
         drc = os.path.join(str(tmp_path), "cl%d.drc" % cl)
         assert subprocess.call([os.path.join(BIN, "draco_encoder"), "-i", obj, "-o", drc, "-qp", "14", "-qt", "12", "-qn", "10", "-cl", str(cl)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0
-        assert open(drc, "rb").read() == want
+        assert open(drc, "rb").read() == (want0 if cl == 0 else want)
     assert subprocess.call([os.path.join(BIN, "draco_encoder"), "-i", obj, "-o", drc, "-cl", "11"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0
     pat = os.path.join(str(tmp_path), "PNG", "export_%05u.png"); ktx = os.path.join(str(tmp_path), "u.ktx2")
     assert subprocess.call([os.path.join(BIN, "basisu"), "-uastc", "-ktx2", "-tex_type", "video", "-multifile_printf", pat, "-multifile_num", "3", "-multifile_first", "0", "-y_flip", "-output_file", ktx], stdout=subprocess.DEVNULL) == 0

@@ -355,3 +355,23 @@ def test_gpu_decoder_reads_the_other_draco_tool_sets(oracle, gpu_codec):
     from test_hipemu_geom import _check_decoded
     for data, got in zip(files, gpu_codec.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)
+
+
+def test_gpu_sequential_connectivity_at_compression_level_0(oracle):
+    """SURVEY row a3b on the device: DRACO_COMPRESSION_LEVEL 0 = sequential connectivity.  Bytes equal the CPU restatement's (method 2)
+    at test sizes and at 100k vertices (lattice and shuffled storage), and the frames round-trip (same triangles, positions within
+    half a quantisation step) through the fixture-pinned decoder's sequential branch."""
+    import synth, uvol
+    cd = uvol.Codec(device=0, DRACO_COMPRESSION_LEVEL=0)
+    try:
+        big = synth.sphere_mesh(frame=1, seed=1)
+        ms = [synth.torus_mesh(), synth.grid_mesh(), big, synth.shuffle_mesh(big, seed=5), dict(pos=big["pos"], idx_pos=big["idx_pos"])]
+        got = cd.encode_mesh_batch(ms)
+        for m, g in zip(ms, got):
+            assert g == oracle.drc_encode(m["pos"], m["idx_pos"], m.get("uv"), m.get("idx_uv"), m.get("nrm"), m.get("idx_nrm"), method=2)
+        check_roundtrip(oracle, ms[2], got[2]); check_roundtrip(oracle, ms[0], got[0])
+        from test_hipemu_geom import _check_decoded
+        for data, dec in zip(got, cd.decode_mesh_batch(got)):
+            _check_decoded(oracle, data, dec)
+    finally:
+        cd.close()

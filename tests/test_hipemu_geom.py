@@ -36,7 +36,8 @@ def test_hipemu_error_paths(hipemu_lib):
     bad = dict(pos=pos, idx_pos=np.array([0, 1, 7], np.uint32))
     res = cd.encode_mesh_batch([bad, good], raise_on_error=False)
     assert res[0] is None and res[1] is not None and res[1][:5] == b"DRACO"
-    # every documented DRACO_COMPRESSION_LEVEL (0..10, scripts/Encoder.py:171-179) is accepted and encoded with the cl 7 tool set
+    # every documented DRACO_COMPRESSION_LEVEL (0..10, scripts/Encoder.py:171-179) is accepted; 1..10 are encoded with the cl 7 tool set
+    # (0 = sequential connectivity, test_hipemu_sequential_connectivity_at_compression_level_0)
     c3 = uvol.Codec(lib_path=hipemu_lib, DRACO_COMPRESSION_LEVEL=3)
     assert c3.encode_mesh(**good) == res[1]
     c3.close()
@@ -126,6 +127,31 @@ def test_hipemu_enqueue_form_of_the_abi(oracle, hipemu_lib):
         c2.finish()
     assert c2.finish() == []                                   # the error was reported once
     c2.close()
+
+
+def test_hipemu_sequential_connectivity_at_compression_level_0(oracle, hipemu_lib):
+    """SURVEY row a3b (north_star: "edgebreaker / sequential connectivity"): DRACO_COMPRESSION_LEVEL 0 selects sequential connectivity
+    (what stock draco_encoder does at that level).  HIP bytes = the restatement's (method 2) on regular meshes, a frame without
+    uv / normals, the corner-table edge cases, adversarial soups and a shuffled storage order; the stream decodes on the HIP decoder
+    to what the restatement's decoder gives."""
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib, DRACO_COMPRESSION_LEVEL=0)
+    ms = [m for _, m in _meshes()]
+    ms.append(dict(pos=ms[2]["pos"], idx_pos=ms[2]["idx_pos"]))
+    ms += list(synth.edge_case_meshes().values()) + [synth.random_soup_mesh(5), synth.random_soup_mesh(6, 60, 300), synth.shuffle_mesh(ms[0], seed=3)]
+    got = cd.encode_mesh_batch(ms, raise_on_error=False)
+    files = []
+    for m, g in zip(ms, got):
+        try:
+            want = oracle.drc_encode(m["pos"], m["idx_pos"], m.get("uv"), m.get("idx_uv"), m.get("nrm"), m.get("idx_nrm"), method=2)
+        except Exception:
+            want = None
+        assert g == want
+        if g is not None:
+            files.append(g)
+    for data, dec in zip(files, cd.decode_mesh_batch(files)):
+        _check_decoded(oracle, data, dec)
+    cd.close()
 
 
 def _check_decoded(oracle, data, got):

@@ -71,6 +71,12 @@ struct GeoJob {
   float *pos_s;                            // positions in new-id order
   uint32_t *fperm, *cidx;                  // sorted slot -> input face; input face -> its index among the kept faces (original order)
   int32_t *forig, *s_of_o;                 // stored face -> original kept-face index, and back
+  // sequential connectivity (DRACO_COMPRESSION_LEVEL 0, k_sq_*): points = distinct (position, uv, normal) value triples in order
+  // of first appearance over the corners; a 64-bit-keyed hash table finds the first corner of every pair, twice
+  int32_t seq; uint32_t sq_cap, sq_np, sq_idx_bytes;
+  unsigned long long *sq_keys; uint32_t *sq_val;
+  int32_t *sq_pu, *sq_first, *sq_pid, *sq_cop;       // per corner: first corner with the same (pos, uv) / the same triple; point id; per point: its first corner
+  uint8_t *sq_flag; uint8_t *sq_idx;                  // scan flags / per-corner index byte counts; the index section's bytes
   uint32_t *he_part, *he_cnt; uint32_t he_vpb, he_nb, he_nblk;      // partitioned bucket build: {from, to, corner} records by vertex range; counts[bin][tile]; vertices per bin (0: atomic build)
   uint32_t *he_start, *he_cur; unsigned long long *he_ent;   // half-edges bucketed by their from-vertex: [he_start[a], he_cur[a]) holds (to-vertex << 32 | corner)
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)

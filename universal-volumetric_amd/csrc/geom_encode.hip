@@ -54,12 +54,12 @@ __device__ inline uint32_t block_sum(uint32_t v) {
 
 // scan selectors.  The producers of the KEEP / ELIG / EVENTS flags write the per-block sums themselves (block_sum), so only
 // SCAN_ORI still runs k_scan_blocks; k_scan_sums turns the sums into block offsets for all four.
-enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3 };
+enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3, SCAN_SEQ = 4 };      // SCAN_SEQ: per input corner (sequential connectivity)
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
 // register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
-__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.keep : (sel == SCAN_EVENTS ? J.evcnt : (sel == SCAN_ELIG ? J.elig : J.has_ori)); }
-__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u))); }
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_SEQ ? J.sq_flag : (sel == SCAN_KEEP ? J.keep : (sel == SCAN_EVENTS ? J.evcnt : (sel == SCAN_ELIG ? J.elig : J.has_ori))); }
+__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_SEQ ? 3u * J.nf_in : (sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u)))); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
   const uint8_t *flags = scan_flags(J, sel); const uint32_t n = scan_count(J, sel);
@@ -2050,6 +2050,118 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   for (int k = 0; k < 2; k++) J.sym_nrm[2 * d + k] = (uint32_t)(ch[k] < 0 ? ch[k] + ot.MAXQ : ch[k]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sequential connectivity (DRACO_COMPRESSION_LEVEL 0: what stock `draco_encoder -cl 0` selects; north_star "edgebreaker /
+// sequential connectivity").  No traversal at all, so every stage is parallel: points = the distinct (position, uv, normal)
+// value triples in order of first appearance over the corners (hash table: first corner of every (pos, uv) pair, then of every
+// (pair, normal) pair; flag scan), the index section = the point of every corner in the smallest storage type, every attribute
+// coded per point with the DIFFERENCE predictor (previous point; wrap / canonicalised-octahedron transform) through the same
+// histogram / table / rANS kernels as the edgebreaker path.  Every face is kept, also degenerate ones.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long sq_key(const GeoJob &J, uint32_t c, int level) {
+  if (level == 0) return ((unsigned long long)J.canon[0][J.ipos[c]] << 32) | (unsigned long long)(J.has_uv ? J.canon[1][J.iuv[c]] : 0u);
+  return ((unsigned long long)(uint32_t)J.sq_pu[c] << 32) | (unsigned long long)(J.has_nrm ? J.canon[2][J.inrm[c]] : 0u);
+}
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sq_clear(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.y];
+  for (uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x; i < J.sq_cap; i += gridDim.x * UVOL_BLOCK) { J.sq_keys[i] = ~0ull; J.sq_val[i] = 0xffffffffu; }
+}
+// phase 0: validate the corner's indices (first level only), claim a slot for its key, keep the lowest corner; phase 1: read it back
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sq_hash(GeoJob *jobs, int level, int phase) {
+  JOB_OR_RETURN;
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c >= 3 * J.nf_in) return;
+  if (level == 0 && phase == 0 && (J.ipos[c] >= J.n_pos || (J.has_uv && J.iuv[c] >= J.n_uv) || (J.has_nrm && J.inrm[c] >= J.n_nrm))) { J.status = -2; return; }
+  const unsigned long long key = sq_key(J, c, level);
+  uint32_t s = (uint32_t)g_mix64(key) & (J.sq_cap - 1);
+  for (uint32_t guard = 0; guard <= J.sq_cap; guard++) {
+    unsigned long long cur = J.sq_keys[s];
+    if (phase == 0 && cur == ~0ull) { const unsigned long long old = atomicCAS(&J.sq_keys[s], ~0ull, key); cur = old == ~0ull ? key : old; }
+    if (cur == key) { if (phase == 0) atomicMin(&J.sq_val[s], c); else (level == 0 ? J.sq_pu : J.sq_first)[c] = (int32_t)J.sq_val[s]; return; }
+    if (cur == ~0ull) break;
+    s = (s + 1) & (J.sq_cap - 1);
+  }
+  J.status = -20;
+}
+// step 0: flag the first corner of every point (+ block sums); step 1 (after the scan): point ids of the first corners, corner of
+// every point, the point count; step 2: every corner's point id + the byte count of its index; step 3 (after the second scan): bytes
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sq_points(GeoJob *jobs, int step) {
+  GeoJob &J = jobs[blockIdx.y];
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x, nc = 3 * J.nf_in;
+  const bool live = J.status == 0 && c < nc;
+  if (step == 0 || step == 2) {
+    uint32_t v = 0;
+    if (live && step == 0) v = J.sq_first[c] == (int32_t)c ? 1u : 0u;
+    if (live && step == 2) {
+      const uint32_t p = (uint32_t)J.sq_pid[J.sq_first[c]], np = J.sq_np; J.sq_pid[c] = (int32_t)p;
+      v = np < 256u ? 1u : (np < (1u << 16) ? 2u : (np < (1u << 21) ? (p < 128u ? 1u : (p < 16384u ? 2u : 3u)) : 4u));
+    }
+    if (live) J.sq_flag[c] = (uint8_t)v;
+    const uint32_t tot = block_sum(v);
+    if (threadIdx.x == 0 && blockIdx.x < uvol_blocks_dev(nc)) J.bsum[blockIdx.x] = tot;
+    return;
+  }
+  uint32_t v = live ? J.sq_flag[c] : 0, tot;
+  const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(nc)) ? J.bsum[blockIdx.x] : 0);
+  if (step == 1) {
+    if (live && v) { J.sq_pid[c] = (int32_t)pos; if (pos < J.ecap) J.sq_cop[pos] = (int32_t)c; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
+      const uint32_t np = J.bsum[uvol_blocks_dev(nc)];
+      J.sq_np = np; J.nf = J.nf_in; J.nc = nc; J.nverts = np; J.ne[0] = np;
+      if (np > J.ecap) J.status = GEO_E_WS_OVERFLOW;
+      J.rs[6].n = 3 * np; J.rs[7].n = J.has_uv ? 2 * np : 0; J.rs[8].n = J.has_nrm ? 2 * np : 0;
+    }
+  } else {
+    if (live) {
+      const uint32_t p = (uint32_t)J.sq_pid[c], np = J.sq_np; uint8_t *o = J.sq_idx + pos;
+      if (np < 256u) o[0] = (uint8_t)p;
+      else if (np < (1u << 16)) { o[0] = (uint8_t)p; o[1] = (uint8_t)(p >> 8); }
+      else if (np < (1u << 21)) { uint32_t q = p; uint32_t k = 0; while (q >= 0x80u) { o[k++] = (uint8_t)(q | 0x80u); q >>= 7; } o[k] = (uint8_t)q; }
+      else { o[0] = (uint8_t)p; o[1] = (uint8_t)(p >> 8); o[2] = (uint8_t)(p >> 16); o[3] = (uint8_t)(p >> 24); }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.sq_idx_bytes = J.bsum[uvol_blocks_dev(nc)];
+  }
+}
+// per point: quantised values of its first corner (z: 0 position, 1 uv, 2 normal) + the wrap bounds
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sq_quant(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const uint32_t p = blockIdx.x * UVOL_BLOCK + threadIdx.x; const int a = blockIdx.z;
+  int lo = 0x7fffffff, hi = -0x7fffffff - 1; bool have = false;
+  if (p < J.sq_np && !(a == 1 && !J.has_uv) && !(a == 2 && !J.has_nrm)) {
+    const uint32_t c = (uint32_t)J.sq_cop[p];
+    if (a == 0) {
+      const float range = quant_range(J.pos_min_u, J.pos_max_u, 3), inv = (float)((1u << J.qp) - 1) / range;
+      const float *v = J.pos + 3 * (size_t)J.canon[0][J.ipos[c]];
+      for (int k = 0; k < 3; k++) { float t = v[k] - g_float_unorder(J.pos_min_u[k]); t = t * inv; const int q = (int)floorf(t + 0.5f); J.P[3 * p + k] = q; lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
+      have = true;
+    } else if (a == 1) {
+      const float range = quant_range(J.uv_min_u, J.uv_max_u, 2), inv = (float)((1u << J.qt) - 1) / range;
+      const float *v = J.uv + 2 * (size_t)J.canon[1][J.iuv[c]];
+      for (int k = 0; k < 2; k++) { float t = v[k] - g_float_unorder(J.uv_min_u[k]); t = t * inv; const int q = (int)floorf(t + 0.5f); J.U[2 * p + k] = q; lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
+      have = true;
+    } else { GOct ot = g_oct(J.qn); int s_, t_; float_to_oct(ot, J.nrm + 3 * (size_t)J.canon[2][J.inrm[c]], s_, t_); J.O[2 * p] = s_; J.O[2 * p + 1] = t_; }
+  }
+  if (a < 2) {
+    for (int d = 32; d >= 1; d >>= 1) { const int l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d); lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
+    const unsigned long long any = __ballot(have);
+    if ((threadIdx.x & 63) == 0 && any) { atomicMin(&J.wrap_lo[a], lo); atomicMax(&J.wrap_hi[a], hi); }
+  }
+}
+// DIFFERENCE predictor: the previous point's value (zeros for the first point) -> symbols
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sq_pred(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  const uint32_t p = blockIdx.x * UVOL_BLOCK + threadIdx.x; const int a = blockIdx.z;
+  if (p >= J.sq_np || (a == 1 && !J.has_uv) || (a == 2 && !J.has_nrm)) return;
+  if (a == 0) { for (int k = 0; k < 3; k++) J.sym_pos[3 * p + k] = g_sym_of(g_wrap_corr(J.wrap_lo[0], J.wrap_hi[0], J.P[3 * p + k], p ? (long long)J.P[3 * (p - 1) + k] : 0ll)); }
+  else if (a == 1) { for (int k = 0; k < 2; k++) J.sym_uv[2 * p + k] = g_sym_of(g_wrap_corr(J.wrap_lo[1], J.wrap_hi[1], J.U[2 * p + k], p ? (long long)J.U[2 * (p - 1) + k] : 0ll)); }
+  else {
+    const GOct ot = g_oct(J.qn);
+    const int orig[2] = { J.O[2 * p], J.O[2 * p + 1] }, pred[2] = { p ? J.O[2 * (p - 1)] : 0, p ? J.O[2 * (p - 1) + 1] : 0 }; int corr[2];
+    g_oct_corr(ot, orig, pred, corr);
+    J.sym_nrm[2 * p] = (uint32_t)corr[0]; J.sym_nrm[2 * p + 1] = (uint32_t)corr[1];
+  }
+}
+
 // single thread per frame: publish stream lengths once the entry counts are known
 __global__ void __launch_bounds__(64) k_stream_setup(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
@@ -2566,6 +2678,49 @@ __global__ void __launch_bounds__(64) k_layout(GeoJob *jobs) {
   J.out_len = total;
   if (total > J.out_cap) J.status = UVOL_E_NOSPACE;
 }
+// layout of a frame with sequential connectivity (see k_sq_*): header, index section, ONE attributes decoder
+__global__ void __launch_bounds__(64) k_sq_layout(GeoJob *jobs) {
+  GeoJob &J = jobs[blockIdx.x];
+  if (threadIdx.x != 0 || J.status != 0) return;
+  uint8_t *a = J.arena; uint32_t o = 0, total = 0, b0 = 0;
+  J.n_pieces = 0;
+  a[o++] = 'D'; a[o++] = 'R'; a[o++] = 'A'; a[o++] = 'C'; a[o++] = 'O'; a[o++] = 2; a[o++] = 2; a[o++] = 1; a[o++] = 0; a[o++] = 0; a[o++] = 0;
+  o += g_put_varint(a + o, J.nf_in); o += g_put_varint(a + o, J.sq_np); a[o++] = 1;                 // connectivity_method 1: indices stored directly
+  add_piece(J, a + b0, o - b0, total);
+  add_piece(J, J.sq_idx, J.sq_idx_bytes, total);
+  b0 = o;
+  a[o++] = 1;
+  o += g_put_varint(a + o, (uint32_t)(1 + J.nad));
+  a[o++] = 0; a[o++] = 9; a[o++] = 3; a[o++] = 0; a[o++] = 0;
+  { int id = 1;
+    if (J.has_uv) { a[o++] = 3; a[o++] = 9; a[o++] = 2; a[o++] = 0; a[o++] = (uint8_t)id++; }
+    if (J.has_nrm) { a[o++] = 1; a[o++] = 9; a[o++] = 3; a[o++] = 0; a[o++] = (uint8_t)id++; } }
+  a[o++] = 2; if (J.has_uv) a[o++] = 2; if (J.has_nrm) a[o++] = 3;
+  a[o++] = 0; a[o++] = 1; a[o++] = 1;                                                                // position: DIFFERENCE, wrap, compressed
+  add_piece(J, a + b0, o - b0, total);
+  add_rans(J, 6, total);
+  b0 = o; put_i32(a, o, J.wrap_lo[0]); put_i32(a, o, J.wrap_hi[0]);
+  if (J.has_uv) {
+    a[o++] = 0; a[o++] = 1; a[o++] = 1;
+    add_piece(J, a + b0, o - b0, total);
+    add_rans(J, 7, total);
+    b0 = o; put_i32(a, o, J.wrap_lo[1]); put_i32(a, o, J.wrap_hi[1]);
+  }
+  if (J.has_nrm) {
+    const GOct ot = g_oct(J.qn);
+    a[o++] = 0; a[o++] = 3; a[o++] = 1;
+    add_piece(J, a + b0, o - b0, total);
+    add_rans(J, 8, total);
+    b0 = o; put_i32(a, o, ot.MAXQ); put_i32(a, o, ot.CEN);
+  }
+  for (int k = 0; k < 3; k++) put_f32(a, o, g_float_unorder(J.pos_min_u[k]));
+  put_f32(a, o, quant_range(J.pos_min_u, J.pos_max_u, 3)); a[o++] = (uint8_t)J.qp;
+  if (J.has_uv) { put_f32(a, o, g_float_unorder(J.uv_min_u[0])); put_f32(a, o, g_float_unorder(J.uv_min_u[1])); put_f32(a, o, quant_range(J.uv_min_u, J.uv_max_u, 2)); a[o++] = (uint8_t)J.qt; }
+  if (J.has_nrm) a[o++] = (uint8_t)J.qn;
+  add_piece(J, a + b0, o - b0, total);
+  J.out_len = total;
+  if (total > J.out_cap) J.status = UVOL_E_NOSPACE;
+}
 // the frames' bitstreams are gathered back to back (16-byte aligned) so that the host fetches the whole batch with ONE copy
 __global__ void __launch_bounds__(64) k_out_offsets(GeoJob *jobs, int n) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -2699,6 +2854,12 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
     CARVE(J.fperm, uint32_t, nfi + 1, PH_FACES, PH_FACES); CARVE(J.cidx, uint32_t, nfi + 1, PH_FACES, PH_FACES);
     CARVE(J.forig, int32_t, nfi + 1, PH_FACES, PH_CT); CARVE(J.s_of_o, int32_t, nfi + 1, PH_FACES, PH_WALK);
   }
+  if (J.seq) {                                              // sequential connectivity: hash table, per-corner maps, the index section
+    J.sq_cap = pow2_at_least(2ull * nc + 2);
+    CARVE(J.sq_keys, unsigned long long, J.sq_cap, PH_DEDUP, PH_LAYOUT); CARVE(J.sq_val, uint32_t, J.sq_cap, PH_DEDUP, PH_LAYOUT);
+    CARVE(J.sq_pu, int32_t, nc + 3, PH_DEDUP, PH_LAYOUT); CARVE(J.sq_first, int32_t, nc + 3, PH_DEDUP, PH_LAYOUT); CARVE(J.sq_pid, int32_t, nc + 3, PH_DEDUP, PH_LAYOUT);
+    CARVE(J.sq_cop, int32_t, ecap + 1, PH_DEDUP, PH_LAYOUT); CARVE(J.sq_flag, uint8_t, nc + 3, PH_DEDUP, PH_LAYOUT); CARVE(J.sq_idx, uint8_t, 4 * nc + 16, PH_DEDUP, PH_LAYOUT);
+  }
   // ---- pinned, zero-initialised ----
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
@@ -2712,7 +2873,8 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   // ---- scan scratch (tiny, kept for the whole batch) ----
   CARVE(J.bsum, uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT); CARVE(J.bsum2, uint32_t, nc / UVOL_BLOCK + 8, PH_DEDUP, PH_LAYOUT);
   // ---- K2 / K3 ----
-  CARVE(J.canon[0], uint32_t, J.n_pos + 1, PH_DEDUP, PH_FACES); CARVE(J.canon[1], uint32_t, J.n_uv + 1, PH_DEDUP, PH_FACES); CARVE(J.canon[2], uint32_t, J.n_nrm + 1, PH_DEDUP, PH_FACES);
+  { const int cl = J.seq ? PH_LAYOUT : PH_FACES;          // the sequential path reads the canonical ids when it quantises the points
+    CARVE(J.canon[0], uint32_t, J.n_pos + 1, PH_DEDUP, cl); CARVE(J.canon[1], uint32_t, J.n_uv + 1, PH_DEDUP, cl); CARVE(J.canon[2], uint32_t, J.n_nrm + 1, PH_DEDUP, cl); }
   CARVE(J.keep, uint8_t, nfi + 1, PH_FACES, PH_FACES);
   CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_RENUM);
   CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_FANS0); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_FANS0);      // k_vert0 walks the buckets
@@ -2809,7 +2971,7 @@ void ws_place(std::vector<WsItem> &items, WsPlan &P) {
 // of jobs with the same dimensions (a sequence's frames usually are).
 size_t layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlan &P, std::vector<WsItem> &items) {
   ws_collect(J, full, r8, items);
-  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26), items.size() };
+  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26) | ((uint64_t)(J.seq != 0) << 27), items.size() };
   if (key != P.key) { ws_place(items, P); P.key = key; }
   if (base) for (size_t i = 0; i < items.size(); i++) *reinterpret_cast<uint8_t **>((char *)&J + items[i].slot) = base + P.offs[i];
   return P.total;
@@ -2932,6 +3094,54 @@ extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   WsPlan P; std::vector<WsItem> items;
   return layout_job(J, nullptr, false, geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)), P, items) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
 }
+// stages of a batch with sequential connectivity, between k_minmax and the layout (all parallel; see k_sq_*)
+static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, uint32_t max_nfi, uint32_t max_vals, uint32_t max_ecap, uint64_t algo_in) {
+  const unsigned N = (unsigned)n, bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));
+  const uvol_params &prm = ctx->prm;
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
+    if (!full) {
+      uint32_t slots = DD_SLOTS; { const char *e = getenv("UVOL_DD_SLOTS"); const int v = e ? atoi(e) : 0; if (v >= 4 && v <= DD_SLOTS && !(v & (v - 1))) slots = (uint32_t)v; }
+      const unsigned bt = (unsigned)((max_vals + DD_TILE - 1) / DD_TILE), nbm = (unsigned)std::min<uint64_t>(DD_MAXBINS, pow2_at_least(std::max<uint64_t>(1, max_vals / 1024)));
+      LAUNCH(k_dd_count, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dd_scan, dim3(1, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dd_scatter, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_dd_resolve, dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
+    } else {
+      LAUNCH(k_dd_clear, dim3(16, N, 3), dim3(UVOL_BLOCK), dj);
+      for (int ph = 0; ph < 2; ph++) { LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, ph); LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, ph); LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, ph); }
+    }
+  }
+  {
+    uvol_ctx::Scope sc(ctx, "geo.seq_points", (uint64_t)3 * max_nfi * 12);
+    for (int level = 0; level < 2; level++) {
+      LAUNCH(k_sq_clear, dim3(256, N), dim3(UVOL_BLOCK), dj);
+      LAUNCH(k_sq_hash, dim3(bc, N), dim3(UVOL_BLOCK), dj, level, 0);
+      LAUNCH(k_sq_hash, dim3(bc, N), dim3(UVOL_BLOCK), dj, level, 1);
+    }
+    for (int step = 0; step < 4; step++) {
+      LAUNCH(k_sq_points, dim3(bc, N), dim3(UVOL_BLOCK), dj, step);
+      if (step == 0 || step == 2) LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_SEQ);
+    }
+  }
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
+    LAUNCH(k_sq_quant, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_sq_pred, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
+  }
+  {
+    uvol_ctx::Scope sc0(ctx, "geo.k7_hist_tables", 0);
+    LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi, 16 * UVOL_BLOCK), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_rans_tables, dim3(GEO_NSTREAM, N), dim3(64), dj);
+  }
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k7_entropy_encode", 0);
+    unsigned W = 4; while (W < 64 && 5u * N > 512u * W) W *= 2;
+    LAUNCH(k_rans_recip, dim3(uvol_blocks(((size_t)2 << std::max(prm.q_position_attr, std::max(prm.q_texture_attr, prm.q_normal_attr))) + 8), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH_SM(k_entropy_simt, dim3((N + W - 1) / W, GEO_NSTREAM), dim3(64), (size_t)W * SB_STRIDE * 4, dj, n, (int)W);
+  }
+  return UVOL_OK;
+}
 static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                                  uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full);
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
@@ -2954,6 +3164,9 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   // 0..10): every legal level is encoded with the cl-7 tool set (edgebreaker + valence contexts, parallelogram / tex-coord /
   // geometric-normal prediction, RAW rANS), which any Draco decoder reads; the shims say so on stderr
   if (prm.draco_compression_level < 0 || prm.draco_compression_level > 10) { ctx->set_error("DRACO_COMPRESSION_LEVEL %d outside 0..10", prm.draco_compression_level); return UVOL_E_INVALID; }
+  // DRACO_COMPRESSION_LEVEL 0 selects sequential connectivity in stock draco_encoder (speed 10); every other level is written with the
+  // level-7 tool set (valence edgebreaker)
+  const bool seq = prm.draco_compression_level == 0;
   G->hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
@@ -2967,7 +3180,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
-    J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = geo_relabel_mode();
+    J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = seq ? 0 : geo_relabel_mode(); J.seq = seq ? 1 : 0;
     J.has_uv = (m.uv && m.idx_uv && m.n_uv) ? 1 : 0; J.has_nrm = (m.nrm && m.idx_nrm && m.n_nrm) ? 1 : 0;
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
@@ -3025,9 +3238,11 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
                  be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
-  const bool relabel = geo_relabel_on();
+  const bool relabel = geo_relabel_on() && !seq;
   // bounding boxes first: the relabelling's Morton keys are taken over them (k_quantize uses them much later)
   LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
+  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; }
+  else {
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
     if (!full) {
@@ -3171,9 +3386,10 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
       LAUNCH_SM(k_entropy_simt, dim3((N + W - 1) / W, GEO_NSTREAM + GEO_NRABS), dim3(64), (size_t)W * SB_STRIDE * 4, dj, n, (int)W);
     }
   }
+  }   // !seq
   {
     uvol_ctx::Scope sc(ctx, "geo.k8_layout_gather", 0);
-    LAUNCH(k_layout, dim3(N), dim3(64), dj);
+    if (seq) LAUNCH(k_sq_layout, dim3(N), dim3(64), dj); else LAUNCH(k_layout, dim3(N), dim3(64), dj);
     LAUNCH(k_out_offsets, dim3(1), dim3(64), dj, n);
     LAUNCH(k_gather, dim3(64, GEO_MAXPIECES, N), dim3(UVOL_BLOCK), dj);
   }

@@ -19,7 +19,8 @@ int main(int argc, char **argv) {
   if (in.empty()) { std::fprintf(stderr, "Usage: draco_encoder -i <input.obj> -o <output.drc> [-qp -qt -qn -qg -cl]\n"); return 1; }
   if (out.empty()) out = in + ".drc";
   if (prm.draco_compression_level < 0 || prm.draco_compression_level > 10) { std::fprintf(stderr, "Error: The compression level must be in [0, 10].\n"); return 1; }
-  if (prm.draco_compression_level != 7) std::fprintf(stderr, "draco_encoder (uvol shim): -cl %d is encoded with the cl 7 tool set (same bitstream syntax, any Draco decoder reads it)\n", prm.draco_compression_level);
+  if (prm.draco_compression_level == 0) std::fprintf(stderr, "draco_encoder (uvol shim): -cl 0 = sequential connectivity with the difference predictor (what stock draco_encoder selects at this level)\n");
+  else if (prm.draco_compression_level != 7) std::fprintf(stderr, "draco_encoder (uvol shim): -cl %d is encoded with the cl 7 tool set (same bitstream syntax, any Draco decoder reads it)\n", prm.draco_compression_level);
   uvolh::ObjMesh m; std::string err;
   if (!uvolh::read_obj(in, m, err)) { std::fprintf(stderr, "Failed loading the input mesh: %s\n", err.c_str()); return 1; }
   uvol_ctx *ctx = nullptr;

@@ -79,7 +79,8 @@ int main(int argc, char **argv) {
   Config cfg; std::string err;
   if (!load_config(std::string(raw.begin(), raw.end()), cfg, err)) { std::printf("❌ %s\n", err.c_str()); return 1; }
   if (cfg.compression_level < 0 || cfg.compression_level > 10) { std::printf("❌ DRACO_COMPRESSION_LEVEL must be in [0, 10]\n"); return 1; }
-  if (cfg.compression_level != 7) std::printf("💡 DRACO_COMPRESSION_LEVEL %d: encoded with the compression-level-7 tool set (same bitstream syntax)\n", cfg.compression_level);
+  if (cfg.compression_level == 0) std::printf("💡 DRACO_COMPRESSION_LEVEL 0: sequential connectivity with the difference predictor (what stock draco_encoder selects at this level)\n");
+  else if (cfg.compression_level != 7) std::printf("💡 DRACO_COMPRESSION_LEVEL %d: encoded with the compression-level-7 tool set (same bitstream syntax)\n", cfg.compression_level);
   char cwd[4096]; if (!getcwd(cwd, sizeof cwd)) return 1;
   cfg.output_directory = join(cwd, cfg.output_directory);          // scripts/Encoder.py:201
   if (!make_dirs(cfg.output_directory)) { std::printf("❌ cannot create %s\n", cfg.output_directory.c_str()); return 1; }
