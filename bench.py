@@ -328,6 +328,7 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
     drc = [bytes(x) for x in out["drc"][:480]]; ktx = list(out["ktx2"][:192])
+    drc = (drc * 4)[:1920]                                      # one call of 1920 frames (~90 MB of decode workspace each)
     for c in geos + texs:
         c.close()
     del geos[:]; del texs[:]

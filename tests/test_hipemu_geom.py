@@ -236,6 +236,10 @@ def test_hipemu_compact_workspace_overflow_is_retried(oracle, hipemu_lib):
     res = cd.encode_mesh_batch([t, dict(pos=pos, idx_pos=idx), t])
     assert res[1] == oracle.drc_encode(pos, idx, None, None, None, None)
     assert res[0] == res[2] == oracle.drc_encode(t["pos"], t["idx_pos"], t["uv"], t["idx_uv"], t["nrm"], t["idx_nrm"])
+    # the DECODER's compact workspace (entries <= 1.5 x faces) overflows on the same stream - three vertices per face - and the frame is
+    # decoded again with worst-case sizes; its neighbours in the batch are decoded once
+    for data, got in zip(res, cd.decode_mesh_batch(res)):
+        _check_decoded(oracle, data, got)
     m = synth.sphere_mesh(400, 251)
     assert cd.mesh_workspace(**m) < 80e6          # 100,002 vertices / 200,000 faces: was 220 MB before the arrays shared addresses
     cd.close()

@@ -16,12 +16,14 @@
 //   k_gdec_finish   parallel           dequantisation (fp32, octahedral) and per-corner entry indices
 #include "uvol_common.hpp"
 #include "geom_device.hpp"
+#include "uvol_ws.hpp"
 
 #define GD_NRS 10          // rANS streams: 0..5 valence contexts, 6 + d = attribute decoder d (d < 4)
 #define GD_MAXDEC 4
 #define GD_MAXAD 4
 #define GD_MAX_NS (1u << 18)   // largest symbol alphabet of an attribute stream (16-bit quantisation residuals fit)
 #define GD_CTX_NS 16
+#define GD_E_WS_OVERFLOW (-50)      // the compact workspace cannot hold this frame (more entries per face than usual): retried with worst-case sizes
 
 struct GDRans { uint32_t present, scheme, bl, prec_bits, ns, max_ns, max_prec_bits, tab_off, pay_off, pay_len, nvals; uint32_t *probs, *cum, *lut, *out; };
 struct GDRabs { uint32_t present, p0, pay_off, pay_len; };
@@ -37,6 +39,8 @@ struct GeoDecJob {
   int32_t method, traversal;     // encoder_method: 1 edgebreaker (traversal 2 valence / 0 standard), 0 sequential (traversal = connectivity method: 0 compressed / 1 raw)
   uint32_t symbits_off, symbits_n;   // standard traversal: the symbols as an LSB-first bit sequence (byte offset, bits)
   uint32_t seq_idx_off, seq_idx_w;   // sequential, raw indices: byte offset; bytes per index (1, 2, 4) or 0 = varints
+  uint32_t ecap;                 // capacity of the per-entry / per-table-vertex arrays (GD_E_WS_OVERFLOW past it: the frame is decoded again with worst-case sizes)
+  uint8_t *ws_base; uint64_t ws_zero;   // zero-initialised head of this frame's workspace (k_gdec_clear)
   int32_t nev, nf, nad, nsym, nsplit, nts, ndec, nv, n_interior_start;
   uint32_t ts_off, ts_bits_off;  // topology split events: varint pairs, then packed source-edge bits
   GDRabs rb_start, rb_seam[GD_MAXAD];
@@ -83,6 +87,7 @@ __device__ inline void gd_index_sequential(GeoDecJob &J, GRd &r) {
   const uint32_t n = r.n;
   const int nf = (int)gr_varint(r), np = (int)gr_varint(r), cm = (int)gr_u8(r);
   if (r.err || nf <= 0 || nf != J.nf || np <= 0 || np != J.nev || (cm != 0 && cm != 1)) { J.status = -6; return; }
+  if ((uint32_t)np > J.ecap) { J.status = GD_E_WS_OVERFLOW; return; }
   J.traversal = cm; J.nad = 0; J.nsym = 0; J.nsplit = 0; J.nts = 0; J.nv = np;
   for (int i = 0; i < GD_NRS; i++) { J.rs[i].present = 0; J.rs[i].nvals = 0; }
   if (cm == 1) {
@@ -142,6 +147,7 @@ __global__ void __launch_bounds__(64) k_gdec_index(GeoDecJob *jobs) {
   // count above nf (one split needs one S symbol, one symbol per face) would let k_gdec_conn write past it
   if (r.err || nf <= 0 || nf != J.nf || nad < 0 || nad > GD_MAXAD || nsym < 0 || nsym > nf || nts < 0 || nts > nf || nsplit < 0 || nsplit > nf || nev < 0 || nev != J.nev) { J.status = -6; return; }
   J.nad = nad; J.nsym = nsym; J.nsplit = nsplit; J.nts = nts;
+  if ((uint32_t)nev + (uint32_t)nsplit + 3u > J.ecap) { J.status = GD_E_WS_OVERFLOW; return; }
   { int last = 0; for (int i = 0; i < nts; i++) { const int d = (int)gr_varint(r), src = d + last, d2 = (int)gr_varint(r); J.sp_src[i] = src; J.sp_spl[i] = src - d2; last = src; }
     if (r.o + (uint32_t)(nts + 7) / 8 > n) r.err = 1;
     else { for (int i = 0; i < nts; i++) J.sp_edge[i] = (b[r.o + (i >> 3)] >> (i & 7)) & 1; if (nts > 0) r.o += (uint32_t)(nts + 7) / 8; } }
@@ -263,11 +269,13 @@ __device__ __forceinline__ int gd_rabs_bit(GDBit &R) {
 }
 
 // ---- K3: connectivity, one lane per frame ----
+// (STD = the standard traversal's bit-coded symbols; a template so that the valence loop carries neither the test nor the bit reader's registers)
+template <bool STD>
 __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   GeoDecJob &J = jobs[blockIdx.x];
-  if (threadIdx.x != 0 || J.status != 0 || J.method == 0) return;
+  if (threadIdx.x != 0 || J.status != 0 || J.method == 0 || (J.traversal == 0) != STD) return;
   const int nf = J.nf, nsym = J.nsym, nts = J.nts, maxv = J.nev + J.nsplit + 3;
-  const bool std_trav = J.traversal == 0; const uint8_t *sbits = J.file + J.symbits_off; uint32_t sbit = 0; const uint32_t sbit_n = J.symbits_n;
+  const uint8_t *sbits = J.file + J.symbits_off; uint32_t sbit = 0; const uint32_t sbit_n = J.symbits_n;
   UVOL_G(int32_t) opp = UVOL_TO_G(int32_t, J.opp); UVOL_G(int32_t) c2v = UVOL_TO_G(int32_t, J.c2v); UVOL_G(int32_t) lm = UVOL_TO_G(int32_t, J.lm);
   UVOL_G(int32_t) val = UVOL_TO_G(int32_t, J.val); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) tsac = UVOL_TO_G(int32_t, J.tsac);
   UVOL_G(const uint32_t) ctxs[6]; for (int i = 0; i < 6; i++) ctxs[i] = UVOL_TO_G(const uint32_t, J.rs[i].out);
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
 #define GD_BADC(c) ((unsigned)(c) >= (unsigned)(3 * nf))
   for (int sid = 0; sid < nsym && !rc; sid++) {
     const int face = nfaces++; int check = 0, sym;
-    if (std_trav) {                                     // 1 bit: C; else two more bits: S 1, L 3, R 5, E 7
+    if (STD) {                                          // 1 bit: C; else two more bits: S 1, L 3, R 5, E 7
       if (sbit + 1 > sbit_n) { rc = -10; break; }
       sym = (sbits[sbit >> 3] >> (sbit & 7)) & 1; sbit++;
       if (sym) { if (sbit + 2 > sbit_n) { rc = -10; break; } for (int k = 0; k < 2; k++, sbit++) sym |= ((sbits[sbit >> 3] >> (sbit & 7)) & 1) << (1 + k); }
@@ -478,7 +486,7 @@ __global__ void __launch_bounds__(64) k_gdec_attscan(GeoDecJob *jobs) {
     if (v < J.nv) cntp[v] = run + x - mine;
     run += __shfl(x, 63);
   }
-  if (lane == 0) J.t_nv[i] = run;
+  if (lane == 0) { J.t_nv[i] = run; if ((uint32_t)run > J.ecap) J.status = GD_E_WS_OVERFLOW; }
 }
 
 // ---- K6: on-boundary flags per table + the scalars the shared traversal kernels read from their GeoJob ----
@@ -536,7 +544,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_pgram(GeoDecJob *jobs, GeoJ
   if (!(A.pred_method == 1 || A.pred_method == 0)) return;
   const int t = A.table, p = (int)(blockIdx.x * UVOL_BLOCK + threadIdx.x);
   if (p >= (int)G.ne[t]) return;
-  int32_t *nb = J.nbr + (size_t)d * ((size_t)9 * J.nf + 64) + 3 * (size_t)p;
+  int32_t *nb = J.nbr + (size_t)d * ((size_t)3 * J.ecap + 64) + 3 * (size_t)p;
   nb[0] = nb[1] = nb[2] = -1;
   if (p == 0 || A.pred_method != 1) return;
   const int32_t *v2d = G.v2d[t], *xc2v = t == 0 ? J.c2v : J.t_c2v[t - 1];
@@ -594,7 +602,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_normals(GeoDecJob *jobs, Ge
   GTab X; X.opp = J.opp; X.seam = t == 0 ? nullptr : J.edge_seam[t - 1];
   int q = 0; while ((1 << q) - 1 < A.maxq) q++;
   const GOct ot = g_oct(q);
-  const uint32_t *syms = J.rs[6 + d].out; const uint8_t *flips = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
+  const uint32_t *syms = J.rs[6 + d].out; const uint8_t *flips = J.aux_bits + (size_t)d * ((size_t)J.ecap + 64);
   const int c0 = G.order[t][dd];
   const int32_t *cenp = P + 3 * b_v2d[c2v[c0]];
   long long N[3] = { 0, 0, 0 };
@@ -670,7 +678,7 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
   }
   else if (A.pred_method == 1 || A.pred_method == 0) {
     const int32_t lo = A.lo, hi = A.hi;
-    UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)9 * J.nf + 64));
+    UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)3 * J.ecap + 64));
     // component count as a template parameter: the per-component arrays must stay in registers (a run-time bound sends
     // them to scratch memory)
     if (nc == 3) gd_pgram_loop<3>(ne, nbr, syms, out, lo, hi);
@@ -679,7 +687,8 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
     else gd_pgram_loop<4>(ne, nbr, syms, out, lo, hi);
   } else if (A.pred_method == 5) {
     if (pdec < 0) { J.status = -26; return; }
-    const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
+    const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)J.ecap + 64);
+    if ((uint32_t)no > J.ecap) { J.status = -26; return; }                // more orientation bits than entries: corrupt
     { GDBit Rb; if (gd_rabs_open(Rb, J, A.aux)) { J.status = -26; return; } int last = 1; for (int k = 0; k < no; k++) { if (!gd_rabs_bit(Rb)) last = !last; ori[k] = (uint8_t)last; } }
     const int32_t lo = A.lo, hi = A.hi; int nori = no;
     const int dz = UVOL_LANE_ZERO();
@@ -748,7 +757,7 @@ __global__ void __launch_bounds__(64) k_gdec_flips(GeoDecJob *jobs, GeoJob *gj) 
   const GOct ot = g_oct(q);
   if (ot.MAXQ != A.maxq || ot.CEN != A.cen) { J.status = -30; return; }
   GDBit Fb; if (gd_rabs_open(Fb, J, A.aux)) { J.status = -29; return; }
-  uint8_t *flips = J.aux_bits + (size_t)d * ((size_t)3 * J.nf + 64);
+  uint8_t *flips = J.aux_bits + (size_t)d * ((size_t)J.ecap + 64);
   const int ne = (int)G.ne[A.table];
   for (int k = 0; k < ne; k++) flips[k] = (uint8_t)gd_rabs_bit(Fb);
 }
@@ -795,7 +804,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_finish(GeoDecJob *jobs, Geo
 // ================================================================================================
 // host side
 // ================================================================================================
-struct GeoDecState { uvol_devbuf files, slab, jobs, gjobs, outs; std::vector<GeoDecJob> hjobs; std::vector<GeoJob> hg; };
+struct GDPlan { std::vector<uint64_t> key; std::vector<size_t> offs; size_t total = 0, zero = 0; };      // workspace placement of the last frame dimensions seen (gdec_carve)
+struct GeoDecState { uvol_devbuf files, slab, jobs, gjobs, outs; std::vector<GeoDecJob> hjobs; std::vector<GeoJob> hg; GDPlan plan; };
 int geodec_create(uvol_ctx *ctx) { ctx->geodec = new GeoDecState(); return UVOL_OK; }
 void geodec_destroy(uvol_ctx *ctx) {
   GeoDecState *t = ctx->geodec; if (!t) return;
@@ -830,35 +840,60 @@ bool geo_records8(uint32_t max_nfi);
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } } \
   } while (0)
 
-// workspace of one frame (base == nullptr: size only); also wires the GeoJob view the shared traversal kernels read:
-// table 1 = base corner table, 2 / 3 = attribute tables 0 / 1
-static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base, bool r8) {
-  size_t o = 0;
-  auto take = [&](size_t bytes) -> uint8_t * { uint8_t *p = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return p; };
-  const size_t nf = (size_t)J.nf, nc = 3 * nf, maxv = (size_t)J.nev + nf + 8;          // nsplit <= nf
-  J.sp_src = (int32_t *)take(4 * (nf + 1)); J.sp_spl = (int32_t *)take(4 * (nf + 1)); J.sp_edge = take(nf + 8);
-  J.opp = (int32_t *)take(4 * nc); J.c2v = (int32_t *)take(4 * nc);
-  J.lm = (int32_t *)take(4 * maxv); J.val = (int32_t *)take(4 * maxv);
-  J.stack = (int32_t *)take(4 * (nf + 8)); J.tsac = (int32_t *)take(4 * (nf + 2));
-  for (int k = 0; k < GD_MAXAD; k++) { J.edge_seam[k] = take(nc); J.t_c2v[k] = (int32_t *)take(4 * nc); J.t_lm[k] = (int32_t *)take(4 * nc); }
-  J.vseam = take(GD_MAXAD * (maxv + 64)); J.t_cnt = (int32_t *)take(4 * GD_MAXAD * (maxv + 64)); J.seam_bits = take(GD_MAXAD * (nc + 64));
-  for (int k = 0; k < 1 + GD_MAXAD; k++) J.vopen[k] = take(nc + 64);
-  J.aux_bits = take(GD_MAXDEC * (nc + 64)); J.nbr = (int32_t *)take(4 * GD_MAXDEC * (3 * nc + 64)); J.uvgeo = take(32 * (nc + 8));
-  for (int k = 0; k < 6; k++) { GDRans &S = J.rs[k]; S.max_ns = GD_CTX_NS; S.max_prec_bits = 12; S.probs = (uint32_t *)take(4 * GD_CTX_NS); S.cum = (uint32_t *)take(4 * GD_CTX_NS); S.lut = (uint32_t *)take(4 * (1u << 12)); S.out = (uint32_t *)take(4 * (nf + 1)); }
-  for (int k = 0; k < GD_MAXDEC; k++) {
-    GDRans &S = J.rs[6 + k]; S.max_ns = GD_MAX_NS; S.max_prec_bits = 20;
-    S.probs = (uint32_t *)take(4 * (size_t)GD_MAX_NS); S.cum = (uint32_t *)take(4 * (size_t)GD_MAX_NS); S.lut = (uint32_t *)take(4 * (size_t)(1u << 20));
-    S.out = (uint32_t *)take(4 * (4 * nc + 4)); J.att[k].vals = (int32_t *)take(4 * (4 * nc + 4));
-  }
-  G.status = 0; G.nf = (uint32_t)nf; G.nc = (uint32_t)nc; G.nad = 2; G.nverts = 0xffffffffu; G.ecap = (uint32_t)(nc + 3);
-  G.nopp = J.opp; G.bvert = J.c2v; G.avert[0] = J.t_c2v[0]; G.avert[1] = J.t_c2v[1]; G.seam[0] = J.edge_seam[0]; G.seam[1] = J.edge_seam[1];
-  G.vopen_d[1] = J.vopen[0]; G.vopen_d[2] = J.vopen[1]; G.vopen_d[3] = J.vopen[2];
-  for (int k = 1; k < 4; k++) G.rec[k] = (int32_t *)take((r8 ? 32 : 64) * (nf + 1));     // 8- or 16-byte corner records, decided per batch (geo_records8)
-  for (int k = 0; k < 3; k++) { G.order[k] = (int32_t *)take(4 * (nc + 3)); G.v2d[k] = (int32_t *)take(4 * (nc + 3)); G.t_stack[k] = (int32_t *)take(4 * (nf + 2)); G.t_vvis[k] = take(nc + 64); }
-  return o;
+// zero the head of every frame's workspace (the arrays that must start out zero: valences, seam flags, visited bitmaps)
+__global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_clear(GeoDecJob *jobs) {
+  GeoDecJob &J = jobs[blockIdx.y];
+  uint4 *p = reinterpret_cast<uint4 *>(J.ws_base);
+  const size_t n16 = (size_t)(J.ws_zero / 16);
+  for (size_t i = (size_t)blockIdx.x * UVOL_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * UVOL_BLOCK) p[i] = make_uint4(0, 0, 0, 0);
 }
 
+// Workspace of one frame (base == nullptr: size only); also wires the GeoJob view the shared traversal kernels read (table 1 =
+// base corner table, 2 / 3 = attribute tables 0 / 1).  Every array carries the first and last stage that touches it and arrays
+// with disjoint lifetimes share addresses (uvol_ws.hpp); the arrays that must start out zero form the pinned head.  Per-entry
+// arrays (traversal order, predictor scratch, symbols, values) are sized for `ecap` entries - faces + faces / 2 in the compact
+// layout, a frame that needs more (every corner its own entry) fails with GD_E_WS_OVERFLOW on the device and is decoded again
+// with the worst case (3 x faces).  265 -> ~90 MB per 200 k-face frame.
+enum { DS_INDEX = 0, DS_CTX, DS_CONN, DS_TABLES, DS_TRAV, DS_SYM, DS_PRED, DS_FIN, DS_COUNT };
+static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base, bool r8, bool full, GDPlan &P) {
+  const size_t nf = (size_t)J.nf, nc = 3 * nf, maxv = (size_t)J.nev + nf + 8;          // nsplit <= nf
+  const size_t E = full ? nc + 3 : std::min(nc + 3, nf + nf / 2 + 4096);
+  J.ecap = (uint32_t)E;
+  std::vector<UvolWsItem> items; std::vector<void **> slots;
+#define DCARVE(field, bytes, first, last) do { items.push_back(UvolWsItem{ (size_t)(bytes), (first), (last), 0 }); slots.push_back((void **)&(field)); } while (0)
+  DCARVE(J.sp_src, 4 * (nf + 1), DS_INDEX, DS_CONN); DCARVE(J.sp_spl, 4 * (nf + 1), DS_INDEX, DS_CONN); DCARVE(J.sp_edge, nf + 8, DS_INDEX, DS_CONN);
+  DCARVE(J.opp, 4 * nc, DS_INDEX, DS_FIN); DCARVE(J.c2v, 4 * nc, DS_INDEX, DS_FIN);
+  DCARVE(J.lm, 4 * maxv, DS_CONN, DS_TABLES); DCARVE(J.val, 4 * maxv, UVOL_WS_PINNED, UVOL_WS_PINNED);
+  DCARVE(J.stack, 4 * (nf + 8), DS_CONN, DS_CONN); DCARVE(J.tsac, 4 * (nf + 2), DS_INDEX, DS_CONN);
+  for (int k = 0; k < GD_MAXAD; k++) { DCARVE(J.edge_seam[k], nc, UVOL_WS_PINNED, UVOL_WS_PINNED); DCARVE(J.t_c2v[k], 4 * nc, DS_INDEX, DS_FIN); DCARVE(J.t_lm[k], 4 * E, DS_TABLES, DS_TABLES); }
+  DCARVE(J.vseam, GD_MAXAD * (maxv + 64), UVOL_WS_PINNED, UVOL_WS_PINNED); DCARVE(J.t_cnt, 4 * GD_MAXAD * (maxv + 64), DS_TABLES, DS_TABLES); DCARVE(J.seam_bits, GD_MAXAD * (nc + 64), DS_TABLES, DS_TABLES);
+  for (int k = 0; k < 1 + GD_MAXAD; k++) DCARVE(J.vopen[k], std::max(E, maxv) + 64, DS_TABLES, DS_TRAV);
+  DCARVE(J.aux_bits, GD_MAXDEC * (E + 64), DS_PRED, DS_PRED); DCARVE(J.nbr, 4 * GD_MAXDEC * (3 * E + 64), DS_PRED, DS_PRED); DCARVE(J.uvgeo, 32 * (E + 8), DS_PRED, DS_PRED);
+  for (int k = 0; k < 6; k++) { GDRans &S = J.rs[k]; S.max_ns = GD_CTX_NS; S.max_prec_bits = 12; DCARVE(S.probs, 4 * GD_CTX_NS, DS_CTX, DS_CONN); DCARVE(S.cum, 4 * GD_CTX_NS, DS_CTX, DS_CONN); DCARVE(S.lut, 4 * (1u << 12), DS_CTX, DS_CONN); DCARVE(S.out, 4 * (nf + 1), DS_CTX, DS_CONN); }
+  for (int k = 0; k < GD_MAXDEC; k++) {
+    GDRans &S = J.rs[6 + k]; S.max_ns = GD_MAX_NS; S.max_prec_bits = 20;
+    DCARVE(S.probs, 4 * (size_t)GD_MAX_NS, DS_SYM, DS_SYM); DCARVE(S.cum, 4 * (size_t)GD_MAX_NS, DS_SYM, DS_SYM); DCARVE(S.lut, 4 * (size_t)(1u << 20), DS_SYM, DS_SYM);
+    // (the last slot also holds the index differences of a frame with compressed sequential connectivity: one per corner)
+    DCARVE(S.out, 4 * (std::max(4 * E, k == GD_MAXDEC - 1 ? nc : (size_t)0) + 4), DS_SYM, DS_PRED); DCARVE(J.att[k].vals, 4 * (4 * E + 4), DS_PRED, DS_FIN);
+  }
+  for (int k = 1; k < 4; k++) DCARVE(G.rec[k], (r8 ? 32 : 64) * (nf + 1), DS_TRAV, DS_TRAV);     // 8- or 16-byte corner records, decided per batch (geo_records8)
+  for (int k = 0; k < 3; k++) { DCARVE(G.order[k], 4 * (E + 3), DS_TRAV, DS_FIN); DCARVE(G.v2d[k], 4 * (std::max(E, maxv) + 3), DS_TRAV, DS_FIN); DCARVE(G.t_stack[k], 4 * (nf + 2), DS_TRAV, DS_TRAV); DCARVE(G.t_vvis[k], std::max(E, maxv) / 8 + 64, UVOL_WS_PINNED, UVOL_WS_PINNED); }
+#undef DCARVE
+  const std::vector<uint64_t> key = { (uint64_t)nf, (uint64_t)J.nev, (uint64_t)r8 | ((uint64_t)full << 1), (uint64_t)items.size() };
+  if (key != P.key) { P.total = uvol_ws_place(items, &P.zero, DS_COUNT, "geometry decode"); P.offs.resize(items.size()); for (size_t i = 0; i < items.size(); i++) P.offs[i] = items[i].off; P.key = key; }
+  for (size_t i = 0; i < slots.size(); i++) *slots[i] = base ? (void *)(base + P.offs[i]) : nullptr;
+  J.ws_base = base; J.ws_zero = P.zero;
+  G.status = 0; G.nf = (uint32_t)nf; G.nc = (uint32_t)nc; G.nad = 2; G.nverts = 0xffffffffu; G.ecap = (uint32_t)E;
+  G.nopp = J.opp; G.bvert = J.c2v; G.avert[0] = J.t_c2v[0]; G.avert[1] = J.t_c2v[1]; G.seam[0] = J.edge_seam[0]; G.seam[1] = J.edge_seam[1];
+  G.vopen_d[1] = J.vopen[0]; G.vopen_d[2] = J.vopen[1]; G.vopen_d[3] = J.vopen[2];
+  return P.total;
+}
+
+static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool full);
 int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
+  return geo_decode_batch_impl(ctx, files, lens, n, out, status, false);
+}
+static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool full) {
   GeoDecState *T = ctx->geodec;
   if (n <= 0) return UVOL_OK;
   T->hjobs.assign((size_t)n, GeoDecJob{}); T->hg.assign((size_t)n, GeoJob{});
@@ -874,7 +909,7 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
     GeoDecJob &J = T->hjobs[i]; J.nf = (int32_t)nf; J.nev = (int32_t)nev; J.file_len = (uint32_t)lens[i];
     max_nf = std::max(max_nf, nf); max_nev = std::max(max_nev, nev);
     foff[i] = ftot; ftot += a256(lens[i] + 16);
-    GeoJob gtmp{}; const size_t w = gdec_carve(J, gtmp, nullptr, r8);
+    GeoJob gtmp{}; const size_t w = gdec_carve(J, gtmp, nullptr, r8, full, T->plan);
     woff[i] = wtot; wtot += a256(w);
     { const size_t nc = 3 * (size_t)nf; ooff[i] = otot; otot += 3 * (a256(4 * 3 * nc) + a256(4 * nc)); }
   }
@@ -884,13 +919,12 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   if ((rc = uvol_ensure(ctx, T->jobs, sizeof(GeoDecJob) * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, T->gjobs, sizeof(GeoJob) * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, T->outs, otot))) return rc;
-  UVOL_HIP_CHECK(ctx, hipMemsetAsync(T->slab.p, 0, wtot, ctx->stream));
   for (int i = 0; i < n; i++) {
     GeoDecJob &J = T->hjobs[i]; GeoJob &G = T->hg[i];
     uint8_t *fd = (uint8_t *)T->files.p + foff[i];
     UVOL_HIP_CHECK(ctx, hipMemcpyAsync(fd, files[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
     J.file = fd; J.status = 0;
-    (void)gdec_carve(J, G, (uint8_t *)T->slab.p + woff[i], r8);
+    (void)gdec_carve(J, G, (uint8_t *)T->slab.p + woff[i], r8, full, T->plan);
     const size_t nc = 3 * (size_t)J.nf;
     uint8_t *ob = (uint8_t *)T->outs.p + ooff[i]; size_t oo = 0;
     for (int k = 0; k < 3; k++) { J.o_val[k] = (float *)(ob + oo); oo += a256(4 * 3 * nc); J.o_idx[k] = (uint32_t *)(ob + oo); oo += a256(4 * nc); }
@@ -899,9 +933,10 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->gjobs.p, T->hg.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   GeoDecJob *dj = (GeoDecJob *)T->jobs.p; GeoJob *gj = (GeoJob *)T->gjobs.p;
   const unsigned N = (unsigned)n, bc = uvol_blocks((size_t)3 * max_nf);
+  GLAUNCH(k_gdec_clear, dim3(64, N), dim3(UVOL_BLOCK), 0, dj);
   { uvol_ctx::Scope sc(ctx, "geodec.k1_index", 0); GLAUNCH(k_gdec_init, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj); GLAUNCH(k_gdec_index, dim3(N), dim3(64), 0, dj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(6, N), dim3(64), 0, dj, 0, 6); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 0); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn<false>, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_conn<true>, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 0); }
   { uvol_ctx::Scope sc(ctx, "geodec.k4_seams_tables", 0);
     GLAUNCH(k_gdec_seams, dim3(N), dim3(64), 0, dj);
     GLAUNCH(k_gdec_vseam, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj);
@@ -927,8 +962,10 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(GeoDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   int worst = UVOL_OK;
+  std::vector<int> retry;
   for (int i = 0; i < n; i++) {
     const GeoDecJob &J = T->hjobs[i]; uvol_decoded_mesh &M = out[i];
+    if (!full && J.status == GD_E_WS_OVERFLOW) { retry.push_back(i); if (status) status[i] = UVOL_OK; continue; }      // decoded again below, alone, with worst-case sizes
     const int st = J.status == 0 ? UVOL_OK : UVOL_E_ENCODE;
     if (status) status[i] = st;
     if (st != UVOL_OK) { ctx->set_error("frame %d: corrupt or unsupported .drc (device status %d)", i, J.status); worst = st; continue; }
@@ -944,5 +981,12 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
   }
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
+  for (int i : retry) {                                   // frames the compact workspace could not hold (more entries per face than usual)
+    int st1 = UVOL_OK;
+    const int rc1 = geo_decode_batch_impl(ctx, files + i, lens + i, 1, out + i, &st1, true);
+    if (rc1 != UVOL_OK) return rc1;
+    if (status) status[i] = st1;
+    if (st1 != UVOL_OK) worst = st1;
+  }
   return status ? UVOL_OK : worst;
 }

@@ -14,6 +14,7 @@
 #include <thread>
 #include "uvol_common.hpp"
 #include "geom_device.hpp"
+#include "uvol_ws.hpp"
 #include <algorithm>
 
 #define JOB_OR_RETURN GeoJob &J = jobs[blockIdx.y]; if (J.status != 0) return
@@ -2939,32 +2940,11 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
 
 // first-fit placement over the lifetime intervals; pinned items first (they form the zeroed head)
 void ws_place(std::vector<WsItem> &items, WsPlan &P) {
-  auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  size_t off = 0;
-  for (auto &it : items) if (it.first == PH_PINNED) { it.off = off; off = a256(off + it.bytes); }
-  P.zero = off;
-  std::vector<size_t> order;
-  for (size_t i = 0; i < items.size(); i++) if (items[i].first != PH_PINNED) order.push_back(i);
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].bytes > items[b].bytes; });
-  std::vector<size_t> placed; std::vector<std::pair<size_t, size_t>> busy;
-  size_t total = P.zero;
-  for (size_t i : order) {
-    WsItem &it = items[i];
-    busy.clear();
-    for (size_t j : placed) if (items[j].first <= it.last && it.first <= items[j].last) busy.emplace_back(items[j].off, a256(items[j].off + items[j].bytes));
-    std::sort(busy.begin(), busy.end());
-    size_t cur = P.zero;
-    for (auto &b : busy) { if (cur + it.bytes <= b.first) break; cur = std::max(cur, b.second); }
-    it.off = cur; total = std::max(total, a256(cur + it.bytes));
-    placed.push_back(i);
-  }
-  static const bool dump = [] { const char *e = getenv("UVOL_WS_DUMP"); return e && *e == '1'; }();
-  if (dump) {
-    fprintf(stderr, "[uvol-ws] zero head %.2f MB, total %.2f MB\n", P.zero / 1e6, total / 1e6);
-    for (int ph = 0; ph <= PH_LAYOUT; ph++) { size_t live = 0; for (auto &it : items) if (it.first != PH_PINNED && it.first <= ph && ph <= it.last) live += a256(it.bytes); fprintf(stderr, "[uvol-ws]   phase %2d: %.2f MB live\n", ph, live / 1e6); }
-  }
-  P.total = total; P.offs.resize(items.size());
-  for (size_t i = 0; i < items.size(); i++) P.offs[i] = items[i].off;
+  std::vector<UvolWsItem> w(items.size());
+  for (size_t i = 0; i < items.size(); i++) w[i] = UvolWsItem{ items[i].bytes, items[i].first, items[i].last, 0 };
+  P.total = uvol_ws_place(w, &P.zero, PH_LAYOUT + 1, "geometry encode");
+  P.offs.resize(items.size());
+  for (size_t i = 0; i < items.size(); i++) { items[i].off = w[i].off; P.offs[i] = w[i].off; }
 }
 
 // Lays out one job's workspace (sizes + capacities always; pointers when base != nullptr).  The placement is cached for runs
