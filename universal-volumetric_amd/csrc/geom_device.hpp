@@ -63,7 +63,8 @@ struct GeoJob {
   // locality relabelling (k_ms_*): positions get new ids in Morton order of their quantised coordinates, faces are stored in the
   // order of their lowest new vertex id.  Ids and storage order are identities only - the bitstream is the one the input order
   // gives (component starts and non-manifold tie-breaks still follow the ORIGINAL face order through forig / s_of_o).
-  int32_t relabel;                         // 1: on for this frame
+  int32_t relabel;                         // 1: on for this frame (2 while undecided: k_coherence / k_relabel_decide)
+  uint32_t coh_share, coh_tight, coh_same; // k_coherence: faces sharing a vertex with their predecessor / with a narrow index span / equal to the same face of the previous frame
   uint32_t *ms_key[2];                     // [0] Morton key per position; [1] per input face: lowest new vertex id (~0u: dropped face)
   uint2 *ms_part; uint32_t *ms_cnt;        // {key, index} records by bin; counts[bin][tile]
   uint32_t ms_nb[2], ms_nblk[2], ms_sh[2]; // bins, tiles, bin = key >> sh

@@ -303,27 +303,36 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_ms_key_pos(GeoJob *jobs) {
 // passes (+8 % on the lattice bench) and is skipped for this frame.  relabel: 2 = decide here, 1 = forced on, 0 = off.
 __global__ void __launch_bounds__(UVOL_BLOCK) k_coherence(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
-  const bool on = J.status == 0 && J.relabel == 2;
+  const bool on = J.status == 0;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  uint32_t share = 0, tight = 0;
-  if (on && f > 0 && f < J.nf_in) {
-    const uint32_t a0 = J.ipos[3 * f], a1 = J.ipos[3 * f + 1], a2 = J.ipos[3 * f + 2], b0 = J.ipos[3 * f - 3], b1 = J.ipos[3 * f - 2], b2 = J.ipos[3 * f - 1];
-    share = (a0 == b0 || a0 == b1 || a0 == b2 || a1 == b0 || a1 == b1 || a1 == b2 || a2 == b0 || a2 == b1 || a2 == b2) ? 1u : 0u;
-    const uint32_t mx = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2), mn = a0 < a1 ? (a0 < a2 ? a0 : a2) : (a1 < a2 ? a1 : a2);
-    tight = (mx - mn) <= J.n_pos / 16u + 64u ? 1u : 0u;
+  uint32_t share = 0, tight = 0, same = 0;
+  if (on && f < J.nf_in) {
+    const uint32_t a0 = J.ipos[3 * f], a1 = J.ipos[3 * f + 1], a2 = J.ipos[3 * f + 2];
+    if (f > 0 && J.relabel == 2) {
+      const uint32_t b0 = J.ipos[3 * f - 3], b1 = J.ipos[3 * f - 2], b2 = J.ipos[3 * f - 1];
+      share = (a0 == b0 || a0 == b1 || a0 == b2 || a1 == b0 || a1 == b1 || a1 == b2 || a2 == b0 || a2 == b1 || a2 == b2) ? 1u : 0u;
+      const uint32_t mx = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2), mn = a0 < a1 ? (a0 < a2 ? a0 : a2) : (a1 < a2 ? a1 : a2);
+      tight = (mx - mn) <= J.n_pos / 16u + 64u ? 1u : 0u;
+    }
+    // the same connectivity as the previous frame of the batch (an animated mesh of fixed topology): such frames are walked in
+    // lock step, which decides how many walkers share a wave (geo_encode_batch)
+    if (blockIdx.y > 0) { const GeoJob &P = jobs[blockIdx.y - 1]; if (P.nf_in == J.nf_in && P.n_pos == J.n_pos) same = (P.ipos[3 * f] == a0 && P.ipos[3 * f + 1] == a1 && P.ipos[3 * f + 2] == a2) ? 1u : 0u; }
   }
-  const uint32_t s1 = block_sum(share), s2 = block_sum(tight);
-  if (threadIdx.x == 0 && on) { if (s1) atomicAdd(&J.ms_nb[1], s1); if (s2) atomicAdd(&J.ms_nblk[1], s2); }     // (the two fields are set for good by k_relabel_decide)
+  const uint32_t s1 = block_sum(share), s2 = block_sum(tight), s3 = block_sum(same);
+  if (threadIdx.x == 0 && on) { if (s1) atomicAdd(&J.coh_share, s1); if (s2) atomicAdd(&J.coh_tight, s2); if (s3) atomicAdd(&J.coh_same, s3); }
 }
-__global__ void __launch_bounds__(64) k_relabel_decide(GeoJob *jobs, int n) {
+// per frame: relabel or not; per batch (counts[0..1]): frames that are relabelled, frames with their predecessor's connectivity
+__global__ void __launch_bounds__(64) k_relabel_decide(GeoJob *jobs, int n, uint32_t *counts) {
   const int j = (int)(blockIdx.x * 64 + threadIdx.x);
   if (j >= n) return;
   GeoJob &J = jobs[j];
   if (J.relabel == 2) {
-    const uint64_t nf = J.nf_in, share = J.ms_nb[1], tight = J.ms_nblk[1];
+    const uint64_t nf = J.nf_in, share = J.coh_share, tight = J.coh_tight;
     J.relabel = (share * 100 >= nf * 60 && tight * 100 >= nf * 90) ? 0 : 1;
   }
   J.ms_nb[1] = ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1; J.ms_nblk[1] = (J.nf_in + MS_TILE - 1) / MS_TILE;
+  if (J.relabel) atomicAdd(&counts[0], 1u);
+  if (J.coh_same == J.nf_in) atomicAdd(&counts[1], 1u);
 }
 __device__ __forceinline__ uint32_t ms_count_of(const GeoJob &J, int which) { return which == 0 ? J.n_pos : J.nf_in; }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_ms_count(GeoJob *jobs, int which) {
@@ -1819,7 +1828,7 @@ __global__ void __launch_bounds__(64) k_traverse_simt(GeoJob *jobs, int n, int W
   if (lane >= W) return;
   const int id = (int)blockIdx.x * W + lane;
   if (id >= 3 * n) return;
-  const int t = id / n, j = id - t * n;
+  const int t = id / n, j = id - t * n;                  // (the three tables of ONE frame in neighbouring lanes was measured slower: 347 vs 307 / 202 ms)
   GeoJob &J = jobs[j];
   const int ai = t > 0 ? t - 1 : 0;
   if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
@@ -2763,6 +2772,7 @@ struct GeoState {
   int num_cu = 256;                    // CUs this context's streams may run on
   hipStream_t aux = nullptr;           // second stream: valence replay runs beside renumber/seams/DFS
   hipEvent_t ev_walk = nullptr, ev_val = nullptr;
+  uint32_t *counts = nullptr;          // device: {frames relabelled, frames with their predecessor's connectivity} of the batch (k_relabel_decide)
 };
 
 int geo_create(uvol_ctx *ctx) {
@@ -2795,6 +2805,7 @@ void geo_destroy(uvol_ctx *ctx) {
   if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
   if (g->ev_walk) (void)hipEventDestroy(g->ev_walk);
   if (g->ev_val) (void)hipEventDestroy(g->ev_val);
+  if (g->counts) (void)hipFree(g->counts);
   delete g; ctx->geo = nullptr;
 }
 
@@ -2846,7 +2857,7 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
     const uint32_t lb0 = std::min<uint32_t>(10, bits_of(J.n_pos / 512)), lb1 = std::min<uint32_t>(10, bits_of(nfi / 512));
     J.ms_sh[0] = 30 - lb0; J.ms_nb[0] = 1u << lb0; J.ms_nblk[0] = (uint32_t)((J.n_pos + MS_TILE - 1) / MS_TILE);
     { const uint32_t kb = bits_of(J.n_pos ? J.n_pos - 1 : 0); J.ms_sh[1] = kb > lb1 ? kb - lb1 : 0; }
-    J.ms_nb[1] = 0; J.ms_nblk[1] = 0;                      // k_coherence counts in them, k_relabel_decide then sets bins / tiles of the face sort
+    J.ms_nb[1] = 0; J.ms_nblk[1] = 0;                      // set by k_relabel_decide
     const uint32_t ms_nblk1 = (uint32_t)((nfi + MS_TILE - 1) / MS_TILE);
     CARVE(J.ms_key[0], uint32_t, (size_t)J.n_pos + 1, PH_DEDUP, PH_DEDUP); CARVE(J.ms_key[1], uint32_t, nfi + 1, PH_FACES, PH_FACES);
     CARVE(J.ms_part, uint2, nmax + 1, PH_DEDUP, PH_FACES);
@@ -3219,6 +3230,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
                  be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
   const bool relabel = geo_relabel_on() && !seq;
+  bool lockstep = true;                                      // walkers of this batch move in lock step (see below); decides lanes per wave of the traversers
   // bounding boxes first: the relabelling's Morton keys are taken over them (k_quantize uses them much later)
   LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
   if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; }
@@ -3243,9 +3255,25 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
       LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 1);
     }
     const unsigned mt0 = (unsigned)((max_vals + MS_TILE - 1) / MS_TILE), mt1 = (unsigned)(((size_t)max_nfi + MS_TILE - 1) / MS_TILE);
-    if (relabel) {                                           // new position ids (Morton order) and the positions in that order
+    // How the frames are stored decides two things, so the batch is looked at once (k_coherence: one pass over the index arrays) and the
+    // two counts come back to the host (the only mid-batch synchronisation; the encode kernels of a large batch take 0.2 - 0.9 s):
+    //  * frames stored coherently skip the locality relabelling - if none needs it, its ~6 M (empty) workgroups are not even launched;
+    //  * frames with the SAME connectivity as their predecessor (an animated mesh of fixed topology) are walked in lock step by the
+    //    lanes of a wave - 16 attribute traversers per wave then beat one per wave (200 vs 300 ms per 2160 frames), while walkers on
+    //    unrelated meshes diverge and miss at different times, and one per wave is the faster form (307 vs 392 ms).
+    bool any_relabel = relabel;
+    if (relabel || N >= 256) {
+      if (!G->counts) UVOL_HIP_CHECK(ctx, hipMalloc((void **)&G->counts, 64));
+      uint32_t hc[2] = { 0, 0 };
+      UVOL_HIP_CHECK(ctx, hipMemsetAsync(G->counts, 0, 64, ctx->stream));
       LAUNCH(k_coherence, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_relabel_decide, dim3((N + 63) / 64), dim3(64), dj, n);
+      LAUNCH(k_relabel_decide, dim3((N + 63) / 64), dim3(64), dj, n, G->counts);
+      UVOL_HIP_CHECK(ctx, hipMemcpyAsync(hc, G->counts, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+      UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      any_relabel = relabel && hc[0] != 0;
+      lockstep = (uint64_t)hc[1] * 10u >= (uint64_t)n * 9u;
+    }
+    if (any_relabel) {                                       // new position ids (Morton order) and the positions in that order
       LAUNCH(k_ms_key_pos, dim3(bv, N), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_ms_count, dim3(mt0, N), dim3(UVOL_BLOCK), dj, 0);
       LAUNCH(k_ms_scan, dim3(1, N), dim3(UVOL_BLOCK), dj, 0);
@@ -3254,7 +3282,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     }
     LAUNCH(k_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_KEEP);
-    if (relabel) {                                           // faces stored in the order of their lowest new vertex id
+    if (any_relabel) {                                       // faces stored in the order of their lowest new vertex id
       LAUNCH(k_face_cidx, dim3(bf, N), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_ms_count, dim3(mt1, N), dim3(UVOL_BLOCK), dj, 1);
       LAUNCH(k_ms_scan, dim3(1, N), dim3(UVOL_BLOCK), dj, 1);
@@ -3323,7 +3351,9 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
     static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
     const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
-    launch_traversals(ctx, dj, n, walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg), r8);
+    WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg);
+    if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = 1;      // unrelated meshes: one traverser per wave
+    launch_traversals(ctx, dj, n, wp_trav, r8);
     LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, r8);
   }
   {
