@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --no-cpu-baseline > $O/bench_run2.json 2>> $O/bench.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2>> $O/bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants > $O/bench_under_rocprof.json 2>> $O/bench.err
 cp $(find $O/kt -name bench_kernel_stats.csv | head -1) $O/kernel_stats.csv
 # HBM traffic of every kernel: tools/pmc_pack.sh (own processes per half)
 rm -rf $O/kt

@@ -3354,8 +3354,8 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg);
     if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = 1;      // unrelated meshes: one traverser per wave
     launch_traversals(ctx, dj, n, wp_trav, r8);
-    LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, r8);
   }
+  { uvol_ctx::Scope sc(ctx, "geo.k5b_v2d", 0); LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, r8); }      // (own scope: geo.k5_traverse is exactly the traversal kernel, as rocprof lists it)
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
     LAUNCH(k_quantize, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
