@@ -41,6 +41,25 @@ def test_hipemu_texture_quality_levels_match_oracle(oracle, hipemu_lib):
         cd.close()
 
 
+def test_hipemu_selector_statistics_in_small_windows(oracle, hipemu_lib):
+    """The selector tree build keeps its leaf statistics across rounds and counts only the items a split moves, in windows of
+    UVOL_SEL_LCAP new leaves per pass (default 256).  With 16-leaf windows every round from the fifth on needs several passes
+    (window 0 moves the items, the later ones find them by their new leaf): same bytes.  Read once per process."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import synth, uvol\nimport oracle as o\n"
+        "o.lib()\ntex = synth.texture_sequence(2, size=48, seed=4)\n"
+        "for q in (128, 255):\n"
+        "    c = uvol.Codec(lib_path=%r, etc1s_quality=q)\n"
+        "    assert c.encode_texture_segment(tex) == o.ktx2_encode(tex, quality=q), q\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_SEL_LCAP="16"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_hipemu_texture_decode_matches_oracle(oracle, hipemu_lib):
     """Decode path: the HIP ETC1S/BasisLZ decoder, through the shim, against the pinned oracle decoder —
     on the reference's own fixture (written by Basis Universal 1.16) and on this codec's output, ragged sizes included."""

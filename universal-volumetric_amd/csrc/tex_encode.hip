@@ -203,6 +203,57 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force,
 // all 768 leaves the kernel waited for LDS 3-4x longer than it ran); the host runs one pass per 256 leaves the round can have.
 // field f: 0 = W, 1..16 = S[f-1], 17..32 = Q[f-17];  word = f >> 1, half = f & 1.
 #define SEL_STATS_ITEMS 6144
+// one wave's items into the LDS table: `todo` items carry the window-relative leaf `rl` (< ncap) and the selector word `sw`
+__device__ __forceinline__ void sel_stats_accumulate(uint32_t *lds, bool todo, uint32_t rl, uint32_t sw, uint32_t lane) {
+  // while the wave's items sit in few leaves (always in the early rounds, mostly later: neighbouring blocks look
+  // alike) count with ballots - c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 - and let 33 lanes
+  // post one add each; whatever is left after 4 leaders takes the per-item path.
+  unsigned long long rem = __ballot(todo);
+  for (int rounds = 0; rounds < 4 && rem; rounds++) {
+    const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
+    const uint32_t ll = UVOL_READLANE(rl, leader);
+    const bool inm = todo && rl == ll;
+    const unsigned long long m = __ballot(inm);
+    uint32_t myv = 0;
+    for (int d = 0; d < 16; d++) {
+      const uint32_t xv = (sw >> (2 * d)) & 3u;
+      const uint32_t c1 = (uint32_t)__popcll(__ballot(inm && xv == 1)), c2 = (uint32_t)__popcll(__ballot(inm && xv == 2)), c3 = (uint32_t)__popcll(__ballot(inm && xv == 3));
+      if (lane == (uint32_t)(1 + d)) myv = c1 + 2 * c2 + 3 * c3;
+      if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
+    }
+    if (lane == 0) myv = (uint32_t)__popcll(m);
+    if (lane < 33 && myv) atomicAdd(&lds[ll * 17 + (lane >> 1)], myv << ((lane & 1) * 16));
+    rem &= ~m;
+    if (inm) todo = false;
+  }
+  if (!todo) return;
+  uint32_t *p = lds + (size_t)rl * 17;
+  uint32_t prev = 1;                                                   // field 0: W += 1
+  for (int d = 0; d < 16; d++) {                                       // fields 1..16: S
+    const uint32_t xv = (sw >> (2 * d)) & 3u;
+    if (d & 1) prev = xv; else { const uint32_t v = prev | (xv << 16); if (v) atomicAdd(&p[d >> 1], v); }
+  }
+  // fields 16 (S15) | 17 (Q0), then Q1|Q2 ... Q13|Q14, then Q15 alone
+  { const uint32_t q0 = (sw & 3u) * (sw & 3u), v = prev | (q0 << 16); if (v) atomicAdd(&p[8], v); }
+  for (int d = 1; d < 15; d += 2) {
+    const uint32_t a = (sw >> (2 * d)) & 3u, b = (sw >> (2 * d + 2)) & 3u, v = (a * a) | ((b * b) << 16);
+    if (v) atomicAdd(&p[9 + (d >> 1)], v);
+  }
+  { const uint32_t a = (sw >> 30) & 3u; if (a) atomicAdd(&p[16], a * a); }
+}
+__device__ __forceinline__ void sel_stats_flush(TexVQ &V, const uint32_t *lds, uint32_t ncap, uint32_t leaf0) {
+  for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) {
+    const uint32_t v = lds[k]; if (!v) continue;
+    const uint32_t l = leaf0 + k / 17, w = k % 17;
+    for (int h = 0; h < 2; h++) {
+      const unsigned long long part = h ? (v >> 16) : (v & 0xffffu); if (!part) continue;
+      const uint32_t f = 2 * w + (uint32_t)h;
+      if (f == 0) atomicAdd(&V.stW[l], part);
+      else if (f <= 16) atomicAdd(&V.stS[(size_t)l * 16 + (f - 1)], part);
+      else atomicAdd(&V.stQ[(size_t)l * 16 + (f - 17)], part);
+    }
+  }
+}
 __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force, uint32_t lcap, uint32_t leaf_base) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[1];
@@ -217,64 +268,62 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force
     bool todo = i < V.n_items;
     const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
     todo = todo && l - leaf_base < ncap;                                   // leaves outside this pass's window: another pass
-    // while the wave's items sit in few leaves (always in the early rounds, mostly later: neighbouring blocks look
-    // alike) count with ballots — c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 — and let 33 lanes
-    // post one add each; whatever is left after 4 leaders takes the per-item path.
     const uint32_t sw = todo ? J.bsel[J.item[i]] : 0;
-    unsigned long long rem = __ballot(todo);
-    for (int rounds = 0; rounds < 4 && rem; rounds++) {
-      const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
-      const uint32_t ll = UVOL_READLANE(l, leader) - leaf_base;          // >= ncap (incl. wrapped): another pass counts that leaf
-      const bool inm = todo && l - leaf_base == ll;
-      const unsigned long long m = __ballot(inm);
-      uint32_t myv = 0;
-      for (int d = 0; d < 16; d++) {
-        const uint32_t xv = (sw >> (2 * d)) & 3u;
-        const uint32_t c1 = (uint32_t)__popcll(__ballot(inm && xv == 1)), c2 = (uint32_t)__popcll(__ballot(inm && xv == 2)), c3 = (uint32_t)__popcll(__ballot(inm && xv == 3));
-        if (lane == (uint32_t)(1 + d)) myv = c1 + 2 * c2 + 3 * c3;
-        if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
-      }
-      if (lane == 0) myv = (uint32_t)__popcll(m);
-      if (lane < 33 && myv && ll < ncap) atomicAdd(&lds[ll * 17 + (lane >> 1)], myv << ((lane & 1) * 16));
-      rem &= ~m;
-      if (inm) todo = false;
-    }
-    if (!todo || l - leaf_base >= ncap) continue;                        // other passes' leaves
-    {
-      uint32_t *p = lds + (size_t)(l - leaf_base) * 17;
-      uint32_t prev = 1;                                                   // field 0: W += 1
-      for (int d = 0; d < 16; d++) {                                       // fields 1..16: S
-        const uint32_t xv = (sw >> (2 * d)) & 3u;
-        if (d & 1) prev = xv; else { const uint32_t v = prev | (xv << 16); if (v) atomicAdd(&p[d >> 1], v); }
-      }
-      // fields 16 (S15) | 17 (Q0), then Q1|Q2 ... Q13|Q14, then Q15 alone
-      { const uint32_t q0 = (sw & 3u) * (sw & 3u), v = prev | (q0 << 16); if (v) atomicAdd(&p[8], v); }
-      for (int d = 1; d < 15; d += 2) {
-        const uint32_t a = (sw >> (2 * d)) & 3u, b = (sw >> (2 * d + 2)) & 3u, v = (a * a) | ((b * b) << 16);
-        if (v) atomicAdd(&p[9 + (d >> 1)], v);
-      }
-      { const uint32_t a = (sw >> 30) & 3u; if (a) atomicAdd(&p[16], a * a); }
-    }
+    sel_stats_accumulate(lds, todo, l - leaf_base, sw, lane);
   }
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) {
-    const uint32_t v = lds[k]; if (!v) continue;
-    const uint32_t l = leaf_base + k / 17, w = k % 17;
-    for (int h = 0; h < 2; h++) {
-      const unsigned long long part = h ? (v >> 16) : (v & 0xffffu); if (!part) continue;
-      const uint32_t f = 2 * w + (uint32_t)h;
-      if (f == 0) atomicAdd(&V.stW[l], part);
-      else if (f <= 16) atomicAdd(&V.stS[(size_t)l * 16 + (f - 1)], part);
-      else atomicAdd(&V.stQ[(size_t)l * 16 + (f - 17)], part);
-    }
+  sel_stats_flush(V, lds, ncap, leaf_base);
+}
+// One round of the selector tree build, after k_vq_decide<16, true>: items of a chosen leaf whose coordinate on the split axis
+// exceeds the threshold move to the leaf's new sibling (what k_vq_apply does), and the moved items' statistics are accumulated
+// for the new leaves [nl_old + win_base, + lcap) - the only statistics a round changes, apart from the parents' loss, which
+// the next k_vq_decide subtracts.  Window 0 moves the items; a later window (more than lcap new leaves in one round) finds
+// them by their new leaf.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sel_split_stats(TexJob *job, uint32_t lcap, uint32_t win_base) {
+  TJOB_OR_RETURN;
+  TexVQ &V = J.vq[1];
+  if (!V.round_active || V.m_round <= win_base) return;
+  UVOL_DYN_SMEM(uint32_t, lds);
+  const uint32_t m = V.m_round - win_base, ncap = m < lcap ? m : lcap, nl_old = V.nl - V.m_round, leaf0 = nl_old + win_base;
+  for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) lds[k] = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const bool in = i < V.n_items;
+    uint32_t l = in ? V.leaf[i] : 0u, sw = 0;
+    bool todo = false;
+    if (in && win_base == 0 && l < nl_old && V.chosen[l]) {
+      sw = J.bsel[J.item[i]];
+      const int ax = V.axis[l];
+      if ((long long)((sw >> (2 * ax)) & 3u) > V.th[l]) { l = V.newidx[l]; V.leaf[i] = l; todo = true; }
+    } else if (in && win_base != 0 && l >= leaf0) { sw = J.bsel[J.item[i]]; todo = true; }
+    todo = todo && l - leaf0 < ncap;
+    sel_stats_accumulate(lds, todo, l - leaf0, sw, lane);
   }
+  __syncthreads();
+  sel_stats_flush(V, lds, ncap, leaf0);
 }
 // split decision — one workgroup
-template <int DIM>
-__global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job) {
+// INCR (selector VQ): the leaf statistics are kept across rounds.  A split moves the items above the threshold to a new leaf;
+// k_sel_split_stats accumulates the statistics of exactly those items into the new leaf's (zero) slots, and the next call
+// here subtracts them from the parent - exact integer sums, so the result equals a recount of every leaf (which is what the
+// rounds did before: one to three full passes over all items per round).  fold_only: after the last round.
+template <int DIM, bool INCR>
+__global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job, int fold_only) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[DIM == 4 ? 0 : 1];
-  if (V.done) { if (threadIdx.x == 0) V.round_active = 0; return; }
+  if (INCR && V.round_active) {                      // uniform: written by the previous launch
+    const uint32_t nlp = V.nl - V.m_round;
+    for (uint32_t l = threadIdx.x; l < nlp; l += UVOL_BLOCK) {
+      if (!V.chosen[l]) continue;
+      const uint32_t ch = V.newidx[l];
+      V.stW[l] -= V.stW[ch];
+      for (int d = 0; d < DIM; d++) { V.stS[(size_t)l * DIM + d] -= V.stS[(size_t)ch * DIM + d]; V.stQ[(size_t)l * DIM + d] -= V.stQ[(size_t)ch * DIM + d]; }
+    }
+    __syncthreads();
+  }
+  if (V.done || fold_only) { __syncthreads(); if (threadIdx.x == 0) V.round_active = 0; return; }
   const uint32_t nl = V.nl, K = V.K;
   __shared__ uint32_t s_navail, s_carry;
   if (threadIdx.x == 0) { s_navail = 0; s_carry = 0; }
@@ -321,7 +370,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job) {
   // statistics pass): k_vq_apply keys on round_active, not on done, so the leaf count can advance here; the statistics
   // have all been read above (every thread passed the barriers of the scan), so they are cleared for the next round here
   if (threadIdx.x == 0) { V.m_round = m; V.round_active = 1; V.nl = nl + m; if (nl + m >= K) V.done = 1; }
-  for (uint32_t i = threadIdx.x; i < K * DIM; i += UVOL_BLOCK) { if (i < K) V.stW[i] = 0; V.stS[i] = 0; V.stQ[i] = 0; }
+  if (!INCR) for (uint32_t i = threadIdx.x; i < K * DIM; i += UVOL_BLOCK) { if (i < K) V.stW[i] = 0; V.stS[i] = 0; V.stQ[i] = 0; }
 }
 template <int DIM>
 __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_apply(TexJob *job) {
@@ -1099,7 +1148,7 @@ static void run_vq_rounds(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsig
     // no second pass - they fit next to the geometry walkers' bitmaps instead of waiting for a CU with 58 KB free
     const uint32_t leaves_r = r < 20 ? std::min<uint32_t>(kmax, 1u << r) : kmax, lds_leaves = std::min<uint32_t>((uint32_t)LCAP, std::max<uint32_t>(leaves_r, 16u));
     for (uint32_t lb = 0; lb < leaves_r; lb += LCAP) TLAUNCH((k_vq_stats<DIM, LCAP, CT>), dim3(sb), dim3(UVOL_BLOCK), (size_t)lds_leaves * (1 + 2 * DIM) * sizeof(CT), dj, 0, lb, lds_leaves);
-    TLAUNCH((k_vq_decide<DIM>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH((k_vq_decide<DIM, false>), dim3(1), dim3(UVOL_BLOCK), 0, dj, 0);
     TLAUNCH((k_vq_apply<DIM>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
   }
 }
@@ -1123,12 +1172,18 @@ static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned N
   for (uint32_t lb = 0; lb < leaves; lb += lcap) TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap, lb);
 }
 static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
-  TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, 0);   // later rounds: cleared by k_vq_decide
+  // statistics of the root leaf (all items; force: a segment with K <= 1 is 'done' from the start and still needs its centroid),
+  // then per round: decide (folds the previous round's moves into the parents) -> move the items + count the new leaves.
+  // The statistics are complete after the last fold: the first Lloyd iteration reads them as they are.
+  (void)item_blocks;
+  run_sel_stats(ctx, dj, J, NSEG, 1, 0);
   for (int r = 0; r < TEX_VQ_ROUNDS; r++) {
-    run_sel_stats(ctx, dj, J, NSEG, 0, r);
-    TLAUNCH((k_vq_decide<16>), dim3(1), dim3(UVOL_BLOCK), 0, dj);
-    TLAUNCH((k_vq_apply<16>), dim3(item_blocks), dim3(UVOL_BLOCK), 0, dj);
+    TLAUNCH((k_vq_decide<16, true>), dim3(1), dim3(UVOL_BLOCK), 0, dj, 0);
+    const uint32_t m_max = r < 20 ? std::min<uint32_t>(J.Kmax_s, 1u << r) : J.Kmax_s;        // a round splits every leaf at most once
+    const uint32_t lcap = std::min<uint32_t>(sel_lcap(J), std::max<uint32_t>(m_max, 16u));
+    for (uint32_t wb = 0; wb < m_max; wb += lcap) TLAUNCH(k_sel_split_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, lcap, wb);
   }
+  TLAUNCH((k_vq_decide<16, true>), dim3(1), dim3(UVOL_BLOCK), 0, dj, 1);
 }
 
 // n_seg segments of n_layers layers each (rgba[s * n_layers + l]), all of one size: ONE launch per stage for the whole batch
@@ -1198,7 +1253,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     uvol_ctx::Scope sc(ctx, "tex.k10_selector_codebook", src_bytes * 2);
     run_sel_rounds(ctx, dj, J, bNB, NSEG);
     for (int it = 0; it < 2; it++) {
-      run_sel_stats(ctx, dj, J, NSEG, 1);
+      if (it) run_sel_stats(ctx, dj, J, NSEG, 1);
       TLAUNCH(k_sel_centroids, dim3(bK), dim3(UVOL_BLOCK), 0, dj);
       { uvol_ctx::Scope sc2(ctx, "tex.k10_sel_assign", 0); TLAUNCH(k_sel_assign, dim3(bNB), dim3(UVOL_BLOCK), 0, dj); }   // work (integer ops) added after the job read-back
     }
