@@ -24,6 +24,7 @@ struct TexVQ {
   uint32_t *leaf;                          // [n_items]
   unsigned long long *stW, *stS, *stQ;     // [K], [K*DIM], [K*DIM]
   uint8_t *splittable, *chosen; int32_t *axis; long long *th, *prio; uint32_t *newidx;   // [K]
+  uint32_t *split;                         // [K] selector VQ: this round's split of a leaf in one word (chosen << 31 | axis << 24 | threshold << 16 | new leaf), 0 = not split
 };
 
 struct TexHuff { uint32_t n; uint32_t *freq; uint8_t *size; uint16_t *code; };   // code bit-reversed (LSB-first emission)

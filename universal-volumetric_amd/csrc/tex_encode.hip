@@ -196,80 +196,77 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_stats(TexJob *job, int force,
     else atomicAdd(&V.stQ[(size_t)l * DIM + (f - 1 - DIM)], v);
   }
 }
-// Selector-vector statistics (DIM 16, unit weights).  The host bounds the items one workgroup visits by SEL_STATS_ITEMS,
-// so every per-workgroup partial sum fits 16 bits (count <= 6144, S <= 3 * 6144, Q <= 9 * 6144 = 55296): two counters
-// share an LDS word, 17 words per leaf {W|S0, S1|S2, ... , Q15|-}.  One pass privatises the lcap <= 256 leaves from leaf_base
-// (17 KiB of LDS: a workgroup finds room on a CU whose LDS is mostly held by the geometry walkers' bitmaps; with 52 KiB for
-// all 768 leaves the kernel waited for LDS 3-4x longer than it ran); the host runs one pass per 256 leaves the round can have.
-// field f: 0 = W, 1..16 = S[f-1], 17..32 = Q[f-17];  word = f >> 1, half = f & 1.
-#define SEL_STATS_ITEMS 6144
-// one wave's items into the LDS table: `todo` items carry the window-relative leaf `rl` (< ncap) and the selector word `sw`
-__device__ __forceinline__ void sel_stats_accumulate(uint32_t *lds, bool todo, uint32_t rl, uint32_t sw, uint32_t lane) {
-  // while the wave's items sit in few leaves (always in the early rounds, mostly later: neighbouring blocks look
-  // alike) count with ballots - c_v = popc(ballot(x_d == v)), S = c1+2c2+3c3, Q = c1+4c2+9c3 - and let 33 lanes
-  // post one add each; whatever is left after 4 leaders takes the per-item path.
+// Selector-vector statistics (DIM 16, unit weights): 17 LDS words per leaf {S0|Q0, S1|Q1, ... , S15|Q15, W}, S in the low and Q
+// in the high half of a word.  One pass privatises the lcap <= 256 leaves from leaf_base (34 KiB of LDS with 64-bit words);
+// the host runs one pass per 256 leaves the round can have.
+#define SEL_ILP 4
+// one wave's items into the LDS table: `todo` items carry the window-relative leaf `rl` (< ncap) and the selector word `sw`.
+// Table layout: 17 words per leaf, word d < 16 = S_d | Q_d << 16, word 16 = W.
+template <typename WT> __device__ __forceinline__ void sel_stats_accumulate(WT *lds, bool todo, uint32_t rl, uint32_t sw, uint32_t lane) {
+  constexpr int QS = sizeof(WT) * 4;            // S in the low half of a word, Q in the high half
+  // While a large part of the wave sits in one leaf (always in the early rounds) count with ballots - c_v = popc(ballot(x_d == v)),
+  // S = c1+2c2+3c3, Q = c1+4c2+9c3 - and let 17 lanes post one add each.  Smaller groups take the per-item path below.
   unsigned long long rem = __ballot(todo);
   for (int rounds = 0; rounds < 4 && rem; rounds++) {
     const uint32_t leader = (uint32_t)(__ffsll((long long)rem) - 1);
     const uint32_t ll = UVOL_READLANE(rl, leader);
     const bool inm = todo && rl == ll;
     const unsigned long long m = __ballot(inm);
-    uint32_t myv = 0;
+    if (__popcll(m) < 24) break;
+    WT myv = 0;
     for (int d = 0; d < 16; d++) {
       const uint32_t xv = (sw >> (2 * d)) & 3u;
       const uint32_t c1 = (uint32_t)__popcll(__ballot(inm && xv == 1)), c2 = (uint32_t)__popcll(__ballot(inm && xv == 2)), c3 = (uint32_t)__popcll(__ballot(inm && xv == 3));
-      if (lane == (uint32_t)(1 + d)) myv = c1 + 2 * c2 + 3 * c3;
-      if (lane == (uint32_t)(17 + d)) myv = c1 + 4 * c2 + 9 * c3;
+      if (lane == (uint32_t)d) myv = (WT)(c1 + 2 * c2 + 3 * c3) | ((WT)(c1 + 4 * c2 + 9 * c3) << QS);
     }
-    if (lane == 0) myv = (uint32_t)__popcll(m);
-    if (lane < 33 && myv) atomicAdd(&lds[ll * 17 + (lane >> 1)], myv << ((lane & 1) * 16));
+    if (lane == 16) myv = (WT)__popcll(m);
+    if (lane < 17 && myv) atomicAdd(&lds[ll * 17 + lane], myv);
     rem &= ~m;
     if (inm) todo = false;
   }
   if (!todo) return;
-  uint32_t *p = lds + (size_t)rl * 17;
-  uint32_t prev = 1;                                                   // field 0: W += 1
-  for (int d = 0; d < 16; d++) {                                       // fields 1..16: S
-    const uint32_t xv = (sw >> (2 * d)) & 3u;
-    if (d & 1) prev = xv; else { const uint32_t v = prev | (xv << 16); if (v) atomicAdd(&p[d >> 1], v); }
+  // per item: 17 adds, each lane starting at its own word (lane mod 17) - lanes of one leaf then hit different words in the
+  // same instruction instead of queueing on one address (same-address LDS atomics of a wave are serialised)
+  WT *p = lds + (size_t)rl * 17;
+  uint32_t f = lane % 17u;
+  for (int k = 0; k < 17; k++) {
+    const uint32_t xv = (sw >> (2 * (f & 15u))) & 3u;
+    const WT v = f == 16u ? (WT)1 : ((WT)xv | ((WT)(xv * xv) << QS));
+    if (v) atomicAdd(&p[f], v);
+    f = f == 16u ? 0u : f + 1u;
   }
-  // fields 16 (S15) | 17 (Q0), then Q1|Q2 ... Q13|Q14, then Q15 alone
-  { const uint32_t q0 = (sw & 3u) * (sw & 3u), v = prev | (q0 << 16); if (v) atomicAdd(&p[8], v); }
-  for (int d = 1; d < 15; d += 2) {
-    const uint32_t a = (sw >> (2 * d)) & 3u, b = (sw >> (2 * d + 2)) & 3u, v = (a * a) | ((b * b) << 16);
-    if (v) atomicAdd(&p[9 + (d >> 1)], v);
-  }
-  { const uint32_t a = (sw >> 30) & 3u; if (a) atomicAdd(&p[16], a * a); }
 }
-__device__ __forceinline__ void sel_stats_flush(TexVQ &V, const uint32_t *lds, uint32_t ncap, uint32_t leaf0) {
+template <typename WT> __device__ __forceinline__ void sel_stats_flush(TexVQ &V, const WT *lds, uint32_t ncap, uint32_t leaf0) {
+  constexpr int QS = sizeof(WT) * 4;
+  const WT lo = ((WT)1 << QS) - 1;
   for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) {
-    const uint32_t v = lds[k]; if (!v) continue;
+    const WT v = lds[k]; if (!v) continue;
     const uint32_t l = leaf0 + k / 17, w = k % 17;
-    for (int h = 0; h < 2; h++) {
-      const unsigned long long part = h ? (v >> 16) : (v & 0xffffu); if (!part) continue;
-      const uint32_t f = 2 * w + (uint32_t)h;
-      if (f == 0) atomicAdd(&V.stW[l], part);
-      else if (f <= 16) atomicAdd(&V.stS[(size_t)l * 16 + (f - 1)], part);
-      else atomicAdd(&V.stQ[(size_t)l * 16 + (f - 17)], part);
+    if (w == 16) atomicAdd(&V.stW[l], (unsigned long long)v);
+    else {
+      if (v & lo) atomicAdd(&V.stS[(size_t)l * 16 + w], (unsigned long long)(v & lo));
+      if (v >> QS) atomicAdd(&V.stQ[(size_t)l * 16 + w], (unsigned long long)(v >> QS));
     }
   }
 }
-__global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force, uint32_t lcap, uint32_t leaf_base) {
+template <typename WT> __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force, uint32_t lcap, uint32_t leaf_base) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[1];
   if ((V.done && !force) || V.nl <= leaf_base) return;
-  UVOL_DYN_SMEM(uint32_t, lds);                 // [lcap * 17]: the leaves [leaf_base, leaf_base + lcap) of this pass
+  UVOL_DYN_SMEM(WT, lds);                       // [lcap * 17]: the leaves [leaf_base, leaf_base + lcap) of this pass
   const uint32_t nl = V.nl - leaf_base, ncap = nl < lcap ? nl : lcap;
   for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) lds[k] = 0;
   __syncthreads();
-  const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
-    const uint32_t i = base + threadIdx.x;
-    bool todo = i < V.n_items;
-    const uint32_t l = todo ? V.leaf[i] : 0xffffffffu;
-    todo = todo && l - leaf_base < ncap;                                   // leaves outside this pass's window: another pass
-    const uint32_t sw = todo ? J.bsel[J.item[i]] : 0;
-    sel_stats_accumulate(lds, todo, l - leaf_base, sw, lane);
+  const uint32_t lane = threadIdx.x & 63, n_items = V.n_items;
+  const uint32_t *const leaf = V.leaf, *const item = J.item, *const bsel = J.bsel;
+  for (uint32_t base = blockIdx.x * (UVOL_BLOCK * SEL_ILP); base < n_items; base += gridDim.x * (UVOL_BLOCK * SEL_ILP)) {
+    uint32_t l[SEL_ILP], it[SEL_ILP], sw[SEL_ILP];
+#pragma unroll
+    for (int k = 0; k < SEL_ILP; k++) { const uint32_t i = base + k * UVOL_BLOCK + threadIdx.x; const bool in = i < n_items; l[k] = in ? leaf[i] : 0xffffffffu; it[k] = in ? item[i] : 0u; }
+#pragma unroll
+    for (int k = 0; k < SEL_ILP; k++) sw[k] = l[k] != 0xffffffffu ? bsel[it[k]] : 0u;
+#pragma unroll
+    for (int k = 0; k < SEL_ILP; k++) sel_stats_accumulate(lds, l[k] != 0xffffffffu && l[k] - leaf_base < ncap, l[k] - leaf_base, sw[k], lane);   // leaves outside this pass's window: another pass
   }
   __syncthreads();
   sel_stats_flush(V, lds, ncap, leaf_base);
@@ -279,27 +276,33 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_stats(TexJob *job, int force
 // for the new leaves [nl_old + win_base, + lcap) - the only statistics a round changes, apart from the parents' loss, which
 // the next k_vq_decide subtracts.  Window 0 moves the items; a later window (more than lcap new leaves in one round) finds
 // them by their new leaf.
-__global__ void __launch_bounds__(UVOL_BLOCK) k_sel_split_stats(TexJob *job, uint32_t lcap, uint32_t win_base) {
+template <typename WT> __global__ void __launch_bounds__(UVOL_BLOCK) k_sel_split_stats(TexJob *job, uint32_t lcap, uint32_t win_base) {
   TJOB_OR_RETURN;
   TexVQ &V = J.vq[1];
   if (!V.round_active || V.m_round <= win_base) return;
-  UVOL_DYN_SMEM(uint32_t, lds);
+  UVOL_DYN_SMEM(WT, lds);
   const uint32_t m = V.m_round - win_base, ncap = m < lcap ? m : lcap, nl_old = V.nl - V.m_round, leaf0 = nl_old + win_base;
   for (uint32_t k = threadIdx.x; k < ncap * 17; k += UVOL_BLOCK) lds[k] = 0;
   __syncthreads();
-  const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t base = blockIdx.x * UVOL_BLOCK; base < V.n_items; base += gridDim.x * UVOL_BLOCK) {
-    const uint32_t i = base + threadIdx.x;
-    const bool in = i < V.n_items;
-    uint32_t l = in ? V.leaf[i] : 0u, sw = 0;
-    bool todo = false;
-    if (in && win_base == 0 && l < nl_old && V.chosen[l]) {
-      sw = J.bsel[J.item[i]];
-      const int ax = V.axis[l];
-      if ((long long)((sw >> (2 * ax)) & 3u) > V.th[l]) { l = V.newidx[l]; V.leaf[i] = l; todo = true; }
-    } else if (in && win_base != 0 && l >= leaf0) { sw = J.bsel[J.item[i]]; todo = true; }
-    todo = todo && l - leaf0 < ncap;
-    sel_stats_accumulate(lds, todo, l - leaf0, sw, lane);
+  const uint32_t lane = threadIdx.x & 63, n_items = V.n_items;
+  uint32_t *const leaf = V.leaf; const uint32_t *const split = V.split, *const item = J.item, *const bsel = J.bsel;
+  // SEL_ILP items per thread and trip: the two dependent chains of an item (leaf -> split word, item -> selector word) are in
+  // flight for all of them at once; with one item per trip a workgroup spent its time waiting for four round trips in a row
+  for (uint32_t base = blockIdx.x * (UVOL_BLOCK * SEL_ILP); base < n_items; base += gridDim.x * (UVOL_BLOCK * SEL_ILP)) {
+    uint32_t l[SEL_ILP], it[SEL_ILP], sw[SEL_ILP], sp[SEL_ILP];
+#pragma unroll
+    for (int k = 0; k < SEL_ILP; k++) { const uint32_t i = base + k * UVOL_BLOCK + threadIdx.x; const bool in = i < n_items; l[k] = in ? leaf[i] : 0xffffffffu; it[k] = in ? item[i] : 0u; }
+#pragma unroll
+    for (int k = 0; k < SEL_ILP; k++) { sw[k] = l[k] != 0xffffffffu ? bsel[it[k]] : 0u; sp[k] = (win_base == 0 && l[k] < nl_old) ? split[l[k]] : 0u; }
+#pragma unroll
+    for (int k = 0; k < SEL_ILP; k++) {
+      bool todo = false; uint32_t nl_ = l[k];
+      if (win_base == 0) {
+        if ((sp[k] >> 31) && ((sw[k] >> (2 * ((sp[k] >> 24) & 15u))) & 3u) > ((sp[k] >> 16) & 0xffu)) { nl_ = sp[k] & 0xffffu; leaf[base + k * UVOL_BLOCK + threadIdx.x] = nl_; todo = true; }
+      } else todo = l[k] != 0xffffffffu && l[k] >= leaf0;
+      todo = todo && nl_ - leaf0 < ncap;
+      sel_stats_accumulate(lds, todo, nl_ - leaf0, sw[k], lane);
+    }
   }
   __syncthreads();
   sel_stats_flush(V, lds, ncap, leaf0);
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vq_decide(TexJob *job, int fold_
     uint32_t v = l < nl ? V.chosen[l] : 0, tot;
     const uint32_t ex = t_block_excl_scan(v, &tot);
     const uint32_t c = s_carry;
-    if (l < nl) V.newidx[l] = nl + c + ex;
+    if (l < nl) { V.newidx[l] = nl + c + ex; if (INCR) V.split[l] = v ? (0x80000000u | ((uint32_t)V.axis[l] << 24) | ((uint32_t)V.th[l] << 16) | (nl + c + ex)) : 0u; }
     __syncthreads();
     if (threadIdx.x == 0) s_carry = c + tot;
     __syncthreads();
@@ -1103,7 +1106,7 @@ size_t tex_layout(TexJob &J, uint8_t *base, size_t *zero_bytes) {
     TCARVE(V.leaf, uint32_t, ni + 8);
     TCARVE(V.stW, unsigned long long, KC + 8); TCARVE(V.stS, unsigned long long, (KC + 8) * dim); TCARVE(V.stQ, unsigned long long, (KC + 8) * dim);
     TCARVE(V.splittable, uint8_t, KC + 8); TCARVE(V.chosen, uint8_t, KC + 8); TCARVE(V.axis, int32_t, KC + 8);
-    TCARVE(V.th, long long, KC + 8); TCARVE(V.prio, long long, KC + 8); TCARVE(V.newidx, uint32_t, KC + 8);
+    TCARVE(V.th, long long, KC + 8); TCARVE(V.prio, long long, KC + 8); TCARVE(V.newidx, uint32_t, KC + 8); TCARVE(V.split, uint32_t, KC + 8);
   }
   TCARVE(J.ecb, uint32_t, KC + 8); TCARVE(J.emap, uint32_t, KC + 8);
   TCARVE(J.bei, uint16_t, NB + 8); TCARVE(J.bsi, uint16_t, NB + 8); TCARVE(J.bsel, uint32_t, NB + 8);
@@ -1161,15 +1164,21 @@ static void run_vq_stats(uvol_ctx *ctx, TexJob *dj, unsigned item_blocks, unsign
 
 // selector VQ (16-D, unit weights): same rounds, statistics through k_sel_stats
 static inline uint32_t sel_lcap_max() { static const uint32_t v = [] { const char *e = getenv("UVOL_SEL_LCAP"); const int x = e ? atoi(e) : 0; return (uint32_t)(x >= 16 && x <= 768 ? x : 256); }(); return v; }
-static inline uint32_t sel_lcap(const TexJob &J) { return J.Kmax_s < sel_lcap_max() ? J.Kmax_s : sel_lcap_max(); }   // leaves per pass: 17 KiB of LDS, placeable next to the geometry walkers' bitmaps
-static inline unsigned sel_stat_blocks(const TexJob &J, unsigned nseg) { return std::max<unsigned>(std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))), (unsigned)((J.NB + SEL_STATS_ITEMS - 1) / SEL_STATS_ITEMS)); }   // >= NB / SEL_STATS_ITEMS: the 16-bit partial sums
+static inline uint32_t sel_lcap(const TexJob &J) { const uint32_t cap = std::min<uint32_t>(sel_lcap_max(), 448u); return J.Kmax_s < cap ? J.Kmax_s : cap; }   // (448 x 17 x 8 bytes: within the 64 KiB of dynamic LDS a kernel gets without opting in)   // leaves per pass: 17 KiB of LDS, placeable next to the geometry walkers' bitmaps
+// LDS words of the selector statistics are 64-bit (S | Q << 32): no bound on the items a workgroup visits, so few workgroups per
+// segment and few flushes (a flush is up to 33 global atomics per leaf and workgroup).  Measured against 16-bit halves of
+// 32-bit words (<= 6144 items per workgroup, 213 workgroups per 2048^2 x 5 segment): 15.9 against 27.4 ms per step.
+typedef unsigned long long sel_word_t;
+static inline unsigned sel_stat_blocks(unsigned nseg) { return std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))); }
 static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force, int round = -1) {
   // round r of the tree build has <= 2^r leaves: reserve LDS for those only (leaves past the cap would still be counted, through
   // global atomics)
   const uint32_t leaves = (round >= 0 && round < 20) ? std::min<uint32_t>(J.Kmax_s, std::max<uint32_t>(1u << round, 16u)) : J.Kmax_s;
   const uint32_t lcap = std::min<uint32_t>(sel_lcap(J), leaves);
   if (force) TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
-  for (uint32_t lb = 0; lb < leaves; lb += lcap) TLAUNCH(k_sel_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, force, lcap, lb);
+  for (uint32_t lb = 0; lb < leaves; lb += lcap) {
+    TLAUNCH(k_sel_stats<sel_word_t>, dim3(sel_stat_blocks(NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * sizeof(sel_word_t), dj, force, lcap, lb);
+  }
 }
 static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
   // statistics of the root leaf (all items; force: a segment with K <= 1 is 'done' from the start and still needs its centroid),
@@ -1181,7 +1190,9 @@ static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned 
     TLAUNCH((k_vq_decide<16, true>), dim3(1), dim3(UVOL_BLOCK), 0, dj, 0);
     const uint32_t m_max = r < 20 ? std::min<uint32_t>(J.Kmax_s, 1u << r) : J.Kmax_s;        // a round splits every leaf at most once
     const uint32_t lcap = std::min<uint32_t>(sel_lcap(J), std::max<uint32_t>(m_max, 16u));
-    for (uint32_t wb = 0; wb < m_max; wb += lcap) TLAUNCH(k_sel_split_stats, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * 4, dj, lcap, wb);
+    for (uint32_t wb = 0; wb < m_max; wb += lcap) {
+      TLAUNCH(k_sel_split_stats<sel_word_t>, dim3(sel_stat_blocks(NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * sizeof(sel_word_t), dj, lcap, wb);
+    }
   }
   TLAUNCH((k_vq_decide<16, true>), dim3(1), dim3(UVOL_BLOCK), 0, dj, 1);
 }
