@@ -114,6 +114,12 @@ def test_gpu_mesh_decode_matches_oracle(oracle, gpu_codec):
     t = frames[2]
     frames.append(dict(pos=t["pos"], idx_pos=t["idx_pos"]))
     files = gpu_codec.encode_mesh_batch(frames)
+    # 16-bit quantisation of every attribute (the largest operands the tex-coord predictor's f64 form must keep exact), 4 bits, and
+    # a 50k-vertex frame at 16 bits: long chains of entries that refer to each other inside a 64-entry chunk
+    import synth
+    big = synth.sphere_mesh(280, 180, frame=1)
+    for f, qb in ((frames[0], 16), (frames[1], 16), (frames[0], 4), (big, 16), (big, 11)):
+        files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), qp=qb, qt=qb, qn=qb))
     files += [open(os.path.join(GOLDEN, n), "rb").read() for n in ("00000.drc", "00075.drc")]
     for data, got in zip(files, gpu_codec.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)

@@ -210,10 +210,13 @@ __device__ __forceinline__ int gd_ans_init(const uint8_t *buf, uint32_t n, uint3
   else { if (!allow3 || n < 4) return -1; st = ((uint32_t)buf[n - 4] | (uint32_t)buf[n - 3] << 8 | (uint32_t)buf[n - 2] << 16 | (uint32_t)buf[n - 1] << 24) & 0x3fffffff; off -= 4; }
   st += L; return 0;
 }
+// Grid = (frames, streams), frame index fastest: consecutive workgroups land on the four SIMDs of a CU in turn, and with
+// (streams, frames) and four streams per frame the one long stream of every frame went to the same SIMD of every CU - a
+// quarter of the chip's issue slots for all the serial work of the launch (k_gdec_pred: 0.75 us per entry instead of 0.15)
 __global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, int count) {
-  GeoDecJob &J = jobs[blockIdx.y];
-  const int si = first + (int)blockIdx.x;
-  if ((int)blockIdx.x >= count) return;
+  GeoDecJob &J = jobs[blockIdx.x];
+  const int si = first + (int)blockIdx.y;
+  if ((int)blockIdx.y >= count) return;
   GDRans &S = J.rs[si];
   const uint32_t lane = threadIdx.x;
   // the job status can be changed by the sibling workgroups of this frame (other streams) while this one runs: sample it
@@ -627,49 +630,104 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_normals(GeoDecJob *jobs, Ge
   gd_oct_orig(ot, po, corr, A.vals + 2 * dd);
 }
 
-// parallelogram + wrap recurrence of one decoder (A.6).  The sequential inputs of entry p + 1 (neighbour entries, symbols)
-// are requested while entry p is computed (UVOL_LANE_ZERO / UVOL_READFIRST); only the reads of earlier OUTPUTS stay in the chain.
+// Value recurrences of one decoder (A.6 parallelogram + wrap, A.8 tex-coord-portable), one wave per (decoder, frame), 64 entries
+// at a time.  An entry's operands are earlier OUTPUTS; read back from global memory right after the store, each costs a round
+// trip through L2 (the chain ran at ~1.3 us per entry).  Per chunk of 64 entries:
+//   stage (64 lanes): neighbour entries / geometry record / symbols of the lane's entry; operands older than the chunk are
+//                     fetched now - from the LDS ring of the last GDP_R outputs, or from global memory when older than that
+//                     (written at least four chunks ago) - and only operands INSIDE the chunk stay as references;
+//   chain (lane 0):   the 64 entries in order, operands from the staged record or the chunk's LDS tile;
+//   store (64 lanes): tile -> out[] (coalesced) and -> ring.
+#define GDP_R 256
+#define GDP_STAGE 16      // words per staged entry
 template <int NC>
-__device__ __forceinline__ void gd_pgram_loop(int ne, UVOL_G(const int32_t) nbr, UVOL_G(const uint32_t) syms, UVOL_G(int32_t) out, int32_t lo, int32_t hi) {
-  const int dz = UVOL_LANE_ZERO();
-  int n0 = ne > 0 ? nbr[dz] : -1, n1 = ne > 0 ? nbr[1 + dz] : -1, n2 = ne > 0 ? nbr[2 + dz] : -1;
-  uint32_t sy[NC];
+__device__ __forceinline__ void gd_pgram_chunks(int ne, UVOL_G(const int32_t) nbr, UVOL_G(const uint32_t) syms, UVOL_G(int32_t) out, int32_t lo, int32_t hi,
+                                                int32_t *ring, int32_t *stage, int32_t *tile) {
+  // (typed global pointers: with generic ones every load is a flat_load the compiler must drain before the next LDS store,
+  //  and the staging of a chunk became a dozen round trips in a row)
+  const int lane = (int)threadIdx.x;
+  for (int base = 0; base < ne; base += 64) {
+    const int e = base + lane;
+    if (e < ne) {
+      const int a = nbr[3 * (size_t)e], bn = nbr[3 * (size_t)e + 1], bp = nbr[3 * (size_t)e + 2];
+      int32_t cr[NC];
 #pragma unroll
-  for (int k = 0; k < NC; k++) sy[k] = ne > 0 ? syms[k + dz] : 0u;
-  for (int p = 0; p < ne; p++) {
-    int32_t pred[NC];
-    const int a = UVOL_READFIRST(n0), bn = UVOL_READFIRST(n1), bp = UVOL_READFIRST(n2);
-    uint32_t cs[NC];
+      for (int k = 0; k < NC; k++) cr[k] = gd_sgn(syms[(size_t)e * NC + k]);
+      int q[3] = { -1, -1, -1 };                          // operands: +q0 +q1 -q2
+      if (a >= 0) { q[0] = bn; q[1] = bp; q[2] = a; } else if (e > 0) q[0] = e - 1;
+      int32_t ps[NC]; uint32_t refs = 0;
 #pragma unroll
-    for (int k = 0; k < NC; k++) cs[k] = (uint32_t)UVOL_READFIRST(sy[k]);
-    if (p + 1 < ne) {
-      n0 = nbr[3 * (p + 1) + dz]; n1 = nbr[3 * (p + 1) + 1 + dz]; n2 = nbr[3 * (p + 1) + 2 + dz];
+      for (int k = 0; k < NC; k++) ps[k] = 0;
 #pragma unroll
-      for (int k = 0; k < NC; k++) sy[k] = syms[(p + 1) * NC + k + dz];
+      for (int i = 0; i < 3; i++) {
+        if (q[i] < 0) continue;
+        if (q[i] >= base) { refs |= (uint32_t)(q[i] - base + 1) << (8 * i); continue; }
+        if (q[i] < base - GDP_R) {
+#pragma unroll
+          for (int k = 0; k < NC; k++) { const int32_t v = out[(size_t)q[i] * NC + k]; ps[k] += i == 2 ? -v : v; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NC; k++) { const int32_t v = ring[(q[i] & (GDP_R - 1)) * NC + k]; ps[k] += i == 2 ? -v : v; }
+        }
+      }
+      int32_t *st = stage + lane * GDP_STAGE;
+#pragma unroll
+      for (int k = 0; k < NC; k++) { st[k] = ps[k]; st[4 + k] = cr[k]; }
+      st[8] = (int32_t)refs;
     }
+    __syncthreads();
+    if (lane == 0) {
+      // the chain: per entry one round trip to the LDS tile (all three possible references are read at once, unused ones masked)
+      // and the wrap; the staged record of the next entry is requested before this one is computed
+      const int cnt = ne - base < 64 ? ne - base : 64;
+      int32_t ps[NC], cr[NC]; uint32_t refs = (uint32_t)stage[8];
 #pragma unroll
-    for (int k = 0; k < NC; k++) pred[k] = a >= 0 ? out[bn * NC + k] + out[bp * NC + k] - out[a * NC + k] : (p > 0 ? out[(p - 1) * NC + k] : 0);
+      for (int k = 0; k < NC; k++) { ps[k] = stage[k]; cr[k] = stage[4 + k]; }
+      for (int j = 0; j < cnt; j++) {
+        const int32_t *sn = stage + (j + 1 < cnt ? j + 1 : j) * GDP_STAGE;
+        int32_t nps[NC], ncr[NC]; const uint32_t nrefs = (uint32_t)sn[8];
 #pragma unroll
-    for (int k = 0; k < NC; k++) out[p * NC + k] = gd_wrap(pred[k], gd_sgn(cs[k]), lo, hi);
+        for (int k = 0; k < NC; k++) { nps[k] = sn[k]; ncr[k] = sn[4 + k]; }
+        const uint32_t r0 = refs & 255u, r1 = (refs >> 8) & 255u, r2 = refs >> 16;
+        const int32_t *t0 = tile + (r0 ? r0 - 1 : 0) * NC, *t1 = tile + (r1 ? r1 - 1 : 0) * NC, *t2 = tile + (r2 ? r2 - 1 : 0) * NC;
+        int32_t a0[NC], a1[NC], a2[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { a0[k] = t0[k]; a1[k] = t1[k]; a2[k] = t2[k]; }
+#pragma unroll
+        for (int k = 0; k < NC; k++) tile[j * NC + k] = gd_wrap(ps[k] + (r0 ? a0[k] : 0) + (r1 ? a1[k] : 0) - (r2 ? a2[k] : 0), cr[k], lo, hi);
+#pragma unroll
+        for (int k = 0; k < NC; k++) { ps[k] = nps[k]; cr[k] = ncr[k]; }
+        refs = nrefs;
+      }
+    }
+    __syncthreads();
+    if (e < ne) {
+#pragma unroll
+      for (int k = 0; k < NC; k++) { const int32_t v = tile[lane * NC + k]; out[(size_t)e * NC + k] = v; ring[(size_t)(e & (GDP_R - 1)) * NC + k] = v; }
+    }
+    __syncthreads();
   }
 }
-
 __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, int phase) {
-  GeoDecJob &J = jobs[blockIdx.y];
-  const GeoJob &G = gj[blockIdx.y];
-  const int d = blockIdx.x;
-  if (threadIdx.x != 0 || J.status != 0 || G.status != 0 || d >= J.ndec) return;
+  GeoDecJob &J = jobs[blockIdx.x];
+  const GeoJob &G = gj[blockIdx.x];
+  const int d = blockIdx.y, lane = (int)threadIdx.x;                  // (frame index fastest: see k_gdec_rans)
+  __shared__ int s_go, s_bad;
+  __shared__ __attribute__((aligned(16))) int32_t s_ring[GDP_R * 4], s_stage[64 * GDP_STAGE], s_tile[64 * 4];
+  // the job status can be changed by the sibling workgroups of this frame while this one runs: sample it once per workgroup
+  if (lane == 0) { s_go = (J.status == 0 && G.status == 0 && d < J.ndec) ? 1 : 0; s_bad = 0; }
+  __syncthreads();
+  if (!s_go) return;
   GDAtt &A = J.att[d];
   if (A.pred_method == 6) return;                       // normals: k_gdec_flips + k_gdec_normals
   const bool needs_pos = A.pred_method == 5;
   if ((phase == 0) == needs_pos) return;
   const int t = A.table, nc = A.nc, ne = (int)G.ne[t];
-  // typed (global) pointers: the recurrence stores out[p] and reads earlier entries — with generic pointers every read
-  // would wait for the previous store's acknowledgement (see uvol_common.hpp)
   UVOL_G(const uint32_t) syms = UVOL_TO_G(const uint32_t, J.rs[6 + d].out); UVOL_G(int32_t) out = UVOL_TO_G(int32_t, A.vals);
   int pdec = -1; for (int k = 0; k < J.ndec; k++) if (J.att[k].att_type == 0 && J.att[k].att_data_id == -1) pdec = k;
-  if (A.pred_method == -2) { for (int i = 0; i < ne * nc; i++) out[i] = gd_sgn(syms[i]); }          // no prediction (sequential streams)
+  if (A.pred_method == -2) { for (int i = lane; i < ne * nc; i += 64) out[i] = gd_sgn(syms[i]); }          // no prediction (sequential streams)
   else if (A.pred_method == 0 && A.transform == 3) {                                                // DIFFERENCE through the canonicalised octahedron (sequential normals)
+    if (lane != 0) return;
     int q = 0; while ((1 << q) - 1 < A.maxq) q++;
     const GOct ot = g_oct(q);
     if (ot.MAXQ != A.maxq || ot.CEN != A.cen || nc != 2) { J.status = -30; return; }
@@ -681,52 +739,110 @@ __global__ void __launch_bounds__(64) k_gdec_pred(GeoDecJob *jobs, GeoJob *gj, i
     UVOL_G(const int32_t) nbr = UVOL_TO_G(const int32_t, J.nbr + (size_t)d * ((size_t)3 * J.ecap + 64));
     // component count as a template parameter: the per-component arrays must stay in registers (a run-time bound sends
     // them to scratch memory)
-    if (nc == 3) gd_pgram_loop<3>(ne, nbr, syms, out, lo, hi);
-    else if (nc == 1) gd_pgram_loop<1>(ne, nbr, syms, out, lo, hi);
-    else if (nc == 2) gd_pgram_loop<2>(ne, nbr, syms, out, lo, hi);
-    else gd_pgram_loop<4>(ne, nbr, syms, out, lo, hi);
+    if (nc == 3) gd_pgram_chunks<3>(ne, nbr, syms, out, lo, hi, s_ring, s_stage, s_tile);
+    else if (nc == 1) gd_pgram_chunks<1>(ne, nbr, syms, out, lo, hi, s_ring, s_stage, s_tile);
+    else if (nc == 2) gd_pgram_chunks<2>(ne, nbr, syms, out, lo, hi, s_ring, s_stage, s_tile);
+    else gd_pgram_chunks<4>(ne, nbr, syms, out, lo, hi, s_ring, s_stage, s_tile);
   } else if (A.pred_method == 5) {
-    if (pdec < 0) { J.status = -26; return; }
     const int no = A.n_orient; uint8_t *ori = J.aux_bits + (size_t)d * ((size_t)J.ecap + 64);
-    if ((uint32_t)no > J.ecap) { J.status = -26; return; }                // more orientation bits than entries: corrupt
-    { GDBit Rb; if (gd_rabs_open(Rb, J, A.aux)) { J.status = -26; return; } int last = 1; for (int k = 0; k < no; k++) { if (!gd_rabs_bit(Rb)) last = !last; ori[k] = (uint8_t)last; } }
-    const int32_t lo = A.lo, hi = A.hi; int nori = no;
-    const int dz = UVOL_LANE_ZERO();
-    UVOL_G(const int32_t) uvw = UVOL_TO_G(const int32_t, reinterpret_cast<const int32_t *>(J.uvgeo));           // the same records as 8 words
-    int32_t gw[8]; uint32_t sy0 = 0, sy1 = 0;
-    for (int k = 0; k < 8 && ne > 0; k++) gw[k] = uvw[k + dz];
-    if (ne > 0) { sy0 = syms[dz]; sy1 = syms[1 + dz]; }
-    for (int p = 0; p < ne; p++) {
-      GDUvGeo g; uint32_t cs[2];
-      { uint32_t u[8]; for (int k = 0; k < 8; k++) u[k] = (uint32_t)UVOL_READFIRST(gw[k]);
-        g.nd = (int32_t)u[0]; g.pd = (int32_t)u[1]; g.pn2 = (long long)(((unsigned long long)u[3] << 32) | u[2]); g.dd = (long long)(((unsigned long long)u[5] << 32) | u[4]); g.ns = (long long)(((unsigned long long)u[7] << 32) | u[6]);
-        cs[0] = (uint32_t)UVOL_READFIRST(sy0); cs[1] = (uint32_t)UVOL_READFIRST(sy1); }
-      if (p + 1 < ne) { for (int k = 0; k < 8; k++) gw[k] = uvw[8 * (size_t)(p + 1) + k + dz]; sy0 = syms[2 * (p + 1) + dz]; sy1 = syms[2 * (p + 1) + 1 + dz]; }
-      const int nd = g.nd, pd = g.pd;
-      long long pred[2]; bool have = false;
-      if (pd < p && nd < p) {
-        const long long nuv[2] = { out[nd * 2], out[nd * 2 + 1] }, puv[2] = { out[pd * 2], out[pd * 2 + 1] };
-        if (puv[0] == nuv[0] && puv[1] == nuv[1]) { pred[0] = puv[0]; pred[1] = puv[1]; have = true; }
-        else if (g.pn2 != 0) {
-          const long long pn2 = g.pn2, dd = g.dd, ns_ = g.ns;
-          const long long pnuv[2] = { puv[0] - nuv[0], puv[1] - nuv[1] };
-          const long long xuv[2] = { nuv[0] * pn2 + dd * pnuv[0], nuv[1] * pn2 + dd * pnuv[1] };
-          const long long cxuv[2] = { pnuv[1] * ns_, -pnuv[0] * ns_ };
-          if (nori <= 0) { J.status = -27; return; }
-          const int o_ = ori[--nori];
-          if (o_) { pred[0] = (xuv[0] + cxuv[0]) / pn2; pred[1] = (xuv[1] + cxuv[1]) / pn2; }
-          else { pred[0] = (xuv[0] - cxuv[0]) / pn2; pred[1] = (xuv[1] - cxuv[1]) / pn2; }
-          have = true;
-        }
-      }
-      if (!have) {
-        if (nd < p) { pred[0] = out[nd * 2]; pred[1] = out[nd * 2 + 1]; }
-        else if (p > 0) { pred[0] = out[(p - 1) * 2]; pred[1] = out[(p - 1) * 2 + 1]; }
-        else { pred[0] = pred[1] = 0; }
-      }
-      for (int k = 0; k < 2; k++) out[p * 2 + k] = gd_wrap((int32_t)pred[k], gd_sgn(cs[k]), lo, hi);
+    if (lane == 0) {
+      if (pdec < 0 || (uint32_t)no > J.ecap) { J.status = -26; s_bad = 1; }                // (more orientation bits than entries: corrupt)
+      else { GDBit Rb; if (gd_rabs_open(Rb, J, A.aux)) { J.status = -26; s_bad = 1; } else { int last = 1; for (int k = 0; k < no; k++) { if (!gd_rabs_bit(Rb)) last = !last; ori[k] = (uint8_t)last; } } }
     }
-    if (nori != 0) { J.status = -28; return; }
+    __syncthreads();
+    if (s_bad) return;
+    const int32_t lo = A.lo, hi = A.hi; int nori = no;
+    UVOL_G(const int32_t) uvw = UVOL_TO_G(const int32_t, reinterpret_cast<const int32_t *>(J.uvgeo));           // GDUvGeo records as 8 words
+    UVOL_G(const uint8_t) orig = UVOL_TO_G(const uint8_t, ori);
+    __shared__ uint8_t s_ori[64]; __shared__ int s_nori;
+    // f64 form of the prediction (below): exact while every product stays below 2^53, which quantisation up to 16 bits guarantees
+    // (|uv| < 2^17, pn2 / dd / ns < 2^35); anything larger - only a corrupt stream - takes the int64 form
+    const bool small_uv = lo > -(1 << 17) && hi < (1 << 17);
+    if (lane == 0) s_nori = no;
+    // staged entry: [0] flags (1: nd < p, 2: pd < p too, 4: a value to fall back on, 8: f64 form is exact), [1] in-chunk references
+    // (nd + 1) | (pd + 1) << 8, [2..3] nuv, [4..5] puv, [6..7] corrections, [8..9] pn2, [10..11] dd, [12..13] ns, [14..15] 1 / pn2 (f64)
+    for (int base = 0; base < ne; base += 64) {
+      const int e = base + lane;
+      __syncthreads();
+      { const int k = s_nori - 1 - lane; s_ori[lane] = k >= 0 ? orig[k] : 0; }          // the (at most 64) orientation bits this chunk can consume
+      if (e < ne) {
+        GDUvGeo g;
+        { uint32_t u[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) u[k] = (uint32_t)uvw[8 * (size_t)e + k];
+          g.nd = (int32_t)u[0]; g.pd = (int32_t)u[1]; g.pn2 = (long long)(((unsigned long long)u[3] << 32) | u[2]); g.dd = (long long)(((unsigned long long)u[5] << 32) | u[4]); g.ns = (long long)(((unsigned long long)u[7] << 32) | u[6]); }
+        const int32_t sy0 = gd_sgn(syms[2 * (size_t)e]), sy1 = gd_sgn(syms[2 * (size_t)e + 1]);
+        int32_t *st = s_stage + lane * GDP_STAGE;
+        const bool hn = (uint32_t)g.nd < (uint32_t)e, hp = hn && (uint32_t)g.pd < (uint32_t)e;      // (negative = an entry the tables never reached: corrupt input)
+        uint32_t refs = 0; int32_t nuv[2] = { 0, 0 }, puv[2] = { 0, 0 };
+        const int qn = hn ? g.nd : (e > 0 ? e - 1 : -1);       // without a decoded 'next' vertex the previous entry predicts
+        if (qn >= 0) {
+          if (qn >= base) refs |= (uint32_t)(qn - base + 1);
+          else if (qn < base - GDP_R) { nuv[0] = out[2 * (size_t)qn]; nuv[1] = out[2 * (size_t)qn + 1]; }
+          else { nuv[0] = s_ring[2 * (qn & (GDP_R - 1))]; nuv[1] = s_ring[2 * (qn & (GDP_R - 1)) + 1]; }
+        }
+        if (hp) {
+          if (g.pd >= base) refs |= (uint32_t)(g.pd - base + 1) << 8;
+          else if (g.pd < base - GDP_R) { puv[0] = out[2 * (size_t)g.pd]; puv[1] = out[2 * (size_t)g.pd + 1]; }
+          else { puv[0] = s_ring[2 * (g.pd & (GDP_R - 1))]; puv[1] = s_ring[2 * (g.pd & (GDP_R - 1)) + 1]; }
+        }
+        const bool fast = small_uv && g.pn2 > 0 && g.pn2 < (1ll << 35) && g.dd > -(1ll << 35) && g.dd < (1ll << 35) && g.ns >= 0 && g.ns < (1ll << 35);
+        st[0] = (hn ? 1 : 0) | (hp ? 2 : 0) | (qn >= 0 ? 4 : 0) | (fast ? 8 : 0); st[1] = (int32_t)refs; st[2] = nuv[0]; st[3] = nuv[1]; st[4] = puv[0]; st[5] = puv[1];
+        st[6] = sy0; st[7] = sy1;
+        st[8] = (int32_t)(uint32_t)g.pn2; st[9] = (int32_t)(g.pn2 >> 32); st[10] = (int32_t)(uint32_t)g.dd; st[11] = (int32_t)(g.dd >> 32); st[12] = (int32_t)(uint32_t)g.ns; st[13] = (int32_t)(g.ns >> 32);
+        const double rp = fast ? 1.0 / (double)g.pn2 : 0.0;
+        *reinterpret_cast<double *>(st + 14) = rp;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        const int cnt = ne - base < 64 ? ne - base : 64;
+        int used = 0;
+        for (int j = 0; j < cnt; j++) {
+          const int32_t *st = s_stage + j * GDP_STAGE;
+          const uint32_t fl = (uint32_t)st[0], refs = (uint32_t)st[1];
+          const uint32_t rn = refs & 255u, rp_ = refs >> 8;
+          // both possible references and the next orientation bit in one LDS round trip
+          const int32_t tn0 = s_tile[2 * (rn ? rn - 1 : 0)], tn1 = s_tile[2 * (rn ? rn - 1 : 0) + 1], tp0 = s_tile[2 * (rp_ ? rp_ - 1 : 0)], tp1 = s_tile[2 * (rp_ ? rp_ - 1 : 0) + 1];
+          const int o_ = s_ori[used & 63];
+          const int32_t nuv[2] = { rn ? tn0 : st[2], rn ? tn1 : st[3] }, puv[2] = { rp_ ? tp0 : st[4], rp_ ? tp1 : st[5] };
+          const long long pn2 = *reinterpret_cast<const long long *>(st + 8), dd = *reinterpret_cast<const long long *>(st + 10), ns_ = *reinterpret_cast<const long long *>(st + 12);
+          const bool both = (fl & 2u) != 0, same = puv[0] == nuv[0] && puv[1] == nuv[1], par = both && !same && pn2 != 0;
+          int32_t pred[2] = { (fl & 4u) ? nuv[0] : 0, (fl & 4u) ? nuv[1] : 0 };       // the 'next' vertex's value or the previous entry's (both && same: equal to puv)
+          if (par) {
+            if (nori <= 0) { J.status = -27; s_bad = 1; break; }
+            nori--; used++;
+            if (fl & 8u) {
+              // (xuv +- cxuv) / pn2, truncated: all terms are integers below 2^53, so the f64 sums are exact; the quotient estimate
+              // through the staged reciprocal is within one of the truth and the remainder (one fma, exact) settles it
+              const double P = (double)pn2, D = (double)dd, NS = (double)ns_, RP = *reinterpret_cast<const double *>(st + 14);
+              const double pu = (double)(puv[0] - nuv[0]), pv = (double)(puv[1] - nuv[1]);
+              const double cs = o_ ? NS : -NS;
+              const double n0 = fma((double)nuv[0], P, fma(D, pu, pv * cs)), n1 = fma((double)nuv[1], P, fma(D, pv, -(pu * cs)));
+#pragma unroll
+              for (int k = 0; k < 2; k++) {
+                const double nk = k ? n1 : n0;
+                double q = trunc(nk * RP); const double r = fma(-q, P, nk);
+                const double up = nk >= 0 ? (r >= P ? 1.0 : 0.0) : (r > 0 ? 1.0 : 0.0), dn = nk >= 0 ? (r < 0 ? 1.0 : 0.0) : (r <= -P ? 1.0 : 0.0);
+                q += up - dn;
+                pred[k] = (int32_t)q;
+              }
+            } else {
+              const long long pnuv[2] = { (long long)puv[0] - nuv[0], (long long)puv[1] - nuv[1] };
+              const long long xuv[2] = { nuv[0] * pn2 + dd * pnuv[0], nuv[1] * pn2 + dd * pnuv[1] };
+              const long long cxuv[2] = { pnuv[1] * ns_, -pnuv[0] * ns_ };
+              if (o_) { pred[0] = (int32_t)((xuv[0] + cxuv[0]) / pn2); pred[1] = (int32_t)((xuv[1] + cxuv[1]) / pn2); }
+              else { pred[0] = (int32_t)((xuv[0] - cxuv[0]) / pn2); pred[1] = (int32_t)((xuv[1] - cxuv[1]) / pn2); }
+            }
+          }
+          s_tile[2 * j] = gd_wrap(pred[0], st[6], lo, hi); s_tile[2 * j + 1] = gd_wrap(pred[1], st[7], lo, hi);
+        }
+        s_nori = nori;
+      }
+      __syncthreads();
+      if (s_bad) return;
+      if (e < ne) { const int32_t v0 = s_tile[2 * lane], v1 = s_tile[2 * lane + 1]; out[2 * (size_t)e] = v0; out[2 * (size_t)e + 1] = v1; s_ring[2 * (e & (GDP_R - 1))] = v0; s_ring[2 * (e & (GDP_R - 1)) + 1] = v1; }
+    }
+    if (lane == 0 && nori != 0) J.status = -28;
   }
 }
 
@@ -748,8 +864,8 @@ __global__ void __launch_bounds__(64) k_gdec_seq_conn(GeoDecJob *jobs) {
 
 // flip bits of the normal decoders: the only sequential part of the geometric-normal scheme (one lane per decoder)
 __global__ void __launch_bounds__(64) k_gdec_flips(GeoDecJob *jobs, GeoJob *gj) {
-  GeoDecJob &J = jobs[blockIdx.y]; const GeoJob &G = gj[blockIdx.y];
-  const int d = blockIdx.x;
+  GeoDecJob &J = jobs[blockIdx.x]; const GeoJob &G = gj[blockIdx.x];
+  const int d = blockIdx.y;
   if (threadIdx.x != 0 || J.status != 0 || G.status != 0 || d >= J.ndec) return;
   GDAtt &A = J.att[d];
   if (A.pred_method != 6) return;
@@ -935,7 +1051,7 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
   const unsigned N = (unsigned)n, bc = uvol_blocks((size_t)3 * max_nf);
   GLAUNCH(k_gdec_clear, dim3(64, N), dim3(UVOL_BLOCK), 0, dj);
   { uvol_ctx::Scope sc(ctx, "geodec.k1_index", 0); GLAUNCH(k_gdec_init, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj); GLAUNCH(k_gdec_index, dim3(N), dim3(64), 0, dj); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(6, N), dim3(64), 0, dj, 0, 6); }
+  { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, 6), dim3(64), 0, dj, 0, 6); }
   { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn<false>, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_conn<true>, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 0); }
   { uvol_ctx::Scope sc(ctx, "geodec.k4_seams_tables", 0);
     GLAUNCH(k_gdec_seams, dim3(N), dim3(64), 0, dj);
@@ -948,15 +1064,15 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
   { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
     if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) return rc;
     GLAUNCH(k_gdec_counts, dim3(N), dim3(64), 0, dj, gj); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(GD_MAXDEC, N), dim3(64), 0, dj, 6, GD_MAXDEC);
+  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, GD_MAXDEC), dim3(64), 0, dj, 6, GD_MAXDEC);
     GLAUNCH(k_gdec_seq_conn, dim3(N), dim3(64), 0, dj); }                  // frames with sequential connectivity: their index section
   { uvol_ctx::Scope sc(ctx, "geodec.k7_predict", 0);
     GLAUNCH(k_gdec_pgram, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
-    GLAUNCH(k_gdec_flips, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj);
-    GLAUNCH(k_gdec_pred, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj, 0);
+    GLAUNCH(k_gdec_flips, dim3(N, GD_MAXDEC), dim3(64), 0, dj, gj);
+    GLAUNCH(k_gdec_pred, dim3(N, GD_MAXDEC), dim3(64), 0, dj, gj, 0);
     GLAUNCH(k_gdec_normals, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
     GLAUNCH(k_gdec_uvgeo, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
-    GLAUNCH(k_gdec_pred, dim3(GD_MAXDEC, N), dim3(64), 0, dj, gj, 1); }
+    GLAUNCH(k_gdec_pred, dim3(N, GD_MAXDEC), dim3(64), 0, dj, gj, 1); }
   { uvol_ctx::Scope sc(ctx, "geodec.k8_finish", 0); GLAUNCH(k_gdec_finish, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(GeoDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
