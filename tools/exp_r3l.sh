@@ -1,0 +1,11 @@
+#!/bin/bash
+# small jobs after the frame-major grid of the wave-per-stream entropy coder
+mkdir -p gpurun_out/r03_l
+for n in 150 300; do
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --frames-per-step $n > gpurun_out/r03_l/bench_n$n.json 2> gpurun_out/r03_l/err.log
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/r03_l/bench_n$n.json').read().strip().splitlines()[-1]); g=d['kernel_groups_ms_per_step']
+print('N', $n, 'fps', round(d['value'],1), 'ms', round(d['ms_per_step'],1), {k:round(v,1) for k,v in g.items() if k.startswith('geo')})
+PY
+done

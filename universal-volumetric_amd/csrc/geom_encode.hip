@@ -2308,7 +2308,7 @@ __device__ __forceinline__ uint2 g_recip(uint32_t d) {          // {m, s - 1}; d
     st = st + (ADD) + q_ * (MULT);                                                                              \
   }
 __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
-  GeoJob &J = jobs[blockIdx.y];
+  GeoJob &J = jobs[blockIdx.x];
 #ifndef HIPEMU
   const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
 #endif
@@ -2317,8 +2317,8 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
   const uint32_t lane = threadIdx.x;
   const bool ok = J.status == 0;
   uint32_t stage = 0, w = 0;
-  if (blockIdx.x < GEO_NSTREAM) {
-    RansStream &S = J.rs[blockIdx.x];
+  if (blockIdx.y < GEO_NSTREAM) {
+    RansStream &S = J.rs[blockIdx.y];
     const uint32_t n = ok ? S.n : 0;
     const uint32_t ns = S.max_sym + 1;
     const bool in_lds = ns <= RANS_LDS_ENTRIES;
@@ -2369,7 +2369,7 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
       }
     }
 #ifndef HIPEMU
-    if (dbg && blockIdx.y == 0 && lane == 0) printf("[entropy] rans stream %d: n=%u alphabet=%u bytes=%u  %.3f ms\n", (int)blockIdx.x, n, ns, w, (double)(wall_clock64() - t_begin) * 1e-5);
+    if (dbg && blockIdx.x == 0 && lane == 0) printf("[entropy] rans stream %d: n=%u alphabet=%u bytes=%u  %.3f ms\n", (int)blockIdx.y, n, ns, w, (double)(wall_clock64() - t_begin) * 1e-5);
 #endif
     if (w + 4 > cap) { if (lane == 0) J.status = -32; return; }
     if (lane < (w & 63)) pay[(w & ~63u) + lane] = (uint8_t)stage;
@@ -2385,7 +2385,7 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
       S.pay_off = 8 - vl; S.pay_len = vl + w;
     }
   } else {
-    RabsStream &B = J.rb[blockIdx.x - GEO_NSTREAM];
+    RabsStream &B = J.rb[blockIdx.y - GEO_NSTREAM];
     __syncthreads();
     if (!ok) return;
     const uint32_t n = B.n; const uint64_t total = n ? n : 1;
@@ -2415,7 +2415,7 @@ __global__ void __launch_bounds__(64) k_entropy_encode(GeoJob *jobs, int dbg) {
       }
     }
 #ifndef HIPEMU
-    if (dbg && blockIdx.y == 0 && lane == 0) printf("[entropy] rabs stream %d: n=%u bytes=%u  %.3f ms\n", (int)blockIdx.x - GEO_NSTREAM, n, w, (double)(wall_clock64() - t_begin) * 1e-5);
+    if (dbg && blockIdx.x == 0 && lane == 0) printf("[entropy] rabs stream %d: n=%u bytes=%u  %.3f ms\n", (int)blockIdx.y - GEO_NSTREAM, n, w, (double)(wall_clock64() - t_begin) * 1e-5);
 #endif
     if (w + 3 > cap) { if (lane == 0) J.status = -33; return; }
     if (lane < (w & 63)) pay[(w & ~63u) + lane] = (uint8_t)stage;
@@ -3385,7 +3385,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     static const int ent_env = [] { const char *e = getenv("UVOL_ENTROPY_WAVE"); return !e ? -1 : (*e == '1' ? 1 : 0); }();
     static const int ent_w_env = [] { const char *e = getenv("UVOL_ENTROPY_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // lanes per wave of the lane form (implies it)
     const bool ent_wave = ent_env >= 0 ? ent_env == 1 : (ent_w_env == 0 && (size_t)(GEO_NSTREAM + GEO_NRABS) * N <= (size_t)20 * G->num_cu);
-    if (ent_wave) LAUNCH(k_entropy_encode, dim3(GEO_NSTREAM + GEO_NRABS, N), dim3(64), dj, uvol_debug() ? 1 : 0);
+    if (ent_wave) LAUNCH(k_entropy_encode, dim3(N, GEO_NSTREAM + GEO_NRABS), dim3(64), dj, uvol_debug() ? 1 : 0);      // frame index fastest: the long streams of the frames spread over the four SIMDs of a CU (geom_decode.hip: k_gdec_rans)
     else {
       // lanes per wave: five streams of a frame are long (three attribute symbol streams, two seam-bit streams; ~300 k steps) and a
       // wave runs as long as its longest lane, so the launch should put at most ONE long wave on a SIMD (1024 of them): waves that
