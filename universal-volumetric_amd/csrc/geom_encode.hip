@@ -211,7 +211,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_scatter(GeoJob *jobs) {
     }
   }
 }
-// pass 4: one workgroup per bin: LDS hash table slot -> (record of the first value that claimed it, lowest index of its value)
+// pass 4: one workgroup per bin: LDS hash table slot -> (record of the first value that claimed it, lowest index of its value).
+// A thread's records are fetched together (DD_PER independent 16-byte loads) and the bin's keys are staged in LDS, so a probe
+// that meets an occupied slot compares against LDS: with a global read of the slot's record per probe every trip of the loop was
+// two dependent round trips for the whole wave.
+#define DD_PER 6
+#define DD_KEYS (UVOL_BLOCK * DD_PER)          // keys of a bin held in LDS (bins average ~1 k values; the rest compares through global memory)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_resolve(GeoJob *jobs, uint32_t slots) {
   JOB_OR_RETURN_UNIFORM;
   const int which = (int)blockIdx.z; const DdSrc S = dd_src(J, which);
@@ -220,21 +225,32 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_resolve(GeoJob *jobs, uint32_
   const uint32_t lo = J.dd_cnt[which][(size_t)blockIdx.x * nblk], hi = J.dd_cnt[which][(size_t)(blockIdx.x + 1) * nblk];
   const uint4 *part = J.dd_part[which];
   __shared__ uint32_t t_rec[DD_SLOTS], t_min[DD_SLOTS];
+  __shared__ uint32_t kw0[DD_KEYS], kw1[DD_KEYS], kw2[DD_KEYS];
   __shared__ uint32_t n_ins, any_dup, fail;
   for (uint32_t s = threadIdx.x; s < slots; s += UVOL_BLOCK) { t_rec[s] = 0; t_min[s] = 0xffffffffu; }
   if (threadIdx.x == 0) { n_ins = 0; any_dup = 0; fail = 0; }
-  __syncthreads();
-  for (uint32_t e0 = lo; e0 < hi; e0 += UVOL_BLOCK) {
-    const uint32_t e = e0 + threadIdx.x;
-    if (e < hi) {
-      const uint4 r = part[e]; const uint32_t w[3] = { r.y, r.z, r.w };
+#define DD_SAME(c, r) ((c) - 1 < DD_KEYS ? (kw0[(c) - 1] == (r).y && kw1[(c) - 1] == (r).z && kw2[(c) - 1] == (r).w) \
+                                        : (part[lo + (c) - 1].y == (r).y && part[lo + (c) - 1].z == (r).z && part[lo + (c) - 1].w == (r).w))
+  for (uint32_t e0 = lo; e0 < hi; e0 += DD_KEYS) {
+    uint4 r[DD_PER];
+#pragma unroll
+    for (int k = 0; k < DD_PER; k++) { const uint32_t e = e0 + k * UVOL_BLOCK + threadIdx.x; r[k] = e < hi ? part[e] : make_uint4(0, 0, 0, 0); }
+    if (e0 == lo) {
+#pragma unroll
+      for (int k = 0; k < DD_PER; k++) { const uint32_t q = k * UVOL_BLOCK + threadIdx.x; kw0[q] = r[k].y; kw1[q] = r[k].z; kw2[q] = r[k].w; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DD_PER; k++) {
+      const uint32_t e = e0 + k * UVOL_BLOCK + threadIdx.x;
+      if (e >= hi) continue;
+      const uint32_t w[3] = { r[k].y, r[k].z, r[k].w };
       uint32_t s = dd_slot(dd_hash(w, S.nw), slots);
       for (uint32_t guard = 0;; guard++) {
         if (guard >= slots) { fail = 1; break; }
         uint32_t c = t_rec[s];
-        if (c == 0) { const uint32_t old = atomicCAS(&t_rec[s], 0u, e - lo + 1); if (old == 0) { atomicMin(&t_min[s], r.x); atomicAdd(&n_ins, 1u); break; } c = old; }
-        const uint4 o = part[lo + c - 1];
-        if (o.y == r.y && o.z == r.z && o.w == r.w) { atomicMin(&t_min[s], r.x); any_dup = 1; break; }
+        if (c == 0) { const uint32_t old = atomicCAS(&t_rec[s], 0u, e - lo + 1); if (old == 0) { atomicMin(&t_min[s], r[k].x); atomicAdd(&n_ins, 1u); break; } c = old; }
+        if (DD_SAME(c, r[k])) { atomicMin(&t_min[s], r[k].x); any_dup = 1; break; }
         s = (s + 1) & (slots - 1);
       }
     }
@@ -250,12 +266,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_resolve(GeoJob *jobs, uint32_
       for (uint32_t guard = 0; guard < slots; guard++) {
         const uint32_t c = t_rec[s];
         if (c == 0) break;
-        const uint4 o = part[lo + c - 1];
-        if (o.y == r.y && o.z == r.z && o.w == r.w) { if (t_min[s] != r.x) J.canon[which][r.x] = t_min[s]; break; }
+        if (DD_SAME(c, r)) { if (t_min[s] != r.x) J.canon[which][r.x] = t_min[s]; break; }
         s = (s + 1) & (slots - 1);
       }
     }
   }
+#undef DD_SAME
 }
 
 // three ints moved as one 12-byte access
@@ -1220,6 +1236,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_flags(GeoJob *jobs) {
 __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  // events are rare (two per S symbol): a block whose scanned sums say 'none' has nothing to place (uniform: read by every thread
+  // from the same two words)
+  if (J.status == 0 && blockIdx.x != 0 && blockIdx.x < uvol_blocks_dev(J.nf) && J.bsum2[blockIdx.x + 1] == J.bsum2[blockIdx.x]) return;
   const bool live = J.status == 0 && i < J.nf;
   uint32_t v = live ? J.evcnt[i] : 0, tot;
   const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum2[blockIdx.x] : 0);
@@ -1234,7 +1253,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
 __global__ void __launch_bounds__(UVOL_BLOCK) k_valence_init(GeoJob *jobs) {
   JOB_OR_RETURN;
   const uint32_t t = blockIdx.x * UVOL_BLOCK + threadIdx.x, stride = gridDim.x * UVOL_BLOCK;
-  for (uint32_t c = t; c < J.nc; c += stride) J.c2vm[c] = J.vert[c];
+  { const uint32_t n4 = J.nc / 4;                                                     // 16 bytes per lane (both arrays are 16-byte aligned)
+    const uint4 *src = reinterpret_cast<const uint4 *>(J.vert); uint4 *dst = reinterpret_cast<uint4 *>(J.c2vm);
+    for (uint32_t q = t; q < n4; q += stride) dst[q] = src[q];
+    for (uint32_t c = 4 * n4 + t; c < J.nc; c += stride) J.c2vm[c] = J.vert[c]; }
   const uint32_t nv0 = J.nverts_t[0] < J.ecap ? J.nverts_t[0] : J.ecap;
   for (uint32_t v = t; v < nv0; v += stride) J.vval[v] = J.ring_d[v];
 }
@@ -1409,20 +1431,34 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_seams(GeoJob *jobs) {
   __syncthreads();
   if (threadIdx.x < 3) { const uint32_t b = 3 * blockIdx.x + threadIdx.x; if (b < uvol_blocks_dev(J.nc)) J.bsum[b] = ecnt[threadIdx.x]; }
 }
+// seam bits of the eligible corners, in corner order.  SB_E corners per thread (8-byte loads of the flags and of both seam
+// arrays): with one corner per thread the kernel was 5 M workgroups per batch, each a chain of two byte loads and a scan
+#define SB_E 8
 __global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
-  uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  bool live = J.status == 0 && c < J.nc;
-  uint32_t v = live ? J.elig[c] : 0, tot;
-  uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nc)) ? J.bsum[blockIdx.x] : 0);
-  // zero counts: one global atomic per block and attribute (was one per wave on the same two words: 9 k per frame)
+  const bool ok = J.status == 0;
+  const uint32_t nc = ok ? J.nc : 0u, c0 = (blockIdx.x * UVOL_BLOCK + threadIdx.x) * SB_E;
+  unsigned long long e8 = 0;
+  if (c0 + SB_E <= nc) e8 = *reinterpret_cast<const unsigned long long *>(J.elig + c0);
+  else for (uint32_t k = 0; c0 + k < nc && k < SB_E; k++) e8 |= (unsigned long long)J.elig[c0 + k] << (8 * k);
+  e8 &= 0x0101010101010101ull;
+  uint32_t cnt = (uint32_t)__popcll(e8), tot;
+  uint32_t pos = block_excl_scan(cnt, &tot) + ((ok && blockIdx.x * SB_E <= uvol_blocks_dev(J.nc)) ? J.bsum[blockIdx.x * SB_E] : 0);
+  // zero counts: one global atomic per block and attribute
   __shared__ uint32_t zc[2];
   if (threadIdx.x < 2) zc[threadIdx.x] = 0;
   __syncthreads();
-  if (live && v) for (int i = 0; i < J.nad; i++) { uint8_t s = J.seam[i][c]; J.seam_bits[i][pos] = s; if (!s) atomicAdd(&zc[i], 1u); }
+  if (cnt) for (int i = 0; i < J.nad; i++) {
+    unsigned long long s8 = 0;
+    if (c0 + SB_E <= nc) s8 = *reinterpret_cast<const unsigned long long *>(J.seam[i] + c0);
+    else for (uint32_t k = 0; c0 + k < nc && k < SB_E; k++) s8 |= (unsigned long long)J.seam[i][c0 + k] << (8 * k);
+    uint32_t p = pos, z = 0;
+    for (int k = 0; k < SB_E; k++) if ((e8 >> (8 * k)) & 1ull) { const uint8_t sb = (uint8_t)(s8 >> (8 * k)); J.seam_bits[i][p++] = sb; z += sb ? 0u : 1u; }
+    if (z) atomicAdd(&zc[i], z);
+  }
   __syncthreads();
   if (threadIdx.x < 2 && zc[threadIdx.x]) atomicAdd(&J.rb[1 + threadIdx.x].zeros, zc[threadIdx.x]);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ok) {
     uint32_t n = J.bsum[uvol_blocks_dev(J.nc)];
     J.n_elig = n; for (int i = 0; i < J.nad; i++) J.rb[1 + i].n = n;
   }
@@ -3335,7 +3371,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_renumber_seams, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
-    LAUNCH(k_seam_bits, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_seam_bits, dim3((bc + SB_E - 1) / SB_E, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_aseg_a, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_aseg_b, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
   }
