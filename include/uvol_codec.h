@@ -120,7 +120,11 @@ int uvol_encode_mesh_batch_dev_async(uvol_ctx *ctx, const uvol_mesh *meshes, int
 
 /* Replaces one `basisu -ktx2 -tex_type video` process (scripts/Encoder.py:290-292):
  * n_layers RGBA8 images (width*height*4 bytes each, top row first as a PNG decoder yields them)
- * -> one ETC1S/BasisLZ .ktx2 with n_layers array layers (layer 0 I-frame, others P-frames). */
+ * -> one ETC1S/BasisLZ .ktx2 with n_layers array layers (layer 0 I-frame, others P-frames).
+ * A segment any of whose images has alpha != 255 gets ALPHA SLICES, as basisu writes them and the stock player reads them
+ * (src/lib/KTX2Loader.js:493-497): a second slice per image (the alpha channel as a grey image through the same codebooks), a second
+ * DFD sample (channel 15) and the image descs' second offset / length pair; opaque segments are unchanged, and the two kinds may
+ * share a batch.  Read back by uvol_decode_texture_segments (RGBA32); the opaque targets (ETC1 / BC7) refuse such a file. */
 size_t uvol_texture_bound(uint32_t width, uint32_t height, int n_layers);
 int uvol_encode_texture_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers,
                                 uint32_t width, uint32_t height,
@@ -151,7 +155,7 @@ int uvol_encode_texture_segments_dev_async(uvol_ctx *ctx, const uint8_t *const *
  * Replaces, for the RGBA32 target, what the stock player does per .ktx2 segment: KTX2Loader parses the container and
  * hands every array layer to the basis transcoder (reference src/lib/KTX2Loader.js:469-580; src/V2/player.ts:338-356
  * uploads the layers as one sampler2DArray).  Input: BasisLZ/ETC1S .ktx2 files as uvol_encode_texture_segment[s] or
- * `basisu -ktx2 -tex_type video` write them (no alpha slices, one mip level), or the UASTC .ktx2 files this codec writes with
+ * `basisu -ktx2 -tex_type video` write them (with or without alpha slices, one mip level), or the UASTC .ktx2 files this codec writes with
  * uvol_params.uastc (told apart by the DFD colour model).  Output: RGBA8, rows in stored order. */
 /* host-only: container dimensions of one file (UVOL_E_INVALID if it is not a KTX2/BasisLZ file this decoder handles;
  * UVOL_E_UNSUPPORTED for a UASTC file whose level data are Zstandard-supercompressed - the default of stock `basisu -uastc -ktx2`;

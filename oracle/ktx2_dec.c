@@ -90,15 +90,24 @@ int ktx2_decode(const uint8_t *b, size_t n, ktx2_file *f) {
       if (!strcmp(key, "KTXanimData") && len >= kl + 1 + 12) { f->has_anim = 1; f->anim_duration = rd32(b + o + kl + 1); f->anim_timescale = rd32(b + o + kl + 5); f->anim_loops = rd32(b + o + kl + 9); }
       o += (len + 3) & ~3u;
     } }
-  const int nsl = (int)(f->layers ? f->layers : 1);
+  const int nimg = (int)(f->layers ? f->layers : 1);
+  if (nimg > KTX2_MAX_LAYERS) return -4;
+  const uint8_t *s = b + f->sgd_off;
+  if (f->sgd_len < 20 + 20 * (uint64_t)nimg) return -5;
+  /* alpha slices: announced by a second DFD sample (channel 15, AAA) and carried by the image descs' second offset / length pair;
+   * all images of a file have one or none.  Slice order: rgb0 a0 rgb1 a1 ...; a P-frame slice refers to the previous slice of its kind */
+  { int any = 0, all = 1; for (int i = 0; i < nimg; i++) { const uint8_t *d = s + 20 + 20 * i; if (rd32(d + 16)) any = 1; else all = 0; }
+    if (any != all) return -6;
+    f->has_alpha = any;
+    if (any && !(f->dfd_len >= 60 && (b[f->dfd_off + 44 + 3] & 15) == 15)) return -6; }
+  const int stride = f->has_alpha ? 2 : 1, nsl = nimg * stride;
   if (nsl > KTX2_MAX_LAYERS) return -4;
   f->n_slices = nsl;
-  const uint8_t *s = b + f->sgd_off;
-  if (f->sgd_len < 20 + 20 * (uint64_t)nsl) return -5;
   f->n_endpoints = s[0] | (s[1] << 8); f->n_selectors = s[2] | (s[3] << 8);
   f->endpoints_len = rd32(s + 4); f->selectors_len = rd32(s + 8); f->tables_len = rd32(s + 12); f->extended_len = rd32(s + 16);
-  for (int i = 0; i < nsl; i++) { const uint8_t *d = s + 20 + 20 * i; f->slice_flags[i] = rd32(d); f->slice_off[i] = rd32(d + 4); f->slice_len[i] = rd32(d + 8); if (rd32(d + 12) || rd32(d + 16)) return -6; /* alpha slices unsupported */ }
-  const uint8_t *p = s + 20 + 20 * nsl;
+  for (int i = 0; i < nimg; i++) { const uint8_t *d = s + 20 + 20 * i;
+    for (int k = 0; k < stride; k++) { f->slice_flags[i * stride + k] = rd32(d); f->slice_off[i * stride + k] = rd32(d + 4 + 8 * k); f->slice_len[i * stride + k] = rd32(d + 8 + 8 * k); } }
+  const uint8_t *p = s + 20 + 20 * nimg;
   if ((uint64_t)(p - s) + f->endpoints_len + f->selectors_len + f->tables_len > f->sgd_len) return -5;
   const uint32_t ne = f->n_endpoints, ns = f->n_selectors;
   int rc = 0;
@@ -163,10 +172,10 @@ int ktx2_decode(const uint8_t *b, size_t n, ktx2_file *f) {
     for (int sl = 0; sl < nsl && !rc; sl++) {
       if ((uint64_t)f->slice_off[sl] + f->slice_len[sl] > f->level_len) { rc = -11; break; }
       const int is_p = (f->slice_flags[sl] & 2) != 0;
-      if (is_p && sl == 0) { rc = -11; break; }
+      if (is_p && sl < stride) { rc = -11; break; }
       bitr R = { b + f->level_off + f->slice_off[sl], f->slice_len[sl], 0 };
       uint16_t *oe = f->block_ei + (size_t)sl * bx * by, *os = f->block_si + (size_t)sl * bx * by;
-      const uint16_t *pve = sl ? oe - (size_t)bx * by : NULL, *pvs = sl ? os - (size_t)bx * by : NULL;
+      const uint16_t *pve = sl >= stride ? oe - (size_t)stride * bx * by : NULL, *pvs = sl >= stride ? os - (size_t)stride * bx * by : NULL;
       uint32_t hist[64]; for (uint32_t i = 0; i < hs; i++) hist[i] = i;
       uint32_t rover = hs / 2, RLE = ns + hs, prev_sym = 0, rep = 0, prev_ei = 0, sel_rle = 0, nskip = 0;
       memset(pe[0], 0, 2 * (bx + 1)); memset(pe[1], 0, 2 * (bx + 1)); memset(pb[0], 0, bx + 1); memset(pb[1], 0, bx + 1);
@@ -226,15 +235,20 @@ static inline uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 
 
 void ktx2_layer_rgba(const ktx2_file *f, int layer, uint8_t *out) {
   const uint32_t bx = f->bx, by = f->by, W = f->width, H = f->height;
-  const uint16_t *ei = f->block_ei + (size_t)layer * bx * by, *si = f->block_si + (size_t)layer * bx * by;
+  const int stride = f->has_alpha ? 2 : 1;
+  const uint16_t *ei = f->block_ei + (size_t)layer * stride * bx * by, *si = f->block_si + (size_t)layer * stride * bx * by;
+  const uint16_t *aei = ei + (size_t)bx * by, *asi = si + (size_t)bx * by;          /* the alpha slice (read only with has_alpha) */
   for (uint32_t Y = 0; Y < by; Y++) for (uint32_t X = 0; X < bx; X++) {
     const uint8_t *e = f->endpoints + 4 * (size_t)ei[X + Y * bx]; const uint32_t sel = f->selectors[si[X + Y * bx]];
     int base[3]; for (int c = 0; c < 3; c++) base[c] = (e[c] << 3) | (e[c] >> 2);
+    const uint8_t *ae = f->has_alpha ? f->endpoints + 4 * (size_t)aei[X + Y * bx] : NULL; const uint32_t asel = f->has_alpha ? f->selectors[asi[X + Y * bx]] : 0;
+    const int abase = ae ? ((ae[1] << 3) | (ae[1] >> 2)) : 0;
     for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
       uint32_t px = X * 4 + x, py = Y * 4 + y; if (px >= W || py >= H) continue;
       int s = (int)((sel >> (8 * y + 2 * x)) & 3), d = INTEN[e[3]][s];
       uint8_t *o = out + 4 * ((size_t)py * W + px);
-      o[0] = clamp255(base[0] + d); o[1] = clamp255(base[1] + d); o[2] = clamp255(base[2] + d); o[3] = 255;
+      o[0] = clamp255(base[0] + d); o[1] = clamp255(base[1] + d); o[2] = clamp255(base[2] + d);
+      o[3] = ae ? clamp255(abase + INTEN[ae[3]][(asel >> (8 * y + 2 * x)) & 3]) : 255;
     }
   }
 }

@@ -176,11 +176,17 @@ static uint32_t bsearch_u32(const uint32_t *a, uint32_t n, uint32_t key) { uint3
 
 static void cell_coords(uint32_t cell, int32_t x[4]) { x[0] = expand5((cell >> 10) & 31); x[1] = expand5((cell >> 5) & 31); x[2] = expand5(cell & 31); x[3] = INTEN[(cell >> 15) & 7][3]; }
 
-int ktx2_encode(const uint8_t *const *layers, int L, uint32_t W, uint32_t H, const ktx2_enc_params *prm, orc_buf *out) {
-  if (L < 1 || L > KTX2_MAX_LAYERS || W == 0 || H == 0 || W > 16384 || H > 16384) return -1;
-  /* basisu writes alpha slices for images with alpha != 255; neither this restatement nor the product implements them:
-   * both refuse such input (the product with UVOL_E_UNSUPPORTED) instead of dropping the channel */
-  for (int l = 0; l < L; l++) for (size_t i = 0; i < (size_t)W * H; i++) if (layers[l][4 * i + 3] != 255) return -60;
+int ktx2_encode(const uint8_t *const *layers, int Lr, uint32_t W, uint32_t H, const ktx2_enc_params *prm, orc_buf *out) {
+  if (Lr < 1 || Lr > KTX2_MAX_LAYERS || W == 0 || H == 0 || W > 16384 || H > 16384) return -1;
+  /* Alpha (basisu: any source image with alpha != 255 gives the file alpha slices; KTX2Loader.js:493-497 reads them): every
+   * image then contributes TWO slices, colour and alpha, in the order rgb0 a0 rgb1 a1 ...; the alpha slice is the image
+   * (a, a, a) run through the same block model, the same two codebooks and the same Huffman tables; a P-frame slice refers
+   * to the previous slice OF ITS KIND.  Below, `L` counts slices ("virtual layers"): slice v shows image v / stride,
+   * kind v % stride (0 colour, 1 alpha), and its predecessor is slice v - stride.  PARITY UNPINNED: no reference fixture has alpha. */
+  int has_alpha = 0;
+  for (int l = 0; l < Lr && !has_alpha; l++) for (size_t i = 0; i < (size_t)W * H; i++) if (layers[l][4 * i + 3] != 255) { has_alpha = 1; break; }
+  const int stride = has_alpha ? 2 : 1, L = Lr * stride;
+  if (L > KTX2_MAX_LAYERS) return -1;
   const int q = clampi(prm && prm->quality > 0 ? prm->quality : 128, 1, 255), yflip = prm ? prm->y_flip : 1;
   const uint32_t bx = (W + 3) / 4, by = (H + 3) / 4, nb = bx * by, NB = nb * (uint32_t)L;
   const uint32_t Kmax_e = (uint32_t)clampi(q * 12, 32, 16128), Kmax_s = (uint32_t)clampi(q * 6, 32, 16128);
@@ -192,15 +198,16 @@ int ktx2_encode(const uint8_t *const *layers, int L, uint32_t W, uint32_t H, con
     for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
       uint32_t px = X * 4 + x, py = Y * 4 + y; if (px >= W) px = W - 1; if (py >= H) py = H - 1;
       uint32_t sr = yflip ? H - 1 - py : py;
-      const uint8_t *p = layers[l] + 4 * ((size_t)sr * W + px);
-      b->px[y * 4 + x][0] = p[0]; b->px[y * 4 + x][1] = p[1]; b->px[y * 4 + x][2] = p[2];
+      const uint8_t *p = layers[l / stride] + 4 * ((size_t)sr * W + px);
+      if (l % stride) { b->px[y * 4 + x][0] = b->px[y * 4 + x][1] = b->px[y * 4 + x][2] = p[3]; }
+      else { b->px[y * 4 + x][0] = p[0]; b->px[y * 4 + x][1] = p[1]; b->px[y * 4 + x][2] = p[2]; }
     }
   }
   /* ---- step 0: P-frame skip flags against the anchor (last coded) source block ---- */
   uint8_t *skip = (uint8_t *)calloc(NB, 1);
-  for (uint32_t b = 0; b < nb; b++) {
-    int anchor = 0;
-    for (int l = 1; l < L; l++) {
+  for (uint32_t b = 0; b < nb; b++) for (int kind = 0; kind < stride; kind++) {
+    int anchor = kind;
+    for (int l = kind + stride; l < L; l += stride) {
       const blk *c = &B[(size_t)l * nb + b], *a = &B[(size_t)anchor * nb + b]; uint32_t d = 0;
       for (int i = 0; i < 16; i++) for (int k = 0; k < 3; k++) { int e = (int)c->px[i][k] - a->px[i][k]; d += (uint32_t)(e * e); }
       if (d <= T_skip) skip[(size_t)l * nb + b] = 1; else anchor = l;
@@ -297,7 +304,7 @@ int ktx2_encode(const uint8_t *const *layers, int L, uint32_t W, uint32_t H, con
   qsort(scu, ns, 4, cmp_u32); ns = uniq_sorted(scu, ns);
   for (uint32_t i = 0; i < nitems; i++) bsi[item[i]] = (uint16_t)bsearch_u32(scu, ns, scb[sleaf[i]]);
   /* skipped blocks copy the previous layer's final indices */
-  for (int l = 1; l < L; l++) for (uint32_t b = 0; b < nb; b++) if (skip[(size_t)l * nb + b]) { bei[(size_t)l * nb + b] = bei[(size_t)(l - 1) * nb + b]; bsi[(size_t)l * nb + b] = bsi[(size_t)(l - 1) * nb + b]; }
+  for (int l = stride; l < L; l++) for (uint32_t b = 0; b < nb; b++) if (skip[(size_t)l * nb + b]) { bei[(size_t)l * nb + b] = bei[(size_t)(l - stride) * nb + b]; bsi[(size_t)l * nb + b] = bsi[(size_t)(l - stride) * nb + b]; }
 
   /* ---- step I: symbolisation ---- */
   const uint32_t HS = 64, SEL_RLE = ns + HS;
@@ -307,7 +314,7 @@ int ktx2_encode(const uint8_t *const *layers, int L, uint32_t W, uint32_t H, con
   uint32_t *f_ep = (uint32_t *)calloc(257, 4), *f_de = (uint32_t *)calloc(ne + 1, 4), *f_sel = (uint32_t *)calloc(ns + HS + 2, 4), *f_rle = (uint32_t *)calloc(64, 4);
   uint8_t *pred = (uint8_t *)malloc(nb);
   for (int l = 0; l < L; l++) {
-    const uint16_t *ei = bei + (size_t)l * nb, *si = bsi + (size_t)l * nb; const uint8_t *sk = skip + (size_t)l * nb; const int is_p = l > 0;
+    const uint16_t *ei = bei + (size_t)l * nb, *si = bsi + (size_t)l * nb; const uint8_t *sk = skip + (size_t)l * nb; const int is_p = l >= stride;
     for (uint32_t y = 0; y < by; y++) for (uint32_t x = 0; x < bx; x++) {
       uint32_t b = y * bx + x; uint8_t p;
       if (is_p && sk[b]) p = 2;
@@ -419,24 +426,26 @@ int ktx2_encode(const uint8_t *const *layers, int L, uint32_t W, uint32_t H, con
   orc_buf kvd = {0};
   { ob_u32(&kvd, 12 + 12); ob_bytes(&kvd, "KTXanimData", 12); ob_u32(&kvd, 1); ob_u32(&kvd, 15); ob_u32(&kvd, 0);
     uint32_t wl = 10 + (uint32_t)sizeof(writer); ob_u32(&kvd, wl); ob_bytes(&kvd, "KTXwriter", 10); ob_bytes(&kvd, writer, sizeof(writer)); while (kvd.n & 3) ob_u8(&kvd, 0); }
-  const uint32_t dfd_off = 80 + 24, dfd_len = 44, kvd_off = dfd_off + dfd_len, kvd_len = (uint32_t)kvd.n;
+  const uint32_t dfd_off = 80 + 24, dfd_len = has_alpha ? 60 : 44, kvd_off = dfd_off + dfd_len, kvd_len = (uint32_t)kvd.n;
   uint64_t sgd_off = (kvd_off + kvd_len + 7) & ~7ull;
-  const uint64_t sgd_len = 20 + 20 * (uint64_t)L + wep.b.n + wsel.b.n + wtab.b.n;
+  const uint64_t sgd_len = 20 + 20 * (uint64_t)Lr + wep.b.n + wsel.b.n + wtab.b.n;
   const uint64_t lvl_off = sgd_off + sgd_len;
   ob_bytes(out, ident, 12);
-  ob_u32(out, 0); ob_u32(out, 1); ob_u32(out, W); ob_u32(out, H); ob_u32(out, 0); ob_u32(out, (uint32_t)L); ob_u32(out, 1); ob_u32(out, 1); ob_u32(out, 1);
+  ob_u32(out, 0); ob_u32(out, 1); ob_u32(out, W); ob_u32(out, H); ob_u32(out, 0); ob_u32(out, (uint32_t)Lr); ob_u32(out, 1); ob_u32(out, 1); ob_u32(out, 1);
   ob_u32(out, dfd_off); ob_u32(out, dfd_len); ob_u32(out, kvd_off); ob_u32(out, kvd_len); ob_u64(out, sgd_off); ob_u64(out, sgd_len);
   ob_u64(out, lvl_off); ob_u64(out, level.n); ob_u64(out, 0);
   /* DFD: ETC1S, BT709, sRGB */
-  ob_u32(out, 44); ob_u32(out, 0); ob_u16(out, 2); ob_u16(out, 40);
+  ob_u32(out, dfd_len); ob_u32(out, 0); ob_u16(out, 2); ob_u16(out, (uint16_t)(dfd_len - 4));
   ob_u8(out, 163); ob_u8(out, 1); ob_u8(out, 2); ob_u8(out, 0);
   ob_u8(out, 3); ob_u8(out, 3); ob_u8(out, 0); ob_u8(out, 0);
   for (int i = 0; i < 8; i++) ob_u8(out, 0);
   ob_u16(out, 0); ob_u8(out, 63); ob_u8(out, 0); ob_u8(out, 0); ob_u8(out, 0); ob_u8(out, 0); ob_u8(out, 0); ob_u32(out, 0); ob_u32(out, 0xFFFFFFFFu);
+  if (has_alpha) {                                       /* second sample: channel 15 (AAA) at bit 64 */
+    ob_u16(out, 64); ob_u8(out, 63); ob_u8(out, 15); ob_u8(out, 0); ob_u8(out, 0); ob_u8(out, 0); ob_u8(out, 0); ob_u32(out, 0); ob_u32(out, 0xFFFFFFFFu); }
   ob_bytes(out, kvd.p, kvd.n);
   while (out->n < sgd_off) ob_u8(out, 0);
   ob_u16(out, (uint16_t)ne); ob_u16(out, (uint16_t)ns); ob_u32(out, (uint32_t)wep.b.n); ob_u32(out, (uint32_t)wsel.b.n); ob_u32(out, (uint32_t)wtab.b.n); ob_u32(out, 0);
-  for (int l = 0; l < L; l++) { ob_u32(out, l > 0 ? 2 : 0); ob_u32(out, sl_off[l]); ob_u32(out, sl_len[l]); ob_u32(out, 0); ob_u32(out, 0); }
+  for (int l = 0; l < Lr; l++) { ob_u32(out, l > 0 ? 2 : 0); ob_u32(out, sl_off[l * stride]); ob_u32(out, sl_len[l * stride]); ob_u32(out, has_alpha ? sl_off[l * stride + 1] : 0); ob_u32(out, has_alpha ? sl_len[l * stride + 1] : 0); }
   ob_bytes(out, wep.b.p, wep.b.n); ob_bytes(out, wsel.b.p, wsel.b.n); ob_bytes(out, wtab.b.p, wtab.b.n);
   ob_bytes(out, level.p, level.n);
 

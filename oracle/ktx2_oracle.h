@@ -31,11 +31,13 @@ typedef struct {
   uint16_t *block_ei, *block_si; /* n_slices * bx*by */
   char writer[64];
   uint32_t anim_duration, anim_timescale, anim_loops; int has_anim;
+  int has_alpha;                 /* every image has a second (alpha) slice: slice 2 * layer + 1; n_slices = 2 * layers */
 } ktx2_file;
 
 int ktx2_decode(const uint8_t *b, size_t n, ktx2_file *f);
 void ktx2_free(ktx2_file *f);
-/* decode one layer to RGBA8, rows in stored order (top of stored image first) */
+/* decode one layer (image) to RGBA8, rows in stored order (top of stored image first); alpha from the image's alpha slice (its green
+ * channel, as the basis transcoder does), 255 without one */
 void ktx2_layer_rgba(const ktx2_file *f, int layer, uint8_t *out);
 
 /* ---- encoder restatement ---- */

@@ -215,7 +215,7 @@ class Ktx2File(C.Structure):
                 ("slice_flags", C.c_uint32 * KTX2_MAX_LAYERS), ("slice_off", C.c_uint32 * KTX2_MAX_LAYERS), ("slice_len", C.c_uint32 * KTX2_MAX_LAYERS),
                 ("slice_bits_used", C.c_uint64 * KTX2_MAX_LAYERS), ("slice_skip", C.c_uint32 * KTX2_MAX_LAYERS),
                 ("block_ei", C.POINTER(C.c_uint16)), ("block_si", C.POINTER(C.c_uint16)),
-                ("writer", C.c_char * 64), ("anim_duration", C.c_uint32), ("anim_timescale", C.c_uint32), ("anim_loops", C.c_uint32), ("has_anim", C.c_int)]
+                ("writer", C.c_char * 64), ("anim_duration", C.c_uint32), ("anim_timescale", C.c_uint32), ("anim_loops", C.c_uint32), ("has_anim", C.c_int), ("has_alpha", C.c_int)]
 
 
 class Ktx2EncParams(C.Structure):
@@ -243,7 +243,7 @@ class DecodedKtx2:
                   "kvd_off", "kvd_len", "sgd_off", "sgd_len", "level_off", "level_len", "level_ulen", "dfd_model", "dfd_transfer",
                   "dfd_primaries", "n_endpoints", "n_selectors", "endpoints_len", "selectors_len", "tables_len", "extended_len",
                   "bx", "by", "hist_size", "ep_bits_used", "sel_bits_used", "tab_bits_used", "n_slices", "has_anim",
-                  "anim_duration", "anim_timescale", "anim_loops"):
+                  "anim_duration", "anim_timescale", "anim_loops", "has_alpha"):
             setattr(self, k, getattr(f, k))
         self.writer = f.writer.decode(errors="replace")
         n = f.n_slices
@@ -256,7 +256,7 @@ class DecodedKtx2:
         self.block_si = np.ctypeslib.as_array(f.block_si, (n, nb)).copy()
         self.images = []
         if images:
-            for l in range(n):
+            for l in range(max(1, f.layers)):               # one image per layer (its colour slice + its alpha slice, if any)
                 img = np.zeros((f.height, f.width, 4), dtype=np.uint8)
                 lib().ktx2_layer_rgba(C.byref(f), l, img.ctypes.data)
                 self.images.append(img)

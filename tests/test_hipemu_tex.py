@@ -150,20 +150,49 @@ def test_hipemu_uastc_mode_matches_oracle(oracle, hipemu_lib):
     cd.close()
 
 
-def test_hipemu_etc1s_refuses_alpha(oracle, hipemu_lib):
-    """basisu would write alpha slices for a non-opaque image; this codec's ETC1S path has none, so it fails loudly (as does the
-    oracle) instead of dropping the channel — and the UASTC mode takes the same image."""
+def _alpha_sequence(n, size, seed):
+    """A texture sequence whose alpha channel is a moving soft disc (so alpha slices have coded and skipped blocks of their own)."""
+    import numpy as np, synth
+    tex = [t.copy() for t in synth.texture_sequence(n, size=size, seed=seed)]
+    yy, xx = np.mgrid[0:size, 0:size]
+    for k, t in enumerate(tex):
+        t[..., 3] = np.clip(((xx - size // 2 - 3 * k) ** 2 + (yy - size // 2) ** 2) * (900.0 / size ** 2), 0, 255).astype(np.uint8)
+    return tex
+
+
+def test_hipemu_etc1s_alpha_slices(oracle, hipemu_lib):
+    """images with alpha != 255 get alpha slices, as basisu writes them and the stock player reads them
+    (src/lib/KTX2Loader.js:493-497): a second slice per image (the alpha channel as a grey image through the same codebooks), a second
+    DFD sample (channel 15), the second offset / length pair of the image descs.  Bit-exact against the oracle, which has the same
+    restated layout (parity with basisu unpinned: no reference fixture has alpha); decoded back by both decoders; a batch that
+    mixes opaque and alpha segments; the opaque targets (ETC1 / BC7) refuse such a file; the UASTC mode takes the same images."""
     import numpy as np, pytest
     import synth, uvol
-    tex = synth.texture_sequence(2, size=32, seed=4)
-    tex[1] = tex[1].copy(); tex[1][5, 7, 3] = 254
     cd = uvol.Codec(lib_path=hipemu_lib)
+    tex = _alpha_sequence(3, 36, 2)
+    one = tex[0].copy(); one[..., 3] = 255; one[5, 7, 3] = 254                        # a single non-opaque texel is enough
+    opaque = synth.texture_sequence(3, size=36, seed=5)
+    for name, t in (("disc", tex), ("one_texel_ragged", [one[:34, :29]])):
+        got = cd.encode_texture_segment(t)
+        assert got == oracle.ktx2_encode(t), name
+        d = oracle.ktx2_decode(got)
+        assert d.has_alpha == 1 and d.n_slices == 2 * len(t) and d.layers == len(t), name
+        dec = cd.decode_texture_segments([got])[0]
+        for l in range(len(t)):
+            assert np.array_equal(dec[l], d.images[l]), (name, l)
+        if name == "disc": d_disc = d
+    # quality of the round trip: alpha comes back like a colour channel does
+    d = d_disc
+    for l in range(3):
+        err = d.images[l][..., 3].astype(int) - tex[l][::-1, :, 3].astype(int)
+        assert (err ** 2).mean() < 40.0
+    # opaque and alpha segments in one batch: each as if encoded alone
+    got = cd.encode_texture_segments([opaque, tex])
+    assert got[0] == oracle.ktx2_encode(opaque) and got[1] == oracle.ktx2_encode(tex)
+    assert oracle.ktx2_decode(got[0]).has_alpha == 0
     with pytest.raises(uvol.UvolError, match="alpha"):
-        cd.encode_texture_segment(tex)
-    assert cd.encode_texture_segment([tex[0]]) == oracle.ktx2_encode([tex[0]])       # the context stays usable
+        cd.transcode_texture_segments_etc1([got[1]])
     cd.close()
-    with pytest.raises(ValueError):
-        oracle.ktx2_encode(tex)
     cu = uvol.Codec(lib_path=hipemu_lib, uastc=1)
     assert cu.encode_texture_segment(tex) == oracle.uastc_ktx2_encode(tex)
     cu.close()

@@ -25,11 +25,12 @@ struct DHuff { uint32_t n, valid; uint32_t first_code[18], first_idx[18], count[
 struct TexDecJob {
   const uint8_t *file; uint32_t file_len;
   uint32_t width, height, layers, bx, by;
+  uint32_t ashift, nsl;          // alpha slices: every image (layer) has two slices, colour 2l and alpha 2l + 1 (nsl = layers << ashift); a P-frame slice follows slice s - (1 << ashift)
   uint32_t ne, ns, ep_off, ep_len, sel_off, sel_len, tab_off, tab_len, level_off, level_len;
   uint32_t slice_flags[TD_MAX_LAYERS], slice_off[TD_MAX_LAYERS], slice_len[TD_MAX_LAYERS];
   uint8_t *endpoints;            // ne * 4: r5 g5 b5 inten
   uint32_t *selectors;           // ns: byte j = row j, texel x at bits 2x..2x+1
-  uint16_t *ei, *si;             // layers * bx * by
+  uint16_t *ei, *si;             // nsl * bx * by
   DHuff hm[4];                   // epm, dem, sm, rle
   DHuff tmp[5];                  // codebook models (3 colour-delta, intensity-delta, selector byte-delta)
   uint32_t hist_size;
@@ -229,7 +230,7 @@ __device__ __forceinline__ int tdec_row(const TexDecJob &J, const SliceLuts &T, 
 }
 __device__ __forceinline__ int tdec_slice_begin(const TexDecJob &J, uint32_t sl, SliceState &S, UVOL_L(uint32_t) hist, UVOL_L(uint16_t) pe, UVOL_L(uint8_t) pb, uint32_t rowsz) {
   if ((unsigned long long)J.slice_off[sl] + J.slice_len[sl] > J.level_len) return -11;
-  if ((J.slice_flags[sl] & 2u) && sl == 0) return -11;
+  if ((J.slice_flags[sl] & 2u) && (sl >> J.ashift) == 0) return -11;
   db_init(S.R, J.file + J.level_off + J.slice_off[sl], J.slice_len[sl]);
   for (uint32_t i = 0; i < J.hist_size; i++) hist[i] = i;
   S.rover = J.hist_size / 2; S.prev_sym = 0; S.rep = 0; S.prev_ei = 0; S.sel_rle = 0;
@@ -240,7 +241,8 @@ __device__ __forceinline__ int tdec_slice_begin(const TexDecJob &J, uint32_t sl,
 
 // LDS layout shared by both slice kernels: [4 LUTs][per slice-wave: hist 64 x u32 | pe 2 x rowsz u16 | pb 2 x rowsz u8 | row buffers ei, si: 2 x rowsz u16 each]
 #define TD_LUT_WORDS ((1u << TD_LUT_EPM) + (1u << TD_LUT_DEM) + (1u << TD_LUT_SM) + (1u << TD_LUT_RLE))
-__host__ __device__ inline uint32_t td_wave_words(uint32_t rowsz) { return 64 + rowsz /* pe: 2 rows of u16 */ + (2 * rowsz + 3) / 4 /* pb */ + 2 * rowsz /* ei, si rows, double buffered */; }
+// (row buffers: 2 deep, 4 deep with alpha slices - the consumer of a row is then two waves and two steps behind its producer)
+__host__ __device__ inline uint32_t td_wave_words(uint32_t rowsz, uint32_t depth) { return 64 + rowsz /* pe: 2 rows of u16 */ + (2 * rowsz + 3) / 4 /* pb */ + depth * rowsz /* ei, si rows: depth x rowsz u16 each */; }
 
 // Serial form (any layer count): one lane walks the slices of a segment one after the other; rows through global memory.
 __global__ void __launch_bounds__(64) k_tdec_slices(TexDecJob *jobs) {
@@ -257,13 +259,15 @@ __global__ void __launch_bounds__(64) k_tdec_slices(TexDecJob *jobs) {
   UVOL_L(uint32_t) hist = UVOL_TO_L(uint32_t, l_w); UVOL_L(uint16_t) pe = UVOL_TO_L(uint16_t, reinterpret_cast<uint16_t *>(l_w + 64));
   UVOL_L(uint8_t) pb = UVOL_TO_L(uint8_t, reinterpret_cast<uint8_t *>(l_w + 64 + rowsz));
   const size_t nbk = (size_t)bx * by;
-  for (uint32_t sl = 0; sl < J.layers; sl++) {
+  const uint32_t st = 1u << J.ashift;
+  for (uint32_t sl = 0; sl < J.nsl; sl++) {
     SliceState S;
     int rc = tdec_slice_begin(J, sl, S, hist, pe, pb, rowsz);
     const bool is_p = (J.slice_flags[sl] & 2u) != 0;
+    const uint32_t pv = sl >= st ? sl - st : 0;            // the previous slice of the same kind
     for (uint32_t y = 0; y < by && !rc; y++) {
       const size_t ro = (size_t)y * bx;
-      rc = tdec_row(J, T, S, y, is_p, hist, pe, pb, rowsz, UVOL_TO_G(const uint16_t, J.ei + (sl ? sl - 1 : 0) * nbk + ro), UVOL_TO_G(const uint16_t, J.si + (sl ? sl - 1 : 0) * nbk + ro),
+      rc = tdec_row(J, T, S, y, is_p, hist, pe, pb, rowsz, UVOL_TO_G(const uint16_t, J.ei + pv * nbk + ro), UVOL_TO_G(const uint16_t, J.si + pv * nbk + ro),
                     UVOL_TO_G(uint16_t, J.ei + sl * nbk + ro), UVOL_TO_G(uint16_t, J.si + sl * nbk + ro));
     }
     if (!rc && S.R.consumed > 8ull * J.slice_len[sl]) rc = -15;
@@ -281,12 +285,12 @@ __global__ void __launch_bounds__(1024) k_tdec_slices_pipe(TexDecJob *jobs) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, sl = tid >> 6, nthreads = blockDim.x;
   const bool ok = J.status == 0;
   uint32_t *l_epm = lds, *l_dem = l_epm + (1u << TD_LUT_EPM), *l_sm = l_dem + (1u << TD_LUT_DEM), *l_rle = l_sm + (1u << TD_LUT_SM);
-  const uint32_t bx = J.bx, by = J.by, rowsz = (bx + 2) & ~1u, L = J.layers, ww = td_wave_words(rowsz);
+  const uint32_t bx = J.bx, by = J.by, rowsz = (bx + 2) & ~1u, L = J.nsl, st = 1u << J.ashift, depth = 2u << J.ashift, ww = td_wave_words(rowsz, depth);
   if (tid == 0) s_fail = 0;
   if (ok) { lut_build(J.hm[0], l_epm, TD_LUT_EPM, tid, nthreads); lut_build(J.hm[1], l_dem, TD_LUT_DEM, tid, nthreads); lut_build(J.hm[2], l_sm, TD_LUT_SM, tid, nthreads); lut_build(J.hm[3], l_rle, TD_LUT_RLE, tid, nthreads); }
   if (!ok) return;                                   // uniform for the whole workgroup
   SliceLuts T; T.epm = UVOL_TO_L(const uint32_t, l_epm); T.dem = UVOL_TO_L(const uint32_t, l_dem); T.sm = UVOL_TO_L(const uint32_t, l_sm); T.rle = UVOL_TO_L(const uint32_t, l_rle);
-  uint32_t *mine = lds + TD_LUT_WORDS + sl * ww, *prevw = lds + TD_LUT_WORDS + (sl ? sl - 1 : 0) * ww;
+  uint32_t *mine = lds + TD_LUT_WORDS + sl * ww, *prevw = lds + TD_LUT_WORDS + (sl >= st ? sl - st : 0) * ww;
   UVOL_L(uint32_t) hist = UVOL_TO_L(uint32_t, mine); UVOL_L(uint16_t) pe = UVOL_TO_L(uint16_t, reinterpret_cast<uint16_t *>(mine + 64));
   UVOL_L(uint8_t) pb = UVOL_TO_L(uint8_t, reinterpret_cast<uint8_t *>(mine + 64 + rowsz));
   const uint32_t rows_off = 64 + rowsz + (2 * rowsz + 3) / 4;                           // words; then ei[2][rowsz], si[2][rowsz] as u16
@@ -299,15 +303,15 @@ __global__ void __launch_bounds__(1024) k_tdec_slices_pipe(TexDecJob *jobs) {
   __syncthreads();
   for (uint32_t t = 0; t < by + L - 1; t++) {
     const bool active = sl < L && t >= sl && t - sl < by;
-    const uint32_t y = t - sl, buf = y & 1;
+    const uint32_t y = t - sl, buf = y & (depth - 1);
     if (active && lane == 0 && !s_fail) {
-      const int rc = tdec_row(J, T, S, y, is_p, hist, pe, pb, rowsz, pv_rows + buf * rowsz, pv_rows + (2 + buf) * rowsz, my_rows + buf * rowsz, my_rows + (2 + buf) * rowsz);
+      const int rc = tdec_row(J, T, S, y, is_p, hist, pe, pb, rowsz, pv_rows + buf * rowsz, pv_rows + (depth + buf) * rowsz, my_rows + buf * rowsz, my_rows + (depth + buf) * rowsz);
       if (rc) s_fail = rc;
     }
     __syncthreads();
     if (active) {                                    // the finished row goes to global memory, 64 lanes wide
       uint16_t *ge = J.ei + sl * nbk + (size_t)y * bx, *gs = J.si + sl * nbk + (size_t)y * bx;
-      for (uint32_t x = lane; x < bx; x += 64) { ge[x] = my_rows[buf * rowsz + x]; gs[x] = my_rows[(2 + buf) * rowsz + x]; }
+      for (uint32_t x = lane; x < bx; x += 64) { ge[x] = my_rows[buf * rowsz + x]; gs[x] = my_rows[(depth + buf) * rowsz + x]; }
     }
   }
   if (sl < L && lane == 0 && !s_fail && S.R.consumed > 8ull * J.slice_len[sl]) s_fail = -15;
@@ -324,10 +328,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_unpack(TexDecJob *jobs) {
   if (layer >= J.layers || b >= bx * by) return;
   const int INTEN[8][4] = { {-8, -2, 2, 8}, {-17, -5, 5, 17}, {-29, -9, 9, 29}, {-42, -13, 13, 42}, {-60, -18, 18, 60}, {-80, -24, 24, 80}, {-106, -33, 33, 106}, {-183, -47, 47, 183} };
   const uint32_t X = b % bx, Y = b / bx;
-  const size_t o = (size_t)layer * bx * by + b;
+  const size_t o = (size_t)(layer << J.ashift) * bx * by + b;
   const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
   int base[3]; for (int c = 0; c < 3; c++) base[c] = (e[c] << 3) | (e[c] >> 2);
   const int t = e[3];
+  // alpha: the block of the image's alpha slice, green channel (what the basis transcoder takes)
+  const uint8_t *ae = J.ashift ? J.endpoints + 4 * (size_t)J.ei[o + (size_t)bx * by] : e; const uint32_t asel = J.ashift ? J.selectors[J.si[o + (size_t)bx * by]] : 0u;
+  const int abase = (ae[1] << 3) | (ae[1] >> 2), at = ae[3];
   uint8_t *out = J.out[layer];
   for (int y = 0; y < 4; y++) {
     const uint32_t py = Y * 4 + (uint32_t)y; if (py >= H) break;
@@ -336,7 +343,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_unpack(TexDecJob *jobs) {
       const int d = INTEN[t][(sel >> (8 * y + 2 * x)) & 3];
       int r = base[0] + d, g = base[1] + d, bb = base[2] + d;
       r = r < 0 ? 0 : (r > 255 ? 255 : r); g = g < 0 ? 0 : (g > 255 ? 255 : g); bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
-      px4[x] = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)bb << 16) | 0xff000000u;
+      int a = 255;
+      if (J.ashift) { a = abase + INTEN[at][(asel >> (8 * y + 2 * x)) & 3]; a = a < 0 ? 0 : (a > 255 ? 255 : a); }
+      px4[x] = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)bb << 16) | ((uint32_t)a << 24);
     }
     uint32_t *row = reinterpret_cast<uint32_t *>(out + 4 * ((size_t)py * W + X * 4));
     if (X * 4 + 3 < W && (W & 3) == 0) *reinterpret_cast<uint4 *>(row) = make_uint4(px4[0], px4[1], px4[2], px4[3]);
@@ -450,16 +459,25 @@ static int tdec_parse(const uint8_t *b, size_t n, TexDecJob &J) {
   if (vk != 0 || sc != 1 || levels != 1 || faces != 1 || W == 0 || H == 0 || W > 16384 || H > 16384) return -2;
   // untrusted 64-bit fields: compared without forming a sum that could wrap
   if (sgd_off > n || sgd_len > n - sgd_off || lv_off > n || lv_len > n - lv_off) return -3;
-  const uint32_t nsl = layers ? layers : 1;
-  if (nsl > TD_MAX_LAYERS) return -4;
-  if (sgd_len < 20 + 20ull * nsl) return -5;
+  const uint32_t nimg = layers ? layers : 1;
+  if (nimg > TD_MAX_LAYERS) return -4;
+  if (sgd_len < 20 + 20ull * nimg) return -5;
   const uint8_t *s = b + sgd_off;
-  J.width = W; J.height = H; J.layers = nsl; J.bx = (W + 3) / 4; J.by = (H + 3) / 4;
+  // alpha slices (basisu writes them for images with alpha; src/lib/KTX2Loader.js:493-497 reads them): the second offset / length pair
+  // of every image desc, announced by a second DFD sample of channel 15 (AAA).  All images of a file have one or none.
+  uint32_t any = 0, all = 1;
+  for (uint32_t i = 0; i < nimg; i++) { if (rd32h(s + 20 + 20 * i + 16)) any = 1; else all = 0; }
+  if (any != all) return -6;
+  if (any) { const uint32_t dfd_off = rd32h(b + 48), dfd_len = rd32h(b + 52); if (dfd_len < 60 || dfd_off > n || dfd_len > n - dfd_off || (b[dfd_off + 44 + 3] & 15) != 15) return -6; }
+  const uint32_t ash = any, nsl = nimg << ash;
+  if (nsl > TD_MAX_LAYERS) return -4;
+  J.width = W; J.height = H; J.layers = nimg; J.ashift = ash; J.nsl = nsl; J.bx = (W + 3) / 4; J.by = (H + 3) / 4;
   J.ne = (uint32_t)s[0] | ((uint32_t)s[1] << 8); J.ns = (uint32_t)s[2] | ((uint32_t)s[3] << 8);
   J.ep_len = rd32h(s + 4); J.sel_len = rd32h(s + 8); J.tab_len = rd32h(s + 12);
-  for (uint32_t i = 0; i < nsl; i++) { const uint8_t *d = s + 20 + 20 * i; J.slice_flags[i] = rd32h(d); J.slice_off[i] = rd32h(d + 4); J.slice_len[i] = rd32h(d + 8); if (rd32h(d + 12) || rd32h(d + 16)) return -6; }
-  const uint64_t p = sgd_off + 20 + 20ull * nsl;
-  if (20 + 20ull * nsl + (uint64_t)J.ep_len + J.sel_len + J.tab_len > sgd_len) return -5;
+  for (uint32_t i = 0; i < nimg; i++) { const uint8_t *d = s + 20 + 20 * i;
+    for (uint32_t k = 0; k <= ash; k++) { J.slice_flags[(i << ash) + k] = rd32h(d); J.slice_off[(i << ash) + k] = rd32h(d + 4 + 8 * k); J.slice_len[(i << ash) + k] = rd32h(d + 8 + 8 * k); } }
+  const uint64_t p = sgd_off + 20 + 20ull * nimg;
+  if (20 + 20ull * nimg + (uint64_t)J.ep_len + J.sel_len + J.tab_len > sgd_len) return -5;
   for (uint32_t i = 0; i < nsl; i++) if ((uint64_t)J.slice_off[i] + J.slice_len[i] > lv_len) return -6;
   J.ep_off = (uint32_t)p; J.sel_off = J.ep_off + J.ep_len; J.tab_off = J.sel_off + J.sel_len;
   J.level_off = (uint32_t)lv_off; J.level_len = (uint32_t)lv_len;
@@ -516,16 +534,17 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   for (int i = 0; i < n; i++) {
     const int rc = tdec_parse(files[i], lens[i], T->hjobs[i]);
     if (rc) { ctx->set_error("segment %d: not a KTX2 / BasisLZ ETC1S file this decoder supports (parse code %d)", i, rc); return rc == -2 || rc == -6 ? UVOL_E_UNSUPPORTED : UVOL_E_INVALID; }
-    if (T->hjobs[i].width != T->hjobs[0].width || T->hjobs[i].height != T->hjobs[0].height || T->hjobs[i].layers != T->hjobs[0].layers) { ctx->set_error("segment %d: size / layer count differs from segment 0", i); return UVOL_E_INVALID; }
+    if (T->hjobs[i].width != T->hjobs[0].width || T->hjobs[i].height != T->hjobs[0].height || T->hjobs[i].layers != T->hjobs[0].layers || T->hjobs[i].ashift != T->hjobs[0].ashift) { ctx->set_error("segment %d: size / layer count differs from segment 0", i); return UVOL_E_INVALID; }
     foff[i] = files_total; files_total += (lens[i] + 16 + 255) & ~(size_t)255;
   }
   const TexDecJob &J0 = T->hjobs[0];
-  const size_t nbk = (size_t)J0.bx * J0.by, L = J0.layers;
+  const size_t nbk = (size_t)J0.bx * J0.by, L = J0.layers, NSL = J0.nsl;
+  if (J0.ashift && target != 0) { ctx->set_error("segment 0 has alpha slices: only the RGBA32 target reads them (the ETC1 / BC7 targets of this decoder are opaque formats)"); return UVOL_E_UNSUPPORTED; }
   const size_t layer_bytes = target == 1 ? nbk * 8 : (target == 2 ? nbk * 16 : (size_t)J0.width * J0.height * 4);   // 0: RGBA8, 1: ETC1 blocks, 2: BC7 blocks
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small: %zu < %zu", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   // per-segment workspace: codebooks, block indices, Huffman size / sorted arrays of 9 models
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t ws = a256((size_t)TD_MAX_SYMS * 4) + a256((size_t)TD_MAX_SYMS * 4) + 2 * a256(L * nbk * 2) + 9 * (a256((size_t)TD_MAX_SYMS + 512) + a256((size_t)TD_MAX_SYMS * 4 + 64));
+  const size_t ws = a256((size_t)TD_MAX_SYMS * 4) + a256((size_t)TD_MAX_SYMS * 4) + 2 * a256(NSL * nbk * 2) + 9 * (a256((size_t)TD_MAX_SYMS + 512) + a256((size_t)TD_MAX_SYMS * 4 + 64));
   const size_t out_seg = outputs_on_device ? 0 : L * a256(layer_bytes);
   int rc;
   if ((rc = uvol_ensure(ctx, T->files, files_total + 64))) return rc;
@@ -540,7 +559,7 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
     uint8_t *w = (uint8_t *)T->slab.p + ws * (size_t)i; size_t o = 0;
     auto take = [&](size_t bytes) { uint8_t *p = w + o; o += a256(bytes); return p; };
     J.endpoints = take((size_t)TD_MAX_SYMS * 4); J.selectors = (uint32_t *)take((size_t)TD_MAX_SYMS * 4);
-    J.ei = (uint16_t *)take(L * nbk * 2); J.si = (uint16_t *)take(L * nbk * 2);
+    J.ei = (uint16_t *)take(NSL * nbk * 2); J.si = (uint16_t *)take(NSL * nbk * 2);
     for (int k = 0; k < 9; k++) { DHuff &H = k < 4 ? J.hm[k] : J.tmp[k - 4]; H.sizes = take((size_t)TD_MAX_SYMS + 512); H.sorted = (uint32_t *)take((size_t)TD_MAX_SYMS * 4 + 64); }
     for (size_t l = 0; l < L; l++) J.out[l] = outputs_on_device ? rgba[(size_t)i * L + l] : (uint8_t *)T->outs.p + out_seg * (size_t)i + l * a256(layer_bytes);
     J.status = 0;
@@ -548,12 +567,13 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->jobs.p, T->hjobs.data(), sizeof(TexDecJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   TexDecJob *dj = (TexDecJob *)T->jobs.p;
   const uint32_t rowsz = (J0.bx + 2) & ~1u;
-  const size_t lds_serial = ((size_t)TD_LUT_WORDS + td_wave_words(rowsz)) * 4, lds_pipe = ((size_t)TD_LUT_WORDS + (size_t)L * td_wave_words(rowsz)) * 4;
-  const bool pipe = L <= 16 && lds_pipe <= T->max_lds;
+  const uint32_t depth = 2u << J0.ashift;
+  const size_t lds_serial = ((size_t)TD_LUT_WORDS + td_wave_words(rowsz, 2)) * 4, lds_pipe = ((size_t)TD_LUT_WORDS + NSL * td_wave_words(rowsz, depth)) * 4;
+  const bool pipe = NSL <= 16 && lds_pipe <= T->max_lds;
   if ((pipe ? lds_pipe : lds_serial) > T->max_lds) { ctx->set_error("texture too wide for the slice decoder's row buffers"); return UVOL_E_UNSUPPORTED; }
   { uvol_ctx::Scope sc(ctx, "texdec.k1_tables", 0); DLAUNCH(k_tdec_tables, dim3((unsigned)n), dim3(64), 0, dj); }
   { uvol_ctx::Scope sc(ctx, "texdec.k2_slices", 0);
-    if (pipe) DLAUNCH(k_tdec_slices_pipe, dim3((unsigned)n), dim3(64 * (unsigned)L), lds_pipe, dj);
+    if (pipe) DLAUNCH(k_tdec_slices_pipe, dim3((unsigned)n), dim3(64 * (unsigned)NSL), lds_pipe, dj);
     else DLAUNCH(k_tdec_slices, dim3((unsigned)n), dim3(64), lds_serial, dj); }
   { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes);
     if (target == 1) DLAUNCH(k_tdec_etc1, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);

@@ -17,7 +17,7 @@
 #define TEX_VQ_ROUNDS 24
 #define TEX_NMODEL 9                    // 0 endpoint_pred, 1 delta_endpoint, 2 selector, 3 selector_rle, 4..6 colour5 delta, 7 inten delta, 8 selector byte delta
 #define TEX_MODEL_CAP (TEX_MAX_CODEBOOK + TEX_HS + 8)
-#define TEX_E_ALPHA (-60)               // device status: a texel with alpha != 255 (ETC1S alpha slices are not implemented)
+#define TEX_E_ALPHA (-60)               // device status of the opaque layout: a texel with alpha != 255 (the host encodes the segment again with alpha slices)
 
 struct TexVQ {
   uint32_t n_items, K, nl, done, m_round, round_active;
@@ -31,7 +31,8 @@ struct TexHuff { uint32_t n; uint32_t *freq; uint8_t *size; uint16_t *code; };  
 
 struct TexJob {
   const uint8_t *layer[TEX_MAX_LAYERS];
-  uint32_t W, H, L, bx, by, nb, NB;
+  uint32_t W, H, L, bx, by, nb, NB;          // L = SLICES: images << ashift (with alpha every image has a colour and an alpha slice: rgb0 a0 rgb1 a1 ...)
+  uint32_t ashift;                            // 1: alpha slices; slice v shows image v >> 1, kind v & 1, and follows slice v - 2 of its kind
   int32_t yflip; uint32_t Kmax_e, Kmax_s, T_skip;
   int32_t status;
   uint8_t *skip;            // [NB]
@@ -69,18 +70,21 @@ __device__ __forceinline__ int t_inten(int t, int s) {
 
 // 4x4 block fetch with y-flip and edge replication; px[i] = R | G<<8 | B<<16 (i = y*4+x)
 // amask (optional): AND of the texels' alpha bytes (bits 24..31), for the opacity check of the ETC1S path
+// With alpha slices (J.ashift) `l` is a slice: odd slices are the image's alpha channel as the grey image (a, a, a).
 __device__ inline void t_load_block(const TexJob &J, uint32_t l, uint32_t X, uint32_t Y, uint32_t px[16], uint32_t *amask = nullptr) {
-  const uint8_t *img = J.layer[l];
+  const uint8_t *img = J.layer[l >> J.ashift];
+  const bool akind = (l & J.ashift) != 0;
   for (int y = 0; y < 4; y++) {
     uint32_t py = Y * 4 + y; if (py >= J.H) py = J.H - 1;
     const uint32_t sr = J.yflip ? J.H - 1 - py : py;
     const uint8_t *row = img + 4 * ((size_t)sr * J.W);
     if (X * 4 + 3 < J.W && (J.W & 3) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * (size_t)X);
-      px[4 * y + 0] = v.x & 0xffffffu; px[4 * y + 1] = v.y & 0xffffffu; px[4 * y + 2] = v.z & 0xffffffu; px[4 * y + 3] = v.w & 0xffffffu;
+      if (akind) { px[4 * y + 0] = (v.x >> 24) * 0x010101u; px[4 * y + 1] = (v.y >> 24) * 0x010101u; px[4 * y + 2] = (v.z >> 24) * 0x010101u; px[4 * y + 3] = (v.w >> 24) * 0x010101u; }
+      else { px[4 * y + 0] = v.x & 0xffffffu; px[4 * y + 1] = v.y & 0xffffffu; px[4 * y + 2] = v.z & 0xffffffu; px[4 * y + 3] = v.w & 0xffffffu; }
       if (amask) *amask &= v.x & v.y & v.z & v.w;
     } else {
-      for (int x = 0; x < 4; x++) { uint32_t pxx = X * 4 + x; if (pxx >= J.W) pxx = J.W - 1; const uint8_t *p = row + 4 * (size_t)pxx; px[4 * y + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); if (amask) *amask &= (uint32_t)p[3] << 24; }
+      for (int x = 0; x < 4; x++) { uint32_t pxx = X * 4 + x; if (pxx >= J.W) pxx = J.W - 1; const uint8_t *p = row + 4 * (size_t)pxx; px[4 * y + x] = akind ? (uint32_t)p[3] * 0x010101u : ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)); if (amask) *amask &= (uint32_t)p[3] << 24; }
     }
   }
 }

@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #define TJOB_OR_RETURN TexJob &J = job[blockIdx.z]; if (J.status != 0) return
+#define TEX_RETRY_ALPHA (~(size_t)0)          // out_lens[] marker between the two passes of tex_encode_segments
 
 // ------------------------------------------------------------------------------------------------
 // scans (block-level exclusive scan shared with nothing else in this TU)
@@ -67,22 +68,25 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_skip(TexJob *job) {
   if (b >= J.nb) return;
   const uint32_t X = b % J.bx, Y = b / J.bx;
   uint32_t anchor[16], cur[16], amask = 0xff000000u;
-  t_load_block(J, 0, X, Y, anchor, &amask);
-  J.skip[b] = 0; J.flag[b] = 1;
-  for (uint32_t l = 1; l < J.L; l++) {
-    t_load_block(J, l, X, Y, cur, &amask);
-    uint32_t d = 0;
-    for (int i = 0; i < 16; i++) {
-      const int dr = (int)(cur[i] & 255) - (int)(anchor[i] & 255), dg = (int)((cur[i] >> 8) & 255) - (int)((anchor[i] >> 8) & 255), db = (int)((cur[i] >> 16) & 255) - (int)((anchor[i] >> 16) & 255);
-      d += (uint32_t)(dr * dr + dg * dg + db * db);
+  const uint32_t st = 1u << J.ashift;                     // slices of one kind follow each other at this distance
+  for (uint32_t kind = 0; kind < st; kind++) {
+    t_load_block(J, kind, X, Y, anchor, &amask);
+    J.skip[(size_t)kind * J.nb + b] = 0; J.flag[(size_t)kind * J.nb + b] = 1;
+    for (uint32_t l = kind + st; l < J.L; l += st) {
+      t_load_block(J, l, X, Y, cur, &amask);
+      uint32_t d = 0;
+      for (int i = 0; i < 16; i++) {
+        const int dr = (int)(cur[i] & 255) - (int)(anchor[i] & 255), dg = (int)((cur[i] >> 8) & 255) - (int)((anchor[i] >> 8) & 255), db = (int)((cur[i] >> 16) & 255) - (int)((anchor[i] >> 16) & 255);
+        d += (uint32_t)(dr * dr + dg * dg + db * db);
+      }
+      const bool sk = d <= J.T_skip;
+      J.skip[(size_t)l * J.nb + b] = sk ? 1 : 0; J.flag[(size_t)l * J.nb + b] = sk ? 0 : 1;      // coded blocks -> item list (k_item_compact)
+      if (!sk) for (int i = 0; i < 16; i++) anchor[i] = cur[i];
     }
-    const bool sk = d <= J.T_skip;
-    J.skip[(size_t)l * J.nb + b] = sk ? 1 : 0; J.flag[(size_t)l * J.nb + b] = sk ? 0 : 1;      // coded blocks -> item list (k_item_compact)
-    if (!sk) for (int i = 0; i < 16; i++) anchor[i] = cur[i];
   }
-  // basisu writes alpha slices for such images; this path does not: fail loudly rather than drop the channel (every block of
+  // an image with alpha != 255 met in the opaque layout: the host encodes this segment again with alpha slices (every block of
   // every layer passes through here)
-  if ((amask & 0xff000000u) != 0xff000000u) J.status = TEX_E_ALPHA;
+  if (!J.ashift && (amask & 0xff000000u) != 0xff000000u) J.status = TEX_E_ALPHA;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,9 +602,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_copy_skipped(TexJob *job) {
   const uint32_t b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (b >= J.nb) return;
   uint32_t nsk = 0;
-  for (uint32_t l = 1; l < J.L; l++) {
-    const size_t o = (size_t)l * J.nb + b;
-    if (J.skip[o]) { J.bei[o] = J.bei[o - J.nb]; J.bsi[o] = J.bsi[o - J.nb]; nsk++; }
+  const uint32_t st = 1u << J.ashift;                     // the previous slice of the same kind
+  for (uint32_t l = st; l < J.L; l++) {
+    const size_t o = (size_t)l * J.nb + b, pv = o - (size_t)st * J.nb;
+    if (J.skip[o]) { J.bei[o] = J.bei[pv]; J.bsi[o] = J.bsi[pv]; nsk++; }
   }
   if (nsk) atomicAdd(&J.n_skipped, nsk);
 }
@@ -612,10 +617,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_copy_skipped(TexJob *job) {
 __device__ __forceinline__ uint32_t t_pred_of(const TexJob &J, uint32_t l, uint32_t x, uint32_t y) {
   const size_t o = (size_t)l * J.nb; const uint32_t b = y * J.bx + x;
   const uint16_t *ei = J.bei + o;
-  if (l > 0 && J.skip[o + b]) return 2;
+  if (J.skip[o + b]) return 2;                            // (never set in the first slice of a kind)
   if (x > 0 && ei[b] == ei[b - 1]) return 0;
   if (y > 0 && ei[b] == ei[b - J.bx]) return 1;
-  if (l == 0 && x > 0 && y > 0 && ei[b] == ei[b - J.bx - 1]) return 2;
+  if ((l >> J.ashift) == 0 && x > 0 && y > 0 && ei[b] == ei[b - J.bx - 1]) return 2;
   return 3;
 }
 // pred[b] bits 0-1: this block's predictor; for macroblock-origin blocks bits 8.. are not stored: the
@@ -668,7 +673,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tok_delta(TexJob *job) {
   unsigned long long *T = J.tok + 3 * (size_t)b;
   T[0] = TOK_NOP; T[2] = TOK_NOP;
   T[1] = J.pred[b] == 3 ? TOK(2, e >= pe ? e - pe : e + J.ne - pe, 0) : TOK_NOP;
-  J.flag[b] = (l > 0 && J.skip[b]) ? 0 : 1;
+  J.flag[b] = J.skip[b] ? 0 : 1;
 }
 // coded blocks of each slice, in raster order
 __global__ void __launch_bounds__(UVOL_BLOCK) k_coded_list(TexJob *job) {
@@ -1169,7 +1174,7 @@ static inline uint32_t sel_lcap(const TexJob &J) { const uint32_t cap = std::min
 // segment and few flushes (a flush is up to 33 global atomics per leaf and workgroup).  Measured against 16-bit halves of
 // 32-bit words (<= 6144 items per workgroup, 213 workgroups per 2048^2 x 5 segment): 15.9 against 27.4 ms per step.
 typedef unsigned long long sel_word_t;
-static inline unsigned sel_stat_blocks(unsigned nseg) { return std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))); }
+static inline unsigned sel_stat_blocks(const TexJob &J, unsigned nseg) { return std::min(std::max(32u, std::min(512u, 4096u / std::max(1u, nseg))), std::max(1u, (unsigned)((J.NB + UVOL_BLOCK * SEL_ILP - 1) / (UVOL_BLOCK * SEL_ILP)))); }   // (no more workgroups than trips over the blocks)
 static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned NSEG, int force, int round = -1) {
   // round r of the tree build has <= 2^r leaves: reserve LDS for those only (leaves past the cap would still be counted, through
   // global atomics)
@@ -1177,7 +1182,7 @@ static void run_sel_stats(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned N
   const uint32_t lcap = std::min<uint32_t>(sel_lcap(J), leaves);
   if (force) TLAUNCH((k_vq_zero<16>), dim3(uvol_blocks((size_t)TEX_MAX_CODEBOOK * 16)), dim3(UVOL_BLOCK), 0, dj, force);
   for (uint32_t lb = 0; lb < leaves; lb += lcap) {
-    TLAUNCH(k_sel_stats<sel_word_t>, dim3(sel_stat_blocks(NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * sizeof(sel_word_t), dj, force, lcap, lb);
+    TLAUNCH(k_sel_stats<sel_word_t>, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * sizeof(sel_word_t), dj, force, lcap, lb);
   }
 }
 static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned item_blocks, unsigned NSEG) {
@@ -1191,21 +1196,25 @@ static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned 
     const uint32_t m_max = r < 20 ? std::min<uint32_t>(J.Kmax_s, 1u << r) : J.Kmax_s;        // a round splits every leaf at most once
     const uint32_t lcap = std::min<uint32_t>(sel_lcap(J), std::max<uint32_t>(m_max, 16u));
     for (uint32_t wb = 0; wb < m_max; wb += lcap) {
-      TLAUNCH(k_sel_split_stats<sel_word_t>, dim3(sel_stat_blocks(NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * sizeof(sel_word_t), dj, lcap, wb);
+      TLAUNCH(k_sel_split_stats<sel_word_t>, dim3(sel_stat_blocks(J, NSEG)), dim3(UVOL_BLOCK), (size_t)lcap * 17 * sizeof(sel_word_t), dj, lcap, wb);
     }
   }
   TLAUNCH((k_vq_decide<16, true>), dim3(1), dim3(UVOL_BLOCK), 0, dj, 1);
 }
 
 // n_seg segments of n_layers layers each (rgba[s * n_layers + l]), all of one size: ONE launch per stage for the whole batch
-int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
-                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+// alpha = 1: every image gets a colour and an alpha slice (basisu does this for any source image with alpha != 255; the stock
+// player reads them, src/lib/KTX2Loader.js:493-497).  Called with alpha = 0 first; segments whose images turn out to have alpha
+// (k_tex_skip sees every texel anyway) come back with TEX_E_ALPHA and are encoded again here with alpha = 1 - opaque
+// content, the common case, pays nothing for the feature.
+static int tex_encode_segments_impl(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
+                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha) {
   TexState *T = ctx->tex;
   if (n_seg <= 0) return UVOL_OK;
-  if (n_layers > TEX_MAX_LAYERS || W > 16384 || H > 16384 || n_seg > 65535) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }
+  if ((n_layers << alpha) > TEX_MAX_LAYERS || W > 16384 || H > 16384 || n_seg > 65535) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }
   const unsigned NSEG = (unsigned)n_seg;
   TexJob J0; memset(&J0, 0, sizeof(J0));
-  J0.W = W; J0.H = H; J0.L = (uint32_t)n_layers; J0.bx = (W + 3) / 4; J0.by = (H + 3) / 4; J0.nb = J0.bx * J0.by; J0.NB = J0.nb * J0.L;
+  J0.W = W; J0.H = H; J0.L = (uint32_t)n_layers << alpha; J0.ashift = (uint32_t)alpha; J0.bx = (W + 3) / 4; J0.by = (H + 3) / 4; J0.nb = J0.bx * J0.by; J0.NB = J0.nb * J0.L;
   J0.yflip = ctx->prm.y_flip ? 1 : 0;
   const int q = std::min(255, std::max(1, ctx->prm.etc1s_quality));
   J0.Kmax_e = (uint32_t)std::min(TEX_MAX_CODEBOOK, std::max(32, q * 12)); J0.Kmax_s = (uint32_t)std::min(TEX_MAX_CODEBOOK, std::max(32, q * 6));
@@ -1303,7 +1312,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   }
   // packed payloads: sections <= caps, slices <= slice_cap each; the bound below is what the workspace itself can hold
   size_t pack_cap = 0;
-  { const TexJob &Jc = T->hjobs[0]; pack_cap = (((size_t)Jc.sec_cap[0] + Jc.sec_cap[1] + Jc.sec_cap[2] + (size_t)Jc.slice_cap * (size_t)n_layers) + 15) & ~(size_t)15; }
+  { const TexJob &Jc = T->hjobs[0]; pack_cap = (((size_t)Jc.sec_cap[0] + Jc.sec_cap[1] + Jc.sec_cap[2] + (size_t)Jc.slice_cap * (size_t)Jc.L) + 15) & ~(size_t)15; }
   // typical output is ~1 % of that bound: start from 1/8 of it and grow on demand (checked after the copy of the job records)
   size_t want_pack = std::max<size_t>(T->packed.cap, pack_cap * (size_t)n_seg / 8 + 4096);
   if (int rc = uvol_ensure(ctx, T->packed, want_pack)) return rc;
@@ -1342,15 +1351,16 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   put32(kp, 12 + 12); memcpy(kp, "KTXanimData", 12); kp += 12; put32(kp, 1); put32(kp, 15); put32(kp, 0);
   put32(kp, 10 + (uint32_t)sizeof(writer)); memcpy(kp, "KTXwriter", 10); kp += 10; memcpy(kp, writer, sizeof(writer)); kp += sizeof(writer);
   while ((kp - kvd) & 3) *kp++ = 0;
-  const uint32_t dfd_off = 80 + 24, dfd_len = 44, kvd_off = dfd_off + dfd_len, kvd_len = (uint32_t)(kp - kvd);
+  const uint32_t dfd_off = 80 + 24, dfd_len = alpha ? 60 : 44, kvd_off = dfd_off + dfd_len, kvd_len = (uint32_t)(kp - kvd);
+  const int nsl = n_layers << alpha;
   const uint64_t sgd_off = ((uint64_t)kvd_off + kvd_len + 7) & ~7ull;
   int worst = UVOL_OK;
   for (int s = 0; s < n_seg; s++) {
     const TexJob &R = T->hjobs[s];
-    if (R.status == TEX_E_ALPHA) { ctx->set_error("texture segment %d: image has alpha != 255; ETC1S alpha slices are not implemented (make the images opaque, or use the UASTC mode: uvol_params.uastc / basisu -uastc, which encodes alpha)", s); worst = UVOL_E_UNSUPPORTED; out_lens[s] = 0; continue; }
+    if (R.status == TEX_E_ALPHA && !alpha) { out_lens[s] = TEX_RETRY_ALPHA; continue; }                    // encoded again with alpha slices by the caller
     if (R.status != 0) { ctx->set_error("texture segment %d: device status %d", s, R.status); worst = UVOL_E_ENCODE; out_lens[s] = 0; continue; }
     const uint64_t sgd_len = 20 + 20 * (uint64_t)n_layers + R.sec_len[0] + R.sec_len[1] + R.sec_len[2];
-    uint64_t lvl_len = 0; for (int l = 0; l < n_layers; l++) lvl_len += R.slice_len[l];
+    uint64_t lvl_len = 0; for (int l = 0; l < nsl; l++) lvl_len += R.slice_len[l];
     const uint64_t lvl_off = sgd_off + sgd_len, total = lvl_off + lvl_len;
     out_lens[s] = (size_t)total;
     if (total > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%llu > %llu)", s, (unsigned long long)total, (unsigned long long)caps[s]); worst = UVOL_E_NOSPACE; continue; }
@@ -1359,18 +1369,37 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     put32(p, 0); put32(p, 1); put32(p, W); put32(p, H); put32(p, 0); put32(p, (uint32_t)n_layers); put32(p, 1); put32(p, 1); put32(p, 1);
     put32(p, dfd_off); put32(p, dfd_len); put32(p, kvd_off); put32(p, kvd_len); put64(p, sgd_off); put64(p, sgd_len);
     put64(p, lvl_off); put64(p, lvl_len); put64(p, 0);
-    put32(p, 44); put32(p, 0); put16(p, 2); put16(p, 40);
+    put32(p, dfd_len); put32(p, 0); put16(p, 2); put16(p, (uint16_t)(dfd_len - 4));
     *p++ = 163; *p++ = 1; *p++ = 2; *p++ = 0; *p++ = 3; *p++ = 3; *p++ = 0; *p++ = 0;
     for (int i = 0; i < 8; i++) *p++ = 0;
     put16(p, 0); *p++ = 63; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; put32(p, 0); put32(p, 0xFFFFFFFFu);
+    if (alpha) { put16(p, 64); *p++ = 63; *p++ = 15; *p++ = 0; *p++ = 0; *p++ = 0; *p++ = 0; put32(p, 0); put32(p, 0xFFFFFFFFu); }      // second sample: channel 15 (AAA) at bit 64
     memcpy(p, kvd, kvd_len); p += kvd_len;
     while ((uint64_t)(p - out) < sgd_off) *p++ = 0;
     put16(p, (uint16_t)R.ne); put16(p, (uint16_t)R.ns); put32(p, R.sec_len[0]); put32(p, R.sec_len[1]); put32(p, R.sec_len[2]); put32(p, 0);
-    { uint32_t off = 0; for (int l = 0; l < n_layers; l++) { put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, R.slice_len[l]); put32(p, 0); put32(p, 0); off += R.slice_len[l]; } }
+    { uint32_t off = 0;
+      for (int l = 0; l < n_layers; l++) {
+        const uint32_t c = R.slice_len[l << alpha], a = alpha ? R.slice_len[(l << alpha) + 1] : 0u;
+        put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, c); put32(p, alpha ? off + c : 0u); put32(p, a); off += c + a; } }
     if (R.pack_len != sgd_len - 20 - 20 * (uint64_t)n_layers + lvl_len) { ctx->set_error("texture segment %d: packed payload length mismatch", s); worst = UVOL_E_ENCODE; continue; }
     memcpy(p, T->pinned + R.pack_off, (size_t)R.pack_len);            // sections then slices, already in container order
   }
   return worst;
+}
+int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
+                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+  if (n_seg <= 0) return UVOL_OK;
+  int rc = tex_encode_segments_impl(ctx, rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0);
+  std::vector<int> again;
+  for (int s = 0; s < n_seg; s++) if (out_lens[s] == TEX_RETRY_ALPHA) { again.push_back(s); out_lens[s] = 0; }
+  if (again.empty() || (rc != UVOL_OK && rc != UVOL_E_NOSPACE && rc != UVOL_E_ENCODE)) return rc;
+  // the segments with alpha, as one batch; host inputs were uploaded by the first pass and are read where they lie
+  TexState *T = ctx->tex;
+  std::vector<const uint8_t *> src; std::vector<uint8_t *> o2; std::vector<size_t> c2, l2(again.size(), 0);
+  for (int s : again) { for (int l = 0; l < n_layers; l++) src.push_back(on_device ? rgba[(size_t)s * n_layers + l] : T->hjobs[s].layer[l]); o2.push_back(outs[s]); c2.push_back(caps[s]); }
+  const int rc2 = tex_encode_segments_impl(ctx, src.data(), (int)again.size(), n_layers, W, H, true, o2.data(), c2.data(), l2.data(), 1);
+  for (size_t i = 0; i < again.size(); i++) out_lens[again[i]] = l2[i];
+  return rc != UVOL_OK ? rc : rc2;
 }
 
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t W, uint32_t H,
