@@ -3355,13 +3355,18 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   }
   // valence replay + context scatter depend only on the walk: run them on the auxiliary stream, beside
   // renumber / seams / fans / DFS traversal on the main stream; joined again before the entropy stage.
+  // The parallel kernels of the replay's preparation run on the MAIN stream, before the fork: beside the renumber / seams group they
+  // took 25 + 39 ms of the auxiliary stream's time (its workgroups wait behind the main stream's 5 M-workgroup grids), which made
+  // the auxiliary chain (125 ms) longer than the group it hides behind (70 ms) - the join below waited ~55 ms per batch.
+  {
+    LAUNCH(k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
+    LAUNCH(k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_valence_init, dim3(bc, N), dim3(UVOL_BLOCK), dj);
+  }
   UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_walk, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(G->aux, G->ev_walk, 0));
   {
-    LAUNCH_ON(G->aux, k_eb_event_flags, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH_ON(G->aux, k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_EVENTS);
-    LAUNCH_ON(G->aux, k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH_ON(G->aux, k_valence_init, dim3(bc, N), dim3(UVOL_BLOCK), dj);
     { uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence", 0, G->aux); LAUNCH_ON(G->aux, k_eb_valence, dim3(N), dim3(64), dj); }
     LAUNCH_ON(G->aux, k_eb_ctx, dim3(N), dim3(64), dj);
   }
