@@ -3262,6 +3262,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->jobs.p, G->hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   GeoJob *dj = (GeoJob *)G->jobs.p;
   const unsigned N = (unsigned)n;
+  const double t_prep = ms_since(t_enter);
   LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
                  be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
@@ -3490,7 +3491,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     if (status) status[i] = st1;
     if (st1 != UVOL_OK) worst = st1;
   }
-  if (timing) fprintf(stderr, "[uvol-timing] geo batch n=%d sizeof(GeoJob)=%zu: enqueued %.1f ms, gpu done %.1f, packed d2h %.1f, copied out %.1f (enter at %.1f)\n", n, sizeof(GeoJob), t_enq, t_gpu, t_d2h, ms_since(t_enter),
+  if (timing) fprintf(stderr, "[uvol-timing] geo batch n=%d sizeof(GeoJob)=%zu: host prepared %.1f ms, enqueued %.1f, gpu done %.1f, packed d2h %.1f, copied out %.1f (enter at %.1f)\n", n, sizeof(GeoJob), t_prep, t_enq, t_gpu, t_d2h, ms_since(t_enter),
                       std::chrono::duration<double, std::milli>(t_enter.time_since_epoch()).count());
   return status ? UVOL_OK : worst;
 }
