@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the workload variants reported next to the headline on one GPU")
     ap.add_argument("--traverse-vbits-l2", type=int, default=0, help="LDS walkers (small batches): 1 = attribute traversers keep their vertex bitmap in L2")
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
+    ap.add_argument("--geo-priority", type=int, default=0, help="1: geometry contexts use a high-priority HIP stream (diagnostic)")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
@@ -128,6 +129,8 @@ def main():
     GS = max(1, args.geo_streams)
     if args.tex_priority:
         tcfg.update(stream_priority=1)
+    if args.geo_priority:
+        gcfg.update(stream_priority=1)
     if args.traverse_vbits_l2 == 1:
         gcfg.update(traverse_vbits_l2=1)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]

@@ -74,6 +74,7 @@ struct GeoJob {
   int32_t *forig, *s_of_o;                 // stored face -> original kept-face index, and back
   // sequential connectivity (DRACO_COMPRESSION_LEVEL 0, k_sq_*): points = distinct (position, uv, normal) value triples in order
   // of first appearance over the corners; a 64-bit-keyed hash table finds the first corner of every pair, twice
+  int32_t late_join;        // small batches: the auxiliary stream (valence replay) is joined before the entropy stage, not before the record tables (its inputs then keep their own bytes)
   int32_t seq; uint32_t sq_cap, sq_np, sq_idx_bytes;
   unsigned long long *sq_keys; uint32_t *sq_val;
   int32_t *sq_pu, *sq_first, *sq_pid, *sq_cop;       // per corner: first corner with the same (pos, uv) / the same triple; point id; per point: its first corner

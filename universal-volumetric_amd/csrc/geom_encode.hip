@@ -2932,20 +2932,21 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
     J.he_nb = J.he_vpb ? (J.n_pos + vpb - 1) / vpb : 0u; J.he_nblk = J.he_vpb ? (uint32_t)((nc + HE_TILE - 1) / HE_TILE) : 0u;
     if (J.he_vpb) { CARVE(J.he_part, uint32_t, 3 * nc + 4, PH_CT, PH_CT); CARVE(J.he_cnt, uint32_t, (size_t)J.he_nb * J.he_nblk + 2, PH_CT, PH_CT); }
   }
-  CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_SEAMS);                     // events / valence replay (auxiliary stream) read it until the join
+  const int aux_last = J.late_join ? PH_PRED : PH_SEAMS;            // what the auxiliary stream (valence replay, context scatter) reads lives until its join
+  CARVE(J.opp, int32_t, nc + 3, PH_CT, aux_last);
   CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_SEAMS);
   // ---- K4 ----
   const size_t rec_bytes = (r8 ? 32 : 64) * (nfi + 1);
   CARVE(J.rec[0], uint8_t, rec_bytes, PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
   for (int w = 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
   CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_SEAMS);
-  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, PH_SEAMS);
-  CARVE(J.proc, int32_t, nfi + 1, PH_WALK, PH_SEAMS); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, PH_SEAMS);
+  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, aux_last);
+  CARVE(J.proc, int32_t, nfi + 1, PH_WALK, aux_last); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, aux_last);
   CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_RENUM); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
   // auxiliary stream (forked after PH_FTIME, joined before PH_HIST)
   CARVE(J.evcnt, uint8_t, nfi + 1, PH_RENUM, PH_SEAMS);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_spl, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT);
-  CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, PH_SEAMS); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, PH_SEAMS); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, PH_SEAMS);
+  CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, aux_last); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, aux_last); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, aux_last);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1, PH_RENUM, PH_ENT);
   // ---- renumbering, seams ----
   CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
@@ -3194,6 +3195,11 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   // DRACO_COMPRESSION_LEVEL 0 selects sequential connectivity in stock draco_encoder (speed 10); every other level is written with the
   // level-7 tool set (valence edgebreaker)
   const bool seq = prm.draco_compression_level == 0;
+  // The valence replay is one wave per frame and takes what one frame takes (~25-50 ms); the renumber / seams group it runs beside shrinks
+  // with the batch.  Below ~1200 frames the replay is the longer of the two, so it is joined late (before the entropy stage) and
+  // overlaps the traversals too; its inputs then cannot share bytes with the record tables (+7.7 MB per frame, irrelevant at that size).
+  static const int late_env = [] { const char *e = getenv("UVOL_LATE_JOIN"); return e ? atoi(e) : -1; }();      // tests: 0 / 1 force the early / late join
+  const bool late_join = late_env >= 0 ? late_env != 0 : n <= 1200;
   G->hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
@@ -3207,7 +3213,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
-    J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = seq ? 0 : geo_relabel_mode(); J.seq = seq ? 1 : 0;
+    J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = seq ? 0 : geo_relabel_mode(); J.seq = seq ? 1 : 0; J.late_join = late_join ? 1 : 0;
     J.has_uv = (m.uv && m.idx_uv && m.n_uv) ? 1 : 0; J.has_nrm = (m.nrm && m.idx_nrm && m.n_nrm) ? 1 : 0;
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
@@ -3385,7 +3391,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   // entropy stage: it then overlaps the renumber / seams group only (about as long), but everything it reads (old-order
   // opposite corners and vertices, the symbol sequence, the valence scratch: 11.6 MB per frame) is dead before the three record
   // tables of the attribute traversals are written and shares their addresses - the workspace peak drops from 63 to 52 MB.
-  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
+  if (!late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
     LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, r8);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
@@ -3413,6 +3419,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_ori_bits, dim3(be, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_pred_nrm, dim3(be, N), dim3(UVOL_BLOCK), dj);
   }
+  if (late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
   {
     uvol_ctx::Scope sc0(ctx, "geo.k7_hist_tables", 0);
     LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi, 16 * UVOL_BLOCK), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
