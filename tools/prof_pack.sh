@@ -8,7 +8,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o ben
 cp $(find $O/kt -name bench_kernel_stats.csv | head -1) $O/kernel_stats.csv
 # HBM traffic of every kernel: tools/pmc_pack.sh (own processes per half)
 rm -rf $O/kt
-PMC_TIMEOUT=150 bash tools/pmc_pack.sh $TAG
+PMC_TIMEOUT=200 bash tools/pmc_pack.sh $TAG
 python tools/uastc_timing.py 24 > $O/uastc_timing.json 2>> $O/bench.err
 python tools/dec_timing.py 96 > $O/dec_timing.json 2>> $O/bench.err
 python tools/gdec_timing.py 1920 > $O/gdec_timing.json 2>> $O/bench.err
