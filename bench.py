@@ -87,7 +87,7 @@ def main():
         F = args.frames_per_step
         assert F % B == 0
         nseg = F // B
-    variants_on = world == 1 and not args.no_variants and not args.only and not args.host_inputs and not strong and args.mesh_order == "lattice"
+    variants_on = world == 1 and not args.no_variants and (not args.only or os.environ.get("UVOL_VARIANTS_WITH_ONLY") == "1") and not args.host_inputs and not strong and args.mesh_order == "lattice"
     F_alloc = max(F, 1)
 
     # ---- synthetic frames (seeded), uploaded once; inputs are resident in HBM when timing starts ----
@@ -303,7 +303,10 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     import torch
     import uvol, synth
     v = {}
+    def note(what):                                            # progress on stderr (a fault in a variant is then attributable)
+        print("[bench] variant: " + what, file=sys.stderr, flush=True)
     # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
+    note("events_off")
     set_profiling(False)
     r = Job(F).timed(2, 0)
     v["events_off"] = dict(r, note="headline workload without the per-group hipEvent brackets; ms_per_step with them: %.1f" % ms_step,
@@ -312,12 +315,16 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     #     BASELINE configs[3] (1200 frames, 150 per GPU): 8 x rate(150-frame job) / rate(1200-frame job on one GPU)
     for n in (150, 300, 1200):
         if n <= F:
+            note("job_%d" % n)
             v["job_%d" % n] = Job(n).timed(3, 1)
     if "job_150" in v and "job_1200" in v:
         v["projected_8gpu_speedup_configs3"] = {"value": 8.0 * v["job_150"]["frames_per_s"] / v["job_1200"]["frames_per_s"],
                                                 "how": "8 x frames/s of the 150-frame share of one GPU / frames/s of the whole 1200-frame job on one GPU; "
                                                        "the manifest gather (32 bytes per rank) is not modelled"}
+    if args.only:                                              # (diagnostic: UVOL_VARIANTS_WITH_ONLY=1) one half of the path, job sizes only
+        return v
     # (2) scan-like storage order: the resident input buffers are overwritten with a seeded permutation of faces and values
+    note("shuffled_order")
     sh = [synth.shuffle_mesh(m, seed=100 + k) for k, m in enumerate(meshes_h)]
     for i, t in enumerate(frame_t):
         for key, val in sh[i % len(sh)].items():
@@ -325,11 +332,13 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     torch.cuda.synchronize()
     v["shuffled_order"] = dict(Job(F).timed(2, 1), note="same surfaces, faces and value arrays in a seeded random order (no locality between consecutive faces)")
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
+    note("host_inputs")
     frame_t.clear(); keep.clear()
     torch.cuda.empty_cache()
     nh = min(F, 1080)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
+    note("decode")
     drc = [bytes(x) for x in out["drc"][:480]]; ktx = list(out["ktx2"][:192])
     drc = (drc * 4)[:1920]                                      # one call of 1920 frames (~90 MB of decode workspace each)
     for c in geos + texs:

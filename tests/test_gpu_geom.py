@@ -334,6 +334,24 @@ def test_gpu_256_full_size_frames_in_one_batch(oracle, gpu_codec):
         assert r == first[k], (i, k)
 
 
+def test_gpu_batch_sizes_alternate_on_one_context(oracle):
+    """Batches above 1200 frames join the auxiliary stream (valence replay) before the attribute record tables are written, its
+    inputs sharing their bytes; smaller batches join it before the entropy stage and give those arrays longer lifetimes.  The
+    workspace plan is cached per frame shape - and must be keyed by that choice too: a small batch after a large one of the same
+    shape once inherited the large batch's plan and raced (found by the bench's variants).  Same shape, 1300 frames then 7, then
+    1300 again, one context: bytes of the oracle every time."""
+    import synth, uvol
+    frames = [synth.sphere_mesh(40, 21, charts=(5, 4), frame=k % 4) for k in range(1300)]
+    want = [oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm")) for f in frames[:4]]
+    cd = uvol.Codec(device=0, max_batch=1300)
+    try:
+        for n in (1300, 7, 1300, 150):
+            got = cd.encode_mesh_batch(frames[:n])
+            assert all(got[i] == want[i % 4] for i in range(n)), n
+    finally:
+        cd.close()
+
+
 def test_gpu_enqueue_form_of_the_abi(oracle, gpu_codec):
     """uvol_encode_mesh_batch_async / uvol_encode_texture_segments_async + uvol_sync on the device: several calls enqueued back to
     back, results equal to the blocking entry points' (and the oracle's), a failing frame fails alone."""

@@ -1,5 +1,6 @@
 # tools/prof_pack.sh <tag>: the measurement pack of a build (run on the GPU box through gpurun); results under gpurun_out/<tag>/
 TAG=$1
+ulimit -c 0; export HSA_ENABLE_COREDUMP=0          # a GPU fault must not fill the box's disk with a core dump (it did once, and every later step failed)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err

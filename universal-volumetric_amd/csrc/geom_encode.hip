@@ -2999,7 +2999,7 @@ void ws_place(std::vector<WsItem> &items, WsPlan &P) {
 // of jobs with the same dimensions (a sequence's frames usually are).
 size_t layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlan &P, std::vector<WsItem> &items) {
   ws_collect(J, full, r8, items);
-  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26) | ((uint64_t)(J.seq != 0) << 27), items.size() };
+  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26) | ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28), items.size() };      // everything ws_collect's sizes AND lifetimes depend on
   if (key != P.key) { ws_place(items, P); P.key = key; }
   if (base) for (size_t i = 0; i < items.size(); i++) *reinterpret_cast<uint8_t **>((char *)&J + items[i].slot) = base + P.offs[i];
   return P.total;
