@@ -283,6 +283,11 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   UVOL_G(int32_t) val = UVOL_TO_G(int32_t, J.val); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) tsac = UVOL_TO_G(int32_t, J.tsac);
   UVOL_G(const uint32_t) ctxs[6]; for (int i = 0; i < 6; i++) ctxs[i] = UVOL_TO_G(const uint32_t, J.rs[i].out);
   int cnt[6]; for (int i = 0; i < 6; i++) cnt[i] = (int)J.rs[i].nvals;
+  // the next two symbols of every context are kept in registers (the streams are consumed from their ends): the symbol a step needs is
+  // chosen by a valence it has only just computed, and a load issued then would be one more round trip in a chain of five
+  uint32_t q0[6], q1[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { q0[i] = (!STD && cnt[i] > 0) ? ctxs[i][cnt[i] - 1] : 0u; q1[i] = (!STD && cnt[i] > 1) ? ctxs[i][cnt[i] - 2] : 0u; }
   GDBit SF; if (gd_rabs_open(SF, J, J.rb_start)) { J.status = -7; return; }
   int rc = 0, nv = 0, sp = 0, nfaces = 0, active_ctx = -1, splits_left = nts, n_int = 0;
   int top = GEO_INV;                 // mirror of stack[sp - 1]: the machine reads its own last write most of the time
@@ -299,16 +304,27 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
       sym = (sbits[sbit >> 3] >> (sbit & 7)) & 1; sbit++;
       if (sym) { if (sbit + 2 > sbit_n) { rc = -10; break; } for (int k = 0; k < 2; k++, sbit++) sym |= ((sbits[sbit >> 3] >> (sbit & 7)) & 1) << (1 + k); }
     }
-    else if (active_ctx != -1) { if (--cnt[active_ctx] < 0) { rc = -10; break; } const uint32_t s = ctxs[active_ctx][cnt[active_ctx]]; if (s > 4) { rc = -10; break; } sym = SYM2TOPO[s]; }
+    else if (active_ctx != -1) {
+      uint32_t s = 0; bool under = false;
+#pragma unroll
+      for (int i = 0; i < 6; i++) if (active_ctx == i) {          // (unrolled: the per-context registers must not become a scratch array)
+        if (--cnt[i] < 0) under = true;
+        else { s = q0[i]; q0[i] = q1[i]; q1[i] = cnt[i] > 1 ? ctxs[i][cnt[i] - 2] : 0u; }
+      }
+      if (under || s > 4) { rc = -10; break; }
+      sym = SYM2TOPO[s];
+    }
     else sym = 7;
     const int corner = 3 * face;
     if (sym == 0) {
       if (sp == 0) { rc = -11; break; }
-      const int ca = top; if (GD_BADC(ca)) { rc = -11; break; } const int vx = c2v[g_nxt(ca)]; if (GD_BADV(vx) || GD_BADC(lm[vx])) { rc = -11; break; }
-      const int cb = g_nxt(lm[vx]);
+      // `top` is always corner 0 of the face added by the previous symbol, whose vertices are still in fv0..fv2: no c2v reads for it
+      const int ca = top; if (GD_BADC(ca)) { rc = -11; break; } const int vx = fv1; if (GD_BADV(vx)) { rc = -11; break; }
+      const int lmx = lm[vx]; if (GD_BADC(lmx)) { rc = -11; break; }
+      const int cb = g_nxt(lmx);
       if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -11; break; }
       GD_SETOPP(ca, corner + 1); GD_SETOPP(cb, corner + 2);
-      const int vap = c2v[g_prv(ca)], vbn = c2v[g_nxt(cb)]; if (GD_BADV(vap) || GD_BADV(vbn)) { rc = -11; break; }
+      const int vap = fv2, vbn = c2v[g_nxt(cb)]; if (GD_BADV(vap) || GD_BADV(vbn)) { rc = -11; break; }
       c2v[corner] = vx; c2v[corner + 1] = vbn; c2v[corner + 2] = vap; lm[vap] = corner + 2;
       fv0 = vx; fv1 = vbn; fv2 = vap;
       stack[sp - 1] = corner; top = corner;
@@ -318,7 +334,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
       int oc, cl, cr;
       if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; } else { oc = corner + 1; cl = corner; cr = corner + 2; }
       GD_SETOPP(oc, ca); const int nvx = GD_ADDV(); if (rc) break; c2v[oc] = nvx; lm[nvx] = oc;
-      const int vr = c2v[g_prv(ca)], vl = c2v[g_nxt(ca)]; if (GD_BADV(vr) || GD_BADV(vl)) { rc = -12; break; } c2v[cr] = vr; lm[vr] = cr;
+      const int vr = fv2, vl = fv1; if (GD_BADV(vr) || GD_BADV(vl)) { rc = -12; break; } c2v[cr] = vr; lm[vr] = cr;
       c2v[cl] = vl;
       if (sym == 5) { fv0 = vr; fv1 = vl; fv2 = nvx; } else { fv0 = vl; fv1 = nvx; fv2 = vr; }
       stack[sp - 1] = corner; top = corner; check = 1;
@@ -350,11 +366,15 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
     }
     { // the active corner is corner 0 of the face just added: its vertices are fv0 (corner), fv1 (next), fv2 (prev)
       if (GD_BADV(fv0) || GD_BADV(fv1) || GD_BADV(fv2)) { rc = -18; break; }
-      if (sym == 0 || sym == 1) { val[fv1] += 1; val[fv2] += 1; }
-      else if (sym == 5) { val[fv0] += 1; val[fv1] += 1; val[fv2] += 2; }
-      else if (sym == 3) { val[fv0] += 1; val[fv1] += 2; val[fv2] += 1; }
-      else { val[fv0] += 2; val[fv1] += 2; val[fv2] += 2; }
-      int av = val[fv1]; av = av < 2 ? 2 : (av > 7 ? 7 : av); active_ctx = av - 2; }
+      // valence increments of the face's three vertices (C / S: 0 1 1, R: 1 1 2, L: 1 2 1, E: 2 2 2), applied in corner order; the three old
+      // values are fetched together and the new valence of fv1 - the next symbol's context - is taken from registers: reading it back
+      // after the stores was one more round trip through L2 in the chain (aliases among the three only occur in degenerate streams)
+      const int i0 = (sym == 0 || sym == 1) ? 0 : (sym == 7 ? 2 : 1), i1 = sym == 3 || sym == 7 ? 2 : 1, i2 = sym == 5 || sym == 7 ? 2 : 1;
+      const int o0 = val[fv0], o1 = val[fv1], o2 = val[fv2];
+      const int t0 = o0 + i0, t1 = (fv1 == fv0 ? t0 : o1) + i1, t2 = (fv2 == fv1 ? t1 : (fv2 == fv0 ? t0 : o2)) + i2;
+      if (i0) val[fv0] = t0;
+      val[fv1] = t1; val[fv2] = t2;
+      int av = fv2 == fv1 ? t2 : t1; av = av < 2 ? 2 : (av > 7 ? 7 : av); active_ctx = av - 2; }
     if (check) {
       const int esid = nsym - sid - 1;
       while (splits_left > 0 && J.sp_src[splits_left - 1] == esid) {
