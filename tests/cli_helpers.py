@@ -14,7 +14,7 @@ def write_obj(path, m):
             f.write("f " + " ".join("%d/%d/%d" % (a[k], b[k], c[k]) for k in range(3)) + "\n")
 
 
-def make_sequence(root, n_frames=10, tex=64, batch=5, comments=True):
+def make_sequence(root, n_frames=10, tex=64, batch=5, comments=True, alpha=False):
     import synth
     from PIL import Image
     os.makedirs(os.path.join(root, "OBJ")); os.makedirs(os.path.join(root, "PNG"))
@@ -22,6 +22,12 @@ def make_sequence(root, n_frames=10, tex=64, batch=5, comments=True):
     for k, m in enumerate(meshes):
         write_obj(os.path.join(root, "OBJ", "frame_%05d.obj" % k), m)
     texs = synth.texture_sequence(n_frames, size=tex, seed=3)
+    if alpha:                                  # RGBA PNGs with a real alpha channel (a moving soft disc): basisu would write alpha slices
+        import numpy as np
+        yy, xx = np.mgrid[0:tex, 0:tex]
+        texs = [t.copy() for t in texs]
+        for k, t in enumerate(texs):
+            t[..., 3] = np.clip(((xx - tex // 2 - 2 * k) ** 2 + (yy - tex // 2) ** 2) * (900.0 / tex ** 2), 0, 255).astype(np.uint8)
     for k, t in enumerate(texs):
         Image.fromarray(t, "RGBA").save(os.path.join(root, "PNG", "export_%05d.png" % k))
     cfg = {"name": "test", "OBJFilesPath": os.path.join(root, "OBJ", "frame_#####.obj"), "ImagesPath": os.path.join(root, "PNG", "export_#####.png"),

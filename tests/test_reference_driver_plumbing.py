@@ -84,6 +84,27 @@ def test_uvolenc_hipemu_pipeline(oracle, tmp_path):
         assert os.path.isfile(os.path.join(out, rel)), rel
 
 
+def test_uvolenc_hipemu_rgba_pngs_get_alpha_slices(oracle, tmp_path):
+    """PNGs with an alpha channel through the whole driver: the segments carry alpha slices exactly as the oracle writes
+    them (second slice per image, second DFD sample), the manifest is unchanged; `--targets ...,etc2` is an opaque format and fails
+    loudly on such a sequence instead of dropping the channel."""
+    import cli_helpers
+    pkg = os.path.join(ROOT, "universal-volumetric_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "hipemu-bins"])
+    cfgp, cfg, meshes, texs = cli_helpers.make_sequence(str(tmp_path), n_frames=4, tex=32, batch=2, alpha=True)
+    exe = os.path.join(ROOT, "tests", "hipemu", "bin", "uvolenc")
+    r = subprocess.run([exe, cfgp, "--batch-frames", "4"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = cfg["OutputDirectory"]
+    for s in range(2):
+        got = open(os.path.join(out, "texture_ktx2_baseColor_default", "%05d.ktx2" % s), "rb").read()
+        assert got == oracle.ktx2_encode(texs[2 * s:2 * s + 2])
+        d = oracle.ktx2_decode(got)
+        assert d.has_alpha == 1 and d.layers == 2 and d.n_slices == 4
+    r = subprocess.run([exe, cfgp, "--batch-frames", "4", "--targets", "ktx2,etc2", "--force"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "alpha" in (r.stdout + r.stderr)
+
+
 def test_uvolenc_hipemu_targets_etc2_and_multi_gpu_plan(oracle, tmp_path):
     """`--targets ktx2,etc2` (src/Interfaces.ts:19, :60-73): one raw ETC2-RGB block image per frame next to the KTX2
     segments, both targets in the manifest; a renderer with the ETC extension picks `etc2` (src/V2/player.ts:208-222) and every URL
