@@ -13,7 +13,7 @@ import numpy as np
 import oracle as o, synth, uvol
 from test_hipemu_tex import _alpha_sequence
 
-lib = os.path.join(ROOT, "tests", "hipemu", "libuvolcodec_hipemu_asan.so")
+lib = os.environ.get("UVOL_SAN_LIB", os.path.join(ROOT, "tests", "hipemu", "libuvolcodec_hipemu_asan.so"))
 ncorrupt = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 o.lib()
 cd = uvol.Codec(lib_path=lib)
