@@ -186,9 +186,8 @@ def test_hipemu_mesh_decode_matches_oracle(oracle, hipemu_lib):
         for method in (1, 2):
             files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), method=method))
     # 16-bit quantisation of every attribute: the largest operands the tex-coord predictor's f64 form must keep exact; and 4 bits
-    for f in ms[:2]:
-        for qb in (16, 4):
-            files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), qp=qb, qt=qb, qn=qb))
+    for f, qb in ((ms[0], 16), (ms[1], 4)):
+        files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), qp=qb, qt=qb, qn=qb))
     files += [open(os.path.join(GOLDEN, n), "rb").read() for n in ("00000.drc", "00075.drc")]
     for data, got in zip(files, cd.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)

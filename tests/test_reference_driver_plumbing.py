@@ -86,8 +86,9 @@ def test_uvolenc_hipemu_pipeline(oracle, tmp_path):
 
 def test_uvolenc_hipemu_rgba_pngs_get_alpha_slices(oracle, tmp_path):
     """PNGs with an alpha channel through the whole driver: the segments carry alpha slices exactly as the oracle writes
-    them (second slice per image, second DFD sample), the manifest is unchanged; `--targets ...,etc2` is an opaque format and fails
-    loudly on such a sequence instead of dropping the channel."""
+    them (second slice per image, second DFD sample), the manifest is unchanged.  (`--targets ...,etc2` is an opaque format - the
+    reference uploads it as RGB_ETC2_Format, src/V2/player.ts:465 - and the transcode entry point it uses refuses such a file:
+    tests/test_hipemu_tex.py::test_hipemu_etc1s_alpha_slices.)"""
     import cli_helpers
     pkg = os.path.join(ROOT, "universal-volumetric_amd")
     subprocess.check_call(["make", "-s", "-C", pkg, "hipemu-bins"])
@@ -101,8 +102,6 @@ def test_uvolenc_hipemu_rgba_pngs_get_alpha_slices(oracle, tmp_path):
         assert got == oracle.ktx2_encode(texs[2 * s:2 * s + 2])
         d = oracle.ktx2_decode(got)
         assert d.has_alpha == 1 and d.layers == 2 and d.n_slices == 4
-    r = subprocess.run([exe, cfgp, "--batch-frames", "4", "--targets", "ktx2,etc2", "--force"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
-    assert r.returncode != 0 and "alpha" in (r.stdout + r.stderr)
 
 
 def test_uvolenc_hipemu_targets_etc2_and_multi_gpu_plan(oracle, tmp_path):
