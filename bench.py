@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames-per-step", type=int, default=2160, help="frames in flight per step (per GPU); a frame holds ~55 MB of geometry workspace + 27 MB of inputs")
+    ap.add_argument("--frames-per-step", type=int, default=2560, help="frames in flight per step (per GPU); a frame holds ~56 MB of geometry workspace + 27 MB of inputs: 2560 frames leave ~17 GB of the 288 GB free (2760 no longer fit)")
     ap.add_argument("--total-frames", type=int, default=0, help="STRONG scaling: one job of this many frames split over the ranks (shard.plan, whole texture segments per rank); "
                                                                 "a step is the whole job.  BASELINE configs[3]: --total-frames 1200 --gpus 8")
     ap.add_argument("--tex-size", type=int, default=2048)
