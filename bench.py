@@ -46,7 +46,11 @@ def main():
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
     ap.add_argument("--batch", type=int, default=5, help="KTX2_BATCH_SIZE")
-    ap.add_argument("--distinct", type=int, default=5, help="distinct synthetic frames whose content is cycled")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames whose content is cycled (each its own tessellation; >= 64 for the headline)")
+    ap.add_argument("--connectivity", choices=["distinct", "identical"], default="distinct",
+                    help="distinct (headline): every synthetic frame has its own connectivity and vertex count, like a capture's frames; identical (DIAGNOSTIC): "
+                         "the frames share one index array (an animated mesh of fixed topology) and the lane-per-walker kernels run in lock step")
+    ap.add_argument("--parity-frames", type=int, default=8, help="frames of the timed step whose bytes are compared with the CPU oracle's after the timed region (0: skip)")
     ap.add_argument("--shared-inputs", action="store_true", help="DIAGNOSTIC: all frames read the same --distinct input buffers / one texture segment")
     ap.add_argument("--geo-streams", type=int, default=1, help="geometry contexts (HIP streams); frames of a step are split evenly between them")
     ap.add_argument("--mesh-order", choices=["lattice", "shuffled"], default="lattice", help="DIAGNOSTIC 'shuffled': seeded permutation of faces and values (scan-like storage order, no cache-line locality between consecutive faces)")
@@ -91,27 +95,38 @@ def main():
     F_alloc = max(F, 1)
 
     # ---- synthetic frames (seeded), uploaded once; inputs are resident in HBM when timing starts ----
-    meshes_h = [synth.sphere_mesh(args.segs, args.rings, frame=k, seed=k) for k in range(args.distinct)]
+    def identical_meshes():                # round 1-3's workload: five seeded deformations of ONE tessellation (shared index arrays)
+        return [synth.sphere_mesh(args.segs, args.rings, frame=k, seed=k) for k in range(min(args.distinct, 5))]
+    meshes_h = synth.distinct_meshes(args.distinct, args.segs, args.rings) if args.connectivity == "distinct" else identical_meshes()
     if args.mesh_order == "shuffled":
         meshes_h = [synth.shuffle_mesh(m, seed=100 + k) for k, m in enumerate(meshes_h)]
     tex_h = synth.texture_sequence(B, size=args.tex_size, seed=0)
-    V, Fc = len(meshes_h[0]["pos"]), len(meshes_h[0]["idx_pos"]) // 3
     keep = []
     dev_meshes = []
-    # every frame of the step has its OWN input buffers in HBM (content cycles through the --distinct synthetic frames): no
-    # frame finds its inputs in a cache because another frame of the batch read the same addresses
-    base_t = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in m.items()} for m in meshes_h]
     frame_t = []
-    for i in range(F_alloc if not args.shared_inputs else args.distinct):
-        m = meshes_h[i % args.distinct]
-        t = base_t[i % args.distinct] if i < args.distinct else {k: v.clone() for k, v in base_t[i % args.distinct].items()}
-        frame_t.append(t)
-        mm = uvol.Mesh()
-        mm.pos = t["pos"].data_ptr(); mm.n_pos = len(m["pos"]); mm.uv = t["uv"].data_ptr(); mm.n_uv = len(m["uv"])
-        mm.nrm = t["nrm"].data_ptr(); mm.n_nrm = len(m["nrm"])
-        mm.idx_pos = t["idx_pos"].data_ptr(); mm.idx_uv = t["idx_uv"].data_ptr(); mm.idx_nrm = t["idx_nrm"].data_ptr()
-        mm.n_faces = len(m["idx_pos"]) // 3
-        dev_meshes.append(mm)
+
+    def build_inputs(mh):
+        """Every frame of the step gets its OWN input buffers in HBM (content cycles through the synthetic frames `mh`): no frame finds
+        its inputs in a cache because another frame of the batch read the same addresses.  Replaces the previous set."""
+        del dev_meshes[:]; del frame_t[:]
+        torch.cuda.empty_cache()
+        nd = len(mh)
+        base_t = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in m.items()} for m in mh]
+        for i in range(F_alloc if not args.shared_inputs else nd):
+            m = mh[i % nd]
+            t = base_t[i % nd] if i < nd else {k: v.clone() for k, v in base_t[i % nd].items()}
+            frame_t.append(t)
+            mm = uvol.Mesh()
+            mm.pos = t["pos"].data_ptr(); mm.n_pos = len(m["pos"]); mm.uv = t["uv"].data_ptr(); mm.n_uv = len(m["uv"])
+            mm.nrm = t["nrm"].data_ptr(); mm.n_nrm = len(m["nrm"])
+            mm.idx_pos = t["idx_pos"].data_ptr(); mm.idx_uv = t["idx_uv"].data_ptr(); mm.idx_nrm = t["idx_nrm"].data_ptr()
+            mm.n_faces = len(m["idx_pos"]) // 3
+            dev_meshes.append(mm)
+        torch.cuda.synchronize()
+    build_inputs(meshes_h)
+    ND = len(meshes_h)
+    V = sum(len(meshes_h[i % ND]["pos"]) for i in range(F_alloc)) / F_alloc                  # per-frame averages over the frames of a step
+    Fc = sum(len(meshes_h[i % ND]["idx_pos"]) // 3 for i in range(F_alloc)) / F_alloc
     tex_d = [torch.from_numpy(a).to(dev) for a in tex_h]
     tex_ptrs = [t.data_ptr() for t in tex_d]
     # texture segments: own buffers AND own content per segment (the base segment shifted by whole 4x4 blocks along x)
@@ -145,7 +160,7 @@ def main():
             self.gsl = [(gi * n // GS, (gi + 1) * n // GS) for gi in range(GS)]
             nd = len(dev_meshes)
             self.gb = [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
-            self.hf = [meshes_h[i % args.distinct] for i in range(n)] if host else None
+            self.hf = [meshes_h[i % ND] for i in range(n)] if host else None
 
         def run_geo(self, gi):
             a, b = self.gsl[gi]
@@ -256,17 +271,20 @@ def main():
         achieved = algo_per_frame * units / (avg_ms * 1e-3) / 1e9
         workload = ("BASELINE configs[3] shape: ONE job of %d frames split over %d rank(s) by whole texture segments (rank 0: %d frames)" % (args.total_frames, world, F)) if strong else \
                    ("BASELINE configs[2] shape, %d frames per step" % F)
+        conn = ("distinct connectivity per frame (%d tessellations cycled: vertex / face counts, chart seams and quad diagonals differ from frame to frame)" % ND) if args.connectivity == "distinct" else \
+               "DIAGNOSTIC identical connectivity (the frames share one index array: lane-per-walker kernels run in lock step)"
         res = {
             "metric": "frames/s encode, 100k-vert mesh + 2048^2 texture",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else "") + (" DIAGNOSTIC %s only" % args.only if args.only else ""),
-            "config": {"workload": "%s: %d-vertex/%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, qp11/qt10/qn8/cl7; %s%s"
-                                   % (workload, V, Fc, args.tex_size, args.tex_size, B, "DIAGNOSTIC shuffled face / value order; " if args.mesh_order == "shuffled" else "",
+            "config": {"workload": "%s, %s: ~%d-vertex/~%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, qp11/qt10/qn8/cl7; %s%s"
+                                   % (workload, conn, round(V), round(Fc), args.tex_size, args.tex_size, B, "DIAGNOSTIC shuffled face / value order; " if args.mesh_order == "shuffled" else "",
                                       "DIAGNOSTIC shared input buffers" if args.shared_inputs else "every frame / segment reads its own input buffers in HBM"),
                        "frames_per_step": F if not strong else args.total_frames, "ktx2_batch_size": B,
                        "parallelism": "frames sharded per GPU in blocks of whole segments; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
-                       "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len, "mesh_order": args.mesh_order,
+                       "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len, "mesh_order": args.mesh_order, "connectivity": args.connectivity, "distinct_frames": ND,
+                       "vertices_per_frame": V, "faces_per_frame": Fc,
                        "geometry_workspace_bytes_per_frame": geos[0].mesh_workspace(**meshes_h[0])},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], units), "avg_launch_ms": avg_ms, "units_per_launch": units,
@@ -282,9 +300,12 @@ def main():
                                     "frac": tops / I8_PEAK_TOPS, "avg_launch_ms": mfma_grp["total_ms"] / max(1, mfma_grp["launches"]),
                                     "ops_per_launch": mfma_grp["algo_bytes"] / max(1, mfma_grp["launches"]), "dtype": "i8 x i8 -> i32"}
         res["quality"] = quality_gates(geos[0], texs[0], out, meshes_h[0], tex_h, B) if not args.only and F else None
+        if args.parity_frames > 0 and F and not args.host_inputs:
+            res["parity"] = parity_check(out, meshes_h, tex_h, args.parity_frames, args.only, args.mesh_order)
+            res["parity_checked_frames"] = res["parity"].get("geometry_frames_equal_to_oracle", 0)
         if variants_on:
             try:
-                res["variants"] = run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, res["ms_per_step"], F, B, V, Fc, local_rank)
+                res["variants"] = run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, res["ms_per_step"], F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes)
             except Exception as e:                                   # the headline stands on its own
                 res["variants"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
@@ -296,7 +317,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, ms_step, F, B, V, Fc, local_rank):
+def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, ms_step, F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes):
     """The same path on other boundaries / job sizes / storage orders, each a few passes (about 25 s in all), reported NEXT TO the
     headline: what a user of the reference sees depends on where the inputs are and how large the job is (VERDICT r2 #3)."""
     import numpy as np
@@ -331,9 +352,15 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
             t[key].copy_(torch.from_numpy(np.ascontiguousarray(val)), non_blocking=False)
     torch.cuda.synchronize()
     v["shuffled_order"] = dict(Job(F).timed(2, 1), note="same surfaces, faces and value arrays in a seeded random order (no locality between consecutive faces)")
+    # (2b) rounds 1-3's headline workload: the frames share ONE index array, walkers of a wave never diverge (new input buffers)
+    if args.connectivity == "distinct":
+        note("identical_connectivity")
+        build_inputs(identical_meshes())
+        v["identical_connectivity"] = dict(Job(F).timed(2, 1), note="DIAGNOSTIC: five deformations of one tessellation (shared index arrays): the lane-per-walker kernels move in lock step; "
+                                                                     "this was `value` until round 3 and flatters the dominant kernel")
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
     note("host_inputs")
-    frame_t.clear(); keep.clear()
+    frame_t.clear(); keep.clear(); del dev_meshes[:]
     torch.cuda.empty_cache()
     nh = min(F, 1080)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
@@ -366,6 +393,50 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     except Exception as e:
         v["decode_error"] = repr(e)
     return v
+
+
+def parity_check(out, meshes_h, tex_h, n_check, only, mesh_order):
+    """After the timed region, the oracle as CHECKER only: (1) frames of the step with equal content must have byte-identical
+    outputs (frame i and frame i mod ND read equal bytes from different buffers); (2) `n_check` DISTINCT frames spread over the
+    step (and texture segment 0) must equal the CPU oracle's bytes for the same input.  A mismatch does not hide the line: it is
+    reported in it (`mismatches`) and on stderr."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    O.lib()
+    ND = len(meshes_h)
+    res = {"geometry_frames_equal_to_oracle": 0, "mismatches": []}
+    if only != "tex":
+        drc = out["drc"]; n = len(drc)
+        same = 0
+        for i in range(ND, n):
+            a, b = drc[i], drc[i % ND]
+            if len(a) == len(b) and np.array_equal(np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)):
+                same += 1
+            else:
+                res["mismatches"].append("drc[%d] != drc[%d] (equal content)" % (i, i % ND))
+        res["equal_content_frames_identical"] = same; res["equal_content_frames"] = max(0, n - ND)
+        pick = sorted({(k * n) // max(1, n_check) + (k % ND) for k in range(n_check)} & set(range(n))) if n else []
+        pick = pick[:n_check]
+        for i in pick:
+            m = meshes_h[i % ND]
+            ref = O.drc_encode(m["pos"], m["idx_pos"], m.get("uv"), m.get("idx_uv"), m.get("nrm"), m.get("idx_nrm"))
+            if bytes(drc[i]) == bytes(ref):
+                res["geometry_frames_equal_to_oracle"] += 1
+            else:
+                res["mismatches"].append("drc[%d] != oracle (content %d)" % (i, i % ND))
+        res["geometry_frames_checked"] = pick
+        res["geometry_distinct_contents_checked"] = len({i % ND for i in pick})
+    if only != "geo" and out.get("ktx2"):
+        ref = O.ktx2_encode(tex_h)
+        ok = bytes(out["ktx2"][0]) == bytes(ref)
+        res["texture_segments_equal_to_oracle"] = 1 if ok else 0
+        if not ok:
+            res["mismatches"].append("ktx2[0] != oracle")
+    if res["mismatches"]:
+        print("[bench] PARITY MISMATCH: %s" % res["mismatches"][:8], file=sys.stderr, flush=True)
+    res["mismatches"] = res["mismatches"][:16]
+    return res
 
 
 def quality_gates(geo, tex, out, mesh0, tex0, B):

@@ -334,6 +334,24 @@ def test_gpu_256_full_size_frames_in_one_batch(oracle, gpu_codec):
         assert r == first[k], (i, k)
 
 
+def test_gpu_1280_distinct_full_size_frames_in_one_call(oracle):
+    """the regime the bench runs in - more than 1200 frames of ~100 k vertices in ONE call, every frame with its OWN
+    connectivity (vertex / face counts, chart seams and quad diagonals differ; positions differ) - byte-checked against the oracle
+    on a sample spread over the call, every frame decodable in size (non-empty, plausible length)."""
+    import synth, uvol
+    n = 1280
+    frames = synth.distinct_meshes(n, bases=16)
+    assert len({(len(f["pos"]), len(f["idx_pos"])) for f in frames}) >= 12 and not np.array_equal(frames[0]["idx_pos"], frames[16]["idx_pos"])
+    cd = uvol.Codec(device=0, max_batch=n)
+    try:
+        res = cd.encode_mesh_batch(frames)
+    finally:
+        cd.close()
+    assert len(res) == n and all(100_000 < len(r) < 600_000 for r in res)
+    for i in (0, 1, 15, 16, 17, 333, 640, 641, 1000, 1201, 1278, 1279):
+        assert res[i] == _oracle_bytes(oracle, frames[i]), i
+
+
 def test_gpu_batch_sizes_alternate_on_one_context(oracle):
     """Batches above 1200 frames join the auxiliary stream (valence replay) before the attribute record tables are written, its
     inputs sharing their bytes; smaller batches join it before the entropy stage and give those arrays longer lifetimes.  The

@@ -93,6 +93,52 @@ def sphere_mesh(n_seg=400, n_ring=251, frame=0, charts=(40, 25), seed=0, crease=
     return dict(pos=pos, idx_pos=idx_pos.reshape(-1), uv=uv, idx_uv=idx_uv.reshape(-1), nrm=nrm, idx_nrm=idx_nrm.reshape(-1).astype(np.uint32))
 
 
+def flip_diagonals(m, n_seg, n_ring, seed, frac=0.5, jitter=0.0):
+    """A sphere_mesh() with a seeded subset of its body quads re-triangulated along the other diagonal: (a, c, b) + (b, c, d) becomes
+    (a, c, d) + (a, d, b) in all three index arrays.  Same surface, same value arrays, still a closed manifold with the same seams and
+    the same winding - but its own connectivity: the edgebreaker walk and the attribute traversals of two such frames take different
+    paths (a capture's frames never share an index array; the reference's 250 frames have 26,144 - 27,979 vertices each).
+    jitter > 0 also moves the positions by a seeded offset, so frames made from one base differ in content too."""
+    rng = np.random.default_rng(seed)
+    nq = n_seg * (n_ring - 2)                         # body quads, stored as face pairs right behind the top cap
+    pick = np.flatnonzero(rng.random(nq) < frac)
+    out = dict(m)
+    for key in ("idx_pos", "idx_uv", "idx_nrm"):
+        if m.get(key) is None:
+            continue
+        f = np.array(m[key]).reshape(-1, 3)
+        t1 = f[n_seg + 2 * pick]; t2 = f[n_seg + 2 * pick + 1]
+        assert np.array_equal(t1[:, 2], t2[:, 0]) and np.array_equal(t1[:, 1], t2[:, 1]), "quad halves do not share their diagonal"
+        a, c, b, d = t1[:, 0], t1[:, 1], t1[:, 2], t2[:, 2]
+        f[n_seg + 2 * pick] = np.stack([a, c, d], -1); f[n_seg + 2 * pick + 1] = np.stack([a, d, b], -1)
+        out[key] = f.reshape(-1)
+    if jitter > 0:
+        out["pos"] = (np.asarray(m["pos"], np.float32) + rng.standard_normal(np.asarray(m["pos"]).shape).astype(np.float32) * np.float32(jitter)).astype(np.float32)
+    return out
+
+
+def distinct_meshes(count, n_seg=400, n_ring=251, bases=None, charts=(40, 25)):
+    """`count` frames of about n_seg * (n_ring - 1) vertices, each with its OWN connectivity (SURVEY 8d's sequence made honest about
+    what a capture looks like).  Tessellations differ three ways: segment / ring counts within +-2 (vertex and face counts differ from
+    frame to frame), the chart grid of the UV atlas (+-1 column / row: different seams), and a seeded half of the quads flipped.
+    `bases` bounds the number of sphere_mesh() calls (0.5 s each at 100 k vertices): frame k is base k % bases with its own flips and,
+    from the second use of a base on, its own position jitter.  Default: one base per frame up to 64."""
+    bases = min(count, 64) if bases is None else max(1, min(bases, count))
+    var = [(0, 0), (1, -1), (-1, 1), (2, 0), (0, 2), (-2, 1), (1, -2), (-1, -1), (2, 2), (-2, -2), (0, -1), (-1, 0), (1, 1), (2, -1), (-2, 2), (0, 1)]
+    small = n_seg < 24 or n_ring < 16                  # tiny test meshes keep their lattice (the +-2 would change them by a large factor)
+    B = []
+    for b in range(bases):
+        ds, dr = (0, 0) if small else var[b % len(var)]
+        ns, nr = n_seg + ds, n_ring + dr
+        ch = (max(1, charts[0] + (b // len(var)) % 3 - 1), max(1, charts[1] + (b // (3 * len(var))) % 3 - 1))
+        B.append((ns, nr, sphere_mesh(ns, nr, frame=b, seed=b, charts=ch)))
+    out = []
+    for k in range(count):
+        ns, nr, m = B[k % bases]
+        out.append(flip_diagonals(m, ns, nr, seed=7919 * k + 13, frac=0.5, jitter=0.0 if k < bases else 0.05))
+    return out
+
+
 def grid_mesh(nx=24, ny=16, seed=1, holes=True):
     """Open height-field patch with a boundary (and optionally a punched hole): exercises L/R/E starts and boundary fans."""
     rng = np.random.default_rng(seed)
