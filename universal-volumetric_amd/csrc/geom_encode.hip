@@ -16,6 +16,7 @@
 #include "geom_device.hpp"
 #include "uvol_ws.hpp"
 #include <algorithm>
+#include <map>
 
 #define JOB_OR_RETURN GeoJob &J = jobs[blockIdx.y]; if (J.status != 0) return
 // For kernels with barriers: the frame's status is read by ONE thread and the whole workgroup takes the same decision.  Another
@@ -2796,13 +2797,16 @@ struct WsItem { size_t slot, bytes; int first, last; size_t off; };
 struct WsPlan {
   std::vector<uint64_t> key; std::vector<size_t> offs; size_t total = 0, zero = 0;
 };
+// placements by (bucketed) frame shape: the frames of a capture all differ a little in their counts (the reference's 250 frames have
+// 26,144 - 27,979 vertices), and a first-fit placement per frame (~100 us, twice) would cost the host more than the GPU needs to encode
+struct WsPlanCache { std::map<std::vector<uint64_t>, WsPlan> plans; };
 struct GeoState {
   uvol_devbuf slab;       // all per-job workspaces
   uvol_devbuf inputs;     // staged inputs when the caller passes host pointers
   uvol_devbuf jobs;       // GeoJob[n]
   uvol_devbuf outs;       // output buffers
   std::vector<GeoJob> hjobs;
-  WsPlan plan; std::vector<WsItem> items;     // workspace placement of the last job dimensions seen
+  WsPlanCache plan; std::vector<WsItem> items;     // workspace placements by frame shape
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
   size_t max_lds = 64 * 1024;
   int num_cu = 256;                    // CUs this context's streams may run on
@@ -2995,14 +2999,35 @@ void ws_place(std::vector<WsItem> &items, WsPlan &P) {
   for (size_t i = 0; i < items.size(); i++) { items[i].off = w[i].off; P.offs[i] = w[i].off; }
 }
 
-// Lays out one job's workspace (sizes + capacities always; pointers when base != nullptr).  The placement is cached for runs
-// of jobs with the same dimensions (a sequence's frames usually are).
-size_t layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlan &P, std::vector<WsItem> &items) {
+// Lays out one job's workspace (sizes + capacities always; pointers when base != nullptr).  The capacities stored in J come from its
+// own counts; the PLACEMENT is the one of the frame's shape bucket - its counts rounded up to multiples of 1024 (2048 faces), at most
+// 1 % more bytes at 100 k vertices - so that the differing frames of a sequence share a handful of cached placements.
+const WsPlan &layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlanCache &C, std::vector<WsItem> &items) {
   ws_collect(J, full, r8, items);
-  std::vector<uint64_t> key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26) | ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28), items.size() };      // everything ws_collect's sizes AND lifetimes depend on
-  if (key != P.key) { ws_place(items, P); P.key = key; }
+  auto up = [](uint32_t v, uint32_t q) { return (uint64_t)((v + (uint64_t)q - 1) / q) * q; };
+  const uint64_t flags = (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26) |
+                         ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28);      // everything ws_collect's sizes AND lifetimes depend on
+  std::vector<uint64_t> key = { up(J.nf_in, 2048), up(J.n_pos, 1024), up(J.n_uv, 1024), up(J.n_nrm, 1024), flags, items.size(), 0 };
+  auto it = C.plans.find(key);
+  if (it == C.plans.end()) {
+    GeoJob R = J; R.nf_in = (uint32_t)std::min<uint64_t>(key[0], 1u << 26); R.n_pos = (uint32_t)key[1]; R.n_uv = (uint32_t)key[2]; R.n_nrm = (uint32_t)key[3];
+    std::vector<WsItem> ri; ws_collect(R, full, r8, ri);
+    bool ok = ri.size() == items.size();
+    for (size_t i = 0; ok && i < ri.size(); i++) ok = ri[i].slot == items[i].slot && ri[i].bytes >= items[i].bytes && ri[i].first == items[i].first && ri[i].last == items[i].last;
+    if (!ok) {                                             // a count on a structural boundary (an array the rounded shape does not have): exact placement for this shape
+      key = { J.nf_in, J.n_pos, J.n_uv, J.n_nrm, flags, items.size(), 1 };
+      it = C.plans.find(key);
+      ri = items;
+    }
+    if (it == C.plans.end()) {
+      if (C.plans.size() >= 512) C.plans.clear();
+      WsPlan P; ws_place(ri, P); P.key = key;
+      it = C.plans.emplace(key, std::move(P)).first;
+    }
+  }
+  const WsPlan &P = it->second;
   if (base) for (size_t i = 0; i < items.size(); i++) *reinterpret_cast<uint8_t **>((char *)&J + items[i].slot) = base + P.offs[i];
-  return P.total;
+  return P;
 }
 }  // namespace
 
@@ -3119,8 +3144,8 @@ extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   if (!ctx || !m || !m->n_faces) return 0;
   GeoJob J{}; J.relabel = geo_relabel_mode(); J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
   J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
-  WsPlan P; std::vector<WsItem> items;
-  return layout_job(J, nullptr, false, geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)), P, items) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
+  WsPlanCache P; std::vector<WsItem> items;
+  return layout_job(J, nullptr, false, geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)), P, items).total + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
 }
 // stages of a batch with sequential connectivity, between k_minmax and the layout (all parallel; see k_sq_*)
 static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, uint32_t max_nfi, uint32_t max_vals, uint32_t max_ecap, uint64_t algo_in) {
@@ -3218,8 +3243,8 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
     { int k = 0; if (J.has_uv) J.att_kind[k++] = 0; if (J.has_nrm) J.att_kind[k++] = 1; for (; k < 2; k++) J.att_kind[k] = -1; }
-    const size_t sz = layout_job(J, nullptr, full, r8 != 0, G->plan, G->items);
-    ws_off[i] = ws_total; ws_total += sz; zero_sz[i] = G->plan.zero;
+    const WsPlan &wp = layout_job(J, nullptr, full, r8 != 0, G->plan, G->items);
+    ws_off[i] = ws_total; ws_total += wp.total; zero_sz[i] = wp.zero;
     const size_t in_sz = ((size_t)m.n_pos * 12 + 255) / 256 * 256 + ((size_t)J.n_uv * 8 + 255) / 256 * 256 + ((size_t)J.n_nrm * 12 + 255) / 256 * 256 +
                          (size_t)(1 + J.has_uv + J.has_nrm) * (((size_t)m.n_faces * 12 + 255) / 256 * 256);
     in_off[i] = in_total; in_total += on_device ? 0 : in_sz;
@@ -3351,7 +3376,11 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_edge_match, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
   }
-  const WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)N);
+  WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)N);
+  // UVOL_SIMT_W_WALK / UVOL_SIMT_W_TRAV (diagnostic): lanes per wave of one of the two lane-per-walker kernels only (UVOL_SIMT_W sets both)
+  static const int w_walk_env = [] { const char *e = getenv("UVOL_SIMT_W_WALK"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+  static const int w_trav_env = [] { const char *e = getenv("UVOL_SIMT_W_TRAV"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+  if (w_walk_env && wp_walk.simt_w) wp_walk.simt_w = w_walk_env;
   {
     LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, r8);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
@@ -3401,6 +3430,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
     WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg);
     if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = 1;      // unrelated meshes: one traverser per wave
+    if (w_trav_env && wp_trav.simt_w) wp_trav.simt_w = w_trav_env;
     launch_traversals(ctx, dj, n, wp_trav, r8);
   }
   { uvol_ctx::Scope sc(ctx, "geo.k5b_v2d", 0); LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, r8); }      // (own scope: geo.k5_traverse is exactly the traversal kernel, as rocprof lists it)
