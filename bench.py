@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--traverse-vbits-l2", type=int, default=0, help="LDS walkers (small batches): 1 = attribute traversers keep their vertex bitmap in L2")
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
     ap.add_argument("--geo-priority", type=int, default=0, help="1: geometry contexts use a high-priority HIP stream (diagnostic)")
+    ap.add_argument("--blocking-calls", action="store_true", help="DIAGNOSTIC: one blocking geometry call per pass instead of enqueued passes completed by one uvol_sync")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
@@ -159,8 +160,24 @@ def main():
             self.n, self.nseg, self.host, self.only = n, n // B, host, only
             self.gsl = [(gi * n // GS, (gi + 1) * n // GS) for gi in range(GS)]
             nd = len(dev_meshes)
-            self.gb = [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
+            self.gb = None if host else [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
             self.hf = [meshes_h[i % ND] for i in range(n)] if host else None
+
+        def run_geo_passes(self, gi, kk):
+            """kk passes of this geometry stream.  Device inputs: the passes are ENQUEUED (uvol_encode_mesh_batch_dev_async) and completed
+            by one uvol_sync - the context then runs the front end of pass k + 1 beside the walkers of pass k (two output buffer sets in
+            turn: a pass's bytes are in host memory when the pass after the next one starts).  --blocking-calls: one blocking call per pass."""
+            a, b = self.gsl[gi]
+            if self.host or args.blocking_calls or b <= a:
+                for _ in range(kk):
+                    self.run_geo(gi)
+                return
+            for k in range(kk):
+                geos[gi].start_mesh_batch_dev(self.gb[gi], slot=k & 1)
+            res = geos[gi].finish()
+            if any(r is None for r in res[-1]):
+                raise RuntimeError("bench: a geometry frame failed")
+            out["drc_%d" % gi] = res[-1]
 
         def run_geo(self, gi):
             a, b = self.gsl[gi]
@@ -195,7 +212,7 @@ def main():
             rounds = [(1, k)] if not args.lockstep else [(k, 1)]
             for reps, kk in rounds:
                 for _ in range(reps):
-                    th = [threading.Thread(target=guarded, args=(loop, self.run_geo, gi, kk)) for gi in range(GS) if self.only != "tex"] + \
+                    th = [threading.Thread(target=guarded, args=(self.run_geo_passes, gi, kk)) for gi in range(GS) if self.only != "tex"] + \
                          [threading.Thread(target=guarded, args=(loop, self.run_tex, ti, kk)) for ti in range(len(texs)) if self.only != "geo"]
                     for t in th:
                         t.start()
@@ -266,7 +283,9 @@ def main():
         # the texture stream runs beside it and is idle a third of the time).  With --only tex the longest texture group stands in.
         cand = [g for g in groups if g["name"].startswith("geo.")] or [g for g in groups if g["name"] != "tex.k10_sel_assign"]
         dom = cand[0]
-        units = max(F // GS, 1) if dom["name"].startswith("geo.") else max(F // len(texs), 1)          # frames one launch of that group processes
+        # frames one launch of that group processes: a geometry call is cut into groups on the context's lanes (each its own launch), a
+        # texture call is one launch per stage
+        units = max(1.0, F * args.steps / max(1, dom["launches"]))
         avg_ms = dom["total_ms"] / max(1, dom["launches"])
         achieved = algo_per_frame * units / (avg_ms * 1e-3) / 1e9
         workload = ("BASELINE configs[3] shape: ONE job of %d frames split over %d rank(s) by whole texture segments (rank 0: %d frames)" % (args.total_frames, world, F)) if strong else \

@@ -55,7 +55,9 @@ struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcess
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+// HIPEMU_DEVICES=N: the emulation reports N devices (all the same heap), so that the multi-device HOST paths - `uvolenc --gpus N`, one
+// thread and one context pair per device - run without a GPU
+inline hipError_t hipGetDeviceCount(int *n) { static const int nd = [] { const char *e = getenv("HIPEMU_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }(); *n = nd; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "gfx950-hipemu"); p->multiProcessorCount = 256; p->totalGlobalMem = (size_t)8 << 30; return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : 2; }

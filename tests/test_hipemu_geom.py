@@ -60,11 +60,11 @@ def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
         c2.close()
 
 
-@pytest.mark.parametrize("force", ["vglobal", "global", "rec16", "simt5", "simt64", "relabel", "relabel_simt", "earlyjoin"])
+@pytest.mark.parametrize("force", ["vglobal", "global", "rec16", "simt5", "simt64", "simtcorner", "relabel", "relabel_simt", "earlyjoin"])
 def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
     """Visited bitmaps in LDS (default, covered above), vertex bitmap in global memory (a table with more vertices than
     the LDS slot), nothing in LDS (mesh too large for LDS: the lane-per-walker kernels, one lane per wave), "simtN": the
-    lane-per-walker kernels with N lanes per wave and the lane-per-stream entropy coder (what large batches use; small ones get the
+    lane-per-walker kernels with N lanes per wave on one 16-byte record per face ("simtcorner": on the 8-byte corner records, UVOL_REC_FACE=0) and the lane-per-stream entropy coder (what large batches use; small ones get the
     cooperative LDS walkers and the wave-per-stream coder, covered above): same bytes.  "rec16": the 16-byte corner records
     that batches with >= 2^18 faces per mesh use instead of the packed 8-byte ones (UVOL_REC16=1).  The switches are read
     "relabel": the locality relabelling forced on (these small lattice-built meshes are stored coherently, so the per-frame
@@ -83,7 +83,7 @@ def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib, force.startswith("relabel"))
-    env = dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="7") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="8") if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
+    env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="7") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="8") if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
@@ -129,6 +129,40 @@ def test_hipemu_enqueue_form_of_the_abi(oracle, hipemu_lib):
         c2.finish()
     assert c2.finish() == []                                   # the error was reported once
     c2.close()
+
+
+def test_hipemu_call_spread_over_lanes(oracle, hipemu_lib):
+    """Round 4: a call is cut into groups that run on different lanes (own streams, workspaces, output areas), consecutive enqueued
+    calls overlap (a lane's group completes when a later call needs the lane, or at uvol_sync).  With UVOL_GEO_MIN_GROUP=2 a 9-frame
+    call becomes four groups; results, per-frame failures and the worst-case retry of one frame must be exactly those of one group."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, synth, uvol, oracle as O\n"
+        "O.lib()\n"
+        "enc = lambda f: O.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
+        "cd = uvol.Codec(lib_path=%r)\n"
+        "t, g, s = synth.torus_mesh(16, 8), synth.grid_mesh(), synth.sphere_mesh(24, 13, charts=(3, 2))\n"
+        "rng = np.random.default_rng(1)\n"
+        "fat = dict(pos=rng.random((12, 3)).astype(np.float32), idx_pos=rng.integers(0, 12, size=(6000, 3)).astype(np.uint32).reshape(-1))\n"
+        "bad = dict(t, idx_pos=t['idx_pos'].copy()); bad['idx_pos'][5] = 10 ** 6\n"
+        "frames = [t, g, s, fat, t, bad, s, g, t]\n"
+        "want = [enc(f) if f is not bad else None for f in frames]\n"
+        "assert cd.encode_mesh_batch(frames, raise_on_error=False) == want\n"
+        "ds = synth.distinct_meshes(7, 24, 13, bases=3, charts=(3, 2))\n"
+        "assert cd.encode_mesh_batch(ds) == [enc(f) for f in ds]\n"
+        "cd.start_mesh_batch(frames[:3]); cd.start_mesh_batch(frames); cd.start_mesh_batch(ds); cd.start_mesh_batch([g])\n"
+        "r = cd.finish()\n"
+        "assert r[0] == want[:3] and r[1] == want and r[2] == [enc(f) for f in ds] and r[3] == [enc(g)]\n"
+        "cd.start_mesh_batch(ds)\n"
+        "assert cd.encode_mesh_batch(frames[:4]) == want[:4]\n"
+        "assert cd.finish() == [[enc(f) for f in ds]]\n"
+        "cd.close(); print('lanes ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
+    for lanes in ("4", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_GEO_MIN_GROUP="2", UVOL_GEO_LANES=lanes), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "lanes ok" in r.stdout, (lanes, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_hipemu_sequential_connectivity_at_compression_level_0(oracle, hipemu_lib):

@@ -138,7 +138,7 @@ def test_uvolenc_hipemu_targets_etc2_and_multi_gpu_plan(oracle, tmp_path):
             raw = np.frombuffer(open(os.path.join(out, "texture_etc2_baseColor_default", "%05d.etc2" % (3 * s + l)), "rb").read(), np.uint8)
             assert raw.size == 8 * 8 * 8
             assert np.array_equal(helpers.etc1_decode_blocks(raw.reshape(8, 8, 8), 32, 32), ref.images[l])
-    # two "GPUs" (the shim has one device: --gpus is clamped, so call the plan itself) and the same output with 2 ranks of frames
+    # the plan itself (uvolenc --gpus N > 1 runs end to end in test_uvolenc_hipemu_gpus_2_and_8_write_what_one_gpu_writes)
     import ctypes as C
     L = C.CDLL(os.path.join(pkg, "libuvolhost.so"))
     L.uvolh_shard_plan.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
@@ -147,6 +147,40 @@ def test_uvolenc_hipemu_targets_etc2_and_multi_gpu_plan(oracle, tmp_path):
         for rk in range(w):
             o4 = (C.c_long * 4)(); L.uvolh_shard_plan(n, b, w, rk, o4)
             assert tuple(o4) == tuple(shard.plan(n, b, w, rk))
+
+
+def test_uvolenc_hipemu_gpus_2_and_8_write_what_one_gpu_writes(oracle, tmp_path):
+    """the multi-device host path of uvolenc (one thread and one context pair per device, segment-aligned blocks of
+    frames per device, scripts/Encoder.py:103-154 accounting) executed with N > 1 - on the emulation's HIPEMU_DEVICES - must write
+    exactly the files and the manifest that --gpus 1 writes: 11 frames, KTX2_BATCH_SIZE 3 (a short last segment, fewer segments than
+    devices for N = 8 so some devices get nothing)."""
+    import filecmp, cli_helpers
+    pkg = os.path.join(ROOT, "universal-volumetric_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "hipemu-bins"])
+    exe = os.path.join(ROOT, "tests", "hipemu", "bin", "uvolenc")
+    outs = {}
+    for gpus in (1, 2, 8):
+        root = str(tmp_path / ("g%d" % gpus)); os.makedirs(root)
+        cfgp, cfg, meshes, texs = cli_helpers.make_sequence(root, n_frames=11, tex=32, batch=3)
+        r = subprocess.run([exe, cfgp, "--batch-frames", "4", "--gpus", str(gpus)], cwd=root, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, HIPEMU_DEVICES="8"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[gpus] = cfg["OutputDirectory"]
+    ref = outs[1]
+    names = sorted(os.path.relpath(os.path.join(d, f), ref) for d, _, fs in os.walk(ref) for f in fs)
+    assert len([n for n in names if n.endswith(".drc")]) == 11 and len([n for n in names if n.endswith(".ktx2")]) == 4
+    for gpus in (2, 8):
+        got = sorted(os.path.relpath(os.path.join(d, f), outs[gpus]) for d, _, fs in os.walk(outs[gpus]) for f in fs)
+        assert got == names, (gpus, set(got) ^ set(names))
+        for n in names:
+            if n.endswith("uvol.json"):
+                a, b = json.load(open(os.path.join(ref, n))), json.load(open(os.path.join(outs[gpus], n)))
+                assert a == b, (gpus, n)
+            else:
+                assert filecmp.cmp(os.path.join(ref, n), os.path.join(outs[gpus], n), shallow=False), (gpus, n)
+    # and what one device wrote is what the oracle writes
+    m0 = cli_helpers.make_sequence(str(tmp_path / "chk"), n_frames=1, tex=32, batch=3)[2][0]
+    assert open(os.path.join(ref, "geometry_draco", "00000.drc"), "rb").read() == oracle.drc_encode(m0["pos"], m0["idx_pos"], m0["uv"], m0["idx_uv"], m0["nrm"], m0["idx_nrm"])
 
 
 def test_audio_duration_probe(tmp_path):

@@ -754,8 +754,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vert0(GeoJob *jobs) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool dense_table_live(const GeoJob &J, int which) { const int ai = which >= 2 ? which - 2 : 0; return !(which >= 2 && (ai >= J.nad || !J.interior_seams[ai])); }
 // the three records of face f (r[k] = opposite corner of corner k, vc[k] = vertex << 1 | open) in either format
+// r8: 0 = 16 bytes per corner, 1 = 8 bytes per corner, 2 = ONE 16-byte record per FACE (f16_*, the lane-per-walker kernels)
 __device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, const int vc[3], const int r[3], int r8) {
-  if (r8) {
+  if (r8 == 2) {
+    // {vertex << 1 | open} x 3 in the low 64 bits (bit 63: the walker's face-visited flag), the opposite corner codes x 3 in the high
+    // 64 bits, 21-bit fields: what the three 8-byte corner records hold (each opposite twice) in half the bytes, and the flag in it
+    uint64_t lo = 0, hi = 0;
+    for (int k = 0; k < 3; k++) { lo |= (uint64_t)((uint32_t)vc[k] & 0x1fffffu) << (21 * k); hi |= (uint64_t)((uint32_t)code_of_corner(r[k]) & 0x1fffffu) << (21 * k); }
+    reinterpret_cast<uint4 *>(rec)[f] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+  } else if (r8) {
     uint4 *dst = reinterpret_cast<uint4 *>(rec) + 2 * (size_t)f;      // the face's 32-byte block as two 16-byte stores
     uint2 q[3];
     for (int k = 0; k < 3; k++) {
@@ -1211,7 +1218,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs, int r8) {
   if (t > 0 && (t - 1 >= J.nad || !J.interior_seams[t - 1])) return;
   const int c = J.order[t][i];
   const size_t code = (size_t)code_of_corner(c);
-  const int vi = r8 ? (int)((uint32_t)J.rec[1 + t][2 * code] & 0x1fffffu) : J.rec[1 + t][4 * code];
+  int vi;
+  if (r8 == 2) { const uint32_t *q = reinterpret_cast<const uint32_t *>(J.rec[1 + t]) + 4 * (size_t)(c / 3); vi = (int)((uint32_t)((((uint64_t)q[1] << 32) | q[0]) >> (21 * (c % 3))) & 0x1fffffu); }
+  else vi = r8 ? (int)((uint32_t)J.rec[1 + t][2 * code] & 0x1fffffu) : J.rec[1 + t][4 * code];
   J.v2d[t][vi >> 1] = (int32_t)i;
 }
 
@@ -1875,6 +1884,190 @@ __global__ void __launch_bounds__(64) k_traverse_simt(GeoJob *jobs, int n, int W
 #undef S_FLAG
 #undef S_PRE
 #undef S_TAKE
+
+// ------------------------------------------------------------------------------------------------
+// The same two lane-per-walker kernels on ONE 16-byte record per FACE (format 2, pack_face_records): the three vertex fields, the
+// three opposite-corner codes and the face-visited flag.  A step still moves by corner codes (4 * face + k): the vertex of corner k
+// is vertex field k, its right / left neighbours are opposite fields (k + 1) % 3 / (k + 2) % 3 of the same record.  Against the
+// 8-byte corner records this halves the bytes the walkers fetch and write back (the flag dirties the line it is in), puts eight faces
+// instead of four on a 128-byte line (more of a walker's dependent loads hit a line a neighbouring face already brought in), brings a
+// candidate's record AND its visited flag in one load instead of two, and halves the record tables (4 x 3.2 MB less per frame in flight).
+// Batches whose face count or id space does not fit the 21-bit fields keep the 16-byte corner records (geo_rec8).
+// ------------------------------------------------------------------------------------------------
+#ifdef HIPEMU
+struct uvol_u4 { uint32_t x, y, z, w; };
+#else
+typedef uint32_t uvol_u4 __attribute__((ext_vector_type(4)));
+#endif
+__device__ __forceinline__ uvol_u4 f16_load(UVOL_G(uint32_t) rec, int face) { return *(UVOL_G(const uvol_u4))(rec + 4 * (size_t)face); }
+__device__ __forceinline__ void f16_dec(const uvol_u4 &q, int k, int &vi, int &rc, int &lc) {
+  const uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+  const int s = 21 * k, sr = k == 2 ? 0 : s + 21, sl = k == 0 ? 42 : s - 21;
+  vi = (int)((uint32_t)(lo >> s) & 0x1fffffu);
+  rc = (int)((uint32_t)(hi >> sr) << 11) >> 11;            // 21-bit field, all ones = none
+  lc = (int)((uint32_t)(hi >> sl) << 11) >> 11;
+}
+#define F16_SEEN(q) ((q).y >> 31)
+#define F16_MARK(face, q) (rec[4 * (size_t)(face) + 1] = (q).y | 0x80000000u)
+__device__ inline void eb_walk_simt_f16(GeoJob &J) {
+  const int nf = (int)J.nf;
+  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[0]));
+  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis));
+  UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
+  UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
+  const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
+  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
+  int fo = 0, sp = 0, x = -1, vi = 0, rcn = -1, lcn = -1;
+  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
+  for (;;) {
+    if (x < 0) {                                          // rare: a corner to go on from - the stack, else the next component
+      bool finished = false;
+      for (;;) {
+        if (sp > 0) {
+          const int c = stack[sp - 1];
+          if (c < 0) { sp--; continue; }
+          const uvol_u4 qq = f16_load(rec, c >> 2);
+          if (F16_SEEN(qq)) { sp--; continue; }
+          x = c; q = qq; f16_dec(q, x & 3, vi, rcn, lcn);
+          break;
+        }
+        if (fo >= nf || nproc + ninit >= nf) { finished = true; break; }
+        const int f0 = rl ? s_of_o[fo] : fo;             // component starts follow the ORIGINAL face order
+        fo++;
+        const uvol_u4 q0 = f16_load(rec, f0);
+        if (F16_SEEN(q0)) continue;
+        int v0[3], r0_[3], l0_[3];
+        for (int k = 0; k < 3; k++) f16_dec(q0, k, v0[k], r0_[k], l0_[k]);
+        const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
+        int interior = 1, start = 4 * f0;
+        for (int k = 0; k < 3; k++) {
+          if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
+          if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
+            int ci = 4 * f0 + k, rc = ci;
+            while (rc >= 0) { ci = rc; int v_, r_, l_; f16_dec(f16_load(rec, rc >> 2), rc & 3, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
+            interior = 0; start = code_prv(ci); break;
+          }
+        }
+        start_bits[nstart] = (uint8_t)interior;
+        nstart++;
+        int from;
+        if (interior) {
+          for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = vbits[v >> 5]; vbits[v >> 5] = w | (1u << (v & 31)); }
+          F16_MARK(f0, q0);
+          initc[ninit] = 3 * f0 + 1;
+          ninit++;
+          from = o0[1];
+          if (from < 0 || (rec[4 * (size_t)(from >> 2) + 1] >> 31)) continue;
+        } else from = start;
+        stack[0] = from; sp = 1;
+      }
+      if (finished) break;
+    }
+    // ---- the common step (straight-line, see eb_walk_simt) ----
+    F16_MARK(x >> 2, q);
+    const uvol_u4 qr = f16_load(rec, (rcn < 0 ? x : rcn) >> 2), ql = f16_load(rec, (lcn < 0 ? x : lcn) >> 2);
+    proc[nproc] = 3 * (x >> 2) + (x & 3);
+    const int v = vi >> 1;
+    const uint32_t vw = vbits[v >> 5];
+    vbits[v >> 5] = vw | (1u << (v & 31));                                  // (already set when the tip was visited)
+    const uint32_t vvis = (vw >> (v & 31)) & 1u;
+    const uint32_t rvis = (rcn < 0 || F16_SEEN(qr)) ? 1u : 0u, lvis = (lcn < 0 || F16_SEEN(ql)) ? 1u : 0u;
+    const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;                    // tip unvisited and not on a boundary
+    const uint32_t sym = ccase ? 0u : 1u + 2u * lvis + 4u * rvis;           // C 0, S 1, L 3, R 5, E 7
+    symb[nproc] = (uint8_t)sym;
+    nproc++;
+    if (sym == 1u) { stack[sp - 1] = lcn; stack[sp] = rcn; sp++; nsplit++; }   // S: the left neighbour waits on the stack, the walk goes right
+    if (sym == 7u) { sp--; x = -1; }
+    else {
+      const bool go_l = sym == 5u;
+      x = go_l ? lcn : rcn;
+      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
+      f16_dec(q, x & 3, vi, rcn, lcn);
+    }
+  }
+  J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
+  if (nproc + ninit != nf) J.status = -10;
+  J.rb[0].n = (uint32_t)nstart;
+  uint32_t z = 0; for (int i = 0; i < nstart; i++) z += start_bits[i] == 0;
+  J.rb[0].zeros = z;
+}
+__global__ void __launch_bounds__(64) k_eb_walk_simt_f16(GeoJob *jobs, int n, int W) {
+  const int lane = (int)threadIdx.x;
+  if (lane >= W) return;
+  const int j = (int)blockIdx.x * W + lane;
+  if (j >= n) return;
+  GeoJob &J = jobs[j];
+  if (J.status != 0) return;
+  eb_walk_simt_f16(J);
+}
+__device__ inline void traverse_simt_f16(GeoJob &J, int t) {
+  const int nf = (int)J.nf;
+  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
+  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
+  UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
+  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
+  for (;;) {
+    if (x < 0) {                                          // rare: the stack, else the next unvisited face starts a component
+      bool finished = false;
+      for (;;) {
+        if (sp > 0) {
+          const int c = stack[sp - 1];
+          if (c < 0) { sp--; continue; }
+          const uvol_u4 qq = f16_load(rec, c >> 2);
+          if (F16_SEEN(qq)) { sp--; continue; }
+          x = c; q = qq; f16_dec(q, x & 3, vi, rc, lc);
+          break;
+        }
+        if (f >= nf || nvis >= nf) { finished = true; break; }
+        const int f0 = f; f++;
+        const uvol_u4 q0 = f16_load(rec, f0);
+        if (F16_SEEN(q0)) continue;
+        stack[0] = 4 * f0; sp = 1;
+        int vn, vp, r_, l_; f16_dec(q0, 1, vn, r_, l_); f16_dec(q0, 2, vp, r_, l_); vn >>= 1; vp >>= 1;
+        uint32_t w = vbits[vn >> 5];
+        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f0 + 1; n++; }
+        w = vbits[vp >> 5];
+        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f0 + 2; n++; }
+      }
+      if (finished) break;
+    }
+    F16_MARK(x >> 2, q);
+    nvis++;
+    const uvol_u4 qr = f16_load(rec, (rc < 0 ? x : rc) >> 2), ql = f16_load(rec, (lc < 0 ? x : lc) >> 2);
+    const int v = vi >> 1;
+    const uint32_t vw = vbits[v >> 5];
+    vbits[v >> 5] = vw | (1u << (v & 31));
+    const uint32_t vvis = (vw >> (v & 31)) & 1u;
+    if (!vvis) { order[n] = 3 * (x >> 2) + (x & 3); n++; }                  // a vertex seen for the first time takes the next place
+    const uint32_t rvis = (rc < 0 || F16_SEEN(qr)) ? 1u : 0u, lvis = (lc < 0 || F16_SEEN(ql)) ? 1u : 0u;
+    const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;
+    const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
+    if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; }
+    if (k == 4u) { sp--; x = -1; }
+    else {
+      const bool go_l = k == 2u;
+      x = go_l ? lc : rc;
+      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
+      f16_dec(q, x & 3, vi, rc, lc);
+    }
+  }
+  J.ne[t] = (uint32_t)n;
+  if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
+}
+__global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, int W) {
+  const int lane = (int)threadIdx.x;
+  if (lane >= W) return;
+  const int id = (int)blockIdx.x * W + lane;
+  if (id >= 3 * n) return;
+  const int t = id / n, j = id - t * n;
+  GeoJob &J = jobs[j];
+  const int ai = t > 0 ? t - 1 : 0;
+  if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
+  traverse_simt_f16(J, t);
+}
+#undef F16_SEEN
+#undef F16_MARK
 
 // ------------------------------------------------------------------------------------------------
 // K1: attribute min/max (orderable-float atomics) and quantisation of the entries in coding order
@@ -2800,24 +2993,59 @@ struct WsPlan {
 // placements by (bucketed) frame shape: the frames of a capture all differ a little in their counts (the reference's 250 frames have
 // 26,144 - 27,979 vertices), and a first-fit placement per frame (~100 us, twice) would cost the host more than the GPU needs to encode
 struct WsPlanCache { std::map<std::vector<uint64_t>, WsPlan> plans; };
-struct GeoState {
+// A lane = everything ONE group of frames needs while it is in flight: two streams (main + auxiliary), its events, its device
+// buffers and the host-side record of the call it belongs to.  A call is cut into groups that run on different lanes, so that the
+// bandwidth-bound front end of one group runs beside the latency-bound walkers of another (geo_encode_batch); lane 0 runs on the
+// context's own stream.
+struct GeoLane {
+  hipStream_t stream = nullptr, aux = nullptr; bool own_stream = false;     // aux: valence replay runs beside renumber / seams / traversals
+  hipEvent_t ev_walk = nullptr, ev_val = nullptr, ev_fe = nullptr;          // ev_fe: this group's front end (dedup + corner table) is done
   uvol_devbuf slab;       // all per-job workspaces
   uvol_devbuf inputs;     // staged inputs when the caller passes host pointers
   uvol_devbuf jobs;       // GeoJob[n]
   uvol_devbuf outs;       // output buffers
   std::vector<GeoJob> hjobs;
-  WsPlanCache plan; std::vector<WsItem> items;     // workspace placements by frame shape
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
+  uint32_t *counts = nullptr;          // device: {frames relabelled, frames with their predecessor's connectivity} of the group (k_relabel_decide)
+  // the group in flight (submitted, not completed): its slice of the caller's arrays (the pointer arrays are copied: an enqueued call's arrays are gone by then)
+  bool busy = false, on_device = false, full = false;
+  std::vector<uvol_mesh> meshes; std::vector<uint8_t *> outp; std::vector<size_t> caps;
+  size_t *out_lens = nullptr; int *status = nullptr; int n = 0, n_conc = 0;
+  std::chrono::steady_clock::time_point t_enter; double t_prep = 0, t_enq = 0;
+};
+struct GeoState {
+  std::vector<GeoLane *> lanes; int next_lane = 0;
+  hipEvent_t fe_last = nullptr;        // front-end event of the group submitted last (the front ends of consecutive groups run one after the other)
+  int deferred_rc = UVOL_OK;           // first error among groups completed on behalf of a later call (geo_flush returns it)
+  WsPlanCache plan; std::vector<WsItem> items;     // workspace placements by frame shape
   size_t max_lds = 64 * 1024;
   int num_cu = 256;                    // CUs this context's streams may run on
-  hipStream_t aux = nullptr;           // second stream: valence replay runs beside renumber/seams/DFS
-  hipEvent_t ev_walk = nullptr, ev_val = nullptr;
-  uint32_t *counts = nullptr;          // device: {frames relabelled, frames with their predecessor's connectivity} of the batch (k_relabel_decide)
 };
+static void geo_lane_free(GeoLane *L) {
+  if (L->aux) { (void)hipStreamSynchronize(L->aux); (void)hipStreamDestroy(L->aux); }
+  if (L->own_stream && L->stream) { (void)hipStreamSynchronize(L->stream); (void)hipStreamDestroy(L->stream); }
+  for (uvol_devbuf *b : { &L->slab, &L->inputs, &L->jobs, &L->outs }) if (b->p) (void)hipFree(b->p);
+  if (L->pinned) (void)hipHostFree(L->pinned);
+  for (hipEvent_t e : { L->ev_walk, L->ev_val, L->ev_fe }) if (e) (void)hipEventDestroy(e);
+  if (L->counts) (void)hipFree(L->counts);
+  delete L;
+}
+// lane k of the context (created on first use; lane 0 = the context's stream)
+static GeoLane *geo_lane(uvol_ctx *ctx, int k) {
+  GeoState *G = ctx->geo;
+  while ((int)G->lanes.size() <= k) {
+    GeoLane *L = new GeoLane();
+    if (G->lanes.empty()) L->stream = ctx->stream; else { if (uvol_make_stream(ctx, &L->stream) != hipSuccess) { delete L; return nullptr; } L->own_stream = true; }
+    if (uvol_make_stream(ctx, &L->aux) != hipSuccess || hipEventCreate(&L->ev_walk) != hipSuccess || hipEventCreate(&L->ev_val) != hipSuccess ||
+        hipEventCreateWithFlags(&L->ev_fe, hipEventDisableTiming) != hipSuccess) { geo_lane_free(L); return nullptr; }
+    G->lanes.push_back(L);
+  }
+  return G->lanes[k];
+}
 
 int geo_create(uvol_ctx *ctx) {
   ctx->geo = new GeoState();
-  if (uvol_make_stream(ctx, &ctx->geo->aux) != hipSuccess || hipEventCreate(&ctx->geo->ev_walk) != hipSuccess || hipEventCreate(&ctx->geo->ev_val) != hipSuccess) return UVOL_E_HIP;
+  if (!geo_lane(ctx, 0)) return UVOL_E_HIP;
 #ifndef HIPEMU
   // the serial walkers keep their visited bitmaps in LDS: allow the full 160 KiB of a gfx950 CU
   int v = 0;
@@ -2837,15 +3065,7 @@ int geo_create(uvol_ctx *ctx) {
 void geo_destroy(uvol_ctx *ctx) {
   if (!ctx->geo) return;
   GeoState *g = ctx->geo;
-  if (g->slab.p) (void)hipFree(g->slab.p);
-  if (g->inputs.p) (void)hipFree(g->inputs.p);
-  if (g->jobs.p) (void)hipFree(g->jobs.p);
-  if (g->outs.p) (void)hipFree(g->outs.p);
-  if (g->pinned) (void)hipHostFree(g->pinned);
-  if (g->aux) { (void)hipStreamSynchronize(g->aux); (void)hipStreamDestroy(g->aux); }
-  if (g->ev_walk) (void)hipEventDestroy(g->ev_walk);
-  if (g->ev_val) (void)hipEventDestroy(g->ev_val);
-  if (g->counts) (void)hipFree(g->counts);
+  for (GeoLane *L : g->lanes) geo_lane_free(L);
   delete g; ctx->geo = nullptr;
 }
 
@@ -2870,7 +3090,8 @@ enum { PH_DEDUP = 0, PH_FACES, PH_CT, PH_FANS0, PH_DENSE0, PH_WALK, PH_FTIME, PH
        PH_PRED, PH_HIST, PH_ENT, PH_LAYOUT, PH_PINNED = -1 };
 
 // Collects the arrays of job J (sizes from its input counts) and sets the capacities stored in J.  full = worst-case sizes.
-void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
+// fmt0 / fmtT: record format of the walk table / of the three traversal tables (pack_face_records: 0, 1, 2)
+void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &items) {
   items.clear();
   const size_t nfi = J.nf_in, nc = 3 * nfi;
   const size_t vmax = std::max<size_t>(J.n_pos, std::max<size_t>(J.n_uv, J.n_nrm));
@@ -2940,8 +3161,9 @@ void ws_collect(GeoJob &J, bool full, bool r8, std::vector<WsItem> &items) {
   CARVE(J.opp, int32_t, nc + 3, PH_CT, aux_last);
   CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_SEAMS);
   // ---- K4 ----
-  const size_t rec_bytes = (r8 ? 32 : 64) * (nfi + 1);
-  CARVE(J.rec[0], uint8_t, rec_bytes, PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
+  auto rec_size = [&](int fmt) { return (size_t)(fmt == 2 ? 16 : (fmt == 1 ? 32 : 64)) * (nfi + 1); };
+  const size_t rec_bytes = rec_size(fmtT);
+  CARVE(J.rec[0], uint8_t, rec_size(fmt0), PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
   for (int w = 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
   CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_SEAMS);
   CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, aux_last);
@@ -3002,16 +3224,16 @@ void ws_place(std::vector<WsItem> &items, WsPlan &P) {
 // Lays out one job's workspace (sizes + capacities always; pointers when base != nullptr).  The capacities stored in J come from its
 // own counts; the PLACEMENT is the one of the frame's shape bucket - its counts rounded up to multiples of 1024 (2048 faces), at most
 // 1 % more bytes at 100 k vertices - so that the differing frames of a sequence share a handful of cached placements.
-const WsPlan &layout_job(GeoJob &J, uint8_t *base, bool full, bool r8, WsPlanCache &C, std::vector<WsItem> &items) {
-  ws_collect(J, full, r8, items);
+const WsPlan &layout_job(GeoJob &J, uint8_t *base, bool full, int fmt0, int fmtT, WsPlanCache &C, std::vector<WsItem> &items) {
+  ws_collect(J, full, fmt0, fmtT, items);
   auto up = [](uint32_t v, uint32_t q) { return (uint64_t)((v + (uint64_t)q - 1) / q) * q; };
-  const uint64_t flags = (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)r8 << 25) | ((uint64_t)(J.relabel != 0) << 26) |
-                         ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28);      // everything ws_collect's sizes AND lifetimes depend on
+  const uint64_t flags = (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)(J.relabel != 0) << 26) |
+                         ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28) | ((uint64_t)fmt0 << 29) | ((uint64_t)fmtT << 31);      // everything ws_collect's sizes AND lifetimes depend on
   std::vector<uint64_t> key = { up(J.nf_in, 2048), up(J.n_pos, 1024), up(J.n_uv, 1024), up(J.n_nrm, 1024), flags, items.size(), 0 };
   auto it = C.plans.find(key);
   if (it == C.plans.end()) {
     GeoJob R = J; R.nf_in = (uint32_t)std::min<uint64_t>(key[0], 1u << 26); R.n_pos = (uint32_t)key[1]; R.n_uv = (uint32_t)key[2]; R.n_nrm = (uint32_t)key[3];
-    std::vector<WsItem> ri; ws_collect(R, full, r8, ri);
+    std::vector<WsItem> ri; ws_collect(R, full, fmt0, fmtT, ri);
     bool ok = ri.size() == items.size();
     for (size_t i = 0; ok && i < ri.size(); i++) ok = ri[i].slot == items[i].slot && ri[i].bytes >= items[i].bytes && ri[i].first == items[i].first && ri[i].last == items[i].last;
     if (!ok) {                                             // a count on a structural boundary (an array the rounded shape does not have): exact placement for this shape
@@ -3122,7 +3344,11 @@ static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
 bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
-  if (P.simt_w) { const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W; if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
+  if (P.simt_w) {
+    const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W;
+    if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
+    else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
+  }
   else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
   else LAUNCH_SM((k_traverse<false>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
 }
@@ -3145,7 +3371,8 @@ extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   GeoJob J{}; J.relabel = geo_relabel_mode(); J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
   J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
   WsPlanCache P; std::vector<WsItem> items;
-  return layout_job(J, nullptr, false, geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)), P, items).total + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
+  const int fmt = geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)) ? 2 : 0;       // what a frame of a large batch holds (lane-per-walker kernels, one record per face)
+  return layout_job(J, nullptr, false, fmt, fmt, P, items).total + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
 }
 // stages of a batch with sequential connectivity, between k_minmax and the layout (all parallel; see k_sq_*)
 static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, uint32_t max_nfi, uint32_t max_vals, uint32_t max_ecap, uint64_t algo_in) {
@@ -3195,19 +3422,16 @@ static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, ui
   }
   return UVOL_OK;
 }
-static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
-                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full);
-int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
-                     uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
-  return geo_encode_batch_impl(ctx, meshes, n, on_device, outs, caps, out_lens, status, false);
-}
+static int geo_submit(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, int n, int n_conc, bool on_device,
+                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full);
+static int geo_complete(uvol_ctx *ctx, GeoLane &L);
 
-// full = worst-case workspace and output sizes (the retry of a frame the compact layout could not hold)
-static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
-                                 uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full) {
+// First half of a group of frames on lane L: lays out the workspaces, uploads host inputs, enqueues every kernel of the group and the
+// read-back of its job records.  Returns without waiting for the GPU (but for the one look at the batch's storage order, below).
+// full = worst-case workspace and output sizes (the retry of a frame the compact layout could not hold); n_conc = frames of the whole
+// call (what is on the chip together decides the kernel forms, not this group's share).
+static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, int n, int n_conc, bool on_device, const size_t *caps, bool full) {
   GeoState *G = ctx->geo;
-  if (n <= 0) return UVOL_OK;
-  static const bool timing = [] { const char *e = getenv("UVOL_TIMING"); return e && *e == '1'; }();       // diagnostic: host-side phases of a batch on stderr
   const auto t_enter = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   const uvol_params &prm = ctx->prm;
@@ -3224,8 +3448,8 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   // with the batch.  Below ~1200 frames the replay is the longer of the two, so it is joined late (before the entropy stage) and
   // overlaps the traversals too; its inputs then cannot share bytes with the record tables (+7.7 MB per frame, irrelevant at that size).
   static const int late_env = [] { const char *e = getenv("UVOL_LATE_JOIN"); return e ? atoi(e) : -1; }();      // tests: 0 / 1 force the early / late join
-  const bool late_join = late_env >= 0 ? late_env != 0 : n <= 1200;
-  G->hjobs.assign((size_t)n, GeoJob{});
+  const bool late_join = late_env >= 0 ? late_env != 0 : std::max(n, n_conc) <= 1200;      // (n_conc: the frames of the whole call are on the chip together, whatever this group's share)
+  L.hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
   uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0, he_nb_max = 0, ms_nb_max = 1; bool he_part_all = true; uint64_t algo_in = 0;
@@ -3233,17 +3457,27 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; max_nfi = std::max(max_nfi, m.n_faces);
     max_ids = std::max(max_ids, geo_ecap(m.n_pos, (m.uv && m.idx_uv) ? m.n_uv : 0, (m.nrm && m.idx_nrm) ? m.n_nrm : 0, m.n_faces, full));
+    max_vals = std::max(max_vals, std::max(m.n_pos, std::max((m.uv && m.idx_uv) ? m.n_uv : 0u, (m.nrm && m.idx_nrm) ? m.n_nrm : 0u)));
   }
   const int r8 = geo_rec8(max_nfi, max_ids) ? 1 : 0;
+  // How the serial walkers of this group run is decided here, before the workspaces are laid out: the lane-per-walker kernels read ONE
+  // 16-byte record per face (format 2) where the 21-bit fields allow it, and the record tables are sized for the format
+  const unsigned NC0 = (unsigned)std::max(n, n_conc);
+  WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)NC0);
+  static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
+  const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
+  WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, tvg);
+  static const bool f16_off = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }();      // UVOL_REC_FACE=0 (diagnostic): corner records in the lane-per-walker kernels too
+  const int fmt0 = (r8 && wp_walk.simt_w && !f16_off) ? 2 : r8, fmtT = (r8 && wp_trav.simt_w && !f16_off) ? 2 : r8;
   for (int i = 0; i < n; i++) {
-    const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
+    const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
     J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = seq ? 0 : geo_relabel_mode(); J.seq = seq ? 1 : 0; J.late_join = late_join ? 1 : 0;
     J.has_uv = (m.uv && m.idx_uv && m.n_uv) ? 1 : 0; J.has_nrm = (m.nrm && m.idx_nrm && m.n_nrm) ? 1 : 0;
     J.n_uv = J.has_uv ? m.n_uv : 0; J.n_nrm = J.has_nrm ? m.n_nrm : 0;
     J.nad = J.has_uv + J.has_nrm; J.qp = prm.q_position_attr; J.qt = prm.q_texture_attr; J.qn = prm.q_normal_attr;
     { int k = 0; if (J.has_uv) J.att_kind[k++] = 0; if (J.has_nrm) J.att_kind[k++] = 1; for (; k < 2; k++) J.att_kind[k] = -1; }
-    const WsPlan &wp = layout_job(J, nullptr, full, r8 != 0, G->plan, G->items);
+    const WsPlan &wp = layout_job(J, nullptr, full, fmt0, fmtT, G->plan, G->items);
     ws_off[i] = ws_total; ws_total += wp.total; zero_sz[i] = wp.zero;
     const size_t in_sz = ((size_t)m.n_pos * 12 + 255) / 256 * 256 + ((size_t)J.n_uv * 8 + 255) / 256 * 256 + ((size_t)J.n_nrm * 12 + 255) / 256 * 256 +
                          (size_t)(1 + J.has_uv + J.has_nrm) * (((size_t)m.n_faces * 12 + 255) / 256 * 256);
@@ -3258,20 +3492,20 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
   int rc;
-  if ((rc = uvol_ensure(ctx, G->slab, ws_total))) return rc;
-  if ((rc = uvol_ensure(ctx, G->jobs, sizeof(GeoJob) * (size_t)n))) return rc;
-  if ((rc = uvol_ensure(ctx, G->outs, out_total))) return rc;
-  if (!on_device && (rc = uvol_ensure(ctx, G->inputs, in_total))) return rc;
+  if ((rc = uvol_ensure(ctx, L.slab, ws_total))) return rc;
+  if ((rc = uvol_ensure(ctx, L.jobs, sizeof(GeoJob) * (size_t)n))) return rc;
+  if ((rc = uvol_ensure(ctx, L.outs, out_total))) return rc;
+  if (!on_device && (rc = uvol_ensure(ctx, L.inputs, in_total))) return rc;
   std::vector<UvolUpItem> ups; if (!on_device) ups.reserve((size_t)n * 6);
   for (int i = 0; i < n; i++) {
-    const uvol_mesh &m = meshes[i]; GeoJob &J = G->hjobs[i];
-    uint8_t *base = (uint8_t *)G->slab.p + ws_off[i];
-    (void)layout_job(J, base, full, r8 != 0, G->plan, G->items);
+    const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
+    uint8_t *base = (uint8_t *)L.slab.p + ws_off[i];
+    (void)layout_job(J, base, full, fmt0, fmtT, G->plan, G->items);
     J.ws_base = base; J.ws_zero = zero_sz[i];          // cleared by ONE k_job_clear launch for the whole batch (was 2 memsets per frame)
-    J.out_pack = (uint8_t *)G->outs.p; J.slab_cap = out_total;
+    J.out_pack = (uint8_t *)L.outs.p; J.slab_cap = out_total;
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
     else {
-      uint8_t *ib = (uint8_t *)G->inputs.p + in_off[i]; size_t o = 0;
+      uint8_t *ib = (uint8_t *)L.inputs.p + in_off[i]; size_t o = 0;
       auto up = [&](const void *src, size_t bytes) -> const void * {                 // queued: ONE staged upload for the whole batch below
         void *d = ib + o; if (bytes) ups.push_back(UvolUpItem{ in_off[i] + o, src, bytes }); o += (bytes + 255) / 256 * 256; return d; };
       J.pos = (const float *)up(m.pos, (size_t)m.n_pos * 12);
@@ -3289,11 +3523,16 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     J.rb[0].bits = J.start_bits; J.rb[1].bits = J.seam_bits[0]; J.rb[2].bits = J.seam_bits[1]; J.rb[3].bits = J.ori_bits; J.rb[4].bits = J.flips;
     // rabs slot 1/2 follow the attribute-data slot; slot 3 = uv orientations, slot 4 = normal flips
   }
-  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)G->inputs.p, ups); if (rcu != UVOL_OK) return rcu; }
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->jobs.p, G->hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  GeoJob *dj = (GeoJob *)G->jobs.p;
-  const unsigned N = (unsigned)n;
-  const double t_prep = ms_since(t_enter);
+  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.inputs.p, ups); if (rcu != UVOL_OK) return rcu; }
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.jobs.p, L.hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  GeoJob *dj = (GeoJob *)L.jobs.p;
+  const unsigned N = (unsigned)n, NC = (unsigned)std::max(n, n_conc);      // NC: frames on the chip together (all groups of the call)
+  L.t_prep = ms_since(t_enter);
+  // The front ends (dedup, corner table: streaming kernels that fill the chip) of consecutive groups run one after the other, so that a
+  // group's front end meets the WALKERS of the groups before it - latency-bound, a few hundred waves - instead of their front ends:
+  // each group then gets through its bandwidth-bound phases at close to the chip's full rate and the groups stay staggered.
+  static const bool fe_chain = [] { const char *e = getenv("UVOL_GEO_CHAIN"); return !(e && *e == '0'); }();
+  if (fe_chain && G->fe_last && G->fe_last != L.ev_fe) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->fe_last, 0));
   LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
                  be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
@@ -3301,7 +3540,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   bool lockstep = true;                                      // walkers of this batch move in lock step (see below); decides lanes per wave of the traversers
   // bounding boxes first: the relabelling's Morton keys are taken over them (k_quantize uses them much later)
   LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
-  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; }
+  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe; }
   else {
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
@@ -3330,13 +3569,13 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     //    lanes of a wave - 16 attribute traversers per wave then beat one per wave (200 vs 300 ms per 2160 frames), while walkers on
     //    unrelated meshes diverge and miss at different times, and one per wave is the faster form (307 vs 392 ms).
     bool any_relabel = relabel;
-    if (relabel || N >= 256) {
-      if (!G->counts) UVOL_HIP_CHECK(ctx, hipMalloc((void **)&G->counts, 64));
+    if (relabel || NC >= 256) {
+      if (!L.counts) UVOL_HIP_CHECK(ctx, hipMalloc((void **)&L.counts, 64));
       uint32_t hc[2] = { 0, 0 };
-      UVOL_HIP_CHECK(ctx, hipMemsetAsync(G->counts, 0, 64, ctx->stream));
+      UVOL_HIP_CHECK(ctx, hipMemsetAsync(L.counts, 0, 64, ctx->stream));
       LAUNCH(k_coherence, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_relabel_decide, dim3((N + 63) / 64), dim3(64), dj, n, G->counts);
-      UVOL_HIP_CHECK(ctx, hipMemcpyAsync(hc, G->counts, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+      LAUNCH(k_relabel_decide, dim3((N + 63) / 64), dim3(64), dj, n, L.counts);
+      UVOL_HIP_CHECK(ctx, hipMemcpyAsync(hc, L.counts, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
       UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       any_relabel = relabel && hc[0] != 0;
       lockstep = (uint64_t)hc[1] * 10u >= (uint64_t)n * 9u;
@@ -3376,15 +3615,19 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_edge_match, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
   }
-  WalkPlan wp_walk = walk_plan(G, max_nfi, max_vals, (size_t)N);
+  UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe;
   // UVOL_SIMT_W_WALK / UVOL_SIMT_W_TRAV (diagnostic): lanes per wave of one of the two lane-per-walker kernels only (UVOL_SIMT_W sets both)
   static const int w_walk_env = [] { const char *e = getenv("UVOL_SIMT_W_WALK"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
   static const int w_trav_env = [] { const char *e = getenv("UVOL_SIMT_W_TRAV"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
   if (w_walk_env && wp_walk.simt_w) wp_walk.simt_w = w_walk_env;
   {
-    LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, r8);
+    LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, fmt0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
-    if (wp_walk.simt_w) { const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W; if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W); }
+    if (wp_walk.simt_w) {
+      const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
+      if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
+      else if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
+    }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());
     else LAUNCH_SM((k_eb_walk<false>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());
     LAUNCH(k_face_time, dim3(bf, N), dim3(UVOL_BLOCK), dj);
@@ -3400,13 +3643,13 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_valence_init, dim3(bc, N), dim3(UVOL_BLOCK), dj);
   }
-  UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_walk, ctx->stream));
-  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(G->aux, G->ev_walk, 0));
+  UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_walk, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(L.aux, L.ev_walk, 0));
   {
-    { uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence", 0, G->aux); LAUNCH_ON(G->aux, k_eb_valence, dim3(N), dim3(64), dj); }
-    LAUNCH_ON(G->aux, k_eb_ctx, dim3(N), dim3(64), dj);
+    { uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence", 0, L.aux); LAUNCH_ON(L.aux, k_eb_valence, dim3(N), dim3(64), dj); }
+    LAUNCH_ON(L.aux, k_eb_ctx, dim3(N), dim3(64), dj);
   }
-  UVOL_HIP_CHECK(ctx, hipEventRecord(G->ev_val, G->aux));
+  UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_val, L.aux));
   {
     uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
     LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
@@ -3420,20 +3663,17 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
   // entropy stage: it then overlaps the renumber / seams group only (about as long), but everything it reads (old-order
   // opposite corners and vertices, the symbol sequence, the valence scratch: 11.6 MB per frame) is dead before the three record
   // tables of the attribute traversals are written and shares their addresses - the workspace peak drops from 63 to 52 MB.
-  if (!late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
+  if (!late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, L.ev_val, 0));
   {
-    LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, r8);
+    LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, fmtT);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): LDS traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
-    static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
-    const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
-    WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * N, tvg);
     if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = 1;      // unrelated meshes: one traverser per wave
     if (w_trav_env && wp_trav.simt_w) wp_trav.simt_w = w_trav_env;
-    launch_traversals(ctx, dj, n, wp_trav, r8);
+    launch_traversals(ctx, dj, n, wp_trav, fmtT);
   }
-  { uvol_ctx::Scope sc(ctx, "geo.k5b_v2d", 0); LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, r8); }      // (own scope: geo.k5_traverse is exactly the traversal kernel, as rocprof lists it)
+  { uvol_ctx::Scope sc(ctx, "geo.k5b_v2d", 0); LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, fmtT); }      // (own scope: geo.k5_traverse is exactly the traversal kernel, as rocprof lists it)
   {
     uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
     LAUNCH(k_quantize, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
@@ -3449,7 +3689,7 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_ori_bits, dim3(be, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_pred_nrm, dim3(be, N), dim3(UVOL_BLOCK), dj);
   }
-  if (late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->ev_val, 0));
+  if (late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, L.ev_val, 0));
   {
     uvol_ctx::Scope sc0(ctx, "geo.k7_hist_tables", 0);
     LAUNCH(k_hist, dim3(uvol_blocks((size_t)9 * max_nfi, 16 * UVOL_BLOCK), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
@@ -3463,13 +3703,13 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     // UVOL_ENTROPY_WAVE=1 / 0 (tests / diagnostic) forces one form.
     static const int ent_env = [] { const char *e = getenv("UVOL_ENTROPY_WAVE"); return !e ? -1 : (*e == '1' ? 1 : 0); }();
     static const int ent_w_env = [] { const char *e = getenv("UVOL_ENTROPY_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // lanes per wave of the lane form (implies it)
-    const bool ent_wave = ent_env >= 0 ? ent_env == 1 : (ent_w_env == 0 && (size_t)(GEO_NSTREAM + GEO_NRABS) * N <= (size_t)20 * G->num_cu);
+    const bool ent_wave = ent_env >= 0 ? ent_env == 1 : (ent_w_env == 0 && (size_t)(GEO_NSTREAM + GEO_NRABS) * NC <= (size_t)20 * G->num_cu);
     if (ent_wave) LAUNCH(k_entropy_encode, dim3(N, GEO_NSTREAM + GEO_NRABS), dim3(64), dj, uvol_debug() ? 1 : 0);      // frame index fastest: the long streams of the frames spread over the four SIMDs of a CU (geom_decode.hip: k_gdec_rans)
     else {
       // lanes per wave: five streams of a frame are long (three attribute symbol streams, two seam-bit streams; ~300 k steps) and a
       // wave runs as long as its longest lane, so the launch should put at most ONE long wave on a SIMD (1024 of them): waves that
       // share a SIMD share its issue slots (2160 frames: 172 / 105 / 60 / 64 / 55 / 52 ms with 1 / 2 / 4 / 8 / 16 / 32 lanes per wave)
-      unsigned W = 4; while (W < 64 && 5u * N > 512u * W) W *= 2;
+      unsigned W = 4; while (W < 64 && 5u * NC > 512u * W) W *= 2;
       if (ent_w_env) W = (unsigned)ent_w_env;
       LAUNCH(k_rans_recip, dim3(uvol_blocks(((size_t)2 << std::max(prm.q_position_attr, std::max(prm.q_texture_attr, prm.q_normal_attr))) + 8), GEO_NSTREAM, N), dim3(UVOL_BLOCK), dj);
       LAUNCH_SM(k_entropy_simt, dim3((N + W - 1) / W, GEO_NSTREAM + GEO_NRABS), dim3(64), (size_t)W * SB_STRIDE * 4, dj, n, (int)W);
@@ -3483,34 +3723,45 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     LAUNCH(k_gather, dim3(64, GEO_MAXPIECES, N), dim3(UVOL_BLOCK), dj);
   }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
-  const double t_enq = ms_since(t_enter);
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->hjobs.data(), dj, sizeof(GeoJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.hjobs.data(), dj, sizeof(GeoJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  L.t_enq = ms_since(t_enter); L.t_enter = t_enter;
+  return UVOL_OK;
+}
+
+// Second half of a group: waits for its stream, copies the packed bitstreams out (one device-to-host copy into pinned staging, then
+// plain memcpy into the caller's buffers), fills out_lens / status, re-encodes the frames the compact workspace could not hold.
+static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
+  static const bool timing = [] { const char *e = getenv("UVOL_TIMING"); return e && *e == '1'; }();       // diagnostic: host-side phases of a batch on stderr
+  auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  const int n = L.n; const bool full = L.full, on_device = L.on_device;
+  uint8_t *const *outs = L.outp.data(); size_t *out_lens = L.out_lens; int *status = L.status;
+  const auto t_enter = L.t_enter; const double t_prep = L.t_prep, t_enq = L.t_enq;
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const double t_gpu = ms_since(t_enter);
   int worst = UVOL_OK;
   // one device-to-host copy of the packed bitstreams into pinned staging, then plain memcpy into the caller's buffers
   size_t packed = 0;
-  for (int i = 0; i < n; i++) { const GeoJob &J = G->hjobs[i]; if (J.status == 0) packed = std::max<size_t>(packed, (size_t)J.out_pack_off + J.out_len); }
-  if (packed > G->pinned_cap) {
-    if (G->pinned) (void)hipHostFree(G->pinned);
-    G->pinned = nullptr; G->pinned_cap = 0;
+  for (int i = 0; i < n; i++) { const GeoJob &J = L.hjobs[i]; if (J.status == 0) packed = std::max<size_t>(packed, (size_t)J.out_pack_off + J.out_len); }
+  if (packed > L.pinned_cap) {
+    if (L.pinned) (void)hipHostFree(L.pinned);
+    L.pinned = nullptr; L.pinned_cap = 0;
     const size_t want = packed + packed / 4 + (1u << 20);
-    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&G->pinned, want, hipHostMallocDefault));
-    G->pinned_cap = want;
+    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&L.pinned, want, hipHostMallocDefault));
+    L.pinned_cap = want;
   }
   if (packed) {
-    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(G->pinned, G->outs.p, packed, hipMemcpyDeviceToHost, ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.pinned, L.outs.p, packed, hipMemcpyDeviceToHost, ctx->stream));
     UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   const double t_d2h = ms_since(t_enter);
   std::vector<int> retry;
   // staging -> the caller's buffers: a few host threads for large batches (2160 frames x 250 KB took ~60 ms of one core per batch)
   { const int nt = packed > ((size_t)32 << 20) ? 8 : 1;
-    auto copy_range = [&](int a, int b) { for (int i = a; i < b; i++) { const GeoJob &J = G->hjobs[i]; if (J.status == 0) memcpy(outs[i], G->pinned + J.out_pack_off, J.out_len); } };
+    auto copy_range = [&](int a, int b) { for (int i = a; i < b; i++) { const GeoJob &J = L.hjobs[i]; if (J.status == 0) memcpy(outs[i], L.pinned + J.out_pack_off, J.out_len); } };
     if (nt == 1) copy_range(0, n);
     else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(copy_range, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); for (auto &x : th) x.join(); } }
   for (int i = 0; i < n; i++) {
-    const GeoJob &J = G->hjobs[i];
+    const GeoJob &J = L.hjobs[i];
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
     out_lens[i] = J.out_len;
     if (st == UVOL_OK) { }
@@ -3518,17 +3769,85 @@ static int geo_encode_batch_impl(uvol_ctx *ctx, const uvol_mesh *meshes, int n, 
     else { ctx->set_error("mesh %d: encode failed (device status %d)", i, J.status); worst = st; }
     if (status) status[i] = st;
   }
-  ctx->resolve_profile();
   // frames the compact workspace (or the packed output area) could not hold: once more, alone, with worst-case sizes
-  for (int i : retry) {
-    if (timing) fprintf(stderr, "[uvol-timing] mesh %d: device status %d, re-encoding with worst-case workspace\n", i, G->hjobs.empty() ? 0 : 0);
-    int st1 = UVOL_OK;
-    const int rc1 = geo_encode_batch_impl(ctx, meshes + i, 1, on_device, outs + i, caps + i, out_lens + i, &st1, true);
-    if (rc1 != UVOL_OK) return rc1;
-    if (status) status[i] = st1;
-    if (st1 != UVOL_OK) worst = st1;
+  if (!retry.empty()) {
+    // the lane's own record of the group is replaced by the one-frame retries: keep what is still needed
+    const std::vector<uvol_mesh> rm(L.meshes); const std::vector<uint8_t *> ro(L.outp); const std::vector<size_t> rcap(L.caps);
+    for (int i : retry) {
+      if (timing) fprintf(stderr, "[uvol-timing] mesh %d: re-encoding with worst-case workspace\n", i);
+      int st1 = UVOL_OK;
+      int rc1 = geo_submit(ctx, L, &rm[i], 1, 1, on_device, &ro[i], &rcap[i], out_lens + i, &st1, true);
+      if (rc1 == UVOL_OK) rc1 = geo_complete(ctx, L);
+      if (rc1 != UVOL_OK) return rc1;
+      if (status) status[i] = st1;
+      if (st1 != UVOL_OK) worst = st1;
+    }
   }
-  if (timing) fprintf(stderr, "[uvol-timing] geo batch n=%d sizeof(GeoJob)=%zu: host prepared %.1f ms, enqueued %.1f, gpu done %.1f, packed d2h %.1f, copied out %.1f (enter at %.1f)\n", n, sizeof(GeoJob), t_prep, t_enq, t_gpu, t_d2h, ms_since(t_enter),
+  if (timing) fprintf(stderr, "[uvol-timing] geo group n=%d sizeof(GeoJob)=%zu: host prepared %.1f ms, enqueued %.1f, gpu done %.1f, packed d2h %.1f, copied out %.1f (enter at %.1f)\n", n, sizeof(GeoJob), t_prep, t_enq, t_gpu, t_d2h, ms_since(t_enter),
                       std::chrono::duration<double, std::milli>(t_enter.time_since_epoch()).count());
   return status ? UVOL_OK : worst;
+}
+
+// the lane's streams stand in for the context's while one of its groups is submitted / completed (LAUNCH, Scope, uvol_ensure use ctx->stream)
+static int geo_submit(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, int n, int n_conc, bool on_device,
+                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full) {
+  L.meshes.assign(meshes, meshes + n); L.outp.assign(outs, outs + n); L.caps.assign(caps, caps + n);
+  L.out_lens = out_lens; L.status = status; L.n = n; L.n_conc = n_conc; L.on_device = on_device; L.full = full;
+  hipStream_t saved = ctx->stream; ctx->stream = L.stream;
+  const int rc = geo_submit_impl(ctx, L, L.meshes.data(), n, n_conc, on_device, L.caps.data(), full);
+  ctx->stream = saved;
+  L.busy = rc == UVOL_OK;
+  return rc;
+}
+static int geo_complete(uvol_ctx *ctx, GeoLane &L) {
+  if (!L.busy) return UVOL_OK;
+  L.busy = false;
+  hipStream_t saved = ctx->stream; ctx->stream = L.stream;
+  const int rc = geo_complete_impl(ctx, L);
+  ctx->stream = saved;
+  return rc;
+}
+
+// completes every group still in flight (enqueued calls complete lazily, so that the next call's front end overlaps this call's walkers);
+// returns the first error among them and among the groups completed earlier on behalf of later calls
+int geo_flush(uvol_ctx *ctx) {
+  GeoState *G = ctx->geo; if (!G) return UVOL_OK;
+  int rc = G->deferred_rc; G->deferred_rc = UVOL_OK;
+  const int nl = (int)G->lanes.size();
+  for (int k = 0; k < nl; k++) { GeoLane *L = G->lanes[(G->next_lane + k) % nl]; const int r = geo_complete(ctx, *L); if (rc == UVOL_OK) rc = r; }
+  ctx->resolve_profile();
+  return rc;
+}
+
+// lanes a call may be spread over: UVOL_GEO_LANES (default 4; 1 = the whole call as one group on the context's stream, as before round 4)
+static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 4; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
+// frames per group at least (UVOL_GEO_MIN_GROUP, tests: small values spread small calls over the lanes): below 2 x this a call stays one
+// group - its walkers are the whole critical path anyway
+static inline int geo_min_group() { static const int v = [] { const char *e = getenv("UVOL_GEO_MIN_GROUP"); const int k = e ? atoi(e) : 160; return k < 1 ? 1 : k; }(); return v; }
+
+// Enqueue n frames: the call is cut into up to `lanes` contiguous groups, each submitted on the next lane of the ring.  A lane that still
+// holds a group of an EARLIER call is completed first (its error, if any, is kept for geo_flush).
+int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
+                           uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  GeoState *G = ctx->geo;
+  if (n <= 0) return UVOL_OK;
+  const int want = geo_lanes_wanted();
+  const int groups = std::max(1, std::min(want, n / geo_min_group()));
+  for (int g = 0; g < groups; g++) {
+    const int a = (int)((long long)n * g / groups), b = (int)((long long)n * (g + 1) / groups);
+    GeoLane *L = geo_lane(ctx, G->next_lane % want);
+    if (!L) { ctx->set_error("geometry lane: stream / event creation failed"); return UVOL_E_HIP; }
+    G->next_lane = (G->next_lane + 1) % want;
+    if (L->busy) { const int r = geo_complete(ctx, *L); if (r != UVOL_OK && G->deferred_rc == UVOL_OK) G->deferred_rc = r; }
+    const int rc = geo_submit(ctx, *L, meshes + a, b - a, n, on_device, outs + a, caps + a, out_lens + a, status ? status + a : nullptr, false);
+    if (rc != UVOL_OK) return rc;
+  }
+  return UVOL_OK;
+}
+// blocking form: begin + flush
+int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
+                     uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  const int rc = geo_encode_batch_begin(ctx, meshes, n, on_device, outs, caps, out_lens, status);
+  const int rf = geo_flush(ctx);
+  return rc != UVOL_OK ? rc : rf;
 }

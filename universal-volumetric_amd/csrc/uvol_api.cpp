@@ -47,16 +47,33 @@ static void async_worker(uvol_ctx *ctx) {
     if (A->q.empty()) { if (A->stop) return; continue; }
     std::function<int()> f = std::move(A->q.front()); A->q.pop_front(); A->busy = true;
     l.unlock();
-    const int rc = f();
+    int rc = UVOL_OK;
+    try { rc = f(); } catch (...) { rc = UVOL_E_HIP; ctx->set_error("enqueued call: out of memory on the host"); }
     l.lock();
     if (rc != UVOL_OK && A->first_err == UVOL_OK) { A->first_err = rc; snprintf(A->err, sizeof A->err, "%s", ctx->err); }
+    if (A->q.empty()) {                                    // nothing else queued: the mesh groups still in flight on the lanes are completed now
+      l.unlock();
+      (void)hipSetDevice(ctx->device);
+      int rf = UVOL_OK;
+      try { rf = geo_flush(ctx); } catch (...) { rf = UVOL_E_HIP; ctx->set_error("enqueued call: out of memory on the host"); }
+      l.lock();
+      if (rf != UVOL_OK && A->first_err == UVOL_OK) { A->first_err = rf; snprintf(A->err, sizeof A->err, "%s", ctx->err); }
+    }
     A->busy = false;
     if (A->q.empty()) A->cv_idle.notify_all();
   }
 }
 static int async_push(uvol_ctx *ctx, std::function<int()> f) {
-  if (!ctx->async) { ctx->async = new (std::nothrow) uvol_ctx::AsyncQ(); if (!ctx->async) return UVOL_E_HIP; ctx->async->th = std::thread(async_worker, ctx); }
-  { std::lock_guard<std::mutex> l(ctx->async->m); ctx->async->q.push_back(std::move(f)); }
+  try {
+    if (!ctx->async) {
+      // published before the thread starts (the worker reads ctx->async) and taken back if the thread cannot be started: a context
+      // whose worker never ran would queue calls nobody executes and wait for them for ever in uvol_sync / uvol_ctx_destroy
+      uvol_ctx::AsyncQ *A = new (std::nothrow) uvol_ctx::AsyncQ(); if (!A) return UVOL_E_HIP;
+      ctx->async = A;
+      try { A->th = std::thread(async_worker, ctx); } catch (...) { ctx->async = nullptr; delete A; ctx->set_error("enqueue: the worker thread could not be started"); return UVOL_E_HIP; }
+    }
+    { std::lock_guard<std::mutex> l(ctx->async->m); ctx->async->q.push_back(std::move(f)); }
+  } catch (...) { ctx->set_error("enqueue: out of memory on the host"); return UVOL_E_HIP; }
   ctx->async->cv_work.notify_one();
   return UVOL_OK;
 }
@@ -142,14 +159,16 @@ int uvol_sync(uvol_ctx *ctx) {
   return arc;
 }
 
+// defer = the enqueue form: the call's groups are submitted and completed lazily (by the worker when its queue runs empty, or when a
+// later call needs the lane), so that consecutive enqueued calls overlap on the device
 static int encode_batch_common(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool dev,
-                               uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+                               uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool defer = false) {
   if (!ctx || !meshes || n < 0 || !outs || !caps || !out_lens) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   const int mb = ctx->prm.max_batch;
   for (int b0 = 0; b0 < n; b0 += mb) {
     const int nb = n - b0 < mb ? n - b0 : mb;
-    int rc = geo_encode_batch(ctx, meshes + b0, nb, dev, outs + b0, caps + b0, out_lens + b0, status ? status + b0 : nullptr);
+    int rc = (defer ? geo_encode_batch_begin : geo_encode_batch)(ctx, meshes + b0, nb, dev, outs + b0, caps + b0, out_lens + b0, status ? status + b0 : nullptr);
     if (rc != UVOL_OK) return rc;
   }
   return UVOL_OK;
@@ -213,9 +232,11 @@ int uvol_encode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *rgba_d
 // ---- enqueue forms (see the block comment above async_worker) ----
 static int mesh_batch_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool dev, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   if (!ctx || !meshes || n < 0 || !outs || !caps || !out_lens) return UVOL_E_INVALID;
-  std::vector<uvol_mesh> m(meshes, meshes + n); std::vector<uint8_t *> o(outs, outs + n); std::vector<size_t> c(caps, caps + n);
-  return async_push(ctx, [ctx, m = std::move(m), o = std::move(o), c = std::move(c), n, dev, out_lens, status]() {
-    return encode_batch_common(ctx, m.data(), n, dev, o.data(), c.data(), out_lens, status); });
+  try {
+    std::vector<uvol_mesh> m(meshes, meshes + n); std::vector<uint8_t *> o(outs, outs + n); std::vector<size_t> c(caps, caps + n);
+    return async_push(ctx, [ctx, m = std::move(m), o = std::move(o), c = std::move(c), n, dev, out_lens, status]() {
+      return encode_batch_common(ctx, m.data(), n, dev, o.data(), c.data(), out_lens, status, true); });
+  } catch (...) { ctx->set_error("enqueue: out of memory on the host"); return UVOL_E_HIP; }
 }
 int uvol_encode_mesh_batch_async(uvol_ctx *ctx, const uvol_mesh *meshes, int n, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   return mesh_batch_async(ctx, meshes, n, false, outs, caps, out_lens, status);
@@ -226,11 +247,13 @@ int uvol_encode_mesh_batch_dev_async(uvol_ctx *ctx, const uvol_mesh *meshes, int
 static int tex_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height, bool dev,
                               uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
   if (!ctx || !rgba || n_segments <= 0 || n_layers <= 0 || !outs || !caps || !out_lens || width == 0 || height == 0) return UVOL_E_INVALID;
-  std::vector<const uint8_t *> r(rgba, rgba + (size_t)n_segments * n_layers); std::vector<uint8_t *> o(outs, outs + n_segments); std::vector<size_t> c(caps, caps + n_segments);
-  return async_push(ctx, [ctx, r = std::move(r), o = std::move(o), c = std::move(c), n_segments, n_layers, width, height, dev, out_lens]() {
-    (void)hipSetDevice(ctx->device);
-    if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens);
-    return tex_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens); });
+  try {
+    std::vector<const uint8_t *> r(rgba, rgba + (size_t)n_segments * n_layers); std::vector<uint8_t *> o(outs, outs + n_segments); std::vector<size_t> c(caps, caps + n_segments);
+    return async_push(ctx, [ctx, r = std::move(r), o = std::move(o), c = std::move(c), n_segments, n_layers, width, height, dev, out_lens]() {
+      (void)hipSetDevice(ctx->device);
+      if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens);
+      return tex_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens); });
+  } catch (...) { ctx->set_error("enqueue: out of memory on the host"); return UVOL_E_HIP; }
 }
 int uvol_encode_texture_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height,
                                        uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
@@ -300,13 +323,16 @@ int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_
   return UVOL_OK;
 }
 
-int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; ctx->profiling = on != 0; return UVOL_OK; }
+// (the profile entry points wait for enqueued work first: the worker thread updates the same records)
+int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; UVOL_AFTER_ASYNC(ctx); ctx->profiling = on != 0; return UVOL_OK; }
 int uvol_profile_reset(uvol_ctx *ctx) {
   if (!ctx) return UVOL_E_INVALID;
+  UVOL_AFTER_ASYNC(ctx);
   (void)hipStreamSynchronize(ctx->stream); ctx->resolve_profile(); ctx->prof.clear(); return UVOL_OK;
 }
-int uvol_profile_count(uvol_ctx *ctx) { if (!ctx) return 0; ctx->resolve_profile(); return (int)ctx->prof.size(); }
+int uvol_profile_count(uvol_ctx *ctx) { if (!ctx) return 0; UVOL_AFTER_ASYNC(ctx); ctx->resolve_profile(); return (int)ctx->prof.size(); }
 int uvol_profile_get(uvol_ctx *ctx, int i, char *name, size_t name_cap, uint64_t *launches, double *total_ms, uint64_t *algo_bytes) {
+  if (ctx) UVOL_AFTER_ASYNC(ctx);
   if (!ctx || i < 0 || i >= (int)ctx->prof.size()) return UVOL_E_INVALID;
   const uvol_prof_entry &e = ctx->prof[i];
   if (name && name_cap) { strncpy(name, e.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }

@@ -146,7 +146,7 @@ int main(int argc, char **argv) {
         std::atomic<int> wbad{-1};
         parallel_for(prev.nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, prev.b0 + k); if (!write_file(join(geo_dir, name), (*prev.outs)[k].get(), prev.lens[k])) wbad = (int)(prev.b0 + k); });
         prev.nb = 0;
-        if (wbad >= 0) geo_failed = wbad.load();
+        if (wbad >= 0 && geo_failed < 0) geo_failed = wbad.load();                        // (the first error stands)
       };
       for (size_t b0 = lo; b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
         const double tw0 = now_ms();
@@ -175,7 +175,7 @@ int main(int argc, char **argv) {
         prev.outs = &outs; prev.lens = lens; prev.b0 = b0; prev.nb = nb;
         if (g_timing) std::fprintf(stderr, "[uvolenc-timing] geo batch b0=%zu: waited for load %.0f ms, prepare %.0f, write of the previous batch (GPU busy) %.0f, waited for the GPU %.0f\n", b0, tw1 - tw0, te0 - tw1, te1 - te0, now_ms() - te1);
       }
-      if (geo_failed < 0) write_prev();
+      write_prev();          // also after a failure: the batch before the failing one was encoded and is written, as the reference's frame-at-a-time loop would have left it (scripts/Encoder.py:256-267)
       if (nextb.valid()) nextb.wait();
     });
   }

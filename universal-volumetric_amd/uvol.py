@@ -171,6 +171,26 @@ class Codec:
             raise UvolError(f"encode_mesh_batch_async rc={rc}: {self.error()}")
         self._pending = getattr(self, "_pending", []) + [("mesh", n, bufs, lens, st, keep, meshes)]
 
+    def start_mesh_batch_dev(self, meshes, slot=0):
+        """Enqueues uvol_encode_mesh_batch_dev_async for a ctypes array of Mesh holding DEVICE pointers.  The output buffers of `slot`
+        are re-used by every call with that slot (two slots let consecutive enqueued calls overlap without a buffer set per call);
+        finish() returns numpy views into them."""
+        n = len(meshes)
+        sets = self.__dict__.setdefault("_slot_bufs", {})
+        bufs = sets.setdefault(slot, [])
+        while len(bufs) < n:
+            bufs.append(np.empty(0, dtype=np.uint8))
+        caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)()
+        for i in range(n):
+            cap = self.L.uvol_mesh_bound(C.byref(meshes[i]))
+            if bufs[i].size < cap:
+                bufs[i] = np.empty(cap, dtype=np.uint8)
+            caps[i] = cap; outs[i] = bufs[i].ctypes.data
+        rc = self.L.uvol_encode_mesh_batch_dev_async(self.h, meshes, n, outs, caps, lens, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_mesh_batch_dev_async rc={rc}: {self.error()}")
+        self._pending = getattr(self, "_pending", []) + [("mesh_views", n, bufs, lens, st, (caps, outs), meshes)]
+
     def start_texture_segments(self, segments):
         """Enqueues uvol_encode_texture_segments_async for host segments."""
         arrs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in seg] for seg in segments]
@@ -189,11 +209,16 @@ class Codec:
         """uvol_sync: completes every enqueued call; returns their results in call order (meshes: None for a failed frame)."""
         rc = self.L.uvol_sync(self.h)
         pend, self._pending = getattr(self, "_pending", []), []
-        if rc != UVOL_OK:
-            raise UvolError(f"uvol_sync rc={rc}: {self.error()}")
         res = []
         for kind, n, bufs, lens, st, _, _ in pend:
-            res.append([(bufs[i][:lens[i]].tobytes() if (st is None or st[i] == UVOL_OK) else None) for i in range(n)])
+            if kind == "mesh_views":
+                res.append([(bufs[i][:lens[i]] if st[i] == UVOL_OK else None) for i in range(n)])
+            else:
+                res.append([(bufs[i][:lens[i]].tobytes() if ((st is None or st[i] == UVOL_OK) and lens[i]) else None) for i in range(n)])
+        if rc != UVOL_OK:
+            # a call that failed as a whole leaves its lengths at zero (entries None); the calls that succeeded are not lost with it
+            e = UvolError(f"uvol_sync rc={rc}: {self.error()}"); e.partial_results = res
+            raise e
         return res
 
     def _run_batch(self, fn, meshes, n, raise_on_error, views=False):
