@@ -28,6 +28,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "universal-volumetric_amd"))
+# One hardware queue per stream: the runtime's default is 4 hardware queues per process, and streams that share one run one after the
+# other.  The codec's contexts hold two streams per geometry lane plus the texture stream (measured: 4 lanes, 2922 frames/s geometry-only
+# on 4 queues, 3420 on 24).  Read by the HIP runtime when it initialises, i.e. before torch / the codec library are loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 I8_PEAK_TOPS = 3944.0        # dense i8 MFMA (16x16x64), MI355X_MICROARCH.md

@@ -3723,7 +3723,8 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     LAUNCH(k_gather, dim3(64, GEO_MAXPIECES, N), dim3(UVOL_BLOCK), dj);
   }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.hjobs.data(), dj, sizeof(GeoJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  // (the job records are read back by geo_complete_impl: a device-to-host copy into pageable memory does not return before the stream
+  // has reached it, i.e. before every kernel of this group is done - here it serialised the groups of a call)
   L.t_enq = ms_since(t_enter); L.t_enter = t_enter;
   return UVOL_OK;
 }
@@ -3737,6 +3738,7 @@ static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
   uint8_t *const *outs = L.outp.data(); size_t *out_lens = L.out_lens; int *status = L.status;
   const auto t_enter = L.t_enter; const double t_prep = L.t_prep, t_enq = L.t_enq;
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpy(L.hjobs.data(), L.jobs.p, sizeof(GeoJob) * (size_t)n, hipMemcpyDeviceToHost));
   const double t_gpu = ms_since(t_enter);
   int worst = UVOL_OK;
   // one device-to-host copy of the packed bitstreams into pinned staging, then plain memcpy into the caller's buffers
