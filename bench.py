@@ -160,8 +160,8 @@ def main():
     class Job:
         """One pass over the first n frames / n // B segments of the resident inputs (n = F for the headline; the variants run
         smaller jobs on the same contexts and buffers)."""
-        def __init__(self, n, host=False, only=args.only):
-            self.n, self.nseg, self.host, self.only = n, n // B, host, only
+        def __init__(self, n, host=False, only=args.only, blocking=False):
+            self.n, self.nseg, self.host, self.only, self.blocking = n, n // B, host, only, blocking or args.blocking_calls
             self.gsl = [(gi * n // GS, (gi + 1) * n // GS) for gi in range(GS)]
             nd = len(dev_meshes)
             self.gb = None if host else [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
@@ -172,7 +172,7 @@ def main():
             by one uvol_sync - the context then runs the front end of pass k + 1 beside the walkers of pass k (two output buffer sets in
             turn: a pass's bytes are in host memory when the pass after the next one starts).  --blocking-calls: one blocking call per pass."""
             a, b = self.gsl[gi]
-            if self.host or args.blocking_calls or b <= a:
+            if self.host or self.blocking or b <= a:
                 for _ in range(kk):
                     self.run_geo(gi)
                 return
@@ -360,11 +360,16 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     for n in (150, 300, 1200):
         if n <= F:
             note("job_%d" % n)
-            v["job_%d" % n] = Job(n).timed(3, 1)
+            v["job_%d" % n] = dict(Job(n, blocking=True).timed(3, 1), note="ONE job = one blocking call per pass (its latency is what the 8-GPU projection needs)")
     if "job_150" in v and "job_1200" in v:
         v["projected_8gpu_speedup_configs3"] = {"value": 8.0 * v["job_150"]["frames_per_s"] / v["job_1200"]["frames_per_s"],
                                                 "how": "8 x frames/s of the 150-frame share of one GPU / frames/s of the whole 1200-frame job on one GPU; "
                                                        "the manifest gather (32 bytes per rank) is not modelled"}
+    if 300 <= F:                                               # a STREAM of 300-frame jobs: enqueued calls, consecutive jobs overlap on the context's lanes
+        note("stream_of_300_frame_jobs")
+        v["stream_of_300_frame_jobs"] = dict(Job(300).timed(6, 2), note="300-frame jobs enqueued back to back (uvol_encode_mesh_batch_dev_async), one uvol_sync at the end")
+    note("blocking_calls")
+    v["blocking_calls"] = dict(Job(F, blocking=True).timed(2, 0), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
     if args.only:                                              # (diagnostic: UVOL_VARIANTS_WITH_ONLY=1) one half of the path, job sizes only
         return v
     # (2) scan-like storage order: the resident input buffers are overwritten with a seeded permutation of faces and values

@@ -161,7 +161,7 @@ def test_hipemu_call_spread_over_lanes(oracle, hipemu_lib):
         "cd.close(); print('lanes ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
     for lanes in ("4", "2"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_GEO_MIN_GROUP="2", UVOL_GEO_LANES=lanes), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_GEO_MIN_GROUP="2", UVOL_GEO_LANES=lanes, UVOL_GEO_SPLIT="1"), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "lanes ok" in r.stdout, (lanes, r.stdout[-500:], r.stderr[-2000:])
 
 

@@ -10,7 +10,7 @@ O=gpurun_out/$TAG; mkdir -p $O
 for H in ${PMC_HALVES:-geo tex}; do for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   for TRY in 1 2 3; do
     rm -rf $O/p_${H}_$C
-    UVOL_DEBUG=1 timeout ${PMC_TIMEOUT:-100} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p_${H}_$C -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --frames-per-step 2160 --only $H > /dev/null 2> $O/pmc_${H}_$C.err
+    UVOL_GEO_LANES=1 UVOL_DEBUG=1 timeout ${PMC_TIMEOUT:-100} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p_${H}_$C -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --frames-per-step 2160 --only $H > /dev/null 2> $O/pmc_${H}_$C.err
     if python tools/pmc_one.py $O/p_${H}_$C $C $O/pmc_${H}_$C.json >> $O/pmc.log 2>&1; then echo "$H $C ok (try $TRY)" >> $O/pmc.log; break; else echo "$H $C FAILED (try $TRY)" >> $O/pmc.log; fi
   done
   rm -rf $O/p_${H}_$C $O/pmc_${H}_$C.err

@@ -3342,6 +3342,7 @@ static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
 }
 // the decode path sizes its record tables with the same rule; its vertex ids are dense (< 3 * faces)
 bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
+static inline bool geo_rec_face_off() { static const bool v = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }(); return v; }      // UVOL_REC_FACE=0 (diagnostic, tests): corner records in the lane-per-walker kernels too
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) {
@@ -3357,8 +3358,11 @@ static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &
 int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint32_t max_vals) {
   GeoState *G = ctx->geo;
   const unsigned N = (unsigned)n, bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi);
-  const WalkPlan P = walk_plan(G, max_nfi, max_vals, (size_t)3 * N);
-  const int r8 = geo_records8(max_nfi) ? 1 : 0;
+  WalkPlan P = walk_plan(G, max_nfi, max_vals, (size_t)3 * N);
+  // files of a batch are unrelated meshes as far as the decoder knows: one traverser per wave (several per wave pay for each other's
+  // rare paths and misses: 953 against 293 ms per 2560 distinct frames with 16 / 1), and one 16-byte record per face where the fields allow it
+  if (P.simt_w > 1 && geo_simt_env() == 0) P.simt_w = 1;
+  const int r8 = geo_records8(max_nfi) ? ((P.simt_w && !geo_rec_face_off()) ? 2 : 1) : 0;
   for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w, r8);
   launch_traversals(ctx, dj, n, P, r8);
   LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
@@ -3467,7 +3471,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
   const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
   WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, tvg);
-  static const bool f16_off = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }();      // UVOL_REC_FACE=0 (diagnostic): corner records in the lane-per-walker kernels too
+  const bool f16_off = geo_rec_face_off();
   const int fmt0 = (r8 && wp_walk.simt_w && !f16_off) ? 2 : r8, fmtT = (r8 && wp_trav.simt_w && !f16_off) ? 2 : r8;
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
@@ -3492,7 +3496,12 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
   int rc;
-  if ((rc = uvol_ensure(ctx, L.slab, ws_total))) return rc;
+  if ((rc = uvol_ensure(ctx, L.slab, ws_total))) {
+    // out of device memory: the workspaces idle lanes still hold from earlier (larger) groups are given back, then once more
+    (void)hipGetLastError();
+    for (GeoLane *o : G->lanes) if (o != &L && !o->busy) for (uvol_devbuf *b : { &o->slab, &o->inputs, &o->outs }) if (b->p) { (void)hipStreamSynchronize(o->stream); (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if ((rc = uvol_ensure(ctx, L.slab, ws_total))) return rc;
+  }
   if ((rc = uvol_ensure(ctx, L.jobs, sizeof(GeoJob) * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, L.outs, out_total))) return rc;
   if (!on_device && (rc = uvol_ensure(ctx, L.inputs, in_total))) return rc;
@@ -3821,25 +3830,34 @@ int geo_flush(uvol_ctx *ctx) {
   return rc;
 }
 
-// lanes a call may be spread over: UVOL_GEO_LANES (default 4; 1 = the whole call as one group on the context's stream, as before round 4)
-static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 4; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
+// lanes of a context: UVOL_GEO_LANES (default 2; 1 = every call one group on the context's stream, as before round 4).  Measured on 2560
+// distinct frames per call, enqueued calls: 1 / 2 / 3 / 4 lanes = 3176 / 3433 / 3401 / 3420 frames/s geometry alone, 2607 / 2682 / 2421 / 2517
+// beside the texture context - two groups overlap their front ends and walkers, more only add interference - while a blocking call cut
+// into four groups was SLOWER than one group (2454 against 3176: nothing runs beside the last group's walkers, and every group pays
+// its own read-back).
+static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 2; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
 // frames per group at least (UVOL_GEO_MIN_GROUP, tests: small values spread small calls over the lanes): below 2 x this a call stays one
 // group - its walkers are the whole critical path anyway
 static inline int geo_min_group() { static const int v = [] { const char *e = getenv("UVOL_GEO_MIN_GROUP"); const int k = e ? atoi(e) : 160; return k < 1 ? 1 : k; }(); return v; }
 
 // Enqueue n frames: the call is cut into up to `lanes` contiguous groups, each submitted on the next lane of the ring.  A lane that still
 // holds a group of an EARLIER call is completed first (its error, if any, is kept for geo_flush).
+// split: cut the call into groups (enqueued calls, whose successor overlaps their tail; blocking calls with HOST inputs, whose groups
+// upload while the groups before them encode); a blocking call on device inputs stays one group.
 int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
-                           uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+                           uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool split) {
   GeoState *G = ctx->geo;
   if (n <= 0) return UVOL_OK;
   const int want = geo_lanes_wanted();
-  const int groups = std::max(1, std::min(want, n / geo_min_group()));
+  static const int split_env = [] { const char *e = getenv("UVOL_GEO_SPLIT"); return e ? atoi(e) : -1; }();      // tests / diagnostic: 1 / 0 force / forbid the split
+  if (split_env >= 0) split = split_env != 0;
+  const int groups = split ? std::max(1, std::min(want, n / geo_min_group())) : 1;
   for (int g = 0; g < groups; g++) {
     const int a = (int)((long long)n * g / groups), b = (int)((long long)n * (g + 1) / groups);
-    GeoLane *L = geo_lane(ctx, G->next_lane % want);
+    // a blocking call on device inputs always runs on lane 0 (one workspace of its size per context, as before); the others take the ring
+    GeoLane *L = geo_lane(ctx, split ? G->next_lane % want : 0);
     if (!L) { ctx->set_error("geometry lane: stream / event creation failed"); return UVOL_E_HIP; }
-    G->next_lane = (G->next_lane + 1) % want;
+    if (split) G->next_lane = (G->next_lane + 1) % want;
     if (L->busy) { const int r = geo_complete(ctx, *L); if (r != UVOL_OK && G->deferred_rc == UVOL_OK) G->deferred_rc = r; }
     const int rc = geo_submit(ctx, *L, meshes + a, b - a, n, on_device, outs + a, caps + a, out_lens + a, status ? status + a : nullptr, false);
     if (rc != UVOL_OK) return rc;
@@ -3849,7 +3867,7 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
 // blocking form: begin + flush
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
-  const int rc = geo_encode_batch_begin(ctx, meshes, n, on_device, outs, caps, out_lens, status);
+  const int rc = geo_encode_batch_begin(ctx, meshes, n, on_device, outs, caps, out_lens, status, !on_device);
   const int rf = geo_flush(ctx);
   return rc != UVOL_OK ? rc : rf;
 }

@@ -168,7 +168,8 @@ static int encode_batch_common(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bo
   const int mb = ctx->prm.max_batch;
   for (int b0 = 0; b0 < n; b0 += mb) {
     const int nb = n - b0 < mb ? n - b0 : mb;
-    int rc = (defer ? geo_encode_batch_begin : geo_encode_batch)(ctx, meshes + b0, nb, dev, outs + b0, caps + b0, out_lens + b0, status ? status + b0 : nullptr);
+    int rc = defer ? geo_encode_batch_begin(ctx, meshes + b0, nb, dev, outs + b0, caps + b0, out_lens + b0, status ? status + b0 : nullptr, true)
+                   : geo_encode_batch(ctx, meshes + b0, nb, dev, outs + b0, caps + b0, out_lens + b0, status ? status + b0 : nullptr);
     if (rc != UVOL_OK) return rc;
   }
   return UVOL_OK;

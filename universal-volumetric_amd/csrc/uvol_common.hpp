@@ -220,7 +220,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
 // enqueue form: the groups of the call are submitted to the context's lanes and completed by geo_flush (or when a later call needs the lane)
 int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_on_device,
-                           uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+                           uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool split);
 int geo_flush(uvol_ctx *ctx);
 int geodec_create(uvol_ctx *ctx);
 void geodec_destroy(uvol_ctx *ctx);
