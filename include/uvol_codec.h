@@ -108,6 +108,15 @@ int uvol_encode_mesh_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
 int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
                                uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
 
+/* GPU-resident form (SURVEY 8(b) "variants taking arrays of frames + hipStream_t"; caller-owned buffers as in
+ * deprecated/encoder_legacy/codec/corto_codec.h:41-43): inputs are device pointers PRODUCED ON `producer_stream` (a hipStream_t passed
+ * as void *, NULL = already complete) - the codec's kernels are ordered after the work queued on that stream so far, without a host
+ * wait -, and the .drc bitstreams are LEFT IN HBM: packed into the caller's device buffer `dev_out` (capacity dev_cap bytes; 32768 +
+ * 8 bytes per face per frame always suffices for the default quantisation), frame i at dev_out + out_offs[i], out_lens[i] bytes long;
+ * offsets, lengths and status come back to the host, the payload never does.  A frame that does not fit gets UVOL_E_NOSPACE.  Blocking. */
+int uvol_encode_mesh_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, void *producer_stream,
+                                   uint8_t *dev_out, size_t dev_cap, size_t *out_offs, size_t *out_lens, int *status);
+
 /* Enqueue forms.  The call returns as soon as its arguments are recorded (the `meshes`, `outs` and `caps` ARRAYS are copied);
  * the frames' input arrays, the output buffers and `out_lens` / `status` belong to the call until uvol_sync(ctx) returns, which
  * reports the first failing call (its message through uvol_last_error).  Calls enqueued on one ctx run in order; a blocking entry
@@ -208,6 +217,10 @@ typedef struct uvol_decoded_mesh {
 int uvol_drc_info(const uint8_t *drc, size_t len, uint32_t *n_faces, uint32_t *max_values);
 /* n frames, one kernel launch per stage; status[i] per frame (may be NULL) */
 int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
+/* Same with the buffers of `out` in HBM (device pointers): the decoded arrays stay on the device - what a GPU-resident consumer
+ * (a renderer's vertex buffers, or uvol_encode_mesh_batch_dev[_out] re-encoding them) reads without a host round trip.  The .drc
+ * files themselves are host memory; counts come back in `out`. */
+int uvol_decode_mesh_batch_dev(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
 
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */

@@ -131,6 +131,45 @@ def test_hipemu_enqueue_form_of_the_abi(oracle, hipemu_lib):
     c2.close()
 
 
+def test_hipemu_gpu_resident_decode_then_encode(oracle, hipemu_lib):
+    """SURVEY 8(b) / VERDICT r3 #9: the forms a GPU-resident caller chains without a host copy - uvol_decode_mesh_batch_dev leaves the
+    decoded arrays in caller-owned device buffers, uvol_encode_mesh_batch_dev_out reads device arrays and leaves the .drc bitstreams in
+    a caller-owned device buffer (offsets / lengths to the host).  (In the emulation device memory is host memory, so the buffers are
+    numpy arrays; tests/test_gpu_geom.py runs the same chain on HBM.)  Re-encoding the decoded arrays gives the oracle's bytes for
+    them; a buffer that is too small fails the frames that do not fit, alone."""
+    import ctypes as C, synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    src = [synth.torus_mesh(16, 8), synth.sphere_mesh(24, 13, charts=(3, 2)), synth.grid_mesh()]
+    files = cd.encode_mesh_batch(src)
+    n = len(files)
+    metas = (uvol.DecodedMesh * n)(); bufs = []
+    for i, f in enumerate(files):
+        nf, mv = cd.drc_info(f)
+        a = dict(pos=np.zeros((mv, 3), np.float32), uv=np.zeros((mv, 2), np.float32), nrm=np.zeros((mv, 3), np.float32),
+                 idx_pos=np.zeros(3 * nf, np.uint32), idx_uv=np.zeros(3 * nf, np.uint32), idx_nrm=np.zeros(3 * nf, np.uint32))
+        bufs.append(a); metas[i].cap_faces = nf; metas[i].cap_values = mv
+        for k, v in a.items():
+            setattr(metas[i], k, v.ctypes.data)
+    assert cd.decode_mesh_batch_dev(files, metas) == [0] * n
+    meshes = (uvol.Mesh * n)(); host = []
+    for i in range(n):
+        m, a, mm = metas[i], bufs[i], meshes[i]
+        mm.pos, mm.n_pos, mm.uv, mm.n_uv, mm.nrm, mm.n_nrm = m.pos, m.n_pos, m.uv, m.n_uv, m.nrm, m.n_nrm
+        mm.idx_pos, mm.idx_uv, mm.idx_nrm, mm.n_faces = m.idx_pos, m.idx_uv, m.idx_nrm, m.n_faces
+        host.append(dict(pos=a["pos"][:m.n_pos], idx_pos=a["idx_pos"], uv=a["uv"][:m.n_uv], idx_uv=a["idx_uv"], nrm=a["nrm"][:m.n_nrm], idx_nrm=a["idx_nrm"]))
+    out = np.zeros(1 << 20, np.uint8)
+    offs, lens, st = cd.encode_mesh_batch_dev_out(meshes, out.ctypes.data, out.size)
+    assert st == [0] * n
+    for i in range(n):
+        h = host[i]
+        assert out[offs[i]:offs[i] + lens[i]].tobytes() == oracle.drc_encode(h["pos"], h["idx_pos"], h["uv"], h["idx_uv"], h["nrm"], h["idx_nrm"])
+    assert all(offs[i] + lens[i] <= offs[i + 1] for i in range(n - 1))
+    small = np.zeros(lens[0] + lens[1] + 64, np.uint8)                       # room for two of the three
+    offs2, lens2, st2 = cd.encode_mesh_batch_dev_out(meshes, small.ctypes.data, small.size)
+    assert st2[0] == 0 and st2[1] == 0 and st2[2] != 0 and small[offs2[1]:offs2[1] + lens2[1]].tobytes() == out[offs[1]:offs[1] + lens[1]].tobytes()
+    cd.close()
+
+
 def test_hipemu_call_spread_over_lanes(oracle, hipemu_lib):
     """Round 4: a call is cut into groups that run on different lanes (own streams, workspaces, output areas), consecutive enqueued
     calls overlap (a lane's group completes when a later call needs the lane, or at uvol_sync).  With UVOL_GEO_MIN_GROUP=2 a 9-frame

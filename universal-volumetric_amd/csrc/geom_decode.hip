@@ -1025,11 +1025,11 @@ static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base, bool r8, bool f
   return P.total;
 }
 
-static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool full);
-int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
-  return geo_decode_batch_impl(ctx, files, lens, n, out, status, false);
+static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool full, bool out_dev);
+int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool outputs_on_device) {
+  return geo_decode_batch_impl(ctx, files, lens, n, out, status, false, outputs_on_device);
 }
-static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool full) {
+static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool full, bool out_dev) {
   GeoDecState *T = ctx->geodec;
   if (n <= 0) return UVOL_OK;
   T->hjobs.assign((size_t)n, GeoDecJob{}); T->hg.assign((size_t)n, GeoJob{});
@@ -1111,15 +1111,16 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
     for (int k = 0; k < 3; k++) {
       *cnt[k] = J.o_n[k];
       if (!J.o_n[k]) continue;
-      if (vals[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(vals[k], J.o_val[k], (size_t)J.o_n[k] * comps[k] * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (idx[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(idx[k], J.o_idx[k], (size_t)J.nf * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+      const hipMemcpyKind kind = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;      // (uvol_decode_mesh_batch_dev: the arrays stay in HBM)
+      if (vals[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(vals[k], J.o_val[k], (size_t)J.o_n[k] * comps[k] * 4, kind, ctx->stream));
+      if (idx[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(idx[k], J.o_idx[k], (size_t)J.nf * 3 * 4, kind, ctx->stream));
     }
   }
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
   for (int i : retry) {                                   // frames the compact workspace could not hold (more entries per face than usual)
     int st1 = UVOL_OK;
-    const int rc1 = geo_decode_batch_impl(ctx, files + i, lens + i, 1, out + i, &st1, true);
+    const int rc1 = geo_decode_batch_impl(ctx, files + i, lens + i, 1, out + i, &st1, true, out_dev);
     if (rc1 != UVOL_OK) return rc1;
     if (status) status[i] = st1;
     if (st1 != UVOL_OK) worst = st1;

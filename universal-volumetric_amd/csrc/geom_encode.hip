@@ -3011,6 +3011,8 @@ struct GeoLane {
   bool busy = false, on_device = false, full = false;
   std::vector<uvol_mesh> meshes; std::vector<uint8_t *> outp; std::vector<size_t> caps;
   size_t *out_lens = nullptr; int *status = nullptr; int n = 0, n_conc = 0;
+  // GPU-resident form (uvol_encode_mesh_batch_dev_out): the packed output area is the CALLER's device buffer and the payload is not copied out
+  uint8_t *ext_out = nullptr; size_t ext_cap = 0; size_t *ext_offs = nullptr; hipStream_t producer = nullptr; hipEvent_t ev_prod = nullptr;
   std::chrono::steady_clock::time_point t_enter; double t_prep = 0, t_enq = 0;
 };
 struct GeoState {
@@ -3026,7 +3028,7 @@ static void geo_lane_free(GeoLane *L) {
   if (L->own_stream && L->stream) { (void)hipStreamSynchronize(L->stream); (void)hipStreamDestroy(L->stream); }
   for (uvol_devbuf *b : { &L->slab, &L->inputs, &L->jobs, &L->outs }) if (b->p) (void)hipFree(b->p);
   if (L->pinned) (void)hipHostFree(L->pinned);
-  for (hipEvent_t e : { L->ev_walk, L->ev_val, L->ev_fe }) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : { L->ev_walk, L->ev_val, L->ev_fe, L->ev_prod }) if (e) (void)hipEventDestroy(e);
   if (L->counts) (void)hipFree(L->counts);
   delete L;
 }
@@ -3503,7 +3505,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     if ((rc = uvol_ensure(ctx, L.slab, ws_total))) return rc;
   }
   if ((rc = uvol_ensure(ctx, L.jobs, sizeof(GeoJob) * (size_t)n))) return rc;
-  if ((rc = uvol_ensure(ctx, L.outs, out_total))) return rc;
+  if (!L.ext_out && (rc = uvol_ensure(ctx, L.outs, out_total))) return rc;
   if (!on_device && (rc = uvol_ensure(ctx, L.inputs, in_total))) return rc;
   std::vector<UvolUpItem> ups; if (!on_device) ups.reserve((size_t)n * 6);
   for (int i = 0; i < n; i++) {
@@ -3511,7 +3513,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uint8_t *base = (uint8_t *)L.slab.p + ws_off[i];
     (void)layout_job(J, base, full, fmt0, fmtT, G->plan, G->items);
     J.ws_base = base; J.ws_zero = zero_sz[i];          // cleared by ONE k_job_clear launch for the whole batch (was 2 memsets per frame)
-    J.out_pack = (uint8_t *)L.outs.p; J.slab_cap = out_total;
+    if (L.ext_out) { J.out_pack = L.ext_out; J.slab_cap = L.ext_cap; } else { J.out_pack = (uint8_t *)L.outs.p; J.slab_cap = out_total; }
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
     else {
       uint8_t *ib = (uint8_t *)L.inputs.p + in_off[i]; size_t o = 0;
@@ -3537,6 +3539,11 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   GeoJob *dj = (GeoJob *)L.jobs.p;
   const unsigned N = (unsigned)n, NC = (unsigned)std::max(n, n_conc);      // NC: frames on the chip together (all groups of the call)
   L.t_prep = ms_since(t_enter);
+  if (L.producer) {                                        // the inputs are produced on the caller's stream: ordered after what it holds now, no host wait
+    if (!L.ev_prod) UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_prod, hipEventDisableTiming));
+    UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_prod, L.producer));
+    UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, L.ev_prod, 0));
+  }
   // The front ends (dedup, corner table: streaming kernels that fill the chip) of consecutive groups run one after the other, so that a
   // group's front end meets the WALKERS of the groups before it - latency-bound, a few hundred waves - instead of their front ends:
   // each group then gets through its bandwidth-bound phases at close to the chip's full rate and the groups stay staggered.
@@ -3753,6 +3760,7 @@ static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
   // one device-to-host copy of the packed bitstreams into pinned staging, then plain memcpy into the caller's buffers
   size_t packed = 0;
   for (int i = 0; i < n; i++) { const GeoJob &J = L.hjobs[i]; if (J.status == 0) packed = std::max<size_t>(packed, (size_t)J.out_pack_off + J.out_len); }
+  if (L.ext_out) packed = 0;                               // GPU-resident form: the bitstreams stay where k_gather put them
   if (packed > L.pinned_cap) {
     if (L.pinned) (void)hipHostFree(L.pinned);
     L.pinned = nullptr; L.pinned_cap = 0;
@@ -3768,13 +3776,14 @@ static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
   std::vector<int> retry;
   // staging -> the caller's buffers: a few host threads for large batches (2160 frames x 250 KB took ~60 ms of one core per batch)
   { const int nt = packed > ((size_t)32 << 20) ? 8 : 1;
-    auto copy_range = [&](int a, int b) { for (int i = a; i < b; i++) { const GeoJob &J = L.hjobs[i]; if (J.status == 0) memcpy(outs[i], L.pinned + J.out_pack_off, J.out_len); } };
+    auto copy_range = [&](int a, int b) { for (int i = a; i < b; i++) { const GeoJob &J = L.hjobs[i]; if (J.status == 0 && !L.ext_out) memcpy(outs[i], L.pinned + J.out_pack_off, J.out_len); } };
     if (nt == 1) copy_range(0, n);
     else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(copy_range, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); for (auto &x : th) x.join(); } }
   for (int i = 0; i < n; i++) {
     const GeoJob &J = L.hjobs[i];
     int st = J.status == 0 ? UVOL_OK : (J.status == UVOL_E_NOSPACE ? UVOL_E_NOSPACE : UVOL_E_ENCODE);
     out_lens[i] = J.out_len;
+    if (L.ext_offs) L.ext_offs[i] = (size_t)J.out_pack_off;
     if (st == UVOL_OK) { }
     else if (!full && (J.status == GEO_E_WS_OVERFLOW || J.status == GEO_E_SLAB_FULL || J.status == GEO_E_DD_OVERFLOW)) { retry.push_back(i); st = UVOL_OK; }
     else { ctx->set_error("mesh %d: encode failed (device status %d)", i, J.status); worst = st; }
@@ -3784,11 +3793,20 @@ static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
   if (!retry.empty()) {
     // the lane's own record of the group is replaced by the one-frame retries: keep what is still needed
     const std::vector<uvol_mesh> rm(L.meshes); const std::vector<uint8_t *> ro(L.outp); const std::vector<size_t> rcap(L.caps);
+    // GPU-resident form: a retried frame goes behind the frames already packed into the caller's buffer
+    uint8_t *const ext0 = L.ext_out; const size_t ext_cap0 = L.ext_cap; size_t *const offs0 = L.ext_offs; size_t tail = 0;
+    if (ext0) for (int i = 0; i < n; i++) { const GeoJob &J = L.hjobs[i]; if (J.status == 0) tail = std::max<size_t>(tail, ((size_t)J.out_pack_off + J.out_len + 255) & ~(size_t)255); }
     for (int i : retry) {
       if (timing) fprintf(stderr, "[uvol-timing] mesh %d: re-encoding with worst-case workspace\n", i);
       int st1 = UVOL_OK;
-      int rc1 = geo_submit(ctx, L, &rm[i], 1, 1, on_device, &ro[i], &rcap[i], out_lens + i, &st1, true);
+      if (ext0) {
+        if (tail >= ext_cap0) { if (status) status[i] = UVOL_E_NOSPACE; worst = UVOL_E_NOSPACE; out_lens[i] = 0; continue; }
+        L.ext_out = ext0 + tail; L.ext_cap = ext_cap0 - tail; L.ext_offs = nullptr; L.producer = nullptr;
+      }
+      size_t cap1 = ext0 ? std::min<size_t>(ext_cap0 - tail, 0xffffffffu) : rcap[i];
+      int rc1 = geo_submit(ctx, L, &rm[i], 1, 1, on_device, &ro[i], &cap1, out_lens + i, &st1, true);
       if (rc1 == UVOL_OK) rc1 = geo_complete(ctx, L);
+      if (ext0) { L.ext_out = ext0; L.ext_cap = ext_cap0; L.ext_offs = offs0; if (offs0) offs0[i] = tail; if (rc1 == UVOL_OK && st1 == UVOL_OK) tail = (tail + out_lens[i] + 255) & ~(size_t)255; }
       if (rc1 != UVOL_OK) return rc1;
       if (status) status[i] = st1;
       if (st1 != UVOL_OK) worst = st1;
@@ -3848,7 +3866,8 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
                            uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool split) {
   GeoState *G = ctx->geo;
   if (n <= 0) return UVOL_OK;
-  const int want = geo_lanes_wanted();
+  // host inputs: four groups at least (a group uploads while the groups before it encode; the first group's upload is the only one nothing hides)
+  const int want = on_device ? geo_lanes_wanted() : std::max(geo_lanes_wanted(), 4);
   static const int split_env = [] { const char *e = getenv("UVOL_GEO_SPLIT"); return e ? atoi(e) : -1; }();      // tests / diagnostic: 1 / 0 force / forbid the split
   if (split_env >= 0) split = split_env != 0;
   const int groups = split ? std::max(1, std::min(want, n / geo_min_group())) : 1;
@@ -3863,6 +3882,20 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
     if (rc != UVOL_OK) return rc;
   }
   return UVOL_OK;
+}
+// GPU-resident form: one group on lane 0 (the packed output area is one caller buffer), ordered after `producer`
+int geo_encode_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, hipStream_t producer, uint8_t *dev_out, size_t dev_cap, size_t *out_offs, size_t *out_lens, int *status) {
+  if (n <= 0) return UVOL_OK;
+  int rf = geo_flush(ctx);                                 // nothing else of this context in flight
+  GeoLane *L = geo_lane(ctx, 0);
+  if (!L) { ctx->set_error("geometry lane: stream / event creation failed"); return UVOL_E_HIP; }
+  std::vector<uint8_t *> outs((size_t)n, nullptr); std::vector<size_t> caps((size_t)n, std::min<size_t>(dev_cap, 0xffffffffu));
+  L->ext_out = dev_out; L->ext_cap = dev_cap; L->ext_offs = out_offs; L->producer = producer;
+  int rc = geo_submit(ctx, *L, meshes, n, n, true, outs.data(), caps.data(), out_lens, status, false);
+  if (rc == UVOL_OK) rc = geo_complete(ctx, *L);
+  L->ext_out = nullptr; L->ext_cap = 0; L->ext_offs = nullptr; L->producer = nullptr;
+  ctx->resolve_profile();
+  return rf != UVOL_OK ? rf : rc;
 }
 // blocking form: begin + flush
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,

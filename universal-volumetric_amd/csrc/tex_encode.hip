@@ -1066,21 +1066,28 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tex_pack(TexJob *job, uint8_t *p
   }
 }
 
-struct TexState {
+// A lane = the buffers and the stream of one batch of segments in flight.  A call on HOST inputs is cut into parts that alternate between
+// the two lanes, so that the layers of part k + 1 cross PCIe (its lane's stream) while the kernels of part k run (tex_encode_segments);
+// device inputs use lane 0 = the context's stream only.
+struct TexLane {
+  hipStream_t stream = nullptr; bool own_stream = false;
   uvol_devbuf slab, layers, job, packed;
   std::vector<TexJob> hjobs;
   uint8_t *pinned = nullptr; size_t pinned_cap = 0;
+  // the part in flight (tex_submit ... tex_finish)
+  int n_seg = 0, n_layers = 0, alpha = 0; uint32_t W = 0, H = 0;
+  uint8_t *const *outs = nullptr; const size_t *caps = nullptr; size_t *out_lens = nullptr;
 };
-int tex_create(uvol_ctx *ctx) { ctx->tex = new TexState(); return UVOL_OK; }
+struct TexState { TexLane lane[2]; };
+int tex_create(uvol_ctx *ctx) { ctx->tex = new TexState(); ctx->tex->lane[0].stream = ctx->stream; return UVOL_OK; }
 void tex_destroy(uvol_ctx *ctx) {
   if (!ctx->tex) return;
-  TexState *t = ctx->tex;
-  if (t->slab.p) (void)hipFree(t->slab.p);
-  if (t->packed.p) (void)hipFree(t->packed.p);
-  if (t->pinned) (void)hipHostFree(t->pinned);
-  if (t->layers.p) (void)hipFree(t->layers.p);
-  if (t->job.p) (void)hipFree(t->job.p);
-  delete t; ctx->tex = nullptr;
+  for (TexLane &t : ctx->tex->lane) {
+    if (t.own_stream && t.stream) { (void)hipStreamSynchronize(t.stream); (void)hipStreamDestroy(t.stream); }
+    for (uvol_devbuf *b : { &t.slab, &t.packed, &t.layers, &t.job }) if (b->p) (void)hipFree(b->p);
+    if (t.pinned) (void)hipHostFree(t.pinned);
+  }
+  delete ctx->tex; ctx->tex = nullptr;
 }
 size_t uvol_texture_bound(uint32_t w, uint32_t h, int n) {
   const size_t nb = (size_t)((w + 3) / 4) * ((h + 3) / 4);
@@ -1207,9 +1214,10 @@ static void run_sel_rounds(uvol_ctx *ctx, TexJob *dj, const TexJob &J, unsigned 
 // player reads them, src/lib/KTX2Loader.js:493-497).  Called with alpha = 0 first; segments whose images turn out to have alpha
 // (k_tex_skip sees every texel anyway) come back with TEX_E_ALPHA and are encoded again here with alpha = 1 - opaque
 // content, the common case, pays nothing for the feature.
-static int tex_encode_segments_impl(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
-                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha) {
-  TexState *T = ctx->tex;
+// first half: buffers, upload of host layers, every kernel of the batch enqueued on ctx->stream (= the lane's stream, tex_run_lane)
+static int tex_submit_impl(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
+                           bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha) {
+  L.n_seg = n_seg; L.n_layers = n_layers; L.alpha = alpha; L.W = W; L.H = H; L.outs = outs; L.caps = caps; L.out_lens = out_lens;
   if (n_seg <= 0) return UVOL_OK;
   if ((n_layers << alpha) > TEX_MAX_LAYERS || W > 16384 || H > 16384 || n_seg > 65535) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }
   const unsigned NSEG = (unsigned)n_seg;
@@ -1223,25 +1231,25 @@ static int tex_encode_segments_impl(uvol_ctx *ctx, const uint8_t *const *rgba, i
   size_t zero_bytes = 0; const size_t ws = tex_layout(J0, nullptr, &zero_bytes);
   const size_t lbytes = (size_t)W * H * 4;
   int rc;
-  if ((rc = uvol_ensure(ctx, T->slab, ws * (size_t)n_seg))) return rc;
-  if ((rc = uvol_ensure(ctx, T->job, sizeof(TexJob) * (size_t)n_seg))) return rc;
-  if (!on_device && (rc = uvol_ensure(ctx, T->layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
-  T->hjobs.assign((size_t)n_seg, J0);
+  if ((rc = uvol_ensure(ctx, L.slab, ws * (size_t)n_seg))) return rc;
+  if ((rc = uvol_ensure(ctx, L.job, sizeof(TexJob) * (size_t)n_seg))) return rc;
+  if (!on_device && (rc = uvol_ensure(ctx, L.layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
+  L.hjobs.assign((size_t)n_seg, J0);
   std::vector<UvolUpItem> ups;                                           // host layers: one staged upload for the whole batch
   for (int s = 0; s < n_seg; s++) {
-    TexJob &J = T->hjobs[s];
-    uint8_t *base = (uint8_t *)T->slab.p + ws * (size_t)s;
+    TexJob &J = L.hjobs[s];
+    uint8_t *base = (uint8_t *)L.slab.p + ws * (size_t)s;
     tex_layout(J, base, &zero_bytes);
     UVOL_HIP_CHECK(ctx, hipMemsetAsync(base, 0, zero_bytes, ctx->stream));
     for (int l = 0; l < n_layers; l++) {
       const uint8_t *src = rgba[(size_t)s * n_layers + l];
       if (on_device) J.layer[l] = src;
-      else { uint8_t *d = (uint8_t *)T->layers.p + lbytes * ((size_t)s * n_layers + l); ups.push_back(UvolUpItem{ lbytes * ((size_t)s * n_layers + l), src, lbytes }); J.layer[l] = d; }
+      else { uint8_t *d = (uint8_t *)L.layers.p + lbytes * ((size_t)s * n_layers + l); ups.push_back(UvolUpItem{ lbytes * ((size_t)s * n_layers + l), src, lbytes }); J.layer[l] = d; }
     }
   }
-  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)T->layers.p, ups); if (rcu != UVOL_OK) return rcu; }
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->job.p, T->hjobs.data(), sizeof(TexJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
-  TexJob *dj = (TexJob *)T->job.p;
+  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.layers.p, ups); if (rcu != UVOL_OK) return rcu; }
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.job.p, L.hjobs.data(), sizeof(TexJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
+  TexJob *dj = (TexJob *)L.job.p;
   const TexJob &J = J0;
   const unsigned bnb = uvol_blocks(J.nb), bNB = uvol_blocks(J.NB), bcell = (1u << 18) / UVOL_BLOCK, bK = uvol_blocks(TEX_MAX_CODEBOOK);
   const uint64_t src_bytes = (uint64_t)lbytes * n_layers * (uint64_t)n_seg;
@@ -1312,38 +1320,45 @@ static int tex_encode_segments_impl(uvol_ctx *ctx, const uint8_t *const *rgba, i
   }
   // packed payloads: sections <= caps, slices <= slice_cap each; the bound below is what the workspace itself can hold
   size_t pack_cap = 0;
-  { const TexJob &Jc = T->hjobs[0]; pack_cap = (((size_t)Jc.sec_cap[0] + Jc.sec_cap[1] + Jc.sec_cap[2] + (size_t)Jc.slice_cap * (size_t)Jc.L) + 15) & ~(size_t)15; }
+  { const TexJob &Jc = L.hjobs[0]; pack_cap = (((size_t)Jc.sec_cap[0] + Jc.sec_cap[1] + Jc.sec_cap[2] + (size_t)Jc.slice_cap * (size_t)Jc.L) + 15) & ~(size_t)15; }
   // typical output is ~1 % of that bound: start from 1/8 of it and grow on demand (checked after the copy of the job records)
-  size_t want_pack = std::max<size_t>(T->packed.cap, pack_cap * (size_t)n_seg / 8 + 4096);
-  if (int rc = uvol_ensure(ctx, T->packed, want_pack)) return rc;
+  size_t want_pack = std::max<size_t>(L.packed.cap, pack_cap * (size_t)n_seg / 8 + 4096);
+  if (int rc = uvol_ensure(ctx, L.packed, want_pack)) return rc;
   { uvol_ctx::Scope sc(ctx, "tex.k13_pack", 0);
     hipLaunchKernelGGL(k_tex_pack_offsets, dim3(1), dim3(64), 0, ctx->stream, dj, n_seg);
-    TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)T->packed.p, (unsigned long long)T->packed.cap); }
+    TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)L.packed.p, (unsigned long long)L.packed.cap); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
-  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexJob) * (size_t)n_seg, hipMemcpyDeviceToHost, ctx->stream));
+  return UVOL_OK;
+}
+// second half: waits for the lane's stream, reads the job records and the packed payloads back, writes the KTX2 containers
+static int tex_finish_impl(uvol_ctx *ctx, TexLane &L) {
+  const int n_seg = L.n_seg, n_layers = L.n_layers, alpha = L.alpha; const uint32_t W = L.W, H = L.H;
+  uint8_t *const *outs = L.outs; const size_t *caps = L.caps; size_t *out_lens = L.out_lens;
+  if (n_seg <= 0) return UVOL_OK;
+  TexJob *dj = (TexJob *)L.job.p; const unsigned NSEG = (unsigned)n_seg;
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipMemcpy(L.hjobs.data(), dj, sizeof(TexJob) * (size_t)n_seg, hipMemcpyDeviceToHost));
   if (ctx->profiling) {            // matrix-core work of the two k_sel_assign launches: items x entries (padded to tiles of 16) x 64-long dot x 2 planes x 2 ops
     uint64_t ops = 0;
-    for (int s = 0; s < n_seg; s++) { const TexVQ &V = T->hjobs[s].vq[1]; ops += 2ull * (uint64_t)V.n_items * (uint64_t)((V.nl + 15u) & ~15u) * 64ull * 2ull * 2ull; }
+    for (int s = 0; s < n_seg; s++) { const TexVQ &V = L.hjobs[s].vq[1]; ops += 2ull * (uint64_t)V.n_items * (uint64_t)((V.nl + 15u) & ~15u) * 64ull * 2ull * 2ull; }
     ctx->prof[ctx->prof_index("tex.k10_sel_assign")].algo_bytes += ops;
   }
   size_t packed_total = 0;
-  for (int s = 0; s < n_seg; s++) packed_total = std::max<size_t>(packed_total, (size_t)(T->hjobs[s].pack_off + ((T->hjobs[s].pack_len + 15ull) & ~15ull)));
-  if (packed_total > T->packed.cap) {                                  // rare: grow and gather again
-    if (int rc = uvol_ensure(ctx, T->packed, packed_total)) return rc;
-    TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)T->packed.p, (unsigned long long)T->packed.cap);
+  for (int s = 0; s < n_seg; s++) packed_total = std::max<size_t>(packed_total, (size_t)(L.hjobs[s].pack_off + ((L.hjobs[s].pack_len + 15ull) & ~15ull)));
+  if (packed_total > L.packed.cap) {                                  // rare: grow and gather again
+    if (int rc = uvol_ensure(ctx, L.packed, packed_total)) return rc;
+    TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)L.packed.p, (unsigned long long)L.packed.cap);
     UVOL_HIP_CHECK(ctx, hipGetLastError());
   }
-  if (packed_total > T->pinned_cap) {
-    if (T->pinned) (void)hipHostFree(T->pinned);
-    T->pinned = nullptr; T->pinned_cap = 0;
+  if (packed_total > L.pinned_cap) {
+    if (L.pinned) (void)hipHostFree(L.pinned);
+    L.pinned = nullptr; L.pinned_cap = 0;
     const size_t want = packed_total + packed_total / 4 + 4096;
-    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&T->pinned, want, hipHostMallocDefault));
-    T->pinned_cap = want;
+    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&L.pinned, want, hipHostMallocDefault));
+    L.pinned_cap = want;
   }
-  if (packed_total) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->pinned, T->packed.p, packed_total, hipMemcpyDeviceToHost, ctx->stream));
+  if (packed_total) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.pinned, L.packed.p, packed_total, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->resolve_profile();
   // ---- K13: KTX2 containers ----
   static const uint8_t ident[12] = { 0xAB, 'K', 'T', 'X', ' ', '2', '0', 0xBB, '\r', '\n', 0x1A, '\n' };
   static const char writer[] = "uvol-mi355x etc1s 0.1";
@@ -1356,7 +1371,7 @@ static int tex_encode_segments_impl(uvol_ctx *ctx, const uint8_t *const *rgba, i
   const uint64_t sgd_off = ((uint64_t)kvd_off + kvd_len + 7) & ~7ull;
   int worst = UVOL_OK;
   for (int s = 0; s < n_seg; s++) {
-    const TexJob &R = T->hjobs[s];
+    const TexJob &R = L.hjobs[s];
     if (R.status == TEX_E_ALPHA && !alpha) { out_lens[s] = TEX_RETRY_ALPHA; continue; }                    // encoded again with alpha slices by the caller
     if (R.status != 0) { ctx->set_error("texture segment %d: device status %d", s, R.status); worst = UVOL_E_ENCODE; out_lens[s] = 0; continue; }
     const uint64_t sgd_len = 20 + 20 * (uint64_t)n_layers + R.sec_len[0] + R.sec_len[1] + R.sec_len[2];
@@ -1382,24 +1397,67 @@ static int tex_encode_segments_impl(uvol_ctx *ctx, const uint8_t *const *rgba, i
         const uint32_t c = R.slice_len[l << alpha], a = alpha ? R.slice_len[(l << alpha) + 1] : 0u;
         put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, c); put32(p, alpha ? off + c : 0u); put32(p, a); off += c + a; } }
     if (R.pack_len != sgd_len - 20 - 20 * (uint64_t)n_layers + lvl_len) { ctx->set_error("texture segment %d: packed payload length mismatch", s); worst = UVOL_E_ENCODE; continue; }
-    memcpy(p, T->pinned + R.pack_off, (size_t)R.pack_len);            // sections then slices, already in container order
+    memcpy(p, L.pinned + R.pack_off, (size_t)R.pack_len);            // sections then slices, already in container order
   }
   return worst;
 }
+// the lane's stream stands in for the context's while one of its halves runs (TLAUNCH, Scope, uvol_ensure, uvol_upload_staged use ctx->stream)
+static int tex_submit(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
+                      bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha) {
+  hipStream_t saved = ctx->stream; ctx->stream = L.stream;
+  const int rc = tex_submit_impl(ctx, L, rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, alpha);
+  ctx->stream = saved; return rc;
+}
+// finish + the second pass of the segments that turned out to have alpha (one more batch on the same lane; host layers were uploaded
+// by the first pass and are read where they lie)
+static int tex_finish(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, bool on_device) {
+  hipStream_t saved = ctx->stream; ctx->stream = L.stream;
+  const int n_seg = L.n_seg, n_layers = L.n_layers; uint8_t *const *outs = L.outs; const size_t *caps = L.caps; size_t *out_lens = L.out_lens; const uint32_t W = L.W, H = L.H;
+  int rc = tex_finish_impl(ctx, L);
+  std::vector<int> again;
+  for (int s = 0; s < n_seg; s++) if (out_lens[s] == TEX_RETRY_ALPHA) { again.push_back(s); out_lens[s] = 0; }
+  if (!again.empty() && (rc == UVOL_OK || rc == UVOL_E_NOSPACE || rc == UVOL_E_ENCODE)) {
+    std::vector<const uint8_t *> src; std::vector<uint8_t *> o2; std::vector<size_t> c2, l2(again.size(), 0);
+    for (int s : again) { for (int l = 0; l < n_layers; l++) src.push_back(on_device ? rgba[(size_t)s * n_layers + l] : L.hjobs[s].layer[l]); o2.push_back(outs[s]); c2.push_back(caps[s]); }
+    int rc2 = tex_submit_impl(ctx, L, src.data(), (int)again.size(), n_layers, W, H, true, o2.data(), c2.data(), l2.data(), 1);
+    if (rc2 == UVOL_OK) rc2 = tex_finish_impl(ctx, L);
+    for (size_t i = 0; i < again.size(); i++) out_lens[again[i]] = l2[i];
+    if (rc == UVOL_OK) rc = rc2;
+  }
+  ctx->stream = saved; return rc;
+}
+// segments per part of a call on host inputs (UVOL_TEX_PART, tests: small values cut small calls too; 0 = never cut)
+static inline int tex_part_segments() { static const int v = [] { const char *e = getenv("UVOL_TEX_PART"); const int k = e ? atoi(e) : 24; return k < 0 ? 0 : k; }(); return v; }
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
                         bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
   if (n_seg <= 0) return UVOL_OK;
-  int rc = tex_encode_segments_impl(ctx, rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0);
-  std::vector<int> again;
-  for (int s = 0; s < n_seg; s++) if (out_lens[s] == TEX_RETRY_ALPHA) { again.push_back(s); out_lens[s] = 0; }
-  if (again.empty() || (rc != UVOL_OK && rc != UVOL_E_NOSPACE && rc != UVOL_E_ENCODE)) return rc;
-  // the segments with alpha, as one batch; host inputs were uploaded by the first pass and are read where they lie
   TexState *T = ctx->tex;
-  std::vector<const uint8_t *> src; std::vector<uint8_t *> o2; std::vector<size_t> c2, l2(again.size(), 0);
-  for (int s : again) { for (int l = 0; l < n_layers; l++) src.push_back(on_device ? rgba[(size_t)s * n_layers + l] : T->hjobs[s].layer[l]); o2.push_back(outs[s]); c2.push_back(caps[s]); }
-  const int rc2 = tex_encode_segments_impl(ctx, src.data(), (int)again.size(), n_layers, W, H, true, o2.data(), c2.data(), l2.data(), 1);
-  for (size_t i = 0; i < again.size(); i++) out_lens[again[i]] = l2[i];
-  return rc != UVOL_OK ? rc : rc2;
+  T->lane[0].stream = ctx->stream;
+  const int part = tex_part_segments();
+  int rc = UVOL_OK;
+  if (on_device || part <= 0 || n_seg < 2 * part) {                       // one batch on the context's stream
+    rc = tex_submit(ctx, T->lane[0], rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0);
+    if (rc == UVOL_OK) rc = tex_finish(ctx, T->lane[0], rgba, on_device);
+    ctx->resolve_profile();
+    return rc;
+  }
+  // Host inputs, a large call: parts of >= `part` segments alternate between two lanes.  While the GPU encodes part k this thread stages
+  // part k + 1 through the pinned buffers and its DMAs run on the other lane's stream; then part k's containers are written while part
+  // k + 1 encodes.  16.8 MB per layer cross PCIe: without the overlap a call was upload, then encode, one after the other.
+  if (!T->lane[1].stream) { if (uvol_make_stream(ctx, &T->lane[1].stream) != hipSuccess) { ctx->set_error("texture lane: stream creation failed"); return UVOL_E_HIP; } T->lane[1].own_stream = true; }
+  const int parts = std::max(2, std::min(8, n_seg / part));
+  auto lo = [&](int k) { return (int)((long long)n_seg * k / parts); };
+  int worst = UVOL_OK;
+  for (int k = 0; k <= parts; k++) {
+    if (k < parts) {
+      const int a = lo(k), b = lo(k + 1);
+      const int r = tex_submit(ctx, T->lane[k & 1], rgba + (size_t)a * n_layers, b - a, n_layers, W, H, false, outs + a, caps + a, out_lens + a, 0);
+      if (r != UVOL_OK) { if (k > 0) (void)tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, false); return r; }
+    }
+    if (k > 0) { const int r = tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, false); if (r != UVOL_OK && worst == UVOL_OK) worst = r; }
+  }
+  ctx->resolve_profile();
+  return worst;
 }
 
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t W, uint32_t H,

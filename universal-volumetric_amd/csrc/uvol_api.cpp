@@ -325,6 +325,28 @@ int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_
 }
 
 // (the profile entry points wait for enqueued work first: the worker thread updates the same records)
+int uvol_decode_mesh_batch_dev(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !drc || !lens || n < 0 || !out) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  const int mb = ctx->prm.max_batch;
+  for (int b0 = 0; b0 < n; b0 += mb) {
+    const int nb = n - b0 < mb ? n - b0 : mb;
+    const int rc = geo_decode_batch(ctx, drc + b0, lens + b0, nb, out + b0, status ? status + b0 : nullptr, true);
+    if (rc != UVOL_OK) return rc;
+  }
+  return UVOL_OK;
+}
+
+int uvol_encode_mesh_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, void *producer_stream,
+                                   uint8_t *dev_out, size_t dev_cap, size_t *out_offs, size_t *out_lens, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !meshes || n < 0 || !dev_out || !out_offs || !out_lens) return UVOL_E_INVALID;
+  if (n > ctx->prm.max_batch) { ctx->set_error("uvol_encode_mesh_batch_dev_out: %d frames exceed max_batch %d (one packed output area per call)", n, ctx->prm.max_batch); return UVOL_E_INVALID; }
+  (void)hipSetDevice(ctx->device);
+  return geo_encode_batch_dev_out(ctx, meshes, n, (hipStream_t)producer_stream, dev_out, dev_cap, out_offs, out_lens, status);
+}
+
 int uvol_profile_enable(uvol_ctx *ctx, int on) { if (!ctx) return UVOL_E_INVALID; UVOL_AFTER_ASYNC(ctx); ctx->profiling = on != 0; return UVOL_OK; }
 int uvol_profile_reset(uvol_ctx *ctx) {
   if (!ctx) return UVOL_E_INVALID;

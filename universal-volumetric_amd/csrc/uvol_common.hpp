@@ -222,9 +222,11 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_
 int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_on_device,
                            uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool split);
 int geo_flush(uvol_ctx *ctx);
+// GPU-resident form: one group on lane 0, ordered after `producer`, bitstreams packed into the caller's device buffer
+int geo_encode_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, hipStream_t producer, uint8_t *dev_out, size_t dev_cap, size_t *out_offs, size_t *out_lens, int *status);
 int geodec_create(uvol_ctx *ctx);
 void geodec_destroy(uvol_ctx *ctx);
-int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
+int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool outputs_on_device = false);
 int texdec_create(uvol_ctx *ctx);
 void texdec_destroy(uvol_ctx *ctx);
 int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target);

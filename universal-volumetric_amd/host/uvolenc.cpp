@@ -47,6 +47,9 @@ static void parallel_for_w(size_t n, int nthreads, const std::function<void(size
 static void parallel_for(size_t n, int nthreads, const std::function<void(size_t)> &fn) { parallel_for_w(n, nthreads, [&](size_t k, size_t) { fn(k); }); }
 
 int main(int argc, char **argv) {
+  // one hardware queue per HIP stream (the runtime's default is four per process; streams that share one run one after the other, and a
+  // context holds two per geometry lane plus the texture lanes): read by the runtime when it initialises, i.e. before the first HIP call
+  setenv("GPU_MAX_HW_QUEUES", "24", 0);
   if (argc < 2) { std::printf("❌ Invalid number of arguments. Please supply project-config.json as argument\n"); return 1; }
   if (!std::strcmp(argv[1], "create-template")) {
     const std::string t = config_template();

@@ -36,7 +36,7 @@ class Mesh(C.Structure):
 
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
-           "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
+           "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_dev_out", "uvol_decode_mesh_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
@@ -73,6 +73,8 @@ def load(path=None):
     L.uvol_transcode_texture_segments_astc.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
+    L.uvol_decode_mesh_batch_dev.argtypes = L.uvol_decode_mesh_batch.argtypes
+    L.uvol_encode_mesh_batch_dev_out.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.uvol_profile_reset.argtypes = [C.c_void_p]
     L.uvol_profile_count.argtypes = [C.c_void_p]
@@ -155,6 +157,32 @@ class Codec:
         """meshes: ctypes array of Mesh holding DEVICE pointers (inputs resident in HBM).  views=True: numpy views of this
         codec's output buffers instead of `bytes` copies (valid until the next call; no 250 KB copy per frame in Python)."""
         return self._run_batch(self.L.uvol_encode_mesh_batch_dev, meshes, len(meshes), raise_on_error, views)
+
+    def encode_mesh_batch_dev_out(self, meshes, dev_out, dev_cap, producer_stream=None):
+        """GPU-resident form: `meshes` hold device pointers produced on `producer_stream` (a hipStream_t as an int, None = complete), the
+        .drc bitstreams stay in HBM, packed into the caller's device buffer.  -> (offsets, lengths, statuses) as lists."""
+        n = len(meshes)
+        offs = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)()
+        rc = self.L.uvol_encode_mesh_batch_dev_out(self.h, meshes, n, C.c_void_p(producer_stream or 0), C.c_void_p(int(dev_out)), int(dev_cap), offs, lens, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_mesh_batch_dev_out rc={rc}: {self.error()}")
+        return list(offs), list(lens), list(st)
+
+    def decode_mesh_batch_dev(self, files, metas):
+        """files: list of .drc bytes; metas: ctypes array of DecodedMesh whose buffers are DEVICE pointers (capacities filled in by the
+        caller, see uvol_drc_info): the decoded arrays stay in HBM, the counts come back in `metas`.  -> list of statuses."""
+        files = [bytes(f) for f in files]; n = len(files)
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files]); st = (C.c_int * n)()
+        rc = self.L.uvol_decode_mesh_batch_dev(self.h, fp, ln, n, metas, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"decode_mesh_batch_dev rc={rc}: {self.error()}")
+        return list(st)
+
+    def drc_info(self, data):
+        nf, mv = C.c_uint32(), C.c_uint32()
+        if self.L.uvol_drc_info(bytes(data), len(data), C.byref(nf), C.byref(mv)) != UVOL_OK:
+            raise UvolError("not a .drc this decoder handles")
+        return nf.value, mv.value
 
     # ---- enqueue form (uvol_*_async + uvol_sync): start_* record a call, finish() completes all of them in order ----
     def start_mesh_batch(self, frames):
