@@ -3501,6 +3501,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   if ((rc = uvol_ensure(ctx, L.slab, ws_total))) {
     // out of device memory: the workspaces idle lanes still hold from earlier (larger) groups are given back, then once more
     (void)hipGetLastError();
+    for (GeoLane *o : G->lanes) if (o != &L && o->busy) { const int r = geo_complete(ctx, *o); if (r != UVOL_OK && G->deferred_rc == UVOL_OK) G->deferred_rc = r; }      // (their results first)
     for (GeoLane *o : G->lanes) if (o != &L && !o->busy) for (uvol_devbuf *b : { &o->slab, &o->inputs, &o->outs }) if (b->p) { (void)hipStreamSynchronize(o->stream); (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if ((rc = uvol_ensure(ctx, L.slab, ws_total))) return rc;
   }
