@@ -189,6 +189,14 @@ int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *kt
  * weights (endpoint error <= 1, inner colours to the nearest weight); gated by PSNR against the RGBA32 decode, not bit parity. */
 int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                         uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
+/* Files WITH alpha slices (images whose alpha was not 255; reference src/lib/KTX2Loader.js:493-497 reads them): the stock loader asks
+ * such a file for the SECOND format of its table (:672-676) - BC7 with alpha or ETC2 RGBA.  uvol_transcode_texture_segments_bc7 then
+ * writes mode-5 blocks whose alpha endpoints are the alpha block's lowest / highest level (exact) with 2-bit alpha indices;
+ * uvol_transcode_texture_segments_etc2_rgba writes 16-byte ETC2_EAC RGBA8 blocks (EAC alpha block + the exact ETC1 colour re-pack;
+ * opaque files get alpha 255).  Alpha is a re-fit (the basis transcoder's tables are not in the reference): gated by alpha PSNR against
+ * the RGBA32 decode, like the BC7 colour.  The ETC1 target stays opaque-only and refuses a file with alpha slices. */
+int uvol_transcode_texture_segments_etc2_rgba(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                              uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
 
 /* ASTC 4x4 target for UASTC sources (KTX2Loader's first choice for them, reference src/lib/KTX2Loader.js:591-600, :648-689; BASELINE
  * configs[4] "KTX2 -> ASTC"): blocks[s * layers + l] receives ceil(w/4) * ceil(h/4) 16-byte ASTC blocks in raster order.  A direct

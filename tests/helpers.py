@@ -89,6 +89,29 @@ def etc1_decode_blocks(blocks, width, height):
     return out[:height, :width]
 
 
+def eac_alpha_decode_blocks(blocks, width, height):
+    """Independent EAC alpha (ETC2 RGBA8's first 8 bytes) decoder from the public format description: byte 0 base codeword, byte 1
+    multiplier << 4 | table, then 16 x 3-bit indices (pixel i = 4 * x + y, first pixel in the top bits); alpha = clamp(base +
+    multiplier * table[index]).  blocks [by, bx, 8] uint8 -> alpha [height, width] uint8."""
+    T = np.array([[-3, -6, -9, -15, 2, 5, 8, 14], [-3, -7, -10, -13, 2, 6, 9, 12], [-2, -5, -8, -13, 1, 4, 7, 12], [-2, -4, -6, -13, 1, 3, 5, 12],
+                  [-3, -6, -8, -12, 2, 5, 7, 11], [-3, -7, -9, -11, 2, 6, 8, 10], [-4, -7, -8, -11, 3, 6, 7, 10], [-3, -5, -8, -11, 2, 4, 7, 10],
+                  [-2, -6, -8, -10, 1, 5, 7, 9], [-2, -5, -8, -10, 1, 4, 7, 9], [-2, -4, -8, -10, 1, 3, 7, 9], [-2, -5, -7, -10, 1, 4, 6, 9],
+                  [-3, -4, -7, -10, 2, 3, 6, 9], [-1, -2, -3, -10, 0, 1, 2, 9], [-4, -6, -8, -9, 3, 5, 7, 8], [-3, -5, -7, -9, 2, 4, 6, 8]], np.int32)
+    by, bx = blocks.shape[:2]
+    b = blocks.astype(np.int64)
+    base = b[..., 0]; mult = b[..., 1] >> 4; tab = b[..., 1] & 15
+    bits = np.zeros((by, bx), np.int64)
+    for k in range(6):
+        bits = (bits << 8) | b[..., 2 + k]
+    out = np.zeros((by * 4, bx * 4), np.uint8)
+    for x in range(4):
+        for y in range(4):
+            i = 4 * x + y
+            idx = (bits >> (45 - 3 * i)) & 7
+            out[y::4, x::4] = np.clip(base + mult * T[tab, idx], 0, 255).astype(np.uint8)
+    return out[:height, :width]
+
+
 def bc7_decode_blocks(blocks, width, height):
     """Independent BC7 decoder for the two single-subset modes the BC7 transcode target emits (Khronos data-format spec, BPTC):
     mode 5 (7-bit RGB endpoints, 8-bit alpha endpoints, 2-bit colour and alpha indices, rotation) and mode 6 (7-bit RGBA

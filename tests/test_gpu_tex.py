@@ -54,8 +54,12 @@ def test_gpu_etc1s_alpha_slices(oracle, gpu_codec):
         assert np.array_equal(dec[l], d.images[l]), l
     with pytest.raises(Exception, match="alpha"):
         gpu_codec.transcode_texture_segments_etc1([want_a])
+    # the targets the stock loader picks for a file with alpha (KTX2Loader.js:672-676): ETC2 RGBA and BC7 with alpha, at 256^2 and 2048^2
+    from test_hipemu_tex import _check_alpha_targets
+    _check_alpha_targets(oracle, gpu_codec, want_a)
     big = _alpha_sequence(2, 2048, 4)
     f = gpu_codec.encode_texture_segment(big)
+    _check_alpha_targets(oracle, gpu_codec, f)
     dec = gpu_codec.decode_texture_segments([f])[0]
     for l in range(2):
         src = big[l][::-1].astype(np.float64); err = dec[l].astype(np.float64) - src

@@ -378,6 +378,68 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_etc1(TexDecJob *jobs) {
   out[4] = (uint8_t)(msb >> 8); out[5] = (uint8_t)msb; out[6] = (uint8_t)(lsb >> 8); out[7] = (uint8_t)lsb;
 }
 
+// ---- K3'b: ETC2 RGBA target (ETC2_EAC RGBA8: what the stock loader asks an ETC1S file WITH alpha for on ETC2 hardware,
+// src/lib/KTX2Loader.js:672-676 transcoderFormat[1]).  16 bytes per block: an EAC alpha block, then the colour block - the same exact
+// ETC1 re-pack as above (a differential block with zero deltas is a valid ETC2 block).  The alpha block of the alpha slice has four
+// levels abase + {-a, -b, +b, +a} (green channel, clamped); EAC alpha is base + multiplier * table[j], eight levels out of 16 tables:
+// every (table, multiplier 1..15) is tried with five base values around the middle of the levels, each level takes its nearest EAC
+// level, the error is summed over the 16 pixels, the first best (table, multiplier, base ascending) wins.  Not a restatement of the
+// basis transcoder's table-driven path (its tables are not in the reference): gated by alpha PSNR against the RGBA32 decode.
+// Alpha block bytes: base, multiplier << 4 | table, then 16 x 3-bit indices, pixel i = 4 * x + y, first pixel in the top bits.
+__device__ const int8_t EAC_MOD[16][8] = {
+  { -3, -6, -9, -15, 2, 5, 8, 14 }, { -3, -7, -10, -13, 2, 6, 9, 12 }, { -2, -5, -8, -13, 1, 4, 7, 12 }, { -2, -4, -6, -13, 1, 3, 5, 12 },
+  { -3, -6, -8, -12, 2, 5, 7, 11 }, { -3, -7, -9, -11, 2, 6, 8, 10 }, { -4, -7, -8, -11, 3, 6, 7, 10 }, { -3, -5, -8, -11, 2, 4, 7, 10 },
+  { -2, -6, -8, -10, 1, 5, 7, 9 }, { -2, -5, -8, -10, 1, 4, 7, 9 }, { -2, -4, -8, -10, 1, 3, 7, 9 }, { -2, -5, -7, -10, 1, 4, 6, 9 },
+  { -3, -4, -7, -10, 2, 3, 6, 9 }, { -1, -2, -3, -10, 0, 1, 2, 9 }, { -4, -6, -8, -9, 3, 5, 7, 8 }, { -3, -5, -7, -9, 2, 4, 6, 8 } };
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_etc2a(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.z];
+  if (J.status != 0) return;
+  const uint32_t layer = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (layer >= J.layers || b >= J.bx * J.by) return;
+  const size_t nbk = (size_t)J.bx * J.by, o = (size_t)(layer << J.ashift) * nbk + b;
+  const int INTEN[8][4] = { {-8, -2, 2, 8}, {-17, -5, 5, 17}, {-29, -9, 9, 29}, {-42, -13, 13, 42}, {-60, -18, 18, 60}, {-80, -24, 24, 80}, {-106, -33, 33, 106}, {-183, -47, 47, 183} };
+  uint8_t *out = J.out[layer] + 16 * (size_t)b;
+  // ---- alpha half ----
+  int al[4] = { 255, 255, 255, 255 }; uint32_t asel = 0, hist[4] = { 16, 0, 0, 0 };
+  if (J.ashift) {
+    const uint8_t *ae = J.endpoints + 4 * (size_t)J.ei[o + nbk]; asel = J.selectors[J.si[o + nbk]];
+    for (int k = 0; k < 4; k++) { const int v = ((ae[1] << 3) | (ae[1] >> 2)) + INTEN[ae[3] & 7][k]; al[k] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    hist[0] = 0; for (int i = 0; i < 16; i++) hist[(asel >> (2 * i)) & 3u]++;
+  }
+  int lo_l = 255, hi_l = 0;
+  for (int k = 0; k < 4; k++) if (hist[k]) { lo_l = al[k] < lo_l ? al[k] : lo_l; hi_l = al[k] > hi_l ? al[k] : hi_l; }
+  const int mid = (lo_l + hi_l + 1) >> 1;
+  uint32_t best = 0xffffffffu; int bt = 0, bm = 1, bb = mid;
+  for (int t = 0; t < 16 && best; t++) for (int m = 1; m < 16 && best; m++) for (int db = -2; db <= 2; db++) {
+    const int base = mid + db; if (base < 0 || base > 255) continue;
+    uint32_t err = 0;
+    for (int k = 0; k < 4; k++) if (hist[k]) {
+      int be = 1 << 30;
+      for (int j = 0; j < 8; j++) { int v = base + m * EAC_MOD[t][j]; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int d = v - al[k]; be = d * d < be ? d * d : be; }
+      err += hist[k] * (uint32_t)be;
+    }
+    if (err < best) { best = err; bt = t; bm = m; bb = base; }
+  }
+  uint32_t lvl[4];
+  for (int k = 0; k < 4; k++) { int be = 1 << 30; uint32_t bj = 0; for (int j = 0; j < 8; j++) { int v = bb + bm * EAC_MOD[bt][j]; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int d = v - al[k]; if (d * d < be) { be = d * d; bj = (uint32_t)j; } } lvl[k] = bj; }
+  unsigned long long bits = 0;
+  for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { const int i = 4 * x + y; bits |= (unsigned long long)lvl[(asel >> (8 * y + 2 * x)) & 3u] << (45 - 3 * i); }
+  out[0] = (uint8_t)bb; out[1] = (uint8_t)((bm << 4) | bt);
+  for (int k = 0; k < 6; k++) out[2 + k] = (uint8_t)(bits >> (40 - 8 * k));
+  // ---- colour half: the ETC1 re-pack ----
+  const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
+  uint32_t msb = 0, lsb = 0;
+  for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+    const uint32_t s2 = (sel >> (8 * y + 2 * x)) & 3u, idx = s2 == 0 ? 3u : (s2 == 1 ? 2u : (s2 == 2 ? 0u : 1u));
+    const int i = 4 * x + y;
+    msb |= (idx >> 1) << i; lsb |= (idx & 1u) << i;
+  }
+  const uint32_t t = e[3];
+  out[8] = (uint8_t)(e[0] << 3); out[9] = (uint8_t)(e[1] << 3); out[10] = (uint8_t)(e[2] << 3);
+  out[11] = (uint8_t)((t << 5) | (t << 2) | 2u);
+  out[12] = (uint8_t)(msb >> 8); out[13] = (uint8_t)msb; out[14] = (uint8_t)(lsb >> 8); out[15] = (uint8_t)lsb;
+}
+
 // ---- K3'': BC7 target (what KTX2Loader picks on desktop GPUs, reference src/lib/KTX2Loader.js:591-689: astc, then bptc).  An ETC1S
 // block has four colours base + {-a, -b, +b, +a}, clamped per channel.  Two single-subset BC7 modes can hold them with the
 // darkest / brightest colour as endpoints: mode 5 (7-bit RGB endpoints widened by bit replication, 2-bit indices, weights
@@ -395,7 +457,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_bc7(TexDecJob *jobs) {
   if (J.status != 0) return;
   const uint32_t layer = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (layer >= J.layers || b >= J.bx * J.by) return;
-  const size_t o = (size_t)layer * J.bx * J.by + b;
+  const size_t o = (size_t)(layer << J.ashift) * J.bx * J.by + b;
   const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
   const int MODS[8][4] = { { -8, -2, 2, 8 }, { -17, -5, 5, 17 }, { -29, -9, 9, 29 }, { -42, -13, 13, 42 }, { -60, -18, 18, 60 }, { -80, -24, 24, 80 }, { -106, -33, 33, 106 }, { -183, -47, 47, 183 } };
   const int W2[4] = { 0, 21, 43, 64 };
@@ -425,12 +487,26 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_bc7(TexDecJob *jobs) {
   }
   unsigned long long lo, hi = 0; int pos;
   auto put = [&](unsigned long long v, int n) { if (pos < 64) { lo |= v << pos; if (pos + n > 64) hi |= v >> (64 - pos); } else hi |= v << (pos - 64); pos += n; };
-  if (err5 <= err6) {
+  // A file with alpha slices (what the stock loader asks BC7 with alpha for, src/lib/KTX2Loader.js:672-676): always mode 5, whose alpha has
+  // its own 8-bit endpoints and 2-bit indices.  The alpha block's four levels (green channel of the alpha slice, as the basis transcoder
+  // takes them) give the endpoints (lowest / highest level, exact) and every level the nearest of the four interpolated values.
+  uint32_t aidx[4] = { 0, 0, 0, 0 }, asel = 0; int a_lo = 255, a_hi = 255;
+  if (J.ashift) {
+    const size_t oa = o + (size_t)J.bx * J.by;
+    const uint8_t *ae = J.endpoints + 4 * (size_t)J.ei[oa]; asel = J.selectors[J.si[oa]];
+    int al[4];
+    for (int k = 0; k < 4; k++) { const int v = ((ae[1] << 3) | (ae[1] >> 2)) + MODS[ae[3] & 7][k]; al[k] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    a_lo = al[0]; a_hi = al[3];
+    for (int k = 0; k < 4; k++) { uint32_t bw = 0; int be = 1 << 30; for (uint32_t w = 0; w < 4; w++) { const int d = ((a_lo * (64 - W2[w]) + a_hi * W2[w] + 32) >> 6) - al[k]; if (d * d < be) { be = d * d; bw = w; } } aidx[k] = bw; }
+  }
+  if (err5 <= err6 || J.ashift) {
     const bool swap = idx5[sel & 3u] >= 2u;              // pixel 0 = selector bits 0..1 (x = 0, y = 0)
+    const bool aswap = aidx[asel & 3u] >= 2u;            // the alpha index set has its own anchor
     lo = 1ull << 5; pos = 8;
     for (int c = 0; c < 3; c++) { put((unsigned)(swap ? hi7[c] : lo7[c]), 7); put((unsigned)(swap ? lo7[c] : hi7[c]), 7); }
-    put(255u, 8); put(255u, 8);
+    put((unsigned)(aswap ? a_hi : a_lo), 8); put((unsigned)(aswap ? a_lo : a_hi), 8);
     for (int i = 0; i < 16; i++) { uint32_t ix = idx5[(sel >> (2 * i)) & 3u]; if (swap) ix = 3u - ix; put(ix, i == 0 ? 1 : 2); }
+    if (J.ashift) for (int i = 0; i < 16; i++) { uint32_t ix = aidx[(asel >> (2 * i)) & 3u]; if (aswap) ix = 3u - ix; put(ix, i == 0 ? 1 : 2); }
   } else {
     const bool swap = idx6[sel & 3u] >= 8u;
     lo = 1ull << 6; pos = 7;
@@ -539,8 +615,8 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   }
   const TexDecJob &J0 = T->hjobs[0];
   const size_t nbk = (size_t)J0.bx * J0.by, L = J0.layers, NSL = J0.nsl;
-  if (J0.ashift && target != 0) { ctx->set_error("segment 0 has alpha slices: only the RGBA32 target reads them (the ETC1 / BC7 targets of this decoder are opaque formats)"); return UVOL_E_UNSUPPORTED; }
-  const size_t layer_bytes = target == 1 ? nbk * 8 : (target == 2 ? nbk * 16 : (size_t)J0.width * J0.height * 4);   // 0: RGBA8, 1: ETC1 blocks, 2: BC7 blocks
+  if (J0.ashift && target == 1) { ctx->set_error("segment 0 has alpha slices: ETC1 is an opaque format (the stock loader asks such a file for ETC2 RGBA or BC7: uvol_transcode_texture_segments_etc2_rgba / _bc7)"); return UVOL_E_UNSUPPORTED; }
+  const size_t layer_bytes = target == 1 ? nbk * 8 : ((target == 2 || target == 4) ? nbk * 16 : (size_t)J0.width * J0.height * 4);   // 0: RGBA8, 1: ETC1 blocks, 2: BC7 blocks, 4: ETC2 RGBA blocks
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small: %zu < %zu", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   // per-segment workspace: codebooks, block indices, Huffman size / sorted arrays of 9 models
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -578,6 +654,7 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   { uvol_ctx::Scope sc(ctx, "texdec.k3_unpack", (uint64_t)n * L * layer_bytes);
     if (target == 1) DLAUNCH(k_tdec_etc1, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
     else if (target == 2) DLAUNCH(k_tdec_bc7, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
+    else if (target == 4) DLAUNCH(k_tdec_etc2a, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
     else DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -304,6 +304,13 @@ int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx
   return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 2);
 }
 
+int uvol_transcode_texture_segments_etc2_rgba(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return decode_dispatch(ctx, ktx2, lens, n_segments, blocks, layer_cap, outputs_on_device != 0, 4);
+}
+
 int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *blocks, size_t layer_cap, int outputs_on_device) {
   UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !ktx2 || !lens || n_segments <= 0 || !blocks) return UVOL_E_INVALID;

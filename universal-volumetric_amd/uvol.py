@@ -38,7 +38,7 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_dev_out", "uvol_decode_mesh_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
-           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
+           "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_etc2_rgba", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
 
 
@@ -71,6 +71,7 @@ def load(path=None):
     L.uvol_transcode_texture_segments_etc1.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
     L.uvol_transcode_texture_segments_bc7.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_transcode_texture_segments_astc.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
+    L.uvol_transcode_texture_segments_etc2_rgba.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_decode_mesh_batch_dev.argtypes = L.uvol_decode_mesh_batch.argtypes
@@ -365,6 +366,18 @@ class Codec:
         rc = self.L.uvol_transcode_texture_segments_bc7(self.h, fp, ln, n, ptrs, bx * by * 16, 0)
         if rc != UVOL_OK:
             raise UvolError(f"transcode_texture_segments_bc7 rc={rc}: {self.error()}")
+        return outs
+
+    def transcode_texture_segments_etc2_rgba(self, files):
+        """files: list of .ktx2 bytes (with or without alpha slices) -> list (per segment) of [layers, by, bx, 16] uint8 arrays of ETC2 RGBA blocks."""
+        files = [bytes(f) for f in files]
+        w, h, nl = self.ktx2_info(files[0]); n = len(files); bx, by = (w + 3) // 4, (h + 3) // 4
+        outs = [np.empty((nl, by, bx, 16), dtype=np.uint8) for _ in range(n)]
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files])
+        ptrs = (C.c_void_p * (n * nl))(*[outs[s][l].ctypes.data for s in range(n) for l in range(nl)])
+        rc = self.L.uvol_transcode_texture_segments_etc2_rgba(self.h, fp, ln, n, ptrs, bx * by * 16, 0)
+        if rc != UVOL_OK:
+            raise UvolError(f"transcode_texture_segments_etc2_rgba rc={rc}: {self.error()}")
         return outs
 
     def transcode_texture_segments_astc(self, files):
