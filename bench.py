@@ -387,12 +387,12 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     # (2c) one blocking geometry call per pass (the whole call is one group on the context's first lane, which then holds a workspace of
     #      the full call: run last among the device-input variants)
     note("blocking_calls")
-    v["blocking_calls"] = dict(Job(F, blocking=True).timed(2, 0), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
+    v["blocking_calls"] = dict(Job(F, blocking=True).timed(2, 1), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
     note("host_inputs")
     frame_t.clear(); keep.clear(); del dev_meshes[:]
     torch.cuda.empty_cache()
-    nh = min(F, 1080)
+    nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
     note("decode")

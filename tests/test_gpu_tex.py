@@ -118,13 +118,13 @@ def test_gpu_batched_segments_equal_single_calls(oracle, gpu_codec):
 
 
 def test_gpu_host_segments_in_parts_on_two_lanes(oracle, gpu_codec):
-    """Round 4: a call of >= 48 segments on HOST inputs is cut into parts that alternate between two lanes (part k + 1 uploads while
-    part k encodes).  52 segments of 64^2 x 2 (one of them with alpha: second pass on its lane): every segment equals the oracle's
+    """Round 4: a call of >= 128 segments on HOST inputs is cut into parts that alternate between two lanes (part k + 1 uploads while
+    part k encodes).  132 segments of 64^2 x 2 (one of them with alpha: second pass on its lane): every segment equals the oracle's
     bytes, whatever part it fell into."""
     import synth
     from test_hipemu_tex import _alpha_sequence
     base = [synth.texture_sequence(2, size=64, seed=s) for s in range(6)]
-    segs = [base[i % 6] for i in range(52)]
+    segs = [base[i % 6] for i in range(132)]
     segs[30] = _alpha_sequence(2, 64, 5)
     want = [oracle.ktx2_encode(t) for t in base]
     res = gpu_codec.encode_texture_segments(segs)

@@ -1013,7 +1013,7 @@ static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base, bool r8, bool f
     DCARVE(S.out, 4 * (std::max(4 * E, k == GD_MAXDEC - 1 ? nc : (size_t)0) + 4), DS_SYM, DS_PRED); DCARVE(J.att[k].vals, 4 * (4 * E + 4), DS_PRED, DS_FIN);
   }
   for (int k = 1; k < 4; k++) DCARVE(G.rec[k], (r8 ? 32 : 64) * (nf + 1), DS_TRAV, DS_TRAV);     // 8- or 16-byte corner records, decided per batch (geo_records8)
-  for (int k = 0; k < 3; k++) { DCARVE(G.order[k], 4 * (E + 3), DS_TRAV, DS_FIN); DCARVE(G.v2d[k], 4 * (std::max(E, maxv) + 3), DS_TRAV, DS_FIN); DCARVE(G.t_stack[k], 4 * (nf + 2), DS_TRAV, DS_TRAV); DCARVE(G.t_vvis[k], std::max(E, maxv) / 8 + 64, UVOL_WS_PINNED, UVOL_WS_PINNED); }
+  for (int k = 0; k < 3; k++) { DCARVE(G.order[k], 4 * (E + 3), DS_TRAV, DS_FIN); DCARVE(G.v2d[k], 4 * (std::max(E, maxv) + 3), DS_TRAV, DS_FIN); DCARVE(G.t_stack[k], 4 * (nf + 2), DS_TRAV, DS_TRAV); DCARVE(G.t_vvis[k], std::max(E, maxv) / 8 + 64, UVOL_WS_PINNED, UVOL_WS_PINNED); DCARVE(G.t_fvis[k], nf / 8 + 64, UVOL_WS_PINNED, UVOL_WS_PINNED); }
 #undef DCARVE
   const std::vector<uint64_t> key = { (uint64_t)nf, (uint64_t)J.nev, (uint64_t)r8 | ((uint64_t)full << 1), (uint64_t)items.size() };
   if (key != P.key) { P.total = uvol_ws_place(items, &P.zero, DS_COUNT, "geometry decode"); P.offs.resize(items.size()); for (size_t i = 0; i < items.size(); i++) P.offs[i] = items[i].off; P.key = key; }

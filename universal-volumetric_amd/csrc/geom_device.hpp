@@ -96,6 +96,7 @@ struct GeoJob {
   uint8_t *seam[2]; uint8_t *elig; uint8_t *seam_bits[2];
   int32_t *avert[2];
   int32_t *order[3], *v2d[3]; uint8_t *t_vvis[3]; int32_t *t_stack[3];
+  uint8_t *fvis, *t_fvis[3];          // face-visited bits (one per face) of the lane-per-walker kernels on per-face records (walk, three traversals)
   int32_t *P, *U, *O;
   uint32_t *sym_pos, *sym_uv, *sym_nrm;
   uint8_t *has_ori, *ori_val, *ori_c, *ori_bits, *flips;

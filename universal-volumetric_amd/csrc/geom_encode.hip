@@ -1907,8 +1907,19 @@ __device__ __forceinline__ void f16_dec(const uvol_u4 &q, int k, int &vi, int &r
   rc = (int)((uint32_t)(hi >> sr) << 11) >> 11;            // 21-bit field, all ones = none
   lc = (int)((uint32_t)(hi >> sl) << 11) >> 11;
 }
-#define F16_SEEN(q) ((q).y >> 31)
-#define F16_MARK(face, q) (rec[4 * (size_t)(face) + 1] = (q).y | 0x80000000u)
+// FB = true: the face-visited flags are ONE BIT PER FACE in an array of their own (J.fvis / J.t_fvis[t], zeroed with the workspace head)
+// instead of bit 63 of the record.  The record lines then stay clean: with the flag in the record every step dirtied the very line
+// the next steps read their neighbours from (written back once per line: 9.6 MB per frame and table, and a store into a line makes
+// the following loads of that line go back to L2).  A step knows its own face's word from the step before - the word it tested the
+// face in as a candidate -, so marking is one plain store and testing the two candidates two 4-byte loads beside the record loads.
+template <bool FB> struct F16Vis {
+  UVOL_G(uint32_t) rec; UVOL_G(uint32_t) fb;
+  // is face f visited?  q = its record (FB = false), w = its word of the bitmap (FB = true)
+  __device__ __forceinline__ bool seen(const uvol_u4 &q, uint32_t w, int f) const { return FB ? ((w >> (f & 31)) & 1u) != 0 : (q.y >> 31) != 0; }
+  __device__ __forceinline__ uint32_t word(int f) const { return FB ? fb[f >> 5] : 0u; }
+  __device__ __forceinline__ void mark(int f, const uvol_u4 &q, uint32_t w) const { if (FB) fb[f >> 5] = w | (1u << (f & 31)); else rec[4 * (size_t)f + 1] = q.y | 0x80000000u; }
+};
+template <bool FB>
 __device__ inline void eb_walk_simt_f16(GeoJob &J) {
   const int nf = (int)J.nf;
   UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[0]));
@@ -1916,9 +1927,10 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
   UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
   UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
   const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
+  F16Vis<FB> V; V.rec = rec; V.fb = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis));
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   int fo = 0, sp = 0, x = -1, vi = 0, rcn = -1, lcn = -1;
-  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
+  uvol_u4 q; q.x = q.y = q.z = q.w = 0; uint32_t myw = 0;
   for (;;) {
     if (x < 0) {                                          // rare: a corner to go on from - the stack, else the next component
       bool finished = false;
@@ -1926,16 +1938,16 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
         if (sp > 0) {
           const int c = stack[sp - 1];
           if (c < 0) { sp--; continue; }
-          const uvol_u4 qq = f16_load(rec, c >> 2);
-          if (F16_SEEN(qq)) { sp--; continue; }
-          x = c; q = qq; f16_dec(q, x & 3, vi, rcn, lcn);
+          const uvol_u4 qq = f16_load(rec, c >> 2); const uint32_t ww = V.word(c >> 2);
+          if (V.seen(qq, ww, c >> 2)) { sp--; continue; }
+          x = c; q = qq; myw = ww; f16_dec(q, x & 3, vi, rcn, lcn);
           break;
         }
         if (fo >= nf || nproc + ninit >= nf) { finished = true; break; }
         const int f0 = rl ? s_of_o[fo] : fo;             // component starts follow the ORIGINAL face order
         fo++;
-        const uvol_u4 q0 = f16_load(rec, f0);
-        if (F16_SEEN(q0)) continue;
+        const uvol_u4 q0 = f16_load(rec, f0); const uint32_t w0 = V.word(f0);
+        if (V.seen(q0, w0, f0)) continue;
         int v0[3], r0_[3], l0_[3];
         for (int k = 0; k < 3; k++) f16_dec(q0, k, v0[k], r0_[k], l0_[k]);
         const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
@@ -1953,25 +1965,29 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
         int from;
         if (interior) {
           for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = vbits[v >> 5]; vbits[v >> 5] = w | (1u << (v & 31)); }
-          F16_MARK(f0, q0);
+          V.mark(f0, q0, w0);
           initc[ninit] = 3 * f0 + 1;
           ninit++;
           from = o0[1];
-          if (from < 0 || (rec[4 * (size_t)(from >> 2) + 1] >> 31)) continue;
+          if (from < 0) continue;
+          { const int ff = from >> 2; uint32_t wf = V.word(ff); if (FB && (ff >> 5) == (f0 >> 5)) wf |= 1u << (f0 & 31); if (V.seen(f16_load(rec, ff), wf, ff)) continue; }
         } else from = start;
         stack[0] = from; sp = 1;
       }
       if (finished) break;
     }
     // ---- the common step (straight-line, see eb_walk_simt) ----
-    F16_MARK(x >> 2, q);
-    const uvol_u4 qr = f16_load(rec, (rcn < 0 ? x : rcn) >> 2), ql = f16_load(rec, (lcn < 0 ? x : lcn) >> 2);
-    proc[nproc] = 3 * (x >> 2) + (x & 3);
+    const int f = x >> 2, rf = (rcn < 0 ? x : rcn) >> 2, lf = (lcn < 0 ? x : lcn) >> 2;
+    V.mark(f, q, myw);
+    const uvol_u4 qr = f16_load(rec, rf), ql = f16_load(rec, lf);
+    uint32_t wr = V.word(rf), wl = V.word(lf);
+    if (FB) { const uint32_t mine = myw | (1u << (f & 31)); if ((rf >> 5) == (f >> 5)) wr = mine | wr; if ((lf >> 5) == (f >> 5)) wl = mine | wl; }      // (this step's own bit, whatever the load saw)
+    proc[nproc] = 3 * f + (x & 3);
     const int v = vi >> 1;
     const uint32_t vw = vbits[v >> 5];
     vbits[v >> 5] = vw | (1u << (v & 31));                                  // (already set when the tip was visited)
     const uint32_t vvis = (vw >> (v & 31)) & 1u;
-    const uint32_t rvis = (rcn < 0 || F16_SEEN(qr)) ? 1u : 0u, lvis = (lcn < 0 || F16_SEEN(ql)) ? 1u : 0u;
+    const uint32_t rvis = (rcn < 0 || V.seen(qr, wr, rf)) ? 1u : 0u, lvis = (lcn < 0 || V.seen(ql, wl, lf)) ? 1u : 0u;
     const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;                    // tip unvisited and not on a boundary
     const uint32_t sym = ccase ? 0u : 1u + 2u * lvis + 4u * rvis;           // C 0, S 1, L 3, R 5, E 7
     symb[nproc] = (uint8_t)sym;
@@ -1981,7 +1997,7 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
     else {
       const bool go_l = sym == 5u;
       x = go_l ? lcn : rcn;
-      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
+      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w; myw = go_l ? wl : wr;
       f16_dec(q, x & 3, vi, rcn, lcn);
     }
   }
@@ -1991,6 +2007,7 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
   uint32_t z = 0; for (int i = 0; i < nstart; i++) z += start_bits[i] == 0;
   J.rb[0].zeros = z;
 }
+template <bool FB>
 __global__ void __launch_bounds__(64) k_eb_walk_simt_f16(GeoJob *jobs, int n, int W) {
   const int lane = (int)threadIdx.x;
   if (lane >= W) return;
@@ -1998,15 +2015,17 @@ __global__ void __launch_bounds__(64) k_eb_walk_simt_f16(GeoJob *jobs, int n, in
   if (j >= n) return;
   GeoJob &J = jobs[j];
   if (J.status != 0) return;
-  eb_walk_simt_f16(J);
+  eb_walk_simt_f16<FB>(J);
 }
+template <bool FB>
 __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
   const int nf = (int)J.nf;
   UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
   UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  F16Vis<FB> V; V.rec = rec; V.fb = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t]));
   int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
-  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
+  uvol_u4 q; q.x = q.y = q.z = q.w = 0; uint32_t myw = 0;
   for (;;) {
     if (x < 0) {                                          // rare: the stack, else the next unvisited face starts a component
       bool finished = false;
@@ -2014,15 +2033,15 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
         if (sp > 0) {
           const int c = stack[sp - 1];
           if (c < 0) { sp--; continue; }
-          const uvol_u4 qq = f16_load(rec, c >> 2);
-          if (F16_SEEN(qq)) { sp--; continue; }
-          x = c; q = qq; f16_dec(q, x & 3, vi, rc, lc);
+          const uvol_u4 qq = f16_load(rec, c >> 2); const uint32_t ww = V.word(c >> 2);
+          if (V.seen(qq, ww, c >> 2)) { sp--; continue; }
+          x = c; q = qq; myw = ww; f16_dec(q, x & 3, vi, rc, lc);
           break;
         }
         if (f >= nf || nvis >= nf) { finished = true; break; }
         const int f0 = f; f++;
-        const uvol_u4 q0 = f16_load(rec, f0);
-        if (F16_SEEN(q0)) continue;
+        const uvol_u4 q0 = f16_load(rec, f0); const uint32_t w0 = V.word(f0);
+        if (V.seen(q0, w0, f0)) continue;
         stack[0] = 4 * f0; sp = 1;
         int vn, vp, r_, l_; f16_dec(q0, 1, vn, r_, l_); f16_dec(q0, 2, vp, r_, l_); vn >>= 1; vp >>= 1;
         uint32_t w = vbits[vn >> 5];
@@ -2032,15 +2051,18 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
       }
       if (finished) break;
     }
-    F16_MARK(x >> 2, q);
+    const int fc = x >> 2, rf = (rc < 0 ? x : rc) >> 2, lf = (lc < 0 ? x : lc) >> 2;
+    V.mark(fc, q, myw);
     nvis++;
-    const uvol_u4 qr = f16_load(rec, (rc < 0 ? x : rc) >> 2), ql = f16_load(rec, (lc < 0 ? x : lc) >> 2);
+    const uvol_u4 qr = f16_load(rec, rf), ql = f16_load(rec, lf);
+    uint32_t wr = V.word(rf), wl = V.word(lf);
+    if (FB) { const uint32_t mine = myw | (1u << (fc & 31)); if ((rf >> 5) == (fc >> 5)) wr = mine | wr; if ((lf >> 5) == (fc >> 5)) wl = mine | wl; }
     const int v = vi >> 1;
     const uint32_t vw = vbits[v >> 5];
     vbits[v >> 5] = vw | (1u << (v & 31));
     const uint32_t vvis = (vw >> (v & 31)) & 1u;
-    if (!vvis) { order[n] = 3 * (x >> 2) + (x & 3); n++; }                  // a vertex seen for the first time takes the next place
-    const uint32_t rvis = (rc < 0 || F16_SEEN(qr)) ? 1u : 0u, lvis = (lc < 0 || F16_SEEN(ql)) ? 1u : 0u;
+    if (!vvis) { order[n] = 3 * fc + (x & 3); n++; }                        // a vertex seen for the first time takes the next place
+    const uint32_t rvis = (rc < 0 || V.seen(qr, wr, rf)) ? 1u : 0u, lvis = (lc < 0 || V.seen(ql, wl, lf)) ? 1u : 0u;
     const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;
     const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
     if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; }
@@ -2048,13 +2070,14 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
     else {
       const bool go_l = k == 2u;
       x = go_l ? lc : rc;
-      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
+      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w; myw = go_l ? wl : wr;
       f16_dec(q, x & 3, vi, rc, lc);
     }
   }
   J.ne[t] = (uint32_t)n;
   if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
+template <bool FB>
 __global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, int W) {
   const int lane = (int)threadIdx.x;
   if (lane >= W) return;
@@ -2064,10 +2087,8 @@ __global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, i
   GeoJob &J = jobs[j];
   const int ai = t > 0 ? t - 1 : 0;
   if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
-  traverse_simt_f16(J, t);
+  traverse_simt_f16<FB>(J, t);
 }
-#undef F16_SEEN
-#undef F16_MARK
 
 // ------------------------------------------------------------------------------------------------
 // K1: attribute min/max (orderable-float atomics) and quantisation of the entries in coding order
@@ -3140,6 +3161,8 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint32_t, ecap / 32 + 2, PH_PINNED, PH_PINNED);      // one bit per vertex: the whole map stays in L2
   for (int t = 0; t < 3; t++) CARVE(J.t_vvis[t], uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
+  CARVE(J.fvis, uint8_t, nfi / 8 + 64, PH_PINNED, PH_PINNED);                                           // face-visited bits of the lane-per-walker kernels on per-face records
+  for (int t = 0; t < 3; t++) CARVE(J.t_fvis[t], uint8_t, nfi / 8 + 64, PH_PINNED, PH_PINNED);
   for (int s = 0; s < GEO_NSTREAM; s++) {
     const int q = s == 6 ? J.qp : (s == 7 ? J.qt : J.qn);
     J.rs[s].alpha_cap = s < 6 ? 8 : (1u << (q + 1)) + 8;
@@ -3344,12 +3367,13 @@ static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
 }
 // the decode path sizes its record tables with the same rule; its vertex ids are dense (< 3 * faces)
 bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
+static inline bool geo_face_bits() { static const bool v = [] { const char *e = getenv("UVOL_FACE_BITS"); return !(e && *e == '0'); }(); return v; }      // UVOL_FACE_BITS=0 (diagnostic, tests): face-visited flag inside the per-face record
 static inline bool geo_rec_face_off() { static const bool v = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }(); return v; }      // UVOL_REC_FACE=0 (diagnostic, tests): corner records in the lane-per-walker kernels too
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) {
     const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W;
-    if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
+    if (r8 == 2) { if (geo_face_bits()) LAUNCH((k_traverse_simt_f16<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt_f16<false>), dim3(nb), dim3(64), dj, n, (int)W); }
     else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
   }
   else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
@@ -3642,7 +3666,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) {
       const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
-      if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
+      if (fmt0 == 2) { if (geo_face_bits()) LAUNCH((k_eb_walk_simt_f16<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt_f16<false>), dim3(nb), dim3(64), dj, n, (int)W); }
       else if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
     }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());

@@ -1427,7 +1427,7 @@ static int tex_finish(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, boo
   ctx->stream = saved; return rc;
 }
 // segments per part of a call on host inputs (UVOL_TEX_PART, tests: small values cut small calls too; 0 = never cut)
-static inline int tex_part_segments() { static const int v = [] { const char *e = getenv("UVOL_TEX_PART"); const int k = e ? atoi(e) : 24; return k < 0 ? 0 : k; }(); return v; }
+static inline int tex_part_segments() { static const int v = [] { const char *e = getenv("UVOL_TEX_PART"); const int k = e ? atoi(e) : 64; return k < 0 ? 0 : k; }(); return v; }
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
                         bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
   if (n_seg <= 0) return UVOL_OK;
@@ -1445,7 +1445,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   // part k + 1 through the pinned buffers and its DMAs run on the other lane's stream; then part k's containers are written while part
   // k + 1 encodes.  16.8 MB per layer cross PCIe: without the overlap a call was upload, then encode, one after the other.
   if (!T->lane[1].stream) { if (uvol_make_stream(ctx, &T->lane[1].stream) != hipSuccess) { ctx->set_error("texture lane: stream creation failed"); return UVOL_E_HIP; } T->lane[1].own_stream = true; }
-  const int parts = std::max(2, std::min(8, n_seg / part));
+  const int parts = std::max(2, std::min(4, n_seg / part));           // few, large parts: every part pays the serial stages' latency (one wave per slice) once
   auto lo = [&](int k) { return (int)((long long)n_seg * k / parts); };
   int worst = UVOL_OK;
   for (int k = 0; k <= parts; k++) {
