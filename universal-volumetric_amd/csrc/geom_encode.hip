@@ -216,16 +216,20 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_scatter(GeoJob *jobs) {
 // A thread's records are fetched together (DD_PER independent 16-byte loads) and the bin's keys are staged in LDS, so a probe
 // that meets an occupied slot compares against LDS: with a global read of the slot's record per probe every trip of the loop was
 // two dependent round trips for the whole wave.
-#define DD_PER 6
-#define DD_KEYS (UVOL_BLOCK * DD_PER)          // keys of a bin held in LDS (bins average ~1 k values; the rest compares through global memory)
+// Two sizes: bins of the usual load (<= ~1100 values: 100 k-vertex frames give ~780) take a 2048-slot table and 1024 staged keys = 28 KB
+// of LDS; the 4096-slot / 1536-key form (50 KB) is for meshes beyond ~1 M values per attribute, whose 1024 bins hold more.  The small form
+// matters beside other contexts: a workgroup that wants a third of a CU's LDS waits for it - 54 ms per 1280 frames next to the texture
+// context against 9 ms per 2160 alone (profiles/r04_a_kernel_stats.csv).
+template <int DD_TSLOTS, int DD_PER>
 __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_resolve(GeoJob *jobs, uint32_t slots) {
+  constexpr uint32_t DD_KEYS = UVOL_BLOCK * DD_PER;      // keys of a bin held in LDS (the rest compares through global memory)
   JOB_OR_RETURN_UNIFORM;
   const int which = (int)blockIdx.z; const DdSrc S = dd_src(J, which);
   const uint32_t nb = J.dd_nb[which], nblk = J.dd_nblk[which];
   if (blockIdx.x >= nb || S.n == 0) return;
   const uint32_t lo = J.dd_cnt[which][(size_t)blockIdx.x * nblk], hi = J.dd_cnt[which][(size_t)(blockIdx.x + 1) * nblk];
   const uint4 *part = J.dd_part[which];
-  __shared__ uint32_t t_rec[DD_SLOTS], t_min[DD_SLOTS];
+  __shared__ uint32_t t_rec[DD_TSLOTS], t_min[DD_TSLOTS];
   __shared__ uint32_t kw0[DD_KEYS], kw1[DD_KEYS], kw2[DD_KEYS];
   __shared__ uint32_t n_ins, any_dup, fail;
   for (uint32_t s = threadIdx.x; s < slots; s += UVOL_BLOCK) { t_rec[s] = 0; t_min[s] = 0xffffffffu; }
@@ -3416,7 +3420,8 @@ static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, ui
       LAUNCH(k_dd_count, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_dd_scan, dim3(1, N, 3), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_dd_scatter, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_dd_resolve, dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
+      if (max_vals / std::max(1u, nbm) <= 1100u && slots >= 2048u) LAUNCH((k_dd_resolve<2048, 4>), dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, 2048u);
+      else LAUNCH((k_dd_resolve<DD_SLOTS, 6>), dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
     } else {
       LAUNCH(k_dd_clear, dim3(16, N, 3), dim3(UVOL_BLOCK), dj);
       for (int ph = 0; ph < 2; ph++) { LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, ph); LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, ph); LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, ph); }
@@ -3592,7 +3597,8 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
       LAUNCH(k_dd_count, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_dd_scan, dim3(1, N, 3), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_dd_scatter, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_dd_resolve, dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
+      if (max_vals / std::max(1u, nbm) <= 1100u && slots >= 2048u) LAUNCH((k_dd_resolve<2048, 4>), dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, 2048u);
+      else LAUNCH((k_dd_resolve<DD_SLOTS, 6>), dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
     } else {
       LAUNCH(k_dd_clear, dim3(16, N, 3), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, 0);
