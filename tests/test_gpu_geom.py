@@ -101,8 +101,8 @@ def test_gpu_walker_bitmap_placements(oracle):
     # entwave: the wave-per-stream entropy coder instead of the lane-per-stream one
     # relabel: the locality relabelling forced on for these coherently stored meshes (per frame it is decided on the device)
     # earlyjoin: the auxiliary stream joined before the record tables (batches above 1200 frames); small batches join late
-    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "simtcorner", "simtflagrec", "entwave", "relabel", "relabel_simt", "earlyjoin"):
-        env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_SIMT_W="6", UVOL_FACE_BITS="0") if force == "simtflagrec" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="5") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
+    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "simtcorner", "simtfacebits", "entwave", "relabel", "relabel_simt", "earlyjoin"):
+        env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_SIMT_W="6", UVOL_FACE_BITS="1") if force == "simtfacebits" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="5") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (force, r.stdout[-500:], r.stderr[-1500:])
 
@@ -353,37 +353,45 @@ def test_gpu_1280_distinct_full_size_frames_in_one_call(oracle):
 
 
 def test_gpu_resident_decode_then_encode_without_a_host_copy(oracle, gpu_codec):
-    """VERDICT r3 #9 / SURVEY 8(b): uvol_decode_mesh_batch_dev leaves the decoded arrays in caller-owned HBM buffers (torch tensors here),
-    uvol_encode_mesh_batch_dev_out reads them - ordered after the producer's stream, no host wait - and leaves the .drc bitstreams in a
-    caller-owned HBM buffer.  The geometry never visits the host between the two calls; the bytes are the oracle's for the decoded arrays."""
-    import ctypes as C, torch, synth, uvol
+    """VERDICT r3 #9 / SURVEY 8(b): uvol_decode_mesh_batch_dev leaves the decoded arrays in caller-owned HBM buffers (plain hipMalloc
+    through ctypes: the caller need not be torch), uvol_encode_mesh_batch_dev_out reads them - ordered after the producer's stream, no host
+    wait - and leaves the .drc bitstreams in a caller-owned HBM buffer.  The geometry never visits the host between the two calls; the
+    bytes are the oracle's for the decoded arrays."""
+    import ctypes as C, synth, uvol
+    hip = C.CDLL("libamdhip64.so")
+    def dmalloc(nbytes):
+        p = C.c_void_p(); assert hip.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 16))) == 0; return p.value
+    def d2h(ptr, dtype, count):
+        a = np.empty(count, dtype); assert hip.hipMemcpy(C.c_void_p(a.ctypes.data), C.c_void_p(ptr), C.c_size_t(a.nbytes), C.c_int(2)) == 0; return a
     src = [synth.sphere_mesh(120, 61, charts=(12, 6), frame=3), synth.torus_mesh(), synth.sphere_mesh(283, 177)]
     files = gpu_codec.encode_mesh_batch(src)
-    n = len(files); dev = torch.device("cuda", 0)
-    metas = (uvol.DecodedMesh * n)(); bufs = []
+    n = len(files)
+    metas = (uvol.DecodedMesh * n)(); owned = []
     for i, f in enumerate(files):
         nf, mv = gpu_codec.drc_info(f)
-        a = dict(pos=torch.zeros((mv, 3), dtype=torch.float32, device=dev), uv=torch.zeros((mv, 2), dtype=torch.float32, device=dev), nrm=torch.zeros((mv, 3), dtype=torch.float32, device=dev),
-                 idx_pos=torch.zeros(3 * nf, dtype=torch.int32, device=dev), idx_uv=torch.zeros(3 * nf, dtype=torch.int32, device=dev), idx_nrm=torch.zeros(3 * nf, dtype=torch.int32, device=dev))
-        bufs.append(a); metas[i].cap_faces = nf; metas[i].cap_values = mv
-        for k, v in a.items():
-            setattr(metas[i], k, v.data_ptr())
-    torch.cuda.synchronize()
+        metas[i].cap_faces = nf; metas[i].cap_values = mv
+        for k, nb in (("pos", 12 * mv), ("uv", 8 * mv), ("nrm", 12 * mv), ("idx_pos", 12 * nf), ("idx_uv", 12 * nf), ("idx_nrm", 12 * nf)):
+            ptr = dmalloc(nb); owned.append(ptr); setattr(metas[i], k, ptr)
     assert gpu_codec.decode_mesh_batch_dev(files, metas) == [0] * n
     meshes = (uvol.Mesh * n)()
     for i in range(n):
         m, mm = metas[i], meshes[i]
         mm.pos, mm.n_pos, mm.uv, mm.n_uv, mm.nrm, mm.n_nrm = m.pos, m.n_pos, m.uv, m.n_uv, m.nrm, m.n_nrm
         mm.idx_pos, mm.idx_uv, mm.idx_nrm, mm.n_faces = m.idx_pos, m.idx_uv, m.idx_nrm, m.n_faces
-    out = torch.zeros(8 << 20, dtype=torch.uint8, device=dev)
-    offs, lens, st = gpu_codec.encode_mesh_batch_dev_out(meshes, out.data_ptr(), out.numel(), producer_stream=torch.cuda.current_stream().cuda_stream)
+    cap = 8 << 20; out = dmalloc(cap); owned.append(out)
+    stream = C.c_void_p(); assert hip.hipStreamCreate(C.byref(stream)) == 0
+    assert hip.hipMemsetAsync(C.c_void_p(out), C.c_int(0), C.c_size_t(cap), stream) == 0       # work queued on the producer's stream: the encode is ordered behind it
+    offs, lens, st = gpu_codec.encode_mesh_batch_dev_out(meshes, out, cap, producer_stream=stream.value)
     assert st == [0] * n
-    got = out.cpu().numpy()
+    got = d2h(out, np.uint8, cap)
     for i in range(n):
-        m, a = metas[i], bufs[i]
-        h = {k: v.cpu().numpy() for k, v in a.items()}
-        want = oracle.drc_encode(h["pos"][:m.n_pos], h["idx_pos"].view(np.uint32), h["uv"][:m.n_uv], h["idx_uv"].view(np.uint32), h["nrm"][:m.n_nrm], h["idx_nrm"].view(np.uint32))
+        m = metas[i]
+        want = oracle.drc_encode(d2h(m.pos, np.float32, 3 * m.n_pos).reshape(-1, 3), d2h(m.idx_pos, np.uint32, 3 * m.n_faces), d2h(m.uv, np.float32, 2 * m.n_uv).reshape(-1, 2), d2h(m.idx_uv, np.uint32, 3 * m.n_faces),
+                                 d2h(m.nrm, np.float32, 3 * m.n_nrm).reshape(-1, 3), d2h(m.idx_nrm, np.uint32, 3 * m.n_faces))
         assert got[offs[i]:offs[i] + lens[i]].tobytes() == want, i
+    hip.hipStreamDestroy(stream)
+    for ptr in owned:
+        hip.hipFree(C.c_void_p(ptr))
 
 
 def test_gpu_batch_sizes_alternate_on_one_context(oracle):

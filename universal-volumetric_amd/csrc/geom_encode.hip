@@ -3371,7 +3371,10 @@ static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
 }
 // the decode path sizes its record tables with the same rule; its vertex ids are dense (< 3 * faces)
 bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
-static inline bool geo_face_bits() { static const bool v = [] { const char *e = getenv("UVOL_FACE_BITS"); return !(e && *e == '0'); }(); return v; }      // UVOL_FACE_BITS=0 (diagnostic, tests): face-visited flag inside the per-face record
+// UVOL_FACE_BITS=1 (diagnostic, tests): face-visited bits in an array of their own instead of bit 63 of the per-face record.  Measured and
+// NOT the default: traversals 275 against 251 ms, geometry alone 3074 against 3169 frames/s, full path 2580 against 2745 - the two extra
+// 4-byte loads per step cost more than the clean record lines save (tools/experiments/exp_r4h.sh).
+static inline bool geo_face_bits() { static const bool v = [] { const char *e = getenv("UVOL_FACE_BITS"); return e && *e == '1'; }(); return v; }
 static inline bool geo_rec_face_off() { static const bool v = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }(); return v; }      // UVOL_REC_FACE=0 (diagnostic, tests): corner records in the lane-per-walker kernels too
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
