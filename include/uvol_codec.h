@@ -108,6 +108,17 @@ int uvol_encode_mesh_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
 int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
                                uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
 
+/* Ingest on the device (`draco_encoder -i frame.obj` parses the OBJ text itself, scripts/Encoder.py:256-262): n OBJ files
+ * as TEXT in host memory -> meshes_out[i] with DEVICE pointers (v / vt / vn / f lines, polygons fanned, 1-based and negative indices;
+ * bit-identical to the host parser of host/uvol_host.cpp, i.e. to strtof), ready for uvol_encode_mesh_batch_dev[_async].  The arrays
+ * live in the context's slot `slot` (0 or 1) until that slot is parsed into again, so batch b + 1 can be parsed while the enqueued
+ * encode of batch b still reads the other slot.  status[i]: UVOL_OK; UVOL_E_UNSUPPORTED = the text holds a number or line the device
+ * parser leaves to the host (more than 19 significant digits, inf / nan, a value on a float rounding boundary, an incomplete `v` line):
+ * parse that file with the host parser; UVOL_E_INVALID = a face references a missing vertex / no faces.  Blocking; not thread-safe per ctx
+ * except against this ctx's own enqueued encode calls. */
+int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, const size_t *lens, int n, int slot,
+                             uvol_mesh *meshes_out, int *status);
+
 /* GPU-resident form (SURVEY 8(b) "variants taking arrays of frames + hipStream_t"; caller-owned buffers as in
  * deprecated/encoder_legacy/codec/corto_codec.h:41-43): inputs are device pointers PRODUCED ON `producer_stream` (a hipStream_t passed
  * as void *, NULL = already complete) - the codec's kernels are ordered after the work queued on that stream so far, without a host

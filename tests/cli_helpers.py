@@ -4,11 +4,14 @@ import os
 import numpy as np
 
 
-def write_obj(path, m):
+def write_obj(path, m, short=False):
+    """short: numbers with 9 significant digits (they round-trip float32 and the DEVICE parser takes them); else repr() of the double,
+    17 digits, which the device parser hands back to the host parser (more than 2^53 in the mantissa)."""
+    n3 = "v %.9g %.9g %.9g\n" if short else "v %r %r %r\n"; t2 = "vt %.9g %.9g\n" if short else "vt %r %r\n"; nn = "vn %.9g %.9g %.9g\n" if short else "vn %r %r %r\n"
     with open(path, "w") as f:
-        for v in m["pos"]: f.write("v %r %r %r\n" % tuple(float(x) for x in v))
-        for v in m["uv"]: f.write("vt %r %r\n" % tuple(float(x) for x in v))
-        for v in m["nrm"]: f.write("vn %r %r %r\n" % tuple(float(x) for x in v))
+        for v in m["pos"]: f.write(n3 % tuple(float(x) for x in v))
+        for v in m["uv"]: f.write(t2 % tuple(float(x) for x in v))
+        for v in m["nrm"]: f.write(nn % tuple(float(x) for x in v))
         ip, iu, inn = (m[k].reshape(-1, 3) + 1 for k in ("idx_pos", "idx_uv", "idx_nrm"))
         for a, b, c in zip(ip, iu, inn):
             f.write("f " + " ".join("%d/%d/%d" % (a[k], b[k], c[k]) for k in range(3)) + "\n")
@@ -20,7 +23,7 @@ def make_sequence(root, n_frames=10, tex=64, batch=5, comments=True, alpha=False
     os.makedirs(os.path.join(root, "OBJ")); os.makedirs(os.path.join(root, "PNG"))
     meshes = [synth.sphere_mesh(16, 9, charts=(2, 2), frame=k, seed=k) for k in range(n_frames)]
     for k, m in enumerate(meshes):
-        write_obj(os.path.join(root, "OBJ", "frame_%05d.obj" % k), m)
+        write_obj(os.path.join(root, "OBJ", "frame_%05d.obj" % k), m, short=(k % 3 != 1))      # batches mix device-parsed and host-parsed files
     texs = synth.texture_sequence(n_frames, size=tex, seed=3)
     if alpha:                                  # RGBA PNGs with a real alpha channel (a moving soft disc): basisu would write alpha slices
         import numpy as np

@@ -130,7 +130,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
   if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
   if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
   if (uvol_make_stream(ctx, &ctx->stream) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
-  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK || uastc_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
+  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK || uastc_create(ctx) != UVOL_OK || obj_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
   *out = ctx;
   return UVOL_OK;
 }
@@ -141,7 +141,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
-  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx);
+  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx);
   for (int k = 0; k < 2; k++) { if (ctx->up_pin[k]) (void)hipHostFree(ctx->up_pin[k]); if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -343,6 +343,14 @@ int uvol_decode_mesh_batch_dev(uvol_ctx *ctx, const uint8_t *const *drc, const s
     if (rc != UVOL_OK) return rc;
   }
   return UVOL_OK;
+}
+
+// (not behind UVOL_AFTER_ASYNC on purpose: the parse of batch b + 1 runs on its own stream and slot while the enqueued encode of batch b
+// still reads the other slot)
+int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status) {
+  if (!ctx || !obj_text || !lens || n < 0 || !meshes_out) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return obj_parse_batch(ctx, obj_text, lens, n, slot, meshes_out, status);
 }
 
 int uvol_encode_mesh_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, void *producer_stream,

@@ -146,6 +146,7 @@ struct TexState;   // texture pipeline state (tex_encode.hip)
 struct TexDecState;  // texture decode state (tex_decode.hip)
 struct GeoDecState;  // geometry decode state (geom_decode.hip)
 struct UastcState;   // UASTC texture mode (tex_uastc.hip)
+struct ObjState;     // OBJ text ingest on the device (obj_ingest.hip)
 
 struct uvol_ctx {
   int device = 0;
@@ -161,6 +162,7 @@ struct uvol_ctx {
   TexDecState *texdec = nullptr;
   GeoDecState *geodec = nullptr;
   UastcState *uastc = nullptr;
+  ObjState *obj = nullptr;
   // enqueue form of the ABI (uvol_*_async + uvol_sync): calls run in order on this context's worker thread
   struct AsyncQ {
     std::mutex m; std::condition_variable cv_work, cv_idle; std::deque<std::function<int()>> q; std::thread th; bool busy = false, stop = false; int first_err = 0; char err[512] = {0};
@@ -230,6 +232,9 @@ int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *l
 int texdec_create(uvol_ctx *ctx);
 void texdec_destroy(uvol_ctx *ctx);
 int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target);
+int obj_create(uvol_ctx *ctx);
+void obj_destroy(uvol_ctx *ctx);
+int obj_parse_batch(uvol_ctx *ctx, const uint8_t *const *texts, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status);
 int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);
 #define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */

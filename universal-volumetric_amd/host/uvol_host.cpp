@@ -550,6 +550,16 @@ int uvolh_read_obj_positions(const char *path, float *pos, size_t cap_floats) {
   if (m.pos.size() > cap_floats) return -2;
   std::memcpy(pos, m.pos.data(), m.pos.size() * sizeof(float)); return (int)(m.pos.size() / 3);
 }
+// test hook: every array read_obj produces (the device parser of csrc/obj_ingest.hip must agree with it bit for bit); counts6 = {n_pos, n_uv,
+// n_nrm, faces, faces with uv indices, faces with normal indices}; buffers may be NULL (counts only)
+int uvolh_read_obj_arrays(const char *path, float *pos, float *uv, float *nrm, unsigned *ip, unsigned *iu, unsigned *in_, unsigned *counts6) {
+  uvolh::ObjMesh m; std::string err; if (!uvolh::read_obj(path, m, err)) return -1;
+  counts6[0] = (unsigned)m.pos.size() / 3; counts6[1] = (unsigned)m.uv.size() / 2; counts6[2] = (unsigned)m.nrm.size() / 3;
+  counts6[3] = (unsigned)m.idx_pos.size() / 3; counts6[4] = (unsigned)m.idx_uv.size() / 3; counts6[5] = (unsigned)m.idx_nrm.size() / 3;
+  if (pos) std::memcpy(pos, m.pos.data(), m.pos.size() * 4); if (uv) std::memcpy(uv, m.uv.data(), m.uv.size() * 4); if (nrm) std::memcpy(nrm, m.nrm.data(), m.nrm.size() * 4);
+  if (ip) std::memcpy(ip, m.idx_pos.data(), m.idx_pos.size() * 4); if (iu) std::memcpy(iu, m.idx_uv.data(), m.idx_uv.size() * 4); if (in_) std::memcpy(in_, m.idx_nrm.data(), m.idx_nrm.size() * 4);
+  return 0;
+}
 int uvolh_read_png(const char *path, unsigned *wh, unsigned char *rgba, size_t cap) {
   uvolh::Image im; std::string err; if (!uvolh::read_png(path, im, err)) return -1;
   wh[0] = im.w; wh[1] = im.h; if (rgba && cap >= im.rgba.size()) std::memcpy(rgba, im.rgba.data(), im.rgba.size()); return 0;

@@ -58,13 +58,14 @@ int main(int argc, char **argv) {
   }
   const auto t_start = std::chrono::steady_clock::now();
   { const char *e = std::getenv("UVOL_TIMING"); g_timing = e && *e == '1'; }
-  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false;
+  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device0 = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--batch-frames") && i + 1 < argc) frames_per_batch = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) ingest_threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--force")) force = true;
+    else if (!std::strcmp(argv[i], "--host-obj-parser")) host_obj = true;          // OBJ text parsed by the ingest threads (as until round 3) instead of on the GPU
     else if (!std::strcmp(argv[i], "--uastc")) uastc = true;
     else if (!std::strcmp(argv[i], "--encoder-py-manifest")) encpy = true;
     else if (!std::strcmp(argv[i], "--targets") && i + 1 < argc) {
@@ -94,8 +95,11 @@ int main(int argc, char **argv) {
   prm.q_position_attr = cfg.q_position; prm.q_texture_attr = cfg.q_texture; prm.q_normal_attr = cfg.q_normal; prm.q_generic_attr = cfg.q_generic;
   prm.draco_compression_level = cfg.compression_level; prm.ktx2_batch_size = cfg.ktx2_batch_size; prm.max_batch = frames_per_batch; prm.uastc = uastc ? 1 : 0;
   // one geometry and one texture context (= HIP stream) per GPU: the two stages of a GPU run side by side
-  std::vector<uvol_ctx *> ctxs((size_t)n_gpus, nullptr), tctxs((size_t)n_gpus, nullptr);
-  for (int g = 0; g < n_gpus; g++) if (uvol_ctx_create(device0 + g, &prm, &ctxs[g]) != UVOL_OK || uvol_ctx_create(device0 + g, &prm, &tctxs[g]) != UVOL_OK) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
+  // (+ one ingest context per GPU when the OBJ text is parsed on the device: contexts are independent, so batch b + 1 is parsed while the
+  // geometry context's enqueued call encodes batch b)
+  std::vector<uvol_ctx *> ctxs((size_t)n_gpus, nullptr), tctxs((size_t)n_gpus, nullptr), pctxs((size_t)n_gpus, nullptr);
+  for (int g = 0; g < n_gpus; g++) if (uvol_ctx_create(device0 + g, &prm, &ctxs[g]) != UVOL_OK || uvol_ctx_create(device0 + g, &prm, &tctxs[g]) != UVOL_OK ||
+                                       (!host_obj && !cfg.obj_files_path.empty() && uvol_ctx_create(device0 + g, &prm, &pctxs[g]) != UVOL_OK)) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
   // default: the CPUs this process may use (cgroup quota aware) shared by the two stages of every GPU.  Measured under a 16-CPU
   // quota (960 frames): 177 / 182 / 179 / 173 / 134 frames/s with 8 / 12 / 16 / 24 / 64 threads per stage
   if (ingest_threads <= 0) ingest_threads = (int)std::max(1u, std::min(48u, effective_cpus() / (2u * (unsigned)n_gpus)));
@@ -123,23 +127,30 @@ int main(int argc, char **argv) {
     // of batch b+1 is parsed by the ingest threads while the GPU encodes batch b, .drc files are written in parallel.
     // Two batch objects per GPU are recycled (the one being loaded, the one being encoded): their meshes, the ingest workers' scratch
     // buffers and the output buffers keep their capacity, so after the first two batches the stage allocates nothing.
-    struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; std::vector<std::unique_ptr<uint8_t[]>> outs; std::vector<size_t> ocap; };
+    struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; std::vector<std::unique_ptr<uint8_t[]>> outs; std::vector<size_t> ocap;
+                      std::vector<std::vector<uint8_t>> text;              // device parser: the files as they are
+                      std::vector<uvol_mesh> um; std::vector<uint8_t *> op; std::vector<size_t> caps, lens; std::vector<int> st, pst; };
     for (int g = 0; g < n_gpus; g++) geo_threads.emplace_back([&, g] {
       const std::vector<std::string> &files = obj_files;
       const ShardPlan sp = shard_plan((long)files.size(), B, n_gpus, g);
       const size_t lo = (size_t)sp.first_frame, hi = lo + (size_t)sp.n_frames;
-      std::shared_ptr<GeoBatch> pool[2] = { std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>() }; size_t n_loads = 0;
-      std::vector<IngestScratch> scratch((size_t)std::max(1, ingest_threads));
+      // three batch objects in turn: the one being encoded, the next one (loaded, then prepared while the GPU works) and the one being loaded
+      std::shared_ptr<GeoBatch> pool[3] = { std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>() }; size_t n_loads = 0;
+      std::vector<IngestScratch> scratch((size_t)std::max(1, ingest_threads)); IngestScratch fb_scratch;
       auto load = [&](size_t b0, size_t slot) {
         std::shared_ptr<GeoBatch> Bt = pool[slot]; Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; Bt->bad = -1; Bt->err.clear();
         if (Bt->ms.size() < Bt->nb) Bt->ms.resize(Bt->nb);
         std::mutex mu;
         const double tl0 = now_ms();
+        if (!host_obj) {                                     // the GPU parses: the ingest threads only read the files
+          if (Bt->text.size() < Bt->nb) Bt->text.resize(Bt->nb);
+          parallel_for_w(Bt->nb, ingest_threads, [&](size_t k, size_t) { if (!read_file(join(obj_dir, files[b0 + k]), Bt->text[k]) || Bt->text[k].empty()) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = "cannot read " + files[b0 + k]; } } });
+        } else
         parallel_for_w(Bt->nb, ingest_threads, [&](size_t k, size_t w) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), Bt->ms[k], e, &scratch[w])) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = e; } } });
         if (g_timing && Bt->nb) std::fprintf(stderr, "[uvolenc-timing] geo load  b0=%zu n=%zu %.0f ms\n", b0, Bt->nb, now_ms() - tl0);
         return Bt;
       };
-      std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) & 1);
+      std::future<std::shared_ptr<GeoBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) % 3);
       // The GPU call is ENQUEUED (uvol_encode_mesh_batch_async): while the device encodes batch b this thread writes the .drc files of
       // batch b - 1 (and the ingest threads parse batch b + 1), then uvol_sync completes batch b.  A batch object's output buffers are
       // next written by the encode of batch b + 2, after its files are on disk.
@@ -151,32 +162,76 @@ int main(int argc, char **argv) {
         prev.nb = 0;
         if (wbad >= 0 && geo_failed < 0) geo_failed = wbad.load();                        // (the first error stands)
       };
-      for (size_t b0 = lo; b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
-        const double tw0 = now_ms();
-        std::shared_ptr<GeoBatch> Bt = nextb.get();
-        const double tw1 = now_ms();
-        nextb = std::async(std::launch::async, load, b0 + (size_t)frames_per_batch, (n_loads++) & 1);      // the other object: the previous batch is done with its meshes
-        const size_t nb = Bt->nb;
-        if (Bt->bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)Bt->bad].c_str(), Bt->err.c_str()); geo_failed = (int)(b0 + (size_t)Bt->bad); break; }
-        std::vector<uvol_mesh> um(nb); std::vector<std::unique_ptr<uint8_t[]>> &outs = Bt->outs; if (outs.size() < nb) { outs.resize(nb); Bt->ocap.resize(nb, 0); }
-        std::vector<uint8_t *> op(nb); std::vector<size_t> caps(nb), lens(nb); std::vector<int> st(nb);
-        for (size_t k = 0; k < nb; k++) {
-          const ObjMesh &o = Bt->ms[k]; uvol_mesh &m = um[k]; std::memset(&m, 0, sizeof m);
-          m.pos = o.pos.data(); m.n_pos = (uint32_t)o.pos.size() / 3; m.idx_pos = o.idx_pos.data(); m.n_faces = (uint32_t)o.idx_pos.size() / 3;
-          if (!o.uv.empty()) { m.uv = o.uv.data(); m.n_uv = (uint32_t)o.uv.size() / 2; m.idx_uv = o.idx_uv.data(); }
-          if (!o.nrm.empty()) { m.nrm = o.nrm.data(); m.n_nrm = (uint32_t)o.nrm.size() / 3; m.idx_nrm = o.idx_nrm.data(); }
-          caps[k] = uvol_mesh_bound(&m); if (Bt->ocap[k] < caps[k]) { outs[k].reset(new uint8_t[caps[k]]); Bt->ocap[k] = caps[k]; } op[k] = outs[k].get();   // (not zero-filled: the bound is a worst case)
+      // Prepares a loaded batch for the encode call: (device parser) uploads + parses the OBJ text on the ingest context into slot `slot` -
+      // files the device parser hands back (UVOL_E_UNSUPPORTED: a number it cannot decide exactly) are parsed by read_obj and encoded from
+      // host arrays afterwards -, fills the mesh / output arrays of the batch object.  false: a frame failed (message printed).
+      auto prepare = [&](GeoBatch &Bt, int slot) -> bool {
+        const size_t nb = Bt.nb, b0 = Bt.b0;
+        if (Bt.bad >= 0) { std::printf("Failed to compress %s\n%s\n", files[b0 + (size_t)Bt.bad].c_str(), Bt.err.c_str()); geo_failed = (int)(b0 + (size_t)Bt.bad); return false; }
+        Bt.um.assign(nb, uvol_mesh{}); Bt.op.assign(nb, nullptr); Bt.caps.assign(nb, 0); Bt.lens.assign(nb, 0); Bt.st.assign(nb, 0); Bt.pst.assign(nb, 0);
+        if (Bt.outs.size() < nb) { Bt.outs.resize(nb); Bt.ocap.resize(nb, 0); }
+        if (!host_obj) {
+          std::vector<const uint8_t *> tp(nb); std::vector<size_t> tl(nb);
+          for (size_t k = 0; k < nb; k++) { tp[k] = Bt.text[k].data(); tl[k] = Bt.text[k].size(); }
+          const int rc = uvol_parse_obj_batch_dev(pctxs[g], tp.data(), tl.data(), (int)nb, slot, Bt.um.data(), Bt.pst.data());
+          if (rc != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(pctxs[g])); geo_failed = (int)b0; return false; }
+          if (Bt.ms.size() < nb) Bt.ms.resize(nb);
+          for (size_t k = 0; k < nb; k++) {
+            if (Bt.pst[k] == UVOL_OK) continue;
+            std::string e;                                                      // the host parser decides (and words the error)
+            if (!read_obj(join(obj_dir, files[b0 + k]), Bt.ms[k], e, &fb_scratch)) { std::printf("Failed to compress %s\n%s\n", files[b0 + k].c_str(), e.c_str()); geo_failed = (int)(b0 + k); return false; }
+            Bt.pst[k] = UVOL_E_UNSUPPORTED;                                     // parsed on the host: encoded from host arrays (below)
+          }
         }
+        for (size_t k = 0; k < nb; k++) {
+          uvol_mesh &m = Bt.um[k];
+          if (host_obj || Bt.pst[k] != UVOL_OK) {
+            const ObjMesh &o = Bt.ms[k]; std::memset(&m, 0, sizeof m);
+            m.pos = o.pos.data(); m.n_pos = (uint32_t)o.pos.size() / 3; m.idx_pos = o.idx_pos.data(); m.n_faces = (uint32_t)o.idx_pos.size() / 3;
+            if (!o.uv.empty()) { m.uv = o.uv.data(); m.n_uv = (uint32_t)o.uv.size() / 2; m.idx_uv = o.idx_uv.data(); }
+            if (!o.nrm.empty()) { m.nrm = o.nrm.data(); m.n_nrm = (uint32_t)o.nrm.size() / 3; m.idx_nrm = o.idx_nrm.data(); }
+          }
+          Bt.caps[k] = uvol_mesh_bound(&m); if (Bt.ocap[k] < Bt.caps[k]) { Bt.outs[k].reset(new uint8_t[Bt.caps[k]]); Bt.ocap[k] = Bt.caps[k]; } Bt.op[k] = Bt.outs[k].get();   // (not zero-filled: the bound is a worst case)
+        }
+        return true;
+      };
+      // enqueue the batch: device-parsed frames through the _dev entry point (contiguous runs), host-parsed ones through the host entry point
+      auto enqueue = [&](GeoBatch &Bt) -> int {
+        const size_t nb = Bt.nb;
+        for (size_t a = 0; a < nb;) {
+          const bool dev = !host_obj && Bt.pst[a] == UVOL_OK; size_t b = a + 1;
+          while (b < nb && (!host_obj && Bt.pst[b] == UVOL_OK) == dev) b++;
+          const int rc = (dev ? uvol_encode_mesh_batch_dev_async : uvol_encode_mesh_batch_async)(ctxs[g], Bt.um.data() + a, (int)(b - a), Bt.op.data() + a, Bt.caps.data() + a, Bt.lens.data() + a, Bt.st.data() + a);
+          if (rc != UVOL_OK) return rc;
+          a = b;
+        }
+        return UVOL_OK;
+      };
+      std::shared_ptr<GeoBatch> cur = lo < hi ? nextb.get() : nullptr; size_t n_prep = 0;
+      if (cur) { nextb = std::async(std::launch::async, load, lo + (size_t)frames_per_batch, (n_loads++) % 3); if (!prepare(*cur, (int)((n_prep++) & 1))) cur = nullptr; }
+      for (size_t b0 = lo; cur && b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
+        GeoBatch &Bt = *cur; const size_t nb = Bt.nb;
         const double te0 = now_ms();
-        int rc = uvol_encode_mesh_batch_async(ctxs[g], um.data(), (int)nb, op.data(), caps.data(), lens.data(), st.data());
+        int rc = enqueue(Bt);
         write_prev();                                                                  // the previous batch's files, while the GPU works
         const double te1 = now_ms();
+        // ... and the NEXT batch: its files are read (ingest threads), its text uploaded and parsed (ingest context) while this one encodes
+        std::shared_ptr<GeoBatch> nxt; bool nxt_ok = true;
+        if (b0 + (size_t)frames_per_batch < hi) {
+          nxt = nextb.get();
+          nextb = std::async(std::launch::async, load, b0 + 2 * (size_t)frames_per_batch, (n_loads++) % 3);      // (the object of batch b - 1: its files are written, its meshes done with)
+          if (rc == UVOL_OK) nxt_ok = prepare(*nxt, (int)((n_prep++) & 1));
+        }
+        const double te2 = now_ms();
         if (rc == UVOL_OK) rc = uvol_sync(ctxs[g]);
-        if (rc != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); geo_failed = (int)b0; break; }
-        for (size_t k = 0; k < nb; k++) if (st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); geo_failed = (int)(b0 + k); break; }   // scripts/Encoder.py:263-266
-        if (geo_failed >= 0) break;
-        prev.outs = &outs; prev.lens = lens; prev.b0 = b0; prev.nb = nb;
-        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] geo batch b0=%zu: waited for load %.0f ms, prepare %.0f, write of the previous batch (GPU busy) %.0f, waited for the GPU %.0f\n", b0, tw1 - tw0, te0 - tw1, te1 - te0, now_ms() - te1);
+        if (rc != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(ctxs[g])); if (geo_failed < 0) geo_failed = (int)b0; break; }
+        for (size_t k = 0; k < nb; k++) if (Bt.st[k] != UVOL_OK) { std::printf("Failed to compress %s\n", files[b0 + k].c_str()); if (geo_failed < 0 || (int)(b0 + k) < geo_failed) geo_failed = (int)(b0 + k); break; }   // scripts/Encoder.py:263-266
+        if (geo_failed >= 0 && !nxt_ok) break;
+        if (geo_failed >= 0 && (size_t)geo_failed >= b0 && (size_t)geo_failed < b0 + nb) break;
+        prev.outs = &Bt.outs; prev.lens = Bt.lens; prev.b0 = b0; prev.nb = nb;
+        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] geo batch b0=%zu: enqueue + write of the previous batch %.0f ms, load + prepare of the next (GPU busy) %.0f, waited for the GPU %.0f\n", b0, te1 - te0, te2 - te1, now_ms() - te2);
+        if (!nxt_ok) break;
+        cur = nxt;
       }
       write_prev();          // also after a failure: the batch before the failing one was encoded and is written, as the reference's frame-at-a-time loop would have left it (scripts/Encoder.py:256-267)
       if (nextb.valid()) nextb.wait();
@@ -276,6 +331,7 @@ int main(int argc, char **argv) {
   for (auto &t : tex_threads) t.join();
   for (auto *c : ctxs) uvol_ctx_destroy(c);
   for (auto *c : tctxs) uvol_ctx_destroy(c);
+  for (auto *c : pctxs) if (c) uvol_ctx_destroy(c);
   if (geo_failed >= 0 || tex_failed >= 0) return 1;
   const double t_encode = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   if (!cfg.obj_files_path.empty()) cfg.draco_files_path = join(geo_dir, std::string((size_t)pad, '#') + ".drc");
