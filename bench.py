@@ -387,7 +387,9 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     # (2c) one blocking geometry call per pass (the whole call is one group on the context's first lane, which then holds a workspace of
     #      the full call: run last among the device-input variants)
     note("blocking_calls")
-    v["blocking_calls"] = dict(Job(F, blocking=True).timed(2, 1), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
+    kb = max(2, min(args.steps, 4))
+    v["blocking_calls"] = dict(Job(F, blocking=True).timed(kb, 1), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
+    v["blocking_calls"]["enqueued_same_passes"] = Job(F).timed(kb, 1)["frames_per_s"]      # (short runs flatter both: the texture context finishes its passes early)
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
     note("host_inputs")
     frame_t.clear(); keep.clear(); del dev_meshes[:]
