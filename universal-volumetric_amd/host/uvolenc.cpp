@@ -102,7 +102,13 @@ int main(int argc, char **argv) {
                                        (!host_obj && !cfg.obj_files_path.empty() && uvol_ctx_create(device0 + g, &prm, &pctxs[g]) != UVOL_OK)) { std::printf("❌ cannot create codec context on GPU %d\n", device0 + g); return 1; }
   // default: the CPUs this process may use (cgroup quota aware) shared by the two stages of every GPU.  Measured under a 16-CPU
   // quota (960 frames): 177 / 182 / 179 / 173 / 134 frames/s with 8 / 12 / 16 / 24 / 64 threads per stage
+  const bool threads_given = ingest_threads > 0;
   if (ingest_threads <= 0) ingest_threads = (int)std::max(1u, std::min(48u, effective_cpus() / (2u * (unsigned)n_gpus)));
+  // With the OBJ text parsed on the device the geometry stage's host work is reading files (~0.3 ms per frame and thread against 20 ms
+  // for the parse), while a PNG still costs ~35 ms of inflate + un-filter: the CPUs go to the texture stage (measured, 960 frames under a
+  // 16-CPU quota: 8 + 8 threads 183 frames/s - the texture stage alone bounds it at 120 frames per 525 ms).
+  int geo_ingest = ingest_threads, tex_ingest = ingest_threads;
+  if (!threads_given && !host_obj && !cfg.obj_files_path.empty() && !cfg.images_path.empty()) { const int tot = 2 * ingest_threads; geo_ingest = std::max(1, tot / 6); tex_ingest = std::max(1, tot - geo_ingest); }
 
   std::printf("🎯 Dealing with Geomety data\n");
   if (!cfg.abc_file_path.empty()) { std::printf("❌ ABCFilePath needs Blender (bpy); export OBJ files and use OBJFilesPath\n"); return 1; }
@@ -136,7 +142,7 @@ int main(int argc, char **argv) {
       const size_t lo = (size_t)sp.first_frame, hi = lo + (size_t)sp.n_frames;
       // three batch objects in turn: the one being encoded, the next one (loaded, then prepared while the GPU works) and the one being loaded
       std::shared_ptr<GeoBatch> pool[3] = { std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>() }; size_t n_loads = 0;
-      std::vector<IngestScratch> scratch((size_t)std::max(1, ingest_threads)); IngestScratch fb_scratch;
+      std::vector<IngestScratch> scratch((size_t)std::max(1, geo_ingest)); IngestScratch fb_scratch;
       auto load = [&](size_t b0, size_t slot) {
         std::shared_ptr<GeoBatch> Bt = pool[slot]; Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; Bt->bad = -1; Bt->err.clear();
         if (Bt->ms.size() < Bt->nb) Bt->ms.resize(Bt->nb);
@@ -144,9 +150,9 @@ int main(int argc, char **argv) {
         const double tl0 = now_ms();
         if (!host_obj) {                                     // the GPU parses: the ingest threads only read the files
           if (Bt->text.size() < Bt->nb) Bt->text.resize(Bt->nb);
-          parallel_for_w(Bt->nb, ingest_threads, [&](size_t k, size_t) { if (!read_file(join(obj_dir, files[b0 + k]), Bt->text[k]) || Bt->text[k].empty()) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = "cannot read " + files[b0 + k]; } } });
+          parallel_for_w(Bt->nb, geo_ingest, [&](size_t k, size_t) { if (!read_file(join(obj_dir, files[b0 + k]), Bt->text[k]) || Bt->text[k].empty()) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = "cannot read " + files[b0 + k]; } } });
         } else
-        parallel_for_w(Bt->nb, ingest_threads, [&](size_t k, size_t w) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), Bt->ms[k], e, &scratch[w])) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = e; } } });
+        parallel_for_w(Bt->nb, geo_ingest, [&](size_t k, size_t w) { std::string e; if (!read_obj(join(obj_dir, files[b0 + k]), Bt->ms[k], e, &scratch[w])) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = e; } } });
         if (g_timing && Bt->nb) std::fprintf(stderr, "[uvolenc-timing] geo load  b0=%zu n=%zu %.0f ms\n", b0, Bt->nb, now_ms() - tl0);
         return Bt;
       };
@@ -158,7 +164,7 @@ int main(int argc, char **argv) {
       auto write_prev = [&]() {
         if (!prev.outs || !prev.nb) return;
         std::atomic<int> wbad{-1};
-        parallel_for(prev.nb, ingest_threads, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, prev.b0 + k); if (!write_file(join(geo_dir, name), (*prev.outs)[k].get(), prev.lens[k])) wbad = (int)(prev.b0 + k); });
+        parallel_for(prev.nb, geo_ingest, [&](size_t k) { char name[64]; std::snprintf(name, sizeof name, "%0*zu.drc", pad, prev.b0 + k); if (!write_file(join(geo_dir, name), (*prev.outs)[k].get(), prev.lens[k])) wbad = (int)(prev.b0 + k); });
         prev.nb = 0;
         if (wbad >= 0 && geo_failed < 0) geo_failed = wbad.load();                        // (the first error stands)
       };
@@ -256,7 +262,7 @@ int main(int argc, char **argv) {
     for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
       const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;       // = shard_plan's segment block
       std::shared_ptr<TexBatch> pool[2] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
-      std::vector<IngestScratch> scratch((size_t)std::max(1, ingest_threads));
+      std::vector<IngestScratch> scratch((size_t)std::max(1, tex_ingest));
       auto load = [&](size_t s0, size_t slot) {
         std::shared_ptr<TexBatch> T = pool[slot]; T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->bad = -1; T->err.clear();
         // recycled Image objects keep their 16.8 MB pixel buffers (a short last segment shrinks imgs[s]; the layers come back from `spare`)
@@ -265,7 +271,7 @@ int main(int argc, char **argv) {
         for (auto &v : T->imgs) { v.resize((size_t)B); for (auto &im : v) if (!T->spare.empty()) { im = std::move(T->spare.back()[0]); T->spare.pop_back(); } }
         const double tl0 = now_ms();
         std::mutex mu; std::vector<std::vector<uint8_t>> present(T->ns, std::vector<uint8_t>((size_t)B, 0));
-        parallel_for_w(T->ns * (size_t)B, ingest_threads, [&](size_t j, size_t wk) {
+        parallel_for_w(T->ns * (size_t)B, tex_ingest, [&](size_t j, size_t wk) {
           const size_t s = j / (size_t)B; const int k = (int)(j % (size_t)B);
           char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s0 + s] + k));
           std::string e;
@@ -305,7 +311,7 @@ int main(int argc, char **argv) {
         if (g_timing) std::fprintf(stderr, "[uvolenc-timing] tex batch s0=%zu: waited for load %.0f ms, encode (+prepare) %.0f\n", s0, tw1 - tw0, now_ms() - tw1);
         if (tex_failed >= 0) break;
         std::atomic<int> wbad{-1};
-        parallel_for(T->ns, ingest_threads, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].get(), lens[s])) wbad = starts[s0 + s]; });
+        parallel_for(T->ns, tex_ingest, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].get(), lens[s])) wbad = starts[s0 + s]; });
         if (wbad >= 0) { tex_failed = wbad.load(); break; }
         // raw `etc2` target (src/V2/player.ts:338-356): every layer of the segments just written, transcoded on the GPU to ETC1 blocks
         // (valid ETC2 RGB), one .etc2 file per FRAME (the player builds one CompressedTexture per file)
@@ -366,6 +372,6 @@ int main(int argc, char **argv) {
   if (std::fmod(cfg.geometry_frame_rate, cfg.texture_frame_rate) != 0 && std::fmod(cfg.texture_frame_rate, cfg.geometry_frame_rate) != 0)      // scripts/Encoder.py:368-373
     std::printf("⚠️ Warning: Frame rates are not factors of one another. Ambiguities may arise when calulating appropriate texture for geometry frames.\n");
   // machine-readable timing of the encode phase (files read -> all .drc / .ktx2 written), for the end-to-end figure of SURVEY §8d
-  std::printf("[uvolenc] frames %ld, encode phase %.3f s, %.1f frames/s, %d GPU(s), %d ingest threads per stage\n", fc.geometry_frames, t_encode, t_encode > 0 ? (double)fc.geometry_frames / t_encode : 0.0, n_gpus, ingest_threads);
+  std::printf("[uvolenc] frames %ld, encode phase %.3f s, %.1f frames/s, %d GPU(s), %d + %d ingest threads (geometry + texture stage)\n", fc.geometry_frames, t_encode, t_encode > 0 ? (double)fc.geometry_frames / t_encode : 0.0, n_gpus, geo_ingest, tex_ingest);
   return 0;
 }
