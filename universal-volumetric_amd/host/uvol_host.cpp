@@ -556,8 +556,9 @@ int uvolh_read_obj_arrays(const char *path, float *pos, float *uv, float *nrm, u
   uvolh::ObjMesh m; std::string err; if (!uvolh::read_obj(path, m, err)) return -1;
   counts6[0] = (unsigned)m.pos.size() / 3; counts6[1] = (unsigned)m.uv.size() / 2; counts6[2] = (unsigned)m.nrm.size() / 3;
   counts6[3] = (unsigned)m.idx_pos.size() / 3; counts6[4] = (unsigned)m.idx_uv.size() / 3; counts6[5] = (unsigned)m.idx_nrm.size() / 3;
-  if (pos) std::memcpy(pos, m.pos.data(), m.pos.size() * 4); if (uv) std::memcpy(uv, m.uv.data(), m.uv.size() * 4); if (nrm) std::memcpy(nrm, m.nrm.data(), m.nrm.size() * 4);
-  if (ip) std::memcpy(ip, m.idx_pos.data(), m.idx_pos.size() * 4); if (iu) std::memcpy(iu, m.idx_uv.data(), m.idx_uv.size() * 4); if (in_) std::memcpy(in_, m.idx_nrm.data(), m.idx_nrm.size() * 4);
+  auto put = [](void *d, const void *s_, size_t n) { if (d) std::memcpy(d, s_, n); };
+  put(pos, m.pos.data(), m.pos.size() * 4); put(uv, m.uv.data(), m.uv.size() * 4); put(nrm, m.nrm.data(), m.nrm.size() * 4);
+  put(ip, m.idx_pos.data(), m.idx_pos.size() * 4); put(iu, m.idx_uv.data(), m.idx_uv.size() * 4); put(in_, m.idx_nrm.data(), m.idx_nrm.size() * 4);
   return 0;
 }
 int uvolh_read_png(const char *path, unsigned *wh, unsigned char *rgba, size_t cap) {
