@@ -119,6 +119,16 @@ int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
 int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, const size_t *lens, int n, int slot,
                              uvol_mesh *meshes_out, int *status);
 
+/* The PNG half of the ingest stage (`basisu` reads the PNGs itself, scripts/Encoder.py:274-292): n images of one size as INFLATED
+ * scanlines in host memory - what zlib gives for the concatenated IDAT chunks of an 8-bit, non-interlaced RGB (channels 3) or RGBA (4)
+ * PNG: height rows of one filter-type byte + width * channels filtered bytes - are un-filtered on the device (Sub / Up / Average /
+ * Paeth, bit-identical to the host reader) into RGBA8 layers, top row first, in the context's slot `slot` (0 / 1; valid until that slot
+ * is used again): rgba_dev_out[i] is what uvol_encode_texture_segments_dev takes.  The inflate stays with the caller (one serial bit
+ * stream per file; the files of a batch inflate in parallel on host threads).  Other PNG variants (16-bit, palette, grey, interlaced,
+ * wider than 8192): decode them on the host.  Blocking, on the context's stream. */
+int uvol_unfilter_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *inflated, int n, uint32_t width, uint32_t height, int channels,
+                                int slot, const uint8_t **rgba_dev_out);
+
 /* GPU-resident form (SURVEY 8(b) "variants taking arrays of frames + hipStream_t"; caller-owned buffers as in
  * deprecated/encoder_legacy/codec/corto_codec.h:41-43): inputs are device pointers PRODUCED ON `producer_stream` (a hipStream_t passed
  * as void *, NULL = already complete) - the codec's kernels are ordered after the work queued on that stream so far, without a host

@@ -117,6 +117,27 @@ def test_gpu_batched_segments_equal_single_calls(oracle, gpu_codec):
         assert r == oracle.ktx2_encode(seg)
 
 
+def test_gpu_png_scanlines_unfiltered_on_the_device(oracle, gpu_codec):
+    """SURVEY 8 f-3 / VERDICT r3 #8 on the GPU: inflated PNG scanlines (every filter type, seeded random per row; RGB and RGBA; odd sizes
+    and 2048^2) un-filtered by k_png_unfilter = the source pixels, and encoded from HBM = the oracle's bytes."""
+    import ctypes as C, synth
+    from test_hipemu_tex import png_scanlines
+    hip = C.CDLL("libamdhip64.so")
+    def d2h(ptr, n):
+        a = np.empty(n, np.uint8); assert hip.hipMemcpy(C.c_void_p(a.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), C.c_int(2)) == 0; return a
+    rng = np.random.default_rng(22)
+    for (h, w, c, n) in ((37, 53, 4, 3), (50, 3, 3, 2), (1, 1, 4, 1), (2048, 2048, 4, 2), (1000, 1500, 3, 1)):
+        imgs = [(np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] + rng.integers(0, 40, (h, w, c))).astype(np.uint8) for _ in range(n)]
+        ptrs = gpu_codec.unfilter_png_batch_dev([png_scanlines(a, rng) for a in imgs], w, h, c, slot=n & 1)
+        for a, p in zip(imgs, ptrs):
+            got = d2h(p, h * w * 4).reshape(h, w, 4)
+            want = np.concatenate([a, np.full((h, w, 1), 255, np.uint8)], -1) if c == 3 else a
+            assert np.array_equal(got, want), (h, w, c)
+    tex = synth.texture_sequence(2, size=256, seed=4)
+    ptrs = gpu_codec.unfilter_png_batch_dev([png_scanlines(t, rng) for t in tex], 256, 256, 4, slot=0)
+    assert gpu_codec.encode_texture_segment_dev(ptrs, 256, 256) == oracle.ktx2_encode(tex)
+
+
 def test_gpu_host_segments_in_parts_on_two_lanes(oracle, gpu_codec):
     """Round 4: a call of >= 128 segments on HOST inputs is cut into parts that alternate between two lanes (part k + 1 uploads while
     part k encodes).  132 segments of 64^2 x 2 (one of them with alpha: second pass on its lane): every segment equals the oracle's

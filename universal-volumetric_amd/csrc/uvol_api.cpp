@@ -130,7 +130,7 @@ int uvol_ctx_create(int device, const uvol_params *params, uvol_ctx **out) {
   if (ctx->prm.max_batch <= 0) ctx->prm.max_batch = 32;
   if (ctx->prm.etc1s_quality <= 0) ctx->prm.etc1s_quality = 128;
   if (uvol_make_stream(ctx, &ctx->stream) != hipSuccess) { delete ctx; return UVOL_E_HIP; }
-  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK || uastc_create(ctx) != UVOL_OK || obj_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
+  if (geo_create(ctx) != UVOL_OK || tex_create(ctx) != UVOL_OK || texdec_create(ctx) != UVOL_OK || geodec_create(ctx) != UVOL_OK || uastc_create(ctx) != UVOL_OK || obj_create(ctx) != UVOL_OK || png_create(ctx) != UVOL_OK) { uvol_ctx_destroy(ctx); return UVOL_E_HIP; }
   *out = ctx;
   return UVOL_OK;
 }
@@ -141,7 +141,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
-  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx);
+  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx); png_destroy(ctx);
   for (int k = 0; k < 2; k++) { if (ctx->up_pin[k]) (void)hipHostFree(ctx->up_pin[k]); if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -351,6 +351,13 @@ int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, cons
   if (!ctx || !obj_text || !lens || n < 0 || !meshes_out) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return obj_parse_batch(ctx, obj_text, lens, n, slot, meshes_out, status);
+}
+
+int uvol_unfilter_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *inflated, int n, uint32_t width, uint32_t height, int channels, int slot, const uint8_t **rgba_dev_out) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !inflated || n < 0 || !rgba_dev_out) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return png_unfilter_batch(ctx, inflated, n, width, height, channels, slot, rgba_dev_out);
 }
 
 int uvol_encode_mesh_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, void *producer_stream,

@@ -147,6 +147,7 @@ struct TexDecState;  // texture decode state (tex_decode.hip)
 struct GeoDecState;  // geometry decode state (geom_decode.hip)
 struct UastcState;   // UASTC texture mode (tex_uastc.hip)
 struct ObjState;     // OBJ text ingest on the device (obj_ingest.hip)
+struct PngState;     // PNG scanlines un-filtered on the device (png_ingest.hip)
 
 struct uvol_ctx {
   int device = 0;
@@ -163,6 +164,7 @@ struct uvol_ctx {
   GeoDecState *geodec = nullptr;
   UastcState *uastc = nullptr;
   ObjState *obj = nullptr;
+  PngState *png = nullptr;
   // enqueue form of the ABI (uvol_*_async + uvol_sync): calls run in order on this context's worker thread
   struct AsyncQ {
     std::mutex m; std::condition_variable cv_work, cv_idle; std::deque<std::function<int()>> q; std::thread th; bool busy = false, stop = false; int first_err = 0; char err[512] = {0};
@@ -235,6 +237,9 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
 int obj_create(uvol_ctx *ctx);
 void obj_destroy(uvol_ctx *ctx);
 int obj_parse_batch(uvol_ctx *ctx, const uint8_t *const *texts, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status);
+int png_create(uvol_ctx *ctx);
+void png_destroy(uvol_ctx *ctx);
+int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out);
 int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);
 #define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */

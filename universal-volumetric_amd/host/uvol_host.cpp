@@ -406,6 +406,28 @@ bool read_png(const std::string &path, Image &img, std::string &err, IngestScrat
   return true;
 }
 
+int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestScratch *scratch) {
+  IngestScratch local; IngestScratch &S = scratch ? *scratch : local;
+  std::vector<uint8_t> &d = S.file; if (!read_file(path, d)) { err = "cannot read " + path; return -1; }
+  static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
+  if (d.size() < 33 || std::memcmp(d.data(), sig, 8)) { err = path + ": not a PNG"; return -1; }
+  auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
+  uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0; std::vector<uint8_t> &idat = S.idat; idat.clear();
+  for (size_t o = 8; o + 12 <= d.size();) {
+    uint32_t len = be32(o); if (o + 12 + len > d.size()) break;
+    const char *t = (const char *)&d[o + 4]; const uint8_t *body = &d[o + 8];
+    if (!std::memcmp(t, "IHDR", 4) && len >= 13) { w = be32(o + 8); h = be32(o + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+    else if (!std::memcmp(t, "IDAT", 4)) { if (idat.empty()) idat.reserve(d.size()); idat.insert(idat.end(), body, body + len); }
+    else if (!std::memcmp(t, "IEND", 4)) break;
+    o += 12 + len;
+  }
+  if (!w || !h || interlace || depth != 8 || (ctype != 2 && ctype != 6) || w > 8192 || h > 16384) return 0;        // read_png decides (and words the errors)
+  out.w = w; out.h = h; out.ch = ctype == 2 ? 3 : 4;
+  out.raw.resize(((size_t)w * out.ch + 1) * h);
+  if (!inflate_zlib_stream(idat.data(), idat.size(), out.raw.data(), out.raw.size())) { err = path + ": zlib inflate failed"; return -1; }
+  return 1;
+}
+
 // ------------------------------------------------------------------ frame accounting (scripts/Encoder.py:103-154)
 static void split_path(const std::string &p, std::string &dir, std::string &base) { size_t k = p.find_last_of('/'); if (k == std::string::npos) { dir = ""; base = p; } else { dir = p.substr(0, k); base = p.substr(k + 1); } }
 bool check_total_frames(const std::string &drc_pat, const std::string &ktx2_pat, int batch, double geo_rate, double tex_rate, FrameCounts &out, std::string &err) {

@@ -58,13 +58,14 @@ int main(int argc, char **argv) {
   }
   const auto t_start = std::chrono::steady_clock::now();
   { const char *e = std::getenv("UVOL_TIMING"); g_timing = e && *e == '1'; }
-  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false;
+  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false, host_png = false;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device0 = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--batch-frames") && i + 1 < argc) frames_per_batch = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) ingest_threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--force")) force = true;
+    else if (!std::strcmp(argv[i], "--host-png-unfilter")) host_png = true;       // PNG scanlines un-filtered by the ingest threads (as until round 3) instead of on the GPU
     else if (!std::strcmp(argv[i], "--host-obj-parser")) host_obj = true;          // OBJ text parsed by the ingest threads (as until round 3) instead of on the GPU
     else if (!std::strcmp(argv[i], "--uastc")) uastc = true;
     else if (!std::strcmp(argv[i], "--encoder-py-manifest")) encpy = true;
@@ -258,7 +259,8 @@ int main(int argc, char **argv) {
     // through the batched entry point (one launch per stage for all of them); PNGs of the next call are inflated by the
     // ingest threads meanwhile.  A short last segment (fewer layers) is encoded on its own.
     const int segs_per_call = std::max(1, frames_per_batch / std::max(1, cfg.ktx2_batch_size));
-    struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::vector<std::vector<Image>> spare; std::string err; int bad = -1; };
+    struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::vector<std::vector<Image>> spare; std::string err; int bad = -1;
+                      bool dev = false; std::vector<std::vector<PngRaw>> raws; };      // dev: the images are INFLATED scanlines, un-filtered on the GPU
     for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
       const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;       // = shard_plan's segment block
       std::shared_ptr<TexBatch> pool[2] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
@@ -271,6 +273,33 @@ int main(int argc, char **argv) {
         for (auto &v : T->imgs) { v.resize((size_t)B); for (auto &im : v) if (!T->spare.empty()) { im = std::move(T->spare.back()[0]); T->spare.pop_back(); } }
         const double tl0 = now_ms();
         std::mutex mu; std::vector<std::vector<uint8_t>> present(T->ns, std::vector<uint8_t>((size_t)B, 0));
+        // device un-filter: the ingest threads parse the chunks and inflate, nothing else; a batch with an image the device path does not take
+        // (16-bit, palette, grey, sizes that differ) is decoded by read_png as before
+        T->dev = false;
+        if (!host_png) {
+          if (T->raws.size() < T->ns) T->raws.resize(T->ns);
+          for (size_t s = 0; s < T->ns; s++) if (T->raws[s].size() < (size_t)B) T->raws[s].resize((size_t)B);
+          std::atomic<int> odd{0};
+          parallel_for_w(T->ns * (size_t)B, tex_ingest, [&](size_t j, size_t wk) {
+            const size_t s = j / (size_t)B; const int k = (int)(j % (size_t)B);
+            char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s0 + s] + k));
+            std::string e;
+            const int r = read_png_raw(path, T->raws[s][(size_t)k], e, &scratch[wk]);
+            if (r == 1) present[s][(size_t)k] = 1;
+            else if (r == 0) odd = 1;
+            else if (k == 0 || starts[s0 + s] + k < cfg.ktx2_file_count) { std::lock_guard<std::mutex> l(mu); if (T->bad < 0 || (int)s < T->bad) { T->bad = (int)s; T->err = e; } }
+          });
+          bool ok = !odd && T->bad < 0 && T->ns > 0 && present[0][0];
+          if (ok) { const PngRaw &r0 = T->raws[0][0]; for (size_t s = 0; s < T->ns && ok; s++) for (size_t k = 0; k < (size_t)B && ok; k++) if (present[s][k]) { const PngRaw &r = T->raws[s][k]; ok = r.w == r0.w && r.h == r0.h && r.ch == r0.ch; } }
+          if (ok) {
+            T->dev = true;
+            for (size_t s = 0; s < T->ns; s++) { size_t n = 0; while (n < (size_t)B && present[s][n]) n++; T->imgs[s].resize(n); for (size_t k = 0; k < n; k++) { T->imgs[s][k].w = T->raws[s][k].w; T->imgs[s][k].h = T->raws[s][k].h; } }
+            if (g_timing && T->ns) std::fprintf(stderr, "[uvolenc-timing] tex load  s0=%zu n=%zu segments %.0f ms (inflate only)\n", s0, T->ns, now_ms() - tl0);
+            return T;
+          }
+          if (T->bad >= 0) return T;                         // a file is missing: reported as before
+          for (auto &v : present) std::fill(v.begin(), v.end(), 0);
+        }
         parallel_for_w(T->ns * (size_t)B, tex_ingest, [&](size_t j, size_t wk) {
           const size_t s = j / (size_t)B; const int k = (int)(j % (size_t)B);
           char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s0 + s] + k));
@@ -297,16 +326,24 @@ int main(int argc, char **argv) {
         std::vector<std::unique_ptr<uint8_t[]>> outs(T->ns); std::vector<size_t> lens(T->ns, 0);
         // full segments: one batched call; segments with fewer layers: one call each
         std::vector<size_t> full; for (size_t s = 0; s < T->ns; s++) if ((int)T->imgs[s].size() == B) full.push_back(s);
+        // device un-filter: every image of the batch in one call, then the segments are encoded from HBM
+        std::vector<std::vector<const uint8_t *>> dptr(T->ns);
+        if (T->dev) {
+          std::vector<const uint8_t *> rp; for (size_t s = 0; s < T->ns; s++) for (size_t k = 0; k < T->imgs[s].size(); k++) rp.push_back(T->raws[s][k].raw.data());
+          std::vector<const uint8_t *> dp(rp.size(), nullptr);
+          if (uvol_unfilter_png_batch_dev(tctxs[g], rp.data(), (int)rp.size(), w, h, T->raws[0][0].ch, (int)((s0 / (size_t)segs_per_call) & 1), dp.data()) != UVOL_OK) { fail(starts[s0], uvol_last_error(tctxs[g])); break; }
+          size_t q = 0; for (size_t s = 0; s < T->ns; s++) for (size_t k = 0; k < T->imgs[s].size(); k++) dptr[s].push_back(dp[q++]);
+        }
         if (!full.empty()) {
           std::vector<const uint8_t *> ptrs; std::vector<uint8_t *> op; std::vector<size_t> caps, ln(full.size(), 0);
-          for (size_t s : full) { for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data()); const size_t cap = uvol_texture_bound(w, h, B); outs[s].reset(new uint8_t[cap]); op.push_back(outs[s].get()); caps.push_back(cap); }
-          if (uvol_encode_texture_segments(tctxs[g], ptrs.data(), (int)full.size(), B, w, h, op.data(), caps.data(), ln.data()) != UVOL_OK) { fail(starts[s0 + full[0]], uvol_last_error(tctxs[g])); break; }
+          for (size_t s : full) { for (size_t k = 0; k < T->imgs[s].size(); k++) ptrs.push_back(T->dev ? dptr[s][k] : T->imgs[s][k].rgba.data()); const size_t cap = uvol_texture_bound(w, h, B); outs[s].reset(new uint8_t[cap]); op.push_back(outs[s].get()); caps.push_back(cap); }
+          if ((T->dev ? uvol_encode_texture_segments_dev : uvol_encode_texture_segments)(tctxs[g], ptrs.data(), (int)full.size(), B, w, h, op.data(), caps.data(), ln.data()) != UVOL_OK) { fail(starts[s0 + full[0]], uvol_last_error(tctxs[g])); break; }
           for (size_t q = 0; q < full.size(); q++) lens[full[q]] = ln[q];
         }
         for (size_t s = 0; s < T->ns && tex_failed < 0; s++) if ((int)T->imgs[s].size() != B) {
-          std::vector<const uint8_t *> ptrs; for (auto &im : T->imgs[s]) ptrs.push_back(im.rgba.data());
+          std::vector<const uint8_t *> ptrs; for (size_t k = 0; k < T->imgs[s].size(); k++) ptrs.push_back(T->dev ? dptr[s][k] : T->imgs[s][k].rgba.data());
           const size_t cap = uvol_texture_bound(w, h, (int)ptrs.size()); outs[s].reset(new uint8_t[cap]);
-          if (uvol_encode_texture_segment(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].get(), cap, &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
+          if ((T->dev ? uvol_encode_texture_segment_dev : uvol_encode_texture_segment)(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].get(), cap, &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
         }
         if (g_timing) std::fprintf(stderr, "[uvolenc-timing] tex batch s0=%zu: waited for load %.0f ms, encode (+prepare) %.0f\n", s0, tw1 - tw0, now_ms() - tw1);
         if (tex_failed >= 0) break;

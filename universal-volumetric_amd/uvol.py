@@ -36,7 +36,7 @@ class Mesh(C.Structure):
 
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
            "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
-           "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_dev_out", "uvol_decode_mesh_batch_dev", "uvol_parse_obj_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
+           "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_dev_out", "uvol_decode_mesh_batch_dev", "uvol_parse_obj_batch_dev", "uvol_unfilter_png_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_etc2_rgba", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get"]
@@ -75,6 +75,7 @@ def load(path=None):
     L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_decode_mesh_batch_dev.argtypes = L.uvol_decode_mesh_batch.argtypes
+    L.uvol_unfilter_png_batch_dev.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.uvol_parse_obj_batch_dev.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(Mesh), C.POINTER(C.c_int)]
     L.uvol_encode_mesh_batch_dev_out.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -188,6 +189,15 @@ class Codec:
         if rc != UVOL_OK:
             raise UvolError(f"parse_obj_batch_dev rc={rc}: {self.error()}")
         return meshes, list(st)
+
+    def unfilter_png_batch_dev(self, inflated, width, height, channels, slot=0):
+        """inflated: list of bytes (the inflated IDAT stream of 8-bit RGB / RGBA PNGs of one size) -> list of DEVICE pointers to RGBA8 layers."""
+        raws = [bytes(r) for r in inflated]; n = len(raws)
+        rp = (C.c_char_p * n)(*raws); out = (C.c_void_p * n)()
+        rc = self.L.uvol_unfilter_png_batch_dev(self.h, rp, n, width, height, channels, slot, out)
+        if rc != UVOL_OK:
+            raise UvolError(f"unfilter_png_batch_dev rc={rc}: {self.error()}")
+        return [int(p) for p in out]
 
     def drc_info(self, data):
         nf, mv = C.c_uint32(), C.c_uint32()
