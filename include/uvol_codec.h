@@ -125,7 +125,9 @@ int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, cons
  * Paeth, bit-identical to the host reader) into RGBA8 layers, top row first, in the context's slot `slot` (0 / 1; valid until that slot
  * is used again): rgba_dev_out[i] is what uvol_encode_texture_segments_dev takes.  The inflate stays with the caller (one serial bit
  * stream per file; the files of a batch inflate in parallel on host threads).  Other PNG variants (16-bit, palette, grey, interlaced,
- * wider than 8192): decode them on the host.  Blocking, on the context's stream. */
+ * wider than 8192): decode them on the host.  The call returns once the kernel is queued on an ingest stream of the context (the host
+ * buffers may be re-used at once: they have been staged); the context's texture entry points order themselves behind it, a caller that
+ * reads the layers itself calls uvol_sync(ctx) first.  So the un-filter of batch k + 1 overlaps the encode of batch k. */
 int uvol_unfilter_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *inflated, int n, uint32_t width, uint32_t height, int channels,
                                 int slot, const uint8_t **rgba_dev_out);
 

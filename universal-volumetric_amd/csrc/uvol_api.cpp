@@ -154,6 +154,7 @@ int uvol_sync(uvol_ctx *ctx) {
   if (!ctx) return UVOL_E_INVALID;
   const int arc = async_drain(ctx);                        // every call enqueued with uvol_*_async has completed; first error among them
   (void)hipSetDevice(ctx->device);
+  { const int pr = png_wait(ctx); if (pr != UVOL_OK) return pr; }       // ... and the last un-filter call (its layers may be read by the caller from here on)
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
   return arc;

@@ -104,6 +104,14 @@
 #define UVOL_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
 
+// value of the lane one below within a row of 16 lanes (DPP row_shr:1: a register move, no LDS round trip; lanes 0 / 16 / 32 / 48 get 0
+// on the GPU and an unrelated value in the shim - callers do not use it there)
+#ifdef HIPEMU
+#define UVOL_ROW_SHR1(v) ((uint32_t)__shfl_up((int)(v), 1))
+#else
+#define UVOL_ROW_SHR1(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x111, 0xf, 0xf, false))
+#endif
+
 // occupancy target of a kernel (waves per SIMD): an attribute hipcc understands, nothing in the tests/hipemu build
 #ifdef HIPEMU
 #define UVOL_WAVES_PER_EU(n)
@@ -239,6 +247,8 @@ void obj_destroy(uvol_ctx *ctx);
 int obj_parse_batch(uvol_ctx *ctx, const uint8_t *const *texts, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status);
 int png_create(uvol_ctx *ctx);
 void png_destroy(uvol_ctx *ctx);
+int png_order_before(uvol_ctx *ctx, hipStream_t stream);
+int png_wait(uvol_ctx *ctx);
 int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out);
 int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);

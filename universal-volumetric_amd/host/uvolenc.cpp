@@ -260,10 +260,12 @@ int main(int argc, char **argv) {
     // ingest threads meanwhile.  A short last segment (fewer layers) is encoded on its own.
     const int segs_per_call = std::max(1, frames_per_batch / std::max(1, cfg.ktx2_batch_size));
     struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::vector<std::vector<Image>> spare; std::string err; int bad = -1;
-                      bool dev = false; std::vector<std::vector<PngRaw>> raws; };      // dev: the images are INFLATED scanlines, un-filtered on the GPU
+                      bool dev = false; std::vector<std::vector<PngRaw>> raws;        // dev: the images are INFLATED scanlines, un-filtered on the GPU
+                      std::vector<std::vector<const uint8_t *>> dptr; bool issued = false; };   // ... their RGBA layers in HBM once the un-filter call is queued
     for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
       const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;       // = shard_plan's segment block
-      std::shared_ptr<TexBatch> pool[2] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
+      // three batch objects in turn: the one being encoded, the next one (loaded; its un-filter queued beside this encode), the one being loaded
+      std::shared_ptr<TexBatch> pool[3] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
       std::vector<IngestScratch> scratch((size_t)std::max(1, tex_ingest));
       auto load = [&](size_t s0, size_t slot) {
         std::shared_ptr<TexBatch> T = pool[slot]; T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->bad = -1; T->err.clear();
@@ -312,12 +314,33 @@ int main(int argc, char **argv) {
         return T;
       };
       auto fail = [&](int first, const char *why) { std::printf("Failed to compress images with indices: [%d, %d]\n%s\n", first, first + B, why); tex_failed = first; };   // :293-298
-      std::future<std::shared_ptr<TexBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) & 1);
-      for (size_t s0 = lo; s0 < hi && tex_failed < 0; s0 += (size_t)segs_per_call) {
+      std::future<std::shared_ptr<TexBatch>> nextb = std::async(std::launch::async, load, lo, (n_loads++) % 3);
+      // device un-filter of a loaded batch: every image in one call, queued on the texture context's ingest stream (returns once the
+      // scanlines are staged); the encode calls order themselves behind it
+      size_t n_issue = 0;
+      auto issue = [&](TexBatch &Tb) -> bool {
+        Tb.issued = true; Tb.dptr.assign(Tb.ns, {});
+        if (!Tb.dev || Tb.bad >= 0) return true;
+        std::vector<const uint8_t *> rp; for (size_t s = 0; s < Tb.ns; s++) for (size_t k = 0; k < Tb.imgs[s].size(); k++) rp.push_back(Tb.raws[s][k].raw.data());
+        std::vector<const uint8_t *> dp(rp.size(), nullptr);
+        if (uvol_unfilter_png_batch_dev(tctxs[g], rp.data(), (int)rp.size(), Tb.raws[0][0].w, Tb.raws[0][0].h, Tb.raws[0][0].ch, (int)((n_issue++) & 1), dp.data()) != UVOL_OK) { fail(starts[Tb.s0], uvol_last_error(tctxs[g])); return false; }
+        size_t q = 0; for (size_t s = 0; s < Tb.ns; s++) for (size_t k = 0; k < Tb.imgs[s].size(); k++) Tb.dptr[s].push_back(dp[q++]);
+        return true;
+      };
+      std::shared_ptr<TexBatch> cur = lo < hi ? nextb.get() : nullptr;
+      if (cur) { nextb = std::async(std::launch::async, load, lo + (size_t)segs_per_call, (n_loads++) % 3); if (!issue(*cur)) cur = nullptr; }
+      for (size_t s0 = lo; cur && s0 < hi && tex_failed < 0; s0 += (size_t)segs_per_call) {
         const double tw0 = now_ms();
-        std::shared_ptr<TexBatch> T = nextb.get();
+        std::shared_ptr<TexBatch> T = cur;
+        // the NEXT batch: loaded (PNG chunks parsed + inflated) by the ingest threads by now or soon; its un-filter kernel runs beside this batch's encode
+        std::shared_ptr<TexBatch> nxt;
+        if (s0 + (size_t)segs_per_call < hi) {
+          nxt = nextb.get();
+          nextb = std::async(std::launch::async, load, s0 + 2 * (size_t)segs_per_call, (n_loads++) % 3);
+          if (!issue(*nxt)) break;
+        }
         const double tw1 = now_ms();
-        nextb = std::async(std::launch::async, load, s0 + (size_t)segs_per_call, (n_loads++) & 1);
+        cur = nxt;
         if (T->bad >= 0) { fail(starts[s0 + (size_t)T->bad], T->err.c_str()); break; }
         const uint32_t w = T->imgs[0][0].w, h = T->imgs[0][0].h; bool same = true;
         for (auto &seg : T->imgs) for (auto &im : seg) if (im.w != w || im.h != h) same = false;
@@ -326,14 +349,7 @@ int main(int argc, char **argv) {
         std::vector<std::unique_ptr<uint8_t[]>> outs(T->ns); std::vector<size_t> lens(T->ns, 0);
         // full segments: one batched call; segments with fewer layers: one call each
         std::vector<size_t> full; for (size_t s = 0; s < T->ns; s++) if ((int)T->imgs[s].size() == B) full.push_back(s);
-        // device un-filter: every image of the batch in one call, then the segments are encoded from HBM
-        std::vector<std::vector<const uint8_t *>> dptr(T->ns);
-        if (T->dev) {
-          std::vector<const uint8_t *> rp; for (size_t s = 0; s < T->ns; s++) for (size_t k = 0; k < T->imgs[s].size(); k++) rp.push_back(T->raws[s][k].raw.data());
-          std::vector<const uint8_t *> dp(rp.size(), nullptr);
-          if (uvol_unfilter_png_batch_dev(tctxs[g], rp.data(), (int)rp.size(), w, h, T->raws[0][0].ch, (int)((s0 / (size_t)segs_per_call) & 1), dp.data()) != UVOL_OK) { fail(starts[s0], uvol_last_error(tctxs[g])); break; }
-          size_t q = 0; for (size_t s = 0; s < T->ns; s++) for (size_t k = 0; k < T->imgs[s].size(); k++) dptr[s].push_back(dp[q++]);
-        }
+        const std::vector<std::vector<const uint8_t *>> &dptr = T->dptr;
         if (!full.empty()) {
           std::vector<const uint8_t *> ptrs; std::vector<uint8_t *> op; std::vector<size_t> caps, ln(full.size(), 0);
           for (size_t s : full) { for (size_t k = 0; k < T->imgs[s].size(); k++) ptrs.push_back(T->dev ? dptr[s][k] : T->imgs[s][k].rgba.data()); const size_t cap = uvol_texture_bound(w, h, B); outs[s].reset(new uint8_t[cap]); op.push_back(outs[s].get()); caps.push_back(cap); }
@@ -345,7 +361,7 @@ int main(int argc, char **argv) {
           const size_t cap = uvol_texture_bound(w, h, (int)ptrs.size()); outs[s].reset(new uint8_t[cap]);
           if ((T->dev ? uvol_encode_texture_segment_dev : uvol_encode_texture_segment)(tctxs[g], ptrs.data(), (int)ptrs.size(), w, h, outs[s].get(), cap, &lens[s]) != UVOL_OK) fail(starts[s0 + s], uvol_last_error(tctxs[g]));
         }
-        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] tex batch s0=%zu: waited for load %.0f ms, encode (+prepare) %.0f\n", s0, tw1 - tw0, now_ms() - tw1);
+        if (g_timing) std::fprintf(stderr, "[uvolenc-timing] tex batch s0=%zu: next batch loaded + its un-filter queued %.0f ms, encode (+prepare) %.0f\n", s0, tw1 - tw0, now_ms() - tw1);
         if (tex_failed >= 0) break;
         std::atomic<int> wbad{-1};
         parallel_for(T->ns, tex_ingest, [&](size_t s) { char name[64]; std::snprintf(name, sizeof name, "%0*d.ktx2", pad, (starts[s0 + s] - cfg.ktx2_first_file) / B); if (!write_file(join(tex_dir, name), outs[s].get(), lens[s])) wbad = starts[s0 + s]; });

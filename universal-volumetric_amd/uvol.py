@@ -190,13 +190,16 @@ class Codec:
             raise UvolError(f"parse_obj_batch_dev rc={rc}: {self.error()}")
         return meshes, list(st)
 
-    def unfilter_png_batch_dev(self, inflated, width, height, channels, slot=0):
-        """inflated: list of bytes (the inflated IDAT stream of 8-bit RGB / RGBA PNGs of one size) -> list of DEVICE pointers to RGBA8 layers."""
+    def unfilter_png_batch_dev(self, inflated, width, height, channels, slot=0, sync=True):
+        """inflated: list of bytes (the inflated IDAT stream of 8-bit RGB / RGBA PNGs of one size) -> list of DEVICE pointers to RGBA8 layers.
+        sync=False: return once the kernel is queued (this context's texture entry points order themselves behind it)."""
         raws = [bytes(r) for r in inflated]; n = len(raws)
         rp = (C.c_char_p * n)(*raws); out = (C.c_void_p * n)()
         rc = self.L.uvol_unfilter_png_batch_dev(self.h, rp, n, width, height, channels, slot, out)
         if rc != UVOL_OK:
             raise UvolError(f"unfilter_png_batch_dev rc={rc}: {self.error()}")
+        if sync and self.L.uvol_sync(self.h) != UVOL_OK:
+            raise UvolError(f"uvol_sync: {self.error()}")
         return [int(p) for p in out]
 
     def drc_info(self, data):
