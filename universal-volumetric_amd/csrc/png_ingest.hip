@@ -102,20 +102,24 @@ __global__ void __launch_bounds__(64) k_png_unfilter(PngJob *jobs) {
 // ================================================================================================
 // host side
 // ================================================================================================
-struct PngState { uvol_devbuf raw, jobs; uvol_devbuf rgba[2]; std::vector<PngJob> hjobs; hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool pending = false; };
+struct PngState { uvol_devbuf raw, jobs; uvol_devbuf rgba[2]; std::vector<PngJob> hjobs; hipStream_t stream = nullptr; hipEvent_t done[2] = { nullptr, nullptr }; bool pending[2] = { false, false }; };
 int png_create(uvol_ctx *ctx) { ctx->png = new PngState(); return UVOL_OK; }
 // the layers of the last un-filter call are ready before anything queued on `stream` from here on (the texture entry points call this
 // before they read device inputs; uvol_sync too)
-int png_order_before(uvol_ctx *ctx, hipStream_t stream) {
-  PngState *S = ctx->png;
-  if (S && S->pending) { UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, S->done, 0)); }
+// (one event per slot: the encode of batch k waits for ITS slot, not for the un-filter of batch k + 1 queued meanwhile into the other one)
+int png_order_before(uvol_ctx *ctx, hipStream_t stream, const uint8_t *layer) {
+  PngState *S = ctx->png; if (!S) return UVOL_OK;
+  for (int k = 0; k < 2; k++) {
+    const uint8_t *b = (const uint8_t *)S->rgba[k].p;
+    if (S->pending[k] && b && layer >= b && layer < b + S->rgba[k].cap) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, S->done[k], 0));
+  }
   return UVOL_OK;
 }
-int png_wait(uvol_ctx *ctx) { PngState *S = ctx->png; if (S && S->pending) { UVOL_HIP_CHECK(ctx, hipEventSynchronize(S->done)); S->pending = false; } return UVOL_OK; }
+int png_wait(uvol_ctx *ctx) { PngState *S = ctx->png; if (S) for (int k = 0; k < 2; k++) if (S->pending[k]) { UVOL_HIP_CHECK(ctx, hipEventSynchronize(S->done[k])); S->pending[k] = false; } return UVOL_OK; }
 void png_destroy(uvol_ctx *ctx) {
   PngState *S = ctx->png; if (!S) return;
   if (S->stream) { (void)hipStreamSynchronize(S->stream); (void)hipStreamDestroy(S->stream); }
-  if (S->done) (void)hipEventDestroy(S->done);
+  for (hipEvent_t e : S->done) if (e) (void)hipEventDestroy(e);
   for (uvol_devbuf *b : { &S->raw, &S->jobs, &S->rgba[0], &S->rgba[1] }) if (b->p) (void)hipFree(b->p);
   delete S; ctx->png = nullptr;
 }
@@ -130,7 +134,7 @@ int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t
   if (slot < 0 || slot > 1 || (channels != 3 && channels != 4) || !w || !h || w > 8192 || h > 16384) { ctx->set_error("uvol_unfilter_png_batch_dev: slot 0 / 1, 3 or 4 channels, at most 8192 x 16384 (wider images: un-filter on the host)"); return UVOL_E_INVALID; }
   const size_t rbytes = ((size_t)w * channels + 1) * h, ra = (rbytes + 4 + 255) & ~(size_t)255, obytes = (size_t)w * h * 4;
   int rc;
-  if (!S->stream) { if (uvol_make_stream(ctx, &S->stream) != hipSuccess || hipEventCreateWithFlags(&S->done, hipEventDisableTiming) != hipSuccess) { ctx->set_error("ingest stream: creation failed"); return UVOL_E_HIP; } }
+  if (!S->stream) { if (uvol_make_stream(ctx, &S->stream) != hipSuccess || hipEventCreateWithFlags(&S->done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S->done[1], hipEventDisableTiming) != hipSuccess) { ctx->set_error("ingest stream: creation failed"); return UVOL_E_HIP; } }
   hipStream_t saved = ctx->stream; ctx->stream = S->stream;            // (uvol_ensure, uvol_upload_staged, Scope use ctx->stream)
   struct Restore { uvol_ctx *c; hipStream_t s; ~Restore() { c->stream = s; } } restore_{ ctx, saved };
   if ((rc = uvol_ensure(ctx, S->raw, ra * (size_t)n))) return rc;
@@ -151,8 +155,8 @@ int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t
     if (uvol_debug()) { fprintf(stderr, "[uvol] launch k_png_unfilter\n"); fflush(stderr); }
     hipLaunchKernelGGL(k_png_unfilter, dim3((unsigned)n), dim3(64), ((size_t)w + 16 * 32) * 4, ctx->stream, (PngJob *)S->jobs.p); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
-  UVOL_HIP_CHECK(ctx, hipEventRecord(S->done, ctx->stream));
-  S->pending = true;
+  UVOL_HIP_CHECK(ctx, hipEventRecord(S->done[slot], ctx->stream));
+  S->pending[slot] = true;
   if (uvol_debug()) UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return UVOL_OK;
 }

@@ -247,7 +247,7 @@ void obj_destroy(uvol_ctx *ctx);
 int obj_parse_batch(uvol_ctx *ctx, const uint8_t *const *texts, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status);
 int png_create(uvol_ctx *ctx);
 void png_destroy(uvol_ctx *ctx);
-int png_order_before(uvol_ctx *ctx, hipStream_t stream);
+int png_order_before(uvol_ctx *ctx, hipStream_t stream, const uint8_t *layer);
 int png_wait(uvol_ctx *ctx);
 int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out);
 int uastc_create(uvol_ctx *ctx);
