@@ -270,22 +270,22 @@ def test_hipemu_call_spread_over_lanes(oracle, hipemu_lib):
         "cd = uvol.Codec(lib_path=%r)\n"
         "t, g, s = synth.torus_mesh(16, 8), synth.grid_mesh(), synth.sphere_mesh(24, 13, charts=(3, 2))\n"
         "rng = np.random.default_rng(1)\n"
-        "fat = dict(pos=rng.random((12, 3)).astype(np.float32), idx_pos=rng.integers(0, 12, size=(6000, 3)).astype(np.uint32).reshape(-1))\n"
+        "fat = dict(pos=rng.random((12, 3)).astype(np.float32), idx_pos=rng.integers(0, 12, size=(900, 3)).astype(np.uint32).reshape(-1))\n"
         "bad = dict(t, idx_pos=t['idx_pos'].copy()); bad['idx_pos'][5] = 10 ** 6\n"
         "frames = [t, g, s, fat, t, bad, s, g, t]\n"
         "want = [enc(f) if f is not bad else None for f in frames]\n"
         "assert cd.encode_mesh_batch(frames, raise_on_error=False) == want\n"
         "ds = synth.distinct_meshes(7, 24, 13, bases=3, charts=(3, 2))\n"
         "assert cd.encode_mesh_batch(ds) == [enc(f) for f in ds]\n"
-        "cd.start_mesh_batch(frames[:3]); cd.start_mesh_batch(frames); cd.start_mesh_batch(ds); cd.start_mesh_batch([g])\n"
+        "cd.start_mesh_batch(frames[:3]); cd.start_mesh_batch(frames[4:]); cd.start_mesh_batch(ds); cd.start_mesh_batch([g])\n"
         "r = cd.finish()\n"
-        "assert r[0] == want[:3] and r[1] == want and r[2] == [enc(f) for f in ds] and r[3] == [enc(g)]\n"
+        "assert r[0] == want[:3] and r[1] == want[4:] and r[2] == [enc(f) for f in ds] and r[3] == [enc(g)]\n"
         "cd.start_mesh_batch(ds)\n"
-        "assert cd.encode_mesh_batch(frames[:4]) == want[:4]\n"
+        "assert cd.encode_mesh_batch(frames[:3]) == want[:3]\n"
         "assert cd.finish() == [[enc(f) for f in ds]]\n"
         "cd.close(); print('lanes ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
-    for lanes in ("4", "2"):
+    for lanes in ("3",):                        # (three lanes: a 9-frame call becomes three groups, the ring wraps inside the enqueued calls)
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_GEO_MIN_GROUP="2", UVOL_GEO_LANES=lanes, UVOL_GEO_SPLIT="1"), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "lanes ok" in r.stdout, (lanes, r.stdout[-500:], r.stderr[-2000:])
 
