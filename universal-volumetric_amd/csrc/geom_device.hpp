@@ -98,6 +98,7 @@ struct GeoJob {
   int32_t *order[3], *v2d[3]; uint8_t *t_vvis[3]; int32_t *t_stack[3];
   uint8_t *fvis, *t_fvis[3];          // face-visited bits (one per face) of the lane-per-walker kernels on per-face records (walk, three traversals)
   int32_t *P, *U, *O;
+  long long *fnorm;                    // per new face: the un-normalised face normal (p1 - p0) x (p2 - p0) of its quantised positions (k_face_normals)
   uint32_t *sym_pos, *sym_uv, *sym_nrm;
   uint8_t *has_ori, *ori_val, *ori_c, *ori_bits, *flips;
   RansStream rs[GEO_NSTREAM];

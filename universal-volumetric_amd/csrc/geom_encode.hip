@@ -2269,6 +2269,26 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_ori_bits(GeoJob *jobs) {
   if (j == 0) J.rb[3].n = n;
 }
 
+// The geometric-normal predictor sums, over the faces around an entry's vertex, (a - cen) x (b - cen) of the face's quantised positions:
+// the face's un-normalised normal, the same whichever of its corners the fan walk arrives at.  It is computed once per face here
+// (9 position words through corner -> vertex -> coding order) instead of once per face AND vertex inside the walk, which then
+// gathers one 24-byte normal per face instead of two positions through three dependent gathers each (k_pred_nrm: 53 -> @@ MB of
+// HBM traffic per frame).
+__global__ void __launch_bounds__(UVOL_BLOCK) k_face_normals(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  if (!J.has_nrm) return;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (f >= J.nf) return;
+  const int32_t *P = J.P, *bv2d = J.v2d[0], *bvert = J.bvert;
+  long long p[3][3];
+  for (int k = 0; k < 3; k++) { const int32_t *q = P + 3 * (size_t)bv2d[bvert[3 * f + k]]; p[k][0] = q[0]; p[k][1] = q[1]; p[k][2] = q[2]; }
+  long long dn[3], dp[3];
+  for (int k = 0; k < 3; k++) { dn[k] = p[1][k] - p[0][k]; dp[k] = p[2][k] - p[0][k]; }
+  const long long n0 = dn[1] * dp[2] - dn[2] * dp[1], n1 = dn[2] * dp[0] - dn[0] * dp[2], n2 = dn[0] * dp[1] - dn[1] * dp[0];
+  // |components| < 2^(2 qp + 1): three 32-bit words per face up to 15 bits of quantisation (12 bytes per face), 64-bit words for 16
+  if (J.qp <= 15) { int32_t *o = reinterpret_cast<int32_t *>(J.fnorm) + 3 * (size_t)f; o[0] = (int32_t)n0; o[1] = (int32_t)n1; o[2] = (int32_t)n2; }
+  else { long long *o = J.fnorm + 3 * (size_t)f; o[0] = n0; o[1] = n1; o[2] = n2; }
+}
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   JOB_OR_RETURN;
   int i = -1; for (int k = 0; k < J.nad; k++) if (J.att_kind[k] == 1) i = k;
@@ -2278,17 +2298,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   if (d == 0) J.rb[4].n = ne;
   if (d >= ne) return;
   GTab X; X.opp = J.nopp; X.seam = J.interior_seams[i] ? J.seam[i] : nullptr;
-  const int32_t *P = J.P, *bv2d = J.v2d[0], *bvert = J.bvert;
+  const long long *FN = J.fnorm;
   const GOct ot = g_oct(J.qn);
   const int c0 = order[d];
-  const int32_t *cen = P + 3 * bv2d[bvert[c0]];
   long long N[3] = {0, 0, 0};
   int c = c0; bool left = true; uint32_t guard = 0;
   while (c >= 0 && guard++ <= J.nc) {
-    const int32_t *a = P + 3 * bv2d[bvert[g_nxt(c)]], *b = P + 3 * bv2d[bvert[g_prv(c)]];
-    long long dn[3], dp[3];
-    for (int k = 0; k < 3; k++) { dn[k] = (long long)a[k] - cen[k]; dp[k] = (long long)b[k] - cen[k]; }
-    N[0] += dn[1] * dp[2] - dn[2] * dp[1]; N[1] += dn[2] * dp[0] - dn[0] * dp[2]; N[2] += dn[0] * dp[1] - dn[1] * dp[0];
+    // (the face's normal, whichever corner of it c is: k_face_normals)
+    if (J.qp <= 15) { const int32_t *fn = reinterpret_cast<const int32_t *>(FN) + 3 * (size_t)(c / 3); N[0] += fn[0]; N[1] += fn[1]; N[2] += fn[2]; }
+    else { const long long *fn = FN + 3 * (size_t)(c / 3); N[0] += fn[0]; N[1] += fn[1]; N[2] += fn[2]; }
     if (left) { c = gt_swl(X, c); if (c == c0) break; if (c < 0) { left = false; c = gt_swr(X, c0); } }
     else c = gt_swr(X, c);
   }
@@ -3215,6 +3233,7 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
   // ---- K5, K1, K6 ----
   for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, ecap, PH_TRAV, PH_PRED); CARVE(J.v2d[t], int32_t, ecap, PH_V2D, PH_PRED); CARVE(J.t_stack[t], int32_t, nfi + 2, PH_TRAV, PH_TRAV); }
   CARVE(J.P, int32_t, 3 * ecap, PH_QUANT, PH_PRED); CARVE(J.U, int32_t, 2 * ecap, PH_QUANT, PH_PRED); CARVE(J.O, int32_t, 2 * ecap, PH_QUANT, PH_PRED);
+  CARVE(J.fnorm, int32_t, J.n_nrm ? (J.qp <= 15 ? 3 : 6) * nfi + 6 : 2, PH_PRED, PH_PRED);
   CARVE(J.sym_pos, uint32_t, 3 * ecap, PH_PRED, PH_ENT); CARVE(J.sym_uv, uint32_t, 2 * ecap, PH_PRED, PH_ENT); CARVE(J.sym_nrm, uint32_t, 2 * ecap, PH_PRED, PH_ENT);
   CARVE(J.has_ori, uint8_t, ecap, PH_PRED, PH_PRED); CARVE(J.ori_val, uint8_t, ecap, PH_PRED, PH_PRED); CARVE(J.ori_c, uint8_t, ecap, PH_PRED, PH_PRED);
   CARVE(J.ori_bits, uint8_t, ecap, PH_PRED, PH_ENT); CARVE(J.flips, uint8_t, ecap, PH_PRED, PH_ENT);
@@ -3737,6 +3756,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ORI);
     LAUNCH(k_ori_compact, dim3(be, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_ori_bits, dim3(be, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_face_normals, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_pred_nrm, dim3(be, N), dim3(UVOL_BLOCK), dj);
   }
   if (late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, L.ev_val, 0));

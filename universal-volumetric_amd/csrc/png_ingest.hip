@@ -11,7 +11,7 @@
 // (c) are what the lane one below (same channel) produced one and two steps earlier - a DPP row shift, no LDS round trip -, the pixel to
 // the left (a) is the lane's own last output.  A band takes width + 15 steps; the last row of a band stays in LDS for row 0 of the next.
 // Every filter type runs the same straight-line step (the predictor is a select), so rows with different filters do not diverge.
-// What a lone wave needs to run at ~0.1 us per step instead of 0.5 (141 -> @@ ms per image, tools/ingest_timing.py): the filtered bytes
+// What a lone wave needs to run at ~0.1 us per step instead of 0.5 (tools/ingest_timing.py: it did not - 141 -> 134 ms per batch: the step is bound by instruction issue, ~1000 cycles for ~150 instructions of one wave): the filtered bytes
 // of the next 16 steps are requested while the current 16 are processed (a global load per step was a memory round trip per step), and
 // the outputs collect in an LDS ring (one byte write per lane and step) that the wave writes out 16 rows x 16 pixels at a time with
 // 16-byte stores.
