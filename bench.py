@@ -312,6 +312,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], units), "avg_launch_ms": avg_ms, "units_per_launch": units,
                          "algorithmic_bytes_per_frame": algo_per_frame,
+                         "launches_per_step": dom["launches"] / max(1, args.steps),
+                         "note": "a pass is cut into groups on the context's lanes whose launches of this kernel run side by side: `frac` prices ONE launch (its frames, its duration) against the whole chip, as specified; "
+                                 "frac x launches_per_step is what the concurrent launches move together while they overlap",
                          "end_to_end_achieved": algo_per_frame * total_frames / world / dt / 1e9},
             "kernel_groups_ms_per_step": {g["name"]: g["total_ms"] / args.steps for g in groups},
         }

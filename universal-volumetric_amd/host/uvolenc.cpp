@@ -144,8 +144,11 @@ int main(int argc, char **argv) {
       // three batch objects in turn: the one being encoded, the next one (loaded, then prepared while the GPU works) and the one being loaded
       std::shared_ptr<GeoBatch> pool[3] = { std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>(), std::make_shared<GeoBatch>() }; size_t n_loads = 0;
       std::vector<IngestScratch> scratch((size_t)std::max(1, geo_ingest)); IngestScratch fb_scratch;
+      // the FIRST batch of a stage is a quarter of the others: the pipeline (read -> parse -> encode -> write) starts after a quarter of the
+      // time a full batch of cold files takes to read (0.6 s of a 4 s run at 960 frames)
+      auto blen = [&](size_t b0) -> size_t { return b0 == lo ? (size_t)std::max(1, std::min(frames_per_batch, std::max(16, frames_per_batch / 4))) : (size_t)frames_per_batch; };
       auto load = [&](size_t b0, size_t slot) {
-        std::shared_ptr<GeoBatch> Bt = pool[slot]; Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, (size_t)frames_per_batch) : 0; Bt->bad = -1; Bt->err.clear();
+        std::shared_ptr<GeoBatch> Bt = pool[slot]; Bt->b0 = b0; Bt->nb = b0 < hi ? std::min(hi - b0, blen(b0)) : 0; Bt->bad = -1; Bt->err.clear();
         if (Bt->ms.size() < Bt->nb) Bt->ms.resize(Bt->nb);
         std::mutex mu;
         const double tl0 = now_ms();
@@ -215,8 +218,8 @@ int main(int argc, char **argv) {
         return UVOL_OK;
       };
       std::shared_ptr<GeoBatch> cur = lo < hi ? nextb.get() : nullptr; size_t n_prep = 0;
-      if (cur) { nextb = std::async(std::launch::async, load, lo + (size_t)frames_per_batch, (n_loads++) % 3); if (!prepare(*cur, (int)((n_prep++) & 1))) cur = nullptr; }
-      for (size_t b0 = lo; cur && b0 < hi && geo_failed < 0; b0 += (size_t)frames_per_batch) {
+      if (cur) { nextb = std::async(std::launch::async, load, lo + blen(lo), (n_loads++) % 3); if (!prepare(*cur, (int)((n_prep++) & 1))) cur = nullptr; }
+      for (size_t b0 = lo; cur && b0 < hi && geo_failed < 0; b0 += blen(b0)) {
         GeoBatch &Bt = *cur; const size_t nb = Bt.nb;
         const double te0 = now_ms();
         int rc = enqueue(Bt);
@@ -224,9 +227,9 @@ int main(int argc, char **argv) {
         const double te1 = now_ms();
         // ... and the NEXT batch: its files are read (ingest threads), its text uploaded and parsed (ingest context) while this one encodes
         std::shared_ptr<GeoBatch> nxt; bool nxt_ok = true;
-        if (b0 + (size_t)frames_per_batch < hi) {
+        if (b0 + blen(b0) < hi) {
           nxt = nextb.get();
-          nextb = std::async(std::launch::async, load, b0 + 2 * (size_t)frames_per_batch, (n_loads++) % 3);      // (the object of batch b - 1: its files are written, its meshes done with)
+          nextb = std::async(std::launch::async, load, b0 + blen(b0) + blen(b0 + blen(b0)), (n_loads++) % 3);      // (the object of batch b - 1: its files are written, its meshes done with)
           if (rc == UVOL_OK) nxt_ok = prepare(*nxt, (int)((n_prep++) & 1));
         }
         const double te2 = now_ms();
@@ -267,8 +270,9 @@ int main(int argc, char **argv) {
       // three batch objects in turn: the one being encoded, the next one (loaded; its un-filter queued beside this encode), the one being loaded
       std::shared_ptr<TexBatch> pool[3] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
       std::vector<IngestScratch> scratch((size_t)std::max(1, tex_ingest));
+      auto slen = [&](size_t s0) -> size_t { return s0 == lo ? (size_t)std::max(1, std::min(segs_per_call, std::max(4, segs_per_call / 4))) : (size_t)segs_per_call; };      // (a short first call, as in the geometry stage)
       auto load = [&](size_t s0, size_t slot) {
-        std::shared_ptr<TexBatch> T = pool[slot]; T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, (size_t)segs_per_call) : 0; T->bad = -1; T->err.clear();
+        std::shared_ptr<TexBatch> T = pool[slot]; T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, slen(s0)) : 0; T->bad = -1; T->err.clear();
         // recycled Image objects keep their 16.8 MB pixel buffers (a short last segment shrinks imgs[s]; the layers come back from `spare`)
         for (auto &v : T->imgs) for (auto &im : v) { T->spare.emplace_back(); T->spare.back().push_back(std::move(im)); }
         T->imgs.clear(); T->imgs.resize(T->ns);
@@ -328,15 +332,15 @@ int main(int argc, char **argv) {
         return true;
       };
       std::shared_ptr<TexBatch> cur = lo < hi ? nextb.get() : nullptr;
-      if (cur) { nextb = std::async(std::launch::async, load, lo + (size_t)segs_per_call, (n_loads++) % 3); if (!issue(*cur)) cur = nullptr; }
-      for (size_t s0 = lo; cur && s0 < hi && tex_failed < 0; s0 += (size_t)segs_per_call) {
+      if (cur) { nextb = std::async(std::launch::async, load, lo + slen(lo), (n_loads++) % 3); if (!issue(*cur)) cur = nullptr; }
+      for (size_t s0 = lo; cur && s0 < hi && tex_failed < 0; s0 += slen(s0)) {
         const double tw0 = now_ms();
         std::shared_ptr<TexBatch> T = cur;
         // the NEXT batch: loaded (PNG chunks parsed + inflated) by the ingest threads by now or soon; its un-filter kernel runs beside this batch's encode
         std::shared_ptr<TexBatch> nxt;
-        if (s0 + (size_t)segs_per_call < hi) {
+        if (s0 + slen(s0) < hi) {
           nxt = nextb.get();
-          nextb = std::async(std::launch::async, load, s0 + 2 * (size_t)segs_per_call, (n_loads++) % 3);
+          nextb = std::async(std::launch::async, load, s0 + slen(s0) + slen(s0 + slen(s0)), (n_loads++) % 3);
           if (!issue(*nxt)) break;
         }
         const double tw1 = now_ms();
