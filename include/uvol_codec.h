@@ -111,11 +111,11 @@ int uvol_encode_mesh_batch_dev(uvol_ctx *ctx, const uvol_mesh *meshes, int n,
 /* Ingest on the device (`draco_encoder -i frame.obj` parses the OBJ text itself, scripts/Encoder.py:256-262): n OBJ files
  * as TEXT in host memory -> meshes_out[i] with DEVICE pointers (v / vt / vn / f lines, polygons fanned, 1-based and negative indices;
  * bit-identical to the host parser of host/uvol_host.cpp, i.e. to strtof), ready for uvol_encode_mesh_batch_dev[_async].  The arrays
- * live in the context's slot `slot` (0 or 1) until that slot is parsed into again, so batch b + 1 can be parsed while the enqueued
- * encode of batch b still reads the other slot.  status[i]: UVOL_OK; UVOL_E_UNSUPPORTED = the text holds a number or line the device
+ * live in the context's slot `slot` (0 or 1) until that slot is parsed into again.  To parse batch b + 1 WHILE batch b encodes, parse on a
+ * second context of the same device (contexts are independent and device pointers are not tied to one; host/uvolenc.cpp does this) -
+ * on one context the call waits for that context's enqueued calls like every other entry point.  status[i]: UVOL_OK; UVOL_E_UNSUPPORTED = the text holds a number or line the device
  * parser leaves to the host (more than 19 significant digits, inf / nan, a value on a float rounding boundary, an incomplete `v` line):
- * parse that file with the host parser; UVOL_E_INVALID = a face references a missing vertex / no faces.  Blocking; not thread-safe per ctx
- * except against this ctx's own enqueued encode calls. */
+ * parse that file with the host parser; UVOL_E_INVALID = a face references a missing vertex / no faces.  Blocking. */
 int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, const size_t *lens, int n, int slot,
                              uvol_mesh *meshes_out, int *status);
 

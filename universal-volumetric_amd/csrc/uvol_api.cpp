@@ -346,9 +346,11 @@ int uvol_decode_mesh_batch_dev(uvol_ctx *ctx, const uint8_t *const *drc, const s
   return UVOL_OK;
 }
 
-// (not behind UVOL_AFTER_ASYNC on purpose: the parse of batch b + 1 runs on its own stream and slot while the enqueued encode of batch b
-// still reads the other slot)
+// (like every entry point it waits for this context's enqueued calls first: the worker thread and this call both borrow ctx->stream.  To
+// parse batch b + 1 WHILE batch b encodes, parse on a second context of the same device - contexts are independent, device pointers are
+// not tied to one -, as host/uvolenc.cpp does)
 int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
   if (!ctx || !obj_text || !lens || n < 0 || !meshes_out) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   return obj_parse_batch(ctx, obj_text, lens, n, slot, meshes_out, status);
