@@ -331,9 +331,11 @@ def main():
             res["parity_checked_frames"] = res["parity"].get("geometry_frames_equal_to_oracle", 0)
         if variants_on:
             try:
-                res["variants"] = run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, res["ms_per_step"], F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes)
+                args._geo_cfg = dict(gcfg, device=local_rank)
+                res["variants"] = {}
+                run_variants(res["variants"], args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, res["ms_per_step"], F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes)
             except Exception as e:                                   # the headline stands on its own
-                res["variants"] = {"error": repr(e)}
+                res["variants"]["error"] = repr(e)                  # (the variants measured before the fault stay in the line)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
         print(json.dumps(res))
@@ -343,15 +345,22 @@ def main():
         dist.destroy_process_group()
 
 
-def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, ms_step, F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes):
+def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, ms_step, F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes):
     """The same path on other boundaries / job sizes / storage orders, each a few passes (about 25 s in all), reported NEXT TO the
     headline: what a user of the reference sees depends on where the inputs are and how large the job is (VERDICT r2 #3)."""
     import numpy as np
     import torch
     import uvol, synth
-    v = {}
     def note(what):                                            # progress on stderr (a fault in a variant is then attributable)
         print("[bench] variant: " + what, file=sys.stderr, flush=True)
+        v["in_progress"] = what                                # (stays in the line only if this variant raises)
+    def renew_geos():                                          # fresh geometry contexts: a lane's workspace only grows, and the variants below change its shape
+        n = len(geos)
+        for c in geos:
+            c.close()
+        del geos[:]
+        torch.cuda.empty_cache()
+        geos.extend(uvol.Codec(**args._geo_cfg) for _ in range(n))
     # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
     note("events_off")
     set_profiling(False)
@@ -372,6 +381,7 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
         note("stream_of_300_frame_jobs")
         v["stream_of_300_frame_jobs"] = dict(Job(300).timed(6, 2), note="300-frame jobs enqueued back to back (uvol_encode_mesh_batch_dev_async), one uvol_sync at the end")
     if args.only:                                              # (diagnostic: UVOL_VARIANTS_WITH_ONLY=1) one half of the path, job sizes only
+        v.pop("in_progress", None)
         return v
     # (2) scan-like storage order: the resident input buffers are overwritten with a seeded permutation of faces and values
     note("shuffled_order")
@@ -390,13 +400,14 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
     # (2c) one blocking geometry call per pass (the whole call is one group on the context's first lane, which then holds a workspace of
     #      the full call: run last among the device-input variants)
     note("blocking_calls")
+    renew_geos()
     kb = max(2, min(args.steps, 4))
     v["blocking_calls"] = dict(Job(F, blocking=True).timed(kb, 1), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
     v["blocking_calls"]["enqueued_same_passes"] = Job(F).timed(kb, 1)["frames_per_s"]      # (short runs flatter both: the texture context finishes its passes early)
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
     note("host_inputs")
     frame_t.clear(); keep.clear(); del dev_meshes[:]
-    torch.cuda.empty_cache()
+    renew_geos()                                               # (the blocking variant left one lane with the workspace of a whole call)
     nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
@@ -427,6 +438,7 @@ def run_variants(args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, 
         d.close()
     except Exception as e:
         v["decode_error"] = repr(e)
+    v.pop("in_progress", None)
     return v
 
 

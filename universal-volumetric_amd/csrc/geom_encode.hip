@@ -2272,7 +2272,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_ori_bits(GeoJob *jobs) {
 // The geometric-normal predictor sums, over the faces around an entry's vertex, (a - cen) x (b - cen) of the face's quantised positions:
 // the face's un-normalised normal, the same whichever of its corners the fan walk arrives at.  It is computed once per face here
 // (9 position words through corner -> vertex -> coding order) instead of once per face AND vertex inside the walk, which then
-// gathers one 24-byte normal per face instead of two positions through three dependent gathers each (k_pred_nrm: 53 -> @@ MB of
+// gathers one 24-byte normal per face instead of two positions through three dependent gathers each (k_pred_nrm: 53 -> 15.3 MB, k_face_normals itself 8.7 MB of
 // HBM traffic per frame).
 __global__ void __launch_bounds__(UVOL_BLOCK) k_face_normals(GeoJob *jobs) {
   JOB_OR_RETURN;
