@@ -1904,8 +1904,9 @@ struct uvol_u4 { uint32_t x, y, z, w; };
 typedef uint32_t uvol_u4 __attribute__((ext_vector_type(4)));
 #endif
 __device__ __forceinline__ uvol_u4 f16_load(UVOL_G(uint32_t) rec, int face) { return *(UVOL_G(const uvol_u4))(rec + 4 * (size_t)face); }
-// LDM = 1 (UVOL_WALK_LD=1, diagnostic): the walkers' loads as agent-scope atomics, which do not look the line up in the CU's L1 - a
-// load of a line the same walker has just stored into does not wait for that store's acknowledgement there
+// LDM = 1 (UVOL_WALK_LD=1, diagnostic): the walkers' loads as agent-scope atomics, which do not look the line up in the CU's L1.  Measured
+// and NOT the default: traversal 234 against 206 ms per 1280 frames (tools/experiments/exp_r4u.sh) - the L1 hits are worth more than what a
+// load behind the walker's own store into the same line waits for
 template <int LDM> __device__ __forceinline__ uvol_u4 f16_ld(UVOL_G(uint32_t) rec, int face) {
   if (LDM == 0) return f16_load(rec, face);
   UVOL_G(uint64_t) p = (UVOL_G(uint64_t))(rec + 4 * (size_t)face);
@@ -2119,172 +2120,6 @@ __global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, i
   const int ai = t > 0 ? t - 1 : 0;
   if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
   traverse_simt_f16<FB, LDM>(J, t);
-}
-
-// One walker per WAVE on the scalar unit (the default when a lane-per-walker launch runs one lane per wave, which is what distinct
-// connectivity asks for: walkers of one wave would wait for each other's branches).  With one active lane every value of the walk is
-// wave-uniform: loaded words are read into scalar registers (UVOL_RFL), the arithmetic of a step then runs on the scalar unit and its
-// branches are scalar branches without the exec-mask bookkeeping of divergent control flow.  A vector instruction occupies its SIMD for
-// four cycles whatever the number of active lanes; rocprofv3 counted 64 vector + 28 scalar instructions per step in the lane form
-// (profiles/r04_walker_counters.json), and the waves of a SIMD queue for its vector pipe long before memory (L2 hit rate 92 %,
-// 179 cycles per request) limits them.  Same records, same order of loads and stores as traverse_simt_f16<false>.
-__device__ __forceinline__ uvol_u4 f16_load_u(UVOL_G(uint32_t) rec, int face) {
-  const uvol_u4 t = f16_load(rec, face); uvol_u4 q;
-  q.x = UVOL_RFL(t.x); q.y = UVOL_RFL(t.y); q.z = UVOL_RFL(t.z); q.w = UVOL_RFL(t.w);
-  return q;
-}
-__device__ inline void traverse_uni_f16(GeoJob &J, int t) {
-  const int nf = (int)J.nf;
-  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
-  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
-  UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
-  int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
-  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
-  for (;;) {
-    if (x < 0) {                                          // rare: the stack, else the next unvisited face starts a component
-      bool finished = false;
-      for (;;) {
-        if (sp > 0) {
-          const int c = UVOL_RFL(stack[sp - 1]);
-          if (c < 0) { sp--; continue; }
-          const uvol_u4 qq = f16_load_u(rec, c >> 2);
-          if (qq.y >> 31) { sp--; continue; }
-          x = c; q = qq; f16_dec(q, x & 3, vi, rc, lc);
-          break;
-        }
-        if (f >= nf || nvis >= nf) { finished = true; break; }
-        const int f0 = f; f++;
-        const uvol_u4 q0 = f16_load_u(rec, f0);
-        if (q0.y >> 31) continue;
-        stack[0] = 4 * f0; sp = 1;
-        int vn, vp, r_, l_; f16_dec(q0, 1, vn, r_, l_); f16_dec(q0, 2, vp, r_, l_); vn >>= 1; vp >>= 1;
-        uint32_t w = UVOL_RFL(vbits[vn >> 5]);
-        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f0 + 1; n++; }
-        w = UVOL_RFL(vbits[vp >> 5]);
-        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f0 + 2; n++; }
-      }
-      if (finished) break;
-    }
-    const int fc = x >> 2, rf = (rc < 0 ? x : rc) >> 2, lf = (lc < 0 ? x : lc) >> 2;
-    rec[4 * (size_t)fc + 1] = q.y | 0x80000000u;
-    nvis++;
-    const uvol_u4 qr = f16_load(rec, rf), ql = f16_load(rec, lf);           // (vector registers: only the flag words and the record the walk moves to are read out)
-    const int v = vi >> 1;
-    const uint32_t vw = UVOL_RFL(vbits[v >> 5]);
-    vbits[v >> 5] = vw | (1u << (v & 31));
-    const uint32_t vvis = (vw >> (v & 31)) & 1u;
-    if (!vvis) { order[n] = 3 * fc + (x & 3); n++; }                        // a vertex seen for the first time takes the next place
-    const uint32_t ry = UVOL_RFL(qr.y), ly = UVOL_RFL(ql.y);
-    const uint32_t rvis = (rc < 0 || (ry >> 31)) ? 1u : 0u, lvis = (lc < 0 || (ly >> 31)) ? 1u : 0u;
-    const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;
-    const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
-    if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; }
-    if (k == 4u) { sp--; x = -1; }
-    else if (k == 2u) { x = lc; q.x = UVOL_RFL(ql.x); q.y = ly; q.z = UVOL_RFL(ql.z); q.w = UVOL_RFL(ql.w); f16_dec(q, x & 3, vi, rc, lc); }
-    else { x = rc; q.x = UVOL_RFL(qr.x); q.y = ry; q.z = UVOL_RFL(qr.z); q.w = UVOL_RFL(qr.w); f16_dec(q, x & 3, vi, rc, lc); }
-  }
-  J.ne[t] = (uint32_t)n;
-  if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
-}
-// the connectivity walk in the same form (eb_walk_simt_f16<false>)
-__device__ inline void eb_walk_uni_f16(GeoJob &J) {
-  const int nf = (int)J.nf;
-  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[0]));
-  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis));
-  UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
-  UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
-  const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
-  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
-  int fo = 0, sp = 0, x = -1, vi = 0, rcn = -1, lcn = -1;
-  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
-  for (;;) {
-    if (x < 0) {                                          // rare: a corner to go on from - the stack, else the next component
-      bool finished = false;
-      for (;;) {
-        if (sp > 0) {
-          const int c = UVOL_RFL(stack[sp - 1]);
-          if (c < 0) { sp--; continue; }
-          const uvol_u4 qq = f16_load_u(rec, c >> 2);
-          if (qq.y >> 31) { sp--; continue; }
-          x = c; q = qq; f16_dec(q, x & 3, vi, rcn, lcn);
-          break;
-        }
-        if (fo >= nf || nproc + ninit >= nf) { finished = true; break; }
-        const int f0 = rl ? UVOL_RFL(s_of_o[fo]) : fo;   // component starts follow the ORIGINAL face order
-        fo++;
-        const uvol_u4 q0 = f16_load_u(rec, f0);
-        if (q0.y >> 31) continue;
-        int v0[3], r0_[3], l0_[3];
-        for (int k = 0; k < 3; k++) f16_dec(q0, k, v0[k], r0_[k], l0_[k]);
-        const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
-        int interior = 1, start = 4 * f0;
-        for (int k = 0; k < 3; k++) {
-          if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
-          if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
-            int ci = 4 * f0 + k, rc = ci;
-            while (rc >= 0) { ci = rc; int v_, r_, l_; f16_dec(f16_load_u(rec, rc >> 2), rc & 3, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }
-            interior = 0; start = code_prv(ci); break;
-          }
-        }
-        start_bits[nstart] = (uint8_t)interior;
-        nstart++;
-        int from;
-        if (interior) {
-          for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = UVOL_RFL(vbits[v >> 5]); vbits[v >> 5] = w | (1u << (v & 31)); }
-          rec[4 * (size_t)f0 + 1] = q0.y | 0x80000000u;
-          initc[ninit] = 3 * f0 + 1;
-          ninit++;
-          from = o0[1];
-          if (from < 0) continue;
-          if (UVOL_RFL(rec[4 * (size_t)(from >> 2) + 1]) >> 31) continue;
-        } else from = start;
-        stack[0] = from; sp = 1;
-      }
-      if (finished) break;
-    }
-    // ---- the common step ----
-    const int f = x >> 2, rf = (rcn < 0 ? x : rcn) >> 2, lf = (lcn < 0 ? x : lcn) >> 2;
-    rec[4 * (size_t)f + 1] = q.y | 0x80000000u;
-    const uvol_u4 qr = f16_load(rec, rf), ql = f16_load(rec, lf);
-    proc[nproc] = 3 * f + (x & 3);
-    const int v = vi >> 1;
-    const uint32_t vw = UVOL_RFL(vbits[v >> 5]);
-    vbits[v >> 5] = vw | (1u << (v & 31));                                  // (already set when the tip was visited)
-    const uint32_t vvis = (vw >> (v & 31)) & 1u;
-    const uint32_t ry = UVOL_RFL(qr.y), ly = UVOL_RFL(ql.y);
-    const uint32_t rvis = (rcn < 0 || (ry >> 31)) ? 1u : 0u, lvis = (lcn < 0 || (ly >> 31)) ? 1u : 0u;
-    const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;                    // tip unvisited and not on a boundary
-    const uint32_t sym = ccase ? 0u : 1u + 2u * lvis + 4u * rvis;           // C 0, S 1, L 3, R 5, E 7
-    symb[nproc] = (uint8_t)sym;
-    nproc++;
-    if (sym == 1u) { stack[sp - 1] = lcn; stack[sp] = rcn; sp++; nsplit++; }   // S: the left neighbour waits on the stack, the walk goes right
-    if (sym == 7u) { sp--; x = -1; }
-    else if (sym == 5u) { x = lcn; q.x = UVOL_RFL(ql.x); q.y = ly; q.z = UVOL_RFL(ql.z); q.w = UVOL_RFL(ql.w); f16_dec(q, x & 3, vi, rcn, lcn); }
-    else { x = rcn; q.x = UVOL_RFL(qr.x); q.y = ry; q.z = UVOL_RFL(qr.z); q.w = UVOL_RFL(qr.w); f16_dec(q, x & 3, vi, rcn, lcn); }
-  }
-  J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
-  if (nproc + ninit != nf) J.status = -10;
-  J.rb[0].n = (uint32_t)nstart;
-  uint32_t z = 0; for (int i = 0; i < nstart; i++) z += start_bits[i] == 0;
-  J.rb[0].zeros = z;
-}
-__global__ void __launch_bounds__(64) k_eb_walk_uni_f16(GeoJob *jobs, int n) {
-  if (threadIdx.x != 0) return;
-  const int j = (int)blockIdx.x;
-  if (j >= n) return;
-  GeoJob &J = jobs[j];
-  if (J.status != 0) return;
-  eb_walk_uni_f16(J);
-}
-__global__ void __launch_bounds__(64) k_traverse_uni_f16(GeoJob *jobs, int n) {
-  if (threadIdx.x != 0) return;
-  const int id = (int)blockIdx.x;
-  if (id >= 3 * n) return;
-  const int t = id / n, j = id - t * n;
-  GeoJob &J = jobs[j];
-  const int ai = t > 0 ? t - 1 : 0;
-  if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
-  traverse_uni_f16(J, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3588,14 +3423,12 @@ bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); 
 // 4-byte loads per step cost more than the clean record lines save (tools/experiments/exp_r4h.sh).
 static inline bool geo_face_bits() { static const bool v = [] { const char *e = getenv("UVOL_FACE_BITS"); return e && *e == '1'; }(); return v; }
 static inline bool geo_rec_face_off() { static const bool v = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }(); return v; }      // UVOL_REC_FACE=0 (diagnostic, tests): corner records in the lane-per-walker kernels too
-static inline bool geo_walk_uni() { static const bool v = [] { const char *e = getenv("UVOL_WALK_UNI"); return e && *e == '1'; }(); return v; }      // UVOL_WALK_UNI=1 (diagnostic): one-walker-per-wave launches on the scalar unit
 static inline bool geo_walk_ld() { static const bool v = [] { const char *e = getenv("UVOL_WALK_LD"); return e && *e == '1'; }(); return v; }
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) {
     const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W;
-    if (r8 == 2 && W == 1 && geo_walk_uni() && !geo_face_bits()) LAUNCH(k_traverse_uni_f16, dim3(nb), dim3(64), dj, n);
-    else if (r8 == 2) { if (geo_face_bits()) LAUNCH((k_traverse_simt_f16<true, 0>), dim3(nb), dim3(64), dj, n, (int)W); else if (geo_walk_ld()) LAUNCH((k_traverse_simt_f16<false, 1>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt_f16<false, 0>), dim3(nb), dim3(64), dj, n, (int)W); }
+    if (r8 == 2) { if (geo_face_bits()) LAUNCH((k_traverse_simt_f16<true, 0>), dim3(nb), dim3(64), dj, n, (int)W); else if (geo_walk_ld()) LAUNCH((k_traverse_simt_f16<false, 1>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt_f16<false, 0>), dim3(nb), dim3(64), dj, n, (int)W); }
     else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
   }
   else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
@@ -3884,15 +3717,13 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   // UVOL_SIMT_W_WALK / UVOL_SIMT_W_TRAV (diagnostic): lanes per wave of one of the two lane-per-walker kernels only (UVOL_SIMT_W sets both)
   static const int w_walk_env = [] { const char *e = getenv("UVOL_SIMT_W_WALK"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
   static const int w_trav_env = [] { const char *e = getenv("UVOL_SIMT_W_TRAV"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
-  if (wp_walk.simt_w > 1 && !lockstep && geo_simt_env() == 0 && geo_walk_uni() && fmt0 == 2) wp_walk.simt_w = 1;      // unrelated meshes: one walker per wave, on the scalar unit
   if (w_walk_env && wp_walk.simt_w) wp_walk.simt_w = w_walk_env;
   {
     LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, fmt0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) {
       const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
-      if (fmt0 == 2 && W == 1 && geo_walk_uni() && !geo_face_bits()) LAUNCH(k_eb_walk_uni_f16, dim3(nb), dim3(64), dj, n);
-      else if (fmt0 == 2) { if (geo_face_bits()) LAUNCH((k_eb_walk_simt_f16<true, 0>), dim3(nb), dim3(64), dj, n, (int)W); else if (geo_walk_ld()) LAUNCH((k_eb_walk_simt_f16<false, 1>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt_f16<false, 0>), dim3(nb), dim3(64), dj, n, (int)W); }
+      if (fmt0 == 2) { if (geo_face_bits()) LAUNCH((k_eb_walk_simt_f16<true, 0>), dim3(nb), dim3(64), dj, n, (int)W); else if (geo_walk_ld()) LAUNCH((k_eb_walk_simt_f16<false, 1>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt_f16<false, 0>), dim3(nb), dim3(64), dj, n, (int)W); }
       else if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
     }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());

@@ -64,11 +64,7 @@
 #define UVOL_TO_G(T, p) (p)
 #define UVOL_TO_L(T, p) (p)
 #define UVOL_OR_NORET(p, v) ((void)(*(p) |= (v)))
-#define UVOL_RFL(v) (v)
 #else
-// a value every active lane holds alike (a wave that runs ONE walker): read into a scalar register, so that what is computed from it
-// runs on the scalar unit and branches on it are scalar branches
-#define UVOL_RFL(v) __builtin_amdgcn_readfirstlane(v)
 #define UVOL_G(T) __attribute__((address_space(1))) T *
 #define UVOL_L(T) __attribute__((address_space(3))) T *
 #define UVOL_TO_G(T, p) ((__attribute__((address_space(1))) T *)(p))
