@@ -25,7 +25,8 @@
 #define GD_CTX_NS 16
 #define GD_E_WS_OVERFLOW (-50)      // the compact workspace cannot hold this frame (more entries per face than usual): retried with worst-case sizes
 
-struct GDRans { uint32_t present, scheme, bl, prec_bits, ns, max_ns, max_prec_bits, tab_off, pay_off, pay_len, nvals; uint32_t *probs, *cum, *lut, *out; };
+struct GDRans { uint32_t present, scheme, bl, prec_bits, ns, max_ns, max_prec_bits, tab_off, pay_off, pay_len, nvals; uint32_t *probs, *cum, *lut, *out;
+                uint32_t early, redo; };      // attribute streams: decoded beside the traversal with the count the tables predict / decoded again after it (count differed)
 struct GDRabs { uint32_t present, p0, pay_off, pay_len; };
 struct GDAtt {
   int32_t att_data_id, dec_type, att_type, data_type, ncomp, unique_id, seq_type, pred_method, transform, nc;
@@ -213,7 +214,7 @@ __device__ __forceinline__ int gd_ans_init(const uint8_t *buf, uint32_t n, uint3
 // Grid = (frames, streams), frame index fastest: consecutive workgroups land on the four SIMDs of a CU in turn, and with
 // (streams, frames) and four streams per frame the one long stream of every frame went to the same SIMD of every CU - a
 // quarter of the chip's issue slots for all the serial work of the launch (k_gdec_pred: 0.75 us per entry instead of 0.15)
-__global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, int count) {
+__global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, int count, int mode) {
   GeoDecJob &J = jobs[blockIdx.x];
   const int si = first + (int)blockIdx.y;
   if ((int)blockIdx.y >= count) return;
@@ -222,7 +223,9 @@ __global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, in
   // the job status can be changed by the sibling workgroups of this frame (other streams) while this one runs: sample it
   // ONCE per workgroup so that all lanes take the same path to the barriers below
   __shared__ int s_err, s_go;
-  if (lane == 0) s_go = (J.status == 0 && S.present && S.nvals != 0) ? 1 : 0;
+  // mode 0: every present stream; 1 / 3: the streams whose value count was predicted after the index / after the seam tables (early passes
+  // on the second stream); 2: the ones the early passes did not cover or whose count the traversal corrected
+  if (lane == 0) s_go = (J.status == 0 && S.present && S.nvals != 0 && (mode == 0 || (mode == 2 ? S.redo != 0 : S.early == (mode == 1 ? 1u : 2u)))) ? 1 : 0;
   __syncthreads();
   if (!s_go) return;
   const uint32_t ns = S.ns, prec = 1u << S.prec_bits, L = prec * 4;
@@ -898,14 +901,36 @@ __global__ void __launch_bounds__(64) k_gdec_flips(GeoDecJob *jobs, GeoJob *gj) 
   for (int k = 0; k < ne; k++) flips[k] = (uint8_t)gd_rabs_bit(Fb);
 }
 
-// attribute symbol counts = entries of the decoder's table x components (known after the traversal)
+// Attribute symbol counts = entries of the decoder's table x components.  The traversal counts the entries, but a valid file's counts are
+// known before it: the header's vertex count for the base table, the attribute vertices the seam tables produced for the others.  The
+// symbol streams (serial rANS chains, 220 ms per 1920 frames) are therefore decoded on a second stream WHILE the traversals (200 ms) run;
+// k_gdec_counts then compares, and a stream whose count the traversal corrected (a header that lies) is decoded again.
+// phase 0 (after the index): the streams of the base table, whose count is in the header - they run beside the connectivity decoder already;
+// phase 1 (after the seam tables): the streams of the attribute tables
+__global__ void __launch_bounds__(64) k_gdec_counts_early(GeoDecJob *jobs, int phase) {
+  GeoDecJob &J = jobs[blockIdx.x];
+  if (threadIdx.x != 0 || J.status != 0) return;
+  if (J.method == 0) { if (phase == 0) for (int d = 0; d < J.ndec; d++) J.rs[6 + d].early = 1; return; }      // sequential connectivity: one entry per point, known from the header
+  for (int d = 0; d < J.ndec; d++) {
+    const int t = J.att[d].table;
+    if ((t == 0) != (phase == 0)) continue;
+    const uint32_t ne = t == 0 ? (uint32_t)J.nev : (t - 1 < J.nad ? (uint32_t)J.t_nv[t - 1] : 0u);
+    GDRans &S = J.rs[6 + d];
+    if (ne != 0 && ne <= J.ecap) { S.nvals = ne * (uint32_t)J.att[d].nc; S.early = 1u + (uint32_t)phase; }
+  }
+}
 __global__ void __launch_bounds__(64) k_gdec_counts(GeoDecJob *jobs, GeoJob *gj) {
   GeoDecJob &J = jobs[blockIdx.x]; GeoJob &G = gj[blockIdx.x];
   if (threadIdx.x != 0) return;
   if (G.status != 0 && J.status == 0) J.status = G.status;
   if (J.status != 0) return;
-  if (J.method == 0) { G.ne[0] = (uint32_t)J.nv; return; }                   // sequential: one entry per point, the value counts were known at once
-  for (int d = 0; d < J.ndec; d++) J.rs[6 + d].nvals = G.ne[J.att[d].table] * (uint32_t)J.att[d].nc;
+  if (J.method == 0) { G.ne[0] = (uint32_t)J.nv; for (int d = 0; d < J.ndec; d++) J.rs[6 + d].redo = J.rs[6 + d].early ? 0u : 1u; return; }      // sequential: one entry per point, the value counts were known at once
+  for (int d = 0; d < J.ndec; d++) {
+    GDRans &S = J.rs[6 + d];
+    const uint32_t nv = G.ne[J.att[d].table] * (uint32_t)J.att[d].nc;
+    S.redo = (S.early && S.nvals == nv) ? 0u : 1u;
+    S.nvals = nv;
+  }
 }
 
 // ---- K10: outputs.  blockIdx.z = 0 position, 1 tex-coord, 2 normal ----
@@ -941,11 +966,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_finish(GeoDecJob *jobs, Geo
 // host side
 // ================================================================================================
 struct GDPlan { std::vector<uint64_t> key; std::vector<size_t> offs; size_t total = 0, zero = 0; };      // workspace placement of the last frame dimensions seen (gdec_carve)
-struct GeoDecState { uvol_devbuf files, slab, jobs, gjobs, outs; std::vector<GeoDecJob> hjobs; std::vector<GeoJob> hg; GDPlan plan; };
+struct GeoDecState { uvol_devbuf files, slab, jobs, gjobs, outs; std::vector<GeoDecJob> hjobs; std::vector<GeoJob> hg; GDPlan plan;
+                     hipStream_t aux = nullptr; hipEvent_t ev_tabs = nullptr, ev_sym = nullptr; };      // aux: the attribute symbol streams, beside the traversals
 int geodec_create(uvol_ctx *ctx) { ctx->geodec = new GeoDecState(); return UVOL_OK; }
 void geodec_destroy(uvol_ctx *ctx) {
   GeoDecState *t = ctx->geodec; if (!t) return;
   for (uvol_devbuf *b : { &t->files, &t->slab, &t->jobs, &t->gjobs, &t->outs }) if (b->p) (void)hipFree(b->p);
+  if (t->aux) { (void)hipStreamSynchronize(t->aux); (void)hipStreamDestroy(t->aux); }
+  if (t->ev_tabs) (void)hipEventDestroy(t->ev_tabs);
+  if (t->ev_sym) (void)hipEventDestroy(t->ev_sym);
   delete t; ctx->geodec = nullptr;
 }
 
@@ -1008,9 +1037,10 @@ static size_t gdec_carve(GeoDecJob &J, GeoJob &G, uint8_t *base, bool r8, bool f
   for (int k = 0; k < 6; k++) { GDRans &S = J.rs[k]; S.max_ns = GD_CTX_NS; S.max_prec_bits = 12; DCARVE(S.probs, 4 * GD_CTX_NS, DS_CTX, DS_CONN); DCARVE(S.cum, 4 * GD_CTX_NS, DS_CTX, DS_CONN); DCARVE(S.lut, 4 * (1u << 12), DS_CTX, DS_CONN); DCARVE(S.out, 4 * (nf + 1), DS_CTX, DS_CONN); }
   for (int k = 0; k < GD_MAXDEC; k++) {
     GDRans &S = J.rs[6 + k]; S.max_ns = GD_MAX_NS; S.max_prec_bits = 20;
-    DCARVE(S.probs, 4 * (size_t)GD_MAX_NS, DS_SYM, DS_SYM); DCARVE(S.cum, 4 * (size_t)GD_MAX_NS, DS_SYM, DS_SYM); DCARVE(S.lut, 4 * (size_t)(1u << 20), DS_SYM, DS_SYM);
+    // (written from the traversal stage on: the early pass of the symbol decoder runs beside the traversals)
+    DCARVE(S.probs, 4 * (size_t)GD_MAX_NS, DS_CTX, DS_SYM); DCARVE(S.cum, 4 * (size_t)GD_MAX_NS, DS_CTX, DS_SYM); DCARVE(S.lut, 4 * (size_t)(1u << 20), DS_CTX, DS_SYM);
     // (the last slot also holds the index differences of a frame with compressed sequential connectivity: one per corner)
-    DCARVE(S.out, 4 * (std::max(4 * E, k == GD_MAXDEC - 1 ? nc : (size_t)0) + 4), DS_SYM, DS_PRED); DCARVE(J.att[k].vals, 4 * (4 * E + 4), DS_PRED, DS_FIN);
+    DCARVE(S.out, 4 * (std::max(4 * E, k == GD_MAXDEC - 1 ? nc : (size_t)0) + 4), DS_CTX, DS_PRED); DCARVE(J.att[k].vals, 4 * (4 * E + 4), DS_PRED, DS_FIN);
   }
   for (int k = 1; k < 4; k++) DCARVE(G.rec[k], (r8 ? 32 : 64) * (nf + 1), DS_TRAV, DS_TRAV);     // 8- or 16-byte corner records, decided per batch (geo_records8)
   for (int k = 0; k < 3; k++) { DCARVE(G.order[k], 4 * (E + 3), DS_TRAV, DS_FIN); DCARVE(G.v2d[k], 4 * (std::max(E, maxv) + 3), DS_TRAV, DS_FIN); DCARVE(G.t_stack[k], 4 * (nf + 2), DS_TRAV, DS_TRAV); DCARVE(G.t_vvis[k], std::max(E, maxv) / 8 + 64, UVOL_WS_PINNED, UVOL_WS_PINNED); DCARVE(G.t_fvis[k], nf / 8 + 64, UVOL_WS_PINNED, UVOL_WS_PINNED); }
@@ -1071,7 +1101,22 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
   const unsigned N = (unsigned)n, bc = uvol_blocks((size_t)3 * max_nf);
   GLAUNCH(k_gdec_clear, dim3(64, N), dim3(UVOL_BLOCK), 0, dj);
   { uvol_ctx::Scope sc(ctx, "geodec.k1_index", 0); GLAUNCH(k_gdec_init, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj); GLAUNCH(k_gdec_index, dim3(N), dim3(64), 0, dj); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, 6), dim3(64), 0, dj, 0, 6); }
+  // the attribute symbol streams on the second stream: the base table's beside the connectivity decoder, the others beside the traversals
+  if (!T->aux) {
+    UVOL_HIP_CHECK(ctx, hipStreamCreateWithFlags(&T->aux, hipStreamNonBlocking));
+    UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_tabs, hipEventDisableTiming));
+    UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_sym, hipEventDisableTiming));
+  }
+  auto early_pass = [&](int phase) -> int {
+    UVOL_HIP_CHECK(ctx, hipEventRecord(T->ev_tabs, ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(T->aux, T->ev_tabs, 0));
+    hipStream_t main = ctx->stream; ctx->stream = T->aux;
+    GLAUNCH(k_gdec_counts_early, dim3(N), dim3(64), 0, dj, phase);
+    GLAUNCH(k_gdec_rans, dim3(N, GD_MAXDEC), dim3(64), 0, dj, 6, GD_MAXDEC, phase == 0 ? 1 : 3);
+    ctx->stream = main;
+    return UVOL_OK; };
+  if ((rc = early_pass(0))) return rc;
+  { uvol_ctx::Scope sc(ctx, "geodec.k2_ctx_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, 6), dim3(64), 0, dj, 0, 6, 0); }
   { uvol_ctx::Scope sc(ctx, "geodec.k3_connectivity", 0); GLAUNCH(k_gdec_conn<false>, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_conn<true>, dim3(N), dim3(64), 0, dj); GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 0); }
   { uvol_ctx::Scope sc(ctx, "geodec.k4_seams_tables", 0);
     GLAUNCH(k_gdec_seams, dim3(N), dim3(64), 0, dj);
@@ -1081,10 +1126,13 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
     GLAUNCH(k_gdec_atttab, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj, 1);
     GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 1);
     GLAUNCH(k_gdec_open, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
+  if ((rc = early_pass(1))) { (void)hipStreamSynchronize(T->aux); return rc; }
+  UVOL_HIP_CHECK(ctx, hipEventRecord(T->ev_sym, T->aux));
   { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
-    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) return rc;
+    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) { (void)hipStreamSynchronize(T->aux); return rc; }
+    UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, T->ev_sym, 0));
     GLAUNCH(k_gdec_counts, dim3(N), dim3(64), 0, dj, gj); }
-  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, GD_MAXDEC), dim3(64), 0, dj, 6, GD_MAXDEC);
+  { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, GD_MAXDEC), dim3(64), 0, dj, 6, GD_MAXDEC, 2);
     GLAUNCH(k_gdec_seq_conn, dim3(N), dim3(64), 0, dj); }                  // frames with sequential connectivity: their index section
   { uvol_ctx::Scope sc(ctx, "geodec.k7_predict", 0);
     GLAUNCH(k_gdec_pgram, dim3(bc, N, GD_MAXDEC), dim3(UVOL_BLOCK), 0, dj, gj);
@@ -1097,6 +1145,8 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(GeoDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (uvol_debug()) { int ne = 0, nr = 0; for (int i = 0; i < n; i++) for (int d = 0; d < T->hjobs[i].ndec; d++) { ne += T->hjobs[i].rs[6 + d].early != 0; nr += T->hjobs[i].rs[6 + d].redo != 0; }
+    fprintf(stderr, "[uvol] decode: %d attribute streams decoded beside the traversal, %d (again) after it\n", ne, nr); }
   int worst = UVOL_OK;
   std::vector<int> retry;
   for (int i = 0; i < n; i++) {
