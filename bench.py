@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
+    ap.add_argument("--host-enqueued", action="store_true", help="with --host-inputs: the passes go through the enqueue forms (uvol_*_async on host buffers, one uvol_sync)")
     args = ap.parse_args()
 
     import numpy as np
@@ -160,8 +161,9 @@ def main():
     class Job:
         """One pass over the first n frames / n // B segments of the resident inputs (n = F for the headline; the variants run
         smaller jobs on the same contexts and buffers)."""
-        def __init__(self, n, host=False, only=args.only, blocking=False):
+        def __init__(self, n, host=False, only=args.only, blocking=False, host_enqueued=False):
             self.n, self.nseg, self.host, self.only, self.blocking = n, n // B, host, only, blocking or args.blocking_calls
+            self.host_enqueued = host and host_enqueued         # host inputs through the enqueue forms (uvol_*_async on host buffers + uvol_sync)
             self.gsl = [(gi * n // GS, (gi + 1) * n // GS) for gi in range(GS)]
             nd = len(dev_meshes)
             self.gb = None if host else [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
@@ -172,6 +174,14 @@ def main():
             by one uvol_sync - the context then runs the front end of pass k + 1 beside the walkers of pass k (two output buffer sets in
             turn: a pass's bytes are in host memory when the pass after the next one starts).  --blocking-calls: one blocking call per pass."""
             a, b = self.gsl[gi]
+            if self.host_enqueued and b > a:
+                for k in range(kk):
+                    geos[gi].start_mesh_batch(self.hf[a:b])
+                res = geos[gi].finish()
+                if any(r is None for r in res[-1]):
+                    raise RuntimeError("bench: a geometry frame failed")
+                out["drc_%d" % gi] = res[-1]
+                return
             if self.host or self.blocking or b <= a:
                 for _ in range(kk):
                     self.run_geo(gi)
@@ -211,6 +221,13 @@ def main():
                     errors.append(e)
 
             def loop(fn, arg, kk):
+                if self.host_enqueued and fn == self.run_tex:            # texture share of a host-input job, enqueued like the geometry share
+                    segs = range(arg, self.nseg, len(texs))
+                    if len(segs):
+                        for _ in range(kk):
+                            texs[arg].start_texture_segments([tex_h] * len(segs))
+                        out["ktx2_%d" % arg] = texs[arg].finish()[-1]
+                        return
                 for _ in range(kk):
                     fn(arg)
             rounds = [(1, k)] if not args.lockstep else [(k, 1)]
@@ -251,7 +268,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    main_job = Job(F, host=args.host_inputs)
+    main_job = Job(F, host=args.host_inputs, host_enqueued=args.host_enqueued)
     if args.warmup:
         main_job.steps(args.warmup)
     set_profiling(True)
@@ -410,7 +427,10 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     frame_t.clear(); keep.clear(); del dev_meshes[:]
     renew_geos()                                               # (fresh workspaces: the host path cuts a call into more groups than the device path)
     nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
-    v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers")
+    v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers; "
+                                                                   "one blocking call per pass and half; enqueued_passes: the same passes through uvol_*_async + uvol_sync (a pass uploads while its predecessor encodes)")
+    note("host_inputs enqueued")
+    v["host_inputs"]["enqueued_passes"] = Job(nh, host=True, host_enqueued=True).timed(3, 1)["frames_per_s"]
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
     note("decode")
     drc = [bytes(x) for x in out["drc"][:480]]; ktx = list(out["ktx2"][:192])

@@ -295,6 +295,8 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
   int rc = 0, nv = 0, sp = 0, nfaces = 0, active_ctx = -1, splits_left = nts, n_int = 0;
   int top = GEO_INV;                 // mirror of stack[sp - 1]: the machine reads its own last write most of the time
   int fv0 = 0, fv1 = 0, fv2 = 0;     // vertices of the new face's corners 0, 1, 2 (known without re-reading c2v)
+  int lm_fv1 = GEO_INV;              // lm[fv1], fetched together with the valences at the end of a step: a C symbol starts from it, and loading it
+                                     // there was the first of three dependent round trips of the step (nothing writes lm[] in between)
   const int SYM2TOPO[5] = { 0, 1, 3, 5, 7 };
 #define GD_SETOPP(a, bb) do { opp[a] = (bb); opp[bb] = (a); } while (0)
 #define GD_ADDV() (nv < maxv ? (lm[nv] = GEO_INV, nv++) : (rc = -9, 0))
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
       if (sp == 0) { rc = -11; break; }
       // `top` is always corner 0 of the face added by the previous symbol, whose vertices are still in fv0..fv2: no c2v reads for it
       const int ca = top; if (GD_BADC(ca)) { rc = -11; break; } const int vx = fv1; if (GD_BADV(vx)) { rc = -11; break; }
-      const int lmx = lm[vx]; if (GD_BADC(lmx)) { rc = -11; break; }
+      const int lmx = lm_fv1; if (GD_BADC(lmx)) { rc = -11; break; }
       const int cb = g_nxt(lmx);
       if (ca == cb || opp[ca] != GEO_INV || opp[cb] != GEO_INV) { rc = -11; break; }
       GD_SETOPP(ca, corner + 1); GD_SETOPP(cb, corner + 2);
@@ -374,6 +376,7 @@ __global__ void __launch_bounds__(64) k_gdec_conn(GeoDecJob *jobs) {
       // after the stores was one more round trip through L2 in the chain (aliases among the three only occur in degenerate streams)
       const int i0 = (sym == 0 || sym == 1) ? 0 : (sym == 7 ? 2 : 1), i1 = sym == 3 || sym == 7 ? 2 : 1, i2 = sym == 5 || sym == 7 ? 2 : 1;
       const int o0 = val[fv0], o1 = val[fv1], o2 = val[fv2];
+      lm_fv1 = lm[fv1];
       const int t0 = o0 + i0, t1 = (fv1 == fv0 ? t0 : o1) + i1, t2 = (fv2 == fv1 ? t1 : (fv2 == fv0 ? t0 : o2)) + i2;
       if (i0) val[fv0] = t0;
       val[fv1] = t1; val[fv2] = t2;
@@ -967,13 +970,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_gdec_finish(GeoDecJob *jobs, Geo
 // ================================================================================================
 struct GDPlan { std::vector<uint64_t> key; std::vector<size_t> offs; size_t total = 0, zero = 0; };      // workspace placement of the last frame dimensions seen (gdec_carve)
 struct GeoDecState { uvol_devbuf files, slab, jobs, gjobs, outs; std::vector<GeoDecJob> hjobs; std::vector<GeoJob> hg; GDPlan plan;
-                     hipStream_t aux = nullptr; hipEvent_t ev_tabs = nullptr, ev_sym = nullptr; };      // aux: the attribute symbol streams, beside the traversals
+                     hipStream_t aux = nullptr; hipEvent_t ev_tabs[2] = { nullptr, nullptr }, ev_sym = nullptr; };      // aux: the attribute symbol streams, beside the traversals
 int geodec_create(uvol_ctx *ctx) { ctx->geodec = new GeoDecState(); return UVOL_OK; }
 void geodec_destroy(uvol_ctx *ctx) {
   GeoDecState *t = ctx->geodec; if (!t) return;
   for (uvol_devbuf *b : { &t->files, &t->slab, &t->jobs, &t->gjobs, &t->outs }) if (b->p) (void)hipFree(b->p);
   if (t->aux) { (void)hipStreamSynchronize(t->aux); (void)hipStreamDestroy(t->aux); }
-  if (t->ev_tabs) (void)hipEventDestroy(t->ev_tabs);
+  for (int k = 0; k < 2; k++) if (t->ev_tabs[k]) (void)hipEventDestroy(t->ev_tabs[k]);
   if (t->ev_sym) (void)hipEventDestroy(t->ev_sym);
   delete t; ctx->geodec = nullptr;
 }
@@ -1104,12 +1107,12 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
   // the attribute symbol streams on the second stream: the base table's beside the connectivity decoder, the others beside the traversals
   if (!T->aux) {
     UVOL_HIP_CHECK(ctx, hipStreamCreateWithFlags(&T->aux, hipStreamNonBlocking));
-    UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_tabs, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_tabs[k], hipEventDisableTiming));      // (one per phase: a wait must not see a later record of its event)
     UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_sym, hipEventDisableTiming));
   }
   auto early_pass = [&](int phase) -> int {
-    UVOL_HIP_CHECK(ctx, hipEventRecord(T->ev_tabs, ctx->stream));
-    UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(T->aux, T->ev_tabs, 0));
+    UVOL_HIP_CHECK(ctx, hipEventRecord(T->ev_tabs[phase], ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(T->aux, T->ev_tabs[phase], 0));
     hipStream_t main = ctx->stream; ctx->stream = T->aux;
     GLAUNCH(k_gdec_counts_early, dim3(N), dim3(64), 0, dj, phase);
     GLAUNCH(k_gdec_rans, dim3(N, GD_MAXDEC), dim3(64), 0, dj, 6, GD_MAXDEC, phase == 0 ? 1 : 3);
