@@ -371,13 +371,10 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     def note(what):                                            # progress on stderr (a fault in a variant is then attributable)
         print("[bench] variant: " + what, file=sys.stderr, flush=True)
         v["in_progress"] = what                                # (stays in the line only if this variant raises)
-    def renew_geos():                                          # fresh geometry contexts: a lane's workspace only grows, and the variants below change its shape
-        n = len(geos)
-        for c in geos:
-            c.close()
-        del geos[:]
+    def trim_geos():                                           # a lane's workspace only grows, and the variants below change its shape: back to the device
+        for c in geos:                                         # (uvol_trim; the contexts and their streams stay - fresh contexts measured 13 % slower,
+            c.trim()                                           #  profiles/r04_d_bench.json against r04_e)
         torch.cuda.empty_cache()
-        geos.extend(uvol.Codec(**args._geo_cfg) for _ in range(n))
     # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
     note("events_off")
     set_profiling(False)
@@ -400,14 +397,6 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     if args.only:                                              # (diagnostic: UVOL_VARIANTS_WITH_ONLY=1) one half of the path, job sizes only
         v.pop("in_progress", None)
         return v
-    # (2c) one blocking geometry call per pass (the whole call is one group on the context's first lane, which then holds a workspace of
-    #      the full call: fresh contexts before and after; the inputs are still the headline's)
-    note("blocking_calls")
-    renew_geos()
-    kb = max(2, min(args.steps, 4))
-    v["blocking_calls"] = dict(Job(F, blocking=True).timed(kb, 1), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
-    v["blocking_calls"]["enqueued_same_passes"] = Job(F).timed(kb, 1)["frames_per_s"]      # (short runs flatter both: the texture context finishes its passes early)
-    renew_geos()
     # (2) scan-like storage order: the resident input buffers are overwritten with a seeded permutation of faces and values
     note("shuffled_order")
     sh = [synth.shuffle_mesh(m, seed=100 + k) for k, m in enumerate(meshes_h)]
@@ -422,10 +411,19 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
         build_inputs(identical_meshes())
         v["identical_connectivity"] = dict(Job(F).timed(2, 1), note="DIAGNOSTIC: five deformations of one tessellation (shared index arrays): the lane-per-walker kernels move in lock step; "
                                                                      "this was `value` until round 3 and flatters the dominant kernel")
+    # (2c) one blocking geometry call per pass (the whole call is one group on the context's first lane, which then holds a workspace of
+    #      the full call: its workspaces are given back before and after; the headline's inputs are rebuilt)
+    note("blocking_calls")
+    if args.connectivity == "distinct":
+        build_inputs(meshes_h)
+    trim_geos()
+    kb = max(2, min(args.steps, 4))
+    v["blocking_calls"] = dict(Job(F, blocking=True).timed(kb, 1), note="headline workload, one blocking geometry call per pass instead of enqueued passes")
+    v["blocking_calls"]["enqueued_same_passes"] = Job(F).timed(kb, 1)["frames_per_s"]      # (short runs flatter both: the texture context finishes its passes early)
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
     note("host_inputs")
     frame_t.clear(); keep.clear(); del dev_meshes[:]
-    renew_geos()                                               # (fresh workspaces: the host path cuts a call into more groups than the device path)
+    trim_geos()                                                # (the host path cuts a call into more groups than the device path)
     nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers; "
                                                                    "one blocking call per pass and half; enqueued_passes: the same passes through uvol_*_async + uvol_sync (a pass uploads while its predecessor encodes)")

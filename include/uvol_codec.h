@@ -75,6 +75,10 @@ void uvol_ctx_destroy(uvol_ctx *ctx);
 const char *uvol_last_error(const uvol_ctx *ctx);
 /* completes everything enqueued on ctx (uvol_*_async calls and the stream); returns the first error among the enqueued calls */
 int  uvol_sync(uvol_ctx *ctx);
+/* uvol_sync, then the geometry workspaces of ctx go back to the device (they only grow: a context that once ran a 2560-frame call as one
+ * group keeps ~130 GB until it is destroyed); its streams stay, the next call allocates what it needs.  No counterpart in the reference
+ * (its encoders are processes that exit, scripts/Encoder.py:266-302); a long-lived host uses it between jobs of very different sizes. */
+int  uvol_trim(uvol_ctx *ctx);
 
 /* One frame of OBJ-shaped geometry: separate value arrays + per-corner index triplets
  * (what draco_encoder parses out of `v/vt/vn/f` lines).  uv / nrm (and their index arrays) may be

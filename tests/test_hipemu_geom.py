@@ -122,6 +122,9 @@ def test_hipemu_enqueue_form_of_the_abi(oracle, hipemu_lib):
     cd.start_mesh_batch([a])
     assert cd.encode_mesh(**b) == enc(b)                      # blocking call: after the queued one
     assert cd.finish() == [[enc(a)]]
+    cd.start_mesh_batch([b, a])                               # uvol_trim: completes what is queued, gives the workspaces back; the context goes on
+    cd.trim()
+    assert cd.finish() == [[enc(b), enc(a)]] and cd.encode_mesh(**a) == enc(a)
     cd.close()
     c2 = uvol.Codec(lib_path=hipemu_lib, Q_POSITION_ATTR=30)
     c2.start_mesh_batch([a])

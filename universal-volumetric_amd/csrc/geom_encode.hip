@@ -3116,6 +3116,17 @@ static GeoLane *geo_lane(uvol_ctx *ctx, int k) {
   return G->lanes[k];
 }
 
+// uvol_trim: the device workspaces of every lane go back to the device (they only grow: a lane that once ran a whole 2560-frame call keeps
+// 130 GB); streams, events and the small job arrays stay.  The caller has completed the context's work (geo_flush).
+int geo_trim(uvol_ctx *ctx) {
+  GeoState *G = ctx->geo; if (!G) return UVOL_OK;
+  for (GeoLane *L : G->lanes) {
+    if (L->busy) continue;
+    UVOL_HIP_CHECK(ctx, hipStreamSynchronize(L->stream)); UVOL_HIP_CHECK(ctx, hipStreamSynchronize(L->aux));
+    for (uvol_devbuf *b : { &L->slab, &L->inputs, &L->outs }) if (b->p) { UVOL_HIP_CHECK(ctx, hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+  }
+  return UVOL_OK;
+}
 int geo_create(uvol_ctx *ctx) {
   ctx->geo = new GeoState();
   if (!geo_lane(ctx, 0)) return UVOL_E_HIP;

@@ -160,6 +160,14 @@ int uvol_sync(uvol_ctx *ctx) {
   return arc;
 }
 
+int uvol_trim(uvol_ctx *ctx) {
+  const int rc = uvol_sync(ctx);
+  if (!ctx) return rc;
+  const int rf = geo_flush(ctx);
+  const int rt = geo_trim(ctx);
+  return rc != UVOL_OK ? rc : (rf != UVOL_OK ? rf : rt);
+}
+
 // defer = the enqueue form: the call's groups are submitted and completed lazily (by the worker when its queue runs empty, or when a
 // later call needs the lane), so that consecutive enqueued calls overlap on the device
 static int encode_batch_common(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool dev,

@@ -234,6 +234,7 @@ int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_
 int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool inputs_on_device,
                            uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool split);
 int geo_flush(uvol_ctx *ctx);
+int geo_trim(uvol_ctx *ctx);
 // GPU-resident form: one group on lane 0, ordered after `producer`, bitstreams packed into the caller's device buffer
 int geo_encode_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, hipStream_t producer, uint8_t *dev_out, size_t dev_cap, size_t *out_offs, size_t *out_lens, int *status);
 int geodec_create(uvol_ctx *ctx);

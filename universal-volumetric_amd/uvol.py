@@ -35,7 +35,7 @@ class Mesh(C.Structure):
 
 
 EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol_ctx_create", "uvol_ctx_destroy",
-           "uvol_last_error", "uvol_sync", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
+           "uvol_last_error", "uvol_sync", "uvol_trim", "uvol_mesh_bound", "uvol_mesh_workspace", "uvol_encode_mesh", "uvol_encode_mesh_batch",
            "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_dev_out", "uvol_decode_mesh_batch_dev", "uvol_parse_obj_batch_dev", "uvol_unfilter_png_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_etc2_rgba", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
@@ -52,6 +52,7 @@ def load(path=None):
     L.uvol_ctx_destroy.argtypes = [C.c_void_p]
     L.uvol_last_error.argtypes = [C.c_void_p]; L.uvol_last_error.restype = C.c_char_p
     L.uvol_sync.argtypes = [C.c_void_p]
+    L.uvol_trim.argtypes = [C.c_void_p]
     L.uvol_mesh_bound.argtypes = [C.POINTER(Mesh)]; L.uvol_mesh_bound.restype = C.c_size_t
     L.uvol_mesh_workspace.argtypes = [C.c_void_p, C.POINTER(Mesh)]; L.uvol_mesh_workspace.restype = C.c_size_t
     L.uvol_encode_mesh.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -256,6 +257,12 @@ class Codec:
         if rc != UVOL_OK:
             raise UvolError(f"encode_texture_segments_async rc={rc}: {self.error()}")
         self._pending = getattr(self, "_pending", []) + [("tex", nseg, bufs, lens, None, flat, ptrs)]
+
+    def trim(self):
+        """uvol_trim: completes the context's work and gives its geometry workspaces back to the device (streams stay)."""
+        rc = self.L.uvol_trim(self.h)
+        if rc != UVOL_OK:
+            raise UvolError(f"uvol_trim rc={rc}: {self.error()}")
 
     def finish(self):
         """uvol_sync: completes every enqueued call; returns their results in call order (meshes: None for a failed frame)."""
