@@ -447,6 +447,9 @@ def test_gpu_batch_sizes_alternate_on_one_context(oracle):
         for n in (1300, 7, 1300, 150):
             got = cd.encode_mesh_batch(frames[:n])
             assert all(got[i] == want[i % 4] for i in range(n)), n
+        cd.trim()                                             # uvol_trim: the workspaces go back to the device, the context goes on
+        got = cd.encode_mesh_batch(frames[:300])
+        assert all(got[i] == want[i % 4] for i in range(300))
     finally:
         cd.close()
 
