@@ -244,18 +244,40 @@ __global__ void __launch_bounds__(64) k_gdec_rans(GeoDecJob *jobs, int first, in
   }
   __syncthreads();
   if (s_err) { if (lane == 0) J.status = -5; return; }
-  for (uint32_t s = lane; s < ns; s += 64) { const uint32_t c = S.cum[s], p = S.probs[s]; for (uint32_t j = 0; j < p; j++) S.lut[c + j] = s; }
+  // small tables (the six valence-context streams: 12-bit precision, a handful of symbols) are decoded out of LDS: the chain of a symbol
+  // is slot -> symbol -> {frequency, cumulative}, two dependent look-ups that cost an L2 round trip each from global memory
+  __shared__ uint16_t l_lut[4096]; __shared__ uint32_t l_probs[256], l_cum[256];
+  const bool small = prec <= 4096 && ns <= 256;
+  for (uint32_t s = lane; s < ns; s += 64) {
+    const uint32_t c = S.cum[s], p = S.probs[s];
+    if (small) { l_probs[s] = p; l_cum[s] = c; for (uint32_t j = 0; j < p; j++) l_lut[c + j] = (uint16_t)s; }
+    else for (uint32_t j = 0; j < p; j++) S.lut[c + j] = s;
+  }
   __threadfence_block();
   __syncthreads();
   if (lane != 0) return;
   const uint8_t *buf = J.file + S.pay_off; uint32_t off, st;
   if (gd_ans_init(buf, S.pay_len, off, st, L, true)) { J.status = -6; return; }
-  const uint32_t mask = prec - 1, pb = S.prec_bits;
-  for (uint32_t k = 0; k < S.nvals; k++) {
-    while (st < L && off > 0) { off--; st = st * 256 + buf[off]; }
-    const uint32_t quo = st >> pb, rem = st & mask, s = S.lut[rem];
-    st = quo * S.probs[s] + rem - S.cum[s];
-    S.out[k] = s;
+  const uint32_t mask = prec - 1, pb = S.prec_bits, nvals = S.nvals;
+  uint32_t *out = S.out;
+  // the next payload byte is fetched one step ahead of the renormalisation that consumes it (a byte load behind the state update was one
+  // more round trip in the chain of most symbols)
+  uint32_t nb = off > 0 ? buf[off - 1] : 0u;
+  if (small) {
+    for (uint32_t k = 0; k < nvals; k++) {
+      while (st < L && off > 0) { off--; st = st * 256 + nb; nb = off > 0 ? buf[off - 1] : 0u; }
+      const uint32_t quo = st >> pb, rem = st & mask, s = l_lut[rem];
+      st = quo * l_probs[s] + rem - l_cum[s];
+      out[k] = s;
+    }
+  } else {
+    const uint32_t *lut = S.lut, *probs = S.probs, *cum = S.cum;
+    for (uint32_t k = 0; k < nvals; k++) {
+      while (st < L && off > 0) { off--; st = st * 256 + nb; nb = off > 0 ? buf[off - 1] : 0u; }
+      const uint32_t quo = st >> pb, rem = st & mask, s = lut[rem];
+      st = quo * probs[s] + rem - cum[s];
+      out[k] = s;
+    }
   }
 }
 
