@@ -308,6 +308,8 @@ inline UvolUpSched &uvol_up_sched(int device) {
 // host threads one upload may use for its memcpy into the pinned buffers: 8 when the process drives one device, fewer per upload
 // when it drives several (`uvolenc --gpus 8`: 16 contexts), so that the copies do not oversubscribe the host
 inline int uvol_up_threads() {
+  static const int forced = [] { const char *e = getenv("UVOL_UP_THREADS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();      // diagnostic
+  if (forced) return forced;
   static const int hw = [] { const unsigned h = std::thread::hardware_concurrency(); return (int)(h ? h : 8); }();
   int ndev = 1; (void)hipGetDeviceCount(&ndev); if (ndev < 1) ndev = 1;
   return std::max(2, std::min(8, hw / (2 * ndev)));
