@@ -22,5 +22,9 @@ torch.cuda.synchronize(); t = time.time()
 c.decode_texture_segments_dev(files, ptrs, size * size * 4)
 torch.cuda.synchronize(); dt = time.time() - t
 rep = c.profile_report()
+c.profile(False)
+nh = min(nseg, 48)                                                      # host outputs (20 MB per layer): arrays kept between calls
+host = c.decode_texture_segments(files[:nh])
+t = time.time(); c.decode_texture_segments(files[:nh], out=host); dth = time.time() - t
 print(json.dumps(dict(segments=nseg, layers=5, size=size, ktx2_bytes=len(seg), wall_s=dt, frames_per_s=nseg * 5 / dt,
-                      rgba_GBps=nseg * 5 * size * size * 4 / dt / 1e9, groups={g["name"]: round(g["total_ms"], 2) for g in rep})))
+                      rgba_GBps=nseg * 5 * size * size * 4 / dt / 1e9, frames_per_s_with_fetch_to_host=nh * 5 / dth, fetch_segments=nh, groups={g["name"]: round(g["total_ms"], 2) for g in rep})))

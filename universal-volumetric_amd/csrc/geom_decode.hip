@@ -1176,6 +1176,7 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
     fprintf(stderr, "[uvol] decode: %d attribute streams decoded beside the traversal, %d (again) after it\n", ne, nr); }
   int worst = UVOL_OK;
   std::vector<int> retry;
+  std::vector<UvolDnItem> dns; if (!out_dev) dns.reserve((size_t)n * 6);      // host outputs: ONE staged download for the whole call (uvol_download_staged)
   for (int i = 0; i < n; i++) {
     const GeoDecJob &J = T->hjobs[i]; uvol_decoded_mesh &M = out[i];
     if (!full && J.status == GD_E_WS_OVERFLOW) { retry.push_back(i); if (status) status[i] = UVOL_OK; continue; }      // decoded again below, alone, with worst-case sizes
@@ -1188,11 +1189,16 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
     for (int k = 0; k < 3; k++) {
       *cnt[k] = J.o_n[k];
       if (!J.o_n[k]) continue;
-      const hipMemcpyKind kind = out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;      // (uvol_decode_mesh_batch_dev: the arrays stay in HBM)
-      if (vals[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(vals[k], J.o_val[k], (size_t)J.o_n[k] * comps[k] * 4, kind, ctx->stream));
-      if (idx[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(idx[k], J.o_idx[k], (size_t)J.nf * 3 * 4, kind, ctx->stream));
+      if (out_dev) {                                                       // (uvol_decode_mesh_batch_dev: the arrays stay in HBM)
+        if (vals[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(vals[k], J.o_val[k], (size_t)J.o_n[k] * comps[k] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (idx[k]) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(idx[k], J.o_idx[k], (size_t)J.nf * 3 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      } else {
+        if (vals[k]) dns.push_back(UvolDnItem{ J.o_val[k], vals[k], (size_t)J.o_n[k] * comps[k] * 4 });
+        if (idx[k]) dns.push_back(UvolDnItem{ J.o_idx[k], idx[k], (size_t)J.nf * 3 * 4 });
+      }
     }
   }
+  if (!out_dev) { const int rcd = uvol_download_staged(ctx, dns); if (rcd != UVOL_OK) return rcd; }
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
   for (int i : retry) {                                   // frames the compact workspace could not hold (more entries per face than usual)

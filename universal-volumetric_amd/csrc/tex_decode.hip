@@ -660,10 +660,10 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < n; i++) if (T->hjobs[i].status != 0) { ctx->set_error("segment %d: corrupt BasisLZ stream (device status %d)", i, T->hjobs[i].status); return UVOL_E_ENCODE; }
-  if (!outputs_on_device) {
-    for (int i = 0; i < n; i++) for (size_t l = 0; l < L; l++)
-      UVOL_HIP_CHECK(ctx, hipMemcpyAsync(rgba[(size_t)i * L + l], T->hjobs[i].out[l], layer_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (!outputs_on_device) {                                  // host outputs: one staged download (pinned double buffers, host threads copy out)
+    std::vector<UvolDnItem> dns; dns.reserve((size_t)n * L);
+    for (int i = 0; i < n; i++) for (size_t l = 0; l < L; l++) dns.push_back(UvolDnItem{ T->hjobs[i].out[l], rgba[(size_t)i * L + l], layer_bytes });
+    const int rcd = uvol_download_staged(ctx, dns); if (rcd != UVOL_OK) return rcd;
   }
   ctx->resolve_profile();
   return UVOL_OK;

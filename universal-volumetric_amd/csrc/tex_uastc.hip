@@ -613,8 +613,11 @@ int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const 
     hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : 1); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (!outputs_on_device) for (int s = 0; s < n; s++) for (uint32_t l = 0; l < L; l++)
-    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(outp[(size_t)s * L + l], (uint8_t *)U->outs.p + layer_bytes * ((size_t)s * L + l), layer_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (!outputs_on_device) {
+    std::vector<UvolDnItem> dns; dns.reserve((size_t)n * L);
+    for (int s = 0; s < n; s++) for (uint32_t l = 0; l < L; l++) dns.push_back(UvolDnItem{ (uint8_t *)U->outs.p + layer_bytes * ((size_t)s * L + l), outp[(size_t)s * L + l], layer_bytes });
+    const int rcd = uvol_download_staged(ctx, dns); if (rcd != UVOL_OK) return rcd;
+  }
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
   for (int s = 0; s < n; s++) if (U->hjobs[s].status != 0) { ctx->set_error("segment %d: corrupt UASTC block or a mode this codec does not read (device status %d)", s, U->hjobs[s].status); return UVOL_E_ENCODE; }

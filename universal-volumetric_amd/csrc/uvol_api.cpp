@@ -143,6 +143,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   ctx->resolve_profile();
   geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx); png_destroy(ctx);
   for (int k = 0; k < 2; k++) { if (ctx->up_pin[k]) (void)hipHostFree(ctx->up_pin[k]); if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]); }
+  for (int k = 0; k < 2; k++) { if (ctx->dn_pin[k]) (void)hipHostFree(ctx->dn_pin[k]); if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -177,6 +177,7 @@ struct uvol_ctx {
   struct AsyncQ {
     std::mutex m; std::condition_variable cv_work, cv_idle; std::deque<std::function<int()>> q; std::thread th; bool busy = false, stop = false; int first_err = 0; char err[512] = {0};
   } *async = nullptr;
+  uint8_t *dn_pin[2] = { nullptr, nullptr }; hipEvent_t dn_ev[2] = { nullptr, nullptr };      // staged downloads (uvol_download_staged)
   uint8_t *up_pin[2] = { nullptr, nullptr }; size_t up_cap = 0; hipEvent_t up_ev[2] = { nullptr, nullptr }; bool up_rec[2] = { false, false };   // staged uploads (uvol_upload_staged); up_rec: a DMA out of that buffer may still be in flight
 
   void set_error(const char *fmt, ...) {
@@ -370,5 +371,62 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
     ctx->up_rec[buf] = true;
     sched.progress(sid, c1 - c0);
   }
+  return UVOL_OK;
+}
+
+// Device -> host download of many arrays into caller-owned (pageable) memory: the mirror of uvol_upload_staged.  hipMemcpyAsync into
+// pageable memory is staged by the runtime on one thread (a decoded 1920-frame batch is 20 GB: several seconds); here consecutive arrays
+// are copied by DMA into one of two pinned buffers, packed, and host threads copy a buffer out into the caller's arrays while the DMAs
+// of the next one run.  The caller's stream is synchronised when the function returns.
+struct UvolDnItem { const void *src; void *dst; size_t bytes; };
+static inline int uvol_download_staged(uvol_ctx *ctx, const std::vector<UvolDnItem> &items) {
+  size_t total = 0; for (const UvolDnItem &it : items) total += it.bytes;
+  const size_t CH = (size_t)128 << 20;
+  bool big = false; for (const UvolDnItem &it : items) big = big || it.bytes > CH;
+  if (total < ((size_t)4 << 20) || big) {                                  // small calls (or one huge array): the runtime's own path
+    for (const UvolDnItem &it : items) if (it.bytes) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return UVOL_OK;
+  }
+  if (!ctx->dn_pin[0]) {
+    uint8_t *pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; k++) { e = hipHostMalloc((void **)&pin[k], CH, hipHostMallocDefault); if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); }
+    if (e != hipSuccess) {
+      for (int k = 0; k < 2; k++) { if (pin[k]) (void)hipHostFree(pin[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+      ctx->set_error("staged download: pinned buffers: %s", hipGetErrorString(e)); return UVOL_E_HIP;
+    }
+    for (int k = 0; k < 2; k++) { ctx->dn_pin[k] = pin[k]; ctx->dn_ev[k] = ev[k]; }
+  }
+  const int nt = uvol_up_threads();
+  size_t ra[2] = { 0, 0 }, rb[2] = { 0, 0 }; bool has[2] = { false, false };
+  auto drain = [&](int b) -> int {                                          // buffer b holds items [ra[b], rb[b]) packed: out to the caller's arrays
+    UVOL_HIP_CHECK(ctx, hipEventSynchronize(ctx->dn_ev[b]));
+    const size_t a = ra[b], e = rb[b];
+    std::vector<size_t> off(e - a + 1, 0); for (size_t i = a; i < e; i++) off[i - a + 1] = off[i - a] + items[i].bytes;
+    const size_t bytes = off[e - a]; const uint8_t *pin = ctx->dn_pin[b];
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&, t]() {                   // thread t takes bytes [lo, hi) of the packed buffer, whatever arrays they belong to
+      const size_t lo = bytes * (size_t)t / (size_t)nt, hi = bytes * (size_t)(t + 1) / (size_t)nt;
+      for (size_t i = a; i < e; i++) {
+        const size_t s0 = std::max(off[i - a], lo), s1 = std::min(off[i - a + 1], hi);
+        if (s1 > s0) memcpy((uint8_t *)items[i].dst + (s0 - off[i - a]), pin + s0, s1 - s0);
+      } });
+    for (auto &x : th) x.join();
+    has[b] = false;
+    return UVOL_OK; };
+  size_t i = 0; int buf = 0;
+  while (i < items.size()) {
+    if (has[buf]) { const int r = drain(buf); if (r != UVOL_OK) return r; }
+    const size_t a = i; size_t o = 0;
+    while (i < items.size() && o + items[i].bytes <= CH) {
+      if (items[i].bytes) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->dn_pin[buf] + o, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, ctx->stream));
+      o += items[i].bytes; i++;
+    }
+    UVOL_HIP_CHECK(ctx, hipEventRecord(ctx->dn_ev[buf], ctx->stream));
+    ra[buf] = a; rb[buf] = i; has[buf] = true;
+    buf ^= 1;
+  }
+  for (int k = 0; k < 2; k++, buf ^= 1) if (has[buf]) { const int r = drain(buf); if (r != UVOL_OK) return r; }      // (the older buffer first)
+  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return UVOL_OK;
 }

@@ -361,12 +361,12 @@ class Codec:
             raise UvolError(f"uvol_ktx2_info rc={rc}")
         return w.value, h.value, n.value
 
-    def decode_texture_segments(self, files):
+    def decode_texture_segments(self, files, out=None):
         """files: list of .ktx2 bytes (one width / height / layer count) -> list (per segment) of [layers, H, W, 4] uint8 arrays,
         rows in stored order (the encoder's -y_flip is part of the stored image)."""
         files = [bytes(f) for f in files]
         w, h, nl = self.ktx2_info(files[0]); n = len(files)
-        outs = [np.empty((nl, h, w, 4), dtype=np.uint8) for _ in range(n)]
+        outs = out if out is not None else [np.empty((nl, h, w, 4), dtype=np.uint8) for _ in range(n)]      # out: arrays of an earlier call, re-used
         fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files])
         ptrs = (C.c_void_p * (n * nl))(*[outs[s][l].ctypes.data for s in range(n) for l in range(nl)])
         rc = self.L.uvol_decode_texture_segments(self.h, fp, ln, n, ptrs, w * h * 4)
@@ -432,17 +432,25 @@ class Codec:
             raise UvolError(f"decode_texture_segments_dev rc={rc}: {self.error()}")
 
     # ---- decode path (geometry half) ----
-    def decode_mesh_batch(self, files, raise_on_error=True, fetch=True):
+    def decode_mesh_batch(self, files, raise_on_error=True, fetch=True, views=False):
         """files: list of .drc bytes -> list of dicts {pos [n,3], uv [n,2], nrm [n,3] float32 in decoding order,
         idx_pos / idx_uv / idx_nrm [3*faces] uint32 entry index per corner}; absent attributes are None."""
         files = [bytes(f) for f in files]; n = len(files)
         metas = (DecodedMesh * n)(); keep = []
+        pool = self.__dict__.setdefault("_dec_bufs", []) if views else None      # views=True: the arrays are kept and re-used by the next call
         for i, f in enumerate(files):
             nf, mv = C.c_uint32(), C.c_uint32()
             if self.L.uvol_drc_info(f, len(f), C.byref(nf), C.byref(mv)) != UVOL_OK:
                 raise UvolError(f"frame {i}: not a .drc this decoder handles")
-            a = dict(pos=np.empty((mv.value, 3), np.float32), uv=np.empty((mv.value, 2), np.float32), nrm=np.empty((mv.value, 3), np.float32),
-                     idx_pos=np.empty(3 * nf.value, np.uint32), idx_uv=np.empty(3 * nf.value, np.uint32), idx_nrm=np.empty(3 * nf.value, np.uint32))
+            a = pool[i] if (pool is not None and i < len(pool) and pool[i]["idx_pos"].size >= 3 * nf.value and pool[i]["pos"].shape[0] >= mv.value) else None
+            if a is None:
+                a = dict(pos=np.empty((mv.value, 3), np.float32), uv=np.empty((mv.value, 2), np.float32), nrm=np.empty((mv.value, 3), np.float32),
+                         idx_pos=np.empty(3 * nf.value, np.uint32), idx_uv=np.empty(3 * nf.value, np.uint32), idx_nrm=np.empty(3 * nf.value, np.uint32))
+                if pool is not None:
+                    if i < len(pool):
+                        pool[i] = a
+                    else:
+                        pool.append(a)
             keep.append(a)
             m = metas[i]; m.cap_faces = nf.value; m.cap_values = mv.value
             for k, v in a.items():
@@ -461,8 +469,9 @@ class Codec:
             cnt = dict(pos=m.n_pos, uv=m.n_uv, nrm=m.n_nrm)
             if not fetch:
                 res.append(dict(n_faces=m.n_faces, n_pos=m.n_pos, n_uv=m.n_uv, n_nrm=m.n_nrm)); continue
-            res.append({k: (a[k][:cnt[k]].copy() if cnt[k] else None) for k in ("pos", "uv", "nrm")} |
-                       {"idx_" + k: (a["idx_" + k].copy() if cnt[k] else None) for k in ("pos", "uv", "nrm")} | {"n_faces": m.n_faces})
+            cp = (lambda v: v) if views else (lambda v: v.copy())
+            res.append({k: (cp(a[k][:cnt[k]]) if cnt[k] else None) for k in ("pos", "uv", "nrm")} |
+                       {"idx_" + k: (cp(a["idx_" + k][:3 * m.n_faces]) if cnt[k] else None) for k in ("pos", "uv", "nrm")} | {"n_faces": m.n_faces})
         return res
 
     # ---- measurement ----
