@@ -358,6 +358,27 @@ def test_hipemu_mesh_decode_matches_oracle(oracle, hipemu_lib):
     cd.close()
 
 
+def test_hipemu_decoder_corrects_a_header_that_lies_about_the_vertex_count(oracle, hipemu_lib):
+    """Round 4: the attribute symbol streams are decoded beside the connectivity decoder / the traversals with the value counts a valid
+    file implies (the header's vertex count for the base table).  A header whose count is off by a few is still a file the decoder
+    reads - the traversal counts the entries, the streams of the base table are decoded again with that count - and the result is
+    what the oracle decoder gives for the same bytes (and for the untouched file)."""
+    import synth, uvol
+    m = synth.torus_mesh(16, 8)
+    drc = oracle.drc_encode(m["pos"], m["idx_pos"], m["uv"], m["idx_uv"], m["nrm"], m["idx_nrm"])
+    assert drc[8] == 1 and drc[12] & 0x7f < 120                # edgebreaker; the vertex count's varint starts at byte 12
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    good = cd.decode_mesh_batch([drc])[0]
+    for delta in (1, 5):
+        b = bytearray(drc); b[12] = (b[12] & 0x80) | ((b[12] & 0x7f) + delta)
+        got = cd.decode_mesh_batch([bytes(b), drc])
+        _check_decoded(oracle, bytes(b), got[0])
+        _check_decoded(oracle, drc, got[1])
+        for k in ("pos", "uv", "nrm", "idx_pos", "idx_uv", "idx_nrm"):
+            assert np.array_equal(got[0][k], good[k]), (delta, k)
+    cd.close()
+
+
 def test_hipemu_decoders_survive_corrupt_input(oracle, hipemu_lib):
     """Decoders take files from outside: bit flips, truncation and overwritten words must end in a decoded result or a
     clean error (every index is validated before the parallel stages use it, fan walks are bounded), never in a crash."""
