@@ -122,6 +122,11 @@ def test_gpu_mesh_decode_matches_oracle(oracle, gpu_codec):
     for f, qb in ((frames[0], 16), (frames[1], 16), (frames[0], 4), (big, 16), (big, 11)):
         files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), qp=qb, qt=qb, qn=qb))
     files += [open(os.path.join(GOLDEN, n), "rb").read() for n in ("00000.drc", "00075.drc")]
+    # a header whose vertex count is off by one: the symbol streams decoded beside the traversal with that count are decoded again
+    lie = bytearray(files[0])
+    if lie[8] == 1 and lie[12] & 0x7f < 127:
+        lie[12] += 1
+        files.append(bytes(lie))
     for data, got in zip(files, gpu_codec.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)
 
