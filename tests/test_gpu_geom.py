@@ -101,8 +101,8 @@ def test_gpu_walker_bitmap_placements(oracle):
     # entwave: the wave-per-stream entropy coder instead of the lane-per-stream one
     # relabel: the locality relabelling forced on for these coherently stored meshes (per frame it is decided on the device)
     # earlyjoin: the auxiliary stream joined before the record tables (batches above 1200 frames); small batches join late
-    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "simtcorner", "simtfacebits", "entwave", "relabel", "relabel_simt", "earlyjoin"):
-        env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_SIMT_W="6", UVOL_FACE_BITS="1") if force == "simtfacebits" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="5") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
+    for force in ("", "vglobal", "global", "rec16", "simt4", "simt64", "simtcorner", "simtrec16", "entwave", "relabel", "relabel_simt", "earlyjoin"):
+        env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_SIMT_W="3", UVOL_REC16="1") if force == "simtrec16" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="5") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="64") if force.startswith("simt") else (dict(os.environ, UVOL_ENTROPY_WAVE="1") if force == "entwave" else dict(os.environ, UVOL_WALK_FORCE=force)))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (force, r.stdout[-500:], r.stderr[-1500:])
 

@@ -60,11 +60,11 @@ def test_hipemu_edge_cases_and_quantisation_bits(oracle, hipemu_lib):
         c2.close()
 
 
-@pytest.mark.parametrize("force", ["vglobal", "global", "rec16", "simt5", "simt64", "simtcorner", "simtfacebits", "relabel", "relabel_simt", "earlyjoin"])
+@pytest.mark.parametrize("force", ["vglobal", "global", "rec16", "simt5", "simt64", "simtcorner", "simtrec16", "relabel", "relabel_simt", "earlyjoin"])
 def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
     """Visited bitmaps in LDS (default, covered above), vertex bitmap in global memory (a table with more vertices than
     the LDS slot), nothing in LDS (mesh too large for LDS: the lane-per-walker kernels, one lane per wave), "simtN": the
-    lane-per-walker kernels with N lanes per wave on one 16-byte record per face ("simtcorner": on the 8-byte corner records, UVOL_REC_FACE=0; "simtfacebits": face-visited bits in an array of their own instead of bit 63 of the record, UVOL_FACE_BITS=1) and the lane-per-stream entropy coder (what large batches use; small ones get the
+    lane-per-walker kernels with N lanes per wave on one 16-byte record per face ("simtcorner": on the 8-byte corner records, UVOL_REC_FACE=0; "simtrec16": on the 16-byte corner records, UVOL_REC16=1) and the lane-per-stream entropy coder (what large batches use; small ones get the
     cooperative LDS walkers and the wave-per-stream coder, covered above): same bytes.  "rec16": the 16-byte corner records
     that batches with >= 2^18 faces per mesh use instead of the packed 8-byte ones (UVOL_REC16=1).  The switches are read
     "relabel": the locality relabelling forced on (these small lattice-built meshes are stored coherently, so the per-frame
@@ -83,7 +83,7 @@ def test_hipemu_walker_bitmap_placements(hipemu_lib, force):
         "    assert r == o.drc_encode(f['pos'], f['idx_pos'], f.get('uv'), f.get('idx_uv'), f.get('nrm'), f.get('idx_nrm'))\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib, force.startswith("relabel"))
-    env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_SIMT_W="6", UVOL_FACE_BITS="1") if force == "simtfacebits" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="7") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="8") if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
+    env = dict(os.environ, UVOL_SIMT_W="5", UVOL_REC_FACE="0") if force == "simtcorner" else dict(os.environ, UVOL_SIMT_W="3", UVOL_REC16="1") if force == "simtrec16" else dict(os.environ, UVOL_LATE_JOIN="0") if force == "earlyjoin" else dict(os.environ, UVOL_RELABEL="1") if force == "relabel" else dict(os.environ, UVOL_RELABEL="1", UVOL_SIMT_W="7") if force == "relabel_simt" else dict(os.environ, UVOL_REC16="1") if force == "rec16" else (dict(os.environ, UVOL_SIMT_W=force[4:], UVOL_ENTROPY_W="8") if force.startswith("simt") else dict(os.environ, UVOL_WALK_FORCE=force))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 

@@ -34,10 +34,6 @@ __device__ inline float quant_range(const uint32_t *mn, const uint32_t *mx, int 
   if (r == 0.f) r = 1.f;
   return r;
 }
-__device__ inline void attr_order(const GeoJob &J, int i, const int32_t *&order, const int32_t *&v2d, const int32_t *&vert, uint32_t &ne) {
-  if (J.interior_seams[i]) { order = J.order[1 + i]; v2d = J.v2d[1 + i]; vert = J.avert[i]; ne = J.ne[1 + i]; }
-  else { order = J.order[0]; v2d = J.v2d[0]; vert = J.bvert; ne = J.ne[0]; }
-}
 __device__ inline void float_to_oct(const GOct &t, const float *v, int &s, int &tt) {
   double abs_sum = fabs((double)v[0]) + fabs((double)v[1]) + fabs((double)v[2]);
   double sv[3];
@@ -51,85 +47,109 @@ __device__ inline void float_to_oct(const GOct &t, const float *v, int &s, int &
   if (sv[2] < 0) iv[2] *= -1;
   g_vec_to_oct(t, iv, s, tt);
 }
-// grid.z selects the attribute: 0 position, 1 uv, 2 normal
-__global__ void __launch_bounds__(UVOL_BLOCK) k_quantize(GeoJob *jobs) {
+// Quantisation BY VALUE ID (round 5): every position / texture coordinate / normal of the input arrays is quantised once, where it lies,
+// into 16-bit fields (quantisation bits <= 16: uvol_params) - one 8-byte record per position, 4 bytes per texture coordinate and per
+// octahedral normal.  The predictors gather these by the value ids of the stored corner table; until round 4 a k_quantize pass wrote the
+// entries' values in coding order (P / U / O: 17 MB of HBM traffic per frame, after the traversals, on the critical chain) and every
+// predictor operand went corner -> vertex -> coding order -> value.  A value no entry refers to is quantised for nothing; the wrap
+// transform's bounds, which run over the CODED values only, are taken by k_v2d.  grid.z selects the attribute: 0 position, 1 uv, 2 normal.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_quant_ids(GeoJob *jobs) {
   JOB_OR_RETURN;
-  const uint32_t p = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const uint32_t id = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   const int a = blockIdx.z;
-  int lo = 0x7fffffff, hi = -0x7fffffff - 1; bool have = false;
   if (a == 0) {
-    if (p < J.ne[0]) {
-      const float range = quant_range(J.pos_min_u, J.pos_max_u, 3), inv = (float)((1u << J.qp) - 1) / range;
-      const float *v = (J.relabel ? J.pos_s : J.pos) + 3 * (size_t)J.npid[J.order[0][p]];
-      for (int k = 0; k < 3; k++) { float t = v[k] - g_float_unorder(J.pos_min_u[k]); t = t * inv; int q = (int)floorf(t + 0.5f); J.P[3 * p + k] = q; lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
-      have = true;
-    }
+    if (id >= J.n_pos) return;
+    const float range = quant_range(J.pos_min_u, J.pos_max_u, 3), inv = (float)((1u << J.qp) - 1) / range;
+    const float *v = (J.relabel ? J.pos_s : J.pos) + 3 * (size_t)id;
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) { float t = v[k] - g_float_unorder(J.pos_min_u[k]); t = t * inv; q[k] = (uint32_t)(int)floorf(t + 0.5f) & 0xffffu; }
+    reinterpret_cast<uint2 *>(J.qpos)[id] = make_uint2(q[0] | (q[1] << 16), q[2]);
+  } else if (a == 1) {
+    if (!J.has_uv || id >= J.n_uv) return;
+    const float range = quant_range(J.uv_min_u, J.uv_max_u, 2), inv = (float)((1u << J.qt) - 1) / range;
+    const float *v = J.uv + 2 * (size_t)id;
+    uint32_t q[2];
+    for (int k = 0; k < 2; k++) { float t = v[k] - g_float_unorder(J.uv_min_u[k]); t = t * inv; q[k] = (uint32_t)(int)floorf(t + 0.5f) & 0xffffu; }
+    reinterpret_cast<uint32_t *>(J.quv)[id] = q[0] | (q[1] << 16);
   } else {
-    int i = -1; for (int k = 0; k < J.nad; k++) if (J.att_kind[k] == a - 1) i = k;
-    if (i >= 0) {
-      const int32_t *order, *v2d, *vert; uint32_t ne; attr_order(J, i, order, v2d, vert, ne);
-      if (p < ne) {
-        if (a == 1) {
-          const float range = quant_range(J.uv_min_u, J.uv_max_u, 2), inv = (float)((1u << J.qt) - 1) / range;
-          const float *v = J.uv + 2 * (size_t)J.nuid[order[p]];
-          for (int k = 0; k < 2; k++) { float t = v[k] - g_float_unorder(J.uv_min_u[k]); t = t * inv; int q = (int)floorf(t + 0.5f); J.U[2 * p + k] = q; lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
-          have = true;
-        } else {
-          GOct ot = g_oct(J.qn); int s, tt;
-          float_to_oct(ot, J.nrm + 3 * (size_t)J.nnid[order[p]], s, tt);
-          J.O[2 * p] = s; J.O[2 * p + 1] = tt;
-        }
-      }
-    }
+    if (!J.has_nrm || id >= J.n_nrm) return;
+    GOct ot = g_oct(J.qn); int s, tt;
+    float_to_oct(ot, J.nrm + 3 * (size_t)id, s, tt);
+    reinterpret_cast<uint32_t *>(J.qnrm)[id] = ((uint32_t)s & 0xffffu) | ((uint32_t)tt << 16);
   }
-  if (a < 2) {
-    for (int d = 32; d >= 1; d >>= 1) { int l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d); lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
-    unsigned long long any = __ballot(have);
-    if ((threadIdx.x & 63) == 0 && any) { atomicMin(&J.wrap_lo[a], lo); atomicMax(&J.wrap_hi[a], hi); }
-  }
+}
+struct GQ3 { int x, y, z; };
+__device__ __forceinline__ GQ3 gq_pos(const GeoJob &J, int pid) { const uint2 r = reinterpret_cast<const uint2 *>(J.qpos)[pid]; GQ3 q; q.x = (int)(r.x & 0xffffu); q.y = (int)(r.x >> 16); q.z = (int)(r.y & 0xffffu); return q; }
+__device__ __forceinline__ void gq_uv(const GeoJob &J, int uid, long long o[2]) { const uint32_t r = reinterpret_cast<const uint32_t *>(J.quv)[uid]; o[0] = (long long)(r & 0xffffu); o[1] = (long long)(r >> 16); }
+// the table attribute slot i is sequenced by: its own (interior seams) or the base table
+__device__ inline void attr_order(const GeoJob &J, int i, const int32_t *&order, const int32_t *&v2d, uint32_t &ne) {
+  if (J.interior_seams[i]) { order = J.order[1 + i]; v2d = J.v2d[1 + i]; ne = J.ne[1 + i]; }
+  else { order = J.order[0]; v2d = J.v2d[0]; ne = J.ne[0]; }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: prediction residuals — parallel per entry (all originals are known on the encoder side)
+// K6: prediction residuals - parallel per entry (all originals are known on the encoder side).  order[] holds corners of the STORED
+// table; the quantised value of the entry at a corner is the quantised value of the corner's value id (every corner of a vertex -
+// of an attribute vertex: of a seam-free segment of its fan - carries the same id), so no operand goes through the coding order:
+// v2d[] is only asked "was this vertex coded before entry p?".
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_pos(GeoJob *jobs) {
   JOB_OR_RETURN;
   const uint32_t p = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (p >= J.ne[0]) return;
-  const int32_t *P = J.P, *v2d = J.v2d[0], *vert = J.bvert;
+  const int32_t *v2d = J.v2d[0];
+  const int ci = J.order[0][p];
+  const GQ3 own = gq_pos(J, J.cp[ci]);
   long long pred[3] = {0, 0, 0};
   if (p > 0) {
     bool have = false;
-    const int ci = J.order[0][p], oci = J.nopp[ci];
+    const int oci = J.opp[ci];
     if (oci >= 0) {
-      const uint32_t a = (uint32_t)v2d[vert[oci]], bn = (uint32_t)v2d[vert[g_nxt(oci)]], bp = (uint32_t)v2d[vert[g_prv(oci)]];
-      if (a < p && bn < p && bp < p) { for (int k = 0; k < 3; k++) pred[k] = (long long)P[3 * bn + k] + P[3 * bp + k] - P[3 * a + k]; have = true; }
+      const int fo = 3 * (oci / 3), j = oci - fo;
+      const uvol_s3 v3 = *reinterpret_cast<const uvol_s3 *>(J.vert + fo);
+      const int vv[3] = { v3.x, v3.y, v3.z };
+      const uint32_t a = (uint32_t)v2d[vv[j]], bn = (uint32_t)v2d[vv[(j + 1) % 3]], bp = (uint32_t)v2d[vv[(j + 2) % 3]];
+      if (a < p && bn < p && bp < p) {
+        const uvol_s3 c3 = *reinterpret_cast<const uvol_s3 *>(J.cp + fo);
+        const int cc[3] = { c3.x, c3.y, c3.z };
+        const GQ3 qa = gq_pos(J, cc[j]), qn = gq_pos(J, cc[(j + 1) % 3]), qp = gq_pos(J, cc[(j + 2) % 3]);
+        pred[0] = (long long)qn.x + qp.x - qa.x; pred[1] = (long long)qn.y + qp.y - qa.y; pred[2] = (long long)qn.z + qp.z - qa.z;
+        have = true;
+      }
     }
-    if (!have) for (int k = 0; k < 3; k++) pred[k] = P[3 * (p - 1) + k];
+    if (!have) { const GQ3 q1 = gq_pos(J, J.cp[J.order[0][p - 1]]); pred[0] = q1.x; pred[1] = q1.y; pred[2] = q1.z; }
   }
-  for (int k = 0; k < 3; k++) J.sym_pos[3 * p + k] = g_sym_of(g_wrap_corr(J.wrap_lo[0], J.wrap_hi[0], P[3 * p + k], pred[k]));
+  const int o[3] = { own.x, own.y, own.z };
+  for (int k = 0; k < 3; k++) J.sym_pos[3 * p + k] = g_sym_of(g_wrap_corr(J.wrap_lo[0], J.wrap_hi[0], o[k], pred[k]));
 }
 
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_uv(GeoJob *jobs) {
   JOB_OR_RETURN;
   int i = -1; for (int k = 0; k < J.nad; k++) if (J.att_kind[k] == 0) i = k;
   if (i < 0) return;
-  const int32_t *order, *v2d, *vert; uint32_t ne; attr_order(J, i, order, v2d, vert, ne);
+  const int32_t *order, *v2d; uint32_t ne; attr_order(J, i, order, v2d, ne);
   const uint32_t p = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (p >= ne) return;
-  const int32_t *U = J.U, *P = J.P, *bv2d = J.v2d[0], *bvert = J.bvert;
-  const int c = order[p], cnx = g_nxt(c), cpv = g_prv(c);
-  const uint32_t nd = (uint32_t)v2d[vert[cnx]], pd = (uint32_t)v2d[vert[cpv]];
+  const int c = order[p], f3 = 3 * (c / 3), j = c - f3, cnx = f3 + (j + 1) % 3, cpv = f3 + (j + 2) % 3;
+  const uvol_s3 u3 = *reinterpret_cast<const uvol_s3 *>(J.cu + f3);
+  const int uu[3] = { u3.x, u3.y, u3.z };
+  const uint32_t nd = (uint32_t)v2d[att_vertex(J, i, cnx)], pd = (uint32_t)v2d[att_vertex(J, i, cpv)];
+  long long own[2], nuv[2], puv[2];
+  gq_uv(J, uu[j], own);
   long long pred[2] = {0, 0}; bool have = false; uint8_t has_ori = 0, ori = 0;
+  if (nd < p) gq_uv(J, uu[(j + 1) % 3], nuv);
   if (pd < p && nd < p) {
-    const long long nuv[2] = { U[2 * nd], U[2 * nd + 1] }, puv[2] = { U[2 * pd], U[2 * pd + 1] };
+    gq_uv(J, uu[(j + 2) % 3], puv);
     if (puv[0] == nuv[0] && puv[1] == nuv[1]) { pred[0] = puv[0]; pred[1] = puv[1]; have = true; }
     else {
-      const int32_t *tip = P + 3 * bv2d[bvert[c]], *np_ = P + 3 * bv2d[bvert[cnx]], *pp_ = P + 3 * bv2d[bvert[cpv]];
+      const uvol_s3 c3 = *reinterpret_cast<const uvol_s3 *>(J.cp + f3);
+      const int cc[3] = { c3.x, c3.y, c3.z };
+      const GQ3 qt = gq_pos(J, cc[j]), qn = gq_pos(J, cc[(j + 1) % 3]), qp = gq_pos(J, cc[(j + 2) % 3]);
+      const long long tip[3] = { qt.x, qt.y, qt.z }, np_[3] = { qn.x, qn.y, qn.z }, pp_[3] = { qp.x, qp.y, qp.z };
       long long pn[3], pn2 = 0, dd = 0;
-      for (int k = 0; k < 3; k++) { pn[k] = (long long)pp_[k] - np_[k]; pn2 += pn[k] * pn[k]; }
+      for (int k = 0; k < 3; k++) { pn[k] = pp_[k] - np_[k]; pn2 += pn[k] * pn[k]; }
       if (pn2 != 0) {
-        for (int k = 0; k < 3; k++) dd += pn[k] * ((long long)tip[k] - np_[k]);
+        for (int k = 0; k < 3; k++) dd += pn[k] * (tip[k] - np_[k]);
         const long long pnuv[2] = { puv[0] - nuv[0], puv[1] - nuv[1] };
         const long long xuv[2] = { nuv[0] * pn2 + dd * pnuv[0], nuv[1] * pn2 + dd * pnuv[1] };
         long long cx2 = 0;
@@ -137,7 +157,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_uv(GeoJob *jobs) {
         const long long ns_ = (long long)g_isqrt((uint64_t)cx2 * (uint64_t)pn2);
         const long long cxuv[2] = { pnuv[1] * ns_, -pnuv[0] * ns_ };
         const long long p0[2] = { (xuv[0] + cxuv[0]) / pn2, (xuv[1] + cxuv[1]) / pn2 }, p1[2] = { (xuv[0] - cxuv[0]) / pn2, (xuv[1] - cxuv[1]) / pn2 };
-        const long long cu0 = U[2 * p], cu1 = U[2 * p + 1];
+        const long long cu0 = own[0], cu1 = own[1];
         const long long d0 = (cu0 - p0[0]) * (cu0 - p0[0]) + (cu1 - p0[1]) * (cu1 - p0[1]);
         const long long d1 = (cu0 - p1[0]) * (cu0 - p1[0]) + (cu1 - p1[1]) * (cu1 - p1[1]);
         has_ori = 1;
@@ -147,11 +167,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_uv(GeoJob *jobs) {
     }
   }
   if (!have) {
-    if (nd < p) { pred[0] = U[2 * nd]; pred[1] = U[2 * nd + 1]; }
-    else if (p > 0) { pred[0] = U[2 * (p - 1)]; pred[1] = U[2 * (p - 1) + 1]; }
+    if (nd < p) { pred[0] = nuv[0]; pred[1] = nuv[1]; }
+    else if (p > 0) { long long q1[2]; gq_uv(J, J.cu[order[p - 1]], q1); pred[0] = q1[0]; pred[1] = q1[1]; }
   }
   J.has_ori[p] = has_ori; J.ori_val[p] = ori;
-  for (int k = 0; k < 2; k++) J.sym_uv[2 * p + k] = g_sym_of(g_wrap_corr(J.wrap_lo[1], J.wrap_hi[1], U[2 * p + k], (long long)(int)pred[k]));
+  for (int k = 0; k < 2; k++) J.sym_uv[2 * p + k] = g_sym_of(g_wrap_corr(J.wrap_lo[1], J.wrap_hi[1], (int)own[k], (long long)(int)pred[k]));
 }
 // orientation list in encoder push order (p descending); bit k = (o_k == o_{k-1}), o_{-1} = true
 __global__ void __launch_bounds__(UVOL_BLOCK) k_ori_compact(GeoJob *jobs) {
@@ -176,34 +196,31 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_ori_bits(GeoJob *jobs) {
 }
 
 // The geometric-normal predictor sums, over the faces around an entry's vertex, (a - cen) x (b - cen) of the face's quantised positions:
-// the face's un-normalised normal, the same whichever of its corners the fan walk arrives at.  It is computed once per face here
-// (9 position words through corner -> vertex -> coding order) instead of once per face AND vertex inside the walk, which then
-// gathers one 24-byte normal per face instead of two positions through three dependent gathers each (k_pred_nrm: 53 -> 15.3 MB, k_face_normals itself 8.7 MB of
-// HBM traffic per frame).
+// the face's un-normalised normal, the same whichever of its corners the fan walk arrives at.  It is computed once per STORED face here
+// (three 8-byte quantised positions by id) instead of once per face AND vertex inside the walk, which then gathers one 12- / 24-byte
+// normal per face (round 4: k_pred_nrm 53 -> 15.3 MB of HBM traffic per frame).
 __global__ void __launch_bounds__(UVOL_BLOCK) k_face_normals(GeoJob *jobs) {
   JOB_OR_RETURN;
   if (!J.has_nrm) return;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (f >= J.nf) return;
-  const int32_t *P = J.P, *bv2d = J.v2d[0], *bvert = J.bvert;
-  long long p[3][3];
-  for (int k = 0; k < 3; k++) { const int32_t *q = P + 3 * (size_t)bv2d[bvert[3 * f + k]]; p[k][0] = q[0]; p[k][1] = q[1]; p[k][2] = q[2]; }
-  long long dn[3], dp[3];
-  for (int k = 0; k < 3; k++) { dn[k] = p[1][k] - p[0][k]; dp[k] = p[2][k] - p[0][k]; }
+  const uvol_s3 c3 = *reinterpret_cast<const uvol_s3 *>(J.cp + 3 * (size_t)f);
+  const GQ3 q0 = gq_pos(J, c3.x), q1 = gq_pos(J, c3.y), q2 = gq_pos(J, c3.z);
+  const long long dn[3] = { (long long)q1.x - q0.x, (long long)q1.y - q0.y, (long long)q1.z - q0.z }, dp[3] = { (long long)q2.x - q0.x, (long long)q2.y - q0.y, (long long)q2.z - q0.z };
   const long long n0 = dn[1] * dp[2] - dn[2] * dp[1], n1 = dn[2] * dp[0] - dn[0] * dp[2], n2 = dn[0] * dp[1] - dn[1] * dp[0];
   // |components| < 2^(2 qp + 1): three 32-bit words per face up to 15 bits of quantisation (12 bytes per face), 64-bit words for 16
-  if (J.qp <= 15) { int32_t *o = reinterpret_cast<int32_t *>(J.fnorm) + 3 * (size_t)f; o[0] = (int32_t)n0; o[1] = (int32_t)n1; o[2] = (int32_t)n2; }
+  if (J.qp <= 15) { uvol_s3 o; o.x = (int32_t)n0; o.y = (int32_t)n1; o.z = (int32_t)n2; *reinterpret_cast<uvol_s3 *>(reinterpret_cast<int32_t *>(J.fnorm) + 3 * (size_t)f) = o; }
   else { long long *o = J.fnorm + 3 * (size_t)f; o[0] = n0; o[1] = n1; o[2] = n2; }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   JOB_OR_RETURN;
   int i = -1; for (int k = 0; k < J.nad; k++) if (J.att_kind[k] == 1) i = k;
   if (i < 0) return;
-  const int32_t *order, *v2d, *vert; uint32_t ne; attr_order(J, i, order, v2d, vert, ne);
+  const int32_t *order, *v2d; uint32_t ne; attr_order(J, i, order, v2d, ne);
   const uint32_t d = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (d == 0) J.rb[4].n = ne;
   if (d >= ne) return;
-  GTab X; X.opp = J.nopp; X.seam = J.interior_seams[i] ? J.seam[i] : nullptr;
+  const int slot = J.interior_seams[i] ? i : -1;                          // the fan is cut at the attribute's seams
   const long long *FN = J.fnorm;
   const GOct ot = g_oct(J.qn);
   const int c0 = order[d];
@@ -211,10 +228,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   int c = c0; bool left = true; uint32_t guard = 0;
   while (c >= 0 && guard++ <= J.nc) {
     // (the face's normal, whichever corner of it c is: k_face_normals)
-    if (J.qp <= 15) { const int32_t *fn = reinterpret_cast<const int32_t *>(FN) + 3 * (size_t)(c / 3); N[0] += fn[0]; N[1] += fn[1]; N[2] += fn[2]; }
+    if (J.qp <= 15) { const uvol_s3 fn = *reinterpret_cast<const uvol_s3 *>(reinterpret_cast<const int32_t *>(FN) + 3 * (size_t)(c / 3)); N[0] += fn.x; N[1] += fn.y; N[2] += fn.z; }
     else { const long long *fn = FN + 3 * (size_t)(c / 3); N[0] += fn[0]; N[1] += fn[1]; N[2] += fn[2]; }
-    if (left) { c = gt_swl(X, c); if (c == c0) break; if (c < 0) { left = false; c = gt_swr(X, c0); } }
-    else c = gt_swr(X, c);
+    if (left) { c = st_swl(J, slot, c); if (c == c0) break; if (c < 0) { left = false; c = st_swr(J, slot, c0); } }
+    else c = st_swr(J, slot, c);
   }
   long long s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]);
   if (s > (1 << 29)) { long long qd = s / (1 << 29); for (int k = 0; k < 3; k++) N[k] /= qd; s = g_labs(N[0]) + g_labs(N[1]) + g_labs(N[2]); }
@@ -229,7 +246,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   g_vec_to_oct(ot, pv, ppos[0], ppos[1]);
   pv[0] = -pv[0]; pv[1] = -pv[1]; pv[2] = -pv[2];
   g_vec_to_oct(ot, pv, pneg[0], pneg[1]);
-  const int orig[2] = { J.O[2 * d], J.O[2 * d + 1] };
+  const uint32_t oq = reinterpret_cast<const uint32_t *>(J.qnrm)[J.cn[c0]];
+  const int orig[2] = { (int)(oq & 0xffffu), (int)(oq >> 16) };
   g_oct_corr(ot, orig, ppos, cpos); g_oct_corr(ot, orig, pneg, cneg);
   for (int k = 0; k < 2; k++) { cpos[k] = g_modmax(ot, cpos[k]); cneg[k] = g_modmax(ot, cneg[k]); }
   const int *ch; uint8_t flip;
@@ -238,4 +256,3 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_nrm(GeoJob *jobs) {
   if (!flip) atomicAdd(&J.rb[4].zeros, 1u);
   for (int k = 0; k < 2; k++) J.sym_nrm[2 * d + k] = (uint32_t)(ch[k] < 0 ? ch[k] + ot.MAXQ : ch[k]);
 }
-

@@ -1,23 +1,56 @@
 // geo_conn.hpp - K4b: inverse maps, split events, valence replay, context streams, seams, attribute vertices.
 // Part of the geometry encoder translation unit: included by geom_encode.hip, in pipeline order (not a standalone header).
+// face_time[f] = index of the symbol that encoded stored face f; the faces that only start a component (interior start faces, no
+// symbol) get -(j + 2), j = their index in initc[].  The inverse of proc[], built in parallel so that the serial walker has no scatter
+// store in its loop.  The same pass writes the DECODER'S face order (decoder face f <-> processed corner nsym - 1 - f,
+// then the interior start faces; decoder corner 3f + k <-> rot^k of that corner) as tstart[f] = code of the stored corner that is the
+// decoder's corner 3f: the only form in which the decoder's numbering exists on the encode side (see GeoJob::tstart).
 __global__ void __launch_bounds__(UVOL_BLOCK) k_face_time(GeoJob *jobs) {
   JOB_OR_RETURN;
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (i < (uint32_t)J.nsym) J.face_time[J.proc[i] / 3] = (int32_t)i;
+  if (i < (uint32_t)J.nsym) { const int c = J.proc[i]; J.face_time[c / 3] = (int32_t)i; J.tstart[J.nsym - 1 - (int)i] = code_of_corner(c); }
+  if (i < (uint32_t)J.ninit) { const int c = J.initc[i]; J.face_time[c / 3] = -(int32_t)i - 2; J.tstart[J.nsym + (int)i] = code_of_corner(c); }
 }
-// v2d[t][vertex] = position of the vertex in the coding order of table t: the inverse of order[t][] (same reason)
+// the vertex field of corner c in the record table of traversal table t (any format)
+__device__ __forceinline__ int rec_vertex_field(const GeoJob &J, int t, int c, int r8) {
+  if (r8 == 2) { const uint32_t *q = reinterpret_cast<const uint32_t *>(J.rec[1 + t]) + 4 * (size_t)(c / 3); return (int)((uint32_t)((((uint64_t)q[1] << 32) | q[0]) >> (21 * (c % 3))) & 0x1fffffu); }
+  const size_t code = (size_t)code_of_corner(c);
+  return r8 ? (int)((uint32_t)J.rec[1 + t][2 * code] & 0x1fffffu) : J.rec[1 + t][4 * code];
+}
+// v2d[t][vertex] = position of the vertex in the coding order of table t: the inverse of order[t][] (same reason).  On the encode
+// side (quantised values by id present) the pass also takes the minimum / maximum of the quantised values that are CODED (the wrap
+// transform's bounds run over the entries, not over every value of the input arrays): positions with table 0, texture coordinates
+// with the table their attribute is sequenced by.
 __global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs, int r8) {
-  JOB_OR_RETURN;
+  GeoJob &J = jobs[blockIdx.y];
   const int t = blockIdx.z;
   const uint32_t i = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  if (i >= J.ne[t]) return;
-  if (t > 0 && (t - 1 >= J.nad || !J.interior_seams[t - 1])) return;
-  const int c = J.order[t][i];
-  const size_t code = (size_t)code_of_corner(c);
-  int vi;
-  if (r8 == 2) { const uint32_t *q = reinterpret_cast<const uint32_t *>(J.rec[1 + t]) + 4 * (size_t)(c / 3); vi = (int)((uint32_t)((((uint64_t)q[1] << 32) | q[0]) >> (21 * (c % 3))) & 0x1fffffu); }
-  else vi = r8 ? (int)((uint32_t)J.rec[1 + t][2 * code] & 0x1fffffu) : J.rec[1 + t][4 * code];
-  J.v2d[t][vi >> 1] = (int32_t)i;
+  const bool live = J.status == 0 && !(t > 0 && (t - 1 >= J.nad || !J.interior_seams[t - 1]));
+  if (blockIdx.x * UVOL_BLOCK >= (live ? J.ne[t] : 0u)) return;            // block-uniform
+  int lo0 = 0x7fffffff, hi0 = -0x7fffffff - 1, lo1 = 0x7fffffff, hi1 = -0x7fffffff - 1;
+  int iu = -1;                                                            // the texture-coordinate slot, if this table sequences it
+  if (J.qpos) for (int k = 0; k < J.nad; k++) if (J.att_kind[k] == 0 && (J.interior_seams[k] ? t == 1 + k : t == 0)) iu = k;
+  if (i < J.ne[t]) {
+    const int c = J.order[t][i];
+    J.v2d[t][rec_vertex_field(J, t, c, r8) >> 1] = (int32_t)i;
+    if (J.qpos && t == 0) {
+      const uint16_t *q = J.qpos + 4 * (size_t)J.cp[c];
+      for (int k = 0; k < 3; k++) { const int v = q[k]; lo0 = v < lo0 ? v : lo0; hi0 = v > hi0 ? v : hi0; }
+    }
+    if (iu >= 0) {
+      const uint16_t *q = J.quv + 2 * (size_t)J.cu[c];
+      for (int k = 0; k < 2; k++) { const int v = q[k]; lo1 = v < lo1 ? v : lo1; hi1 = v > hi1 ? v : hi1; }
+    }
+  }
+  if (!J.qpos) return;
+  for (int d = 32; d >= 1; d >>= 1) {
+    int a = __shfl_xor(lo0, d), b = __shfl_xor(hi0, d); lo0 = a < lo0 ? a : lo0; hi0 = b > hi0 ? b : hi0;
+    a = __shfl_xor(lo1, d); b = __shfl_xor(hi1, d); lo1 = a < lo1 ? a : lo1; hi1 = b > hi1 ? b : hi1;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (t == 0 && lo0 <= hi0) { atomicMin(&J.wrap_lo[0], lo0); atomicMax(&J.wrap_hi[0], hi0); }
+    if (iu >= 0 && lo1 <= hi1) { atomicMin(&J.wrap_lo[1], lo1); atomicMax(&J.wrap_hi[1], hi1); }
+  }
 }
 
 // topology-split events (CheckAndStoreTopologySplitEvent): symbol i contributes an event for each already-encoded
@@ -166,113 +199,110 @@ __global__ void __launch_bounds__(64) k_eb_ctx(GeoJob *jobs) {
   if (lane == 0 && J.status == 0) for (int c = 0; c < 6; c++) { J.ctx_n[c] = base_c[c]; J.rs[c].n = base_c[c]; }
 }
 
-// renumber into decoder order (decoder corner 3f+k <-> rot^k(processed corner f))
-__device__ __forceinline__ int renum_first_corner(const GeoJob &J, uint32_t f) { return (int)f < J.nsym ? J.proc[J.nsym - 1 - (int)f] : J.initc[(int)f - J.nsym]; }
-__global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_a(GeoJob *jobs) {
+// ------------------------------------------------------------------------------------------------
+// Seams, seam bits and attribute vertices on the STORED tables (round 5).  Until round 4 the tables were renumbered into decoder
+// order first (k_renumber_a / k_renumber_seams: five 3F-entry arrays written and read back, 48 MB of HBM traffic per 200 k-face frame,
+// the largest kernel of the front end).  Nothing below needs that: a seam is a property of an edge, an attribute vertex a property of
+// a fan, and the only order-dependent output - the seam bits, one per edge taken from the face with the LOWER decoder index, faces in
+// decoder order, corners in decoder rotation - is produced by walking tstart[] (k_sb_count / k_sb_write).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fseam_bit(const GeoJob &J, int slot, int c) { return (J.fseam[c / 3] >> (3 * slot + c % 3)) & 1u; }
+// seam-masked opposite corner / swings on the stored table (slot < 0: the base table)
+__device__ __forceinline__ int st_opp(const GeoJob &J, int slot, int c) { if (c < 0) return GEO_INV; if (slot >= 0 && fseam_bit(J, slot, c)) return GEO_INV; return J.opp[c]; }
+__device__ __forceinline__ int st_swl(const GeoJob &J, int slot, int c) { const int o = st_opp(J, slot, g_nxt(c)); return o < 0 ? GEO_INV : g_nxt(o); }
+__device__ __forceinline__ int st_swr(const GeoJob &J, int slot, int c) { const int o = st_opp(J, slot, g_prv(c)); return o < 0 ? GEO_INV : g_prv(o); }
+__device__ __forceinline__ bool vseam_bit(const GeoJob &J, int slot, uint32_t v) { return (J.vseam[slot][v >> 5] >> (v & 31)) & 1u; }
+// vertex of corner c in the table that sequences attribute slot `slot` (the base vertex unless an interior seam touches it)
+__device__ __forceinline__ int att_vertex(const GeoJob &J, int slot, int c) {
+  const int v = J.vert[c];
+  return (J.interior_seams[slot] && vseam_bit(J, slot, (uint32_t)v)) ? J.avert[slot][c] : v;
+}
+// One thread per stored face: the seam flags of both attribute slots across its three edges (MeshAttributeCornerTable::InitFromAttribute:
+// a boundary counts as a seam; an interior edge is one when the value ids at either end differ between the two faces), the 'an
+// interior seam touches this vertex' bits and the per-slot 'has interior seams' flag.  The ids across an edge come from the face of the
+// opposite corner: everything else is the face's own three 12-byte triples.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
   JOB_OR_RETURN;
-  uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (f >= J.nf) return;
-  const int c = renum_first_corner(J, f);
-  const int o[3] = { c, g_nxt(c), g_prv(c) };
-  for (int k = 0; k < 3; k++) J.new_of_old[o[k]] = (int)(3 * f + k);
-}
-// One thread per NEW face: the renumbered tables (opposite corners, value ids, vertices under the decoder's corner numbering),
-// the attribute seams (MeshAttributeCornerTable::InitFromAttribute) with the seam-bit eligibility flags and their block sums,
-// and the 'a seam touches this vertex' bits.  The renumbering maps whole faces (rotated), so everything a corner needs from
-// its own face is in the thread's registers (three 12-byte loads per array from the OLD face) and the ids across an edge
-// come from the old face of the opposite corner - 20 loads per face where the per-corner k_renumber_b + k_seams pair issued 60.
-__global__ void __launch_bounds__(UVOL_BLOCK) k_renumber_seams(GeoJob *jobs) {
-  JOB_OR_RETURN_UNIFORM;
-  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x, nf = J.nf;
-  const bool in = f < nf;
-  __shared__ uint32_t ecnt[3];                                         // eligible corners per 256-corner block (three per 256 faces)
-  if (threadIdx.x < 3) ecnt[threadIdx.x] = 0;
-  __syncthreads();
-  if (in) {
-    const int c0 = renum_first_corner(J, f);
-    const int fo = 3 * (c0 / 3), r0 = c0 - fo;                          // old face, rotation
-    int opp_[3], P[3], U[3], Nn[3], V[3];
-    { const uvol_s3 a = *reinterpret_cast<const uvol_s3 *>(J.opp + fo), b = *reinterpret_cast<const uvol_s3 *>(J.cp + fo), c = *reinterpret_cast<const uvol_s3 *>(J.cu + fo),
-                    d = *reinterpret_cast<const uvol_s3 *>(J.cn + fo), e = *reinterpret_cast<const uvol_s3 *>(J.vert + fo);
-      const int ao[3] = { a.x, a.y, a.z }, bo[3] = { b.x, b.y, b.z }, co[3] = { c.x, c.y, c.z }, dn[3] = { d.x, d.y, d.z }, ev[3] = { e.x, e.y, e.z };
-      for (int k = 0; k < 3; k++) { const int j = (r0 + k) % 3; opp_[k] = ao[j]; P[k] = bo[j]; U[k] = co[j]; Nn[k] = dn[j]; V[k] = ev[j]; } }
-    int no[3];
-    for (int k = 0; k < 3; k++) no[k] = opp_[k] < 0 ? GEO_INV : J.new_of_old[opp_[k]];
-    // ids across each edge: the two other corners of the opposite corner's OLD face
-    int bu[3][2], bn[3][2];
+  const uvol_s3 o3 = *reinterpret_cast<const uvol_s3 *>(J.opp + 3 * (size_t)f);
+  const int opp_[3] = { o3.x, o3.y, o3.z };
+  uint32_t bits = 0;
+  for (int i = 0; i < J.nad; i++) {
+    const int32_t *A = J.att_kind[i] == 0 ? J.cu : J.cn;
+    const uvol_s3 a3 = *reinterpret_cast<const uvol_s3 *>(A + 3 * (size_t)f);
+    const int a[3] = { a3.x, a3.y, a3.z };
+    bool any = false;
     for (int k = 0; k < 3; k++) {
-      const int oo = opp_[k] < 0 ? 0 : opp_[k];
-      bu[k][0] = J.cu[g_prv(oo)]; bu[k][1] = J.cu[g_nxt(oo)]; bn[k][0] = J.cn[g_prv(oo)]; bn[k][1] = J.cn[g_nxt(oo)];
-    }
-    { uvol_s3 w; w.x = no[0]; w.y = no[1]; w.z = no[2]; *reinterpret_cast<uvol_s3 *>(J.nopp + 3 * (size_t)f) = w;
-      w.x = P[0]; w.y = P[1]; w.z = P[2]; *reinterpret_cast<uvol_s3 *>(J.npid + 3 * (size_t)f) = w;
-      w.x = U[0]; w.y = U[1]; w.z = U[2]; *reinterpret_cast<uvol_s3 *>(J.nuid + 3 * (size_t)f) = w;
-      w.x = Nn[0]; w.y = Nn[1]; w.z = Nn[2]; *reinterpret_cast<uvol_s3 *>(J.nnid + 3 * (size_t)f) = w;
-      w.x = V[0]; w.y = V[1]; w.z = V[2]; *reinterpret_cast<uvol_s3 *>(J.bvert + 3 * (size_t)f) = w; }
-    for (int k = 0; k < 3; k++) {
-      const uint32_t c = 3 * f + k; const bool e = no[k] >= 0 && (uint32_t)no[k] / 3 > f;
-      J.elig[c] = e ? 1 : 0;
-      if (e) atomicAdd(&ecnt[(3 * threadIdx.x + k) >> 8], 1u);
-    }
-    for (int i = 0; i < J.nad; i++) {
-      const bool uvk = J.att_kind[i] == 0;
-      bool any = false;
-      for (int k = 0; k < 3; k++) {
-        uint8_t sm = 1;
-        if (opp_[k] >= 0) {
-          const int a0 = uvk ? U[(k + 1) % 3] : Nn[(k + 1) % 3], a1 = uvk ? U[(k + 2) % 3] : Nn[(k + 2) % 3];
-          const int b0 = uvk ? bu[k][0] : bn[k][0], b1 = uvk ? bu[k][1] : bn[k][1];
-          sm = (a0 != b0 || a1 != b1) ? 1 : 0;
-          if (sm) {                                                      // both ends of the edge get split
-            any = true;
-            const uint32_t va = (uint32_t)V[(k + 1) % 3], vb = (uint32_t)V[(k + 2) % 3];
-            atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31));
-          }
+      uint32_t sm = 1;
+      if (opp_[k] >= 0) {
+        const int oo = opp_[k];
+        sm = (a[(k + 1) % 3] != A[g_prv(oo)] || a[(k + 2) % 3] != A[g_nxt(oo)]) ? 1u : 0u;
+        if (sm) {                                                         // both ends of the edge get split
+          any = true;
+          const uint32_t va = (uint32_t)J.vert[3 * f + (k + 1) % 3], vb = (uint32_t)J.vert[3 * f + (k + 2) % 3];
+          atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31));
         }
-        J.seam[i][3 * (size_t)f + k] = sm;
       }
-      if (any) J.interior_seams[i] = 1;
+      bits |= sm << (3 * i + k);
     }
+    if (any) J.interior_seams[i] = 1;
   }
-  __syncthreads();
-  if (threadIdx.x < 3) { const uint32_t b = 3 * blockIdx.x + threadIdx.x; if (b < uvol_blocks_dev(J.nc)) J.bsum[b] = ecnt[threadIdx.x]; }
+  J.fseam[f] = (uint8_t)bits;
 }
-// seam bits of the eligible corners, in corner order.  SB_E corners per thread (8-byte loads of the flags and of both seam
-// arrays): with one corner per thread the kernel was 5 M workgroups per batch, each a chain of two byte loads and a scan
-#define SB_E 8
-__global__ void __launch_bounds__(UVOL_BLOCK) k_seam_bits(GeoJob *jobs) {
+// seam bits, pass 1: one thread per DECODER-order face: which of its edges contribute a bit (the neighbour across it has the higher
+// decoder index), in the decoder's corner rotation, and the bits themselves - one byte per face - plus the block sums for the scan
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sb_count(GeoJob *jobs) {
+  JOB_OR_RETURN_UNIFORM;
+  const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  uint32_t cnt = 0;
+  if (f < J.nf) {
+    const int x0 = J.tstart[f], fo = x0 >> 2, r0 = x0 & 3;
+    const uvol_s3 o3 = *reinterpret_cast<const uvol_s3 *>(J.opp + 3 * (size_t)fo);
+    const int opp_[3] = { o3.x, o3.y, o3.z };
+    const uint32_t fs = J.fseam[fo];
+    int nb[3];
+    for (int k = 0; k < 3; k++) nb[k] = opp_[k] < 0 ? -1 : J.face_time[opp_[k] / 3];
+    uint32_t b0 = 0, b1 = 0;
+    for (int k = 0; k < 3; k++) {
+      const int j = (r0 + k) % 3;
+      if (opp_[j] < 0) continue;
+      const int t = nb[j], df = t >= 0 ? J.nsym - 1 - t : J.nsym + (-t - 2);
+      if ((uint32_t)df <= f) continue;
+      b0 |= ((fs >> j) & 1u) << cnt; b1 |= ((fs >> (3 + j)) & 1u) << cnt; cnt++;
+    }
+    J.sbpack[f] = (uint8_t)(cnt | (b0 << 2) | (b1 << 5));
+  }
+  const uint32_t tot = block_sum(cnt);
+  if (threadIdx.x == 0 && blockIdx.x < uvol_blocks_dev(J.nf)) J.bsum[blockIdx.x] = tot;
+}
+// pass 2 (after k_scan_sums over SCAN_ELIG): the bits at their places, zero counts for the rabs coder
+__global__ void __launch_bounds__(UVOL_BLOCK) k_sb_write(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const bool ok = J.status == 0;
-  const uint32_t nc = ok ? J.nc : 0u, c0 = (blockIdx.x * UVOL_BLOCK + threadIdx.x) * SB_E;
-  unsigned long long e8 = 0;
-  if (c0 + SB_E <= nc) e8 = *reinterpret_cast<const unsigned long long *>(J.elig + c0);
-  else for (uint32_t k = 0; c0 + k < nc && k < SB_E; k++) e8 |= (unsigned long long)J.elig[c0 + k] << (8 * k);
-  e8 &= 0x0101010101010101ull;
-  uint32_t cnt = (uint32_t)__popcll(e8), tot;
-  uint32_t pos = block_excl_scan(cnt, &tot) + ((ok && blockIdx.x * SB_E <= uvol_blocks_dev(J.nc)) ? J.bsum[blockIdx.x * SB_E] : 0);
-  // zero counts: one global atomic per block and attribute
+  const uint32_t nf = ok ? J.nf : 0u, f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  const uint32_t pk = f < nf ? J.sbpack[f] : 0u, cnt = pk & 3u;
+  uint32_t tot;
+  const uint32_t pos = block_excl_scan(cnt, &tot) + ((ok && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum[blockIdx.x] : 0);
   __shared__ uint32_t zc[2];
   if (threadIdx.x < 2) zc[threadIdx.x] = 0;
   __syncthreads();
   if (cnt) for (int i = 0; i < J.nad; i++) {
-    unsigned long long s8 = 0;
-    if (c0 + SB_E <= nc) s8 = *reinterpret_cast<const unsigned long long *>(J.seam[i] + c0);
-    else for (uint32_t k = 0; c0 + k < nc && k < SB_E; k++) s8 |= (unsigned long long)J.seam[i][c0 + k] << (8 * k);
-    uint32_t p = pos, z = 0;
-    for (int k = 0; k < SB_E; k++) if ((e8 >> (8 * k)) & 1ull) { const uint8_t sb = (uint8_t)(s8 >> (8 * k)); J.seam_bits[i][p++] = sb; z += sb ? 0u : 1u; }
+    const uint32_t b = (pk >> (2 + 3 * i)) & 7u; uint32_t z = 0;
+    for (uint32_t k = 0; k < cnt; k++) { const uint8_t sb = (uint8_t)((b >> k) & 1u); J.seam_bits[i][pos + k] = sb; z += sb ? 0u : 1u; }
     if (z) atomicAdd(&zc[i], z);
   }
   __syncthreads();
   if (threadIdx.x < 2 && zc[threadIdx.x]) atomicAdd(&J.rb[1 + threadIdx.x].zeros, zc[threadIdx.x]);
   if (blockIdx.x == 0 && threadIdx.x == 0 && ok) {
-    uint32_t n = J.bsum[uvol_blocks_dev(J.nc)];
+    const uint32_t n = J.bsum[uvol_blocks_dev(J.nf)];
     J.n_elig = n; for (int i = 0; i < J.nad; i++) J.rb[1 + i].n = n;
   }
 }
 
 // attribute vertices of the vertices an interior seam touches (grid z = attribute slot): pass a gives every segment (maximal
 // run of fan corners no seam / boundary separates) an id nverts_base + k at its left-most corner, pass b hands it to the other
-// corners of the segment; all other corners keep their base vertex
+// corners of the segment.  Corners of untouched vertices keep their base vertex and are NOT written (att_vertex).
 __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
   JOB_OR_RETURN;
   const int i = (int)blockIdx.z;
@@ -280,20 +310,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
   const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
   int32_t v[GEO_ILP]; uint32_t w[GEO_ILP];
 #pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? J.bvert[c] : 0; }
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? J.vert[c] : 0; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][(uint32_t)v[k] >> 5];
-  // left-most corner of its segment <=> the edge to its left is a seam or a boundary <=> seam[next(c)] (k_seams marks boundaries
-  // too); fetched for every corner (a neighbouring byte) so that the rare seam vertices cost no divergent round trip
-  uint8_t sl[GEO_ILP];
-#pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; sl[k] = J.seam[i][g_nxt(c < nc ? c : 0u)]; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) {
     const uint32_t c = c0 + k * UVOL_BLOCK;
-    if (c >= nc) continue;
-    if (!((w[k] >> ((uint32_t)v[k] & 31)) & 1u)) { J.avert[i][c] = v[k]; continue; }
-    if (sl[k]) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
+    if (c >= nc || !((w[k] >> ((uint32_t)v[k] & 31)) & 1u)) continue;
+    // left-most corner of its segment <=> the edge to its left is a seam or a boundary <=> the seam flag of corner next(c)
+    if (fseam_bit(J, i, g_nxt((int)c))) J.avert[i][c] = (int32_t)(J.nverts_t[0] + atomicAdd(&J.nseg[i], 1u));
   }
 }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
@@ -304,17 +329,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
   if (c0 == 0) { const uint32_t tot = J.nverts_t[0] + J.nseg[i]; J.nverts_t[2 + i] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
   uint32_t v[GEO_ILP], w[GEO_ILP];
 #pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? (uint32_t)J.bvert[c] : 0u; }
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? (uint32_t)J.vert[c] : 0u; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][v[k] >> 5];
-  GTab T; T.opp = J.nopp; T.seam = J.seam[i];
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) {
     const uint32_t c = c0 + k * UVOL_BLOCK;
     if (c >= nc || !((w[k] >> (v[k] & 31)) & 1u)) continue;
     int l = (int)c; uint32_t guard = 0;
-    for (;;) { const int nl = gt_swl(T, l); if (nl < 0) break; l = nl; if (++guard > nc) { J.status = -22; return; } }
+    for (;;) { const int nl = st_swl(J, i, l); if (nl < 0) break; l = nl; if (++guard > nc) { J.status = -22; return; } }
     if (l != (int)c) J.avert[i][c] = J.avert[i][l];
   }
 }
-

@@ -36,8 +36,8 @@ enum { SCAN_KEEP = 0, SCAN_ELIG = 1, SCAN_ORI = 2, SCAN_EVENTS = 3, SCAN_SEQ = 4
 // NOTE: written as value-returning selects on purpose.  The earlier form (out-references assigned in
 // an if/else chain) was miscompiled by hipcc 7.2 -O3 for gfx950: the sel==2 arm left the pointer
 // register undefined ("implicit-def $sgpr8_sgpr9" in the ISA) and the kernel faulted at address 0.
-__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_SEQ ? J.sq_flag : (sel == SCAN_KEEP ? J.keep : (sel == SCAN_EVENTS ? J.evcnt : (sel == SCAN_ELIG ? J.elig : J.has_ori))); }
-__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_SEQ ? 3u * J.nf_in : (sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nc : (J.has_uv ? J.ne_uv : 0u)))); }
+__device__ __forceinline__ const uint8_t *scan_flags(const GeoJob &J, int sel) { return sel == SCAN_SEQ ? J.sq_flag : (sel == SCAN_KEEP ? J.keep : (sel == SCAN_EVENTS ? J.evcnt : (sel == SCAN_ELIG ? J.sbpack : J.has_ori))); }
+__device__ __forceinline__ uint32_t scan_count(const GeoJob &J, int sel) { return sel == SCAN_SEQ ? 3u * J.nf_in : (sel == SCAN_KEEP ? J.nf_in : (sel == SCAN_EVENTS ? J.nf : (sel == SCAN_ELIG ? J.nf : (J.has_uv ? J.ne_uv : 0u)))); }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_scan_blocks(GeoJob *jobs, int sel) {
   GeoJob &J = jobs[blockIdx.y];
   const uint8_t *flags = scan_flags(J, sel); const uint32_t n = scan_count(J, sel);

@@ -15,16 +15,22 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
   WalkStage stg; stg.init(stg_lds);
   int n = 0;
 #define T_EMIT(C) do { stg.w[n & (WALK_STG - 1)] = (C); n++; if ((n & (WALK_STG - 1)) == 0) stg.flush_words(order, n); } while (0)
+  UVOL_G(const int32_t) tstart = UVOL_TO_G(const int32_t, J.tstart);
+  const bool virt = J.tstart != nullptr;                  // encode side: components start in DECODER order, tstart[f] = first corner of decoder face f
+  int nvis = 0;
   for (int f = 0; f < nf; f++) {
-    if ((f & 31) == 0) { while (f + 32 <= nf && pword(fbits, f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; }
-    if (pbit_get(fbits, f)) continue;
-    int x = 4 * f, sp = 0;
+    int x;
+    if (virt) { if (nvis >= nf) break; x = tstart[f]; }
+    else { if ((f & 31) == 0) { while (f + 32 <= nf && pword(fbits, f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; } x = 4 * f; }
+    if (pbit_get(fbits, x >> 2)) continue;
+    int sp = 0;
     stack[sp] = x;
     sp++;
     int top = x; bool top_known = true;
-    { int vn, vp, r_, l_; RO::get(rec, x + 1, vn, r_, l_); RO::get(rec, x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
-      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); T_EMIT(3 * f + 1); }
-      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); T_EMIT(3 * f + 2); } }
+    { const int xn = code_nxt(x), xp = code_prv(x);
+      int vn, vp, r_, l_; RO::get(rec, xn, vn, r_, l_); RO::get(rec, xp, vp, r_, l_); vn >>= 1; vp >>= 1;
+      if (!pbit_get(vbits, vn)) { pbit_set(vbits, vn); T_EMIT(corner_of_code(xn)); }
+      if (!pbit_get(vbits, vp)) { pbit_set(vbits, vp); T_EMIT(corner_of_code(xp)); } }
     while (sp > 0) {
       x = top_known ? top : stack[sp - 1];
       top_known = false;
@@ -36,6 +42,7 @@ __device__ __forceinline__ void traverse_lane0(GeoJob &J, int t, FB fbits, VB vb
         // both records this step can move to are requested now and taken (readfirstlane) only by the branch that goes there
         const typename RO::Pre pR = RO::pre(rec, (rc < 0 ? x : rc) + dz), pL = RO::pre(rec, (lc < 0 ? x : lc) + dz);
         pbit_set(fbits, face);
+        nvis++;
         const int v = vi >> 1;
         // the three bitmap words this step can need, read together (one LDS round trip)
         const uint32_t vw_ = pword(vbits, v >> 5);
@@ -75,18 +82,38 @@ __device__ __forceinline__ void traverse_coop(GeoJob &J, int t, UVOL_L(uint32_t)
   int n = 0;
 #define C_FWORD(k) ((uint32_t)UVOL_BCAST0(lds[k]))
 #define C_EMIT(C) do { ov = UVOL_WRITELANE((C), n & 63, ov); n++; if ((n & 63) == 0) order[n - 64 + lane] = (int32_t)ov; } while (0)
+  const int32_t *tstart = J.tstart;
+  const bool virt = tstart != nullptr;                    // encode side: components start in DECODER order, tstart[f] = first corner of decoder face f
+  int nvis = 0;
   for (int f = 0; f < nf; f++) {
-    if ((f & 31) == 0) { while (f + 32 <= nf && C_FWORD(f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; }
-    if ((C_FWORD(f >> 5) >> (f & 31)) & 1u) continue;
-    int x = 4 * f, sp = 0;
+    int x;
+    if (virt) {
+      // the next decoder-order face that is not visited yet: 64 candidates per round trip (every lane tests one), the first by a ballot
+      if (nvis >= nf) break;
+      bool found = false;
+      while (f < nf) {
+        const int fk = f + lane, xk = fk < nf ? tstart[fk] : -1;
+        const bool un = xk >= 0 && !((lds[xk >> 7] >> ((xk >> 2) & 31)) & 1u);
+        const unsigned long long m = __ballot(un);
+        if (m) { const int k0 = (int)__ffsll((long long)m) - 1; f += k0; x = (int)UVOL_READLANE(xk, k0); found = true; break; }
+        f += 64;
+      }
+      if (!found) break;
+    } else {
+      if ((f & 31) == 0) { while (f + 32 <= nf && C_FWORD(f >> 5) == 0xffffffffu) f += 32; if (f >= nf) break; }
+      if ((C_FWORD(f >> 5) >> (f & 31)) & 1u) continue;
+      x = 4 * f;
+    }
+    int sp = 0;
     if (lane == 0) stack[sp] = x;
     sp++;
     int top = x; bool top_known = true;
-    { int vn, vp, r_, l_; coop_get<R8>(rec, x + 1, vn, r_, l_); coop_get<R8>(rec, x + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
+    { const int xn = code_nxt(x), xp = code_prv(x);
+      int vn, vp, r_, l_; coop_get<R8>(rec, xn, vn, r_, l_); coop_get<R8>(rec, xp, vp, r_, l_); vn >>= 1; vp >>= 1;
       uint32_t w = (uint32_t)UVOL_BCAST0(lds[fw + (vn >> 5)]);
-      if (!((w >> (vn & 31)) & 1u)) { lds[fw + (vn >> 5)] = w | (1u << (vn & 31)); C_EMIT(3 * f + 1); }
+      if (!((w >> (vn & 31)) & 1u)) { lds[fw + (vn >> 5)] = w | (1u << (vn & 31)); C_EMIT(corner_of_code(xn)); }
       w = (uint32_t)UVOL_BCAST0(lds[fw + (vp >> 5)]);
-      if (!((w >> (vp & 31)) & 1u)) { lds[fw + (vp >> 5)] = w | (1u << (vp & 31)); C_EMIT(3 * f + 2); } }
+      if (!((w >> (vp & 31)) & 1u)) { lds[fw + (vp >> 5)] = w | (1u << (vp & 31)); C_EMIT(corner_of_code(xp)); } }
     while (sp > 0) {
       if (top_known) x = top; else { UVOL_WAVE_FENCE(); x = UVOL_BCAST0(stack[sp - 1]); }
       top_known = false;
@@ -102,6 +129,7 @@ __device__ __forceinline__ void traverse_coop(GeoJob &J, int t, UVOL_L(uint32_t)
         const typename RO::Pre pre = RO::pre(rec, ccode);
         if (pf) pub[0] = (uint32_t)x;
         lds[face >> 5] = xw | (1u << (face & 31));
+        nvis++;
         const int v = vi >> 1;
         const uint32_t widx = cl ? (uint32_t)ccode >> 7 : fw + (uint32_t)(v >> 5);
         const uint32_t sh = cl ? ((uint32_t)cand >> 2) & 31u : (uint32_t)v & 31u;

@@ -74,22 +74,24 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack0(GeoJob *jobs, int r8) {
   pack_face_records(J.rec[0], f, vc, r, r8);
   J.face_time[f] = -1;                            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
-// encoder, tables 1..3 (decoder order; table = 1 + blockIdx.z): base table and the attribute tables that have interior seams.
+// encoder, tables first .. 3 (table = first + blockIdx.z), in the STORED face order like table 0: the attribute tables that have interior
+// seams (2, 3) and - only when the walkers do not read one 16-byte record per face - a copy of the base table (1).  With per-face
+// records table 1 IS table 0 (GeoJob::base_hi: the traversal marks its faces in bit 127, the walk used bit 63).
 // An attribute vertex an interior seam does not touch keeps its base id and open flag; the segments of the others are open.
-__global__ void __launch_bounds__(UVOL_BLOCK) k_pack3(GeoJob *jobs, int r8) {
+__global__ void __launch_bounds__(UVOL_BLOCK) k_pack_tabs(GeoJob *jobs, int r8, int first) {
   JOB_OR_RETURN;
-  const int which = 1 + (int)blockIdx.z;
+  const int which = first + (int)blockIdx.z;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (f >= J.nf || !dense_table_live(J, which)) return;
-  const int ai = which >= 2 ? which - 2 : 0;
-  const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
-  const int32_t *vert = which == 1 ? J.bvert : J.avert[ai];
-  const uint32_t nbase = J.nverts_t[0];
+  const int ai = which >= 2 ? which - 2 : -1;
+  const uint32_t nbase = J.nverts_t[0], fs = ai >= 0 ? (uint32_t)J.fseam[f] >> (3 * ai) : 0u;
+  const uvol_s3 o3 = *reinterpret_cast<const uvol_s3 *>(J.opp + 3 * (size_t)f), v3 = *reinterpret_cast<const uvol_s3 *>(J.vert + 3 * (size_t)f);
+  const int oo[3] = { o3.x, o3.y, o3.z }, vv[3] = { v3.x, v3.y, v3.z };
   int r[3], vc[3];
   for (int k = 0; k < 3; k++) {
-    const int c = 3 * (int)f + k;
-    r[k] = (seam && seam[c]) ? GEO_INV : J.nopp[c];
-    const uint32_t v = (uint32_t)vert[c];
+    r[k] = ((fs >> k) & 1u) ? GEO_INV : oo[k];
+    uint32_t v = (uint32_t)vv[k];
+    if (ai >= 0 && ((J.vseam[ai][v >> 5] >> (v & 31)) & 1u)) v = (uint32_t)J.avert[ai][3 * f + k];
     vc[k] = (int)((v << 1) | ((v >= nbase || J.vopen_d[0][v]) ? 1u : 0u));
   }
   pack_face_records(J.rec[which], f, vc, r, r8);
@@ -461,6 +463,3 @@ __global__ void __launch_bounds__(128) k_eb_walk(GeoJob *jobs, int vcap_words, i
   if (tid != 0) return;
   eb_walk_lane0<R8>(J, UVOL_TO_L(uint32_t, lds), UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis)), stg);
 }
-
-// face_time[f] = index of the symbol that encoded face f (-1 for the faces that only start a component): the inverse
-// of proc[], built in parallel so that the serial walker has no scatter store in its loop

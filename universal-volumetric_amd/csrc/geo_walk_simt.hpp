@@ -133,6 +133,8 @@ __device__ inline void traverse_simt(GeoJob &J, int t) {
   UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
   UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  UVOL_G(const int32_t) tstart = UVOL_TO_G(const int32_t, J.tstart);
+  const bool virt = J.tstart != nullptr;
   int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
   for (;;) {
     if (x < 0) {                                          // rare: the stack, else the next unvisited face starts a component
@@ -145,14 +147,16 @@ __device__ inline void traverse_simt(GeoJob &J, int t) {
           break;
         }
         if (f >= nf || nvis >= nf) { finished = true; break; }
-        const int f0 = f; f++;
-        if (S_FLAG(4 * f0)) continue;
-        stack[0] = 4 * f0; sp = 1;
-        int vn, vp, r_, l_; S_REC(4 * f0 + 1, vn, r_, l_); S_REC(4 * f0 + 2, vp, r_, l_); vn >>= 1; vp >>= 1;
+        const int x0 = virt ? tstart[f] : 4 * f;           // components start in DECODER order (tstart: encode side, stored tables)
+        f++;
+        if (S_FLAG(x0)) continue;
+        stack[0] = x0; sp = 1;
+        const int xn = code_nxt(x0), xp = code_prv(x0);
+        int vn, vp, r_, l_; S_REC(xn, vn, r_, l_); S_REC(xp, vp, r_, l_); vn >>= 1; vp >>= 1;
         uint32_t w = vbits[vn >> 5];
-        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f0 + 1; n++; }
+        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = corner_of_code(xn); n++; }
         w = vbits[vp >> 5];
-        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f0 + 2; n++; }
+        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = corner_of_code(xp); n++; }
       }
       if (finished) break;
     }
@@ -201,12 +205,17 @@ __global__ void __launch_bounds__(64) k_traverse_simt(GeoJob *jobs, int n, int W
 
 // ------------------------------------------------------------------------------------------------
 // The same two lane-per-walker kernels on ONE 16-byte record per FACE (format 2, pack_face_records): the three vertex fields, the
-// three opposite-corner codes and the face-visited flag.  A step still moves by corner codes (4 * face + k): the vertex of corner k
+// three opposite-corner codes and the face-visited flags.  A step still moves by corner codes (4 * face + k): the vertex of corner k
 // is vertex field k, its right / left neighbours are opposite fields (k + 1) % 3 / (k + 2) % 3 of the same record.  Against the
 // 8-byte corner records this halves the bytes the walkers fetch and write back (the flag dirties the line it is in), puts eight faces
 // instead of four on a 128-byte line (more of a walker's dependent loads hit a line a neighbouring face already brought in), brings a
-// candidate's record AND its visited flag in one load instead of two, and halves the record tables (4 x 3.2 MB less per frame in flight).
+// candidate's record AND its visited flag in one load instead of two, and halves the record tables.
+// Two flags per record: bit 63 (dword 1) is the edgebreaker walk's, bit 127 (dword 3) the base-table traversal's - the base table of
+// the traversals is the walk's own table (round 5: the decoder's face order is virtual, GeoJob::tstart), so it is never packed twice.
+// The attribute tables with seams have tables of their own and use bit 63.  FD = the dword that holds this walker's flag.
 // Batches whose face count or id space does not fit the 21-bit fields keep the 16-byte corner records (geo_rec8).
+// (Measured in round 4 and removed: the flags as one bit per face in an array of their own - clean record lines, two more loads per
+// step, 275 against 251 ms - and loads that bypass the L1, 234 against 206 ms; docs/HISTORY.md.)
 // ------------------------------------------------------------------------------------------------
 #ifdef HIPEMU
 struct uvol_u4 { uint32_t x, y, z, w; };
@@ -214,17 +223,6 @@ struct uvol_u4 { uint32_t x, y, z, w; };
 typedef uint32_t uvol_u4 __attribute__((ext_vector_type(4)));
 #endif
 __device__ __forceinline__ uvol_u4 f16_load(UVOL_G(uint32_t) rec, int face) { return *(UVOL_G(const uvol_u4))(rec + 4 * (size_t)face); }
-// LDM = 1 (UVOL_WALK_LD=1, diagnostic): the walkers' loads as agent-scope atomics, which do not look the line up in the CU's L1.  Measured
-// and NOT the default: traversal 234 against 206 ms per 1280 frames (tools/experiments/exp_r4u.sh) - the L1 hits are worth more than what a
-// load behind the walker's own store into the same line waits for
-template <int LDM> __device__ __forceinline__ uvol_u4 f16_ld(UVOL_G(uint32_t) rec, int face) {
-  if (LDM == 0) return f16_load(rec, face);
-  UVOL_G(uint64_t) p = (UVOL_G(uint64_t))(rec + 4 * (size_t)face);
-  const uint64_t lo = UVOL_ALOAD(p), hi = UVOL_ALOAD(p + 1);
-  uvol_u4 q; q.x = (uint32_t)lo; q.y = (uint32_t)(lo >> 32); q.z = (uint32_t)hi; q.w = (uint32_t)(hi >> 32);
-  return q;
-}
-template <int LDM> __device__ __forceinline__ uint32_t w_ld(UVOL_G(uint32_t) p) { return LDM == 0 ? *p : UVOL_ALOAD(p); }
 __device__ __forceinline__ void f16_dec(const uvol_u4 &q, int k, int &vi, int &rc, int &lc) {
   const uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
   const int s = 21 * k, sr = k == 2 ? 0 : s + 21, sl = k == 0 ? 42 : s - 21;
@@ -232,19 +230,8 @@ __device__ __forceinline__ void f16_dec(const uvol_u4 &q, int k, int &vi, int &r
   rc = (int)((uint32_t)(hi >> sr) << 11) >> 11;            // 21-bit field, all ones = none
   lc = (int)((uint32_t)(hi >> sl) << 11) >> 11;
 }
-// FB = true: the face-visited flags are ONE BIT PER FACE in an array of their own (J.fvis / J.t_fvis[t], zeroed with the workspace head)
-// instead of bit 63 of the record.  The record lines then stay clean: with the flag in the record every step dirtied the very line
-// the next steps read their neighbours from (written back once per line: 9.6 MB per frame and table, and a store into a line makes
-// the following loads of that line go back to L2).  A step knows its own face's word from the step before - the word it tested the
-// face in as a candidate -, so marking is one plain store and testing the two candidates two 4-byte loads beside the record loads.
-template <bool FB> struct F16Vis {
-  UVOL_G(uint32_t) rec; UVOL_G(uint32_t) fb;
-  // is face f visited?  q = its record (FB = false), w = its word of the bitmap (FB = true)
-  __device__ __forceinline__ bool seen(const uvol_u4 &q, uint32_t w, int f) const { return FB ? ((w >> (f & 31)) & 1u) != 0 : (q.y >> 31) != 0; }
-  __device__ __forceinline__ uint32_t word(int f) const { return FB ? fb[f >> 5] : 0u; }
-  __device__ __forceinline__ void mark(int f, const uvol_u4 &q, uint32_t w) const { if (FB) fb[f >> 5] = w | (1u << (f & 31)); else rec[4 * (size_t)f + 1] = q.y | 0x80000000u; }
-};
-template <bool FB, int LDM>
+template <int FD> __device__ __forceinline__ bool f16_seen(const uvol_u4 &q) { return ((FD == 1 ? q.y : q.w) >> 31) != 0; }
+template <int FD> __device__ __forceinline__ void f16_mark(UVOL_G(uint32_t) rec, int f, const uvol_u4 &q) { rec[4 * (size_t)f + FD] = (FD == 1 ? q.y : q.w) | 0x80000000u; }
 __device__ inline void eb_walk_simt_f16(GeoJob &J) {
   const int nf = (int)J.nf;
   UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[0]));
@@ -252,10 +239,9 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
   UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
   UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
   const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
-  F16Vis<FB> V; V.rec = rec; V.fb = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.fvis));
   int nproc = 0, ninit = 0, nstart = 0, nsplit = 0;
   int fo = 0, sp = 0, x = -1, vi = 0, rcn = -1, lcn = -1;
-  uvol_u4 q; q.x = q.y = q.z = q.w = 0; uint32_t myw = 0;
+  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
   for (;;) {
     if (x < 0) {                                          // rare: a corner to go on from - the stack, else the next component
       bool finished = false;
@@ -263,16 +249,16 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
         if (sp > 0) {
           const int c = stack[sp - 1];
           if (c < 0) { sp--; continue; }
-          const uvol_u4 qq = f16_ld<LDM>(rec, c >> 2); const uint32_t ww = V.word(c >> 2);
-          if (V.seen(qq, ww, c >> 2)) { sp--; continue; }
-          x = c; q = qq; myw = ww; f16_dec(q, x & 3, vi, rcn, lcn);
+          const uvol_u4 qq = f16_load(rec, c >> 2);
+          if (f16_seen<1>(qq)) { sp--; continue; }
+          x = c; q = qq; f16_dec(q, x & 3, vi, rcn, lcn);
           break;
         }
         if (fo >= nf || nproc + ninit >= nf) { finished = true; break; }
         const int f0 = rl ? s_of_o[fo] : fo;             // component starts follow the ORIGINAL face order
         fo++;
-        const uvol_u4 q0 = f16_ld<LDM>(rec, f0); const uint32_t w0 = V.word(f0);
-        if (V.seen(q0, w0, f0)) continue;
+        const uvol_u4 q0 = f16_load(rec, f0);
+        if (f16_seen<1>(q0)) continue;
         int v0[3], r0_[3], l0_[3];
         for (int k = 0; k < 3; k++) f16_dec(q0, k, v0[k], r0_[k], l0_[k]);
         const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
@@ -281,7 +267,7 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
           if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
           if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
             int ci = 4 * f0 + k, rc = ci;
-            while (rc >= 0) { ci = rc; int v_, r_, l_; f16_dec(f16_ld<LDM>(rec, rc >> 2), rc & 3, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
+            while (rc >= 0) { ci = rc; int v_, r_, l_; f16_dec(f16_load(rec, rc >> 2), rc & 3, v_, r_, l_); rc = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
             interior = 0; start = code_prv(ci); break;
           }
         }
@@ -289,13 +275,13 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
         nstart++;
         int from;
         if (interior) {
-          for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = w_ld<LDM>(vbits + (v >> 5)); vbits[v >> 5] = w | (1u << (v & 31)); }
-          V.mark(f0, q0, w0);
+          for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = vbits[v >> 5]; vbits[v >> 5] = w | (1u << (v & 31)); }
+          f16_mark<1>(rec, f0, q0);
           initc[ninit] = 3 * f0 + 1;
           ninit++;
           from = o0[1];
           if (from < 0) continue;
-          { const int ff = from >> 2; uint32_t wf = V.word(ff); if (FB && (ff >> 5) == (f0 >> 5)) wf |= 1u << (f0 & 31); if (V.seen(f16_ld<LDM>(rec, ff), wf, ff)) continue; }
+          if (f16_seen<1>(f16_load(rec, from >> 2))) continue;
         } else from = start;
         stack[0] = from; sp = 1;
       }
@@ -303,16 +289,14 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
     }
     // ---- the common step (straight-line, see eb_walk_simt) ----
     const int f = x >> 2, rf = (rcn < 0 ? x : rcn) >> 2, lf = (lcn < 0 ? x : lcn) >> 2;
-    V.mark(f, q, myw);
-    const uvol_u4 qr = f16_ld<LDM>(rec, rf), ql = f16_ld<LDM>(rec, lf);
-    uint32_t wr = V.word(rf), wl = V.word(lf);
-    if (FB) { const uint32_t mine = myw | (1u << (f & 31)); if ((rf >> 5) == (f >> 5)) wr = mine | wr; if ((lf >> 5) == (f >> 5)) wl = mine | wl; }      // (this step's own bit, whatever the load saw)
+    f16_mark<1>(rec, f, q);
+    const uvol_u4 qr = f16_load(rec, rf), ql = f16_load(rec, lf);
     proc[nproc] = 3 * f + (x & 3);
     const int v = vi >> 1;
-    const uint32_t vw = w_ld<LDM>(vbits + (v >> 5));
+    const uint32_t vw = vbits[v >> 5];
     vbits[v >> 5] = vw | (1u << (v & 31));                                  // (already set when the tip was visited)
     const uint32_t vvis = (vw >> (v & 31)) & 1u;
-    const uint32_t rvis = (rcn < 0 || V.seen(qr, wr, rf)) ? 1u : 0u, lvis = (lcn < 0 || V.seen(ql, wl, lf)) ? 1u : 0u;
+    const uint32_t rvis = (rcn < 0 || f16_seen<1>(qr)) ? 1u : 0u, lvis = (lcn < 0 || f16_seen<1>(ql)) ? 1u : 0u;
     const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;                    // tip unvisited and not on a boundary
     const uint32_t sym = ccase ? 0u : 1u + 2u * lvis + 4u * rvis;           // C 0, S 1, L 3, R 5, E 7
     symb[nproc] = (uint8_t)sym;
@@ -322,7 +306,7 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
     else {
       const bool go_l = sym == 5u;
       x = go_l ? lcn : rcn;
-      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w; myw = go_l ? wl : wr;
+      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
       f16_dec(q, x & 3, vi, rcn, lcn);
     }
   }
@@ -332,7 +316,6 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
   uint32_t z = 0; for (int i = 0; i < nstart; i++) z += start_bits[i] == 0;
   J.rb[0].zeros = z;
 }
-template <bool FB, int LDM>
 __global__ void __launch_bounds__(64) k_eb_walk_simt_f16(GeoJob *jobs, int n, int W) {
   const int lane = (int)threadIdx.x;
   if (lane >= W) return;
@@ -340,17 +323,20 @@ __global__ void __launch_bounds__(64) k_eb_walk_simt_f16(GeoJob *jobs, int n, in
   if (j >= n) return;
   GeoJob &J = jobs[j];
   if (J.status != 0) return;
-  eb_walk_simt_f16<FB, LDM>(J);
+  eb_walk_simt_f16(J);
 }
-template <bool FB, int LDM>
+// Depth-first sequencing of table t.  Components start at the first unvisited face IN DECODER ORDER, at the decoder's corner 0 of that
+// face: face f itself on the decode path (tstart == nullptr), tstart[f] on the encode side, whose tables keep the stored order.
+template <int FD>
 __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
   const int nf = (int)J.nf;
   UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
   UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
   UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
-  F16Vis<FB> V; V.rec = rec; V.fb = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_fvis[t]));
+  UVOL_G(const int32_t) tstart = UVOL_TO_G(const int32_t, J.tstart);
+  const bool virt = J.tstart != nullptr;
   int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
-  uvol_u4 q; q.x = q.y = q.z = q.w = 0; uint32_t myw = 0;
+  uvol_u4 q; q.x = q.y = q.z = q.w = 0;
   for (;;) {
     if (x < 0) {                                          // rare: the stack, else the next unvisited face starts a component
       bool finished = false;
@@ -358,53 +344,51 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
         if (sp > 0) {
           const int c = stack[sp - 1];
           if (c < 0) { sp--; continue; }
-          const uvol_u4 qq = f16_ld<LDM>(rec, c >> 2); const uint32_t ww = V.word(c >> 2);
-          if (V.seen(qq, ww, c >> 2)) { sp--; continue; }
-          x = c; q = qq; myw = ww; f16_dec(q, x & 3, vi, rc, lc);
+          const uvol_u4 qq = f16_load(rec, c >> 2);
+          if (f16_seen<FD>(qq)) { sp--; continue; }
+          x = c; q = qq; f16_dec(q, x & 3, vi, rc, lc);
           break;
         }
         if (f >= nf || nvis >= nf) { finished = true; break; }
-        // the next unvisited face in storage order.  A table with seams falls into many components (one per chart), and between two
+        // the next unvisited face in decoder order.  A table with seams falls into many components (one per chart), and between two
         // of them this scan passes every face once: eight flag words per round trip instead of one record (a lane that scans holds up
         // the other walkers of its wave, and a walker alone spent a sixth of its time here)
-        if (!FB) {
-          int hit = -1;
-          while (f < nf) {
-            uint32_t y[8];
-            for (int k = 0; k < 8; k++) { const int fk = f + k < nf ? f + k : nf - 1; y[k] = w_ld<LDM>(rec + 4 * (size_t)fk + 1); }
-            uint32_t m = 0;
-            for (int k = 0; k < 8; k++) m |= ((y[k] >> 31) ^ 1u) << k;
-            if (nf - f < 8) m &= (1u << (nf - f)) - 1u;
-            if (m) { hit = f + __builtin_ctz(m); break; }
-            f += 8;
-          }
-          if (hit < 0) { finished = true; break; }
-          f = hit;
+        int hit = -1, x0 = 0;
+        while (f < nf) {
+          int xs[8]; uint32_t y[8];
+          for (int k = 0; k < 8; k++) { const int fk = f + k < nf ? f + k : nf - 1; xs[k] = virt ? tstart[fk] : 4 * fk; }
+          for (int k = 0; k < 8; k++) y[k] = rec[4 * (size_t)(xs[k] >> 2) + FD];
+          uint32_t m = 0;
+          for (int k = 0; k < 8; k++) m |= ((y[k] >> 31) ^ 1u) << k;
+          if (nf - f < 8) m &= (1u << (nf - f)) - 1u;
+          if (m) { const int k0 = __builtin_ctz(m); hit = f + k0; x0 = xs[0]; for (int k = 1; k < 8; k++) x0 = k == k0 ? xs[k] : x0; break; }
+          f += 8;
         }
-        const int f0 = f; f++;
-        const uvol_u4 q0 = f16_ld<LDM>(rec, f0); const uint32_t w0 = V.word(f0);
-        if (V.seen(q0, w0, f0)) continue;
-        stack[0] = 4 * f0; sp = 1;
-        int vn, vp, r_, l_; f16_dec(q0, 1, vn, r_, l_); f16_dec(q0, 2, vp, r_, l_); vn >>= 1; vp >>= 1;
-        uint32_t w = w_ld<LDM>(vbits + (vn >> 5));
-        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = 3 * f0 + 1; n++; }
-        w = w_ld<LDM>(vbits + (vp >> 5));
-        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = 3 * f0 + 2; n++; }
+        if (hit < 0) { finished = true; break; }
+        f = hit + 1;
+        const int f0 = x0 >> 2;
+        const uvol_u4 q0 = f16_load(rec, f0);
+        if (f16_seen<FD>(q0)) continue;
+        stack[0] = x0; sp = 1;
+        const int xn = code_nxt(x0), xp = code_prv(x0);
+        int vn, vp, r_, l_; f16_dec(q0, xn & 3, vn, r_, l_); f16_dec(q0, xp & 3, vp, r_, l_); vn >>= 1; vp >>= 1;
+        uint32_t w = vbits[vn >> 5];
+        if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n] = corner_of_code(xn); n++; }
+        w = vbits[vp >> 5];
+        if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n] = corner_of_code(xp); n++; }
       }
       if (finished) break;
     }
     const int fc = x >> 2, rf = (rc < 0 ? x : rc) >> 2, lf = (lc < 0 ? x : lc) >> 2;
-    V.mark(fc, q, myw);
+    f16_mark<FD>(rec, fc, q);
     nvis++;
-    const uvol_u4 qr = f16_ld<LDM>(rec, rf), ql = f16_ld<LDM>(rec, lf);
-    uint32_t wr = V.word(rf), wl = V.word(lf);
-    if (FB) { const uint32_t mine = myw | (1u << (fc & 31)); if ((rf >> 5) == (fc >> 5)) wr = mine | wr; if ((lf >> 5) == (fc >> 5)) wl = mine | wl; }
+    const uvol_u4 qr = f16_load(rec, rf), ql = f16_load(rec, lf);
     const int v = vi >> 1;
-    const uint32_t vw = w_ld<LDM>(vbits + (v >> 5));
+    const uint32_t vw = vbits[v >> 5];
     vbits[v >> 5] = vw | (1u << (v & 31));
     const uint32_t vvis = (vw >> (v & 31)) & 1u;
     if (!vvis) { order[n] = 3 * fc + (x & 3); n++; }                        // a vertex seen for the first time takes the next place
-    const uint32_t rvis = (rc < 0 || V.seen(qr, wr, rf)) ? 1u : 0u, lvis = (lc < 0 || V.seen(ql, wl, lf)) ? 1u : 0u;
+    const uint32_t rvis = (rc < 0 || f16_seen<FD>(qr)) ? 1u : 0u, lvis = (lc < 0 || f16_seen<FD>(ql)) ? 1u : 0u;
     const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;
     const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
     if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; }
@@ -412,23 +396,22 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
     else {
       const bool go_l = k == 2u;
       x = go_l ? lc : rc;
-      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w; myw = go_l ? wl : wr;
+      q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
       f16_dec(q, x & 3, vi, rc, lc);
     }
   }
   J.ne[t] = (uint32_t)n;
   if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
-template <bool FB, int LDM>
-__global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, int W) {
+// walker id = table * n + frame (tables t0 .. t0 + nt - 1): the lanes of a wave walk the same table of consecutive frames
+__global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, int W, int t0, int nt) {
   const int lane = (int)threadIdx.x;
   if (lane >= W) return;
   const int id = (int)blockIdx.x * W + lane;
-  if (id >= 3 * n) return;
-  const int t = id / n, j = id - t * n;
+  if (id >= nt * n) return;
+  const int t = t0 + id / n, j = id % n;
   GeoJob &J = jobs[j];
   const int ai = t > 0 ? t - 1 : 0;
   if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
-  traverse_simt_f16<FB, LDM>(J, t);
+  if (t == 0 && J.base_hi) traverse_simt_f16<3>(J, t); else traverse_simt_f16<1>(J, t);
 }
-

@@ -92,13 +92,22 @@ struct GeoJob {
   uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // per vertex id: on a boundary, ring size; size of the id space per table (encoder: only vopen_d[0])
   uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
   uint8_t *start_bits;
-  int32_t *new_of_old, *nopp, *npid, *nuid, *nnid, *bvert;
-  uint8_t *seam[2]; uint8_t *elig; uint8_t *seam_bits[2];
-  int32_t *avert[2];
+  // Decoder order stays VIRTUAL on the encode side (round 5): every table keeps the stored face order and the decoder's face
+  // numbering appears only as tstart[] (decoder-order face -> code of its first corner in the stored tables), which the traversals'
+  // component starts and the seam-bit order follow.  nopp / bvert / seam[] are the DECODE path's view (geom_decode.hip wires them
+  // to its decoded tables, which are in decoder order by construction; tstart == nullptr there).
+  int32_t *nopp, *bvert; uint8_t *seam[2];
+  int32_t *tstart;
+  uint8_t *fseam;                      // per stored face: bit k = the edge opposite corner k is a seam (or a boundary) of attribute slot 0, bit 3 + k: of slot 1
+  uint8_t *sbpack;                     // per decoder-order face: seam bits it contributes: count (bits 0-1), slot-0 bits (2-4), slot-1 bits (5-7)
+  uint8_t *seam_bits[2];
+  int32_t *avert[2];                   // attribute vertex per corner, WRITTEN ONLY for corners of seam-touched vertices (vseam bit): all others keep vert[]
+  int32_t base_hi;                     // 1: table 0 of the traversals is the walk's own record table (rec[1] == rec[0]); its visited flag is bit 127
   int32_t *order[3], *v2d[3]; uint8_t *t_vvis[3]; int32_t *t_stack[3];
   uint8_t *fvis, *t_fvis[3];          // face-visited bits (one per face) of the lane-per-walker kernels on per-face records (walk, three traversals)
-  int32_t *P, *U, *O;
-  long long *fnorm;                    // per new face: the un-normalised face normal (p1 - p0) x (p2 - p0) of its quantised positions (k_face_normals)
+  int32_t *P, *U, *O;                  // sequential connectivity only: quantised values per point
+  uint16_t *qpos, *quv, *qnrm;         // quantised values BY VALUE ID (k_quant_ids): 4 x u16 per position (one 8-byte gather), 2 x u16 per uv / octahedral normal
+  long long *fnorm;                    // per stored face: the un-normalised face normal (p1 - p0) x (p2 - p0) of its quantised positions (k_face_normals)
   uint32_t *sym_pos, *sym_uv, *sym_nrm;
   uint8_t *has_ori, *ori_val, *ori_c, *ori_bits, *flips;
   RansStream rs[GEO_NSTREAM];

@@ -205,8 +205,6 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint32_t, ecap / 32 + 2, PH_PINNED, PH_PINNED);      // one bit per vertex: the whole map stays in L2
   for (int t = 0; t < 3; t++) CARVE(J.t_vvis[t], uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
-  CARVE(J.fvis, uint8_t, nfi / 8 + 64, PH_PINNED, PH_PINNED);                                           // face-visited bits of the lane-per-walker kernels on per-face records
-  for (int t = 0; t < 3; t++) CARVE(J.t_fvis[t], uint8_t, nfi / 8 + 64, PH_PINNED, PH_PINNED);
   for (int s = 0; s < GEO_NSTREAM; s++) {
     const int q = s == 6 ? J.qp : (s == 7 ? J.qt : J.qn);
     J.rs[s].alpha_cap = s < 6 ? 8 : (1u << (q + 1)) + 8;
@@ -218,7 +216,8 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
   { const int cl = J.seq ? PH_LAYOUT : PH_FACES;          // the sequential path reads the canonical ids when it quantises the points
     CARVE(J.canon[0], uint32_t, J.n_pos + 1, PH_DEDUP, cl); CARVE(J.canon[1], uint32_t, J.n_uv + 1, PH_DEDUP, cl); CARVE(J.canon[2], uint32_t, J.n_nrm + 1, PH_DEDUP, cl); }
   CARVE(J.keep, uint8_t, nfi + 1, PH_FACES, PH_FACES);
-  CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_RENUM); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_RENUM);
+  // the stored corner table (canonical value ids, opposite corners, vertex ids) lives until the predictors: nothing is renumbered
+  CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_PRED); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_PRED); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_PRED);
   CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_FANS0); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_FANS0);      // k_vert0 walks the buckets
   { // partitioned bucket build (compact layout, ranges of <= HE_MAXVPB vertices): records + counts matrix, live in PH_CT only
     uint32_t vpb = 512; while ((uint64_t)vpb * HE_MAXBINS < (uint64_t)J.n_pos) vpb *= 2;
@@ -227,34 +226,38 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
     if (J.he_vpb) { CARVE(J.he_part, uint32_t, 3 * nc + 4, PH_CT, PH_CT); CARVE(J.he_cnt, uint32_t, (size_t)J.he_nb * J.he_nblk + 2, PH_CT, PH_CT); }
   }
   const int aux_last = J.late_join ? PH_PRED : PH_SEAMS;            // what the auxiliary stream (valence replay, context scatter) reads lives until its join
-  CARVE(J.opp, int32_t, nc + 3, PH_CT, aux_last);
-  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_SEAMS);
+  CARVE(J.opp, int32_t, nc + 3, PH_CT, PH_PRED);
+  CARVE(J.vert, int32_t, nc + 3, PH_FANS0, PH_PRED);
   // ---- K4 ----
   auto rec_size = [&](int fmt) { return (size_t)(fmt == 2 ? 16 : (fmt == 1 ? 32 : 64)) * (nfi + 1); };
   const size_t rec_bytes = rec_size(fmtT);
-  CARVE(J.rec[0], uint8_t, rec_size(fmt0), PH_DENSE0, PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
-  for (int w = 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
+  // With one record per face in both the walk and the traversals (formats 2 / 2) the base table of the traversals IS the walk's table
+  // (J.base_hi, rec[1] = rec[0]: set after the placement); otherwise table 1 is a copy in the traversals' format (k_pack_tabs).
+  const bool base_shared = fmt0 == 2 && fmtT == 2;
+  CARVE(J.rec[0], uint8_t, rec_size(fmt0), PH_DENSE0, base_shared ? PH_V2D : PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
+  for (int w = base_shared ? 2 : 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
   CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_SEAMS);
-  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, aux_last);
+  CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, std::max<int>(aux_last, PH_SEAMS));
   CARVE(J.proc, int32_t, nfi + 1, PH_WALK, aux_last); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, aux_last);
-  CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_RENUM); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
+  CARVE(J.tstart, int32_t, nfi + 1, PH_FTIME, PH_TRAV);
+  CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_FTIME); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
   // auxiliary stream (forked after PH_FTIME, joined before PH_HIST)
   CARVE(J.evcnt, uint8_t, nfi + 1, PH_RENUM, PH_SEAMS);
   CARVE(J.ev_src, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_spl, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT);
   CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, aux_last); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, aux_last); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, aux_last);
   for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1, PH_RENUM, PH_ENT);
-  // ---- renumbering, seams ----
-  CARVE(J.new_of_old, int32_t, nc + 3, PH_RENUM, PH_RENUM); CARVE(J.nopp, int32_t, nc + 3, PH_RENUM, PH_PRED);
-  CARVE(J.npid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nuid, int32_t, nc + 3, PH_RENUM, PH_QUANT); CARVE(J.nnid, int32_t, nc + 3, PH_RENUM, PH_QUANT);
-  CARVE(J.bvert, int32_t, nc + 3, PH_RENUM, PH_PRED);
+  // ---- seams (on the stored tables: the decoder's order is virtual, GeoJob::tstart) ----
+  CARVE(J.fseam, uint8_t, nfi + 1, PH_RENUM, PH_PRED); CARVE(J.sbpack, uint8_t, nfi + 1, PH_RENUM, PH_SEAMS);
   for (int i = 0; i < 2; i++) {
-    CARVE(J.seam[i], uint8_t, nc + 3, PH_RENUM, PH_PRED); CARVE(J.seam_bits[i], uint8_t, nc + 3, PH_SEAMS, PH_ENT);
-    CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED);
+    CARVE(J.seam_bits[i], uint8_t, nc + 3, PH_SEAMS, PH_ENT);
+    CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED);          // (address space only: written for the corners of seam-touched vertices)
   }
-  CARVE(J.elig, uint8_t, nc + 3, PH_RENUM, PH_SEAMS);
   // ---- K5, K1, K6 ----
   for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, ecap, PH_TRAV, PH_PRED); CARVE(J.v2d[t], int32_t, ecap, PH_V2D, PH_PRED); CARVE(J.t_stack[t], int32_t, nfi + 2, PH_TRAV, PH_TRAV); }
-  CARVE(J.P, int32_t, 3 * ecap, PH_QUANT, PH_PRED); CARVE(J.U, int32_t, 2 * ecap, PH_QUANT, PH_PRED); CARVE(J.O, int32_t, 2 * ecap, PH_QUANT, PH_PRED);
+  if (J.seq) { CARVE(J.P, int32_t, 3 * ecap, PH_QUANT, PH_PRED); CARVE(J.U, int32_t, 2 * ecap, PH_QUANT, PH_PRED); CARVE(J.O, int32_t, 2 * ecap, PH_QUANT, PH_PRED); }
+  else {                                                  // quantised values by value id (k_quant_ids), gathered by k_v2d and the predictors
+    CARVE(J.qpos, uint16_t, 4 * ((size_t)J.n_pos + 1), PH_FACES, PH_PRED); CARVE(J.quv, uint16_t, 2 * ((size_t)J.n_uv + 1), PH_FACES, PH_PRED); CARVE(J.qnrm, uint16_t, 2 * ((size_t)J.n_nrm + 1), PH_FACES, PH_PRED);
+  }
   CARVE(J.fnorm, int32_t, J.n_nrm ? (J.qp <= 15 ? 3 : 6) * nfi + 6 : 2, PH_PRED, PH_PRED);
   CARVE(J.sym_pos, uint32_t, 3 * ecap, PH_PRED, PH_ENT); CARVE(J.sym_uv, uint32_t, 2 * ecap, PH_PRED, PH_ENT); CARVE(J.sym_nrm, uint32_t, 2 * ecap, PH_PRED, PH_ENT);
   CARVE(J.has_ori, uint8_t, ecap, PH_PRED, PH_PRED); CARVE(J.ori_val, uint8_t, ecap, PH_PRED, PH_PRED); CARVE(J.ori_c, uint8_t, ecap, PH_PRED, PH_PRED);
@@ -337,7 +340,7 @@ size_t uvol_mesh_bound(const uvol_mesh *m) {
     hipLaunchKernelGGL(k, grid, block, 0, ctx->stream, __VA_ARGS__);                             \
     if (uvol_debug()) { hipError_t e_ = hipStreamSynchronize(ctx->stream); if (e_ != hipSuccess) { fprintf(stderr, "[uvol] %s FAILED: %s\n", #k, hipGetErrorString(e_)); fflush(stderr); } \
       GeoJob dbg_; (void)hipMemcpy(&dbg_, dj, sizeof(GeoJob), hipMemcpyDeviceToHost); \
-      fprintf(stderr, "[uvol]   job0 status %d nf %u nverts %u ne %u %u %u ne_uv %u has_ori %p bsum %p elig %p n_ori %u\n", dbg_.status, dbg_.nf, dbg_.nverts, dbg_.ne[0], dbg_.ne[1], dbg_.ne[2], dbg_.ne_uv, (void*)dbg_.has_ori, (void*)dbg_.bsum, (void*)dbg_.elig, dbg_.n_ori); fflush(stderr); } \
+      fprintf(stderr, "[uvol]   job0 status %d nf %u nverts %u ne %u %u %u ne_uv %u has_ori %p bsum %p sbpack %p n_ori %u\n", dbg_.status, dbg_.nf, dbg_.nverts, dbg_.ne[0], dbg_.ne[1], dbg_.ne[2], dbg_.ne_uv, (void*)dbg_.has_ori, (void*)dbg_.bsum, (void*)dbg_.sbpack, dbg_.n_ori); fflush(stderr); } \
   } while (0)
 
 #define LAUNCH_ON(stream_, k, grid, block, ...)                                                  \
@@ -412,17 +415,12 @@ static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
 }
 // the decode path sizes its record tables with the same rule; its vertex ids are dense (< 3 * faces)
 bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
-// UVOL_FACE_BITS=1 (diagnostic, tests): face-visited bits in an array of their own instead of bit 63 of the per-face record.  Measured and
-// NOT the default: traversals 275 against 251 ms, geometry alone 3074 against 3169 frames/s, full path 2580 against 2745 - the two extra
-// 4-byte loads per step cost more than the clean record lines save (tools/experiments/exp_r4h.sh).
-static inline bool geo_face_bits() { static const bool v = [] { const char *e = getenv("UVOL_FACE_BITS"); return e && *e == '1'; }(); return v; }
 static inline bool geo_rec_face_off() { static const bool v = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }(); return v; }      // UVOL_REC_FACE=0 (diagnostic, tests): corner records in the lane-per-walker kernels too
-static inline bool geo_walk_ld() { static const bool v = [] { const char *e = getenv("UVOL_WALK_LD"); return e && *e == '1'; }(); return v; }
 static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) {
     const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W;
-    if (r8 == 2) { if (geo_face_bits()) LAUNCH((k_traverse_simt_f16<true, 0>), dim3(nb), dim3(64), dj, n, (int)W); else if (geo_walk_ld()) LAUNCH((k_traverse_simt_f16<false, 1>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt_f16<false, 0>), dim3(nb), dim3(64), dj, n, (int)W); }
+    if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W, 0, 3);
     else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
   }
   else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
@@ -549,6 +547,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, tvg);
   const bool f16_off = geo_rec_face_off();
   const int fmt0 = (r8 && wp_walk.simt_w && !f16_off) ? 2 : r8, fmtT = (r8 && wp_trav.simt_w && !f16_off) ? 2 : r8;
+  const bool base_shared = fmt0 == 2 && fmtT == 2;
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
@@ -587,6 +586,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
     uint8_t *base = (uint8_t *)L.slab.p + ws_off[i];
     (void)layout_job(J, base, full, fmt0, fmtT, G->plan, G->items);
+    if (base_shared) { J.rec[1] = J.rec[0]; J.base_hi = 1; }      // the traversals' base table is the walk's record table (flag bit 127)
     J.ws_base = base; J.ws_zero = zero_sz[i];          // cleared by ONE k_job_clear launch for the whole batch (was 2 memsets per frame)
     if (L.ext_out) { J.out_pack = L.ext_out; J.slab_cap = L.ext_cap; } else { J.out_pack = (uint8_t *)L.outs.p; J.slab_cap = out_total; }
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
@@ -690,6 +690,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
       LAUNCH(k_relabel_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     }
     LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);       // the frames that are not relabelled (decided per frame on the device)
+    { uvol_ctx::Scope sq(ctx, "geo.k1_quantize", algo_in); LAUNCH(k_quant_ids, dim3(bv, N, 3), dim3(UVOL_BLOCK), dj); }      // (after the relabelling: position ids are the stored ones)
   }
   {
     uvol_ctx::Scope sc(ctx, "geo.k3_corner_table", (uint64_t)n * 0 + (uint64_t)3 * max_nfi * 4 * 3);
@@ -717,7 +718,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) {
       const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
-      if (fmt0 == 2) { if (geo_face_bits()) LAUNCH((k_eb_walk_simt_f16<true, 0>), dim3(nb), dim3(64), dj, n, (int)W); else if (geo_walk_ld()) LAUNCH((k_eb_walk_simt_f16<false, 1>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt_f16<false, 0>), dim3(nb), dim3(64), dj, n, (int)W); }
+      if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
       else if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
     }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());
@@ -743,11 +744,11 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   }
   UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_val, L.aux));
   {
-    uvol_ctx::Scope sc(ctx, "geo.k4b_renumber_seams", 0);
-    LAUNCH(k_renumber_a, dim3(bf, N), dim3(UVOL_BLOCK), dj);
-    LAUNCH(k_renumber_seams, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    uvol_ctx::Scope sc(ctx, "geo.k4b_seams", 0);
+    LAUNCH(k_seams, dim3(bf, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_sb_count, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_scan_sums, dim3(1, N), dim3(UVOL_BLOCK), dj, (int)SCAN_ELIG);
-    LAUNCH(k_seam_bits, dim3((bc + SB_E - 1) / SB_E, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_sb_write, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_aseg_a, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_aseg_b, dim3(bci, N, 2), dim3(UVOL_BLOCK), dj);
   }
@@ -757,7 +758,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   // tables of the attribute traversals are written and shares their addresses - the workspace peak drops from 63 to 52 MB.
   if (!late_join) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, L.ev_val, 0));
   {
-    LAUNCH(k_pack3, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, fmtT);
+    if (base_shared) LAUNCH(k_pack_tabs, dim3(bf, N, 2), dim3(UVOL_BLOCK), dj, fmtT, 2); else LAUNCH(k_pack_tabs, dim3(bf, N, 3), dim3(UVOL_BLOCK), dj, fmtT, 1);
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): LDS traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
@@ -766,10 +767,6 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     launch_traversals(ctx, dj, n, wp_trav, fmtT);
   }
   { uvol_ctx::Scope sc(ctx, "geo.k5b_v2d", 0); LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, fmtT); }      // (own scope: geo.k5_traverse is exactly the traversal kernel, as rocprof lists it)
-  {
-    uvol_ctx::Scope sc(ctx, "geo.k1_quantize", algo_in);
-    LAUNCH(k_quantize, dim3(be, N, 3), dim3(UVOL_BLOCK), dj);
-  }
   {
     uvol_ctx::Scope sc(ctx, "geo.k6_predict", 0);
     LAUNCH(k_stream_setup, dim3(N), dim3(64), dj);
