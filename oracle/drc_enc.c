@@ -146,10 +146,17 @@ static int drc_encode_sequential(const drc_enc_input *in, const drc_enc_params *
   for (uint32_t c = 0; c < nc; c++) if (first[c] == (int32_t)c) { corner_of_point[np] = (int32_t)c; pid[c] = (int32_t)np++; }
   for (uint32_t c = 0; c < nc; c++) pid[c] = pid[first[c]];
   ob_bytes(out, "DRACO", 5); ob_u8(out, 2); ob_u8(out, 2); ob_u8(out, 1); ob_u8(out, 0); ob_u16(out, 0);
+  if (prm->method == 3) {                                                      /* connectivity_method 0 (compress_connectivity): signed differences to the previous index, as symbols */
+    ob_varint(out, nf); ob_varint(out, np); ob_u8(out, 0);
+    uint32_t *sy = (uint32_t *)malloc(4 * (size_t)nc + 4); int32_t last = 0;
+    for (uint32_t c = 0; c < nc; c++) { const int32_t d = pid[c] - last; last = pid[c]; sy[c] = d < 0 ? (((uint32_t)(-d)) << 1) | 1u : ((uint32_t)d) << 1; }
+    orc_encode_symbols(sy, nc, out); free(sy);
+  } else {
   ob_varint(out, nf); ob_varint(out, np); ob_u8(out, 1);                       /* connectivity_method 1: indices stored directly */
   for (uint32_t c = 0; c < nc; c++) {
     const uint32_t v = (uint32_t)pid[c];
     if (np < 256) ob_u8(out, (uint8_t)v); else if (np < (1u << 16)) ob_u16(out, (uint16_t)v); else if (np < (1u << 21)) ob_varint(out, v); else ob_i32(out, (int32_t)v);
+  }
   }
   const int natt = 1 + has_uv + has_nrm;
   ob_u8(out, 1);                                                               /* one attributes decoder */
@@ -216,7 +223,7 @@ int drc_encode(const drc_enc_input *in, const drc_enc_params *prm, orc_buf *out)
     if (has_uv && in->idx_uv[c] >= in->n_uv) return -2;
     if (has_nrm && in->idx_nrm[c] >= in->n_nrm) return -2;
   }
-  if (prm->method == 2) return drc_encode_sequential(in, prm, out);
+  if (prm->method == 2 || prm->method == 3) return drc_encode_sequential(in, prm, out);   /* 3: sequential with compressed indices (test streams for the decoders) */
   /* K2: value dedup (bitwise) */
   uint32_t *canon_p = (uint32_t *)malloc(4 * (size_t)(in->n_pos + 1)), *canon_u = NULL, *canon_n = NULL;
   dedup_values(in->pos, in->n_pos, 12, canon_p);

@@ -169,7 +169,7 @@ def rabs_encode(bits) -> bytes:
 
 
 def drc_encode(pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None, qp=11, qt=10, qn=8, method=0) -> bytes:
-    """method: 0 valence edgebreaker (`draco_encoder -cl 7`), 1 edgebreaker with the standard traversal, 2 sequential connectivity."""
+    """method: 0 valence edgebreaker (`draco_encoder -cl 7`), 1 edgebreaker with the standard traversal, 2 sequential connectivity, 3 sequential connectivity with compressed indices (connectivity_method 0; decoder test streams)."""
     pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
     idx_pos = np.ascontiguousarray(idx_pos, dtype=np.uint32).reshape(-1)
     inp = DrcEncInput()

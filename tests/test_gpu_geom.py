@@ -480,10 +480,11 @@ def test_gpu_decoder_reads_the_other_draco_tool_sets(oracle, gpu_codec):
     ms = [synth.torus_mesh(), synth.grid_mesh(), synth.sphere_mesh(frame=2, seed=2)]
     files = []
     for f in ms:
-        for method in (0, 1, 2):
+        for method in (0, 1, 2, 3):                     # 3: sequential connectivity with compressed indices (connectivity_method 0)
             files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f["uv"], f["idx_uv"], f["nrm"], f["idx_nrm"], method=method))
     t = ms[0]
     files.append(oracle.drc_encode(t["pos"], t["idx_pos"], method=2))
+    files.append(oracle.drc_encode(t["pos"], t["idx_pos"], method=3))
     from test_hipemu_geom import _check_decoded
     for data, got in zip(files, gpu_codec.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)

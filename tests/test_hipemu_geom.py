@@ -344,8 +344,10 @@ def test_hipemu_mesh_decode_matches_oracle(oracle, hipemu_lib):
     files = [oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm")) for f in ms + [bare]]
     # the other Draco tool sets the stock player's decoder reads (src/lib/DRACOLoader.js:470-554): edgebreaker with the STANDARD
     # traversal (stock levels 1..5) and SEQUENTIAL connectivity (level 0), written by the restatement's encoder options
+    # (method 3: sequential connectivity with COMPRESSED indices - connectivity_method 0, the index differences in the last rANS slot:
+    # the early symbol passes once left that slot undecoded; mixed into one batch with the other kinds on purpose)
     for f in ms[:3] + [bare]:
-        for method in (1, 2):
+        for method in (1, 2, 3):
             files.append(oracle.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"), method=method))
     # 16-bit quantisation of every attribute: the largest operands the tex-coord predictor's f64 form must keep exact; and 4 bits
     for f, qb in ((ms[0], 16), (ms[1], 4)):

@@ -31,6 +31,10 @@ for k in ("Q_POSITION_ATTR", "Q_TEXTURE_ATTR", "Q_NORMAL_ATTR"):
 c = uvol.Codec(lib_path=lib, **kw)
 t0 = time.time()
 res = c.encode_mesh_batch(frames, raise_on_error=False)
+# clean frames only (the compact layout holds), then the mixed batch again (the context remembers), then clean again
+clean = [frames[0], frames[1], frames[3]]
+res2 = c.encode_mesh_batch(clean) + c.encode_mesh_batch(frames, raise_on_error=False) + c.encode_mesh_batch(clean)
+assert res2 == [res[0], res[1], res[3]] + res + [res[0], res[1], res[3]], "results depend on the layout mode"
 bad = 0
 for i, (f, r) in enumerate(zip(frames, res)):
     e = O.drc_encode(f["pos"], f["idx_pos"], f.get("uv"), f.get("idx_uv"), f.get("nrm"), f.get("idx_nrm"),

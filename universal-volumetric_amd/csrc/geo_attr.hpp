@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_pos(GeoJob *jobs) {
     const int oci = J.opp[ci];
     if (oci >= 0) {
       const int fo = 3 * (oci / 3), j = oci - fo;
-      const uvol_s3 v3 = *reinterpret_cast<const uvol_s3 *>(J.vert + fo);
+      const uvol_s3 v3 = *reinterpret_cast<const uvol_s3 *>(geo_vt(J) + fo);
       const int vv[3] = { v3.x, v3.y, v3.z };
       const uint32_t a = (uint32_t)v2d[vv[j]], bn = (uint32_t)v2d[vv[(j + 1) % 3]], bp = (uint32_t)v2d[vv[(j + 2) % 3]];
       if (a < p && bn < p && bp < p) {

@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_eb_event_compact(GeoJob *jobs) {
   const uint32_t pos = block_excl_scan(v, &tot) + ((J.status == 0 && blockIdx.x <= uvol_blocks_dev(J.nf)) ? J.bsum2[blockIdx.x] : 0);
   if (live && v) {
     int a[2], b[2]; const int n = eb_events_of(J, i, a, b);
-    for (int k = 0; k < n; k++) { J.ev_src[pos + k] = (int)i; J.ev_spl[pos + k] = a[k]; J.ev_edge[pos + k] = (uint8_t)b[k]; }
+    if (pos + (uint32_t)n > J.evcap) J.status = GEO_E_WS_OVERFLOW;        // (sized for the usual handful of events, not for two per face)
+    else for (int k = 0; k < n; k++) { J.ev_src[pos + k] = (int)i; J.ev_spl[pos + k] = a[k]; J.ev_edge[pos + k] = (uint8_t)b[k]; }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) J.nev = (int)J.bsum2[uvol_blocks_dev(J.nf)];
 }
@@ -93,9 +94,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_valence_init(GeoJob *jobs) {
   JOB_OR_RETURN;
   const uint32_t t = blockIdx.x * UVOL_BLOCK + threadIdx.x, stride = gridDim.x * UVOL_BLOCK;
   { const uint32_t n4 = J.nc / 4;                                                     // 16 bytes per lane (both arrays are 16-byte aligned)
-    const uint4 *src = reinterpret_cast<const uint4 *>(J.vert); uint4 *dst = reinterpret_cast<uint4 *>(J.c2vm);
+    const uint4 *src = reinterpret_cast<const uint4 *>(geo_vt(J)); uint4 *dst = reinterpret_cast<uint4 *>(J.c2vm);
     for (uint32_t q = t; q < n4; q += stride) dst[q] = src[q];
-    for (uint32_t c = 4 * n4 + t; c < J.nc; c += stride) J.c2vm[c] = J.vert[c]; }
+    for (uint32_t c = 4 * n4 + t; c < J.nc; c += stride) J.c2vm[c] = geo_vt(J)[c]; }
   const uint32_t nv0 = J.nverts_t[0] < J.ecap ? J.nverts_t[0] : J.ecap;
   for (uint32_t v = t; v < nv0; v += stride) J.vval[v] = J.ring_d[v];
 }
@@ -176,13 +177,22 @@ __global__ void __launch_bounds__(64) k_eb_valence(GeoJob *jobs) {
   }
 }
 
-// symbols -> the six valence-context streams, in symbol order (wave ballots give each symbol its slot)
+// symbols -> the six valence-context streams, in symbol order (wave ballots give each symbol its slot).  The streams lie back to back in
+// ONE array of nf entries (six arrays of the worst-case length each were 4.8 MB per 200 k-face frame in flight): a first pass over the
+// contexts counts, the second scatters.
 __global__ void __launch_bounds__(64) k_eb_ctx(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.x];
   UVOL_SERIAL_PRIO();
   const uint32_t lane = threadIdx.x;
   const int nsym = J.status == 0 ? J.nsym : 0;
-  uint32_t base_c[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+  for (int base = 1; base < nsym; base += 64) {
+    const int i = base + (int)lane;
+    const int cx = i < nsym ? J.ctx_of[i] : 7;
+    for (int c = 0; c < 6; c++) cnt[c] += (uint32_t)__popcll(__ballot(cx == c));
+  }
+  uint32_t base_c[6]; { uint32_t o = 0; for (int c = 0; c < 6; c++) { base_c[c] = o; o += cnt[c]; } }
+  uint32_t *all = J.ctx_all;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (int base = 1; base < nsym; base += 64) {
     const int i = base + (int)lane;
@@ -192,11 +202,11 @@ __global__ void __launch_bounds__(64) k_eb_ctx(GeoJob *jobs) {
     const uint32_t id = ps == 0 ? 0u : (ps == 1 ? 1u : (ps == 3 ? 2u : (ps == 5 ? 3u : 4u)));
     for (int c = 0; c < 6; c++) {
       const unsigned long long m = __ballot(in && cx == c);
-      if (in && cx == c) J.ctx_sym[c][base_c[c] + (uint32_t)__popcll(m & lt)] = id;
+      if (in && cx == c) all[base_c[c] + (uint32_t)__popcll(m & lt)] = id;
       base_c[c] += (uint32_t)__popcll(m);
     }
   }
-  if (lane == 0 && J.status == 0) for (int c = 0; c < 6; c++) { J.ctx_n[c] = base_c[c]; J.rs[c].n = base_c[c]; }
+  if (lane == 0 && J.status == 0) for (int c = 0; c < 6; c++) { J.ctx_n[c] = cnt[c]; J.rs[c].n = cnt[c]; J.ctx_sym[c] = all + (base_c[c] - cnt[c]); J.rs[c].syms = J.ctx_sym[c]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,7 +224,7 @@ __device__ __forceinline__ int st_swr(const GeoJob &J, int slot, int c) { const 
 __device__ __forceinline__ bool vseam_bit(const GeoJob &J, int slot, uint32_t v) { return (J.vseam[slot][v >> 5] >> (v & 31)) & 1u; }
 // vertex of corner c in the table that sequences attribute slot `slot` (the base vertex unless an interior seam touches it)
 __device__ __forceinline__ int att_vertex(const GeoJob &J, int slot, int c) {
-  const int v = J.vert[c];
+  const int v = geo_vt(J)[c];
   return (J.interior_seams[slot] && vseam_bit(J, slot, (uint32_t)v)) ? J.avert[slot][c] : v;
 }
 // One thread per stored face: the seam flags of both attribute slots across its three edges (MeshAttributeCornerTable::InitFromAttribute:
@@ -240,7 +250,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
         sm = (a[(k + 1) % 3] != A[g_prv(oo)] || a[(k + 2) % 3] != A[g_nxt(oo)]) ? 1u : 0u;
         if (sm) {                                                         // both ends of the edge get split
           any = true;
-          const uint32_t va = (uint32_t)J.vert[3 * f + (k + 1) % 3], vb = (uint32_t)J.vert[3 * f + (k + 2) % 3];
+          const uint32_t va = (uint32_t)geo_vt(J)[3 * f + (k + 1) % 3], vb = (uint32_t)geo_vt(J)[3 * f + (k + 2) % 3];
           atomicOr(&J.vseam[i][va >> 5], 1u << (va & 31)); atomicOr(&J.vseam[i][vb >> 5], 1u << (vb & 31));
         }
       }
@@ -310,7 +320,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_a(GeoJob *jobs) {
   const uint32_t c0 = blockIdx.x * (UVOL_BLOCK * GEO_ILP) + threadIdx.x, nc = J.nc;
   int32_t v[GEO_ILP]; uint32_t w[GEO_ILP];
 #pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? J.vert[c] : 0; }
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? geo_vt(J)[c] : 0; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][(uint32_t)v[k] >> 5];
 #pragma unroll
@@ -329,7 +339,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_aseg_b(GeoJob *jobs) {
   if (c0 == 0) { const uint32_t tot = J.nverts_t[0] + J.nseg[i]; J.nverts_t[2 + i] = tot; if (tot > J.ecap) J.status = GEO_E_WS_OVERFLOW; }
   uint32_t v[GEO_ILP], w[GEO_ILP];
 #pragma unroll
-  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? (uint32_t)J.vert[c] : 0u; }
+  for (int k = 0; k < GEO_ILP; k++) { const uint32_t c = c0 + k * UVOL_BLOCK; v[k] = c < nc ? (uint32_t)geo_vt(J)[c] : 0u; }
 #pragma unroll
   for (int k = 0; k < GEO_ILP; k++) w[k] = J.vseam[i][v[k] >> 5];
 #pragma unroll

@@ -201,13 +201,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vert0(GeoJob *jobs) {
   const int c0 = g_nxt((int)(uint32_t)J.he_ent[s]);                    // bucket entry = corner facing the edge; its next corner sits at p
   int cnt; bool open;
   if (fan_probe(T, c0, (int)n, cnt, open) < 0) { J.status = -22; return; }
-  if ((uint32_t)cnt == n) {                                             // one fan: the position is the vertex
-    for (uint32_t i = 0; i < n; i++) J.vert[g_nxt((int)(uint32_t)J.he_ent[s + i])] = (int32_t)p;
+  if ((uint32_t)cnt == n) {                                             // one fan: the position is the vertex, cp[] of its corners is their vertex id (geo_vt)
     J.vopen_d[0][p] = open ? 1 : 0; J.ring_d[p] = (int32_t)(open ? n + 1 : n);
     atomicAdd(&J.nverts, 1u);
     return;
   }
-  bool first = true;                                                    // non-manifold vertex: one id per fan
+  atomicOr(&J.nmbits[p >> 5], 1u << (p & 31));                          // non-manifold vertex: one id per fan, written to vert[]
+  bool first = true;
   for (uint32_t i = 0; i < n; i++) {
     const int c = g_nxt((int)(uint32_t)J.he_ent[s + i]);
     const int rep = fan_probe(T, c, (int)n, cnt, open);
@@ -222,4 +222,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_vert0(GeoJob *jobs) {
   }
   if (first) J.status = -22;
 }
-
+// Vertex id per corner.  A frame without a non-manifold position (extra_v == 0: the usual case) has vert == cp and nothing is written
+// or read under that name - every consumer asks geo_vt().  Otherwise k_vert0 has written the corners of the non-manifold positions
+// and this pass fills in the rest, so that vert[] is complete.
+__device__ __forceinline__ const int32_t *geo_vt(const GeoJob &J) { return J.extra_v ? J.vert : J.cp; }
+__global__ void __launch_bounds__(UVOL_BLOCK) k_vert_fill(GeoJob *jobs) {
+  JOB_OR_RETURN;
+  if (J.extra_v == 0) return;                                           // block-uniform
+  const uint32_t c = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (c >= J.nc) return;
+  const uint32_t p = (uint32_t)J.cp[c];
+  if (!((J.nmbits[p >> 5] >> (p & 31)) & 1u)) J.vert[c] = (int32_t)p;
+}

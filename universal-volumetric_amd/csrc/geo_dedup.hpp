@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_dd_resolve(GeoJob *jobs, uint32_
   __syncthreads();
   if (fail || n_ins > slots - slots / 4) { if (threadIdx.x == 0) J.status = GEO_E_DD_OVERFLOW; return; }
   if (!any_dup) return;                                   // every value of the bin is unique: canon[] stays the identity
+  if (threadIdx.x == 0) J.n_dup[which] = 1;               // (k_compact_faces: the canonical ids of this attribute are not the input's own)
   for (uint32_t e0 = lo; e0 < hi; e0 += UVOL_BLOCK) {
     const uint32_t e = e0 + threadIdx.x;
     if (e < hi) {

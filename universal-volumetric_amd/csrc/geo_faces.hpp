@@ -41,9 +41,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_coherence(GeoJob *jobs) {
   GeoJob &J = jobs[blockIdx.y];
   const bool on = J.status == 0;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
-  uint32_t share = 0, tight = 0, same = 0;
+  uint32_t share = 0, tight = 0, same = 0, degen = 0;
   if (on && f < J.nf_in) {
     const uint32_t a0 = J.ipos[3 * f], a1 = J.ipos[3 * f + 1], a2 = J.ipos[3 * f + 2];
+    degen = (a0 == a1 || a1 == a2 || a0 == a2) ? 1u : 0u;       // (a dropped face, as long as no two positions are equal: k_relabel_decide)
     if (f > 0 && J.relabel == 2) {
       const uint32_t b0 = J.ipos[3 * f - 3], b1 = J.ipos[3 * f - 2], b2 = J.ipos[3 * f - 1];
       share = (a0 == b0 || a0 == b1 || a0 == b2 || a1 == b0 || a1 == b1 || a1 == b2 || a2 == b0 || a2 == b1 || a2 == b2) ? 1u : 0u;
@@ -54,8 +55,8 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_coherence(GeoJob *jobs) {
     // lock step, which decides how many walkers share a wave (geo_encode_batch)
     if (blockIdx.y > 0) { const GeoJob &P = jobs[blockIdx.y - 1]; if (P.nf_in == J.nf_in && P.n_pos == J.n_pos) same = (P.ipos[3 * f] == a0 && P.ipos[3 * f + 1] == a1 && P.ipos[3 * f + 2] == a2) ? 1u : 0u; }
   }
-  const uint32_t s1 = block_sum(share), s2 = block_sum(tight), s3 = block_sum(same);
-  if (threadIdx.x == 0 && on) { if (s1) atomicAdd(&J.coh_share, s1); if (s2) atomicAdd(&J.coh_tight, s2); if (s3) atomicAdd(&J.coh_same, s3); }
+  const uint32_t s1 = block_sum(share), s2 = block_sum(tight), s3 = block_sum(same), s4 = block_sum(degen);
+  if (threadIdx.x == 0 && on) { if (s1) atomicAdd(&J.coh_share, s1); if (s2) atomicAdd(&J.coh_tight, s2); if (s3) atomicAdd(&J.coh_same, s3); if (s4) atomicAdd(&J.n_degen, s4); }
 }
 // per frame: relabel or not; per batch (counts[0..1]): frames that are relabelled, frames with their predecessor's connectivity
 __global__ void __launch_bounds__(64) k_relabel_decide(GeoJob *jobs, int n, uint32_t *counts) {
@@ -69,6 +70,8 @@ __global__ void __launch_bounds__(64) k_relabel_decide(GeoJob *jobs, int n, uint
   J.ms_nb[1] = ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1; J.ms_nblk[1] = (J.nf_in + MS_TILE - 1) / MS_TILE;
   if (J.relabel) atomicAdd(&counts[0], 1u);
   if (J.coh_same == J.nf_in) atomicAdd(&counts[1], 1u);
+  // frames the compact layout cannot hold: relabelled ones, and ones whose stored value ids are not the caller's index arrays
+  if (J.status == 0 && (J.relabel || J.n_degen || J.n_dup[0] || (J.has_uv && J.n_dup[1]) || (J.has_nrm && J.n_dup[2]))) atomicAdd(&counts[2], 1u);
 }
 __device__ __forceinline__ uint32_t ms_count_of(const GeoJob &J, int which) { return which == 0 ? J.n_pos : J.nf_in; }
 __global__ void __launch_bounds__(UVOL_BLOCK) k_ms_count(GeoJob *jobs, int which) {
@@ -214,25 +217,36 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_faces(GeoJob *jobs) {
   if (threadIdx.x == 0 && blockIdx.x < uvol_blocks_dev(J.nf_in)) J.bsum[blockIdx.x] = tot;
   if (bad) J.status = -2;                                                // after the barriers: a wave that has not started yet leaves at once when it sees it
 }
-__global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs) {
+// The stored corner table's value ids.  When no face is dropped and an attribute has no two equal values - a clean export, the usual
+// case - the canonical ids of that attribute ARE the caller's index array: the job's pointer is turned to it (one thread) and the
+// 2.4 MB copy per attribute and 200 k-face frame is neither written nor read back from its own address (UVOL_FACE_ALIAS=0, tests:
+// always copy).  Nothing downstream writes cp / cu / cn.
+__global__ void __launch_bounds__(UVOL_BLOCK) k_compact_faces(GeoJob *jobs, int alias_ok) {
   GeoJob &J = jobs[blockIdx.y];
   if (J.relabel) return;                                   // block-uniform: k_face_cidx + k_relabel_faces store the faces instead
   uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   bool live = J.status == 0 && f < J.nf_in;
+  const bool all_kept = alias_ok && J.status == 0 && J.bsum[uvol_blocks_dev(J.nf_in)] == J.nf_in;      // (uniform: written by k_scan_sums)
+  const bool al0 = all_kept && !J.n_dup[0], al1 = all_kept && J.has_uv && !J.n_dup[1], al2 = all_kept && J.has_nrm && !J.n_dup[2];
   uint32_t v = live ? J.keep[f] : 0, tot;
   uint32_t pos = block_excl_scan(v, &tot) + (blockIdx.x <= uvol_blocks_dev(J.nf_in) ? J.bsum[blockIdx.x] : 0);
-  if (live && v) {                                        // one 12-byte store per array and face instead of three dword stores
+  if (live && v && !J.compact) {                          // one 12-byte store per array and face instead of three dword stores
     uvol_s3 a, b, c;
-    a.x = (int32_t)J.canon[0][J.ipos[3 * f]]; a.y = (int32_t)J.canon[0][J.ipos[3 * f + 1]]; a.z = (int32_t)J.canon[0][J.ipos[3 * f + 2]];
     b.x = b.y = b.z = 0; c.x = c.y = c.z = 0;
-    if (J.has_uv) { b.x = (int32_t)J.canon[1][J.iuv[3 * f]]; b.y = (int32_t)J.canon[1][J.iuv[3 * f + 1]]; b.z = (int32_t)J.canon[1][J.iuv[3 * f + 2]]; }
-    if (J.has_nrm) { c.x = (int32_t)J.canon[2][J.inrm[3 * f]]; c.y = (int32_t)J.canon[2][J.inrm[3 * f + 1]]; c.z = (int32_t)J.canon[2][J.inrm[3 * f + 2]]; }
-    *reinterpret_cast<uvol_s3 *>(J.cp + 3 * (size_t)pos) = a; *reinterpret_cast<uvol_s3 *>(J.cu + 3 * (size_t)pos) = b; *reinterpret_cast<uvol_s3 *>(J.cn + 3 * (size_t)pos) = c;
+    if (!al0) { a.x = (int32_t)J.canon[0][J.ipos[3 * f]]; a.y = (int32_t)J.canon[0][J.ipos[3 * f + 1]]; a.z = (int32_t)J.canon[0][J.ipos[3 * f + 2]]; *reinterpret_cast<uvol_s3 *>(J.cp + 3 * (size_t)pos) = a; }
+    if (J.has_uv && !al1) { b.x = (int32_t)J.canon[1][J.iuv[3 * f]]; b.y = (int32_t)J.canon[1][J.iuv[3 * f + 1]]; b.z = (int32_t)J.canon[1][J.iuv[3 * f + 2]]; }
+    if (J.has_nrm && !al2) { c.x = (int32_t)J.canon[2][J.inrm[3 * f]]; c.y = (int32_t)J.canon[2][J.inrm[3 * f + 1]]; c.z = (int32_t)J.canon[2][J.inrm[3 * f + 2]]; }
+    if (!al1) *reinterpret_cast<uvol_s3 *>(J.cu + 3 * (size_t)pos) = b;
+    if (!al2) *reinterpret_cast<uvol_s3 *>(J.cn + 3 * (size_t)pos) = c;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && J.status == 0) {
     uint32_t nf = J.bsum[uvol_blocks_dev(J.nf_in)];
     J.nf = nf; J.nc = 3 * nf;
     if (nf == 0) J.status = -3;
+    if (J.compact && !(al0 && (al1 || !J.has_uv) && (al2 || !J.has_nrm))) J.status = -23;      // (cannot happen: the host lays such a group out again)
+    if (al0) J.cp = reinterpret_cast<int32_t *>(const_cast<uint32_t *>(J.ipos));
+    if (al1) J.cu = reinterpret_cast<int32_t *>(const_cast<uint32_t *>(J.iuv));
+    if (al2) J.cn = reinterpret_cast<int32_t *>(const_cast<uint32_t *>(J.inrm));
   }
 }
 

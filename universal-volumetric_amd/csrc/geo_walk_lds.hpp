@@ -37,6 +37,9 @@ __device__ __forceinline__ void pack_face_records(int32_t *rec, uint32_t f, cons
     dst[3] = make_int4(0, 0, 0, 0);
   }
 }
+// per-face records carry one more record at index nf: the DUMMY face (both visited flags set, no neighbours) that k_traverse_wave_f16
+// stands on while it pops, and that "no neighbour" clamps to
+__device__ __forceinline__ void pack_dummy_record(int32_t *rec, uint32_t nf, int r8) { if (r8 == 2) reinterpret_cast<uint4 *>(rec)[nf] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu); }
 // decode path (geom_decode.hip prepares vert / vopen_d itself): which: 1 new base, 2/3 attribute tables (DFS)
 __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int which, int r8) {
   JOB_OR_RETURN;
@@ -44,6 +47,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_faces(GeoJob *jobs, int whi
   if (f >= J.nf) return;
   const int ai = which >= 2 ? which - 2 : 0;
   if (which >= 2 && (ai >= J.nad || !J.interior_seams[ai])) return;
+  if (f == 0) pack_dummy_record(J.rec[which], J.nf, r8);
   const int32_t *opp = which == 0 ? J.opp : J.nopp;
   const uint8_t *seam = which >= 2 ? J.seam[ai] : nullptr;
   const int32_t *vert = which == 0 ? J.vert : (which == 1 ? J.bvert : J.avert[ai]);
@@ -68,10 +72,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack0(GeoJob *jobs, int r8) {
   for (int k = 0; k < 3; k++) {
     const int c = 3 * (int)f + k;
     r[k] = J.opp[c];
-    const uint32_t v = (uint32_t)J.vert[c];
+    const uint32_t v = (uint32_t)geo_vt(J)[c];
     vc[k] = (int)((v << 1) | ((v < J.ecap && J.vopen_d[0][v]) ? 1u : 0u));
   }
   pack_face_records(J.rec[0], f, vc, r, r8);
+  if (f == 0) pack_dummy_record(J.rec[0], J.nf, r8);
   J.face_time[f] = -1;                            // faces that start a component without a symbol keep -1 (see k_face_time)
 }
 // encoder, tables first .. 3 (table = first + blockIdx.z), in the STORED face order like table 0: the attribute tables that have interior
@@ -83,9 +88,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pack_tabs(GeoJob *jobs, int r8, 
   const int which = first + (int)blockIdx.z;
   const uint32_t f = blockIdx.x * UVOL_BLOCK + threadIdx.x;
   if (f >= J.nf || !dense_table_live(J, which)) return;
+  if (f == 0) pack_dummy_record(J.rec[which], J.nf, r8);
   const int ai = which >= 2 ? which - 2 : -1;
   const uint32_t nbase = J.nverts_t[0], fs = ai >= 0 ? (uint32_t)J.fseam[f] >> (3 * ai) : 0u;
-  const uvol_s3 o3 = *reinterpret_cast<const uvol_s3 *>(J.opp + 3 * (size_t)f), v3 = *reinterpret_cast<const uvol_s3 *>(J.vert + 3 * (size_t)f);
+  const uvol_s3 o3 = *reinterpret_cast<const uvol_s3 *>(J.opp + 3 * (size_t)f), v3 = *reinterpret_cast<const uvol_s3 *>(geo_vt(J) + 3 * (size_t)f);
   const int oo[3] = { o3.x, o3.y, o3.z }, vv[3] = { v3.x, v3.y, v3.z };
   int r[3], vc[3];
   for (int k = 0; k < 3; k++) {

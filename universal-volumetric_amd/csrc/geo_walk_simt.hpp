@@ -301,7 +301,7 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
     const uint32_t sym = ccase ? 0u : 1u + 2u * lvis + 4u * rvis;           // C 0, S 1, L 3, R 5, E 7
     symb[nproc] = (uint8_t)sym;
     nproc++;
-    if (sym == 1u) { stack[sp - 1] = lcn; stack[sp] = rcn; sp++; nsplit++; }   // S: the left neighbour waits on the stack, the walk goes right
+    if (sym == 1u) { stack[sp - 1] = lcn; stack[sp] = rcn; sp++; nsplit++; if (sp > (int)J.stcap) { J.status = GEO_E_WS_OVERFLOW; break; } }   // S: the left neighbour waits on the stack, the walk goes right
     if (sym == 7u) { sp--; x = -1; }
     else {
       const bool go_l = sym == 5u;
@@ -310,6 +310,7 @@ __device__ inline void eb_walk_simt_f16(GeoJob &J) {
       f16_dec(q, x & 3, vi, rcn, lcn);
     }
   }
+  if (J.status != 0) return;
   J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
   if (nproc + ninit != nf) J.status = -10;
   J.rb[0].n = (uint32_t)nstart;
@@ -391,7 +392,7 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
     const uint32_t rvis = (rc < 0 || f16_seen<FD>(qr)) ? 1u : 0u, lvis = (lc < 0 || f16_seen<FD>(ql)) ? 1u : 0u;
     const bool ccase = ((vvis | (uint32_t)vi) & 1u) == 0;
     const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
-    if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; }
+    if (k == 1u) { stack[sp - 1] = lc; stack[sp] = rc; sp++; if (J.stcap && sp > (int)J.stcap) { J.status = GEO_E_WS_OVERFLOW; break; } }      // (stcap 0: decode path, a slot per face)
     if (k == 4u) { sp--; x = -1; }
     else {
       const bool go_l = k == 2u;
@@ -400,6 +401,7 @@ __device__ inline void traverse_simt_f16(GeoJob &J, int t) {
       f16_dec(q, x & 3, vi, rc, lc);
     }
   }
+  if (J.status != 0) return;
   J.ne[t] = (uint32_t)n;
   if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
 }
@@ -414,4 +416,125 @@ __global__ void __launch_bounds__(64) k_traverse_simt_f16(GeoJob *jobs, int n, i
   const int ai = t > 0 ? t - 1 : 0;
   if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;
   if (t == 0 && J.base_hi) traverse_simt_f16<3>(J, t); else traverse_simt_f16<1>(J, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave form of the lane-per-walker traverser on per-face records (round 5).  W walkers share a wave (lanes 0 .. W - 1) and ALL 64 lanes
+// stay in the loop, because what kept several walkers from sharing a wave was not the common step but the rare ones (round 4: 293 / 372 /
+// 471 ms per 2560 frames with 1 / 2 / 4 walkers per wave): every lane waited while ONE lane popped its stack (two dependent round trips)
+// or searched the next component (a round trip per eight faces) - and a one-lane wave still holds its SIMD's vector pipe for four cycles
+// per instruction, so 3840 one-walker waves took half of the chip's vector issue slots away from the kernels running beside them.  Here
+//  * a POP is an ordinary step: the walker stands on a dummy face (index nf: visited, no neighbours) whose right neighbour is the top of
+//    the pending stack and whose tip is a dummy vertex that counts as visited.  The step then says "go right" (the candidate is unvisited:
+//    the walk continues there) or "dead end" (it was visited meanwhile: the next pending corner is tried) - the same instructions as a real
+//    step, no branch.  The top of the stack is carried in a register and its successor is fetched with the step's other loads.
+//  * "no neighbour" is the dummy face as well (min(code >> 2, nf) instead of a compare and a select per side); the vertex order entry and
+//    the pending corner are stored unconditionally at their cursors and only the cursors are predicated.
+//  * the search for the next component is done by the WHOLE wave for one walker at a time: 64 faces per round trip (one per lane, first
+//    hit by a ballot) instead of eight, through the walker's pointers broadcast with v_readlane.
+// Same order[] as every other form.  Pending stack here = the left neighbours of the forks only (the other forms also keep the current
+// path's placeholder on it).
+// ------------------------------------------------------------------------------------------------
+#ifdef HIPEMU
+#define UVOL_BCAST64(v, l) ((uint64_t)UVOL_READLANE((uint32_t)(v), l) | ((uint64_t)UVOL_READLANE((uint32_t)((uint64_t)(v) >> 32), l) << 32))
+#else
+#define UVOL_BCAST64(v, l) ((uint64_t)UVOL_READLANE((uint32_t)(v), l) | ((uint64_t)UVOL_READLANE((uint32_t)((uint64_t)(v) >> 32), l) << 32))
+#endif
+template <int FD>
+__device__ __forceinline__ void traverse_wave_f16(GeoJob *jobs, int n, int W, int t) {
+  const int lane = (int)threadIdx.x;
+  const int j = (int)blockIdx.x * W + lane;
+  const int ai = t > 0 ? t - 1 : 0;
+  bool live = lane < W && j < n;
+  if (live) { const GeoJob &J0 = jobs[j]; live = J0.status == 0 && !(t > 0 && (ai >= J0.nad || !J0.interior_seams[ai])); }
+  GeoJob &J = jobs[live ? j : 0];
+  const int nf = live ? (int)J.nf : 0;
+  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
+  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
+  UVOL_G(int32_t) pend_s = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
+  UVOL_G(const int32_t) tstart = UVOL_TO_G(const int32_t, J.tstart);
+  const uint32_t stcap = live ? (J.stcap ? J.stcap : 0x7fffffffu) : 0u;      // (0: the decode path, whose stacks hold a corner per face)
+  const uint32_t vdum = live ? J.nverts_t[1 + t] : 0u;     // dummy vertex: the bit past every id of the table (the bitmaps have 512 bits of slack)
+  if (live) vbits[vdum >> 5] = vbits[vdum >> 5] | (1u << (vdum & 31));
+  int n_ord = 0, nvis = 0, f = 0, pend = 0, top = 0, x = -1, vi = 0, rc = -1, lc = -1;
+  bool done = !live;
+  uvol_u4 q; q.x = q.z = 0; q.y = q.w = 0x80000000u;
+  for (;;) {
+    // ---- walkers without a face to stand on and nothing pending: the next component, searched by the whole wave, one walker at a time ----
+    unsigned long long need = __ballot(!done && x < 0 && pend == 0);
+    while (need) {
+      const int l = (int)__ffsll((long long)need) - 1; need &= need - 1;
+      const uint64_t rec_u = UVOL_BCAST64((uint64_t)(uintptr_t)rec, l), ts_u = UVOL_BCAST64((uint64_t)(uintptr_t)tstart, l);
+      const int nf_u = (int)UVOL_READLANE(nf, l), nvis_u = (int)UVOL_READLANE(nvis, l);
+      int f_u = (int)UVOL_READLANE(f, l), x0 = -1;
+      UVOL_G(uint32_t) rec_l = (UVOL_G(uint32_t))(uintptr_t)rec_u; UVOL_G(const int32_t) ts_l = (UVOL_G(const int32_t))(uintptr_t)ts_u;
+      if (nvis_u < nf_u) {
+        while (f_u < nf_u) {
+          const int fk = f_u + lane;
+          int xs = -1; uint32_t y = 0x80000000u;
+          if (fk < nf_u) { xs = ts_u ? ts_l[fk] : 4 * fk; y = rec_l[4 * (size_t)(xs >> 2) + FD]; }
+          const unsigned long long m = __ballot((y >> 31) == 0);
+          if (m) { const int k0 = (int)__ffsll((long long)m) - 1; x0 = (int)UVOL_READLANE(xs, k0); f_u += k0 + 1; break; }
+          f_u += 64;
+        }
+      }
+      if (lane == l) {
+        f = f_u;
+        if (x0 < 0) done = true;
+        else {                                            // the component starts at the decoder's corner 0 of that face; its two other vertices come first
+          const uvol_u4 q0 = f16_load(rec, x0 >> 2);
+          const int xn = code_nxt(x0), xp = code_prv(x0);
+          int vn, vp, r_, l_; f16_dec(q0, xn & 3, vn, r_, l_); f16_dec(q0, xp & 3, vp, r_, l_); vn >>= 1; vp >>= 1;
+          uint32_t w = vbits[vn >> 5];
+          if (!((w >> (vn & 31)) & 1u)) { vbits[vn >> 5] = w | (1u << (vn & 31)); order[n_ord] = corner_of_code(xn); n_ord++; }
+          w = vbits[vp >> 5];
+          if (!((w >> (vp & 31)) & 1u)) { vbits[vp >> 5] = w | (1u << (vp & 31)); order[n_ord] = corner_of_code(xp); n_ord++; }
+          x = x0; q = q0; f16_dec(q, x & 3, vi, rc, lc);
+        }
+      }
+    }
+    if (!__ballot(!done)) break;
+    if (!done) {
+      // ---- one step: on face x, or (x < 0) on the dummy face with the top of the pending stack to its right ----
+      const bool run = x >= 0;
+      const int fc = run ? x >> 2 : nf;
+      const int rcc = run ? rc : top, lcc = run ? lc : -1;
+      const uint32_t vic = run ? (uint32_t)vi : ((vdum << 1) | 1u);
+      const uint32_t unf = (uint32_t)nf;
+      const uint32_t rf = ((uint32_t)rcc >> 2) < unf ? ((uint32_t)rcc >> 2) : unf, lf = ((uint32_t)lcc >> 2) < unf ? ((uint32_t)lcc >> 2) : unf;
+      f16_mark<FD>(rec, fc, q);
+      const uvol_u4 qr = f16_load(rec, (int)rf), ql = f16_load(rec, (int)lf);
+      const uint32_t v = vic >> 1;
+      const uint32_t vw = vbits[v >> 5];
+      const int top2 = pend_s[pend >= 2 ? pend - 2 : 0];                    // the pending corner below the top (a pop needs it next)
+      vbits[v >> 5] = vw | (1u << (v & 31));
+      const uint32_t vvis = (vw >> (v & 31)) & 1u;
+      order[n_ord] = 3 * fc + (x & 3);                                        // a vertex seen for the first time takes the next place
+      n_ord += (int)(vvis ^ 1u);
+      nvis += run ? 1 : 0;
+      const uint32_t rvis = f16_seen<FD>(qr) ? 1u : 0u, lvis = f16_seen<FD>(ql) ? 1u : 0u;
+      const bool ccase = ((vvis | vic) & 1u) == 0;
+      const uint32_t k = ccase ? 0u : 1u + rvis + 2u * lvis;                  // 0 / 3: right; 2: left; 1: fork (right, left waits); 4: dead end
+      pend_s[pend] = lcc;                                                     // (kept only by a fork)
+      const bool fork = k == 1u;
+      if (!run) { pend--; top = top2; }                                       // the candidate is used up either way
+      if (fork) { pend++; top = lcc; if (pend > (int)stcap) { J.status = GEO_E_WS_OVERFLOW; done = true; } }
+      if (k == 4u) { x = -1; q.x = q.z = 0; q.y = q.w = 0x80000000u; }
+      else {
+        const bool go_l = k == 2u;
+        x = go_l ? lcc : rcc;
+        q.x = go_l ? ql.x : qr.x; q.y = go_l ? ql.y : qr.y; q.z = go_l ? ql.z : qr.z; q.w = go_l ? ql.w : qr.w;
+        f16_dec(q, x & 3, vi, rc, lc);
+      }
+    }
+  }
+  if (live && J.status == 0) {
+    J.ne[t] = (uint32_t)n_ord;
+    if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n_ord != J.nverts) J.status = -11;      // (the decode path has no expected count)
+  }
+}
+// grid (waves, tables): table t0 + blockIdx.y, walkers blockIdx.x * W .. of that table in lanes 0 .. W - 1
+__global__ void __launch_bounds__(64) k_traverse_wave_f16(GeoJob *jobs, int n, int W, int t0, int base_hi) {
+  const int t = t0 + (int)blockIdx.y;
+  if (t == 0 && base_hi) traverse_wave_f16<3>(jobs, n, W, t); else traverse_wave_f16<1>(jobs, n, W, t);
 }

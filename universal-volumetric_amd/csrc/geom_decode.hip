@@ -935,7 +935,9 @@ __global__ void __launch_bounds__(64) k_gdec_flips(GeoDecJob *jobs, GeoJob *gj) 
 __global__ void __launch_bounds__(64) k_gdec_counts_early(GeoDecJob *jobs, int phase) {
   GeoDecJob &J = jobs[blockIdx.x];
   if (threadIdx.x != 0 || J.status != 0) return;
-  if (J.method == 0) { if (phase == 0) for (int d = 0; d < J.ndec; d++) J.rs[6 + d].early = 1; return; }      // sequential connectivity: one entry per point, known from the header
+  // sequential connectivity: one entry per point, known from the header; the compressed index differences (connectivity method 0) sit in the
+  // LAST slot, which no attribute decoder uses then (ndec <= GD_MAXDEC - 1) - it has to be marked too or no pass decodes it
+  if (J.method == 0) { if (phase == 0) { for (int d = 0; d < J.ndec; d++) J.rs[6 + d].early = 1; J.rs[GD_NRS - 1].early = 1; } return; }
   for (int d = 0; d < J.ndec; d++) {
     const int t = J.att[d].table;
     if ((t == 0) != (phase == 0)) continue;
@@ -949,7 +951,7 @@ __global__ void __launch_bounds__(64) k_gdec_counts(GeoDecJob *jobs, GeoJob *gj)
   if (threadIdx.x != 0) return;
   if (G.status != 0 && J.status == 0) J.status = G.status;
   if (J.status != 0) return;
-  if (J.method == 0) { G.ne[0] = (uint32_t)J.nv; for (int d = 0; d < J.ndec; d++) J.rs[6 + d].redo = J.rs[6 + d].early ? 0u : 1u; return; }      // sequential: one entry per point, the value counts were known at once
+  if (J.method == 0) { G.ne[0] = (uint32_t)J.nv; for (int d = 0; d < J.ndec; d++) J.rs[6 + d].redo = J.rs[6 + d].early ? 0u : 1u; J.rs[GD_NRS - 1].redo = J.rs[GD_NRS - 1].early ? 0u : 1u; return; }      // sequential: one entry per point, the value counts were known at once
   for (int d = 0; d < J.ndec; d++) {
     GDRans &S = J.rs[6 + d];
     const uint32_t nv = G.ne[J.att[d].table] * (uint32_t)J.att[d].nc;

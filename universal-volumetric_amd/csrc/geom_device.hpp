@@ -63,6 +63,8 @@ struct GeoJob {
   // locality relabelling (k_ms_*): positions get new ids in Morton order of their quantised coordinates, faces are stored in the
   // order of their lowest new vertex id.  Ids and storage order are identities only - the bitstream is the one the input order
   // gives (component starts and non-manifold tie-breaks still follow the ORIGINAL face order through forig / s_of_o).
+  int32_t compact;                         // 1: laid out without stored value-id copies and relabelling scratch (clean, coherently stored frames only: geo_submit_impl)
+  uint32_t n_degen;                        // faces with two equal position indices (k_coherence; meaningful while no two positions are equal)
   int32_t relabel;                         // 1: on for this frame (2 while undecided: k_coherence / k_relabel_decide)
   uint32_t coh_share, coh_tight, coh_same; // k_coherence: faces sharing a vertex with their predecessor / with a narrow index span / equal to the same face of the previous frame
   uint32_t *ms_key[2];                     // [0] Morton key per position; [1] per input face: lowest new vertex id (~0u: dropped face)
@@ -84,13 +86,15 @@ struct GeoJob {
   uint8_t *keep; uint32_t *bsum, *bsum2;      // scan scratch (max(nf_in, nc)/256 + 1)
   int32_t *cp, *cu, *cn;              // compacted per-corner canonical value ids (old order)
   int32_t *opp, *vert;                // vert: vertex id per corner of the old-order table (position id, or n_pos + k for further fans of a non-manifold position)
+  uint32_t *nmbits;                   // per position: several fans meet there (non-manifold): its corners' vertex ids are in vert[], all others' are cp[] (geo_vt)
   uint32_t extra_v, nseg[2]; uint32_t *vseam[2];   // ids handed out beyond n_pos; attribute segments; per-vertex 'an interior seam of attribute i touches it'
   uint8_t *vvis; int32_t *vval, *c2vm, *proc, *initc, *stack;      // vvis: vertex-visited bitmap of the edgebreaker walk when it is not in LDS
   uint8_t *evcnt;                      // topology-split events per symbol (auxiliary stream)
   int32_t *ev_src, *ev_spl; uint8_t *ev_edge;
   int32_t *rec[4]; uint8_t *symb, *ctx_of; int32_t *face_time;
   uint8_t *vopen_d[4]; int32_t *ring_d; uint32_t nverts_t[4];   // per vertex id: on a boundary, ring size; size of the id space per table (encoder: only vopen_d[0])
-  uint32_t *ctx_sym[6]; uint32_t ctx_n[6];
+  uint32_t *ctx_all; uint32_t *ctx_sym[6]; uint32_t ctx_n[6];      // the six context streams back to back in ONE nf-entry array (k_eb_ctx counts, then scatters)
+  uint32_t evcap, stcap;              // capacities of the split-event arrays / of the walkers' pending stacks (GEO_E_WS_OVERFLOW past them: retried with worst-case sizes)
   uint8_t *start_bits;
   // Decoder order stays VIRTUAL on the encode side (round 5): every table keeps the stored face order and the decoder's face
   // numbering appears only as tstart[] (decoder-order face -> code of its first corner in the stored tables), which the traversals'

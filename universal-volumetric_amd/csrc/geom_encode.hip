@@ -76,6 +76,7 @@ struct GeoState {
   WsPlanCache plan; std::vector<WsItem> items;     // workspace placements by frame shape
   size_t max_lds = 64 * 1024;
   int num_cu = 256;                    // CUs this context's streams may run on
+  bool compact_ok = true;              // the last group was all clean, coherently stored frames: the next one starts in the compact layout (geo_submit_impl)
 };
 static void geo_lane_free(GeoLane *L) {
   if (L->aux) { (void)hipStreamSynchronize(L->aux); (void)hipStreamDestroy(L->aux); }
@@ -178,7 +179,7 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
     else { CARVE(J.dd_part[k], uint4, (size_t)n + 1, PH_DEDUP, PH_DEDUP); CARVE(J.dd_cnt[k], uint32_t, (size_t)J.dd_nb[k] * J.dd_nblk[k] + 2, PH_DEDUP, PH_DEDUP); }
   }
   // locality relabelling (k_ms_*): keys, {key, index} records, counts matrices; new position ids / positions in that order; face maps
-  if (J.relabel) {
+  if (J.relabel && !J.compact) {
     const size_t nmax = std::max<size_t>(J.n_pos, nfi);
     auto bits_of = [&](uint64_t v) { uint32_t b = 0; while (v) { b++; v >>= 1; } return b; };
     // bins of the first level: ~512 keys each, at most MS_MAXBINS (30-bit Morton keys / ids below n_pos: bin = the key's top bits)
@@ -203,6 +204,7 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
   // ---- pinned, zero-initialised ----
   CARVE(J.he_start, uint32_t, (size_t)J.n_pos + 1, PH_PINNED, PH_PINNED);
   CARVE(J.vvis, uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
+  CARVE(J.nmbits, uint32_t, (size_t)J.n_pos / 32 + 2, PH_PINNED, PH_PINNED);
   for (int i = 0; i < 2; i++) CARVE(J.vseam[i], uint32_t, ecap / 32 + 2, PH_PINNED, PH_PINNED);      // one bit per vertex: the whole map stays in L2
   for (int t = 0; t < 3; t++) CARVE(J.t_vvis[t], uint8_t, ecap / 8 + 64, PH_PINNED, PH_PINNED);
   for (int s = 0; s < GEO_NSTREAM; s++) {
@@ -217,7 +219,8 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
     CARVE(J.canon[0], uint32_t, J.n_pos + 1, PH_DEDUP, cl); CARVE(J.canon[1], uint32_t, J.n_uv + 1, PH_DEDUP, cl); CARVE(J.canon[2], uint32_t, J.n_nrm + 1, PH_DEDUP, cl); }
   CARVE(J.keep, uint8_t, nfi + 1, PH_FACES, PH_FACES);
   // the stored corner table (canonical value ids, opposite corners, vertex ids) lives until the predictors: nothing is renumbered
-  CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_PRED); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_PRED); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_PRED);
+  // (the compact layout has no copies: every frame's ids are its caller's index arrays, or the group is laid out again - geo_submit_impl)
+  if (!J.compact) { CARVE(J.cp, int32_t, nc + 3, PH_FACES, PH_PRED); CARVE(J.cu, int32_t, nc + 3, PH_FACES, PH_PRED); CARVE(J.cn, int32_t, nc + 3, PH_FACES, PH_PRED); }
   CARVE(J.he_cur, uint32_t, (size_t)J.n_pos + 1, PH_CT, PH_FANS0); CARVE(J.he_ent, unsigned long long, nc + 1, PH_CT, PH_FANS0);      // k_vert0 walks the buckets
   { // partitioned bucket build (compact layout, ranges of <= HE_MAXVPB vertices): records + counts matrix, live in PH_CT only
     uint32_t vpb = 512; while ((uint64_t)vpb * HE_MAXBINS < (uint64_t)J.n_pos) vpb *= 2;
@@ -234,18 +237,22 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
   // With one record per face in both the walk and the traversals (formats 2 / 2) the base table of the traversals IS the walk's table
   // (J.base_hi, rec[1] = rec[0]: set after the placement); otherwise table 1 is a copy in the traversals' format (k_pack_tabs).
   const bool base_shared = fmt0 == 2 && fmtT == 2;
+  // pending corners of the walkers on per-face records: forks that still wait for their left side - tens on a regular mesh; worst case one per face
+  J.stcap = (uint32_t)(full ? nfi + 2 : nfi / 8 + 1024);
   CARVE(J.rec[0], uint8_t, rec_size(fmt0), PH_DENSE0, base_shared ? PH_V2D : PH_WALK); CARVE(J.vopen_d[0], uint8_t, ecap, PH_FANS0, PH_DENSE1);
   for (int w = base_shared ? 2 : 1; w < 4; w++) CARVE(J.rec[w], uint8_t, rec_bytes, PH_DENSE1, PH_V2D);
   CARVE(J.ring_d, int32_t, ecap, PH_FANS0, PH_SEAMS);
   CARVE(J.face_time, int32_t, nfi + 1, PH_DENSE0, std::max<int>(aux_last, PH_SEAMS));
   CARVE(J.proc, int32_t, nfi + 1, PH_WALK, aux_last); CARVE(J.symb, uint8_t, nfi + 64, PH_WALK, aux_last);
   CARVE(J.tstart, int32_t, nfi + 1, PH_FTIME, PH_TRAV);
-  CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_FTIME); CARVE(J.stack, int32_t, nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
+  CARVE(J.initc, int32_t, nfi + 1, PH_WALK, PH_FTIME); CARVE(J.stack, int32_t, fmt0 == 2 ? J.stcap + 2 : nfi + 2, PH_WALK, PH_WALK); CARVE(J.start_bits, uint8_t, nfi + 1, PH_WALK, PH_ENT);
   // auxiliary stream (forked after PH_FTIME, joined before PH_HIST)
   CARVE(J.evcnt, uint8_t, nfi + 1, PH_RENUM, PH_SEAMS);
-  CARVE(J.ev_src, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_spl, int32_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT); CARVE(J.ev_edge, uint8_t, 2 * nfi + 2, PH_RENUM, PH_LAYOUT);
+  // topology-split events: two per S symbol, a handful per mesh; worst case (retries) two per face
+  J.evcap = (uint32_t)(full ? 2 * nfi + 2 : nfi / 8 + 256);
+  CARVE(J.ev_src, int32_t, J.evcap, PH_RENUM, PH_LAYOUT); CARVE(J.ev_spl, int32_t, J.evcap, PH_RENUM, PH_LAYOUT); CARVE(J.ev_edge, uint8_t, J.evcap, PH_RENUM, PH_LAYOUT);
   CARVE(J.vval, int32_t, ecap + nfi + 3, PH_RENUM, aux_last); CARVE(J.c2vm, int32_t, nc + 3, PH_RENUM, aux_last); CARVE(J.ctx_of, uint8_t, nfi + 64, PH_RENUM, aux_last);
-  for (int i = 0; i < 6; i++) CARVE(J.ctx_sym[i], uint32_t, nfi + 1, PH_RENUM, PH_ENT);
+  CARVE(J.ctx_all, uint32_t, nfi + 8, PH_RENUM, PH_ENT);
   // ---- seams (on the stored tables: the decoder's order is virtual, GeoJob::tstart) ----
   CARVE(J.fseam, uint8_t, nfi + 1, PH_RENUM, PH_PRED); CARVE(J.sbpack, uint8_t, nfi + 1, PH_RENUM, PH_SEAMS);
   for (int i = 0; i < 2; i++) {
@@ -253,7 +260,7 @@ void ws_collect(GeoJob &J, bool full, int fmt0, int fmtT, std::vector<WsItem> &i
     CARVE(J.avert[i], int32_t, nc + 3, PH_SEAMS, PH_PRED);          // (address space only: written for the corners of seam-touched vertices)
   }
   // ---- K5, K1, K6 ----
-  for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, ecap, PH_TRAV, PH_PRED); CARVE(J.v2d[t], int32_t, ecap, PH_V2D, PH_PRED); CARVE(J.t_stack[t], int32_t, nfi + 2, PH_TRAV, PH_TRAV); }
+  for (int t = 0; t < 3; t++) { CARVE(J.order[t], int32_t, ecap + 4, PH_TRAV, PH_PRED); CARVE(J.v2d[t], int32_t, ecap, PH_V2D, PH_PRED); CARVE(J.t_stack[t], int32_t, fmtT == 2 ? J.stcap + 2 : nfi + 2, PH_TRAV, PH_TRAV); }
   if (J.seq) { CARVE(J.P, int32_t, 3 * ecap, PH_QUANT, PH_PRED); CARVE(J.U, int32_t, 2 * ecap, PH_QUANT, PH_PRED); CARVE(J.O, int32_t, 2 * ecap, PH_QUANT, PH_PRED); }
   else {                                                  // quantised values by value id (k_quant_ids), gathered by k_v2d and the predictors
     CARVE(J.qpos, uint16_t, 4 * ((size_t)J.n_pos + 1), PH_FACES, PH_PRED); CARVE(J.quv, uint16_t, 2 * ((size_t)J.n_uv + 1), PH_FACES, PH_PRED); CARVE(J.qnrm, uint16_t, 2 * ((size_t)J.n_nrm + 1), PH_FACES, PH_PRED);
@@ -301,7 +308,7 @@ const WsPlan &layout_job(GeoJob &J, uint8_t *base, bool full, int fmt0, int fmtT
   ws_collect(J, full, fmt0, fmtT, items);
   auto up = [](uint32_t v, uint32_t q) { return (uint64_t)((v + (uint64_t)q - 1) / q) * q; };
   const uint64_t flags = (uint64_t)J.qp | ((uint64_t)J.qt << 8) | ((uint64_t)J.qn << 16) | ((uint64_t)full << 24) | ((uint64_t)(J.relabel != 0) << 26) |
-                         ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28) | ((uint64_t)fmt0 << 29) | ((uint64_t)fmtT << 31);      // everything ws_collect's sizes AND lifetimes depend on
+                         ((uint64_t)(J.seq != 0) << 27) | ((uint64_t)(J.late_join != 0) << 28) | ((uint64_t)fmt0 << 29) | ((uint64_t)fmtT << 31) | ((uint64_t)(J.compact != 0) << 33);      // everything ws_collect's sizes AND lifetimes depend on
   std::vector<uint64_t> key = { up(J.nf_in, 2048), up(J.n_pos, 1024), up(J.n_uv, 1024), up(J.n_nrm, 1024), flags, items.size(), 0 };
   auto it = C.plans.find(key);
   if (it == C.plans.end()) {
@@ -416,11 +423,16 @@ static inline bool geo_rec8(uint32_t max_nfi, uint64_t max_ids) {
 // the decode path sizes its record tables with the same rule; its vertex ids are dense (< 3 * faces)
 bool geo_records8(uint32_t max_nfi) { return geo_rec8(max_nfi, 3ull * max_nfi); }
 static inline bool geo_rec_face_off() { static const bool v = [] { const char *e = getenv("UVOL_REC_FACE"); return e && *e == '0'; }(); return v; }      // UVOL_REC_FACE=0 (diagnostic, tests): corner records in the lane-per-walker kernels too
-static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8) {
+static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &P, int r8, int base_hi = 0) {
   const unsigned N = (unsigned)n;
   if (P.simt_w) {
     const unsigned W = (unsigned)P.simt_w, nb = (3 * N + W - 1) / W;
-    if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W, 0, 3);
+    // UVOL_TRAV_FORM=lane (tests, diagnostic): the lane-per-walker kernel whose idle lanes leave the loop; default: the wave form
+    // (k_traverse_wave_f16: pops as ordinary steps, component search by the whole wave), UVOL_TRAV_W lanes per wave
+    static const bool lane_form = [] { const char *e = getenv("UVOL_TRAV_FORM"); return e && !strcmp(e, "lane"); }();
+    static const int wave_w = [] { const char *e = getenv("UVOL_TRAV_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    if (r8 == 2 && !lane_form) { const unsigned Ww = wave_w ? (unsigned)wave_w : W; LAUNCH(k_traverse_wave_f16, dim3((N + Ww - 1) / Ww, 3), dim3(64), dj, n, (int)Ww, 0, base_hi); }
+    else if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W, 0, 3);
     else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
   }
   else if (r8) LAUNCH_SM((k_traverse<true>), dim3(3, N), dim3(128), P.lds, dj, P.vcw, geo_walk_pf() ? 2 : 0);
@@ -445,7 +457,8 @@ int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint3
 // device workspace one frame of these dimensions holds while it is in flight (compact layout + its share of the packed output area)
 extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   if (!ctx || !m || !m->n_faces) return 0;
-  GeoJob J{}; J.relabel = geo_relabel_mode(); J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
+  GeoJob J{}; J.compact = 1;        // (a clean frame of a large batch: the compact layout; a group with unclean frames holds 36 bytes per face more)
+  J.relabel = geo_relabel_mode(); J.n_pos = m->n_pos; J.nf_in = m->n_faces; J.n_uv = (m->uv && m->idx_uv) ? m->n_uv : 0; J.n_nrm = (m->nrm && m->idx_nrm) ? m->n_nrm : 0;
   J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
   WsPlanCache P; std::vector<WsItem> items;
   const int fmt = geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)) ? 2 : 0;       // what a frame of a large batch holds (lane-per-walker kernels, one record per face)
@@ -527,7 +540,6 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   // overlaps the traversals too; its inputs then cannot share bytes with the record tables (+7.7 MB per frame, irrelevant at that size).
   static const int late_env = [] { const char *e = getenv("UVOL_LATE_JOIN"); return e ? atoi(e) : -1; }();      // tests: 0 / 1 force the early / late join
   const bool late_join = late_env >= 0 ? late_env != 0 : std::max(n, n_conc) <= 1200;      // (n_conc: the frames of the whole call are on the chip together, whatever this group's share)
-  L.hjobs.assign((size_t)n, GeoJob{});
   std::vector<size_t> ws_off(n), in_off(n), zero_sz(n);
   size_t ws_total = 0, in_total = 0, out_total = 0;
   uint32_t max_nfi = 0, max_vals = 0, max_ecap = 0, he_nb_max = 0, ms_nb_max = 1; bool he_part_all = true; uint64_t algo_in = 0;
@@ -548,8 +560,24 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   const bool f16_off = geo_rec_face_off();
   const int fmt0 = (r8 && wp_walk.simt_w && !f16_off) ? 2 : r8, fmtT = (r8 && wp_trav.simt_w && !f16_off) ? 2 : r8;
   const bool base_shared = fmt0 == 2 && fmtT == 2;
+  // COMPACT layout (round 5): a group is laid out without the arrays only an unclean or incoherently stored frame needs - the stored
+  // copies of the canonical value ids (a clean frame's ids ARE the caller's index arrays, k_compact_faces) and the scratch of the
+  // locality relabelling: 7.2 MB of every 200 k-face frame's workspace at its peak, i.e. more frames in flight.  Whether the frames are
+  // clean is known after the dedup (k_coherence / k_relabel_decide count the others, read back with the relabel decision); if one is
+  // not, the group is laid out again in the general form and starts over - the cost of one dedup pass, paid by groups that have such
+  // frames, and the NEXT group starts in the general form at once (GeoState::compact_ok) until a general group turns out all clean.
+  static const bool compact_env = [] { const char *e = getenv("UVOL_COMPACT_IDS"); return !(e && *e == '0'); }();
+  static const int face_alias = [] { const char *e = getenv("UVOL_FACE_ALIAS"); return (e && *e == '0') ? 0 : 1; }();
+  const bool can_probe = (geo_relabel_on() && !seq) || std::max(n, n_conc) >= 256;      // (the mid-batch read-back below happens)
+  bool compact = seq || (compact_env && face_alias && !full && can_probe && G->compact_ok);
+  int rc;
+  bool uploaded = false;
+  auto lay = [&]() -> int {
+  L.hjobs.assign((size_t)n, GeoJob{});
+  ws_total = 0; in_total = 0; out_total = 0; max_ecap = 0; he_nb_max = 0; ms_nb_max = 1; he_part_all = true; algo_in = 0;
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
+    J.compact = compact ? 1 : 0;
     if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0 || m.n_faces > (1u << 26)) { ctx->set_error("mesh %d: empty or invalid", i); return UVOL_E_INVALID; }
     J.n_pos = m.n_pos; J.nf_in = m.n_faces; J.relabel = seq ? 0 : geo_relabel_mode(); J.seq = seq ? 1 : 0; J.late_join = late_join ? 1 : 0;
     J.has_uv = (m.uv && m.idx_uv && m.n_uv) ? 1 : 0; J.has_nrm = (m.nrm && m.idx_nrm && m.n_nrm) ? 1 : 0;
@@ -567,10 +595,9 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     out_total += (oc + 255) & ~(size_t)255; J.out_cap = (uint32_t)std::min<size_t>(caps[i], 0xffffffffu);
     max_vals = std::max(max_vals, std::max(m.n_pos, std::max(J.n_uv, J.n_nrm))); max_ecap = std::max(max_ecap, J.ecap);
     he_nb_max = std::max(he_nb_max, J.he_nb); he_part_all = he_part_all && J.he_vpb != 0;
-    if (J.relabel) ms_nb_max = std::max(ms_nb_max, std::max(J.ms_nb[0], ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1));
+    if (J.relabel && !J.compact) ms_nb_max = std::max(ms_nb_max, std::max(J.ms_nb[0], ((J.n_pos ? J.n_pos - 1 : 0) >> J.ms_sh[1]) + 1));
     algo_in += (uint64_t)m.n_pos * 12 + (uint64_t)J.n_uv * 8 + (uint64_t)J.n_nrm * 12 + (uint64_t)(1 + J.has_uv + J.has_nrm) * m.n_faces * 12;
   }
-  int rc;
   if ((rc = uvol_ensure(ctx, L.slab, ws_total))) {
     // out of device memory: the workspaces idle lanes still hold from earlier (larger) groups are given back, then once more
     (void)hipGetLastError();
@@ -609,8 +636,10 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     J.rb[0].bits = J.start_bits; J.rb[1].bits = J.seam_bits[0]; J.rb[2].bits = J.seam_bits[1]; J.rb[3].bits = J.ori_bits; J.rb[4].bits = J.flips;
     // rabs slot 1/2 follow the attribute-data slot; slot 3 = uv orientations, slot 4 = normal flips
   }
-  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.inputs.p, ups); if (rcu != UVOL_OK) return rcu; }
+  if (!on_device && !uploaded) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.inputs.p, ups); if (rcu != UVOL_OK) return rcu; uploaded = true; }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.jobs.p, L.hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  return UVOL_OK; };
+  if ((rc = lay())) return rc;
   GeoJob *dj = (GeoJob *)L.jobs.p;
   const unsigned N = (unsigned)n, NC = (unsigned)std::max(n, n_conc);      // NC: frames on the chip together (all groups of the call)
   L.t_prep = ms_since(t_enter);
@@ -624,15 +653,16 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   // each group then gets through its bandwidth-bound phases at close to the chip's full rate and the groups stay staggered.
   static const bool fe_chain = [] { const char *e = getenv("UVOL_GEO_CHAIN"); return !(e && *e == '0'); }();
   if (fe_chain && G->fe_last && G->fe_last != L.ev_fe) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->fe_last, 0));
-  LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
-  const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP,
-                 be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
+  const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP;
+  unsigned be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
   const bool relabel = geo_relabel_on() && !seq;
   bool lockstep = true;                                      // walkers of this batch move in lock step (see below); decides lanes per wave of the traversers
+  bool any_relabel = relabel;
+  for (int attempt = 0;; attempt++) {
+  LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   // bounding boxes first: the relabelling's Morton keys are taken over them (k_quantize uses them much later)
   LAUNCH(k_minmax, dim3(std::min(bv, 16u), N), dim3(UVOL_BLOCK), dj);
-  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe; }
-  else {
+  if (seq) break;
   {
     uvol_ctx::Scope sc(ctx, "geo.k2_dedup", algo_in);
     if (!full) {
@@ -653,17 +683,17 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
       LAUNCH(k_dedup<2>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 1, 1);
       LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 2, 1);
     }
-    const unsigned mt0 = (unsigned)((max_vals + MS_TILE - 1) / MS_TILE), mt1 = (unsigned)(((size_t)max_nfi + MS_TILE - 1) / MS_TILE);
-    // How the frames are stored decides two things, so the batch is looked at once (k_coherence: one pass over the index arrays) and the
-    // two counts come back to the host (the only mid-batch synchronisation; the encode kernels of a large batch take 0.2 - 0.9 s):
+    // How the frames are stored decides three things, so the batch is looked at once (k_coherence: one pass over the index arrays) and the
+    // counts come back to the host (the only mid-batch synchronisation; the encode kernels of a large batch take 0.2 - 0.9 s):
     //  * frames stored coherently skip the locality relabelling - if none needs it, its ~6 M (empty) workgroups are not even launched;
     //  * frames with the SAME connectivity as their predecessor (an animated mesh of fixed topology) are walked in lock step by the
     //    lanes of a wave - 16 attribute traversers per wave then beat one per wave (200 vs 300 ms per 2160 frames), while walkers on
-    //    unrelated meshes diverge and miss at different times, and one per wave is the faster form (307 vs 392 ms).
-    bool any_relabel = relabel;
+    //    unrelated meshes diverge and miss at different times, and fewer per wave are the faster form;
+    //  * a group in the compact layout has to be all clean, coherently stored frames (above).
+    any_relabel = relabel;
     if (relabel || NC >= 256) {
       if (!L.counts) UVOL_HIP_CHECK(ctx, hipMalloc((void **)&L.counts, 64));
-      uint32_t hc[2] = { 0, 0 };
+      uint32_t hc[3] = { 0, 0, 0 };
       UVOL_HIP_CHECK(ctx, hipMemsetAsync(L.counts, 0, 64, ctx->stream));
       LAUNCH(k_coherence, dim3(bf, N), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_relabel_decide, dim3((N + 63) / 64), dim3(64), dj, n, L.counts);
@@ -671,7 +701,22 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
       UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
       any_relabel = relabel && hc[0] != 0;
       lockstep = (uint64_t)hc[1] * 10u >= (uint64_t)n * 9u;
+      if (compact && hc[2] != 0 && attempt == 0) {           // a frame with duplicate values, a degenerate face or an incoherent storage order: general layout, once more
+        compact = false; G->compact_ok = false;
+        if ((rc = lay())) return rc;
+        dj = (GeoJob *)L.jobs.p; be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));
+        continue;
+      }
+      if (!compact && !full && hc[2] == 0) G->compact_ok = true;
     }
+  }
+  break;
+  }
+  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe; }
+  else {
+  {
+    uvol_ctx::Scope sc(ctx, "geo.k2b_faces", 0);
+    const unsigned mt0 = (unsigned)((max_vals + MS_TILE - 1) / MS_TILE), mt1 = (unsigned)(((size_t)max_nfi + MS_TILE - 1) / MS_TILE);
     if (any_relabel) {                                       // new position ids (Morton order) and the positions in that order
       LAUNCH(k_ms_key_pos, dim3(bv, N), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_ms_count, dim3(mt0, N), dim3(UVOL_BLOCK), dj, 0);
@@ -689,7 +734,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
       LAUNCH(k_ms_place, dim3(ms_nb_max, N), dim3(UVOL_BLOCK), dj, 1);
       LAUNCH(k_relabel_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     }
-    LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj);       // the frames that are not relabelled (decided per frame on the device)
+    LAUNCH(k_compact_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, face_alias);       // the frames that are not relabelled (decided per frame on the device)
     { uvol_ctx::Scope sq(ctx, "geo.k1_quantize", algo_in); LAUNCH(k_quant_ids, dim3(bv, N, 3), dim3(UVOL_BLOCK), dj); }      // (after the relabelling: position ids are the stored ones)
   }
   {
@@ -707,6 +752,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     }
     LAUNCH(k_edge_match, dim3(bci, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
+    LAUNCH(k_vert_fill, dim3(bc, N), dim3(UVOL_BLOCK), dj);            // (frames with non-manifold vertices only: geo_vt)
   }
   UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe;
   // UVOL_SIMT_W_WALK / UVOL_SIMT_W_TRAV (diagnostic): lanes per wave of one of the two lane-per-walker kernels only (UVOL_SIMT_W sets both)
@@ -764,7 +810,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
     if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = 1;      // unrelated meshes: one traverser per wave
     if (w_trav_env && wp_trav.simt_w) wp_trav.simt_w = w_trav_env;
-    launch_traversals(ctx, dj, n, wp_trav, fmtT);
+    launch_traversals(ctx, dj, n, wp_trav, fmtT, base_shared ? 1 : 0);
   }
   { uvol_ctx::Scope sc(ctx, "geo.k5b_v2d", 0); LAUNCH(k_v2d, dim3(be, N, 3), dim3(UVOL_BLOCK), dj, fmtT); }      // (own scope: geo.k5_traverse is exactly the traversal kernel, as rocprof lists it)
   {
