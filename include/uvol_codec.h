@@ -75,6 +75,15 @@ void uvol_ctx_destroy(uvol_ctx *ctx);
 const char *uvol_last_error(const uvol_ctx *ctx);
 /* completes everything enqueued on ctx (uvol_*_async calls and the stream); returns the first error among the enqueued calls */
 int  uvol_sync(uvol_ctx *ctx);
+
+/* Page-locked host memory (round 5; SURVEY 8(d) times the path from "inputs resident in pinned host memory").  The entry points that take
+ * HOST arrays copy pageable memory through the library's own pinned double buffers (host threads fill them, ~42 GB/s); arrays that lie in
+ * memory from uvol_host_alloc are read by the DMA engines where they are - no staging copy.  It takes effect when EVERY input array of
+ * a call lies in such memory; otherwise the call is staged as before.  Process-wide, thread-safe; NULL when the runtime refuses (no
+ * device, out of lockable memory).  What a caller of the reference holds at this boundary are files / host buffers
+ * (scripts/Encoder.py:244-302): this is where it would read them into. */
+void *uvol_host_alloc(size_t bytes);
+void  uvol_host_free(void *p);
 /* uvol_sync, then the geometry workspaces of ctx go back to the device (they only grow: a context that once ran a 2560-frame call as one
  * group keeps ~130 GB until it is destroyed); its streams stay, the next call allocates what it needs.  No counterpart in the reference
  * (its encoders are processes that exit, scripts/Encoder.py:266-302); a long-lived host uses it between jobs of very different sizes. */
@@ -232,6 +241,26 @@ int uvol_transcode_texture_segments_etc2_rgba(uvol_ctx *ctx, const uint8_t *cons
  * rejected with UVOL_E_UNSUPPORTED (the stock player never picks ASTC for them). */
 int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                          uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
+
+/* ---- per-segment results for the batched texture calls (round 5; additive: uvol_abi_version stays 1) ----
+ * The reference fails per `basisu` process (scripts/Encoder.py:293-298): one bad batch does not undo the others.  The batched texture
+ * entry points above return ONE code for the call; these forms also fill status[s] per segment, like uvol_encode_mesh_batch does per
+ * frame, and return UVOL_OK whenever the call itself ran (bad arguments, device errors and out-of-memory still fail the call).
+ *
+ * uvol_encode_texture_segments_st: as uvol_encode_texture_segments[_dev] (inputs_on_device selects which); a segment whose output buffer
+ * is too small gets UVOL_E_NOSPACE (out_lens[s] = the size it needs), one the device could not encode UVOL_E_ENCODE; the others are written.
+ *
+ * uvol_transcode_texture_segments_st: every decode / transcode target through one entry point.  Files are judged one by one: an
+ * unreadable container (UVOL_E_INVALID / UVOL_E_UNSUPPORTED from uvol_ktx2_info's rules), a shape other than the first readable file's
+ * (UVOL_E_INVALID), a source kind the target does not take (UVOL_E_UNSUPPORTED: ASTC wants UASTC sources, ETC1 / BC7 / ETC2 want
+ * ETC1S), a payload that turns out corrupt on the device (UVOL_E_ENCODE) fail in their own slot; ETC1S and UASTC files may share a
+ * batch.  out[s * layers + l] as in the entry point of the target; slots of failed segments are not read. */
+enum { UVOL_TARGET_RGBA32 = 0, UVOL_TARGET_ETC1 = 1, UVOL_TARGET_BC7 = 2, UVOL_TARGET_ASTC = 3, UVOL_TARGET_ETC2_RGBA = 4 };
+int uvol_encode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers,
+                                    uint32_t width, uint32_t height, int inputs_on_device,
+                                    uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);
+int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                       uint8_t *const *out, size_t layer_cap, int outputs_on_device, int target, int *status);
 
 /* ---- decode path, geometry half ----
  * Replaces what the stock player obtains from the draco WASM decoder per frame (reference src/V2/player.ts:101, :313-336):

@@ -333,3 +333,24 @@ def test_gpu_texture_decoders_survive_corrupt_input(oracle):
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_DEBUG="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout and "FAILED" not in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_gpu_texture_batch_calls_report_per_segment_status(oracle, gpu_codec):
+    """VERDICT r4 #8 on the device: uvol_transcode_texture_segments_st / uvol_encode_texture_segments_st - a corrupt file and a mixed-kind
+    batch in the middle of good ones (the cases of tests/test_hipemu_tex.py)."""
+    import uvol
+    from test_hipemu_tex import _st_cases
+    cu = uvol.Codec(device=0, uastc=1)
+    files, a, b = _st_cases(oracle, gpu_codec, cu)
+    outs, st = gpu_codec.transcode_texture_segments_status(files, "rgba32")
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    ra, rb = oracle.ktx2_decode(files[0]), oracle.ktx2_decode(files[5])
+    assert all(np.array_equal(outs[0][l], ra.images[l]) for l in range(2)) and all(np.array_equal(outs[5][l], rb.images[l]) for l in range(2))
+    assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2]))
+    outs, st = gpu_codec.transcode_texture_segments_status(files, "etc2_rgba")
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    assert np.array_equal(outs[5], gpu_codec.transcode_texture_segments_etc2_rgba([files[5]])[0])
+    enc, st = gpu_codec.encode_texture_segments_status([a, b, a], caps=[1 << 20, 100, 1 << 20])
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_NOSPACE, uvol.UVOL_OK] and enc[0] == files[0] and enc[2] == files[0]
+    cu.close()

@@ -486,3 +486,20 @@ def test_hipemu_random_soups_match_oracle(oracle, hipemu_lib):
                 want = None
             assert g == want
     cd.close()
+
+
+def test_hipemu_inputs_in_pinned_host_memory(oracle, hipemu_lib):
+    """arrays that lie in uvol_host_alloc memory are uploaded from where they lie (no staging copy); a call with one
+    pageable array is staged as before.  Same bytes either way."""
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    ms = [m for _, m in _meshes()]
+    want = cd.encode_mesh_batch(ms)
+    ar = uvol.PinnedArena(64 << 20, lib_path=hipemu_lib)
+    pm = [{k: ar.put(v) for k, v in m.items()} for m in ms]
+    assert cd.encode_mesh_batch(pm) == want
+    mixed = [dict(pm[0]), dict(pm[1], pos=np.array(ms[1]["pos"]))] + pm[2:]        # one pageable array: the staged path
+    assert cd.encode_mesh_batch(mixed) == want
+    tex = synth.texture_sequence(2, size=64, seed=1)
+    assert cd.encode_texture_segments([[ar.put(t) for t in tex]]) == cd.encode_texture_segments([tex])
+    cd.close(); ar.close()

@@ -309,3 +309,42 @@ def test_hipemu_etc1s_alpha_slices(oracle, hipemu_lib):
     cu = uvol.Codec(lib_path=hipemu_lib, uastc=1)
     assert cu.encode_texture_segment(tex) == oracle.uastc_ktx2_encode(tex)
     cu.close()
+
+
+def _st_cases(oracle, cd_etc, cd_uastc):
+    """A mixed batch for uvol_transcode_texture_segments_st: good ETC1S, a file whose codebook tables are overwritten (readable
+    container, corrupt payload), a UASTC file of the same shape, garbage, a file of another shape, good ETC1S."""
+    import synth
+    a = synth.texture_sequence(2, size=64, seed=3); b = synth.texture_sequence(2, size=64, seed=4); small = synth.texture_sequence(2, size=32, seed=5)
+    fa, fb, fs = cd_etc.encode_texture_segment(a), cd_etc.encode_texture_segment(b), cd_etc.encode_texture_segment(small)
+    fu = cd_uastc.encode_texture_segment(a)
+    sgd = int.from_bytes(fa[64:72], "little")                # supercompression global data offset (KTX2 header)
+    bad = bytearray(fa); bad[sgd + 20 + 20 * 2: sgd + 20 + 20 * 2 + 48] = b"\x00" * 48
+    return [fa, bytes(bad), fu, b"not a ktx2 file at all", fs, fb], a, b
+
+
+def test_hipemu_texture_batch_calls_report_per_segment_status(oracle, hipemu_lib):
+    """VERDICT r4 #8 (a failed frame must not poison the batch; the reference fails per basisu process,
+    scripts/Encoder.py:293-298): the _st forms of the batched texture calls fill a status per segment; a corrupt, unreadable,
+    other-shaped or wrong-kind file fails in its own slot, ETC1S and UASTC sources share a batch, the others are decoded as alone."""
+    import uvol
+    cd = uvol.Codec(lib_path=hipemu_lib); cu = uvol.Codec(lib_path=hipemu_lib, uastc=1)
+    files, a, b = _st_cases(oracle, cd, cu)
+    outs, st = cd.transcode_texture_segments_status(files, "rgba32")
+    assert st[0] == uvol.UVOL_OK and st[5] == uvol.UVOL_OK and st[2] == uvol.UVOL_OK
+    assert st[1] == uvol.UVOL_E_ENCODE and st[3] == uvol.UVOL_E_INVALID and st[4] == uvol.UVOL_E_INVALID
+    ra, rb = oracle.ktx2_decode(files[0]), oracle.ktx2_decode(files[5])
+    assert all(np.array_equal(outs[0][l], ra.images[l]) for l in range(2)) and all(np.array_equal(outs[5][l], rb.images[l]) for l in range(2))
+    assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2]))
+    # a target only one of the kinds takes: the other kind is UNSUPPORTED in its slot, the rest still runs
+    outs, st = cd.transcode_texture_segments_status(files, "bc7")
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    assert np.array_equal(outs[0], cd.transcode_texture_segments_bc7([files[0]])[0])
+    outs, st = cd.transcode_texture_segments_status(files, "astc")
+    assert st[2] == uvol.UVOL_OK and st[0] == uvol.UVOL_E_UNSUPPORTED and np.array_equal(outs[2], cu.transcode_texture_segments_astc([files[2]])[0])
+    # encode: a segment whose output buffer is too small fails alone and says what it needs
+    enc, st = cd.encode_texture_segments_status([a, b, a], caps=[1 << 20, 100, 1 << 20])
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_NOSPACE, uvol.UVOL_OK] and enc[0] == files[0] and enc[2] == files[0] and enc[1] is None
+    enc, st = cu.encode_texture_segments_status([a, b], caps=[100, 1 << 20])
+    assert st == [uvol.UVOL_E_NOSPACE, uvol.UVOL_OK] and enc[1] == cu.encode_texture_segment(b)
+    cd.close(); cu.close()

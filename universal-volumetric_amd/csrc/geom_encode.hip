@@ -431,7 +431,9 @@ static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &
     // (k_traverse_wave_f16: pops as ordinary steps, component search by the whole wave), UVOL_TRAV_W lanes per wave
     static const bool lane_form = [] { const char *e = getenv("UVOL_TRAV_FORM"); return e && !strcmp(e, "lane"); }();
     static const int wave_w = [] { const char *e = getenv("UVOL_TRAV_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
-    if (r8 == 2 && !lane_form) { const unsigned Ww = wave_w ? (unsigned)wave_w : W; LAUNCH(k_traverse_wave_f16, dim3((N + Ww - 1) / Ww, 3), dim3(64), dj, n, (int)Ww, 0, base_hi); }
+    static const bool coop_form = [] { const char *e = getenv("UVOL_TRAV_FORM"); return e && !strcmp(e, "coop"); }();
+    if (r8 == 2 && coop_form) LAUNCH(k_traverse_coop_f16, dim3(N, 3), dim3(64), dj, 0, base_hi);
+    else if (r8 == 2 && !lane_form) { const unsigned Ww = wave_w ? (unsigned)wave_w : W; LAUNCH(k_traverse_wave_f16, dim3((N + Ww - 1) / Ww, 3), dim3(64), dj, n, (int)Ww, 0, base_hi); }
     else if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W, 0, 3);
     else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
   }
@@ -764,7 +766,9 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) {
       const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
-      if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
+      static const bool walk_coop = [] { const char *e = getenv("UVOL_WALK_FORM"); return e && !strcmp(e, "coop"); }();
+      if (fmt0 == 2 && walk_coop) LAUNCH(k_eb_walk_coop_f16, dim3(N), dim3(64), dj);
+      else if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
       else if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
     }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());

@@ -601,7 +601,10 @@ void texdec_destroy(uvol_ctx *ctx) {
   } while (0)
 
 // n segments (all of one width / height / layer count), rgba[s * layers + l] = width*height*4 bytes each
-int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target) {
+// status (optional): per-segment result codes; a segment whose stream turns out corrupt on the device then fails alone (UVOL_E_ENCODE in
+// its slot, its layers are not written) and the call returns UVOL_OK - without it the first failing segment fails the call.  The
+// container checks (parse, equal size / layer count) are the caller's with status[]: uvol_transcode_texture_segments_st sorts those out first.
+int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target, int *status) {
   TexDecState *T = ctx->texdec;
   if (n <= 0) return UVOL_OK;
   T->hjobs.assign((size_t)n, TexDecJob{});
@@ -659,10 +662,13 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < n; i++) if (T->hjobs[i].status != 0) { ctx->set_error("segment %d: corrupt BasisLZ stream (device status %d)", i, T->hjobs[i].status); return UVOL_E_ENCODE; }
+  for (int i = 0; i < n; i++) {
+    if (status) status[i] = T->hjobs[i].status != 0 ? UVOL_E_ENCODE : UVOL_OK;
+    if (T->hjobs[i].status != 0) { ctx->set_error("segment %d: corrupt BasisLZ stream (device status %d)", i, T->hjobs[i].status); if (!status) return UVOL_E_ENCODE; }
+  }
   if (!outputs_on_device) {                                  // host outputs: one staged download (pinned double buffers, host threads copy out)
     std::vector<UvolDnItem> dns; dns.reserve((size_t)n * L);
-    for (int i = 0; i < n; i++) for (size_t l = 0; l < L; l++) dns.push_back(UvolDnItem{ T->hjobs[i].out[l], rgba[(size_t)i * L + l], layer_bytes });
+    for (int i = 0; i < n; i++) if (T->hjobs[i].status == 0) for (size_t l = 0; l < L; l++) dns.push_back(UvolDnItem{ T->hjobs[i].out[l], rgba[(size_t)i * L + l], layer_bytes });
     const int rcd = uvol_download_staged(ctx, dns); if (rcd != UVOL_OK) return rcd;
   }
   ctx->resolve_profile();

@@ -1077,6 +1077,7 @@ struct TexLane {
   // the part in flight (tex_submit ... tex_finish)
   int n_seg = 0, n_layers = 0, alpha = 0; uint32_t W = 0, H = 0;
   uint8_t *const *outs = nullptr; const size_t *caps = nullptr; size_t *out_lens = nullptr;
+  int *status = nullptr;               // optional per-segment result codes of the part (uvol_encode_texture_segments_st)
 };
 struct TexState { TexLane lane[2]; };
 int tex_create(uvol_ctx *ctx) { ctx->tex = new TexState(); ctx->tex->lane[0].stream = ctx->stream; return UVOL_OK; }
@@ -1372,13 +1373,14 @@ static int tex_finish_impl(uvol_ctx *ctx, TexLane &L) {
   int worst = UVOL_OK;
   for (int s = 0; s < n_seg; s++) {
     const TexJob &R = L.hjobs[s];
+    if (L.status) L.status[s] = UVOL_OK;
     if (R.status == TEX_E_ALPHA && !alpha) { out_lens[s] = TEX_RETRY_ALPHA; continue; }                    // encoded again with alpha slices by the caller
-    if (R.status != 0) { ctx->set_error("texture segment %d: device status %d", s, R.status); worst = UVOL_E_ENCODE; out_lens[s] = 0; continue; }
+    if (R.status != 0) { ctx->set_error("texture segment %d: device status %d", s, R.status); worst = UVOL_E_ENCODE; out_lens[s] = 0; if (L.status) L.status[s] = UVOL_E_ENCODE; continue; }
     const uint64_t sgd_len = 20 + 20 * (uint64_t)n_layers + R.sec_len[0] + R.sec_len[1] + R.sec_len[2];
     uint64_t lvl_len = 0; for (int l = 0; l < nsl; l++) lvl_len += R.slice_len[l];
     const uint64_t lvl_off = sgd_off + sgd_len, total = lvl_off + lvl_len;
     out_lens[s] = (size_t)total;
-    if (total > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%llu > %llu)", s, (unsigned long long)total, (unsigned long long)caps[s]); worst = UVOL_E_NOSPACE; continue; }
+    if (total > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%llu > %llu)", s, (unsigned long long)total, (unsigned long long)caps[s]); worst = UVOL_E_NOSPACE; if (L.status) L.status[s] = UVOL_E_NOSPACE; continue; }
     uint8_t *out = outs[s], *p = out;
     memcpy(p, ident, 12); p += 12;
     put32(p, 0); put32(p, 1); put32(p, W); put32(p, H); put32(p, 0); put32(p, (uint32_t)n_layers); put32(p, 1); put32(p, 1); put32(p, 1);
@@ -1396,15 +1398,15 @@ static int tex_finish_impl(uvol_ctx *ctx, TexLane &L) {
       for (int l = 0; l < n_layers; l++) {
         const uint32_t c = R.slice_len[l << alpha], a = alpha ? R.slice_len[(l << alpha) + 1] : 0u;
         put32(p, l > 0 ? 2 : 0); put32(p, off); put32(p, c); put32(p, alpha ? off + c : 0u); put32(p, a); off += c + a; } }
-    if (R.pack_len != sgd_len - 20 - 20 * (uint64_t)n_layers + lvl_len) { ctx->set_error("texture segment %d: packed payload length mismatch", s); worst = UVOL_E_ENCODE; continue; }
+    if (R.pack_len != sgd_len - 20 - 20 * (uint64_t)n_layers + lvl_len) { ctx->set_error("texture segment %d: packed payload length mismatch", s); worst = UVOL_E_ENCODE; if (L.status) L.status[s] = UVOL_E_ENCODE; continue; }
     memcpy(p, L.pinned + R.pack_off, (size_t)R.pack_len);            // sections then slices, already in container order
   }
-  return worst;
+  return L.status ? UVOL_OK : worst;      // (with status[] the per-segment codes carry the failures)
 }
 // the lane's stream stands in for the context's while one of its halves runs (TLAUNCH, Scope, uvol_ensure, uvol_upload_staged use ctx->stream)
 static int tex_submit(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
-                      bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha) {
-  hipStream_t saved = ctx->stream; ctx->stream = L.stream;
+                      bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha, int *status = nullptr) {
+  hipStream_t saved = ctx->stream; ctx->stream = L.stream; L.status = status;
   const int rc = tex_submit_impl(ctx, L, rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, alpha);
   ctx->stream = saved; return rc;
 }
@@ -1413,15 +1415,18 @@ static int tex_submit(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, int
 static int tex_finish(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, bool on_device) {
   hipStream_t saved = ctx->stream; ctx->stream = L.stream;
   const int n_seg = L.n_seg, n_layers = L.n_layers; uint8_t *const *outs = L.outs; const size_t *caps = L.caps; size_t *out_lens = L.out_lens; const uint32_t W = L.W, H = L.H;
+  int *const status = L.status;
   int rc = tex_finish_impl(ctx, L);
   std::vector<int> again;
   for (int s = 0; s < n_seg; s++) if (out_lens[s] == TEX_RETRY_ALPHA) { again.push_back(s); out_lens[s] = 0; }
   if (!again.empty() && (rc == UVOL_OK || rc == UVOL_E_NOSPACE || rc == UVOL_E_ENCODE)) {
-    std::vector<const uint8_t *> src; std::vector<uint8_t *> o2; std::vector<size_t> c2, l2(again.size(), 0);
+    std::vector<const uint8_t *> src; std::vector<uint8_t *> o2; std::vector<size_t> c2, l2(again.size(), 0); std::vector<int> st2(again.size(), UVOL_OK);
     for (int s : again) { for (int l = 0; l < n_layers; l++) src.push_back(on_device ? rgba[(size_t)s * n_layers + l] : L.hjobs[s].layer[l]); o2.push_back(outs[s]); c2.push_back(caps[s]); }
+    L.status = status ? st2.data() : nullptr;
     int rc2 = tex_submit_impl(ctx, L, src.data(), (int)again.size(), n_layers, W, H, true, o2.data(), c2.data(), l2.data(), 1);
     if (rc2 == UVOL_OK) rc2 = tex_finish_impl(ctx, L);
-    for (size_t i = 0; i < again.size(); i++) out_lens[again[i]] = l2[i];
+    L.status = status;
+    for (size_t i = 0; i < again.size(); i++) { out_lens[again[i]] = l2[i]; if (status) status[again[i]] = rc2 != UVOL_OK ? rc2 : st2[i]; }
     if (rc == UVOL_OK) rc = rc2;
   }
   ctx->stream = saved; return rc;
@@ -1429,7 +1434,7 @@ static int tex_finish(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, boo
 // segments per part of a call on host inputs (UVOL_TEX_PART, tests: small values cut small calls too; 0 = never cut)
 static inline int tex_part_segments() { static const int v = [] { const char *e = getenv("UVOL_TEX_PART"); const int k = e ? atoi(e) : 64; return k < 0 ? 0 : k; }(); return v; }
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
-                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   if (n_seg <= 0) return UVOL_OK;
   TexState *T = ctx->tex;
   T->lane[0].stream = ctx->stream;
@@ -1437,7 +1442,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   const int part = tex_part_segments();
   int rc = UVOL_OK;
   if (on_device || part <= 0 || n_seg < 2 * part) {                       // one batch on the context's stream
-    rc = tex_submit(ctx, T->lane[0], rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0);
+    rc = tex_submit(ctx, T->lane[0], rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0, status);
     if (rc == UVOL_OK) rc = tex_finish(ctx, T->lane[0], rgba, on_device);
     ctx->resolve_profile();
     return rc;
@@ -1452,7 +1457,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   for (int k = 0; k <= parts; k++) {
     if (k < parts) {
       const int a = lo(k), b = lo(k + 1);
-      const int r = tex_submit(ctx, T->lane[k & 1], rgba + (size_t)a * n_layers, b - a, n_layers, W, H, false, outs + a, caps + a, out_lens + a, 0);
+      const int r = tex_submit(ctx, T->lane[k & 1], rgba + (size_t)a * n_layers, b - a, n_layers, W, H, false, outs + a, caps + a, out_lens + a, 0, status ? status + a : nullptr);
       if (r != UVOL_OK) { if (k > 0) (void)tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, false); return r; }
     }
     if (k > 0) { const int r = tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, false); if (r != UVOL_OK && worst == UVOL_OK) worst = r; }
@@ -1463,5 +1468,5 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
 
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t W, uint32_t H,
                        bool on_device, uint8_t *out, size_t cap, size_t *out_len) {
-  return tex_encode_segments(ctx, rgba, 1, n_layers, W, H, on_device, &out, &cap, out_len);
+  return tex_encode_segments(ctx, rgba, 1, n_layers, W, H, on_device, &out, &cap, out_len, nullptr);
 }

@@ -541,7 +541,7 @@ int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint3
 
 // n_seg segments of n_layers layers -> UASTC .ktx2 files (what `basisu -uastc -ktx2 -tex_type video` writes, without Zstandard)
 int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
-                              bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens) {
+                              bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
   if (on_device) { const int ro = png_order_before(ctx, ctx->stream, rgba[0]); if (ro != UVOL_OK) return ro; }      // layers un-filtered on the ingest stream
   UastcState *U = ctx->uastc;
   if (n_seg <= 0) return UVOL_OK;
@@ -576,15 +576,16 @@ int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
   const size_t lvl_off = uastc_header(nullptr, W, H, (uint32_t)n_layers, false, seg_bytes);
   for (int s = 0; s < n_seg; s++) {
     out_lens[s] = lvl_off + seg_bytes;
-    if (out_lens[s] > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%zu > %zu)", s, out_lens[s], caps[s]); worst = UVOL_E_NOSPACE; continue; }
+    if (status) status[s] = UVOL_OK;
+    if (out_lens[s] > caps[s]) { ctx->set_error("texture segment %d: output buffer too small (%zu > %zu)", s, out_lens[s], caps[s]); worst = UVOL_E_NOSPACE; if (status) status[s] = UVOL_E_NOSPACE; continue; }
     (void)uastc_header(outs[s], W, H, (uint32_t)n_layers, U->hjobs[s].any_alpha != 0, seg_bytes);
     memcpy(outs[s] + lvl_off, U->pinned + seg_bytes * (size_t)s, seg_bytes);
   }
-  return worst;
+  return status ? UVOL_OK : worst;
 }
 
 // UASTC .ktx2 files -> target 0: RGBA8 layers, target 3: ASTC 4x4 blocks (layer buffers of the caller, host or device)
-int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *outp, size_t layer_cap, bool outputs_on_device, int target) {
+int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *outp, size_t layer_cap, bool outputs_on_device, int target, int *status) {
   UastcState *U = ctx->uastc;
   if (n <= 0) return UVOL_OK;
   if (target != 0 && target != 3) { ctx->set_error("UASTC sources transcode to RGBA32 or ASTC 4x4"); return UVOL_E_UNSUPPORTED; }
@@ -615,11 +616,13 @@ int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const 
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   if (!outputs_on_device) {
     std::vector<UvolDnItem> dns; dns.reserve((size_t)n * L);
+    // (a segment that failed on the device - status[] given - is downloaded like the others: its layers hold whatever the kernel wrote before it gave up)
     for (int s = 0; s < n; s++) for (uint32_t l = 0; l < L; l++) dns.push_back(UvolDnItem{ (uint8_t *)U->outs.p + layer_bytes * ((size_t)s * L + l), outp[(size_t)s * L + l], layer_bytes });
     const int rcd = uvol_download_staged(ctx, dns); if (rcd != UVOL_OK) return rcd;
   }
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->resolve_profile();
+  if (status) { for (int s = 0; s < n; s++) status[s] = U->hjobs[s].status != 0 ? UVOL_E_ENCODE : UVOL_OK; return UVOL_OK; }
   for (int s = 0; s < n; s++) if (U->hjobs[s].status != 0) { ctx->set_error("segment %d: corrupt UASTC block or a mode this codec does not read (device status %d)", s, U->hjobs[s].status); return UVOL_E_ENCODE; }
   return UVOL_OK;
 }

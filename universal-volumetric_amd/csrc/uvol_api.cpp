@@ -8,6 +8,26 @@
 // Optional CU partition (params.cu_mod / cu_residues): the context's streams only run on CUs whose index modulo
 // cu_mod has its bit set in cu_residues.  bench.py --cu-split gives geometry 3 of every 4 CUs and texture the 4th,
 // so the latency-bound one-wave walkers never share a CU's memory pipeline with the streaming texture kernels.
+// Page-locked host memory for callers that keep their inputs in it (uvol_host_alloc / uvol_host_free): the registry uvol_upload_staged asks.
+namespace { std::mutex g_pin_m; std::map<uintptr_t, size_t> g_pin; }
+bool uvol_host_pinned(const void *p, size_t n) {
+  std::lock_guard<std::mutex> l(g_pin_m);
+  if (g_pin.empty()) return false;
+  auto it = g_pin.upper_bound((uintptr_t)p);
+  if (it == g_pin.begin()) return false;
+  --it;
+  return (uintptr_t)p >= it->first && (uintptr_t)p + n <= it->first + it->second;
+}
+extern "C" void *uvol_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> l(g_pin_m); g_pin[(uintptr_t)p] = bytes; return p;
+}
+extern "C" void uvol_host_free(void *p) {
+  if (!p) return;
+  { std::lock_guard<std::mutex> l(g_pin_m); g_pin.erase((uintptr_t)p); }
+  (void)hipHostFree(p);
+}
 hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
 #ifndef HIPEMU
   if (ctx->prm.cu_mod > 1 && ctx->prm.cu_mod <= 32 && ctx->prm.cu_residues != 0) {
@@ -287,6 +307,54 @@ static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size
   }
   if (target == 3) { ctx->set_error("ASTC 4x4 is the transcode target of UASTC sources (KTX2Loader.js:591-600); this file is ETC1S"); return UVOL_E_UNSUPPORTED; }
   return tex_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);
+}
+// Per-segment results and mixed batches (reference scripts/Encoder.py:293-298 fails one basisu process, not the run; SURVEY 5
+// "a failed frame must not poison the batch").  Every file is looked at on its own: not a container this decoder reads -> its status; the
+// first readable file fixes the batch's width / height / layer count and a file of another shape is UVOL_E_INVALID in its slot; a source
+// kind that does not transcode to the target is UVOL_E_UNSUPPORTED in its slot; ETC1S and UASTC files run as one batch per kind; a file
+// whose payload turns out corrupt on the device fails alone.  The call itself fails only for bad arguments, memory or the device.
+int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+                                       uint8_t *const *out, size_t layer_cap, int outputs_on_device, int target, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !out || !status || target < UVOL_TARGET_RGBA32 || target > UVOL_TARGET_ETC2_RGBA) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  const int n = n_segments;
+  std::vector<int> kind((size_t)n, -1);                    // 0 ETC1S, 1 UASTC
+  uint32_t W0 = 0, H0 = 0, L0 = 0; bool have = false;
+  for (int i = 0; i < n; i++) {
+    status[i] = UVOL_E_INVALID;
+    if (!ktx2[i]) continue;
+    uint32_t w = 0, h = 0, l = 0; uint64_t lo = 0;
+    const int pu = uastc_ktx2_probe(ktx2[i], lens[i], &w, &h, &l, &lo);
+    if (pu == UASTC_PROBE_SUPERCOMPRESSED) { status[i] = UVOL_E_UNSUPPORTED; continue; }
+    int k = -1;
+    if (pu == 0) k = 1;
+    else { const int ri = uvol_ktx2_info(ktx2[i], lens[i], &w, &h, &l); if (ri != UVOL_OK) { status[i] = ri; continue; } k = 0; }
+    if (!have) { W0 = w; H0 = h; L0 = l; have = true; }
+    else if (w != W0 || h != H0 || l != L0) continue;                       // another shape than the batch's: UVOL_E_INVALID
+    if (k == 1 ? (target != UVOL_TARGET_RGBA32 && target != UVOL_TARGET_ASTC) : target == UVOL_TARGET_ASTC) { status[i] = UVOL_E_UNSUPPORTED; continue; }
+    kind[i] = k; status[i] = UVOL_OK;
+  }
+  for (int k = 0; k < 2; k++) {
+    std::vector<int> ix; for (int i = 0; i < n; i++) if (kind[i] == k) ix.push_back(i);
+    if (ix.empty()) continue;
+    std::vector<const uint8_t *> f(ix.size()); std::vector<size_t> ln(ix.size()); std::vector<uint8_t *> o(ix.size() * L0); std::vector<int> st(ix.size(), UVOL_OK);
+    for (size_t j = 0; j < ix.size(); j++) { f[j] = ktx2[ix[j]]; ln[j] = lens[ix[j]]; for (uint32_t l = 0; l < L0; l++) o[j * L0 + l] = out[(size_t)ix[j] * L0 + l]; }
+    const int rc = k == 1 ? tex_uastc_decode_segments(ctx, f.data(), ln.data(), (int)ix.size(), o.data(), layer_cap, outputs_on_device != 0, target, st.data())
+                          : tex_decode_segments(ctx, f.data(), ln.data(), (int)ix.size(), o.data(), layer_cap, outputs_on_device != 0, target, st.data());
+    if (rc == UVOL_E_HIP || rc == UVOL_E_NOSPACE) return rc;                 // the device / the caller's layer buffers: the call's failure
+    for (size_t j = 0; j < ix.size(); j++) status[ix[j]] = rc != UVOL_OK ? rc : st[j];
+  }
+  return UVOL_OK;
+}
+int uvol_encode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height,
+                                    int inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !rgba || n_segments <= 0 || n_layers < 1 || !outs || !caps || !out_lens || !status) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  for (int s = 0; s < n_segments; s++) { status[s] = UVOL_OK; out_lens[s] = 0; }
+  if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, rgba, n_segments, n_layers, width, height, inputs_on_device != 0, outs, caps, out_lens, status);
+  return tex_encode_segments(ctx, rgba, n_segments, n_layers, width, height, inputs_on_device != 0, outs, caps, out_lens, status);
 }
 int uvol_decode_texture_segments(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments, uint8_t *const *rgba, size_t layer_cap) {
   UVOL_AFTER_ASYNC(ctx);

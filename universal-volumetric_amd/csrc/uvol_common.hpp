@@ -243,7 +243,7 @@ void geodec_destroy(uvol_ctx *ctx);
 int geo_decode_batch(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uvol_decoded_mesh *out, int *status, bool outputs_on_device = false);
 int texdec_create(uvol_ctx *ctx);
 void texdec_destroy(uvol_ctx *ctx);
-int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target);
+int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *rgba, size_t layer_cap, bool outputs_on_device, int target, int *status = nullptr);
 int obj_create(uvol_ctx *ctx);
 void obj_destroy(uvol_ctx *ctx);
 int obj_parse_batch(uvol_ctx *ctx, const uint8_t *const *texts, const size_t *lens, int n, int slot, uvol_mesh *meshes_out, int *status);
@@ -257,12 +257,12 @@ void uastc_destroy(uvol_ctx *ctx);
 #define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */
 int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L, uint64_t *lvl_off);
 int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
-                              bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens);
-int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool outputs_on_device, int target);
+                              bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status = nullptr);
+int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool outputs_on_device, int target, int *status = nullptr);
 int tex_create(uvol_ctx *ctx);
 void tex_destroy(uvol_ctx *ctx);
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
-                        bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens);
+                        bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status = nullptr);
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t w, uint32_t h,
                        bool inputs_on_device, uint8_t *out, size_t cap, size_t *out_len);
 
@@ -315,8 +315,14 @@ inline int uvol_up_threads() {
   int ndev = 1; (void)hipGetDeviceCount(&ndev); if (ndev < 1) ndev = 1;
   return std::max(2, std::min(8, hw / (2 * ndev)));
 }
+// is [p, p + n) inside a buffer handed out by uvol_host_alloc (page-locked: the DMA engines read it directly)?  (uvol_api.cpp)
+bool uvol_host_pinned(const void *p, size_t n);
 static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std::vector<UvolUpItem> &items) {
   if (items.empty()) return UVOL_OK;
+  // A caller that keeps its arrays in uvol_host_alloc memory ("inputs resident in pinned host memory") skips the staging
+  // copy: every array goes from where it lies to the device, asynchronously, in call order.  One pageable array and the whole call is staged.
+  { bool all = true; for (const UvolUpItem &it : items) if (it.bytes && !uvol_host_pinned(it.src, it.bytes)) { all = false; break; }
+    if (all) { for (const UvolUpItem &it : items) if (it.bytes) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(dev_base + it.dev_off, it.src, it.bytes, hipMemcpyHostToDevice, ctx->stream)); return UVOL_OK; } }
   const size_t total = items.back().dev_off + items.back().bytes;
   const size_t CH = (size_t)128 << 20;
   if (total < ((size_t)4 << 20)) {                                           // small batches: the runtime's own path

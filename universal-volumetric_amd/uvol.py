@@ -39,7 +39,8 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
            "uvol_encode_mesh_batch_dev", "uvol_encode_mesh_batch_dev_out", "uvol_decode_mesh_batch_dev", "uvol_parse_obj_batch_dev", "uvol_unfilter_png_batch_dev", "uvol_encode_mesh_batch_async", "uvol_encode_mesh_batch_dev_async", "uvol_encode_texture_segments_async", "uvol_encode_texture_segments_dev_async", "uvol_texture_bound", "uvol_encode_texture_segment",
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_etc2_rgba", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
-           "uvol_profile_get"]
+           "uvol_profile_get", "uvol_encode_texture_segments_st", "uvol_transcode_texture_segments_st",
+           "uvol_host_alloc", "uvol_host_free"]
 
 
 def load(path=None):
@@ -73,6 +74,11 @@ def load(path=None):
     L.uvol_transcode_texture_segments_bc7.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_transcode_texture_segments_astc.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
     L.uvol_transcode_texture_segments_etc2_rgba.argtypes = L.uvol_transcode_texture_segments_etc1.argtypes
+    L.uvol_encode_texture_segments_st.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    L.uvol_transcode_texture_segments_st.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.uvol_host_alloc.argtypes = [C.c_size_t]; L.uvol_host_alloc.restype = C.c_void_p
+    L.uvol_host_free.argtypes = [C.c_void_p]
     L.uvol_drc_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_decode_mesh_batch_dev.argtypes = L.uvol_decode_mesh_batch.argtypes
@@ -89,6 +95,32 @@ def load(path=None):
 
 class UvolError(RuntimeError):
     pass
+
+
+class PinnedArena:
+    """Page-locked host memory from uvol_host_alloc, handed out as numpy arrays (the arrays must not outlive the arena).  Inputs that ALL lie
+    in such memory are uploaded without the library's staging copy."""
+
+    def __init__(self, nbytes, lib_path=None):
+        self.L = load(lib_path); self.n = int(nbytes); self.off = 0
+        self.p = self.L.uvol_host_alloc(self.n)
+        if not self.p:
+            raise UvolError(f"uvol_host_alloc({self.n}) failed")
+        self.buf = (C.c_uint8 * self.n).from_address(self.p)
+
+    def put(self, a):
+        a = np.ascontiguousarray(a); nb = a.nbytes; o = (self.off + 255) & ~255
+        if o + nb > self.n:
+            raise UvolError("pinned arena full")
+        v = np.frombuffer(self.buf, dtype=a.dtype, count=a.size, offset=o).reshape(a.shape)
+        v[...] = a; self.off = o + nb
+        return v
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.buf = None; self.L.uvol_host_free(self.p); self.p = None
+
+    __del__ = close
 
 
 def _f32(a, cols):
@@ -335,6 +367,44 @@ class Codec:
         """dev_ptrs: flat list of n_segments*n_layers device pointers."""
         ptrs = (C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs])
         return self._run_tex_batch(self.L.uvol_encode_texture_segments_dev, ptrs, len(dev_ptrs) // n_layers, n_layers, width, height)
+
+    def encode_texture_segments_status(self, segments, caps=None):
+        """Per-segment results (uvol_encode_texture_segments_st): -> (list of .ktx2 bytes or None, list of status codes).  caps: optional
+        output capacities per segment (tests: a too-small one fails alone with UVOL_E_NOSPACE)."""
+        arrs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in seg] for seg in segments]
+        h, w = arrs[0][0].shape[:2]; nl = len(arrs[0]); nseg = len(arrs)
+        flat = [a for seg in arrs for a in seg]
+        ptrs = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
+        cap = self.L.uvol_texture_bound(w, h, nl)
+        cl = [cap] * nseg if caps is None else [int(c) for c in caps]
+        bufs = [np.empty(max(c, 1), dtype=np.uint8) for c in cl]
+        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs]); capa = (C.c_size_t * nseg)(*cl); lens = (C.c_size_t * nseg)(); st = (C.c_int * nseg)()
+        rc = self.L.uvol_encode_texture_segments_st(self.h, ptrs, nseg, nl, w, h, 0, outs, capa, lens, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_texture_segments_st rc={rc}: {self.error()}")
+        return [bufs[i][:lens[i]].tobytes() if st[i] == UVOL_OK else None for i in range(nseg)], list(st)
+
+    TARGETS = {"rgba32": (0, 4, False), "etc1": (1, 8, True), "bc7": (2, 16, True), "astc": (3, 16, True), "etc2_rgba": (4, 16, True)}
+
+    def transcode_texture_segments_status(self, files, target="rgba32", shape=None):
+        """Per-segment results and mixed batches (uvol_transcode_texture_segments_st): files may mix ETC1S and UASTC sources and contain
+        unreadable or corrupt ones -> (list of arrays or None, list of status codes).  shape = (w, h, layers) if the first file is not readable."""
+        files = [bytes(f) for f in files]; n = len(files)
+        code, unit, blocks = self.TARGETS[target]
+        if shape is None:
+            for f in files:
+                try:
+                    shape = self.ktx2_info(f); break
+                except UvolError:
+                    continue
+        w, h, nl = shape; bx, by = (w + 3) // 4, (h + 3) // 4
+        outs = [np.zeros((nl, by, bx, unit) if blocks else (nl, h, w, 4), dtype=np.uint8) for _ in range(n)]
+        fp = (C.c_char_p * n)(*files); ln = (C.c_size_t * n)(*[len(f) for f in files]); st = (C.c_int * n)()
+        ptrs = (C.c_void_p * (n * nl))(*[outs[s][l].ctypes.data for s in range(n) for l in range(nl)])
+        rc = self.L.uvol_transcode_texture_segments_st(self.h, fp, ln, n, ptrs, bx * by * unit if blocks else w * h * 4, 0, code, st)
+        if rc != UVOL_OK:
+            raise UvolError(f"transcode_texture_segments_st rc={rc}: {self.error()}")
+        return [outs[i] if st[i] == UVOL_OK else None for i in range(n)], list(st)
 
     def _run_tex_batch(self, fn, ptrs, nseg, nl, w, h):
         cap = self.L.uvol_texture_bound(w, h, nl)
