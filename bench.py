@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
+    ap.add_argument("--host-pinned", action="store_true", help="with --host-inputs: the input arrays lie in uvol_host_alloc (page-locked) memory")
     ap.add_argument("--host-enqueued", action="store_true", help="with --host-inputs: the passes go through the enqueue forms (uvol_*_async on host buffers, one uvol_sync)")
     args = ap.parse_args()
 
@@ -158,16 +159,32 @@ def main():
     texs = [uvol.Codec(device=local_rank, **tcfg) for _ in range(max(1, args.tex_streams))]
     out = {}
 
+    _pin = {}
+
+    def pinned_inputs():
+        """The synthetic frames and the texture layers once more, in page-locked host memory (uvol_host_alloc)."""
+        if not _pin:
+            need = sum(v.nbytes + 256 for m in meshes_h for v in m.values()) + sum(t.nbytes + 256 for t in tex_h) + (1 << 20)
+            ar = uvol.PinnedArena(need)
+            _pin["arena"] = ar
+            _pin["m"] = [{k: ar.put(v) for k, v in m.items()} for m in meshes_h]
+            _pin["t"] = [ar.put(t) for t in tex_h]
+        return _pin["m"], _pin["t"]
+
     class Job:
         """One pass over the first n frames / n // B segments of the resident inputs (n = F for the headline; the variants run
         smaller jobs on the same contexts and buffers)."""
-        def __init__(self, n, host=False, only=args.only, blocking=False, host_enqueued=False):
+        def __init__(self, n, host=False, only=args.only, blocking=False, host_enqueued=False, pinned=False):
             self.n, self.nseg, self.host, self.only, self.blocking = n, n // B, host, only, blocking or args.blocking_calls
+            self.tex_h = tex_h
+            if host and pinned:                                  # the caller's arrays in uvol_host_alloc memory: no staging copy inside the library
+                pm, pt = pinned_inputs()
+                self.tex_h = pt
             self.host_enqueued = host and host_enqueued         # host inputs through the enqueue forms (uvol_*_async on host buffers + uvol_sync)
             self.gsl = [(gi * n // GS, (gi + 1) * n // GS) for gi in range(GS)]
             nd = len(dev_meshes)
             self.gb = None if host else [(uvol.Mesh * (b - a))(*[dev_meshes[i % nd] for i in range(a, b)]) for a, b in self.gsl]
-            self.hf = [meshes_h[i % ND] for i in range(n)] if host else None
+            self.hf = [(pm if (host and pinned) else meshes_h)[i % ND] for i in range(n)] if host else None
 
         def run_geo_passes(self, gi, kk):
             """kk passes of this geometry stream.  Device inputs: the passes are ENQUEUED (uvol_encode_mesh_batch_dev_async) and completed
@@ -205,7 +222,7 @@ def main():
             if not len(segs):
                 out["ktx2_%d" % ti] = []
             elif self.host:
-                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([tex_h] * len(segs))
+                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([self.tex_h] * len(segs))
             else:
                 out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev([p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]], B, args.tex_size, args.tex_size)
 
@@ -225,7 +242,7 @@ def main():
                     segs = range(arg, self.nseg, len(texs))
                     if len(segs):
                         for _ in range(kk):
-                            texs[arg].start_texture_segments([tex_h] * len(segs))
+                            texs[arg].start_texture_segments([self.tex_h] * len(segs))
                         out["ktx2_%d" % arg] = texs[arg].finish()[-1]
                         return
                 for _ in range(kk):
@@ -268,7 +285,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    main_job = Job(F, host=args.host_inputs, host_enqueued=args.host_enqueued)
+    main_job = Job(F, host=args.host_inputs, host_enqueued=args.host_enqueued, pinned=args.host_pinned)
     if args.warmup:
         main_job.steps(args.warmup)
     set_profiling(True)
@@ -427,6 +444,8 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers; "
                                                                    "one blocking call per pass and half; enqueued_passes: the same passes through uvol_*_async + uvol_sync (a pass uploads while its predecessor encodes)")
+    note("host_inputs pinned")
+    v["host_inputs"]["pinned"] = dict(Job(nh, host=True, pinned=True).timed(2, 1), note="the same with every input array in uvol_host_alloc memory: DMA from where the arrays lie, no staging copy")
     note("host_inputs enqueued")
     v["host_inputs"]["enqueued_passes"] = Job(nh, host=True, host_enqueued=True).timed(3, 1)["frames_per_s"]
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)

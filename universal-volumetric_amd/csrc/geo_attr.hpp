@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_pred_pos(GeoJob *jobs) {
       const int vv[3] = { v3.x, v3.y, v3.z };
       const uint32_t a = (uint32_t)v2d[vv[j]], bn = (uint32_t)v2d[vv[(j + 1) % 3]], bp = (uint32_t)v2d[vv[(j + 2) % 3]];
       if (a < p && bn < p && bp < p) {
-        const uvol_s3 c3 = *reinterpret_cast<const uvol_s3 *>(J.cp + fo);
+        const uvol_s3 c3 = J.extra_v ? *reinterpret_cast<const uvol_s3 *>(J.cp + fo) : v3;       // (no non-manifold vertex: vertex ids ARE position ids)
         const int cc[3] = { c3.x, c3.y, c3.z };
         const GQ3 qa = gq_pos(J, cc[j]), qn = gq_pos(J, cc[(j + 1) % 3]), qp = gq_pos(J, cc[(j + 2) % 3]);
         pred[0] = (long long)qn.x + qp.x - qa.x; pred[1] = (long long)qn.y + qp.y - qa.y; pred[2] = (long long)qn.z + qp.z - qa.z;

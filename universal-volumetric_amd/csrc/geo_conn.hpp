@@ -11,6 +11,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_face_time(GeoJob *jobs) {
   if (i < (uint32_t)J.nsym) { const int c = J.proc[i]; J.face_time[c / 3] = (int32_t)i; J.tstart[J.nsym - 1 - (int)i] = code_of_corner(c); }
   if (i < (uint32_t)J.ninit) { const int c = J.initc[i]; J.face_time[c / 3] = -(int32_t)i - 2; J.tstart[J.nsym + (int)i] = code_of_corner(c); }
 }
+__device__ __forceinline__ int att_vertex(const GeoJob &J, int slot, int c);
 // the vertex field of corner c in the record table of traversal table t (any format)
 __device__ __forceinline__ int rec_vertex_field(const GeoJob &J, int t, int c, int r8) {
   if (r8 == 2) { const uint32_t *q = reinterpret_cast<const uint32_t *>(J.rec[1 + t]) + 4 * (size_t)(c / 3); return (int)((uint32_t)((((uint64_t)q[1] << 32) | q[0]) >> (21 * (c % 3))) & 0x1fffffu); }
@@ -32,9 +33,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_v2d(GeoJob *jobs, int r8) {
   if (J.qpos) for (int k = 0; k < J.nad; k++) if (J.att_kind[k] == 0 && (J.interior_seams[k] ? t == 1 + k : t == 0)) iu = k;
   if (i < J.ne[t]) {
     const int c = J.order[t][i];
-    J.v2d[t][rec_vertex_field(J, t, c, r8) >> 1] = (int32_t)i;
+    // the vertex of the entry's corner: out of the record table on the decode path; on the encode side from the stored corner table (one
+    // 4-byte gather that table 0 shares with the position id, instead of a 16-byte record per entry)
+    int vid, pid = 0;
+    if (!J.qpos) vid = rec_vertex_field(J, t, c, r8) >> 1;
+    else if (t == 0) { pid = J.cp[c]; vid = J.extra_v ? J.vert[c] : pid; }
+    else vid = att_vertex(J, t - 1, c);
+    J.v2d[t][vid] = (int32_t)i;
     if (J.qpos && t == 0) {
-      const uint16_t *q = J.qpos + 4 * (size_t)J.cp[c];
+      const uint16_t *q = J.qpos + 4 * (size_t)pid;
       for (int k = 0; k < 3; k++) { const int v = q[k]; lo0 = v < lo0 ? v : lo0; hi0 = v > hi0 ? v : hi0; }
     }
     if (iu >= 0) {
@@ -246,8 +253,10 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_seams(GeoJob *jobs) {
     for (int k = 0; k < 3; k++) {
       uint32_t sm = 1;
       if (opp_[k] >= 0) {
-        const int oo = opp_[k];
-        sm = (a[(k + 1) % 3] != A[g_prv(oo)] || a[(k + 2) % 3] != A[g_nxt(oo)]) ? 1u : 0u;
+        const int oo = opp_[k], fo = 3 * (oo / 3), jo = oo - fo;
+        const uvol_s3 b3 = *reinterpret_cast<const uvol_s3 *>(A + fo);     // the neighbour's three ids in one gather
+        const int b[3] = { b3.x, b3.y, b3.z };
+        sm = (a[(k + 1) % 3] != b[(jo + 2) % 3] || a[(k + 2) % 3] != b[(jo + 1) % 3]) ? 1u : 0u;
         if (sm) {                                                         // both ends of the edge get split
           any = true;
           const uint32_t va = (uint32_t)geo_vt(J)[3 * f + (k + 1) % 3], vb = (uint32_t)geo_vt(J)[3 * f + (k + 2) % 3];

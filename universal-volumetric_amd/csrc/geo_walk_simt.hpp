@@ -538,227 +538,7 @@ __global__ void __launch_bounds__(64) k_traverse_wave_f16(GeoJob *jobs, int n, i
   const int t = t0 + (int)blockIdx.y;
   if (t == 0 && base_hi) traverse_wave_f16<3>(jobs, n, W, t); else traverse_wave_f16<1>(jobs, n, W, t);
 }
-
-// ------------------------------------------------------------------------------------------------
-// Cooperative form on per-face records (round 5): ONE walker per wave, the wave works as a team like the LDS walkers of small batches
-// (geo_traverse_lds.hpp: traverse_coop, 0.37 us per face against the 0.75 - 0.85 us of every lane-per-walker form, whatever its lanes
-// per wave: a lane-per-walker step is a chain of ~100 DEPENDENT instructions, and a lone wave issues a dependent instruction every
-// ~10 cycles) - but nothing lives in LDS, so the number of walkers is not capped by it: lane 0 fetches the right neighbour's record,
-// lane 1 the left one's (their visited flags come with them), lane 2 the tip vertex's bitmap word; one ballot gives the case as a scalar
-// mask, the walker's state (corner, record, cursors) is wave-uniform and lives in SGPRs, the record the walk moves to is picked with
-// v_readlane, the order entries collect in a VGPR (lane k = entry k of the current 64) and leave as one 256-byte store.
-// ------------------------------------------------------------------------------------------------
-struct uvol_q4 { uint32_t x, y, z, w; };
-template <int FD> __device__ __forceinline__ bool q4_seen(const uvol_q4 &q) { return ((FD == 1 ? q.y : q.w) >> 31) != 0; }
-__device__ __forceinline__ void q4_dec(const uvol_q4 &q, int k, int &vi, int &rc, int &lc) {
-  const uint64_t lo = (uint64_t)q.x | ((uint64_t)q.y << 32), hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
-  const int s = 21 * k, sr = k == 2 ? 0 : s + 21, sl = k == 0 ? 42 : s - 21;
-  vi = (int)((uint32_t)(lo >> s) & 0x1fffffu);
-  rc = (int)((uint32_t)(hi >> sr) << 11) >> 11;
-  lc = (int)((uint32_t)(hi >> sl) << 11) >> 11;
-}
-// the record of `face`, the same in every lane (one lane's load, broadcast: the walker's state stays scalar)
-__device__ __forceinline__ uvol_q4 q4_load_uniform(UVOL_G(uint32_t) rec, int face) {
-  const uvol_u4 r = f16_load(rec, face);
-  uvol_q4 q; q.x = (uint32_t)UVOL_BCAST0(r.x); q.y = (uint32_t)UVOL_BCAST0(r.y); q.z = (uint32_t)UVOL_BCAST0(r.z); q.w = (uint32_t)UVOL_BCAST0(r.w);
-  return q;
-}
-template <int FD>
-__device__ __forceinline__ void traverse_coop_f16(GeoJob &J, int t) {
-  const int lane = (int)(threadIdx.x & 63);
-  const int nf = (int)J.nf;
-  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[1 + t]));
-  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.t_vvis[t]));
-  UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.t_stack[t]); UVOL_G(int32_t) order = UVOL_TO_G(int32_t, J.order[t]);
-  UVOL_G(const int32_t) tstart = UVOL_TO_G(const int32_t, J.tstart);
-  const bool virt = J.tstart != nullptr;
-  const int stcap = J.stcap ? (int)J.stcap : 0x7fffffff;
-  uint32_t ov = 0;                                         // staged order[] entries: lane k = entry (n & ~63) + k
-  int n = 0, nvis = 0, f = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
-  uvol_q4 q; q.x = q.y = q.z = q.w = 0;
-  bool fail = false;
-#define CF_EMIT(C) do { ov = UVOL_WRITELANE((C), n & 63, ov); n++; if ((n & 63) == 0) order[n - 64 + lane] = (int32_t)ov; } while (0)
-  for (;;) {
-    if (x < 0) {
-      if (sp > 0) {                                       // a pending left neighbour: taken unless it was visited meanwhile
-        const int c = UVOL_BCAST0(stack[sp - 1]);
-        sp--;
-        const uvol_q4 qq = q4_load_uniform(rec, c >> 2);
-        if (q4_seen<FD>(qq)) continue;
-        x = c; q = qq; q4_dec(q, x & 3, vi, rc, lc);
-      } else {                                            // the next component: the first unvisited face in decoder order, 64 candidates per round trip
-        if (nvis >= nf) break;
-        int x0 = -1;
-        while (f < nf) {
-          const int fk = f + lane;
-          int xs = -1; uint32_t y = 0x80000000u;
-          if (fk < nf) { xs = virt ? tstart[fk] : 4 * fk; y = rec[4 * (size_t)(xs >> 2) + FD]; }
-          const unsigned long long m = __ballot((y >> 31) == 0);
-          if (m) { const int k0 = (int)__ffsll((long long)m) - 1; x0 = (int)UVOL_READLANE(xs, k0); f += k0 + 1; break; }
-          f += 64;
-        }
-        if (x0 < 0) break;
-        const uvol_q4 q0 = q4_load_uniform(rec, x0 >> 2);
-        const int xn = code_nxt(x0), xp = code_prv(x0);
-        int vn, vp, r_, l_; q4_dec(q0, xn & 3, vn, r_, l_); q4_dec(q0, xp & 3, vp, r_, l_); vn >>= 1; vp >>= 1;
-        uint32_t w = (uint32_t)UVOL_BCAST0(vbits[vn >> 5]);
-        if (!((w >> (vn & 31)) & 1u)) { if (lane == 0) vbits[vn >> 5] = w | (1u << (vn & 31)); CF_EMIT(corner_of_code(xn)); }
-        w = (uint32_t)UVOL_BCAST0(vbits[vp >> 5]);
-        if (!((w >> (vp & 31)) & 1u)) { if (lane == 0) vbits[vp >> 5] = w | (1u << (vp & 31)); CF_EMIT(corner_of_code(xp)); }
-        UVOL_WAVE_SYNC();                                 // (lane 2 reads these words in the steps: in order on the GPU, a rendezvous in the host emulation)
-        x = x0; q = q0; q4_dec(q, x & 3, vi, rc, lc);
-      }
-    }
-    // ---- one step on face x (record q): every lane has its part ----
-    const int face = x >> 2;
-    const int cand = lane == 0 ? rc : lc;
-    const int cface = cand >= 0 ? cand >> 2 : nf;          // (no neighbour: the dummy face, visited)
-    uvol_u4 pre; pre.x = pre.y = pre.z = pre.w = 0x80000000u;
-    if (lane < 2) pre = f16_load(rec, cface);
-    const int v = vi >> 1;
-    uint32_t vw = 0;
-    if (lane == 2) vw = vbits[v >> 5];
-    if (lane == 0) rec[4 * (size_t)face + FD] = (FD == 1 ? q.y : q.w) | 0x80000000u;
-    const bool hit = lane < 2 ? ((FD == 1 ? pre.y : pre.w) >> 31) != 0 : (lane == 2 && ((vw >> (v & 31)) & 1u) != 0);
-    const uint32_t m = (uint32_t)__ballot(hit) & 7u;
-    if (lane == 2 && !hit) vbits[v >> 5] = vw | (1u << (v & 31));
-    nvis++;
-    // a vertex seen for the first time takes the next place in the order (the slot is simply overwritten otherwise)
-    ov = UVOL_WRITELANE(3 * face + (x & 3), n & 63, ov);
-    const int fresh = (int)((m >> 2) & 1u) ^ 1;
-    n += fresh;
-    if (fresh && (n & 63) == 0) order[n - 64 + lane] = (int32_t)ov;
-    const bool ccase = (((m >> 2) | (uint32_t)vi) & 1u) == 0;
-    const uint32_t k = ccase ? 0u : 1u + (m & 3u);          // 0: go right (new interior vertex); 1: fork; 2: right visited -> left; 3: left visited -> right; 4: dead end
-    if (k == 4u) { x = -1; continue; }
-    if (k == 1u) { if (lane == 0) stack[sp] = lc; sp++; UVOL_WAVE_FENCE(); if (sp > stcap) { fail = true; break; } }
-    const int sel = k == 2u ? 1 : 0;
-    x = sel ? lc : rc;
-    q.x = UVOL_READLANE(pre.x, sel); q.y = UVOL_READLANE(pre.y, sel); q.z = UVOL_READLANE(pre.z, sel); q.w = UVOL_READLANE(pre.w, sel);
-    q4_dec(q, x & 3, vi, rc, lc);
-  }
-#undef CF_EMIT
-  if (lane < (n & 63)) order[(n & ~63) + lane] = (int32_t)ov;
-  if (lane == 0) {
-    if (fail) J.status = GEO_E_WS_OVERFLOW;
-    else {
-      J.ne[t] = (uint32_t)n;
-      if (t == 0 && J.nverts != 0xffffffffu && (uint32_t)n != J.nverts) J.status = -11;      // (the decode path has no expected count)
-    }
-  }
-}
-// grid (frames, tables): one wave per (frame, table t0 + blockIdx.y)
-__global__ void __launch_bounds__(64) k_traverse_coop_f16(GeoJob *jobs, int t0, int base_hi) {
-  GeoJob &J = jobs[blockIdx.x];
-  const int t = t0 + (int)blockIdx.y, ai = t > 0 ? t - 1 : 0;
-  if (J.status != 0 || (t > 0 && (ai >= J.nad || !J.interior_seams[ai]))) return;       // (uniform)
-  if (t == 0 && base_hi) traverse_coop_f16<3>(J, t); else traverse_coop_f16<1>(J, t);
-}
-
-// The edgebreaker walk in the cooperative form (see traverse_coop_f16): one walker per wave, lane 0 / 1 fetch the right / left neighbour's
-// record, lane 2 the tip vertex's word, the case is one ballot; processed corners and symbols collect in two VGPRs (lane k = entry k of
-// the current 64) and leave as one 256-byte and one 64-byte store.  The start of a component (interior / boundary configuration, the
-// swing to the boundary edge) runs wave-uniformly on broadcast loads.
-__device__ __forceinline__ void eb_walk_coop_f16(GeoJob &J) {
-  const int lane = (int)(threadIdx.x & 63);
-  const int nf = (int)J.nf;
-  UVOL_G(uint32_t) rec = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.rec[0]));
-  UVOL_G(uint32_t) vbits = UVOL_TO_G(uint32_t, reinterpret_cast<uint32_t *>(J.vvis));
-  UVOL_G(int32_t) proc = UVOL_TO_G(int32_t, J.proc); UVOL_G(int32_t) stack = UVOL_TO_G(int32_t, J.stack); UVOL_G(int32_t) initc = UVOL_TO_G(int32_t, J.initc);
-  UVOL_G(uint8_t) symb = UVOL_TO_G(uint8_t, J.symb); UVOL_G(uint8_t) start_bits = UVOL_TO_G(uint8_t, J.start_bits);
-  const bool rl = J.relabel != 0; UVOL_G(const int32_t) s_of_o = UVOL_TO_G(const int32_t, J.s_of_o);
-  const int stcap = (int)J.stcap;
-  uint32_t ov = 0, os = 0;                                 // staged proc[] / symb[] entries: lane k = entry (nproc & ~63) + k
-  int nproc = 0, ninit = 0, nstart = 0, nsplit = 0, fo = 0, sp = 0, x = -1, vi = 0, rc = -1, lc = -1;
-  uvol_q4 q; q.x = q.y = q.z = q.w = 0;
-  bool fail = false;
-  for (;;) {
-    if (x < 0) {
-      if (sp > 0) {                                       // a pending left neighbour: taken unless it was visited meanwhile
-        const int c = UVOL_BCAST0(stack[sp - 1]);
-        sp--;
-        const uvol_q4 qq = q4_load_uniform(rec, c >> 2);
-        if (q4_seen<1>(qq)) continue;
-        x = c; q = qq; q4_dec(q, x & 3, vi, rc, lc);
-      } else {                                            // the next component starts at the first unvisited face in the ORIGINAL face order
-        if (nproc + ninit >= nf) break;
-        int f0 = -1;
-        while (fo < nf) {
-          const int fk = fo + lane;
-          int fs = -1; uint32_t y = 0x80000000u;
-          if (fk < nf) { fs = rl ? s_of_o[fk] : fk; y = rec[4 * (size_t)fs + 1]; }
-          const unsigned long long m = __ballot((y >> 31) == 0);
-          if (m) { const int k0 = (int)__ffsll((long long)m) - 1; f0 = (int)UVOL_READLANE(fs, k0); fo += k0 + 1; break; }
-          fo += 64;
-        }
-        if (f0 < 0) break;
-        const uvol_q4 q0 = q4_load_uniform(rec, f0);
-        int v0[3], r0_[3], l0_[3];
-        for (int k = 0; k < 3; k++) q4_dec(q0, k, v0[k], r0_[k], l0_[k]);
-        const int o0[3] = { r0_[2], r0_[0], r0_[1] };                       // opposite(k) = right field of corner (k + 2) % 3
-        int interior = 1, start = 4 * f0;
-        for (int k = 0; k < 3; k++) {
-          if (o0[k] < 0) { interior = 0; start = 4 * f0 + k; break; }
-          if (v0[k] & 1) {                // boundary vertex: swing right to the boundary edge
-            int ci = 4 * f0 + k, rr = ci;
-            while (rr >= 0) { ci = rr; int v_, r_, l_; q4_dec(q4_load_uniform(rec, rr >> 2), rr & 3, v_, r_, l_); rr = l_ < 0 ? -1 : code_prv(l_); }      // left field = opposite(prev): swing right
-            interior = 0; start = code_prv(ci); break;
-          }
-        }
-        if (lane == 0) start_bits[nstart] = (uint8_t)interior;
-        nstart++;
-        int from = start;
-        if (interior) {
-          for (int k = 0; k < 3; k++) { const int v = v0[k] >> 1; const uint32_t w = (uint32_t)UVOL_BCAST0(vbits[v >> 5]); if (lane == 0) vbits[v >> 5] = w | (1u << (v & 31)); }
-          if (lane == 0) { rec[4 * (size_t)f0 + 1] = q0.y | 0x80000000u; initc[ninit] = 3 * f0 + 1; }
-          ninit++;
-          from = o0[1];
-          UVOL_WAVE_SYNC();
-          if (from >= 0 && q4_seen<1>(q4_load_uniform(rec, from >> 2))) from = -1;
-        }
-        UVOL_WAVE_SYNC();                                 // (lane 2 reads the vertex words in the steps: in order on the GPU, a rendezvous in the host emulation)
-        if (from < 0) continue;
-        x = from; q = q4_load_uniform(rec, x >> 2); q4_dec(q, x & 3, vi, rc, lc);
-      }
-    }
-    // ---- one step on face x (record q): every lane has its part ----
-    const int face = x >> 2;
-    const int cand = lane == 0 ? rc : lc;
-    const int cface = cand >= 0 ? cand >> 2 : nf;          // (no neighbour: the dummy face, visited)
-    uvol_u4 pre; pre.x = pre.y = pre.z = pre.w = 0x80000000u;
-    if (lane < 2) pre = f16_load(rec, cface);
-    const int v = vi >> 1;
-    uint32_t vw = 0;
-    if (lane == 2) vw = vbits[v >> 5];
-    if (lane == 0) rec[4 * (size_t)face + 1] = q.y | 0x80000000u;
-    const bool hit = lane < 2 ? (pre.y >> 31) != 0 : (lane == 2 && ((vw >> (v & 31)) & 1u) != 0);
-    const uint32_t m = (uint32_t)__ballot(hit) & 7u;
-    if (lane == 2 && !hit) vbits[v >> 5] = vw | (1u << (v & 31));
-    const bool ccase = (((m >> 2) | (uint32_t)vi) & 1u) == 0;                // tip unvisited and not on a boundary
-    const uint32_t sym = ccase ? 0u : 1u + 2u * ((m >> 1) & 1u) + 4u * (m & 1u);      // C 0, S 1, L 3, R 5, E 7
-    ov = UVOL_WRITELANE(3 * face + (x & 3), nproc & 63, ov); os = UVOL_WRITELANE(sym, nproc & 63, os);
-    nproc++;
-    if ((nproc & 63) == 0) { proc[nproc - 64 + lane] = (int32_t)ov; symb[nproc - 64 + lane] = (uint8_t)os; }
-    if (sym == 7u) { x = -1; continue; }
-    if (sym == 1u) { if (lane == 0) stack[sp] = lc; sp++; nsplit++; UVOL_WAVE_SYNC(); if (sp > stcap) { fail = true; break; } }      // S: the left neighbour waits, the walk goes right
-    const int sel = sym == 5u ? 1 : 0;
-    x = sel ? lc : rc;
-    q.x = UVOL_READLANE(pre.x, sel); q.y = UVOL_READLANE(pre.y, sel); q.z = UVOL_READLANE(pre.z, sel); q.w = UVOL_READLANE(pre.w, sel);
-    q4_dec(q, x & 3, vi, rc, lc);
-  }
-  if (lane < (nproc & 63)) { proc[(nproc & ~63) + lane] = (int32_t)ov; symb[(nproc & ~63) + lane] = (uint8_t)os; }
-  UVOL_WAVE_SYNC();
-  if (lane == 0) {
-    if (fail) { J.status = GEO_E_WS_OVERFLOW; return; }
-    J.nsym = nproc; J.nsplit = nsplit; J.nstart = nstart; J.ninit = ninit;
-    if (nproc + ninit != nf) J.status = -10;
-    J.rb[0].n = (uint32_t)nstart;
-    uint32_t z = 0; for (int i = 0; i < nstart; i++) z += start_bits[i] == 0;
-    J.rb[0].zeros = z;
-  }
-}
-__global__ void __launch_bounds__(64) k_eb_walk_coop_f16(GeoJob *jobs) {
-  GeoJob &J = jobs[blockIdx.x];
-  if (J.status != 0) return;
-  eb_walk_coop_f16(J);
-}
+// (Measured in round 5 and removed, docs/HISTORY.md: a cooperative form of both walkers on per-face records - one walker per wave, lanes 0 / 1
+// fetch the neighbours' records, lane 2 the vertex word, state in SGPRs like the LDS walkers of small batches - with the flags in the
+// records and the vertex bits in global memory: 0.69 us per face at 320 frames, 1.3 us at 2560 (one scalar unit per CU), against 0.32 us
+// for the LDS walk: what makes the LDS walkers fast is that nothing they test per step has to come from L2, not the division of labour.)

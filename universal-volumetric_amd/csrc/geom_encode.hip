@@ -431,9 +431,7 @@ static void launch_traversals(uvol_ctx *ctx, GeoJob *dj, int n, const WalkPlan &
     // (k_traverse_wave_f16: pops as ordinary steps, component search by the whole wave), UVOL_TRAV_W lanes per wave
     static const bool lane_form = [] { const char *e = getenv("UVOL_TRAV_FORM"); return e && !strcmp(e, "lane"); }();
     static const int wave_w = [] { const char *e = getenv("UVOL_TRAV_W"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
-    static const bool coop_form = [] { const char *e = getenv("UVOL_TRAV_FORM"); return e && !strcmp(e, "coop"); }();
-    if (r8 == 2 && coop_form) LAUNCH(k_traverse_coop_f16, dim3(N, 3), dim3(64), dj, 0, base_hi);
-    else if (r8 == 2 && !lane_form) { const unsigned Ww = wave_w ? (unsigned)wave_w : W; LAUNCH(k_traverse_wave_f16, dim3((N + Ww - 1) / Ww, 3), dim3(64), dj, n, (int)Ww, 0, base_hi); }
+    if (r8 == 2 && !lane_form) { const unsigned Ww = wave_w ? (unsigned)wave_w : W; LAUNCH(k_traverse_wave_f16, dim3((N + Ww - 1) / Ww, 3), dim3(64), dj, n, (int)Ww, 0, base_hi); }
     else if (r8 == 2) LAUNCH(k_traverse_simt_f16, dim3(nb), dim3(64), dj, n, (int)W, 0, 3);
     else if (r8) LAUNCH((k_traverse_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_traverse_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
   }
@@ -448,8 +446,8 @@ int geo_run_traversals(uvol_ctx *ctx, GeoJob *dj, int n, uint32_t max_nfi, uint3
   WalkPlan P = walk_plan(G, max_nfi, max_vals, (size_t)3 * N);
   // files of a batch are unrelated meshes as far as the decoder knows: one traverser per wave (several per wave pay for each other's
   // rare paths and misses: 953 against 293 ms per 2560 distinct frames with 16 / 1), and one 16-byte record per face where the fields allow it
-  if (P.simt_w > 1 && geo_simt_env() == 0) P.simt_w = 1;
   const int r8 = geo_records8(max_nfi) ? ((P.simt_w && !geo_rec_face_off()) ? 2 : 1) : 0;
+  if (P.simt_w > 1 && geo_simt_env() == 0) P.simt_w = r8 == 2 ? 4 : 1;      // (four per wave in the wave form on per-face records)
   for (int w = 1; w <= 3; w++) LAUNCH(k_pack_faces, dim3(bf, N), dim3(UVOL_BLOCK), dj, w, r8);
   launch_traversals(ctx, dj, n, P, r8);
   LAUNCH(k_v2d, dim3(bc, N, 3), dim3(UVOL_BLOCK), dj, r8);
@@ -766,9 +764,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) {
       const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
-      static const bool walk_coop = [] { const char *e = getenv("UVOL_WALK_FORM"); return e && !strcmp(e, "coop"); }();
-      if (fmt0 == 2 && walk_coop) LAUNCH(k_eb_walk_coop_f16, dim3(N), dim3(64), dj);
-      else if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
+      if (fmt0 == 2) LAUNCH(k_eb_walk_simt_f16, dim3(nb), dim3(64), dj, n, (int)W);
       else if (r8) LAUNCH((k_eb_walk_simt<true>), dim3(nb), dim3(64), dj, n, (int)W); else LAUNCH((k_eb_walk_simt<false>), dim3(nb), dim3(64), dj, n, (int)W);
     }
     else if (r8) LAUNCH_SM((k_eb_walk<true>), dim3(N), dim3(128), wp_walk.lds, dj, wp_walk.vcw, geo_walk_pf());
@@ -812,7 +808,9 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): LDS traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
-    if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = 1;      // unrelated meshes: one traverser per wave
+    // unrelated meshes: FOUR traversers per wave in the wave form (3488 / 3709 / 3950 / 3993 / 3942 / 3696 frames/s geometry alone with the lane
+    // form at 1 and the wave form at 1 / 2 / 4 / 8 / 16 per wave, 2560 distinct frames: profiles/r05_walker_forms.json)
+    if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = fmtT == 2 ? 4 : 1;
     if (w_trav_env && wp_trav.simt_w) wp_trav.simt_w = w_trav_env;
     launch_traversals(ctx, dj, n, wp_trav, fmtT, base_shared ? 1 : 0);
   }
