@@ -225,6 +225,11 @@ int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *kt
  * weights (endpoint error <= 1, inner colours to the nearest weight); gated by PSNR against the RGBA32 decode, not bit parity. */
 int uvol_transcode_texture_segments_bc7(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                         uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
+/* UASTC sources (round 5): BC7 is what the stock loader asks a UASTC file for wherever ASTC is not supported - every desktop GPU
+ * (reference src/lib/KTX2Loader.js:601-609, chosen at :665-676).  Single-plane blocks and solid blocks become mode 6 (each endpoint with
+ * the p-bit that represents its four values best, every texel the nearest of the 16 interpolated colours), dual-plane blocks mode 5 with
+ * the rotation that puts the second plane's channel into the scalar slot (UASTC's and BC7's 2-bit weights are equal).  A re-fit of the
+ * block's own endpoints, gated by PSNR against the RGBA32 decode like the ETC1S case - the basis transcoder's tables are not restated. */
 /* Files WITH alpha slices (images whose alpha was not 255; reference src/lib/KTX2Loader.js:493-497 reads them): the stock loader asks
  * such a file for the SECOND format of its table (:672-676) - BC7 with alpha or ETC2 RGBA.  uvol_transcode_texture_segments_bc7 then
  * writes mode-5 blocks whose alpha endpoints are the alpha block's lowest / highest level (exact) with 2-bit alpha indices;
@@ -252,8 +257,8 @@ int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *kt
  *
  * uvol_transcode_texture_segments_st: every decode / transcode target through one entry point.  Files are judged one by one: an
  * unreadable container (UVOL_E_INVALID / UVOL_E_UNSUPPORTED from uvol_ktx2_info's rules), a shape other than the first readable file's
- * (UVOL_E_INVALID), a source kind the target does not take (UVOL_E_UNSUPPORTED: ASTC wants UASTC sources, ETC1 / BC7 / ETC2 want
- * ETC1S), a payload that turns out corrupt on the device (UVOL_E_ENCODE) fail in their own slot; ETC1S and UASTC files may share a
+ * (UVOL_E_INVALID), a source kind the target does not take (UVOL_E_UNSUPPORTED: ASTC wants UASTC sources, ETC1 / ETC2 want ETC1S; RGBA32 and
+ * BC7 take both), a payload that turns out corrupt on the device (UVOL_E_ENCODE) fail in their own slot; ETC1S and UASTC files may share a
  * batch.  out[s * layers + l] as in the entry point of the target; slots of failed segments are not read. */
 enum { UVOL_TARGET_RGBA32 = 0, UVOL_TARGET_ETC1 = 1, UVOL_TARGET_BC7 = 2, UVOL_TARGET_ASTC = 3, UVOL_TARGET_ETC2_RGBA = 4 };
 int uvol_encode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers,

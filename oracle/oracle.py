@@ -406,14 +406,14 @@ def uastc_ktx2_info(data: bytes):
 
 
 def uastc_ktx2_decode(data: bytes, target="rgba"):
-    """target 'rgba': [layers, H, W, 4] uint8 (stored row order); 'astc': [layers, by, bx, 16] uint8 ASTC 4x4 blocks."""
+    """target 'rgba': [layers, H, W, 4] uint8 (stored row order); 'astc' / 'bc7': [layers, by, bx, 16] uint8 ASTC 4x4 / BC7 blocks."""
     L = _uastc_setup()
     i = uastc_ktx2_info(data)
     if target == "rgba":
         out = np.zeros((i["layers"], i["height"], i["width"], 4), np.uint8)
     else:
         out = np.zeros((i["layers"], (i["height"] + 3) // 4, (i["width"] + 3) // 4, 16), np.uint8)
-    rc = L.uastc_ktx2_decode(data, len(data), 0 if target == "rgba" else 1, out.ctypes.data)
+    rc = L.uastc_ktx2_decode(data, len(data), {"rgba": 0, "astc": 1, "bc7": 2}[target], out.ctypes.data)
     if rc:
         raise ValueError(f"uastc_ktx2_decode rc={rc}")
     return out

@@ -573,6 +573,90 @@ int uastc_ktx2_info(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32
   return 0;
 }
 /* target 0: RGBA8 layers (W*H*4 each, stored row order); target 1: ASTC 4x4 blocks (bx*by*16 per layer) */
+/* ---- UASTC -> BC7 (target 2): what the stock loader asks a UASTC source for on every desktop GPU (reference src/lib/KTX2Loader.js:601-609
+ * BC7_M5 for UASTC, chosen at :665-676 when ASTC is not supported).  The basis transcoder's own tables are not in the reference; this is a
+ * deterministic re-fit of the block's OWN endpoints and texels, gated by PSNR against the RGBA32 decode (tests), not by bit parity with stock:
+ *  - single-plane modes (0, 10, 12, 18) and solid blocks -> BC7 mode 6 (one subset, RGBA 7-bit endpoints + a p-bit each, 4-bit indices):
+ *    each endpoint takes the p-bit under which its four 8-bit values are represented best, every texel the index of the nearest of the
+ *    16 interpolated colours;
+ *  - dual-plane modes (6, 11) -> BC7 mode 5 (RGB 7-bit endpoints with 2-bit indices, a separate 8-bit scalar channel with its own 2-bit
+ *    indices; the ROTATION puts the block's second-plane channel there): UASTC's and BC7's 2-bit weights are the same {0, 21, 43, 64}.
+ * Bit layouts as in tex_decode.hip (LSB first); pixel 0's index has its top bit implied 0 (else endpoints swapped, indices complemented). */
+static const int BC7_W2[4] = { 0, 21, 43, 64 };
+static const int BC7_W4[16] = { 0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64 };
+static void bc7_put(uint64_t w[2], int *pos, uint64_t v, int nbits) {
+  if (*pos < 64) { w[0] |= v << *pos; if (*pos + nbits > 64) w[1] |= v >> (64 - *pos); } else w[1] |= v << (*pos - 64);
+  *pos += nbits;
+}
+int uastc_to_bc7(const uint8_t in[16], uint8_t out[16]) {
+  uastc_lblock L; const int rc = uastc_unpack(in, &L); if (rc) return rc;
+  uint8_t px[64]; uastc_lblock_rgba(&L, px);
+  int lo[4] = { 0, 0, 0, 255 }, hi[4] = { 0, 0, 0, 255 }, dual = 0, ccs = 0;
+  if (L.mode == 8) { for (int c = 0; c < 4; c++) lo[c] = hi[c] = L.solid[c]; }
+  else {
+    const int range = UM_RANGE[L.mode], nc = UM_COMPS[L.mode];
+    for (int c = 0; c < nc; c++) { lo[c] = astc_unquant_endpoint(range, L.ep[2 * c]); hi[c] = astc_unquant_endpoint(range, L.ep[2 * c + 1]); }
+    dual = UM_PLANES[L.mode] == 2; ccs = L.ccs;
+  }
+  uint64_t w[2] = { 0, 0 }; int pos;
+  if (!dual) {
+    int e7[2][4], pb[2] = { 0, 0 };
+    for (int s = 0; s < 2; s++) {
+      const int *v = s ? hi : lo; int best = 1 << 30;
+      for (int p = 0; p < 2; p++) {
+        int q[4], err = 0;
+        for (int c = 0; c < 4; c++) { int t = (v[c] - p + 1) >> 1; t = t < 0 ? 0 : (t > 127 ? 127 : t); q[c] = t; const int d = ((t << 1) | p) - v[c]; err += d * d; }
+        if (err < best) { best = err; pb[s] = p; for (int c = 0; c < 4; c++) e7[s][c] = q[c]; }
+      }
+    }
+    int idx[16];
+    for (int i = 0; i < 16; i++) {
+      int bw = 0, be = 1 << 30;
+      for (int k = 0; k < 16; k++) {
+        int err = 0;
+        for (int c = 0; c < 4; c++) { const int a = (e7[0][c] << 1) | pb[0], b = (e7[1][c] << 1) | pb[1], d = ((a * (64 - BC7_W4[k]) + b * BC7_W4[k] + 32) >> 6) - px[4 * i + c]; err += d * d; }
+        if (err < be) { be = err; bw = k; }
+      }
+      idx[i] = bw;
+    }
+    const int swap = idx[0] >= 8;
+    w[0] = 1ull << 6; pos = 7;
+    for (int c = 0; c < 4; c++) { bc7_put(w, &pos, (uint64_t)e7[swap ? 1 : 0][c], 7); bc7_put(w, &pos, (uint64_t)e7[swap ? 0 : 1][c], 7); }
+    bc7_put(w, &pos, (uint64_t)pb[swap ? 1 : 0], 1); bc7_put(w, &pos, (uint64_t)pb[swap ? 0 : 1], 1);
+    for (int i = 0; i < 16; i++) bc7_put(w, &pos, (uint64_t)(swap ? 15 - idx[i] : idx[i]), i == 0 ? 3 : 4);
+  } else {
+    const int rot = ccs == 3 ? 0 : ccs + 1;
+    int src[3]; for (int k = 0; k < 3; k++) src[k] = (ccs < 3 && k == ccs) ? 3 : k;       /* encoded colour channel k holds this actual channel */
+    int e7[2][3];
+    for (int s = 0; s < 2; s++) for (int k = 0; k < 3; k++) {
+      const int v = (s ? hi : lo)[src[k]]; int bt = 0, bd = 1 << 30;
+      for (int t = (v >> 1) - 1; t <= (v >> 1) + 1; t++) { if (t < 0 || t > 127) continue; int d = ((t << 1) | (t >> 6)) - v; d = d < 0 ? -d : d; if (d < bd) { bd = d; bt = t; } }
+      e7[s][k] = bt;
+    }
+    const int a0 = lo[ccs], a1 = hi[ccs];
+    int ci[16], ai[16];
+    for (int i = 0; i < 16; i++) {
+      int bw = 0, be = 1 << 30;
+      for (int k = 0; k < 4; k++) {
+        int err = 0;
+        for (int c = 0; c < 3; c++) { const int a = (e7[0][c] << 1) | (e7[0][c] >> 6), b = (e7[1][c] << 1) | (e7[1][c] >> 6), d = ((a * (64 - BC7_W2[k]) + b * BC7_W2[k] + 32) >> 6) - px[4 * i + src[c]]; err += d * d; }
+        if (err < be) { be = err; bw = k; }
+      }
+      ci[i] = bw; bw = 0; be = 1 << 30;
+      for (int k = 0; k < 4; k++) { const int d = ((a0 * (64 - BC7_W2[k]) + a1 * BC7_W2[k] + 32) >> 6) - px[4 * i + ccs]; if (d * d < be) { be = d * d; bw = k; } }
+      ai[i] = bw;
+    }
+    const int cswap = ci[0] >= 2, aswap = ai[0] >= 2;
+    w[0] = 1ull << 5; pos = 6;
+    bc7_put(w, &pos, (uint64_t)rot, 2);
+    for (int c = 0; c < 3; c++) { bc7_put(w, &pos, (uint64_t)e7[cswap ? 1 : 0][c], 7); bc7_put(w, &pos, (uint64_t)e7[cswap ? 0 : 1][c], 7); }
+    bc7_put(w, &pos, (uint64_t)(aswap ? a1 : a0), 8); bc7_put(w, &pos, (uint64_t)(aswap ? a0 : a1), 8);
+    for (int i = 0; i < 16; i++) bc7_put(w, &pos, (uint64_t)(cswap ? 3 - ci[i] : ci[i]), i == 0 ? 1 : 2);
+    for (int i = 0; i < 16; i++) bc7_put(w, &pos, (uint64_t)(aswap ? 3 - ai[i] : ai[i]), i == 0 ? 1 : 2);
+  }
+  memcpy(out, &w[0], 8); memcpy(out + 8, &w[1], 8);
+  return 0;
+}
 int uastc_ktx2_decode(const uint8_t *b, size_t n, int target, uint8_t *out) {
   uint32_t W, H, L; uint64_t lo;
   const int rc = uastc_ktx2_info(b, n, &W, &H, &L, &lo, NULL); if (rc) return rc;
@@ -580,6 +664,7 @@ int uastc_ktx2_decode(const uint8_t *b, size_t n, int target, uint8_t *out) {
   for (uint32_t l = 0; l < L; l++) for (uint32_t y = 0; y < by; y++) for (uint32_t x = 0; x < bx; x++) {
     const uint8_t *blk = b + lo + 16 * (((size_t)l * by + y) * bx + x);
     if (target == 1) { if (uastc_to_astc(blk, out + 16 * (((size_t)l * by + y) * bx + x))) return -10; continue; }
+    if (target == 2) { if (uastc_to_bc7(blk, out + 16 * (((size_t)l * by + y) * bx + x))) return -10; continue; }
     uint8_t px[64]; if (uastc_decode_block(blk, px)) return -10;
     for (int yy = 0; yy < 4 && 4 * y + (uint32_t)yy < H; yy++) for (int xx = 0; xx < 4 && 4 * x + (uint32_t)xx < W; xx++)
       memcpy(out + 4 * (((size_t)l * H + 4 * y + (uint32_t)yy) * W + 4 * x + (uint32_t)xx), px + 4 * (4 * yy + xx), 4);

@@ -114,7 +114,7 @@ def eac_alpha_decode_blocks(blocks, width, height):
 
 def bc7_decode_blocks(blocks, width, height):
     """Independent BC7 decoder for the two single-subset modes the BC7 transcode target emits (Khronos data-format spec, BPTC):
-    mode 5 (7-bit RGB endpoints, 8-bit alpha endpoints, 2-bit colour and alpha indices, rotation) and mode 6 (7-bit RGBA
+    mode 5 (7-bit RGB endpoints, 8-bit alpha endpoints, 2-bit colour and alpha indices, any rotation) and mode 6 (7-bit RGBA
     endpoints + p-bits, 4-bit indices).  blocks [by, bx, 16] uint8 -> RGBA8 [height, width, 4]; other modes assert."""
     W2 = np.array([0, 21, 43, 64], np.int64)
     W4 = np.array([0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64], np.int64)
@@ -147,7 +147,7 @@ def bc7_decode_blocks(blocks, width, height):
         w = W4[bits(pos, n)][..., None]; pos += n
         px6.append((ep[..., 0] * (64 - w) + ep[..., 1] * w + 32) >> 6)
     # mode 5
-    assert np.all(bits(6, 2)[m5] == 0), "rotation not expected"
+    rot = np.where(m5, bits(6, 2), 0)                        # 1 / 2 / 3: the scalar channel was R / G / B (swapped back after the interpolation)
     e5 = np.zeros((by, bx, 4, 2), np.int64)
     for c in range(3):
         for k in range(2):
@@ -159,7 +159,11 @@ def bc7_decode_blocks(blocks, width, height):
         wc = W2[bits(cpos, n)][..., None]; wa = W2[bits(apos, n)]; cpos += n; apos += n
         rgb = (e5[..., :3, 0] * (64 - wc) + e5[..., :3, 1] * wc + 32) >> 6
         a = (e5[..., 3, 0] * (64 - wa) + e5[..., 3, 1] * wa + 32) >> 6
-        px5.append(np.concatenate([rgb, a[..., None]], axis=-1))
+        v = np.concatenate([rgb, a[..., None]], axis=-1)
+        for r in (1, 2, 3):
+            sw = v.copy(); sw[..., r - 1] = v[..., 3]; sw[..., 3] = v[..., r - 1]
+            v = np.where((rot == r)[..., None], sw, v)
+        px5.append(v)
     for i in range(16):
         y, x = divmod(i, 4)
         out[y::4, x::4] = np.where(m5[..., None], px5[i], px6[i]).astype(np.uint8)

@@ -253,6 +253,8 @@ def test_gpu_uastc_mode_bit_exact(oracle):
             assert np.array_equal(dec, oracle.uastc_ktx2_decode(k)), name
             astc = cd.transcode_texture_segments_astc([k])[0]
             assert np.array_equal(astc, oracle.uastc_ktx2_decode(k, "astc")), name
+            from test_hipemu_tex import _check_uastc_bc7
+            _check_uastc_bc7(oracle, cd, k)                  # UASTC -> BC7: the desktop target of the stock loader (KTX2Loader.js:601-609)
             px = oracle.astc_decode_blocks(astc.reshape(-1, 16))                       # [blocks, 16 texels, 4]
             nl, by, bx = astc.shape[:3]
             img = px.reshape(nl, by, bx, 4, 4, 4).transpose(0, 1, 3, 2, 4, 5).reshape(nl, by * 4, bx * 4, 4)[:, :dec.shape[1], :dec.shape[2]]
@@ -348,6 +350,9 @@ def test_gpu_texture_batch_calls_report_per_segment_status(oracle, gpu_codec):
     ra, rb = oracle.ktx2_decode(files[0]), oracle.ktx2_decode(files[5])
     assert all(np.array_equal(outs[0][l], ra.images[l]) for l in range(2)) and all(np.array_equal(outs[5][l], rb.images[l]) for l in range(2))
     assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2]))
+    outs, st = gpu_codec.transcode_texture_segments_status(files, "bc7")               # (BC7 takes both kinds)
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2], "bc7"))
     outs, st = gpu_codec.transcode_texture_segments_status(files, "etc2_rgba")
     assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
     assert np.array_equal(outs[5], gpu_codec.transcode_texture_segments_etc2_rgba([files[5]])[0])

@@ -147,8 +147,24 @@ def test_hipemu_uastc_mode_matches_oracle(oracle, hipemu_lib):
         assert k == oracle.uastc_ktx2_encode(t)
         assert np.array_equal(cd.decode_texture_segments([k])[0], oracle.uastc_ktx2_decode(k))
         assert np.array_equal(cd.transcode_texture_segments_astc([k])[0], oracle.uastc_ktx2_decode(k, "astc"))
+        _check_uastc_bc7(oracle, cd, k)
     assert cd.ktx2_info(k) == (37, 50, 2)
     cd.close()
+
+
+def _check_uastc_bc7(oracle, cd, k, gate=42.0, gate_a=38.0):      # (alpha of the dual-plane modes: 2-bit indices; the test's alpha is per-texel noise)
+    """UASTC -> BC7 (what the stock loader asks a UASTC source for on a desktop GPU, src/lib/KTX2Loader.js:601-609): HIP blocks = the
+    restatement's, and - the gate, since this is a re-fit and not the basis transcoder's tables - the blocks decoded by the independent
+    BC7 decoder of tests/helpers.py stay within a PSNR of the UASTC texels, colour and alpha."""
+    from helpers import bc7_decode_blocks, psnr_rgb
+    b7 = cd.transcode_texture_segments_bc7([k])[0]
+    assert np.array_equal(b7, oracle.uastc_ktx2_decode(k, "bc7"))
+    want = oracle.uastc_ktx2_decode(k)
+    for l in range(want.shape[0]):
+        g = bc7_decode_blocks(b7[l], want.shape[2], want.shape[1])
+        da = g[..., 3].astype(np.float64) - want[l][..., 3].astype(np.float64); mse = float(np.mean(da * da))
+        pa = 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+        assert psnr_rgb(g, want[l]) > gate and pa > gate_a, (l, psnr_rgb(g, want[l]), pa)
 
 
 def _alpha_sequence(n, size, seed):
@@ -337,9 +353,12 @@ def test_hipemu_texture_batch_calls_report_per_segment_status(oracle, hipemu_lib
     assert all(np.array_equal(outs[0][l], ra.images[l]) for l in range(2)) and all(np.array_equal(outs[5][l], rb.images[l]) for l in range(2))
     assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2]))
     # a target only one of the kinds takes: the other kind is UNSUPPORTED in its slot, the rest still runs
-    outs, st = cd.transcode_texture_segments_status(files, "bc7")
+    outs, st = cd.transcode_texture_segments_status(files, "etc1")
     assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
-    assert np.array_equal(outs[0], cd.transcode_texture_segments_bc7([files[0]])[0])
+    assert np.array_equal(outs[0], cd.transcode_texture_segments_etc1([files[0]])[0])
+    outs, st = cd.transcode_texture_segments_status(files, "bc7")                  # (BC7 takes both kinds)
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    assert np.array_equal(outs[0], cd.transcode_texture_segments_bc7([files[0]])[0]) and np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2], "bc7"))
     outs, st = cd.transcode_texture_segments_status(files, "astc")
     assert st[2] == uvol.UVOL_OK and st[0] == uvol.UVOL_E_UNSUPPORTED and np.array_equal(outs[2], cu.transcode_texture_segments_astc([files[2]])[0])
     # encode: a segment whose output buffer is too small fails alone and says what it needs

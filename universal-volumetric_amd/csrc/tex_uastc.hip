@@ -398,6 +398,85 @@ __device__ inline int u_to_astc(const UBits &B, const UConst *K, UBits &A) {
   return 0;
 }
 
+// ---- UASTC -> BC7 (target 2): what the stock loader asks a UASTC source for on every desktop GPU (reference src/lib/KTX2Loader.js:601-609,
+// chosen at :665-676 when ASTC is not supported).  A deterministic re-fit of the block's own endpoints and decoded texels, gated by PSNR
+// against the RGBA32 decode, not by bit parity with the basis transcoder (whose tables are not in the reference):
+//  * single-plane modes (0, 10, 12, 18) and solid blocks -> BC7 mode 6 (RGBA 7-bit endpoints + a p-bit each, 4-bit indices): each endpoint
+//    takes the p-bit under which its four 8-bit values are represented best, every texel the index of the nearest interpolated colour;
+//  * dual-plane modes (6, 11) -> BC7 mode 5 (RGB 7-bit endpoints / 2-bit indices + a separate 8-bit scalar channel with its own indices;
+//    the rotation puts the block's second-plane channel there): UASTC's and BC7's 2-bit weights are the same {0, 21, 43, 64}.
+// Bit layouts as in tex_decode.hip (k_tdec_bc7), LSB first.
+struct UBc7 { unsigned long long lo, hi; int pos;
+  __device__ __forceinline__ void put(unsigned long long v, int n) { if (pos < 64) { lo |= v << pos; if (pos + n > 64) hi |= v >> (64 - pos); } else hi |= v << (pos - 64); pos += n; } };
+__device__ inline void u_to_bc7(const ULog &L, uint32_t solid, const uint32_t px[16], const UTab *T, UBits &out) {
+  const int W2[4] = { 0, 21, 43, 64 };
+  const int W4[16] = { 0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64 };
+  int lo[4] = { 0, 0, 0, 255 }, hi[4] = { 0, 0, 0, 255 }, dual = 0, ccs = 0;
+  if (L.mode == 8) { for (int c = 0; c < 4; c++) lo[c] = hi[c] = (int)((solid >> (8 * c)) & 255u); }
+  else {
+    const UMode M = u_mode(L.mode); const int slot = u_slot(M.range);
+    for (int c = 0; c < M.comps; c++) { lo[c] = T->uq[slot][L.ep[2 * c]]; hi[c] = T->uq[slot][L.ep[2 * c + 1]]; }
+    dual = M.planes == 2; ccs = L.ccs;
+  }
+  UBc7 B; B.lo = 0; B.hi = 0; B.pos = 0;
+  if (!dual) {
+    int e7[2][4], pb[2] = { 0, 0 };
+    for (int s = 0; s < 2; s++) {
+      int best = 1 << 30;
+      for (int p = 0; p < 2; p++) {
+        int q[4], err = 0;
+        for (int c = 0; c < 4; c++) { const int v = s ? hi[c] : lo[c]; int t = (v - p + 1) >> 1; t = t < 0 ? 0 : (t > 127 ? 127 : t); q[c] = t; const int d = ((t << 1) | p) - v; err += d * d; }
+        if (err < best) { best = err; pb[s] = p; for (int c = 0; c < 4; c++) e7[s][c] = q[c]; }
+      }
+    }
+    uint32_t idx[16];
+    for (int i = 0; i < 16; i++) {
+      uint32_t bw = 0; int be = 1 << 30;
+      for (int k = 0; k < 16; k++) {
+        int err = 0;
+        for (int c = 0; c < 4; c++) { const int a = (e7[0][c] << 1) | pb[0], b = (e7[1][c] << 1) | pb[1], d = ((a * (64 - W4[k]) + b * W4[k] + 32) >> 6) - (int)((px[i] >> (8 * c)) & 255u); err += d * d; }
+        if (err < be) { be = err; bw = (uint32_t)k; }
+      }
+      idx[i] = bw;
+    }
+    const int swap = idx[0] >= 8u ? 1 : 0;
+    B.lo = 1ull << 6; B.pos = 7;
+    for (int c = 0; c < 4; c++) { B.put((unsigned)e7[swap][c], 7); B.put((unsigned)e7[swap ^ 1][c], 7); }
+    B.put((unsigned)pb[swap], 1); B.put((unsigned)pb[swap ^ 1], 1);
+    for (int i = 0; i < 16; i++) B.put(swap ? 15u - idx[i] : idx[i], i == 0 ? 3 : 4);
+  } else {
+    const int rot = ccs == 3 ? 0 : ccs + 1;
+    int src[3]; for (int k = 0; k < 3; k++) src[k] = (ccs < 3 && k == ccs) ? 3 : k;       // encoded colour channel k holds this actual channel
+    int e7[2][3];
+    for (int s = 0; s < 2; s++) for (int k = 0; k < 3; k++) {
+      const int v = s ? hi[src[k]] : lo[src[k]]; int bt = 0, bd = 1 << 30;
+      for (int t = (v >> 1) - 1; t <= (v >> 1) + 1; t++) { if (t < 0 || t > 127) continue; int d = ((t << 1) | (t >> 6)) - v; d = d < 0 ? -d : d; if (d < bd) { bd = d; bt = t; } }
+      e7[s][k] = bt;
+    }
+    const int a0 = lo[ccs], a1 = hi[ccs];
+    uint32_t ci[16], ai[16];
+    for (int i = 0; i < 16; i++) {
+      uint32_t bw = 0; int be = 1 << 30;
+      for (int k = 0; k < 4; k++) {
+        int err = 0;
+        for (int c = 0; c < 3; c++) { const int a = (e7[0][c] << 1) | (e7[0][c] >> 6), b = (e7[1][c] << 1) | (e7[1][c] >> 6), d = ((a * (64 - W2[k]) + b * W2[k] + 32) >> 6) - (int)((px[i] >> (8 * src[c])) & 255u); err += d * d; }
+        if (err < be) { be = err; bw = (uint32_t)k; }
+      }
+      ci[i] = bw; bw = 0; be = 1 << 30;
+      for (int k = 0; k < 4; k++) { const int d = ((a0 * (64 - W2[k]) + a1 * W2[k] + 32) >> 6) - (int)((px[i] >> (8 * ccs)) & 255u); if (d * d < be) { be = d * d; bw = (uint32_t)k; } }
+      ai[i] = bw;
+    }
+    const int cswap = ci[0] >= 2u ? 1 : 0, aswap = ai[0] >= 2u ? 1 : 0;
+    B.lo = 1ull << 5; B.pos = 6;
+    B.put((unsigned)rot, 2);
+    for (int c = 0; c < 3; c++) { B.put((unsigned)e7[cswap][c], 7); B.put((unsigned)e7[cswap ^ 1][c], 7); }
+    B.put((unsigned)(aswap ? a1 : a0), 8); B.put((unsigned)(aswap ? a0 : a1), 8);
+    for (int i = 0; i < 16; i++) B.put(cswap ? 3u - ci[i] : ci[i], i == 0 ? 1 : 2);
+    for (int i = 0; i < 16; i++) B.put(aswap ? 3u - ai[i] : ai[i], i == 0 ? 1 : 2);
+  }
+  out.lo = B.lo; out.hi = B.hi;
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +511,7 @@ __global__ void __launch_bounds__(UVOL_BLOCK) UVOL_WAVES_PER_EU(4) k_uastc_encod
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
   dst[0] = B.lo; dst[1] = B.hi;
 }
-// target 0: RGBA8 (W x H x 4 per layer, stored row order), 1: ASTC 4x4 blocks
+// target 0: RGBA8 (W x H x 4 per layer, stored row order), 1: ASTC 4x4 blocks, 2: BC7 blocks
 __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, const UConst *K, int target) {
   UastcJob &J = jobs[blockIdx.z];
   const uint32_t l = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
@@ -449,6 +528,11 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, con
   for (int i = 0; i < 32; i++) L.w[i] = 0;
   if (u_unpack(B, L, solid)) { J.status = -10; return; }
   if (L.mode == 8) for (int i = 0; i < 16; i++) px[i] = solid; else u_decode_log(L, &K->tab, px);
+  if (target == 2) {
+    UBits A; u_to_bc7(L, solid, px, &K->tab, A);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
+    dst[0] = A.lo; dst[1] = A.hi; return;
+  }
   const uint32_t X = b % J.bx, Y = b / J.bx;
   for (int y = 0; y < 4 && 4 * Y + (uint32_t)y < J.H; y++) {
     uint8_t *row = J.out[l] + 4 * ((size_t)(4 * Y + (uint32_t)y) * J.W + 4 * (size_t)X);
@@ -588,7 +672,7 @@ int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
 int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *outp, size_t layer_cap, bool outputs_on_device, int target, int *status) {
   UastcState *U = ctx->uastc;
   if (n <= 0) return UVOL_OK;
-  if (target != 0 && target != 3) { ctx->set_error("UASTC sources transcode to RGBA32 or ASTC 4x4"); return UVOL_E_UNSUPPORTED; }
+  if (target != 0 && target != 3 && target != 2) { ctx->set_error("UASTC sources transcode to RGBA32, ASTC 4x4 or BC7"); return UVOL_E_UNSUPPORTED; }
   int rc; if ((rc = uastc_consts(ctx))) return rc;
   uint32_t W = 0, H = 0, L = 0; uint64_t lo = 0;
   if (uastc_ktx2_probe(files[0], lens[0], &W, &H, &L, &lo)) { ctx->set_error("segment 0: not a UASTC .ktx2 this decoder handles"); return UVOL_E_INVALID; }
@@ -610,8 +694,8 @@ int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const 
     }
   }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : "texdec.uastc_astc", (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
-    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : 1); }
+  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : (target == 3 ? "texdec.uastc_astc" : "texdec.uastc_bc7"), (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
+    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : (target == 3 ? 1 : 2)); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   if (!outputs_on_device) {
