@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--traverse-vbits-l2", type=int, default=0, help="LDS walkers (small batches): 1 = attribute traversers keep their vertex bitmap in L2")
     ap.add_argument("--tex-priority", type=int, default=1, help="1: texture contexts use a high-priority HIP stream")
     ap.add_argument("--geo-priority", type=int, default=0, help="1: geometry contexts use a high-priority HIP stream (diagnostic)")
+    ap.add_argument("--geo-cus", default="", help="DIAGNOSTIC 'mod:residues' (residues in hex): the geometry contexts' streams run on the CUs whose mask index %% mod has its bit set (hipExtStreamCreateWithCUMask; mask bit i lies on XCD i %% 8: profiles/r05_xcd_census.json)")
+    ap.add_argument("--tex-cus", default="", help="DIAGNOSTIC: the same for the texture contexts")
     ap.add_argument("--blocking-calls", action="store_true", help="DIAGNOSTIC: one blocking geometry call per pass instead of enqueued passes completed by one uvol_sync")
     ap.add_argument("--lockstep", action="store_true", help="barrier between all streams after every pass (default: each stream runs its passes back to back)")
     ap.add_argument("--only", choices=["geo", "tex"], default=None, help="diagnostic: run only one half of the path (never the headline value)")
@@ -153,6 +155,9 @@ def main():
         tcfg.update(stream_priority=1)
     if args.geo_priority:
         gcfg.update(stream_priority=1)
+    for spec, c_ in ((args.geo_cus, gcfg), (args.tex_cus, tcfg)):
+        if spec:
+            c_.update(cu_mod=int(spec.split(":")[0]), cu_residues=int(spec.split(":")[1], 16))
     if args.traverse_vbits_l2 == 1:
         gcfg.update(traverse_vbits_l2=1)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]

@@ -1136,6 +1136,9 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
     for (int k = 0; k < 2; k++) UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_tabs[k], hipEventDisableTiming));      // (one per phase: a wait must not see a later record of its event)
     UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&T->ev_sym, hipEventDisableTiming));
   }
+  // any early return from here to the end-of-call synchronisation leaves no kernel running on the second stream (they write J.status and
+  // S.out; a retry or the next call lays T->jobs / T->slab out again on ctx->stream with no ordering against it)
+  struct AuxGuard { hipStream_t s; bool armed; ~AuxGuard() { if (armed) (void)hipStreamSynchronize(s); } } aux_guard{ T->aux, true };
   auto early_pass = [&](int phase) -> int {
     UVOL_HIP_CHECK(ctx, hipEventRecord(T->ev_tabs[phase], ctx->stream));
     UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(T->aux, T->ev_tabs[phase], 0));
@@ -1155,10 +1158,10 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
     GLAUNCH(k_gdec_atttab, dim3(bc, N, GD_MAXAD), dim3(UVOL_BLOCK), 0, dj, 1);
     GLAUNCH(k_gdec_validate, dim3(bc, N), dim3(UVOL_BLOCK), 0, dj, 1);
     GLAUNCH(k_gdec_open, dim3(bc, N, 3), dim3(UVOL_BLOCK), 0, dj, gj); }
-  if ((rc = early_pass(1))) { (void)hipStreamSynchronize(T->aux); return rc; }
+  if ((rc = early_pass(1))) return rc;
   UVOL_HIP_CHECK(ctx, hipEventRecord(T->ev_sym, T->aux));
   { uvol_ctx::Scope sc(ctx, "geodec.k5_traverse", 0);
-    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) { (void)hipStreamSynchronize(T->aux); return rc; }
+    if ((rc = geo_run_traversals(ctx, gj, n, max_nf, max_nev + max_nev / 4 + 64))) return rc;
     UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, T->ev_sym, 0));
     GLAUNCH(k_gdec_counts, dim3(N), dim3(64), 0, dj, gj); }
   { uvol_ctx::Scope sc(ctx, "geodec.k6_attr_symbols", 0); GLAUNCH(k_gdec_rans, dim3(N, GD_MAXDEC), dim3(64), 0, dj, 6, GD_MAXDEC, 2);
@@ -1174,6 +1177,7 @@ static int geo_decode_batch_impl(uvol_ctx *ctx, const uint8_t *const *files, con
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(GeoDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  aux_guard.armed = false;                                 // (the main stream waited for ev_sym: the second stream is idle)
   if (uvol_debug()) { int ne = 0, nr = 0; for (int i = 0; i < n; i++) for (int d = 0; d < T->hjobs[i].ndec; d++) { ne += T->hjobs[i].rs[6 + d].early != 0; nr += T->hjobs[i].rs[6 + d].redo != 0; }
     fprintf(stderr, "[uvol] decode: %d attribute streams decoded beside the traversal, %d (again) after it\n", ne, nr); }
   int worst = UVOL_OK;

@@ -462,7 +462,12 @@ extern "C" size_t uvol_mesh_workspace(const uvol_ctx *ctx, const uvol_mesh *m) {
   J.qp = ctx->prm.q_position_attr; J.qt = ctx->prm.q_texture_attr; J.qn = ctx->prm.q_normal_attr;
   WsPlanCache P; std::vector<WsItem> items;
   const int fmt = geo_rec8(m->n_faces, geo_ecap(J.n_pos, J.n_uv, J.n_nrm, J.nf_in, false)) ? 2 : 0;       // what a frame of a large batch holds (lane-per-walker kernels, one record per face)
-  return layout_job(J, nullptr, false, fmt, fmt, P, items).total + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
+  // a small call (and the one-frame retry) runs the LDS walkers on four 8-byte-per-corner tables instead: the larger of the two placements
+  const size_t big = layout_job(J, nullptr, false, fmt, fmt, P, items).total;
+  WsPlanCache P1; std::vector<WsItem> items1; GeoJob J1 = J; J1.compact = 0;
+  const int fmt1 = fmt ? 1 : 0;
+  const size_t small = layout_job(J1, nullptr, false, fmt1, fmt1, P1, items1).total;
+  return std::max(big, small) + 32768 + 8 * (size_t)m->n_faces + sizeof(GeoJob);
 }
 // stages of a batch with sequential connectivity, between k_minmax and the layout (all parallel; see k_sq_*)
 static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, uint32_t max_nfi, uint32_t max_vals, uint32_t max_ecap, uint64_t algo_in) {

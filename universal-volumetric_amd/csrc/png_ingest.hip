@@ -107,15 +107,26 @@ int png_create(uvol_ctx *ctx) { ctx->png = new PngState(); return UVOL_OK; }
 // the layers of the last un-filter call are ready before anything queued on `stream` from here on (the texture entry points call this
 // before they read device inputs; uvol_sync too)
 // (one event per slot: the encode of batch k waits for ITS slot, not for the un-filter of batch k + 1 queued meanwhile into the other one)
-int png_order_before(uvol_ctx *ctx, hipStream_t stream, const uint8_t *layer) {
+int png_order_before(uvol_ctx *ctx, hipStream_t stream, const uint8_t *const *layers, size_t n_layers) {
   PngState *S = ctx->png; if (!S) return UVOL_OK;
+  // every layer of the call is looked at: a call may mix layers of both slots, or hold a pending slot's layer anywhere in its list
+  bool need[2] = { false, false };
   for (int k = 0; k < 2; k++) {
     const uint8_t *b = (const uint8_t *)S->rgba[k].p;
-    if (S->pending[k] && b && layer >= b && layer < b + S->rgba[k].cap) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, S->done[k], 0));
+    if (!S->pending[k] || !b) continue;
+    for (size_t i = 0; i < n_layers && !need[k]; i++) need[k] = layers[i] >= b && layers[i] < b + S->rgba[k].cap;
   }
+  for (int k = 0; k < 2; k++) if (need[k]) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, S->done[k], 0));
   return UVOL_OK;
 }
-int png_wait(uvol_ctx *ctx) { PngState *S = ctx->png; if (S) for (int k = 0; k < 2; k++) if (S->pending[k]) { UVOL_HIP_CHECK(ctx, hipEventSynchronize(S->done[k])); S->pending[k] = false; } return UVOL_OK; }
+int png_wait(uvol_ctx *ctx) {
+  PngState *S = ctx->png; int rc = UVOL_OK;
+  if (S) for (int k = 0; k < 2; k++) if (S->pending[k]) {
+    const hipError_t e = hipEventSynchronize(S->done[k]); S->pending[k] = false;
+    if (e != hipSuccess && rc == UVOL_OK) { ctx->set_error("hipEventSynchronize (png un-filter slot %d): %s", k, hipGetErrorString(e)); rc = UVOL_E_HIP; }
+  }
+  return rc;
+}
 void png_destroy(uvol_ctx *ctx) {
   PngState *S = ctx->png; if (!S) return;
   if (S->stream) { (void)hipStreamSynchronize(S->stream); (void)hipStreamDestroy(S->stream); }

@@ -1438,7 +1438,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   if (n_seg <= 0) return UVOL_OK;
   TexState *T = ctx->tex;
   T->lane[0].stream = ctx->stream;
-  if (on_device) { const int ro = png_order_before(ctx, ctx->stream, rgba[0]); if (ro != UVOL_OK) return ro; }      // layers un-filtered on the ingest stream (uvol_unfilter_png_batch_dev)
+  if (on_device) { const int ro = png_order_before(ctx, ctx->stream, rgba, (size_t)n_seg * n_layers); if (ro != UVOL_OK) return ro; }      // layers un-filtered on the ingest stream (uvol_unfilter_png_batch_dev)
   const int part = tex_part_segments();
   int rc = UVOL_OK;
   if (on_device || part <= 0 || n_seg < 2 * part) {                       // one batch on the context's stream

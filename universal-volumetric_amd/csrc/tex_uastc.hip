@@ -626,7 +626,7 @@ int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint3
 // n_seg segments of n_layers layers -> UASTC .ktx2 files (what `basisu -uastc -ktx2 -tex_type video` writes, without Zstandard)
 int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
                               bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
-  if (on_device) { const int ro = png_order_before(ctx, ctx->stream, rgba[0]); if (ro != UVOL_OK) return ro; }      // layers un-filtered on the ingest stream
+  if (on_device) { const int ro = png_order_before(ctx, ctx->stream, rgba, (size_t)n_seg * n_layers); if (ro != UVOL_OK) return ro; }      // layers un-filtered on the ingest stream
   UastcState *U = ctx->uastc;
   if (n_seg <= 0) return UVOL_OK;
   if (n_layers > 64 || W > 16384 || H > 16384 || n_seg > 65535) { ctx->set_error("texture segment: unsupported size"); return UVOL_E_UNSUPPORTED; }

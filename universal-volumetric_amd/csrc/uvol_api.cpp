@@ -163,6 +163,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   ctx->resolve_profile();
   geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx); png_destroy(ctx);
   for (int k = 0; k < 2; k++) { if (ctx->up_pin[k]) (void)hipHostFree(ctx->up_pin[k]); if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]); }
+  for (int k = 0; k < 2; k++) if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
   for (int k = 0; k < 2; k++) { if (ctx->dn_pin[k]) (void)hipHostFree(ctx->dn_pin[k]); if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -175,10 +176,13 @@ int uvol_sync(uvol_ctx *ctx) {
   if (!ctx) return UVOL_E_INVALID;
   const int arc = async_drain(ctx);                        // every call enqueued with uvol_*_async has completed; first error among them
   (void)hipSetDevice(ctx->device);
-  { const int pr = png_wait(ctx); if (pr != UVOL_OK) return pr; }       // ... and the last un-filter call (its layers may be read by the caller from here on)
-  UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int pr = png_wait(ctx);                            // ... and the last un-filter call (its layers may be read by the caller from here on)
+  const hipError_t se = hipStreamSynchronize(ctx->stream);  // (the stream is synchronised whatever the two above returned)
   ctx->resolve_profile();
-  return arc;
+  if (arc != UVOL_OK) return arc;                          // the first error of the enqueued calls goes first
+  if (pr != UVOL_OK) return pr;
+  if (se != hipSuccess) { ctx->set_error("hipStreamSynchronize: %s", hipGetErrorString(se)); return UVOL_E_HIP; }
+  return UVOL_OK;
 }
 
 int uvol_trim(uvol_ctx *ctx) {
