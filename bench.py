@@ -41,7 +41,7 @@ PMC_FILE = "r04_pmc_traffic.json"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames-per-step", type=int, default=2560, help="frames in flight per step (per GPU); a frame holds ~56 MB of geometry workspace + 27 MB of inputs: 2560 frames leave ~17 GB of the 288 GB free (2760 no longer fit)")
     ap.add_argument("--total-frames", type=int, default=0, help="STRONG scaling: one job of this many frames split over the ranks (shard.plan, whole texture segments per rank); "
@@ -81,15 +81,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_dev = os.environ.get("UVOL_BENCH_ONE_DEVICE") == "1"      # DIAGNOSTIC: every rank drives device 0, collectives over gloo (the N > 1 code path on a 1-GPU box)
+    if one_dev:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if one_dev else dev              # where the collectives' tensors live
 
     B = args.batch
     strong = args.total_frames > 0
@@ -157,7 +164,10 @@ def main():
         gcfg.update(stream_priority=1)
     for spec, c_ in ((args.geo_cus, gcfg), (args.tex_cus, tcfg)):
         if spec:
-            c_.update(cu_mod=int(spec.split(":")[0]), cu_residues=int(spec.split(":")[1], 16))
+            if spec.startswith("xcd:"):                          # "xcd:lo-hi": the CUs with ordinal lo .. hi - 1 inside every XCD
+                lo_, hi_ = (int(x_) for x_ in spec[4:].split("-")); c_.update(cu_mod=-1, cu_residues=(lo_ << 8) | hi_)
+            else:
+                c_.update(cu_mod=int(spec.split(":")[0]), cu_residues=int(spec.split(":")[1], 16))
     if args.traverse_vbits_l2 == 1:
         gcfg.update(traverse_vbits_l2=1)
     geos = [uvol.Codec(device=local_rank, **gcfg) for _ in range(GS)]
@@ -299,7 +309,7 @@ def main():
     main_job.steps(args.steps)
     # manifest gather: {frames, segments, layers in last segment, bytes} per rank
     nbytes = sum(len(x) for x in out["drc"]) + sum(len(x) for x in out["ktx2"])
-    table = shard.gather_counts(F * args.steps, nseg * args.steps, B, nbytes, device=dev)      # RCCL all_gather when world > 1
+    table = shard.gather_counts(F * args.steps, nseg * args.steps, B, nbytes, device=cdev)      # RCCL all_gather when world > 1
     total_frames, total_segs, total_tex_frames, _ = shard.totals(table, B)
     assert total_frames == total_tex_frames or args.only                                                   # check_total_frames (Encoder.py:135)
     if strong:
@@ -307,17 +317,40 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
 
+    drc_len = sum(len(x) for x in out["drc"]) / max(F, 1)
+    ktx_len = sum(len(x) for x in out["ktx2"]) / max(F, 1)
+    reports = [t.profile_report() for t in geos + texs]        # (of the timed steps: what follows runs without the event brackets)
+    # N > 1: next to the throughput curve (`value`: every GPU its own stream of passes, weak scaling) the STRONG job of BASELINE configs[3] -
+    # ONE 1200-frame sequence split over the ranks by whole texture segments, each rank's share one blocking job, the 32-byte manifest
+    # gather inside the timed region - so that one driver line per N carries both curves
+    strong_extra = None
+    if world > 1 and not strong and not args.host_inputs and not args.only:
+        TF = 1200
+        _, Fs, _, nsegs = shard.plan(TF, B, world, rank)
+        if 0 < Fs <= F:
+            set_profiling(False)
+            js = Job(Fs, blocking=True)
+            js.steps(1)
+            barrier(); ts = time.perf_counter()
+            js.steps(2)
+            tbl = shard.gather_counts(Fs * 2, nsegs * 2, B, 0, device=cdev)
+            barrier(); ds = time.perf_counter() - ts
+            tt = torch.tensor([ds], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ds = float(tt[0])
+            strong_extra = {"what": "BASELINE configs[3]: ONE job of %d frames split over %d ranks by whole texture segments (rank 0: %d frames), 2 jobs timed after 1 warm-up, max over ranks" % (TF, world, Fs),
+                            "frames_per_s": 2.0 * TF / ds, "ms_per_job": 500.0 * ds, "scaling": "strong", "frames_gathered": int(shard.totals(tbl, B)[0])}
+            set_profiling(True)
+
     if rank == 0:
-        drc_len = sum(len(x) for x in out["drc"]) / max(F, 1)
-        ktx_len = sum(len(x) for x in out["ktx2"]) / max(F, 1)
         algo_per_frame = 32.0 * V + 12.0 * Fc + 4.0 * args.tex_size ** 2 + drc_len + ktx_len
         tg = {}
-        for t in geos + texs:
-            for g in t.profile_report():
+        for rep in reports:
+            for g in rep:
                 a = tg.setdefault(g["name"], dict(name=g["name"], launches=0, total_ms=0.0, algo_bytes=0))
                 a["launches"] += g["launches"]; a["total_ms"] += g["total_ms"]; a["algo_bytes"] += g["algo_bytes"]
         groups = sorted(tg.values(), key=lambda g: -g["total_ms"])
@@ -347,11 +380,13 @@ def main():
                        "parallelism": "frames sharded per GPU in blocks of whole segments; per GPU %d geometry + %d texture streams" % (GS, len(texs)),
                        "drc_bytes_per_frame": drc_len, "ktx2_bytes_per_frame": ktx_len, "mesh_order": args.mesh_order, "connectivity": args.connectivity, "distinct_frames": ND,
                        "vertices_per_frame": V, "faces_per_frame": Fc,
-                       "geometry_workspace_bytes_per_frame": geos[0].mesh_workspace(**meshes_h[0])},
+                       "geometry_workspace_bytes_per_frame": geos[0].mesh_workspace(**meshes_h[0]),
+                       "hbm_in_use_gb_after_timed_steps": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1)},
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], units), "avg_launch_ms": avg_ms, "units_per_launch": units,
                          "algorithmic_bytes_per_frame": algo_per_frame,
                          "launches_per_step": dom["launches"] / max(1, args.steps),
+                         "frac_per_pass": achieved / HBM_PEAK_GBS * dom["launches"] / max(1, args.steps),
                          "note": "a pass is cut into groups on the context's lanes whose launches of this kernel run side by side: `frac` prices ONE launch (its frames, its duration) against the whole chip, as specified; "
                                  "frac x launches_per_step is what the concurrent launches move together while they overlap",
                          "end_to_end_achieved": algo_per_frame * total_frames / world / dt / 1e9},
@@ -368,6 +403,8 @@ def main():
         if args.parity_frames > 0 and F and not args.host_inputs:
             res["parity"] = parity_check(out, meshes_h, tex_h, args.parity_frames, args.only, args.mesh_order)
             res["parity_checked_frames"] = res["parity"].get("geometry_frames_equal_to_oracle", 0)
+        if strong_extra:
+            res["strong_configs3"] = strong_extra
         if variants_on:
             try:
                 args._geo_cfg = dict(gcfg, device=local_rank)

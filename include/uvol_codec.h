@@ -51,9 +51,11 @@ typedef struct uvol_params {
   int32_t etc1s_quality;            /* basisu -q equivalent, 1..255, default 128 (Encoder.py passes none) */
   int32_t y_flip;                   /* basisu -y_flip (Encoder.py:290 always passes it), default 1 */
   int32_t max_batch;                /* frames in flight per geometry batch, default 32 */
-  int32_t cu_mod;                   /* experimental CU partition (hipExtStreamCreateWithCUMask): CUs with (index % cu_mod) in cu_residues; 0 = all.
-                                       Measured without effect on kernel placement under ROCm 7.2 on this pool; off by default */
-  int32_t cu_residues;              /* bit r set = residue r allowed */
+  int32_t cu_mod;                   /* experimental CU partition (hipExtStreamCreateWithCUMask), 0 = all CUs (default).  > 1: mask bits with
+                                       (index % cu_mod) in cu_residues; -1: the CUs with ordinal lo .. hi - 1 inside EVERY XCD, cu_residues =
+                                       lo << 8 | hi.  Mask bit i is CU i / 8 of XCD i % 8, and a queue cannot be kept off an XCD
+                                       (profiles/r05_xcd_census.json) */
+  int32_t cu_residues;              /* bit r set = residue r allowed (cu_mod > 1); lo << 8 | hi (cu_mod == -1) */
   int32_t traverse_vbits_l2;        /* 1: the attribute traversers keep only their face bitmap in LDS and the vertex bitmap in L2
                                        (6 instead of 3 per CU): pays off when several contexts keep > 700 frames in flight */
   int32_t stream_priority;          /* 1: create the context's HIP stream with the highest priority (short, LDS-hungry texture

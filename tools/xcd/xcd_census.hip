@@ -24,8 +24,9 @@ static void run(const char *name, const std::vector<uint32_t> &mask, int ncu, bo
   if (mask.empty()) { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return; }
   else if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) { printf("%s{\"mask\": \"%s\", \"error\": \"hipExtStreamCreateWithCUMask failed\"}", first ? "" : ",\n", name); (void)hipGetLastError(); return; }
   const int nb = 8 * ncu; uint32_t *d; hipMalloc(&d, nb * 8); hipMemset(d, 0xff, nb * 8);
+  hipDeviceSynchronize();
   hipLaunchKernelGGL(k_census, dim3(nb), dim3(256), 0, s, d, 200000);     // 2 ms at 100 MHz
-  hipStreamSynchronize(s);
+  { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", name, hipGetErrorString(e)); return; } }
   std::vector<uint32_t> h(2 * nb); hipMemcpy(h.data(), d, nb * 8, hipMemcpyDeviceToHost);
   std::map<int, int> per_xcc; std::set<uint32_t> slots;
   for (int i = 0; i < nb; i++) { const int x = h[2 * i] & 15; per_xcc[x]++; const uint32_t id = h[2 * i + 1]; const uint32_t cu = (id >> 8) & 15, sh = (id >> 12) & 1, se = (id >> 13) & 7; slots.insert((x << 16) | (se << 8) | (sh << 4) | cu); }
@@ -36,6 +37,7 @@ static void run(const char *name, const std::vector<uint32_t> &mask, int ncu, bo
 }
 
 int main() {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0); const int ncu = p.multiProcessorCount; const size_t nw = (ncu + 31) / 32;
   printf("{\"cus\": %d, \"runs\": [\n", ncu);
   run("none", {}, ncu, true);

@@ -562,6 +562,11 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
   const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
   WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, tvg);
+  // Between the batch sizes whose 3 N traversers fit the CUs with both bitmaps in LDS (3 per CU: 256 frames) and twice that, the LDS
+  // form with the VERTEX bitmap in L2 (6 per CU, each walker ~30 % slower) still beats the lane-per-walker kernels, whose step is 2 - 3 x
+  // as long: a 300-frame job (BASELINE configs[2]) is such a batch.  UVOL_TRAV_AUTO_VGLOBAL=0 (diagnostic) keeps the old choice.
+  static const bool auto_vg = [] { const char *e = getenv("UVOL_TRAV_AUTO_VGLOBAL"); return !(e && *e == '0'); }();
+  if (auto_vg && !tvg && wp_trav.simt_w && geo_simt_env() == 0) { const WalkPlan alt = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, true); if (!alt.simt_w) wp_trav = alt; }
   const bool f16_off = geo_rec_face_off();
   const int fmt0 = (r8 && wp_walk.simt_w && !f16_off) ? 2 : r8, fmtT = (r8 && wp_trav.simt_w && !f16_off) ? 2 : r8;
   const bool base_shared = fmt0 == 2 && fmtT == 2;
@@ -663,6 +668,10 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   const bool relabel = geo_relabel_on() && !seq;
   bool lockstep = true;                                      // walkers of this batch move in lock step (see below); decides lanes per wave of the traversers
   bool any_relabel = relabel;
+  // UVOL_FE_SLICE=<frames> (experiment): the streaming front end (dedup; faces, corner table, the walk's record table)
+  // is launched slice by slice of that many frames instead of kernel by kernel over the whole group; 0 / unset = whole group
+  static const unsigned fe_slice_env = [] { const char *e = getenv("UVOL_FE_SLICE"); const int v = e ? atoi(e) : 0; return v <= 0 ? 0u : (unsigned)v; }();
+  const unsigned fe_slice = fe_slice_env ? fe_slice_env : N;
   for (int attempt = 0;; attempt++) {
   LAUNCH(k_job_clear, dim3(128, N), dim3(UVOL_BLOCK), dj);
   // bounding boxes first: the relabelling's Morton keys are taken over them (k_quantize uses them much later)
@@ -674,11 +683,14 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
       // UVOL_DD_SLOTS=<power of two <= 4096> (tests): LDS slots per bin; a small table forces GEO_E_DD_OVERFLOW and the retry
       uint32_t slots = DD_SLOTS; { const char *e = getenv("UVOL_DD_SLOTS"); const int v = e ? atoi(e) : 0; if (v >= 4 && v <= DD_SLOTS && !(v & (v - 1))) slots = (uint32_t)v; }
       const unsigned bt = (unsigned)((max_vals + DD_TILE - 1) / DD_TILE), nbm = (unsigned)std::min<uint64_t>(DD_MAXBINS, pow2_at_least(std::max<uint64_t>(1, max_vals / 1024)));
-      LAUNCH(k_dd_count, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_dd_scan, dim3(1, N, 3), dim3(UVOL_BLOCK), dj);
-      LAUNCH(k_dd_scatter, dim3(bt, N, 3), dim3(UVOL_BLOCK), dj);
-      if (max_vals / std::max(1u, nbm) <= 1100u && slots >= 2048u) LAUNCH((k_dd_resolve<2048, 4>), dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, 2048u);
-      else LAUNCH((k_dd_resolve<DD_SLOTS, 6>), dim3(nbm, N, 3), dim3(UVOL_BLOCK), dj, slots);
+      for (unsigned s0 = 0; s0 < N; s0 += fe_slice) {          // (slices: see fe_slice above)
+        GeoJob *djs = dj + s0; const unsigned Ns = std::min(fe_slice, N - s0);
+        LAUNCH(k_dd_count, dim3(bt, Ns, 3), dim3(UVOL_BLOCK), djs);
+        LAUNCH(k_dd_scan, dim3(1, Ns, 3), dim3(UVOL_BLOCK), djs);
+        LAUNCH(k_dd_scatter, dim3(bt, Ns, 3), dim3(UVOL_BLOCK), djs);
+        if (max_vals / std::max(1u, nbm) <= 1100u && slots >= 2048u) LAUNCH((k_dd_resolve<2048, 4>), dim3(nbm, Ns, 3), dim3(UVOL_BLOCK), djs, 2048u);
+        else LAUNCH((k_dd_resolve<DD_SLOTS, 6>), dim3(nbm, Ns, 3), dim3(UVOL_BLOCK), djs, slots);
+      }
     } else {
       LAUNCH(k_dd_clear, dim3(16, N, 3), dim3(UVOL_BLOCK), dj);
       LAUNCH(k_dedup<3>, dim3(bv, N), dim3(UVOL_BLOCK), dj, 0, 0);
@@ -719,6 +731,28 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   }
   if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe; }
   else {
+  const bool fe_sliced = fe_slice < N && !any_relabel && he_part_all;
+  if (fe_sliced) {
+    // the front end frame-slice by frame-slice: every kernel of the slice before the next slice starts, so that what one kernel writes
+    // (canonical faces, edge records, buckets, opposite corners: ~30 MB per frame) is still in the 256 MiB Infinity Cache when the next reads it
+    uvol_ctx::Scope sc(ctx, "geo.k3_corner_table", (uint64_t)3 * max_nfi * 4 * 3);
+    const unsigned bt = (unsigned)(((size_t)3 * max_nfi + HE_TILE - 1) / HE_TILE);
+    for (unsigned s0 = 0; s0 < N; s0 += fe_slice) {
+      GeoJob *djs = dj + s0; const unsigned Ns = std::min(fe_slice, N - s0);
+      LAUNCH(k_faces, dim3(bf, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_scan_sums, dim3(1, Ns), dim3(UVOL_BLOCK), djs, (int)SCAN_KEEP);
+      LAUNCH(k_compact_faces, dim3(bf, Ns), dim3(UVOL_BLOCK), djs, face_alias);
+      LAUNCH(k_quant_ids, dim3(bv, Ns, 3), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_hp_count, dim3(bt, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_hp_scan, dim3(1, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_hp_scatter, dim3(bt, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_hp_build, dim3(he_nb_max, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_edge_match, dim3(bci, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_vert0, dim3(bv, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_vert_fill, dim3(bc, Ns), dim3(UVOL_BLOCK), djs);
+      LAUNCH(k_pack0, dim3(bf, Ns), dim3(UVOL_BLOCK), djs, fmt0);
+    }
+  } else {
   {
     uvol_ctx::Scope sc(ctx, "geo.k2b_faces", 0);
     const unsigned mt0 = (unsigned)((max_vals + MS_TILE - 1) / MS_TILE), mt1 = (unsigned)(((size_t)max_nfi + MS_TILE - 1) / MS_TILE);
@@ -759,13 +793,14 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     LAUNCH(k_vert0, dim3(bv, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_vert_fill, dim3(bc, N), dim3(UVOL_BLOCK), dj);            // (frames with non-manifold vertices only: geo_vt)
   }
+  }   // !fe_sliced
   UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe;
   // UVOL_SIMT_W_WALK / UVOL_SIMT_W_TRAV (diagnostic): lanes per wave of one of the two lane-per-walker kernels only (UVOL_SIMT_W sets both)
   static const int w_walk_env = [] { const char *e = getenv("UVOL_SIMT_W_WALK"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
   static const int w_trav_env = [] { const char *e = getenv("UVOL_SIMT_W_TRAV"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
   if (w_walk_env && wp_walk.simt_w) wp_walk.simt_w = w_walk_env;
   {
-    LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, fmt0);
+    if (!fe_sliced) LAUNCH(k_pack0, dim3(bf, N), dim3(UVOL_BLOCK), dj, fmt0);
     uvol_ctx::Scope sc(ctx, "geo.k4_eb_walk", (uint64_t)n * 32 * max_nfi);
     if (wp_walk.simt_w) {
       const unsigned W = (unsigned)wp_walk.simt_w, nb = (N + W - 1) / W;
@@ -975,12 +1010,15 @@ int geo_flush(uvol_ctx *ctx) {
   return rc;
 }
 
-// lanes of a context: UVOL_GEO_LANES (default 2; 1 = every call one group on the context's stream, as before round 4).  Measured on 2560
+// lanes of a context: UVOL_GEO_LANES (1 = every call one group on the context's stream, as before round 4).  Measured in round 4 on 2560
 // distinct frames per call, enqueued calls: 1 / 2 / 3 / 4 lanes = 3176 / 3433 / 3401 / 3420 frames/s geometry alone, 2607 / 2682 / 2421 / 2517
 // beside the texture context - two groups overlap their front ends and walkers, more only add interference - while a blocking call cut
 // into four groups was SLOWER than one group (2454 against 3176: nothing runs beside the last group's walkers, and every group pays
 // its own read-back).
-static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 2; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
+// Round 5: THREE lanes, a call still cut into two groups (UVOL_GEO_GROUPS): the third lane takes the first group of the NEXT enqueued call, so
+// 1.5 calls' worth of frames are on the chip while the caller keeps ONE call's inputs resident.  2560 distinct frames per call: geometry alone
+// 4035 -> 4491 frames/s, beside the texture context 3118 - 3161 -> 3266 - 3279 (profiles/r05_frames_in_flight.json; four lanes run out of HBM).
+static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 3; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
 // frames per group at least (UVOL_GEO_MIN_GROUP, tests: small values spread small calls over the lanes): below 2 x this a call stays one
 // group - its walkers are the whole critical path anyway
 static inline int geo_min_group() { static const int v = [] { const char *e = getenv("UVOL_GEO_MIN_GROUP"); const int k = e ? atoi(e) : 160; return k < 1 ? 1 : k; }(); return v; }
@@ -997,7 +1035,12 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   const int want = on_device ? geo_lanes_wanted() : std::max(geo_lanes_wanted(), 4);
   static const int split_env = [] { const char *e = getenv("UVOL_GEO_SPLIT"); return e ? atoi(e) : -1; }();      // tests / diagnostic: 1 / 0 force / forbid the split
   if (split_env >= 0) split = split_env != 0;
-  const int groups = split ? std::max(1, std::min(want, n / geo_min_group())) : 1;
+  // groups per call <= lanes: with device inputs a call is cut into UVOL_GEO_GROUPS (default 2) groups while the ring has `want` lanes, so
+  // that consecutive enqueued calls hold want / groups calls' worth of frames on the chip (the walkers' chain is flat in the frame count:
+  // throughput follows the frames in flight, profiles/r05_frames_in_flight.json) without the caller keeping more inputs resident
+  static const int groups_env = [] { const char *e = getenv("UVOL_GEO_GROUPS"); const int k = e ? atoi(e) : 2; return k < 1 ? 1 : k; }();
+  const int gmax = on_device ? std::min(want, groups_env) : want;
+  const int groups = split ? std::max(1, std::min(gmax, n / geo_min_group())) : 1;
   for (int g = 0; g < groups; g++) {
     const int a = (int)((long long)n * g / groups), b = (int)((long long)n * (g + 1) / groups);
     // a blocking call on device inputs always runs on lane 0 (one workspace of its size per context, as before); the others take the ring

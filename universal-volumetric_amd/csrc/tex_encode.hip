@@ -1439,9 +1439,13 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   TexState *T = ctx->tex;
   T->lane[0].stream = ctx->stream;
   if (on_device) { const int ro = png_order_before(ctx, ctx->stream, rgba, (size_t)n_seg * n_layers); if (ro != UVOL_OK) return ro; }      // layers un-filtered on the ingest stream (uvol_unfilter_png_batch_dev)
-  const int part = tex_part_segments();
+  // device inputs: parts of UVOL_TEX_PART_DEV segments (default 128) - a segment in flight holds ~158 MB of workspace (2048^2 x 5 layers), so
+  // the 512 segments of a 2560-frame pass held 81 GB at once; in parts on the two lanes 40 GB, which the geometry context's frames in
+  // flight are worth more than (profiles/r05_frames_in_flight.json)
+  static const int part_dev = [] { const char *e = getenv("UVOL_TEX_PART_DEV"); const int k = e ? atoi(e) : 128; return k < 0 ? 0 : k; }();
+  const int part = on_device ? part_dev : tex_part_segments();
   int rc = UVOL_OK;
-  if (on_device || part <= 0 || n_seg < 2 * part) {                       // one batch on the context's stream
+  if (part <= 0 || n_seg < 2 * part) {                                    // one batch on the context's stream
     rc = tex_submit(ctx, T->lane[0], rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0, status);
     if (rc == UVOL_OK) rc = tex_finish(ctx, T->lane[0], rgba, on_device);
     ctx->resolve_profile();
@@ -1451,16 +1455,17 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   // part k + 1 through the pinned buffers and its DMAs run on the other lane's stream; then part k's containers are written while part
   // k + 1 encodes.  16.8 MB per layer cross PCIe: without the overlap a call was upload, then encode, one after the other.
   if (!T->lane[1].stream) { if (uvol_make_stream(ctx, &T->lane[1].stream) != hipSuccess) { ctx->set_error("texture lane: stream creation failed"); return UVOL_E_HIP; } T->lane[1].own_stream = true; }
-  const int parts = std::max(2, std::min(4, n_seg / part));           // few, large parts: every part pays the serial stages' latency (one wave per slice) once
+  if (on_device) { const int ro = png_order_before(ctx, T->lane[1].stream, rgba, (size_t)n_seg * n_layers); if (ro != UVOL_OK) return ro; }      // (the second lane reads the un-filtered layers too)
+  const int parts = on_device ? (n_seg + part - 1) / part : std::max(2, std::min(4, n_seg / part));           // few, large parts: every part pays the serial stages' latency (one wave per slice) once
   auto lo = [&](int k) { return (int)((long long)n_seg * k / parts); };
   int worst = UVOL_OK;
   for (int k = 0; k <= parts; k++) {
     if (k < parts) {
       const int a = lo(k), b = lo(k + 1);
-      const int r = tex_submit(ctx, T->lane[k & 1], rgba + (size_t)a * n_layers, b - a, n_layers, W, H, false, outs + a, caps + a, out_lens + a, 0, status ? status + a : nullptr);
-      if (r != UVOL_OK) { if (k > 0) (void)tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, false); return r; }
+      const int r = tex_submit(ctx, T->lane[k & 1], rgba + (size_t)a * n_layers, b - a, n_layers, W, H, on_device, outs + a, caps + a, out_lens + a, 0, status ? status + a : nullptr);
+      if (r != UVOL_OK) { if (k > 0) (void)tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, on_device); return r; }
     }
-    if (k > 0) { const int r = tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, false); if (r != UVOL_OK && worst == UVOL_OK) worst = r; }
+    if (k > 0) { const int r = tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, on_device); if (r != UVOL_OK && worst == UVOL_OK) worst = r; }
   }
   ctx->resolve_profile();
   return worst;

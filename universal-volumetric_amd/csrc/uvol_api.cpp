@@ -30,6 +30,20 @@ extern "C" void uvol_host_free(void *p) {
 }
 hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
 #ifndef HIPEMU
+  // cu_mod == -1: the CUs with per-XCD ordinal in [lo, hi), cu_residues = lo << 8 | hi.  Mask bit i is CU ordinal i / 8 of XCD i % 8
+  // (profiles/r05_xcd_census.json; an XCD whose bits are all clear is NOT excluded - its mask then counts as "all CUs" and the dispatcher
+  // deals workgroups round-robin over the eight XCDs whatever the mask - so a queue cannot be kept off an XCD, only off CUs inside each one)
+  if (ctx->prm.cu_mod == -1 && ctx->prm.cu_residues != 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) {
+      const int ncu = prop.multiProcessorCount, lo = (ctx->prm.cu_residues >> 8) & 255, hi = ctx->prm.cu_residues & 255; std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu; i++) if (i / 8 >= lo && i / 8 < hi) mask[(size_t)i / 32] |= 1u << (i % 32);
+      const hipError_t e = hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+      if (uvol_debug()) fprintf(stderr, "[uvol] CU-masked stream: per-XCD CU ordinals [%d, %d) -> %s\n", lo, hi, hipGetErrorString(e));
+      if (e == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+  }
   if (ctx->prm.cu_mod > 1 && ctx->prm.cu_mod <= 32 && ctx->prm.cu_residues != 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) {

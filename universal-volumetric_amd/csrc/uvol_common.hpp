@@ -217,7 +217,7 @@ struct uvol_ctx {
 static inline int uvol_ensure(uvol_ctx *ctx, uvol_devbuf &b, size_t bytes) {
   if (bytes <= b.cap) return UVOL_OK;
   if (b.p) { UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); UVOL_HIP_CHECK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-  size_t want = bytes + bytes / 8 + 4096;
+  size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20) + 4096;      // slack against re-allocation for slightly larger batches; bounded: an eighth of a 100 GB workspace is frames that could be in flight
   UVOL_HIP_CHECK(ctx, hipMalloc(&b.p, want));
   b.cap = want;
   return UVOL_OK;
