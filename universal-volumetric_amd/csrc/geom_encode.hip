@@ -71,6 +71,7 @@ struct GeoLane {
 };
 struct GeoState {
   std::vector<GeoLane *> lanes; int next_lane = 0;
+  hipEvent_t walk_last = nullptr;      // walk event of the group submitted last (UVOL_GEO_CHAIN=2)
   hipEvent_t fe_last = nullptr;        // front-end event of the group submitted last (the front ends of consecutive groups run one after the other)
   int deferred_rc = UVOL_OK;           // first error among groups completed on behalf of a later call (geo_flush returns it)
   WsPlanCache plan; std::vector<WsItem> items;     // workspace placements by frame shape
@@ -562,11 +563,8 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   static const bool tvg_env = [] { const char *e = getenv("UVOL_TRAVERSE_VGLOBAL"); return e && *e == '1'; }();
   const bool tvg = tvg_env || ctx->prm.traverse_vbits_l2 != 0;
   WalkPlan wp_trav = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, tvg);
-  // Between the batch sizes whose 3 N traversers fit the CUs with both bitmaps in LDS (3 per CU: 256 frames) and twice that, the LDS
-  // form with the VERTEX bitmap in L2 (6 per CU, each walker ~30 % slower) still beats the lane-per-walker kernels, whose step is 2 - 3 x
-  // as long: a 300-frame job (BASELINE configs[2]) is such a batch.  UVOL_TRAV_AUTO_VGLOBAL=0 (diagnostic) keeps the old choice.
-  static const bool auto_vg = [] { const char *e = getenv("UVOL_TRAV_AUTO_VGLOBAL"); return !(e && *e == '0'); }();
-  if (auto_vg && !tvg && wp_trav.simt_w && geo_simt_env() == 0) { const WalkPlan alt = walk_plan(G, max_nfi, max_vals, (size_t)3 * NC0, true); if (!alt.simt_w) wp_trav = alt; }
+  // (Measured in round 5 and not kept, profiles/r05_small_jobs.json: between 256 and 512 frames the LDS traversers with their VERTEX bitmap in L2
+  // - 6 per CU, so 3 N of them fit - lose to the wave-form lane kernels: 190 against 124 ms per 300-frame job, 894 against 1110 frames/s.)
   const bool f16_off = geo_rec_face_off();
   const int fmt0 = (r8 && wp_walk.simt_w && !f16_off) ? 2 : r8, fmtT = (r8 && wp_trav.simt_w && !f16_off) ? 2 : r8;
   const bool base_shared = fmt0 == 2 && fmtT == 2;
@@ -661,8 +659,12 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   // The front ends (dedup, corner table: streaming kernels that fill the chip) of consecutive groups run one after the other, so that a
   // group's front end meets the WALKERS of the groups before it - latency-bound, a few hundred waves - instead of their front ends:
   // each group then gets through its bandwidth-bound phases at close to the chip's full rate and the groups stay staggered.
-  static const bool fe_chain = [] { const char *e = getenv("UVOL_GEO_CHAIN"); return !(e && *e == '0'); }();
-  if (fe_chain && G->fe_last && G->fe_last != L.ev_fe) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->fe_last, 0));
+  // UVOL_GEO_CHAIN: 0 = no chain, 1 = behind the previous group's front end, 2 = behind the previous group's WALK (experiment: a stagger of
+  // front end + walk, about a third of a group's chain, whatever the moment the host submitted the groups - three groups submitted together
+  // otherwise stay bunched: their walkers run together, then their streaming kernels compete)
+  static const int fe_chain = [] { const char *e = getenv("UVOL_GEO_CHAIN"); return e ? atoi(e) : 1; }();
+  if (fe_chain == 2 && G->walk_last && G->walk_last != L.ev_walk) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->walk_last, 0));
+  else if (fe_chain && G->fe_last && G->fe_last != L.ev_fe) UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, G->fe_last, 0));
   const unsigned bf = uvol_blocks(max_nfi), bc = uvol_blocks((size_t)3 * max_nfi), bv = uvol_blocks(max_vals), bci = (bc + GEO_ILP - 1) / GEO_ILP;
   unsigned be = uvol_blocks(std::min<size_t>(max_ecap, (size_t)3 * max_nfi));       // attribute entries (<= ecap, else GEO_E_WS_OVERFLOW)
   const bool relabel = geo_relabel_on() && !seq;
@@ -729,7 +731,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   }
   break;
   }
-  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe; }
+  if (seq) { const int rcq = geo_encode_sequential(ctx, dj, n, full, max_nfi, max_vals, max_ecap, algo_in); if (rcq != UVOL_OK) return rcq; UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_fe, ctx->stream)); G->fe_last = L.ev_fe; G->walk_last = nullptr; }
   else {
   const bool fe_sliced = fe_slice < N && !any_relabel && he_part_all;
   if (fe_sliced) {
@@ -822,7 +824,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     LAUNCH(k_eb_event_compact, dim3(bf, N), dim3(UVOL_BLOCK), dj);
     LAUNCH(k_valence_init, dim3(bc, N), dim3(UVOL_BLOCK), dj);
   }
-  UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_walk, ctx->stream));
+  UVOL_HIP_CHECK(ctx, hipEventRecord(L.ev_walk, ctx->stream)); G->walk_last = L.ev_walk;
   UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(L.aux, L.ev_walk, 0));
   {
     { uvol_ctx::Scope sc(ctx, "geo.k4_eb_valence", 0, L.aux); LAUNCH_ON(L.aux, k_eb_valence, dim3(N), dim3(64), dj); }
