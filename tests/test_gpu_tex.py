@@ -153,6 +153,25 @@ def test_gpu_host_segments_in_parts_on_two_lanes(oracle, gpu_codec):
         assert r == (oracle.ktx2_encode(segs[30]) if i == 30 else want[i % 6]), i
 
 
+def test_gpu_device_segments_in_parts_on_two_lanes(oracle, gpu_codec):
+    """Round 5: a call of >= 256 segments on DEVICE inputs is cut into parts of 128 that alternate between two lanes.  260 segments of
+    64^2 x 2 resident in HBM (one of them with alpha: second pass on its lane): every segment equals the oracle's bytes, whatever part
+    it fell into."""
+    import numpy as np, torch, synth
+    from test_hipemu_tex import _alpha_sequence
+    base = [synth.texture_sequence(2, size=64, seed=s) for s in range(6)]
+    segs = [base[i % 6] for i in range(260)]
+    segs[200] = _alpha_sequence(2, 64, 5)
+    dev = [[torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).cuda() for a in s] for s in base + [segs[200]]]
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() for i in range(260) for t in (dev[6] if i == 200 else dev[i % 6])]
+    want = [oracle.ktx2_encode(t) for t in base]
+    res = gpu_codec.encode_texture_segments_dev(ptrs, 2, 64, 64)
+    assert len(res) == 260
+    for i, r in enumerate(res):
+        assert bytes(r) == (oracle.ktx2_encode(segs[200]) if i == 200 else want[i % 6]), i
+
+
 def test_gpu_texture_decode_matches_oracle(oracle, gpu_codec):
     """Decode path (texture half) on the GPU against the pinned oracle decoder: the reference's own fixture
     (Basis Universal 1.16, 1024x1024x5) and this codec's output; host and device output variants."""

@@ -286,6 +286,13 @@ def test_hipemu_call_spread_over_lanes(oracle, hipemu_lib):
         "cd.start_mesh_batch(ds)\n"
         "assert cd.encode_mesh_batch(frames[:3]) == want[:3]\n"
         "assert cd.finish() == [[enc(f) for f in ds]]\n"
+        # round 5: DEVICE inputs - a call is cut into TWO groups while the ring has three lanes, so the third lane takes the first group of
+        # the next enqueued call (four calls = eight groups round the ring; the emulation's device memory is the heap)
+        "mm = [uvol.Codec._mesh_host(**f) for f in ds]\n"
+        "arr = (uvol.Mesh * len(ds))(*[m for m, _ in mm])\n"
+        "for k in range(4): cd.start_mesh_batch_dev(arr, slot=k & 1)\n"
+        "r = cd.finish(); assert len(r) == 4\n"
+        "for rr in r: assert [bytes(x) for x in rr] == [enc(f) for f in ds]\n"
         "cd.close(); print('lanes ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), hipemu_lib)
     for lanes in ("3",):                        # (three lanes: a 9-frame call becomes three groups, the ring wraps inside the enqueued calls)

@@ -289,6 +289,29 @@ def test_hipemu_host_segments_in_parts_on_two_lanes(oracle, hipemu_lib):
     assert r.returncode == 0 and "parts ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_hipemu_device_segments_in_parts_on_two_lanes(oracle, hipemu_lib):
+    """Round 5: a call on DEVICE inputs of >= 2 x UVOL_TEX_PART_DEV segments is cut into parts that alternate between the two lanes (a
+    segment in flight holds ~141 MB of workspace at 2048^2 x 5; parts halve what a 512-segment pass holds).  UVOL_TEX_PART_DEV=1 cuts a
+    5-segment call into five parts: every segment's bytes are the oracle's, including an alpha segment in the middle (its second pass
+    runs on its lane, reading the device layers again)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path[:0] = [%r, %r, %r]\n"
+        "import numpy as np, synth, uvol, oracle as O\n"
+        "from test_hipemu_tex import _alpha_sequence\n"
+        "O.lib(); cd = uvol.Codec(lib_path=%r)\n"
+        "segs = [synth.texture_sequence(2, size=32, seed=k) for k in range(5)]\n"
+        "segs[2] = _alpha_sequence(2, 32, 7)\n"
+        "arrs = [np.ascontiguousarray(a, dtype=np.uint8) for s in segs for a in s]\n"      # (the emulation's device memory is the heap)
+        "got = cd.encode_texture_segments_dev([a.ctypes.data for a in arrs], 2, 32, 32)\n"
+        "assert [bytes(g) for g in got] == [O.ktx2_encode(s) for s in segs]\n"
+        "cd.close(); print('parts ok')\n"
+    ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), hipemu_lib)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_TEX_PART_DEV="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "parts ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_hipemu_etc1s_alpha_slices(oracle, hipemu_lib):
     """images with alpha != 255 get alpha slices, as basisu writes them and the stock player reads them
     (src/lib/KTX2Loader.js:493-497): a second slice per image (the alpha channel as a grey image through the same codebooks), a second

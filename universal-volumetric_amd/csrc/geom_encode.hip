@@ -71,6 +71,7 @@ struct GeoLane {
 };
 struct GeoState {
   std::vector<GeoLane *> lanes; int next_lane = 0;
+  int lanes_cap = 1 << 20;             // lanes the ring may use: lowered when a lane could not get its workspace (three lanes of general-layout groups do not fit beside a full set of inputs), reset by uvol_trim
   hipEvent_t walk_last = nullptr;      // walk event of the group submitted last (UVOL_GEO_CHAIN=2)
   hipEvent_t fe_last = nullptr;        // front-end event of the group submitted last (the front ends of consecutive groups run one after the other)
   int deferred_rc = UVOL_OK;           // first error among groups completed on behalf of a later call (geo_flush returns it)
@@ -105,6 +106,7 @@ static GeoLane *geo_lane(uvol_ctx *ctx, int k) {
 // 130 GB); streams, events and the small job arrays stay.  The caller has completed the context's work (geo_flush).
 int geo_trim(uvol_ctx *ctx) {
   GeoState *G = ctx->geo; if (!G) return UVOL_OK;
+  G->lanes_cap = 1 << 20;
   for (GeoLane *L : G->lanes) {
     if (L->busy) continue;
     UVOL_HIP_CHECK(ctx, hipStreamSynchronize(L->stream)); UVOL_HIP_CHECK(ctx, hipStreamSynchronize(L->aux));
@@ -611,6 +613,9 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     (void)hipGetLastError();
     for (GeoLane *o : G->lanes) if (o != &L && o->busy) { const int r = geo_complete(ctx, *o); if (r != UVOL_OK && G->deferred_rc == UVOL_OK) G->deferred_rc = r; }      // (their results first)
     for (GeoLane *o : G->lanes) if (o != &L && !o->busy) for (uvol_devbuf *b : { &o->slab, &o->inputs, &o->outs }) if (b->p) { (void)hipStreamSynchronize(o->stream); (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    // ... and the ring gets by with one lane less from here on (until uvol_trim): otherwise every submission takes another lane's workspace away
+    // and allocates its own again (the shuffled-order variant inside the bench line: 1657 frames/s against 2453 as a process of its own)
+    G->lanes_cap = std::max(1, std::min(G->lanes_cap, (int)G->lanes.size()) - 1);
     if ((rc = uvol_ensure(ctx, L.slab, ws_total))) return rc;
   }
   if ((rc = uvol_ensure(ctx, L.jobs, sizeof(GeoJob) * (size_t)n))) return rc;
@@ -931,6 +936,8 @@ static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
     const size_t want = packed + packed / 4 + (1u << 20);
     UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&L.pinned, want, hipHostMallocDefault));
     L.pinned_cap = want;
+    // (the ring's lanes that have their device buffers but no staging yet get it now, for the same reason as in geo_encode_batch_begin)
+    for (GeoLane *o : ctx->geo->lanes) if (o != &L && !o->pinned && o->slab.p && !o->ext_out) { if (hipHostMalloc((void **)&o->pinned, want, hipHostMallocDefault) == hipSuccess) o->pinned_cap = want; else { (void)hipGetLastError(); o->pinned = nullptr; } }
   }
   if (packed) {
     UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.pinned, L.outs.p, packed, hipMemcpyDeviceToHost, ctx->stream));
@@ -1017,10 +1024,13 @@ int geo_flush(uvol_ctx *ctx) {
 // beside the texture context - two groups overlap their front ends and walkers, more only add interference - while a blocking call cut
 // into four groups was SLOWER than one group (2454 against 3176: nothing runs beside the last group's walkers, and every group pays
 // its own read-back).
-// Round 5: THREE lanes, a call still cut into two groups (UVOL_GEO_GROUPS): the third lane takes the first group of the NEXT enqueued call, so
-// 1.5 calls' worth of frames are on the chip while the caller keeps ONE call's inputs resident.  2560 distinct frames per call: geometry alone
-// 4035 -> 4491 frames/s, beside the texture context 3118 - 3161 -> 3266 - 3279 (profiles/r05_frames_in_flight.json; four lanes run out of HBM).
-static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 3; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
+// Round 5: the ring is LONGER than the groups of one call - SIX lanes, an enqueued call of device inputs cut into FOUR groups (UVOL_GEO_GROUPS) - so
+// the lanes past the fourth take the first groups of the NEXT enqueued call: 1.5 calls' worth of frames are on the chip while the caller keeps ONE
+// call's inputs resident, and six groups at different points of their chains mix streaming and walker phases more evenly than three.  2560 distinct
+// frames per call, frames/s geometry alone / beside the texture context: 2 lanes x 2 groups 4035 / 3118 - 3161, 3 x 2 4964 / 3263 - 3397, 6 x 4
+// 5307 / 3525 - 3650, 7 x 4 - / 3743 (244 GB of HBM in use), 8 x 5 5435 / 3583, 12 x 8 - / 3194 (profiles/r05_frames_in_flight.json,
+// r05_ring_shapes.json).  A lane that cannot get its workspace leaves the ring (GeoState::lanes_cap).
+static inline int geo_lanes_wanted() { static const int v = [] { const char *e = getenv("UVOL_GEO_LANES"); const int k = e ? atoi(e) : 6; return k < 1 ? 1 : (k > 16 ? 16 : k); }(); return v; }
 // frames per group at least (UVOL_GEO_MIN_GROUP, tests: small values spread small calls over the lanes): below 2 x this a call stays one
 // group - its walkers are the whole critical path anyway
 static inline int geo_min_group() { static const int v = [] { const char *e = getenv("UVOL_GEO_MIN_GROUP"); const int k = e ? atoi(e) : 160; return k < 1 ? 1 : k; }(); return v; }
@@ -1034,15 +1044,16 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   GeoState *G = ctx->geo;
   if (n <= 0) return UVOL_OK;
   // host inputs: four groups at least (a group uploads while the groups before it encode; the first group's upload is the only one nothing hides)
-  const int want = on_device ? geo_lanes_wanted() : std::max(geo_lanes_wanted(), 4);
+  const int want = std::max(1, std::min(G->lanes_cap, on_device ? geo_lanes_wanted() : std::max(geo_lanes_wanted(), 4)));
   static const int split_env = [] { const char *e = getenv("UVOL_GEO_SPLIT"); return e ? atoi(e) : -1; }();      // tests / diagnostic: 1 / 0 force / forbid the split
   if (split_env >= 0) split = split_env != 0;
-  // groups per call <= lanes: with device inputs a call is cut into UVOL_GEO_GROUPS (default 2) groups while the ring has `want` lanes, so
+  // groups per call <= lanes: with device inputs a call is cut into UVOL_GEO_GROUPS (default 4) groups while the ring has `want` lanes, so
   // that consecutive enqueued calls hold want / groups calls' worth of frames on the chip (the walkers' chain is flat in the frame count:
   // throughput follows the frames in flight, profiles/r05_frames_in_flight.json) without the caller keeping more inputs resident
-  static const int groups_env = [] { const char *e = getenv("UVOL_GEO_GROUPS"); const int k = e ? atoi(e) : 2; return k < 1 ? 1 : k; }();
+  static const int groups_env = [] { const char *e = getenv("UVOL_GEO_GROUPS"); const int k = e ? atoi(e) : 4; return k < 1 ? 1 : k; }();
   const int gmax = on_device ? std::min(want, groups_env) : want;
   const int groups = split ? std::max(1, std::min(gmax, n / geo_min_group())) : 1;
+  GeoLane *last = nullptr;
   for (int g = 0; g < groups; g++) {
     const int a = (int)((long long)n * g / groups), b = (int)((long long)n * (g + 1) / groups);
     // a blocking call on device inputs always runs on lane 0 (one workspace of its size per context, as before); the others take the ring
@@ -1052,6 +1063,21 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
     if (L->busy) { const int r = geo_complete(ctx, *L); if (r != UVOL_OK && G->deferred_rc == UVOL_OK) G->deferred_rc = r; }
     const int rc = geo_submit(ctx, *L, meshes + a, b - a, n, on_device, outs + a, caps + a, out_lens + a, status ? status + a : nullptr, false);
     if (rc != UVOL_OK) return rc;
+    last = L;
+  }
+  // The lanes of the ring that have not held a group yet get their buffers NOW, sized like the group just submitted: a first allocation of tens of
+  // GB takes the runtime from milliseconds to more than a second (profiles/r05_x_regimes.json: 1.1 - 1.6 s per lane in every other process on
+  // this pool), and a ring longer than the groups of one call first reaches its last lane during the caller's SECOND call - here it happens
+  // beside the kernels of the first.  A lane that cannot get them leaves the ring (lanes_cap).
+  if (split && on_device && last && groups < want) {
+    for (int k = 0; k < want; k++) {
+      GeoLane *P = geo_lane(ctx, k);
+      if (!P || P == last || P->busy || P->slab.p) continue;
+      bool ok = true;
+      for (auto pr : { std::make_pair(&P->slab, last->slab.cap), std::make_pair(&P->outs, last->outs.cap), std::make_pair(&P->jobs, last->jobs.cap) })
+        if (ok && pr.second && !pr.first->p) { if (hipMalloc(&pr.first->p, pr.second) == hipSuccess) pr.first->cap = pr.second; else { (void)hipGetLastError(); pr.first->p = nullptr; ok = false; } }
+      if (!ok) { for (uvol_devbuf *b : { &P->slab, &P->outs, &P->jobs }) if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; } G->lanes_cap = std::max(1, std::min(G->lanes_cap, k)); break; }
+    }
   }
   return UVOL_OK;
 }
