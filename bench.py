@@ -35,7 +35,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 I8_PEAK_TOPS = 3944.0        # dense i8 MFMA (16x16x64), MI355X_MICROARCH.md
-PMC_FILE = "r04_pmc_traffic.json"
+PMC_FILE = "r05_pmc_traffic.json"
 
 
 def main():
@@ -597,7 +597,7 @@ def quality_gates(geo, tex, out, mesh0, tex0, B):
 def pmc_traffic(group, units):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE are
     collected in their own runs, profiles/<PMC_FILE> records the per-frame figure and how it was corrected)."""
-    for f in (PMC_FILE, "r02_pmc_traffic.json"):
+    for f in (PMC_FILE, "archive/r02_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", f)))
             e = t["kernels"].get(group)

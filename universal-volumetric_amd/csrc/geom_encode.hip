@@ -855,7 +855,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     uvol_ctx::Scope sc(ctx, "geo.k5_traverse", (uint64_t)n * 32 * max_nfi * 3);
     // params.traverse_vbits_l2 (or UVOL_TRAVERSE_VGLOBAL=1): LDS traversers keep only the face bitmap in LDS (25 KB -> 6 per
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
-    // unrelated meshes: FOUR traversers per wave in the wave form (3488 / 3709 / 3950 / 3993 / 3942 / 3696 frames/s geometry alone with the lane
+    // unrelated meshes: FOUR traversers per wave in the wave form (3207 / 3774 / 4036 / 4060 / 3927 / 3780 frames/s geometry alone on two lanes with the lane
     // form at 1 and the wave form at 1 / 2 / 4 / 8 / 16 per wave, 2560 distinct frames: profiles/r05_walker_forms.json)
     if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = fmtT == 2 ? 4 : 1;
     if (w_trav_env && wp_trav.simt_w) wp_trav.simt_w = w_trav_env;
