@@ -458,6 +458,7 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
         return v
     # (2) scan-like storage order: the resident input buffers are overwritten with a seeded permutation of faces and values
     note("shuffled_order")
+    trim_geos()                                                # (relabelled frames use the general layout: the lanes' workspaces are re-sized, not stacked on the headline's)
     sh = [synth.shuffle_mesh(m, seed=100 + k) for k, m in enumerate(meshes_h)]
     for i, t in enumerate(frame_t):
         for key, val in sh[i % len(sh)].items():
@@ -467,6 +468,7 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     # (2b) rounds 1-3's headline workload: the frames share ONE index array, walkers of a wave never diverge (new input buffers)
     if args.connectivity == "distinct":
         note("identical_connectivity")
+        trim_geos()
         build_inputs(identical_meshes())
         v["identical_connectivity"] = dict(Job(F).timed(2, 1), note="DIAGNOSTIC: five deformations of one tessellation (shared index arrays): the lane-per-walker kernels move in lock step; "
                                                                      "this was `value` until round 3 and flatters the dominant kernel")

@@ -472,6 +472,41 @@ def test_gpu_enqueue_form_of_the_abi(oracle, gpu_codec):
     assert r[0] == [ea, eb] and r[1] == [eb, None, ea] and r[2] == [oracle.ktx2_encode(tex)] * 2
 
 
+def test_gpu_enqueued_device_calls_round_the_lane_ring(oracle):
+    """Round 5: an enqueued call on DEVICE inputs is cut into four groups while the context's ring has six lanes, so the groups of the next
+    call start on the lanes the previous one left free and the ring wraps inside a stream of calls (the lanes past the first call's get
+    their buffers ahead of time).  Four calls of 700 small distinct frames resident in HBM, alternating output slots: every call's bytes
+    are the oracle's, frame by frame."""
+    import torch, synth, uvol
+    frames = synth.distinct_meshes(7, 24, 13, bases=3, charts=(3, 2))
+    want = [_oracle_bytes(oracle, f) for f in frames]
+    n = 700
+    keep, meshes = [], []
+    for f in frames:
+        m, arrs = uvol.Codec._mesh_host(**f)
+        dev = [None if a is None else torch.from_numpy(a).cuda() for a in arrs]
+        keep.append(dev)
+        pos, uv, nrm, ip, iu, inr = dev
+        m.pos = pos.data_ptr(); m.idx_pos = ip.data_ptr()
+        if uv is not None: m.uv = uv.data_ptr(); m.idx_uv = iu.data_ptr()
+        if nrm is not None: m.nrm = nrm.data_ptr(); m.idx_nrm = inr.data_ptr()
+        meshes.append(m)
+    torch.cuda.synchronize()
+    arr = (uvol.Mesh * n)(*[meshes[i % 7] for i in range(n)])
+    cd = uvol.Codec(device=0, max_batch=n)
+    try:
+        for k in range(4):
+            cd.start_mesh_batch_dev(arr, slot=k & 1)
+        res = cd.finish()
+    finally:
+        cd.close()
+    assert len(res) == 4
+    for rr in res[2:]:                                      # (the views of calls 0 / 1 were overwritten by calls 2 / 3 of the same slots: same content)
+        assert len(rr) == n
+        for i, r in enumerate(rr):
+            assert r is not None and bytes(r) == want[i % 7], i
+
+
 def test_gpu_decoder_reads_the_other_draco_tool_sets(oracle, gpu_codec):
     """streams with the STANDARD edgebreaker traversal (stock compression levels 1..5) and with SEQUENTIAL connectivity
     (level 0) decode on the device to exactly what the CPU restatement decodes - at test sizes and at 100k vertices -,

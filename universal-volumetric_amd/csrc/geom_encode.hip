@@ -1069,14 +1069,16 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   // GB takes the runtime from milliseconds to more than a second (profiles/r05_x_regimes.json: 1.1 - 1.6 s per lane in every other process on
   // this pool), and a ring longer than the groups of one call first reaches its last lane during the caller's SECOND call - here it happens
   // beside the kernels of the first.  A lane that cannot get them leaves the ring (lanes_cap).
+  // (only the lanes the NEXT call of this shape will reach: a stream of small calls - one group each - allocates one lane ahead, not the whole ring at once)
   if (split && on_device && last && groups < want) {
-    for (int k = 0; k < want; k++) {
+    for (int j = 0; j < std::min(groups, want); j++) {
+      const int k = (G->next_lane + j) % want;
       GeoLane *P = geo_lane(ctx, k);
       if (!P || P == last || P->busy || P->slab.p) continue;
       bool ok = true;
       for (auto pr : { std::make_pair(&P->slab, last->slab.cap), std::make_pair(&P->outs, last->outs.cap), std::make_pair(&P->jobs, last->jobs.cap) })
         if (ok && pr.second && !pr.first->p) { if (hipMalloc(&pr.first->p, pr.second) == hipSuccess) pr.first->cap = pr.second; else { (void)hipGetLastError(); pr.first->p = nullptr; ok = false; } }
-      if (!ok) { for (uvol_devbuf *b : { &P->slab, &P->outs, &P->jobs }) if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; } G->lanes_cap = std::max(1, std::min(G->lanes_cap, k)); break; }
+      if (!ok) { for (uvol_devbuf *b : { &P->slab, &P->outs, &P->jobs }) if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; } int have = 0; for (GeoLane *o : G->lanes) have += o->slab.p ? 1 : 0; G->lanes_cap = std::max(1, std::min(G->lanes_cap, have)); break; }
     }
   }
   return UVOL_OK;
