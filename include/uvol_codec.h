@@ -262,7 +262,13 @@ int uvol_transcode_texture_segments_astc(uvol_ctx *ctx, const uint8_t *const *kt
  * (UVOL_E_INVALID), a source kind the target does not take (UVOL_E_UNSUPPORTED: ASTC wants UASTC sources, ETC1 / ETC2 want ETC1S; RGBA32 and
  * BC7 take both), a payload that turns out corrupt on the device (UVOL_E_ENCODE) fail in their own slot; ETC1S and UASTC files may share a
  * batch.  out[s * layers + l] as in the entry point of the target; slots of failed segments are not read. */
-enum { UVOL_TARGET_RGBA32 = 0, UVOL_TARGET_ETC1 = 1, UVOL_TARGET_BC7 = 2, UVOL_TARGET_ASTC = 3, UVOL_TARGET_ETC2_RGBA = 4 };
+enum { UVOL_TARGET_RGBA32 = 0, UVOL_TARGET_ETC1 = 1, UVOL_TARGET_BC7 = 2, UVOL_TARGET_ASTC = 3, UVOL_TARGET_ETC2_RGBA = 4,
+       UVOL_TARGET_BC1 = 5, UVOL_TARGET_BC3 = 6 };
+/* UVOL_TARGET_BC1 / UVOL_TARGET_BC3 (round 5, ETC1S sources, through uvol_transcode_texture_segments_st only): the stock loader's
+ * `dxtSupported` row (reference src/lib/KTX2Loader.js:610-618: TranscoderFormat.BC1 for an opaque file, BC3 for one with alpha slices).
+ * 8-byte BC1 blocks (four-colour mode; a file with alpha slices is UVOL_E_UNSUPPORTED: it is asked for BC3) / 16-byte BC3 blocks (BC4
+ * alpha block from the alpha slice - 255 for an opaque file -, then the colour block), raster order.  Re-fits of the four ETC1S colours /
+ * alpha levels, gated by PSNR against the RGBA32 decode like the BC7 target; UASTC sources are UVOL_E_UNSUPPORTED for these two. */
 int uvol_encode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers,
                                     uint32_t width, uint32_t height, int inputs_on_device,
                                     uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);

@@ -170,6 +170,51 @@ def bc7_decode_blocks(blocks, width, height):
     return out[:height, :width]
 
 
+def bc1_decode_blocks(blocks, width, height, four_colour_always=False):
+    """Independent BC1 (DXT1) colour-block decoder written from the format description: colour0 / colour1 as little-endian RGB565, 16 2-bit
+    indices in raster order from bit 0; colour0 > colour1 (or four_colour_always, as inside BC2 / BC3): palette c0, c1, (2 c0 + c1) / 3,
+    (c0 + 2 c1) / 3; otherwise c0, c1, (c0 + c1) / 2 and transparent black.  blocks [by, bx, 8] uint8 -> RGBA8 [height, width, 4]."""
+    by, bx = blocks.shape[:2]
+    out = np.zeros((by * 4, bx * 4, 4), np.uint8)
+    for y in range(by):
+        for x in range(bx):
+            b = [int(v) for v in blocks[y, x]]
+            c0, c1 = b[0] | (b[1] << 8), b[2] | (b[3] << 8)
+            def rgb(c):
+                r, g, bl = c >> 11, (c >> 5) & 63, c & 31
+                return np.array([(r << 3) | (r >> 2), (g << 2) | (g >> 4), (bl << 3) | (bl >> 2)], np.int64)
+            e0, e1 = rgb(c0), rgb(c1)
+            if c0 > c1 or four_colour_always:
+                pal = [(e0, 255), (e1, 255), ((2 * e0 + e1) // 3, 255), ((e0 + 2 * e1) // 3, 255)]
+            else:
+                pal = [(e0, 255), (e1, 255), ((e0 + e1) // 2, 255), (np.zeros(3, np.int64), 0)]
+            idx = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24)
+            for i in range(16):
+                c, a = pal[(idx >> (2 * i)) & 3]
+                out[4 * y + i // 4, 4 * x + i % 4, :3] = c; out[4 * y + i // 4, 4 * x + i % 4, 3] = a
+    return out[:height, :width]
+
+
+def bc3_decode_blocks(blocks, width, height):
+    """Independent BC3 (DXT5) decoder: a BC4 alpha block (alpha0, alpha1, 16 3-bit indices in raster order from bit 0; alpha0 > alpha1: six
+    interpolated values ((8 - j) a0 + (j - 1) a1) / 7 for index j = 2 .. 7, else four interpolated values, then 0 and 255) followed by a
+    BC1 colour block read in four-colour mode.  blocks [by, bx, 16] uint8 -> RGBA8 [height, width, 4]."""
+    by, bx = blocks.shape[:2]
+    out = bc1_decode_blocks(blocks[..., 8:], by * 4, bx * 4, four_colour_always=True).copy()
+    for y in range(by):
+        for x in range(bx):
+            b = [int(v) for v in blocks[y, x, :8]]
+            a0, a1 = b[0], b[1]
+            if a0 > a1:
+                pal = [a0, a1] + [((8 - j) * a0 + (j - 1) * a1) // 7 for j in range(2, 8)]
+            else:
+                pal = [a0, a1] + [((6 - j) * a0 + (j - 1) * a1) // 5 for j in range(2, 6)] + [0, 255]
+            bits = sum(b[2 + k] << (8 * k) for k in range(6))
+            for i in range(16):
+                out[4 * y + i // 4, 4 * x + i % 4, 3] = pal[(bits >> (3 * i)) & 7]
+    return out[:height, :width]
+
+
 def psnr_rgb(a, b):
     d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
     mse = float(np.mean(d * d))

@@ -172,6 +172,12 @@ def test_gpu_device_segments_in_parts_on_two_lanes(oracle, gpu_codec):
         assert bytes(r) == (oracle.ktx2_encode(segs[200]) if i == 200 else want[i % 6]), i
 
 
+def test_gpu_bc1_and_bc3_targets(oracle, gpu_codec):
+    """Round 5: the stock loader's dxtSupported row (src/lib/KTX2Loader.js:610-618) on the GPU - see _check_bc1_bc3."""
+    from test_hipemu_tex import _check_bc1_bc3
+    _check_bc1_bc3(oracle, gpu_codec)
+
+
 def test_gpu_texture_decode_matches_oracle(oracle, gpu_codec):
     """Decode path (texture half) on the GPU against the pinned oracle decoder: the reference's own fixture
     (Basis Universal 1.16, 1024x1024x5) and this codec's output; host and device output variants."""

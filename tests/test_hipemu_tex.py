@@ -220,6 +220,49 @@ def test_hipemu_alpha_transcode_targets(oracle, hipemu_lib):
     cd.close()
 
 
+def _check_bc1_bc3(oracle, cd, gates=(41.0, 30.5)):
+    """BC1 / BC3 targets (round 5; the stock loader's dxtSupported row, src/lib/KTX2Loader.js:610-618) through uvol_transcode_texture_segments_st,
+    decoded by the independent decoders of tests/helpers.py against the pinned RGBA32 decode: colour PSNR above the gate (RGB565 endpoints:
+    the reference fixture measures 42.4 dB, the synthetic noise segment 31.3 - 31.9 dB; the BC7 target 49.3 / 34.8 - 35.4), opaque files exactly opaque, alpha of a file with alpha slices above 38 dB;
+    BC1 refuses a file with alpha slices (it is asked for BC3), UASTC sources are refused for both."""
+    import os, synth, uvol
+    from conftest import GOLDEN
+    from helpers import bc1_decode_blocks, bc3_decode_blocks, psnr_rgb
+    files = [open(os.path.join(GOLDEN, "00000.ktx2"), "rb").read(), oracle.ktx2_encode(synth.texture_sequence(3, size=52, seed=5))]
+    for data, gate in zip(files, gates):
+        want = oracle.ktx2_decode(data)
+        (b1,), st1 = cd.transcode_texture_segments_status([data], "bc1")
+        (b3,), st3 = cd.transcode_texture_segments_status([data], "bc3")
+        assert st1 == [0] and st3 == [0] and b1.shape[-1] == 8 and b3.shape[-1] == 16
+        for l in range(want.n_slices):
+            g1 = bc1_decode_blocks(b1[l], want.width, want.height); g3 = bc3_decode_blocks(b3[l], want.width, want.height)
+            assert np.all(g1[..., 3] == 255) and np.all(g3[..., 3] == 255)
+            assert np.array_equal(g1[..., :3], g3[..., :3])                      # (the same colour block)
+            assert psnr_rgb(g1, want.images[l]) > gate, (l, psnr_rgb(g1, want.images[l]))
+    adata = oracle.ktx2_encode(_alpha_sequence(3, 64, 3))
+    want = oracle.ktx2_decode(adata)
+    (b3,), st3 = cd.transcode_texture_segments_status([adata], "bc3")
+    assert st3 == [0]
+    for l in range(3):
+        g3 = bc3_decode_blocks(b3[l], 64, 64)
+        ea = g3[..., 3].astype(np.float64) - want.images[l][..., 3].astype(np.float64)
+        assert 10 * np.log10(255.0 ** 2 / max(np.mean(ea ** 2), 1e-9)) > 38.0
+        assert psnr_rgb(g3, want.images[l]) > 28.0
+    _, st = cd.transcode_texture_segments_status([adata], "bc1")
+    assert st == [uvol.UVOL_E_UNSUPPORTED]
+    if hasattr(oracle, "uastc_ktx2_encode"):
+        u = oracle.uastc_ktx2_encode(synth.texture_sequence(2, size=32, seed=2))
+        for t in ("bc1", "bc3"):
+            assert cd.transcode_texture_segments_status([u], t)[1] == [uvol.UVOL_E_UNSUPPORTED]
+
+
+def test_hipemu_bc1_and_bc3_targets(oracle, hipemu_lib):
+    import uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    _check_bc1_bc3(oracle, cd)
+    cd.close()
+
+
 def png_scanlines(arr, rng):
     """The INFLATED IDAT stream of an 8-bit PNG holding arr [h, w, c] (c = 3 / 4): per row one filter-type byte (seeded random choice of
     None / Sub / Up / Average / Paeth) + the filtered bytes, exactly as a PNG encoder would write them."""

@@ -440,6 +440,79 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_etc2a(TexDecJob *jobs) {
   out[12] = (uint8_t)(msb >> 8); out[13] = (uint8_t)msb; out[14] = (uint8_t)(lsb >> 8); out[15] = (uint8_t)lsb;
 }
 
+// ---- K3'c: BC1 / BC3 targets (round 5; the stock loader's `dxtSupported` row, src/lib/KTX2Loader.js:610-618: TranscoderFormat.BC1 for an
+// opaque file, BC3 for one with alpha slices - its choice where neither BPTC nor ETC2 exists).  Colour: the block's darkest / brightest ETC1S
+// colour rounded to RGB565 are the endpoints of a four-colour BC1 block (palette c0, c1, (2 c0 + c1) / 3, (c0 + 2 c1) / 3: ETC1's inner
+// colours sit at 0.31 - 0.39 of the span, BC1's at 1/3); each of the four ETC1S colours takes the palette entry nearest in squared error
+// (clamping can bend the line), pixels follow their selectors.  An opaque BC1 block needs colour0 > colour1 as 16-bit numbers (otherwise
+// index 3 means transparent black): endpoints are swapped and indices remapped where needed, equal endpoints use index 0 only.  BC3 = a BC4
+// alpha block (alpha0 = highest, alpha1 = lowest level the block uses, eight-value mode, every level on its nearest palette value; equal
+// levels: index 0) followed by the same colour block, which BC3 always reads in four-colour mode.  Re-fits, not restatements of the basis
+// transcoder's tables (not in the reference): gated by PSNR against the RGBA32 decode through an independent decoder (tests/helpers.py).
+// Layouts: colour0, colour1 (u16 LE, R in the top 5 bits), 16 x 2-bit indices raster order from bit 0; alpha0, alpha1, 16 x 3-bit indices.
+template <bool BC3>
+__global__ void __launch_bounds__(UVOL_BLOCK) k_tdec_bc13(TexDecJob *jobs) {
+  TexDecJob &J = jobs[blockIdx.z];
+  if (J.status != 0) return;
+  const uint32_t layer = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
+  if (layer >= J.layers || b >= J.bx * J.by) return;
+  const size_t nbk = (size_t)J.bx * J.by, o = (size_t)(layer << J.ashift) * nbk + b;
+  const int MODS[8][4] = { { -8, -2, 2, 8 }, { -17, -5, 5, 17 }, { -29, -9, 9, 29 }, { -42, -13, 13, 42 }, { -60, -18, 18, 60 }, { -80, -24, 24, 80 }, { -106, -33, 33, 106 }, { -183, -47, 47, 183 } };
+  uint8_t *out = J.out[layer] + (BC3 ? 16 : 8) * (size_t)b;
+  if (BC3) {
+    int al[4] = { 255, 255, 255, 255 }; uint32_t asel = 0;
+    if (J.ashift) {
+      const uint8_t *ae = J.endpoints + 4 * (size_t)J.ei[o + nbk]; asel = J.selectors[J.si[o + nbk]];
+      for (int k = 0; k < 4; k++) { const int v = ((ae[1] << 3) | (ae[1] >> 2)) + MODS[ae[3] & 7][k]; al[k] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    }
+    uint32_t used = J.ashift ? 0u : 1u;
+    if (J.ashift) for (int i = 0; i < 16; i++) used |= 1u << ((asel >> (2 * i)) & 3u);
+    int a0 = 0, a1 = 255;
+    for (int k = 0; k < 4; k++) if ((used >> k) & 1u) { a0 = al[k] > a0 ? al[k] : a0; a1 = al[k] < a1 ? al[k] : a1; }
+    uint32_t lvl[4] = { 0, 0, 0, 0 };
+    if (a0 > a1) {
+      for (int k = 0; k < 4; k++) {
+        int be = 1 << 30;
+        for (int j = 0; j < 8; j++) { const int v = j == 0 ? a0 : (j == 1 ? a1 : ((8 - j) * a0 + (j - 1) * a1) / 7); const int d = v - al[k]; if (d * d < be) { be = d * d; lvl[k] = (uint32_t)j; } }
+      }
+    }
+    unsigned long long bits = 0;
+    for (int i = 0; i < 16; i++) bits |= (unsigned long long)lvl[(asel >> (2 * i)) & 3u] << (3 * i);
+    out[0] = (uint8_t)a0; out[1] = (uint8_t)a1;
+    for (int k = 0; k < 6; k++) out[2 + k] = (uint8_t)(bits >> (8 * k));
+    out += 8;
+  }
+  const uint8_t *e = J.endpoints + 4 * (size_t)J.ei[o]; const uint32_t sel = J.selectors[J.si[o]];
+  int col[4][3];
+  for (int c = 0; c < 3; c++) {
+    const int base = (e[c] << 3) | (e[c] >> 2);
+    for (int k = 0; k < 4; k++) { const int v = base + MODS[e[3] & 7][k]; col[k][c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+  }
+  // endpoints: brightest -> colour0, darkest -> colour1, rounded to 5 / 6 / 5 bits
+  const int q0[3] = { (col[3][0] * 31 + 127) / 255, (col[3][1] * 63 + 127) / 255, (col[3][2] * 31 + 127) / 255 };
+  const int q1[3] = { (col[0][0] * 31 + 127) / 255, (col[0][1] * 63 + 127) / 255, (col[0][2] * 31 + 127) / 255 };
+  uint32_t c0 = (uint32_t)((q0[0] << 11) | (q0[1] << 5) | q0[2]), c1 = (uint32_t)((q1[0] << 11) | (q1[1] << 5) | q1[2]);
+  int pal[4][3];
+  { const int e0[3] = { (q0[0] << 3) | (q0[0] >> 2), (q0[1] << 2) | (q0[1] >> 4), (q0[2] << 3) | (q0[2] >> 2) };
+    const int e1[3] = { (q1[0] << 3) | (q1[0] >> 2), (q1[1] << 2) | (q1[1] >> 4), (q1[2] << 3) | (q1[2] >> 2) };
+    for (int c = 0; c < 3; c++) { pal[0][c] = e0[c]; pal[1][c] = e1[c]; pal[2][c] = (2 * e0[c] + e1[c]) / 3; pal[3][c] = (e0[c] + 2 * e1[c]) / 3; } }
+  uint32_t map[4] = { 0, 0, 0, 0 };
+  if (c0 != c1) {
+    for (int k = 0; k < 4; k++) {
+      int be = 1 << 30;
+      for (int j = 0; j < 4; j++) { int d = 0; for (int c = 0; c < 3; c++) { const int t = pal[j][c] - col[k][c]; d += t * t; } if (d < be) { be = d; map[k] = (uint32_t)j; } }
+    }
+    if (c0 < c1) {                                          // four-colour mode wants colour0 > colour1: swap, 0 <-> 1 and 2 <-> 3
+      const uint32_t t = c0; c0 = c1; c1 = t;
+      for (int k = 0; k < 4; k++) map[k] ^= 1u;
+    }
+  }
+  uint32_t idx = 0;
+  for (int i = 0; i < 16; i++) idx |= map[(sel >> (2 * i)) & 3u] << (2 * i);
+  out[0] = (uint8_t)c0; out[1] = (uint8_t)(c0 >> 8); out[2] = (uint8_t)c1; out[3] = (uint8_t)(c1 >> 8);
+  out[4] = (uint8_t)idx; out[5] = (uint8_t)(idx >> 8); out[6] = (uint8_t)(idx >> 16); out[7] = (uint8_t)(idx >> 24);
+}
+
 // ---- K3'': BC7 target (what KTX2Loader picks on desktop GPUs, reference src/lib/KTX2Loader.js:591-689: astc, then bptc).  An ETC1S
 // block has four colours base + {-a, -b, +b, +a}, clamped per channel.  Two single-subset BC7 modes can hold them with the
 // darkest / brightest colour as endpoints: mode 5 (7-bit RGB endpoints widened by bit replication, 2-bit indices, weights
@@ -618,8 +691,9 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
   }
   const TexDecJob &J0 = T->hjobs[0];
   const size_t nbk = (size_t)J0.bx * J0.by, L = J0.layers, NSL = J0.nsl;
+  if (J0.ashift && target == 5) { ctx->set_error("segment 0 has alpha slices: BC1 is the opaque target (the stock loader asks such a file for BC3, src/lib/KTX2Loader.js:610-618: UVOL_TARGET_BC3)"); return UVOL_E_UNSUPPORTED; }
   if (J0.ashift && target == 1) { ctx->set_error("segment 0 has alpha slices: ETC1 is an opaque format (the stock loader asks such a file for ETC2 RGBA or BC7: uvol_transcode_texture_segments_etc2_rgba / _bc7)"); return UVOL_E_UNSUPPORTED; }
-  const size_t layer_bytes = target == 1 ? nbk * 8 : ((target == 2 || target == 4) ? nbk * 16 : (size_t)J0.width * J0.height * 4);   // 0: RGBA8, 1: ETC1 blocks, 2: BC7 blocks, 4: ETC2 RGBA blocks
+  const size_t layer_bytes = (target == 1 || target == 5) ? nbk * 8 : ((target == 2 || target == 4 || target == 6) ? nbk * 16 : (size_t)J0.width * J0.height * 4);   // 0: RGBA8, 1: ETC1 blocks, 2: BC7 blocks, 4: ETC2 RGBA blocks, 5: BC1 blocks, 6: BC3 blocks
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small: %zu < %zu", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   // per-segment workspace: codebooks, block indices, Huffman size / sorted arrays of 9 models
   auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -658,6 +732,8 @@ int tex_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t
     if (target == 1) DLAUNCH(k_tdec_etc1, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
     else if (target == 2) DLAUNCH(k_tdec_bc7, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
     else if (target == 4) DLAUNCH(k_tdec_etc2a, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
+    else if (target == 5) DLAUNCH(k_tdec_bc13<false>, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
+    else if (target == 6) DLAUNCH(k_tdec_bc13<true>, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj);
     else DLAUNCH(k_tdec_unpack, dim3(uvol_blocks(nbk), (unsigned)L, (unsigned)n), dim3(UVOL_BLOCK), 0, dj); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(T->hjobs.data(), dj, sizeof(TexDecJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -334,7 +334,7 @@ static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size
 int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                        uint8_t *const *out, size_t layer_cap, int outputs_on_device, int target, int *status) {
   UVOL_AFTER_ASYNC(ctx);
-  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !out || !status || target < UVOL_TARGET_RGBA32 || target > UVOL_TARGET_ETC2_RGBA) return UVOL_E_INVALID;
+  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !out || !status || target < UVOL_TARGET_RGBA32 || target > UVOL_TARGET_BC3) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   const int n = n_segments;
   std::vector<int> kind((size_t)n, -1);                    // 0 ETC1S, 1 UASTC

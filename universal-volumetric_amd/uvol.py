@@ -384,7 +384,7 @@ class Codec:
             raise UvolError(f"encode_texture_segments_st rc={rc}: {self.error()}")
         return [bufs[i][:lens[i]].tobytes() if st[i] == UVOL_OK else None for i in range(nseg)], list(st)
 
-    TARGETS = {"rgba32": (0, 4, False), "etc1": (1, 8, True), "bc7": (2, 16, True), "astc": (3, 16, True), "etc2_rgba": (4, 16, True)}
+    TARGETS = {"rgba32": (0, 4, False), "etc1": (1, 8, True), "bc7": (2, 16, True), "astc": (3, 16, True), "etc2_rgba": (4, 16, True), "bc1": (5, 8, True), "bc3": (6, 16, True)}
 
     def transcode_texture_segments_status(self, files, target="rgba32", shape=None):
         """Per-segment results and mixed batches (uvol_transcode_texture_segments_st): files may mix ETC1S and UASTC sources and contain
