@@ -30,6 +30,8 @@ k1 = cd.encode_texture_segment(tex); assert k1 == o.ktx2_encode(tex)
 ta = _alpha_sequence(2, 36, 2)
 k2 = cd.encode_texture_segment(ta); assert k2 == o.ktx2_encode(ta)
 cd.decode_texture_segments([k1]); cd.decode_texture_segments([k2]); cd.transcode_texture_segments_etc1([k1]); cd.transcode_texture_segments_bc7([k1])
+for t in ("bc1", "bc3", "etc2_rgba", "bc7"):                    # every block target through the per-segment entry point, opaque and alpha files in one batch
+    cd.transcode_texture_segments_status([k1, k2], t, shape=(40, 40, 2)); cd.transcode_texture_segments_status([k2], t, shape=(36, 36, 2))
 c0 = uvol.Codec(lib_path=lib, DRACO_COMPRESSION_LEVEL=0); g0 = c0.encode_mesh_batch(ms[:3]); c0.decode_mesh_batch(g0); c0.close()
 cu = uvol.Codec(lib_path=lib, uastc=1); ku = cu.encode_texture_segment(ta); cu.decode_texture_segments([ku]); cu.close()
 # corrupted decoder inputs: bit flips, truncations, overwritten words - a clean error or a decoded result, never an out-of-bounds access
