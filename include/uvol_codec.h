@@ -205,8 +205,10 @@ int uvol_encode_texture_segments_dev_async(uvol_ctx *ctx, const uint8_t *const *
  * `basisu -ktx2 -tex_type video` write them (with or without alpha slices, one mip level), or the UASTC .ktx2 files this codec writes with
  * uvol_params.uastc (told apart by the DFD colour model).  Output: RGBA8, rows in stored order. */
 /* host-only: container dimensions of one file (UVOL_E_INVALID if it is not a KTX2/BasisLZ file this decoder handles;
- * UVOL_E_UNSUPPORTED for a UASTC file whose level data are Zstandard-supercompressed - the default of stock `basisu -uastc -ktx2`;
- * this library has no Zstandard and reads supercompressionScheme 0 only, i.e. `basisu -uastc -ktx2 -ktx2_no_zstandard`) */
+ * a UASTC file whose level data are Zstandard-supercompressed - supercompressionScheme 2, the default of stock `basisu -uastc -ktx2` - is
+ * read since round 5 when the system's libzstd.so.1 is installed: the decode / transcode entry points inflate the level on the host
+ * (dlopen; this library contains no Zstandard code) and go on as for a scheme-0 file; without libzstd, for another scheme or a corrupt
+ * frame the file is UVOL_E_UNSUPPORTED, as every supercompressed UASTC file was before) */
 int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, uint32_t *height, uint32_t *layers);
 /* n_segments files of one width / height / layer count; rgba[s * layers + l] receives width*height*4 bytes
  * (layer_cap = size of each buffer).  One kernel launch per stage for the whole batch. */
@@ -268,7 +270,9 @@ enum { UVOL_TARGET_RGBA32 = 0, UVOL_TARGET_ETC1 = 1, UVOL_TARGET_BC7 = 2, UVOL_T
  * `dxtSupported` row (reference src/lib/KTX2Loader.js:610-618: TranscoderFormat.BC1 for an opaque file, BC3 for one with alpha slices).
  * 8-byte BC1 blocks (four-colour mode; a file with alpha slices is UVOL_E_UNSUPPORTED: it is asked for BC3) / 16-byte BC3 blocks (BC4
  * alpha block from the alpha slice - 255 for an opaque file -, then the colour block), raster order.  Re-fits of the four ETC1S colours /
- * alpha levels, gated by PSNR against the RGBA32 decode like the BC7 target; UASTC sources are UVOL_E_UNSUPPORTED for these two. */
+ * alpha levels, gated by PSNR against the RGBA32 decode like the BC7 target.  UASTC sources take both targets as well: the decoded texels of
+ * a block are range-fitted (bounding-box corners along the sign of the R-G / B-G covariances, RGB565, nearest palette entry per texel), BC3
+ * takes its BC4 alpha block from the texels' alpha, BC1 drops alpha. */
 int uvol_encode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers,
                                     uint32_t width, uint32_t height, int inputs_on_device,
                                     uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status);

@@ -215,6 +215,30 @@ def bc3_decode_blocks(blocks, width, height):
     return out[:height, :width]
 
 
+def zstd_supercompress(ktx2, level=6):
+    """A scheme-0 single-level .ktx2 (this codec's UASTC output) rewritten the way stock `basisu -uastc -ktx2` writes it by default:
+    supercompressionScheme 2, the level's data as ONE Zstandard frame made by the system's libzstd (ctypes; None when it is not installed),
+    levelIndex byteLength = compressed size, uncompressedByteLength = original size (KTX 2.0 section 'supercompressionScheme')."""
+    import ctypes as C, ctypes.util
+    try:
+        Z = C.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    Z.ZSTD_compressBound.restype = C.c_size_t; Z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    Z.ZSTD_compress.restype = C.c_size_t; Z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    Z.ZSTD_isError.restype = C.c_uint; Z.ZSTD_isError.argtypes = [C.c_size_t]
+    b = bytes(ktx2)
+    assert int.from_bytes(b[44:48], "little") == 0 and int.from_bytes(b[40:44], "little") == 1            # scheme 0, one level
+    lo, ll = int.from_bytes(b[80:88], "little"), int.from_bytes(b[88:96], "little")
+    src = b[lo:lo + ll]
+    cap = Z.ZSTD_compressBound(len(src)); buf = C.create_string_buffer(cap)
+    n = Z.ZSTD_compress(buf, cap, src, len(src), level)
+    assert not Z.ZSTD_isError(n)
+    head = bytearray(b[:lo])
+    head[44:48] = (2).to_bytes(4, "little"); head[88:96] = int(n).to_bytes(8, "little"); head[96:104] = len(src).to_bytes(8, "little")
+    return bytes(head) + buf.raw[:n]
+
+
 def psnr_rgb(a, b):
     d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
     mse = float(np.mean(d * d))

@@ -178,6 +178,17 @@ def test_gpu_bc1_and_bc3_targets(oracle, gpu_codec):
     _check_bc1_bc3(oracle, gpu_codec)
 
 
+def test_gpu_zstd_supercompressed_uastc(oracle):
+    """Round 5: the stock default of `basisu -uastc -ktx2` (Zstandard level data) is read - see _check_zstd_uastc."""
+    import uvol
+    from test_hipemu_tex import _check_zstd_uastc
+    cu = uvol.Codec(device=0, uastc=1)
+    try:
+        _check_zstd_uastc(oracle, cu)
+    finally:
+        cu.close()
+
+
 def test_gpu_texture_decode_matches_oracle(oracle, gpu_codec):
     """Decode path (texture half) on the GPU against the pinned oracle decoder: the reference's own fixture
     (Basis Universal 1.16, 1024x1024x5) and this codec's output; host and device output variants."""

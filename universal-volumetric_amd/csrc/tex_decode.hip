@@ -640,7 +640,10 @@ extern "C" int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, 
   { uint32_t w, h, l; uint64_t lo;                    // UASTC files of this codec (tex_uastc.hip)
     const int pr = uastc_ktx2_probe(ktx2, len, &w, &h, &l, &lo);
     if (pr == 0) { if (width) *width = w; if (height) *height = h; if (layers) *layers = l; return UVOL_OK; }
-    if (pr == UASTC_PROBE_SUPERCOMPRESSED) return UVOL_E_UNSUPPORTED; }          // Zstandard-supercompressed UASTC: recognised, not decoded
+    if (pr == UASTC_PROBE_SUPERCOMPRESSED) {               // Zstandard-supercompressed UASTC: the size fields are in the header either way
+      std::vector<uint8_t> plain; const int rz = uastc_unzstd(ktx2, len, plain);
+      if (rz != 0 || uastc_ktx2_probe(plain.data(), plain.size(), &w, &h, &l, &lo) != 0) return UVOL_E_UNSUPPORTED;      // no libzstd here, another scheme, or a corrupt frame
+      if (width) *width = w; if (height) *height = h; if (layers) *layers = l; return UVOL_OK; } }
   if (tdec_parse(ktx2, len, J)) return UVOL_E_INVALID;
   if (width) *width = J.width; if (height) *height = J.height; if (layers) *layers = J.layers;
   return UVOL_OK;

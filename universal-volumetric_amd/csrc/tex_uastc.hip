@@ -12,6 +12,7 @@
 // arithmetic is a handful of exact integer least-squares fits per block.  Everything is integer and deterministic (the tests compare
 // every output byte with the CPU restatement of the same algorithm).  No MFMA: there is no contraction; the bound is VALU integer throughput and, for the transcodes, HBM.
 #include "uvol_common.hpp"
+#include <dlfcn.h>
 #include <algorithm>
 
 // ---- mode tables (UASTC specification) ----
@@ -533,6 +534,58 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, con
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
     dst[0] = A.lo; dst[1] = A.hi; return;
   }
+  if (target == 3 || target == 4) {
+    // BC1 (8 bytes) / BC3 (16 bytes) from the decoded texels (round 5; the stock loader's dxtSupported row for UASTC sources,
+    // src/lib/KTX2Loader.js:610-618).  Colour: range fit - the corners of the texels' bounding box, the R and B ends swapped where the channel
+    // runs against G (sign of the covariance), pulled in by 1/16 of the range, rounded to RGB565; every texel takes the nearest of the four
+    // palette colours; an opaque BC1 block needs colour0 > colour1 (swap + remap, equal endpoints: index 0).  Alpha (BC3): a BC4 block with
+    // alpha0 = the largest, alpha1 = the smallest alpha of the block, eight-value mode.  Re-fits gated by PSNR against the RGBA32 decode.
+    uint8_t *out = J.out[l] + (target == 4 ? 16 : 8) * (size_t)b;
+    if (target == 4) {
+      int a0 = 0, a1 = 255;
+      for (int i = 0; i < 16; i++) { const int a = (int)(px[i] >> 24); a0 = a > a0 ? a : a0; a1 = a < a1 ? a : a1; }
+      unsigned long long bits = 0;
+      if (a0 > a1) for (int i = 0; i < 16; i++) {
+        const int a = (int)(px[i] >> 24); int be = 1 << 30; uint32_t bj = 0;
+        for (int j = 0; j < 8; j++) { const int v = j == 0 ? a0 : (j == 1 ? a1 : ((8 - j) * a0 + (j - 1) * a1) / 7); const int d = v - a; if (d * d < be) { be = d * d; bj = (uint32_t)j; } }
+        bits |= (unsigned long long)bj << (3 * i);
+      }
+      out[0] = (uint8_t)a0; out[1] = (uint8_t)a1;
+      for (int k = 0; k < 6; k++) out[2 + k] = (uint8_t)(bits >> (8 * k));
+      out += 8;
+    }
+    int mn[3] = { 255, 255, 255 }, mx[3] = { 0, 0, 0 }, sum[3] = { 0, 0, 0 };
+    for (int i = 0; i < 16; i++) for (int c = 0; c < 3; c++) { const int v = (int)((px[i] >> (8 * c)) & 255u); mn[c] = v < mn[c] ? v : mn[c]; mx[c] = v > mx[c] ? v : mx[c]; sum[c] += v; }
+    int cov_rg = 0, cov_bg = 0;
+    for (int i = 0; i < 16; i++) {
+      const int r = 16 * (int)(px[i] & 255u) - sum[0], g = 16 * (int)((px[i] >> 8) & 255u) - sum[1], bl = 16 * (int)((px[i] >> 16) & 255u) - sum[2];
+      cov_rg += (r >> 4) * (g >> 4); cov_bg += (bl >> 4) * (g >> 4);
+    }
+    int hi[3] = { mx[0], mx[1], mx[2] }, lo[3] = { mn[0], mn[1], mn[2] };
+    if (cov_rg < 0) { hi[0] = mn[0]; lo[0] = mx[0]; }
+    if (cov_bg < 0) { hi[2] = mn[2]; lo[2] = mx[2]; }
+    for (int c = 0; c < 3; c++) { const int ins = (hi[c] - lo[c]) / 16; hi[c] -= ins; lo[c] += ins; }
+    const int q0[3] = { (hi[0] * 31 + 127) / 255, (hi[1] * 63 + 127) / 255, (hi[2] * 31 + 127) / 255 };
+    const int q1[3] = { (lo[0] * 31 + 127) / 255, (lo[1] * 63 + 127) / 255, (lo[2] * 31 + 127) / 255 };
+    uint32_t c0 = (uint32_t)((q0[0] << 11) | (q0[1] << 5) | q0[2]), c1 = (uint32_t)((q1[0] << 11) | (q1[1] << 5) | q1[2]);
+    int pal[4][3];
+    { const int e0[3] = { (q0[0] << 3) | (q0[0] >> 2), (q0[1] << 2) | (q0[1] >> 4), (q0[2] << 3) | (q0[2] >> 2) };
+      const int e1[3] = { (q1[0] << 3) | (q1[0] >> 2), (q1[1] << 2) | (q1[1] >> 4), (q1[2] << 3) | (q1[2] >> 2) };
+      for (int c = 0; c < 3; c++) { pal[0][c] = e0[c]; pal[1][c] = e1[c]; pal[2][c] = (2 * e0[c] + e1[c]) / 3; pal[3][c] = (e0[c] + 2 * e1[c]) / 3; } }
+    uint32_t idx = 0;
+    if (c0 != c1) {
+      const uint32_t flip = c0 < c1 ? 1u : 0u;             // four-colour mode wants colour0 > colour1: swap, 0 <-> 1 and 2 <-> 3
+      for (int i = 0; i < 16; i++) {
+        int be = 1 << 30; uint32_t bj = 0;
+        for (int j = 0; j < 4; j++) { int d = 0; for (int c = 0; c < 3; c++) { const int t = pal[j][c] - (int)((px[i] >> (8 * c)) & 255u); d += t * t; } if (d < be) { be = d; bj = (uint32_t)j; } }
+        idx |= (bj ^ flip) << (2 * i);
+      }
+      if (flip) { const uint32_t t = c0; c0 = c1; c1 = t; }
+    }
+    out[0] = (uint8_t)c0; out[1] = (uint8_t)(c0 >> 8); out[2] = (uint8_t)c1; out[3] = (uint8_t)(c1 >> 8);
+    out[4] = (uint8_t)idx; out[5] = (uint8_t)(idx >> 8); out[6] = (uint8_t)(idx >> 16); out[7] = (uint8_t)(idx >> 24);
+    return;
+  }
   const uint32_t X = b % J.bx, Y = b / J.bx;
   for (int y = 0; y < 4 && 4 * Y + (uint32_t)y < J.H; y++) {
     uint8_t *row = J.out[l] + 4 * ((size_t)(4 * Y + (uint32_t)y) * J.W + 4 * (size_t)X);
@@ -623,6 +676,36 @@ int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint3
   return 0;
 }
 
+// Zstandard-supercompressed UASTC (supercompressionScheme 2: what stock `basisu -uastc -ktx2` writes by default; KTX 2.0: every level's data
+// is one Zstandard frame, levelIndex.byteLength = compressed, .uncompressedByteLength = original size, no supercompression global data).
+// Round 5: read when the system's libzstd is installed (dlopen, like libdeflate for PNGs - no Zstandard code here): the level is inflated on
+// the host into an equivalent scheme-0 file (same header / DFD / key-values, level data at a 16-byte aligned offset) that the decoders then
+// take as any other.  0: `out` holds that file; 1: no libzstd on this machine (the caller refuses the file as before); < 0: not such a file /
+// corrupt frame / sizes that do not match the header.
+int uastc_unzstd(const uint8_t *b, size_t n, std::vector<uint8_t> &out) {
+  typedef size_t (*dec_fn)(void *, size_t, const void *, size_t); typedef unsigned (*err_fn)(size_t);
+  static dec_fn dec = nullptr; static err_fn is_err = nullptr;
+  static const bool have = [] {
+    void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL); if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL); if (!h) return false;
+    dec = (dec_fn)dlsym(h, "ZSTD_decompress"); is_err = (err_fn)dlsym(h, "ZSTD_isError"); return dec && is_err; }();
+  if (!b || n < 104 + 44) return -1;
+  uint32_t u[9]; memcpy(u, b + 12, 36);
+  if (u[0] != 0 || u[8] != 2 || u[7] != 1 || u[6] != 1 || !u[2] || !u[3] || u[2] > 16384 || u[3] > 16384) return -2;      // scheme 2 = Zstandard; 1 level, 1 face
+  uint64_t lo, ll, lu; memcpy(&lo, b + 80, 8); memcpy(&ll, b + 88, 8); memcpy(&lu, b + 96, 8);
+  const uint32_t layers = u[5] ? u[5] : 1;
+  const uint64_t need = (uint64_t)layers * ((u[2] + 3) / 4) * ((u[3] + 3) / 4) * 16;
+  if (layers > 64 || lo < 104 || lo > n || ll > n - lo || lu != need) return -4;
+  if (!have) return 1;
+  const size_t head = (size_t)lo, off = (head + 15) & ~(size_t)15;
+  out.assign(off + (size_t)need, 0);
+  memcpy(out.data(), b, head);
+  const size_t got = dec(out.data() + off, (size_t)need, b + lo, (size_t)ll);
+  if (is_err(got) || got != need) return -5;
+  const uint32_t scheme0 = 0; const uint64_t off64 = off;
+  memcpy(out.data() + 12 + 32, &scheme0, 4); memcpy(out.data() + 80, &off64, 8); memcpy(out.data() + 88, &need, 8); memcpy(out.data() + 96, &need, 8);
+  return 0;
+}
+
 // n_seg segments of n_layers layers -> UASTC .ktx2 files (what `basisu -uastc -ktx2 -tex_type video` writes, without Zstandard)
 int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
                               bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
@@ -672,12 +755,12 @@ int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
 int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *outp, size_t layer_cap, bool outputs_on_device, int target, int *status) {
   UastcState *U = ctx->uastc;
   if (n <= 0) return UVOL_OK;
-  if (target != 0 && target != 3 && target != 2) { ctx->set_error("UASTC sources transcode to RGBA32, ASTC 4x4 or BC7"); return UVOL_E_UNSUPPORTED; }
+  if (target != 0 && target != 3 && target != 2 && target != 5 && target != 6) { ctx->set_error("UASTC sources transcode to RGBA32, ASTC 4x4, BC7, BC1 or BC3"); return UVOL_E_UNSUPPORTED; }
   int rc; if ((rc = uastc_consts(ctx))) return rc;
   uint32_t W = 0, H = 0, L = 0; uint64_t lo = 0;
   if (uastc_ktx2_probe(files[0], lens[0], &W, &H, &L, &lo)) { ctx->set_error("segment 0: not a UASTC .ktx2 this decoder handles"); return UVOL_E_INVALID; }
   const uint32_t bx = (W + 3) / 4, by = (H + 3) / 4; const size_t nb = (size_t)bx * by, seg_bytes = nb * 16 * (size_t)L;
-  const size_t layer_bytes = target == 0 ? (size_t)W * H * 4 : nb * 16;
+  const size_t layer_bytes = target == 0 ? (size_t)W * H * 4 : (target == 5 ? nb * 8 : nb * 16);
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small (%zu < %zu)", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   if ((rc = uvol_ensure(ctx, U->jobs, sizeof(UastcJob) * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, U->blocks, seg_bytes * (size_t)n))) return rc;
@@ -694,8 +777,8 @@ int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const 
     }
   }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : (target == 3 ? "texdec.uastc_astc" : "texdec.uastc_bc7"), (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
-    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : (target == 3 ? 1 : 2)); }
+  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : (target == 3 ? "texdec.uastc_astc" : (target == 2 ? "texdec.uastc_bc7" : "texdec.uastc_bc13")), (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
+    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : (target == 3 ? 1 : (target == 2 ? 2 : (target == 5 ? 3 : 4)))); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   if (!outputs_on_device) {

@@ -315,10 +315,13 @@ int uvol_encode_texture_segments_dev_async(uvol_ctx *ctx, const uint8_t *const *
 
 // UASTC and ETC1S files are told apart by the container (DFD colour model 166 vs 163)
 static bool is_uastc(const uint8_t *const *ktx2, const size_t *lens) { uint32_t w, h, l; uint64_t lo; return uastc_ktx2_probe(ktx2[0], lens[0], &w, &h, &l, &lo) == 0; }
-static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool dev, int target) {
+static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2_in, const size_t *lens_in, int n, uint8_t *const *out, size_t layer_cap, bool dev, int target) {
+  // Zstandard-supercompressed UASTC files (the default of stock `basisu -uastc -ktx2`) are inflated on the host through the system's libzstd
+  const UvolUnzstd Z(ktx2_in, lens_in, n);
+  const uint8_t *const *ktx2 = Z.p.data(); const size_t *lens = Z.l.data();
   { uint32_t w, h, l; uint64_t lo;
     if (uastc_ktx2_probe(ktx2[0], lens[0], &w, &h, &l, &lo) == UASTC_PROBE_SUPERCOMPRESSED) {
-      ctx->set_error("Zstandard-supercompressed UASTC (supercompressionScheme != 0, the default of `basisu -uastc -ktx2`) is not supported: write the file with -ktx2_no_zstandard"); return UVOL_E_UNSUPPORTED; } }
+      ctx->set_error("supercompressed UASTC (supercompressionScheme != 0): Zstandard level data are read when libzstd.so.1 is installed and the frame is intact - it is not, or this is another scheme; write the file with -ktx2_no_zstandard"); return UVOL_E_UNSUPPORTED; } }
   if (is_uastc(ktx2, lens)) {
     if (target != 0 && target != 3 && target != 2) { ctx->set_error("UASTC sources transcode to RGBA32, ASTC 4x4 or BC7 here"); return UVOL_E_UNSUPPORTED; }
     return tex_uastc_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);
@@ -331,12 +334,14 @@ static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2, const size
 // first readable file fixes the batch's width / height / layer count and a file of another shape is UVOL_E_INVALID in its slot; a source
 // kind that does not transcode to the target is UVOL_E_UNSUPPORTED in its slot; ETC1S and UASTC files run as one batch per kind; a file
 // whose payload turns out corrupt on the device fails alone.  The call itself fails only for bad arguments, memory or the device.
-int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
+int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2_in, const size_t *lens_in, int n_segments,
                                        uint8_t *const *out, size_t layer_cap, int outputs_on_device, int target, int *status) {
   UVOL_AFTER_ASYNC(ctx);
-  if (!ctx || !ktx2 || !lens || n_segments <= 0 || !out || !status || target < UVOL_TARGET_RGBA32 || target > UVOL_TARGET_BC3) return UVOL_E_INVALID;
+  if (!ctx || !ktx2_in || !lens_in || n_segments <= 0 || !out || !status || target < UVOL_TARGET_RGBA32 || target > UVOL_TARGET_BC3) return UVOL_E_INVALID;
   (void)hipSetDevice(ctx->device);
   const int n = n_segments;
+  const UvolUnzstd Z(ktx2_in, lens_in, n);                  // (Zstandard-supercompressed UASTC files: inflated on the host, see decode_dispatch)
+  const uint8_t *const *ktx2 = Z.p.data(); const size_t *lens = Z.l.data();
   std::vector<int> kind((size_t)n, -1);                    // 0 ETC1S, 1 UASTC
   uint32_t W0 = 0, H0 = 0, L0 = 0; bool have = false;
   for (int i = 0; i < n; i++) {
@@ -350,7 +355,7 @@ int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2
     else { const int ri = uvol_ktx2_info(ktx2[i], lens[i], &w, &h, &l); if (ri != UVOL_OK) { status[i] = ri; continue; } k = 0; }
     if (!have) { W0 = w; H0 = h; L0 = l; have = true; }
     else if (w != W0 || h != H0 || l != L0) continue;                       // another shape than the batch's: UVOL_E_INVALID
-    if (k == 1 ? (target != UVOL_TARGET_RGBA32 && target != UVOL_TARGET_ASTC && target != UVOL_TARGET_BC7) : target == UVOL_TARGET_ASTC) { status[i] = UVOL_E_UNSUPPORTED; continue; }
+    if (k == 1 ? (target != UVOL_TARGET_RGBA32 && target != UVOL_TARGET_ASTC && target != UVOL_TARGET_BC7 && target != UVOL_TARGET_BC1 && target != UVOL_TARGET_BC3) : target == UVOL_TARGET_ASTC) { status[i] = UVOL_E_UNSUPPORTED; continue; }
     kind[i] = k; status[i] = UVOL_OK;
   }
   for (int k = 0; k < 2; k++) {

@@ -257,6 +257,19 @@ int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);
 #define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */
 int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L, uint64_t *lvl_off);
+int uastc_unzstd(const uint8_t *b, size_t n, std::vector<uint8_t> &out);      // Zstandard-supercompressed UASTC -> the equivalent scheme-0 file (needs the system's libzstd; tex_uastc.hip)
+// the files of a decode / transcode call with every Zstandard-supercompressed UASTC file replaced by its inflated equivalent (kept alive here)
+struct UvolUnzstd {
+  std::vector<std::vector<uint8_t>> keep; std::vector<const uint8_t *> p; std::vector<size_t> l; bool any = false;
+  UvolUnzstd(const uint8_t *const *files, const size_t *lens, int n) : p(files, files + n), l(lens, lens + n) {
+    for (int i = 0; i < n; i++) {
+      uint32_t w, h, ly; uint64_t lo;
+      if (!files[i] || uastc_ktx2_probe(files[i], lens[i], &w, &h, &ly, &lo) != UASTC_PROBE_SUPERCOMPRESSED) continue;
+      std::vector<uint8_t> o;
+      if (uastc_unzstd(files[i], lens[i], o) == 0) { keep.push_back(std::move(o)); p[i] = keep.back().data(); l[i] = keep.back().size(); any = true; }
+    }
+  }
+};
 int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
                               bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status = nullptr);
 int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *out, size_t layer_cap, bool outputs_on_device, int target, int *status = nullptr);
