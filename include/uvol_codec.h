@@ -220,7 +220,11 @@ int uvol_decode_texture_segments_dev(uvol_ctx *ctx, const uint8_t *const *ktx2, 
 
 /* ETC1 target (the player's `etc2` raw-texture family, reference src/Interfaces.ts:19, src/V2/player.ts:338-356; any ETC2 sampler
  * reads ETC1 blocks): blocks[s * layers + l] receives ceil(w/4) * ceil(h/4) 8-byte ETC1 blocks in raster order (layer_cap =
- * size of each buffer); an exact re-pack, every ETC1S block is a valid ETC1 block.  outputs_on_device: blocks are device pointers. */
+ * size of each buffer); an exact re-pack, every ETC1S block is a valid ETC1 block.  outputs_on_device: blocks are device pointers.
+ * UASTC sources (round 5; the loader's etc2Supported / etc1Supported rows for UASTC, src/lib/KTX2Loader.js:619-636): this entry point and
+ * uvol_transcode_texture_segments_etc2_rgba take them as well - a plain ETC1 fit of each block's decoded texels (both flips, differential
+ * or individual bases, best intensity table per half-block; not the basis transcoder's hint-driven path) and an EAC fit of their alpha,
+ * gated by PSNR against the RGBA32 decode. */
 int uvol_transcode_texture_segments_etc1(uvol_ctx *ctx, const uint8_t *const *ktx2, const size_t *lens, int n_segments,
                                          uint8_t *const *blocks, size_t layer_cap, int outputs_on_device);
 

@@ -189,6 +189,12 @@ def test_gpu_zstd_supercompressed_uastc(oracle):
         cu.close()
 
 
+def test_gpu_uastc_etc1_and_etc2_targets(oracle, gpu_codec):
+    """Round 5: UASTC sources through the ETC1 / ETC2 RGBA targets - see _check_uastc_etc_targets."""
+    from test_hipemu_tex import _check_uastc_etc_targets
+    _check_uastc_etc_targets(oracle, gpu_codec)
+
+
 def test_gpu_texture_decode_matches_oracle(oracle, gpu_codec):
     """Decode path (texture half) on the GPU against the pinned oracle decoder: the reference's own fixture
     (Basis Universal 1.16, 1024x1024x5) and this codec's output; host and device output variants."""
@@ -389,8 +395,10 @@ def test_gpu_texture_batch_calls_report_per_segment_status(oracle, gpu_codec):
     outs, st = gpu_codec.transcode_texture_segments_status(files, "bc7")               # (BC7 takes both kinds)
     assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
     assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2], "bc7"))
-    outs, st = gpu_codec.transcode_texture_segments_status(files, "etc2_rgba")
-    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    outs, st = gpu_codec.transcode_texture_segments_status(files, "etc2_rgba")                 # (so does ETC2 RGBA since round 5)
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    outs_a, st_a = gpu_codec.transcode_texture_segments_status(files, "astc")                # a target only one kind takes: ETC1S files are UNSUPPORTED in their slots
+    assert st_a == [uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_E_UNSUPPORTED]
     assert np.array_equal(outs[5], gpu_codec.transcode_texture_segments_etc2_rgba([files[5]])[0])
     enc, st = gpu_codec.encode_texture_segments_status([a, b, a], caps=[1 << 20, 100, 1 << 20])
     assert st == [uvol.UVOL_OK, uvol.UVOL_E_NOSPACE, uvol.UVOL_OK] and enc[0] == files[0] and enc[2] == files[0]

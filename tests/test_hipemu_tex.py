@@ -267,6 +267,36 @@ def _check_bc1_bc3(oracle, cd, gates=(41.0, 30.5)):
                 assert 10 * np.log10(255.0 ** 2 / max(np.mean(ea ** 2), 1e-9)) > ga
 
 
+def _check_uastc_etc_targets(oracle, cd):
+    """Round 5: UASTC sources through the ETC1 / ETC2 RGBA targets (the stock loader's etc2Supported / etc1Supported rows for UASTC,
+    src/lib/KTX2Loader.js:619-636): a plain ETC1 fit of the decoded texels (both flips, differential or individual bases, best table per
+    half-block) and an EAC alpha fit, decoded by the independent decoders of tests/helpers.py against the RGBA32 decode."""
+    import synth
+    from helpers import etc1_decode_blocks, eac_alpha_decode_blocks, psnr_rgb
+    for tex, alpha in ((synth.texture_sequence(2, size=64, seed=2), False), (_alpha_sequence(2, 64, 5), True)):
+        u = oracle.uastc_ktx2_encode(tex)
+        want = oracle.uastc_ktx2_decode(u)
+        e1 = cd.transcode_texture_segments_etc1([u])[0]; e2 = cd.transcode_texture_segments_etc2_rgba([u])[0]
+        assert e1.shape == (2, 16, 16, 8) and e2.shape == (2, 16, 16, 16)
+        for l in range(2):
+            g1 = etc1_decode_blocks(e1[l], 64, 64)
+            assert np.array_equal(e2[l][..., 8:], e1[l])                                     # the same colour block
+            assert psnr_rgb(g1, want[l]) > 30.0, (l, psnr_rgb(g1, want[l]))
+            ga = eac_alpha_decode_blocks(e2[l][..., :8], 64, 64)
+            if not alpha:
+                assert np.all(ga == 255)
+            else:
+                ea = ga.astype(np.float64) - want[l][..., 3].astype(np.float64)
+                assert 10 * np.log10(255.0 ** 2 / max(np.mean(ea ** 2), 1e-9)) > 40.0
+
+
+def test_hipemu_uastc_etc1_and_etc2_targets(oracle, hipemu_lib):
+    import uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    _check_uastc_etc_targets(oracle, cd)
+    cd.close()
+
+
 def test_hipemu_bc1_and_bc3_targets(oracle, hipemu_lib):
     import uvol
     cd = uvol.Codec(lib_path=hipemu_lib)
@@ -462,10 +492,10 @@ def test_hipemu_texture_batch_calls_report_per_segment_status(oracle, hipemu_lib
     ra, rb = oracle.ktx2_decode(files[0]), oracle.ktx2_decode(files[5])
     assert all(np.array_equal(outs[0][l], ra.images[l]) for l in range(2)) and all(np.array_equal(outs[5][l], rb.images[l]) for l in range(2))
     assert np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2]))
-    # a target only one of the kinds takes: the other kind is UNSUPPORTED in its slot, the rest still runs
+    # ETC1 takes both kinds since round 5 (UASTC sources: a plain ETC1 fit of the decoded texels)
     outs, st = cd.transcode_texture_segments_status(files, "etc1")
-    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
-    assert np.array_equal(outs[0], cd.transcode_texture_segments_etc1([files[0]])[0])
+    assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
+    assert np.array_equal(outs[0], cd.transcode_texture_segments_etc1([files[0]])[0]) and np.array_equal(outs[2], cd.transcode_texture_segments_etc1([files[2]])[0])
     outs, st = cd.transcode_texture_segments_status(files, "bc7")                  # (BC7 takes both kinds)
     assert st == [uvol.UVOL_OK, uvol.UVOL_E_ENCODE, uvol.UVOL_OK, uvol.UVOL_E_INVALID, uvol.UVOL_E_INVALID, uvol.UVOL_OK]
     assert np.array_equal(outs[0], cd.transcode_texture_segments_bc7([files[0]])[0]) and np.array_equal(outs[2], oracle.uastc_ktx2_decode(files[2], "bc7"))

@@ -513,6 +513,12 @@ __global__ void __launch_bounds__(UVOL_BLOCK) UVOL_WAVES_PER_EU(4) k_uastc_encod
   dst[0] = B.lo; dst[1] = B.hi;
 }
 // target 0: RGBA8 (W x H x 4 per layer, stored row order), 1: ASTC 4x4 blocks, 2: BC7 blocks
+// EAC alpha modifier tables (ETC2 RGBA8's alpha half; the same values as tex_decode.hip's EAC_MOD)
+__device__ const int8_t UASTC_EAC_MOD[16][8] = {
+  { -3, -6, -9, -15, 2, 5, 8, 14 }, { -3, -7, -10, -13, 2, 6, 9, 12 }, { -2, -5, -8, -13, 1, 4, 7, 12 }, { -2, -4, -6, -13, 1, 3, 5, 12 },
+  { -3, -6, -8, -12, 2, 5, 7, 11 }, { -3, -7, -9, -11, 2, 6, 8, 10 }, { -4, -7, -8, -11, 3, 6, 7, 10 }, { -3, -5, -8, -11, 2, 4, 7, 10 },
+  { -2, -6, -8, -10, 1, 5, 7, 9 }, { -2, -5, -8, -10, 1, 4, 7, 9 }, { -2, -4, -8, -10, 1, 3, 7, 9 }, { -2, -5, -7, -10, 1, 4, 6, 9 },
+  { -3, -4, -7, -10, 2, 3, 6, 9 }, { -1, -2, -3, -10, 0, 1, 2, 9 }, { -4, -6, -8, -9, 3, 5, 7, 8 }, { -3, -5, -7, -9, 2, 4, 6, 8 } };
 __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, const UConst *K, int target) {
   UastcJob &J = jobs[blockIdx.z];
   const uint32_t l = blockIdx.y, b = blockIdx.x * UVOL_BLOCK + threadIdx.x;
@@ -533,6 +539,77 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_uastc_decode(UastcJob *jobs, con
     UBits A; u_to_bc7(L, solid, px, &K->tab, A);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(J.out[l] + 16 * (size_t)b);
     dst[0] = A.lo; dst[1] = A.hi; return;
+  }
+  if (target == 5 || target == 6) {
+    // ETC1 (8 bytes) / ETC2 RGBA (16 bytes: EAC alpha block, then the colour block) from the decoded texels (round 5; the stock loader's etc2Supported /
+    // etc1Supported rows for UASTC sources, src/lib/KTX2Loader.js:619-636: what a UASTC file is asked for on ETC2 hardware without ASTC).  A plain
+    // ETC1 fit, not the basis transcoder's hint-driven one (its tables are not in the reference): both flips are tried; a half-block's base is its
+    // mean colour, in differential mode (5 bits + a 3-bit delta clamped to [-4, 3], which also keeps the block out of ETC2's T / H / planar modes)
+    // when both deltas fit, else in individual mode (4 bits each); per half-block the intensity table with the smallest error under per-texel
+    // optimal modifiers; the flip with the smaller total error wins (ties: flip 0).  Gated by PSNR against the RGBA32 decode.
+    const int MAG[8][2] = { { 2, 8 }, { 5, 17 }, { 9, 29 }, { 13, 42 }, { 18, 60 }, { 24, 80 }, { 33, 106 }, { 47, 183 } };
+    uint8_t *out = J.out[l] + (target == 6 ? 16 : 8) * (size_t)b;
+    if (target == 6) {
+      int a0 = 0, a1 = 255;
+      for (int i = 0; i < 16; i++) { const int a = (int)(px[i] >> 24); a0 = a > a0 ? a : a0; a1 = a < a1 ? a : a1; }
+      int bt = 13, bm = 1, bb = a0;                       // constant alpha: table 13 has a zero modifier (index 4)
+      if (a0 > a1) {
+        const int mid = (a0 + a1 + 1) >> 1; uint32_t best = 0xffffffffu;
+        for (int t = 0; t < 16 && best; t++) for (int m = 1; m < 16 && best; m++) for (int db = -2; db <= 2; db++) {
+          const int base = mid + db; if (base < 0 || base > 255) continue;
+          int lv[8]; for (int j = 0; j < 8; j++) { const int v = base + m * UASTC_EAC_MOD[t][j]; lv[j] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+          uint32_t err = 0;
+          for (int i = 0; i < 16 && err < best; i++) { const int a = (int)(px[i] >> 24); int be = 1 << 30; for (int j = 0; j < 8; j++) { const int d = lv[j] - a; be = d * d < be ? d * d : be; } err += (uint32_t)be; }
+          if (err < best) { best = err; bt = t; bm = m; bb = base; }
+        }
+      }
+      unsigned long long bits = 0;
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        const int a = (int)(px[4 * y + x] >> 24); int be = 1 << 30; uint32_t bj = 0;
+        for (int j = 0; j < 8; j++) { int v = bb + bm * UASTC_EAC_MOD[bt][j]; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int d = v - a; if (d * d < be) { be = d * d; bj = (uint32_t)j; } }
+        bits |= (unsigned long long)bj << (45 - 3 * (4 * x + y));
+      }
+      out[0] = (uint8_t)bb; out[1] = (uint8_t)((bm << 4) | bt);
+      for (int k = 0; k < 6; k++) out[2 + k] = (uint8_t)(bits >> (40 - 8 * k));
+      out += 8;
+    }
+    uint32_t best_err = 0xffffffffu; uint8_t best_blk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int flip = 0; flip < 2; flip++) {
+      int sum[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { const int h = flip ? (y >= 2) : (x >= 2); for (int c = 0; c < 3; c++) sum[h][c] += (int)((px[4 * y + x] >> (8 * c)) & 255u); }
+      int q5[2][3], q4[2][3]; bool diff = true;
+      for (int h = 0; h < 2; h++) for (int c = 0; c < 3; c++) { const int m8 = (sum[h][c] + 4) >> 3; q5[h][c] = (m8 * 31 + 127) / 255; q4[h][c] = (m8 * 15 + 127) / 255; }
+      for (int c = 0; c < 3; c++) { const int d = q5[1][c] - q5[0][c]; if (d < -4 || d > 3) diff = false; }
+      int base[2][3];
+      for (int h = 0; h < 2; h++) for (int c = 0; c < 3; c++) base[h][c] = diff ? ((q5[h][c] << 3) | (q5[h][c] >> 2)) : q4[h][c] * 17;
+      uint32_t err = 0; int tab[2] = { 0, 0 }; uint32_t msb = 0, lsb = 0;
+      for (int h = 0; h < 2; h++) {
+        uint32_t bh = 0xffffffffu; uint32_t bm_ = 0, bl_ = 0;
+        for (int t = 0; t < 8; t++) {
+          uint32_t e = 0, m_ = 0, l_ = 0;
+          for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+            if ((flip ? (y >= 2) : (x >= 2)) != (h != 0)) continue;
+            const uint32_t p = px[4 * y + x]; int be = 1 << 30; uint32_t bi = 0;
+            for (uint32_t idx = 0; idx < 4; idx++) {
+              const int mod = (idx & 2u) ? -MAG[t][idx & 1u] : MAG[t][idx & 1u]; int d = 0;
+              for (int c = 0; c < 3; c++) { int v = base[h][c] + mod; v = v < 0 ? 0 : (v > 255 ? 255 : v); const int q = v - (int)((p >> (8 * c)) & 255u); d += q * q; }
+              if (d < be) { be = d; bi = idx; }
+            }
+            e += (uint32_t)be; const int i = 4 * x + y; m_ |= (bi >> 1) << i; l_ |= (bi & 1u) << i;
+          }
+          if (e < bh) { bh = e; tab[h] = t; bm_ = m_; bl_ = l_; }
+        }
+        err += bh; msb |= bm_; lsb |= bl_;
+      }
+      if (err < best_err) {
+        best_err = err;
+        for (int c = 0; c < 3; c++) best_blk[c] = diff ? (uint8_t)((q5[0][c] << 3) | ((q5[1][c] - q5[0][c]) & 7)) : (uint8_t)((q4[0][c] << 4) | q4[1][c]);
+        best_blk[3] = (uint8_t)((tab[0] << 5) | (tab[1] << 2) | (diff ? 2 : 0) | flip);
+        best_blk[4] = (uint8_t)(msb >> 8); best_blk[5] = (uint8_t)msb; best_blk[6] = (uint8_t)(lsb >> 8); best_blk[7] = (uint8_t)lsb;
+      }
+    }
+    for (int k = 0; k < 8; k++) out[k] = best_blk[k];
+    return;
   }
   if (target == 3 || target == 4) {
     // BC1 (8 bytes) / BC3 (16 bytes) from the decoded texels (round 5; the stock loader's dxtSupported row for UASTC sources,
@@ -755,12 +832,12 @@ int tex_uastc_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
 int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const size_t *lens, int n, uint8_t *const *outp, size_t layer_cap, bool outputs_on_device, int target, int *status) {
   UastcState *U = ctx->uastc;
   if (n <= 0) return UVOL_OK;
-  if (target != 0 && target != 3 && target != 2 && target != 5 && target != 6) { ctx->set_error("UASTC sources transcode to RGBA32, ASTC 4x4, BC7, BC1 or BC3"); return UVOL_E_UNSUPPORTED; }
+  if (target < 0 || target > 6) { ctx->set_error("unknown transcode target %d", target); return UVOL_E_UNSUPPORTED; }
   int rc; if ((rc = uastc_consts(ctx))) return rc;
   uint32_t W = 0, H = 0, L = 0; uint64_t lo = 0;
   if (uastc_ktx2_probe(files[0], lens[0], &W, &H, &L, &lo)) { ctx->set_error("segment 0: not a UASTC .ktx2 this decoder handles"); return UVOL_E_INVALID; }
   const uint32_t bx = (W + 3) / 4, by = (H + 3) / 4; const size_t nb = (size_t)bx * by, seg_bytes = nb * 16 * (size_t)L;
-  const size_t layer_bytes = target == 0 ? (size_t)W * H * 4 : (target == 5 ? nb * 8 : nb * 16);
+  const size_t layer_bytes = target == 0 ? (size_t)W * H * 4 : ((target == 5 || target == 1) ? nb * 8 : nb * 16);
   if (layer_cap < layer_bytes) { ctx->set_error("layer buffers too small (%zu < %zu)", layer_cap, layer_bytes); return UVOL_E_NOSPACE; }
   if ((rc = uvol_ensure(ctx, U->jobs, sizeof(UastcJob) * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, U->blocks, seg_bytes * (size_t)n))) return rc;
@@ -777,8 +854,8 @@ int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const 
     }
   }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->jobs.p, U->hjobs.data(), sizeof(UastcJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : (target == 3 ? "texdec.uastc_astc" : (target == 2 ? "texdec.uastc_bc7" : "texdec.uastc_bc13")), (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
-    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : (target == 3 ? 1 : (target == 2 ? 2 : (target == 5 ? 3 : 4)))); }
+  { uvol_ctx::Scope sc(ctx, target == 0 ? "texdec.uastc_rgba" : (target == 3 ? "texdec.uastc_astc" : (target == 2 ? "texdec.uastc_bc7" : ((target == 5 || target == 6) ? "texdec.uastc_bc13" : "texdec.uastc_etc"))), (uint64_t)(nb * 16 + layer_bytes) * L * (uint64_t)n);
+    hipLaunchKernelGGL(k_uastc_decode, dim3(uvol_blocks(nb), L, (unsigned)n), dim3(UVOL_BLOCK), 0, ctx->stream, (UastcJob *)U->jobs.p, (const UConst *)U->consts.p, target == 0 ? 0 : (target == 3 ? 1 : (target == 2 ? 2 : (target == 5 ? 3 : (target == 6 ? 4 : (target == 1 ? 5 : 6)))))); }      // kernel codes: 0 RGBA, 1 ASTC, 2 BC7, 3 BC1, 4 BC3, 5 ETC1, 6 ETC2 RGBA
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(U->hjobs.data(), U->jobs.p, sizeof(UastcJob) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   if (!outputs_on_device) {

@@ -323,7 +323,7 @@ static int decode_dispatch(uvol_ctx *ctx, const uint8_t *const *ktx2_in, const s
     if (uastc_ktx2_probe(ktx2[0], lens[0], &w, &h, &l, &lo) == UASTC_PROBE_SUPERCOMPRESSED) {
       ctx->set_error("supercompressed UASTC (supercompressionScheme != 0): Zstandard level data are read when libzstd.so.1 is installed and the frame is intact - it is not, or this is another scheme; write the file with -ktx2_no_zstandard"); return UVOL_E_UNSUPPORTED; } }
   if (is_uastc(ktx2, lens)) {
-    if (target != 0 && target != 3 && target != 2) { ctx->set_error("UASTC sources transcode to RGBA32, ASTC 4x4 or BC7 here"); return UVOL_E_UNSUPPORTED; }
+    if (target < 0 || target > UVOL_TARGET_BC3) { ctx->set_error("unknown transcode target"); return UVOL_E_UNSUPPORTED; }      // (UASTC sources take every target since round 5)
     return tex_uastc_decode_segments(ctx, ktx2, lens, n, out, layer_cap, dev, target);
   }
   if (target == 3) { ctx->set_error("ASTC 4x4 is the transcode target of UASTC sources (KTX2Loader.js:591-600); this file is ETC1S"); return UVOL_E_UNSUPPORTED; }
@@ -355,7 +355,7 @@ int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2
     else { const int ri = uvol_ktx2_info(ktx2[i], lens[i], &w, &h, &l); if (ri != UVOL_OK) { status[i] = ri; continue; } k = 0; }
     if (!have) { W0 = w; H0 = h; L0 = l; have = true; }
     else if (w != W0 || h != H0 || l != L0) continue;                       // another shape than the batch's: UVOL_E_INVALID
-    if (k == 1 ? (target != UVOL_TARGET_RGBA32 && target != UVOL_TARGET_ASTC && target != UVOL_TARGET_BC7 && target != UVOL_TARGET_BC1 && target != UVOL_TARGET_BC3) : target == UVOL_TARGET_ASTC) { status[i] = UVOL_E_UNSUPPORTED; continue; }
+    if (k == 0 && target == UVOL_TARGET_ASTC) { status[i] = UVOL_E_UNSUPPORTED; continue; }      // (ASTC is the target of UASTC sources only; UASTC sources take every target)
     kind[i] = k; status[i] = UVOL_OK;
   }
   for (int k = 0; k < 2; k++) {
