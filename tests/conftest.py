@@ -25,8 +25,11 @@ def oracle():
 @pytest.fixture(scope="session")
 def hipemu_lib():
     """Test-only host emulation build of the product sources (tests/hipemu); never shipped."""
+    import fcntl
     import subprocess
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "universal-volumetric_amd"), "hipemu"])
+    with open(os.path.join(ROOT, "tests", "hipemu", ".build.lock"), "w") as lk:      # pytest-xdist workers build it once, in turn
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "universal-volumetric_amd"), "hipemu"])
     return os.path.join(ROOT, "tests", "hipemu", "libuvolcodec_hipemu.so")
 
 
