@@ -146,6 +146,19 @@ int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, cons
 int uvol_unfilter_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *inflated, int n, uint32_t width, uint32_t height, int channels,
                                 int slot, const uint8_t **rgba_dev_out);
 
+/* The same with the zlib INFLATE on the device too (what `basisu` does first with every PNG it reads, scripts/Encoder.py:274-292): n images
+ * of one size, each as its zlib stream - the concatenated data of the file's IDAT chunks, zlib header and Adler-32 trailer included -
+ * in host memory.  One wave per stream inflates it (stored, fixed and dynamic blocks; the 32 KiB window lives in LDS) into the scanline
+ * buffer the un-filter kernel then reads, so the host uploads the ~3 MB file instead of inflating it and staging 16.8 MB.  Same slots,
+ * ordering and output as uvol_unfilter_png_batch_dev.  A corrupt stream, or one that does not hold height x (1 + width x channels) bytes,
+ * or whose Adler-32 trailer does not match, fails ALONE: uvol_png_status reports it, its layer is undefined, the other images are not
+ * affected. */
+int uvol_inflate_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *zlib_streams, const size_t *lens, int n, uint32_t width, uint32_t height,
+                               int channels, int slot, const uint8_t **rgba_dev_out);
+/* Per-image statuses of the last uvol_unfilter_png_batch_dev / uvol_inflate_png_batch_dev call on `slot` (waits for its kernels):
+ * status[i] = UVOL_OK or UVOL_E_INVALID, n <= the images of that call.  status == NULL: the first failure is the return value. */
+int uvol_png_status(uvol_ctx *ctx, int slot, int *status, int n);
+
 /* GPU-resident form (SURVEY 8(b) "variants taking arrays of frames + hipStream_t"; caller-owned buffers as in
  * deprecated/encoder_legacy/codec/corto_codec.h:41-43): inputs are device pointers PRODUCED ON `producer_stream` (a hipStream_t passed
  * as void *, NULL = already complete) - the codec's kernels are ordered after the work queued on that stream so far, without a host

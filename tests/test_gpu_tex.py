@@ -138,6 +138,48 @@ def test_gpu_png_scanlines_unfiltered_on_the_device(oracle, gpu_codec):
     assert gpu_codec.encode_texture_segment_dev(ptrs, 256, 256) == oracle.ktx2_encode(tex)
 
 
+def test_gpu_png_inflated_on_the_device(oracle, gpu_codec):
+    """VERDICT r4 item 6a on the GPU: zlib streams (every block type and strategy; windows that wrap; a 2048^2 image at levels 1 / 6 / 9)
+    inflated by k_inflate and un-filtered by k_png_unfilter = the source pixels; corrupt streams fail alone; then on into the encoder."""
+    import ctypes as C, zlib, synth
+    from test_hipemu_tex import png_scanlines, zlib_variants
+    hip = C.CDLL("libamdhip64.so")
+    def d2h(ptr, n):
+        a = np.empty(n, np.uint8); assert hip.hipMemcpy(C.c_void_p(a.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), C.c_int(2)) == 0; return a
+    rng = np.random.default_rng(34)
+    for (h, w, c) in ((37, 53, 4), (64, 64, 3), (1, 1, 4), (300, 700, 3)):
+        smooth = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] + rng.integers(0, 6, (h, w, c))).astype(np.uint8)
+        for a in (smooth, np.full((h, w, c), 77, np.uint8), rng.integers(0, 256, (h, w, c)).astype(np.uint8)):
+            raw = png_scanlines(a, rng); zs = zlib_variants(raw, rng)
+            ptrs, st = gpu_codec.inflate_png_batch_dev(zs, w, h, c, slot=int(rng.integers(0, 2)))
+            assert st == [0] * len(zs), st
+            want = np.concatenate([a, np.full((h, w, 1), 255, np.uint8)], -1) if c == 3 else a
+            for p in ptrs:
+                assert np.array_equal(d2h(p, h * w * 4).reshape(h, w, 4), want), (h, w, c)
+    tex = synth.texture_sequence(1, size=2048, seed=9)[0]
+    raw = png_scanlines(tex, rng)
+    ptrs, st = gpu_codec.inflate_png_batch_dev([zlib.compress(raw, lv) for lv in (1, 6, 9)], 2048, 2048, 4)
+    assert st == [0, 0, 0]
+    for p in ptrs:
+        assert np.array_equal(d2h(p, 2048 * 2048 * 4).reshape(2048, 2048, 4), tex)
+    h, w, c = 40, 40, 4
+    imgs = [(rng.integers(0, 30, (h, w, c)) + 8 * k).astype(np.uint8) for k in range(7)]
+    raws = [png_scanlines(x, rng) for x in imgs]; zs = [zlib.compress(r, 6) for r in raws]
+    bad = list(zs)
+    bad[1] = zs[1][:len(zs[1]) // 2]
+    t = bytearray(zs[2]); t[len(t) // 2] ^= 0x5a; t[len(t) // 2 + 1] ^= 0xff; bad[2] = bytes(t)
+    bad[3] = zlib.compress(raws[3][:-7], 6)
+    bad[4] = bytes(rng.integers(0, 256, 300).astype(np.uint8))
+    bad[5] = b"\x78\x9d" + zs[5][2:]
+    ptrs, st = gpu_codec.inflate_png_batch_dev(bad, w, h, c)
+    assert st[0] == 0 and st[6] == 0 and all(st[k] != 0 for k in (1, 2, 3, 4, 5)), st
+    for k in (0, 6):
+        assert np.array_equal(d2h(ptrs[k], h * w * 4).reshape(h, w, 4), imgs[k])
+    tex = synth.texture_sequence(2, size=256, seed=4)
+    ptrs, st = gpu_codec.inflate_png_batch_dev([zlib.compress(png_scanlines(t, rng), 6) for t in tex], 256, 256, 4, slot=0, sync=False)
+    assert st == [0, 0] and gpu_codec.encode_texture_segment_dev(ptrs, 256, 256) == oracle.ktx2_encode(tex)
+
+
 def test_gpu_host_segments_in_parts_on_two_lanes(oracle, gpu_codec):
     """Round 4: a call of >= 128 segments on HOST inputs is cut into parts that alternate between two lanes (part k + 1 uploads while
     part k encodes).  132 segments of 64^2 x 2 (one of them with alpha: second pass on its lane): every segment equals the oracle's

@@ -383,6 +383,69 @@ def test_hipemu_png_scanlines_unfiltered_on_the_device(oracle, hipemu_lib):
     cd.close()
 
 
+def zlib_variants(raw, rng):
+    """zlib streams of `raw` that exercise every DEFLATE block type: dynamic blocks (levels 1 / 6 / 9), fixed blocks (Z_FIXED), stored blocks
+    (level 0), Huffman-only and RLE strategies (long literal runs / distance-1 matches), and a stream made of several flushed pieces
+    (full-flush markers = empty stored blocks between dynamic ones)."""
+    import zlib
+    out = [zlib.compress(raw, 1), zlib.compress(raw, 6), zlib.compress(raw, 9), zlib.compress(raw, 0)]
+    for strat in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat); out.append(c.compress(raw) + c.flush())
+    c = zlib.compressobj(9, zlib.DEFLATED, 15, 9); z = b""; k = max(1, len(raw) // 5)
+    for i in range(0, len(raw), k):
+        z += c.compress(raw[i:i + k]) + c.flush(zlib.Z_FULL_FLUSH if (i // k) & 1 else zlib.Z_SYNC_FLUSH)
+    out.append(z + c.flush())
+    c = zlib.compressobj(4, zlib.DEFLATED, 9, 1); out.append(c.compress(raw) + c.flush())          # 512-byte window, smallest hash memory
+    return out
+
+
+def test_hipemu_png_inflated_on_the_device(oracle, hipemu_lib):
+    """uvol_inflate_png_batch_dev takes the zlib streams themselves.  k_inflate (one wave per stream, window in LDS)
+    must give what the host zlib gives - checked through the un-filtered RGBA layers, for every block type and strategy - and a corrupt
+    or short stream must fail ALONE (uvol_png_status) without touching its neighbours."""
+    import zlib
+    import uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    rng = np.random.default_rng(33)
+    for (h, w, c) in ((37, 53, 4), (64, 64, 3), (1, 1, 4), (130, 70, 4)):
+        # smooth image + noise (matches of every length and distance up to the previous rows) and a flat one (runs of 258, distance 1)
+        smooth = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] + rng.integers(0, 6, (h, w, c))).astype(np.uint8)
+        flat = np.full((h, w, c), 77, np.uint8); noise = rng.integers(0, 256, (h, w, c)).astype(np.uint8)
+        for a in (smooth, flat, noise):
+            raw = png_scanlines(a, rng); zs = zlib_variants(raw, rng)
+            assert all(zlib.decompress(z) == raw for z in zs)
+            ptrs, st = cd.inflate_png_batch_dev(zs, w, h, c, slot=int(rng.integers(0, 2)))
+            assert st == [0] * len(zs), st
+            want = np.concatenate([a, np.full((h, w, 1), 255, np.uint8)], -1) if c == 3 else a
+            for p in ptrs:
+                assert np.array_equal(_dev_bytes(p, h * w * 4).reshape(h, w, 4), want), (h, w, c)
+    # a larger image: the 32 KiB window wraps many times, matches reach back over whole rows
+    h, w, c = 96, 512, 4
+    a = (np.add.outer(np.arange(h) * 2, np.arange(w))[..., None] // 3 + rng.integers(0, 3, (h, w, c))).astype(np.uint8)
+    a[40:60] = a[10:30]                                             # far matches (8 rows x 2049 bytes back and more)
+    raw = png_scanlines(a, rng)
+    ptrs, st = cd.inflate_png_batch_dev([zlib.compress(raw, 9), zlib.compress(raw, 1)], w, h, c)
+    assert st == [0, 0]
+    for p in ptrs:
+        assert np.array_equal(_dev_bytes(p, h * w * 4).reshape(h, w, 4), a)
+    # failures stay with their image: truncated stream, flipped bits in the middle, a stream of the wrong size, garbage, a bad header
+    h, w, c = 40, 40, 4
+    imgs = [(rng.integers(0, 30, (h, w, c)) + 8 * k).astype(np.uint8) for k in range(7)]
+    raws = [png_scanlines(x, rng) for x in imgs]; zs = [zlib.compress(r, 6) for r in raws]
+    bad = list(zs)
+    bad[1] = zs[1][:len(zs[1]) // 2]
+    t = bytearray(zs[2]); t[len(t) // 2] ^= 0x5a; t[len(t) // 2 + 1] ^= 0xff; bad[2] = bytes(t)
+    bad[3] = zlib.compress(raws[3][:-7], 6)
+    bad[4] = bytes(rng.integers(0, 256, 300).astype(np.uint8))
+    bad[5] = b"\x78\x9d" + zs[5][2:]
+    ptrs, st = cd.inflate_png_batch_dev(bad, w, h, c)
+    assert st[0] == 0 and st[6] == 0 and all(st[k] != 0 for k in (1, 3, 4, 5)), st
+    assert st[2] != 0                                               # (flipped literals can leave a well-formed stream of the right size: the Adler-32 check catches those)
+    for k in (0, 6):
+        assert np.array_equal(_dev_bytes(ptrs[k], h * w * 4).reshape(h, w, 4), imgs[k])
+    cd.close()
+
+
 def test_hipemu_host_segments_in_parts_on_two_lanes(oracle, hipemu_lib):
     """Round 4: a call on HOST inputs is cut into parts that alternate between two lanes (the layers of part k + 1 upload while part k
     encodes).  UVOL_TEX_PART=1 cuts a 4-segment call into four parts: every segment's bytes are the oracle's, including an alpha

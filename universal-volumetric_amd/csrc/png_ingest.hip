@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(64) k_png_unfilter(PngJob *jobs) {
   UVOL_DYN_SMEM(uint32_t, lds);                            // [w] the band's last row (RGBA word per pixel), then [16 rows][32 pixels] output ring
   const uint32_t W = J.w, H = J.h, CH = J.ch; const size_t stride = (size_t)W * CH + 1;
   uint8_t *lastrow = reinterpret_cast<uint8_t *>(lds); uint8_t *ring = reinterpret_cast<uint8_t *>(lds + W);
+  if (J.status != 0) return;                              // (the device inflate found the stream corrupt: block-uniform)
   const int lane = (int)threadIdx.x, r = lane & 15, c = lane >> 4;
   const bool chan = (uint32_t)c < CH;                     // (RGB files: the alpha lane only supplies 255)
   for (uint32_t x = (uint32_t)lane; x < W; x += 64) lds[x] = 0;
@@ -99,10 +100,254 @@ __global__ void __launch_bounds__(64) k_png_unfilter(PngJob *jobs) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// zlib inflate on the device: one WAVE per stream.  A DEFLATE stream is one serial chain of variable-length codes,
+// so a stream cannot be split; what the wave has is 64 lanes for the parts that are parallel (table builds, match copies, the write-out)
+// and an LDS that holds the whole 32 KiB window, so that no match ever waits for a global round trip: literals and matches go to a ring
+// in LDS, the ring leaves for HBM 1 KiB at a time with 16-byte stores.  Every lane runs the same decode on the same (wave-uniform) bit
+// buffer; Huffman symbols come from an 11-bit (literal / length) and a 9-bit (distance) look-up table in LDS, built per block by a
+// canonical walk per table entry (every lane fills its entries, no replication loops of uneven length); longer codes take the canonical
+// walk bit by bit.  Bit-identical to zlib for valid streams (tests: streams of every block type against the host zlib); corrupt streams
+// end with a negative status and never read or write outside their buffers; the Adler-32 trailer is verified (sums by position, one
+// reduction at the end: no serial chain).
+// ------------------------------------------------------------------------------------------------
+struct InflJob { const uint8_t *z; uint8_t *out; uint32_t zlen, out_cap, out_len; int32_t status; };
+#define INF_WIN 32768u
+#define INF_LBITS 11u
+#define INF_DBITS 9u
+#define INF_O_LUTL 32768u                               /* 2048 x u16 */
+#define INF_O_LUTD (INF_O_LUTL + 4096u)                 /* 512 x u16 */
+#define INF_O_LUTC (INF_O_LUTD + 1024u)                 /* 128 x u16 */
+#define INF_O_SORTL (INF_O_LUTC + 256u)                 /* 288 x u16 */
+#define INF_O_SORTD (INF_O_SORTL + 576u)                /* 32 x u16 */
+#define INF_O_SORTC (INF_O_SORTD + 64u)                 /* 32 x u16 */
+#define INF_O_CNT (INF_O_SORTC + 64u)                   /* 3 x 16 x u32 */
+#define INF_O_LENS (INF_O_CNT + 192u)                   /* 320 + 32 code lengths */
+#define INF_LDS (INF_O_LENS + 352u)
+// canonical Huffman code of n symbols with code lengths lens[] (0 = unused): cnt[L] symbols per length, the symbols sorted by (length,
+// symbol), and the table over the next `bits` stream bits (entry = symbol << 4 | length, 0 = a longer code or none).  Returns the
+// "left" of the Kraft sum: < 0 over-subscribed, 0 complete, > 0 incomplete.  Block-wide (one wave), ends synchronised.
+__device__ __forceinline__ int inf_build(const uint8_t *lens, uint32_t n, uint32_t *cnt, uint16_t *sorted, uint16_t *lut, uint32_t bits, int lane) {
+  if (lane < 16) cnt[lane] = 0;
+  __syncthreads();
+  for (uint32_t s = (uint32_t)lane; s < n; s += 64) { const uint32_t L = lens[s]; if (L) atomicAdd(&cnt[L], 1u); }
+  __syncthreads();
+  int left = 1;
+  for (int L = 1; L <= 15; L++) { left <<= 1; left -= (int)UVOL_READFIRST(cnt[L]); if (left < 0) break; }
+  if (lane >= 1 && lane <= 15 && cnt[lane]) {           // lane L places the symbols of length L, in symbol order
+    uint32_t k = 0; for (int L = 1; L < lane; L++) k += cnt[L];
+    for (uint32_t s = 0; s < n; s++) if (lens[s] == (uint8_t)lane) sorted[k++] = (uint16_t)s;
+  }
+  __syncthreads();
+  for (uint32_t e = (uint32_t)lane; e < (1u << bits); e += 64) {
+    int code = 0, first = 0, index = 0; uint32_t ent = 0;
+    for (uint32_t L = 1; L <= bits; L++) {
+      code |= (int)((e >> (L - 1)) & 1u);
+      const int c = (int)cnt[L];
+      if (code - c < first) { ent = ((uint32_t)sorted[index + (code - first)] << 4) | L; break; }
+      index += c; first += c; first <<= 1; code <<= 1;
+    }
+    lut[e] = (uint16_t)ent;
+  }
+  __syncthreads();
+  return left;
+}
+// a code the table does not hold: the canonical walk over the next 15 bits (symbol, or -1: no such code)
+__device__ __forceinline__ int inf_slow(unsigned long long bb, const uint32_t *cnt, const uint16_t *sorted, uint32_t &len) {
+  int code = 0, first = 0, index = 0;
+  for (int L = 1; L <= 15; L++) {
+    code |= (int)((bb >> (L - 1)) & 1ull);
+    const int c = (int)UVOL_READFIRST(cnt[L]);
+    if (code - c < first) { len = (uint32_t)L; return (int)UVOL_READFIRST(sorted[index + (code - first)]); }
+    index += c; first += c; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+// Adler-32 without a serial chain: with N bytes b[0..N), s1 = 1 + sum b, s2 = N + N * sum b - sum pos * b[pos] (mod 65521).  Every lane sums
+// the bytes it writes out and their positions (64-bit, no intermediate modulo up to 2^29-byte outputs); one reduction at the end.
+__device__ __forceinline__ void inf_adler16(const uint4 &v, uint32_t pos0, unsigned long long &A, unsigned long long &P) {
+  const uint32_t w[4] = { v.x, v.y, v.z, v.w }; uint32_t a = 0, jb = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const uint32_t b = (w[k] >> (8 * j)) & 255u; a += b; jb += (uint32_t)(4 * k + j) * b; }
+  }
+  A += a; P += (unsigned long long)pos0 * a + jb;
+}
+__global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint32_t expect) {
+  InflJob &J = jobs[blockIdx.x];
+  UVOL_DYN_SMEM(uint8_t, lds);
+  uint8_t *ring = lds;
+  uint16_t *lutl = reinterpret_cast<uint16_t *>(lds + INF_O_LUTL), *lutd = reinterpret_cast<uint16_t *>(lds + INF_O_LUTD), *lutc = reinterpret_cast<uint16_t *>(lds + INF_O_LUTC);
+  uint16_t *sortl = reinterpret_cast<uint16_t *>(lds + INF_O_SORTL), *sortd = reinterpret_cast<uint16_t *>(lds + INF_O_SORTD), *sortc = reinterpret_cast<uint16_t *>(lds + INF_O_SORTC);
+  uint32_t *cntl = reinterpret_cast<uint32_t *>(lds + INF_O_CNT), *cntd = cntl + 16, *cntc = cntl + 32;
+  uint8_t *lens = lds + INF_O_LENS, *clens = lens + 320;
+  const int lane = (int)threadIdx.x;
+  // every lane runs the same decode: what is read from memory is made wave-uniform explicitly (UVOL_READFIRST), so that the bit buffer, the
+  // positions and every branch live in scalar registers (the compiler cannot know that an LDS read returns the same value in every lane)
+  UVOL_G(const uint32_t) zw = UVOL_TO_G(const uint32_t, reinterpret_cast<const uint32_t *>(J.z));          // 16-byte aligned, >= 16 readable bytes behind the stream
+  UVOL_G(const uint8_t) zb = UVOL_TO_G(const uint8_t, J.z);
+  const uint32_t zlen = (uint32_t)UVOL_READFIRST(J.zlen), nw = (zlen + 3u) / 4u, cap = (uint32_t)UVOL_READFIRST(J.out_cap);
+  UVOL_G(uint8_t) out = UVOL_TO_G(uint8_t, J.out);
+  const int dz = UVOL_LANE_ZERO();                      // (keeps the prefetched stream word in a vector register until it is consumed)
+  unsigned long long bb = 0; uint32_t bc = 0, iw = 0;
+  uint32_t wnext = zw[dz];
+  int err = 0;
+  uint32_t opos = 0, flushed = 0;
+  unsigned long long ad_a = 0, ad_p = 0;                // this lane's share of the Adler-32 sums
+#define INF_REFILL() do { if (bc <= 32u) { bb |= (unsigned long long)(uint32_t)UVOL_READFIRST(wnext) << bc; bc += 32u; iw++; wnext = zw[(iw < nw ? iw : nw) + (uint32_t)dz]; } } while (0)
+#define INF_BITS(n) ((uint32_t)(bb & ((1ull << (n)) - 1ull)))
+#define INF_DROP(n) do { bb >>= (n); bc -= (n); } while (0)
+  // complete KiB of the ring -> HBM (lane = 16 bytes); the ring never holds more than 1 KiB + one token that has not left
+#define INF_FLUSH() do { while (opos - flushed >= 1024u) { UVOL_WAVE_SYNC(); \
+      const uint4 v_ = *reinterpret_cast<const uint4 *>(ring + ((flushed + 16u * (uint32_t)lane) & (INF_WIN - 1u))); \
+      *reinterpret_cast<UVOL_G(uint4)>(out + flushed + 16u * (uint32_t)lane) = v_; inf_adler16(v_, flushed + 16u * (uint32_t)lane, ad_a, ad_p); flushed += 1024u; } } while (0)
+  INF_REFILL();
+  { const uint32_t cmf = INF_BITS(8), flg = (uint32_t)(bb >> 8) & 255u; INF_DROP(16);
+    if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) err = -1; }
+  bool last = false;
+  while (!last && !err) {
+    __syncthreads();                                     // (the tables of the block before are not read any more)
+    INF_REFILL();
+    last = (bb & 1ull) != 0; const uint32_t type = (uint32_t)(bb >> 1) & 3u; INF_DROP(3);
+    if (type == 0u) {
+      INF_DROP(bc & 7u); INF_REFILL();
+      uint32_t len = INF_BITS(16); const uint32_t nlen = (uint32_t)(bb >> 16) & 0xffffu; INF_DROP(32);
+      if ((len ^ nlen) != 0xffffu) { err = -3; break; }
+      uint32_t p = 4u * iw - bc / 8u;                    // byte position of the stored data in the stream
+      if ((unsigned long long)p + len > zlen) { err = -8; break; }
+      if (opos + len > cap || opos + len < opos) { err = -7; break; }
+      while (len) {
+        const uint32_t n = len < 1024u ? len : 1024u;
+        UVOL_WAVE_SYNC();
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64) ring[(opos + i) & (INF_WIN - 1u)] = zb[p + i];
+        opos += n; p += n; len -= n;
+        INF_FLUSH();
+      }
+      iw = p / 4u; bb = 0; bc = 0; wnext = zw[(iw < nw ? iw : nw) + (uint32_t)dz]; INF_REFILL(); INF_DROP(8u * (p & 3u));
+      continue;
+    }
+    if (type == 3u) { err = -2; break; }
+    uint32_t hlit = 288, hdist = 30;
+    if (type == 1u) {
+      for (uint32_t s = (uint32_t)lane; s < 320u; s += 64) lens[s] = s < 144u ? 8 : (s < 256u ? 9 : (s < 280u ? 7 : (s < 288u ? 8 : 5)));
+    } else {
+      INF_REFILL();
+      hlit = INF_BITS(5) + 257u; hdist = ((uint32_t)(bb >> 5) & 31u) + 1u; const uint32_t hclen = ((uint32_t)(bb >> 10) & 15u) + 4u; INF_DROP(14);
+      if (hlit > 286u || hdist > 30u) { err = -4; break; }
+      if (lane < 19) clens[lane] = 0;
+      __syncthreads();
+      for (uint32_t i = 0; i < hclen; i++) {
+        if ((i & 7u) == 0u) INF_REFILL();
+        const uint32_t v = INF_BITS(3); INF_DROP(3);
+        // order of the code length code lengths: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+        const uint32_t o = i < 3u ? 16u + i : (i == 3u ? 0u : ((i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1)));
+        if (lane == 0) clens[o] = (uint8_t)v;
+      }
+      if (inf_build(clens, 19u, cntc, sortc, lutc, 7u, lane) < 0) { err = -4; break; }
+      const uint32_t ntot = hlit + hdist; uint32_t idx = 0, prev = 0;
+      while (idx < ntot) {
+        INF_REFILL();
+        const uint32_t e = (uint32_t)UVOL_READFIRST(lutc[bb & 127ull]);
+        if (!e) { err = -4; break; }
+        const uint32_t sym = e >> 4; INF_DROP(e & 15u);
+        if (sym < 16u) { if (lane == 0) lens[idx] = (uint8_t)sym; idx++; prev = sym; continue; }
+        uint32_t rep, val = 0;
+        if (sym == 16u) { if (!idx) { err = -4; break; } val = prev; rep = 3u + INF_BITS(2); INF_DROP(2); }
+        else if (sym == 17u) { rep = 3u + INF_BITS(3); INF_DROP(3); }
+        else { rep = 11u + INF_BITS(7); INF_DROP(7); }
+        if (idx + rep > ntot) { err = -4; break; }
+        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) lens[idx + k] = (uint8_t)val;
+        idx += rep; prev = val;
+      }
+      if (err) break;
+      __syncthreads();
+      if (UVOL_READFIRST(lens[256]) == 0) { err = -4; break; }            // no end-of-block code
+    }
+    if (inf_build(lens, hlit, cntl, sortl, lutl, INF_LBITS, lane) < 0) { err = -4; break; }
+    if (inf_build(lens + hlit, hdist, cntd, sortd, lutd, INF_DBITS, lane) < 0) { err = -4; break; }
+    for (;;) {
+      INF_REFILL();
+      uint32_t e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]), L, sym;
+      if (e) { L = e & 15u; sym = e >> 4; }
+      else { const int s_ = inf_slow(bb, cntl, sortl, L); if (s_ < 0) { err = -5; break; } sym = (uint32_t)s_; }
+      INF_DROP(L);
+      if (sym < 256u) {
+        if (opos >= cap) { err = -7; break; }
+        if (lane == 0) ring[opos & (INF_WIN - 1u)] = (uint8_t)sym;
+        opos++;
+      } else if (sym == 256u) break;
+      else {
+        sym -= 257u;
+        if (sym >= 29u) { err = -9; break; }
+        uint32_t len;
+        if (sym < 8u) len = 3u + sym;
+        else if (sym == 28u) len = 258u;
+        else { const uint32_t x = (sym - 4u) >> 2; len = 3u + ((4u + (sym & 3u)) << x) + INF_BITS(x); INF_DROP(x); }
+        INF_REFILL();
+        e = (uint32_t)UVOL_READFIRST(lutd[bb & ((1ull << INF_DBITS) - 1ull)]); uint32_t ds;
+        if (e) { L = e & 15u; ds = e >> 4; }
+        else { const int s_ = inf_slow(bb, cntd, sortd, L); if (s_ < 0) { err = -5; break; } ds = (uint32_t)s_; }
+        INF_DROP(L);
+        if (ds >= 30u) { err = -6; break; }
+        uint32_t dist;
+        if (ds < 4u) dist = 1u + ds;
+        else { const uint32_t x = (ds >> 1) - 1u; dist = 1u + ((2u + (ds & 1u)) << x) + INF_BITS(x); INF_DROP(x); }
+        if (dist > opos) { err = -6; break; }
+        if (opos + len > cap) { err = -7; break; }
+        // the copy: 64 bytes per round, reads before writes; a match that overlaps itself repeats its first `dist` bytes
+        const uint32_t from = opos - dist;
+        for (uint32_t b = 0; b < len; b += 64) {
+          const uint32_t i = b + (uint32_t)lane; uint8_t v = 0;
+          UVOL_WAVE_SYNC();
+          if (i < len) v = ring[(from + (dist >= len ? i : i % dist)) & (INF_WIN - 1u)];
+          UVOL_WAVE_SYNC();
+          if (i < len) ring[(opos + i) & (INF_WIN - 1u)] = v;
+        }
+        opos += len;
+      }
+      INF_FLUSH();
+      if (iw > nw + 1u) { err = -8; break; }
+    }
+  }
+  // the trailer: Adler-32 of the output, big-endian, on the next byte boundary
+  uint32_t want = 0;
+  if (!err) { INF_DROP(bc & 7u); INF_REFILL(); const uint32_t t = INF_BITS(32); INF_DROP(32); want = (t >> 24) | ((t >> 8) & 0xff00u) | ((t << 8) & 0xff0000u) | (t << 24); }
+  if (!err && 32ull * iw - bc > 8ull * zlen) err = -8;    // the stream ended inside a code or before its trailer
+  UVOL_WAVE_SYNC();
+  for (uint32_t i = flushed + (uint32_t)lane; i < opos; i += 64) { const uint32_t b = ring[i & (INF_WIN - 1u)]; out[i] = (uint8_t)b; ad_a += b; ad_p += (unsigned long long)i * b; }
+  __syncthreads();
+  unsigned long long *red = reinterpret_cast<unsigned long long *>(lds + INF_O_LUTL);      // (the tables are done with)
+  if (lane < 2) red[lane] = 0;
+  __syncthreads();
+  atomicAdd(&red[0], ad_a); atomicAdd(&red[1], ad_p % 65521ull);
+  __syncthreads();
+  if (!err) {
+    const unsigned long long sa = red[0] % 65521ull, sp = red[1] % 65521ull, n = (unsigned long long)opos % 65521ull;
+    const uint32_t s1 = (uint32_t)((1ull + sa) % 65521ull), s2 = (uint32_t)((n + n * sa + 65521ull - sp) % 65521ull);
+    if (((s2 << 16) | s1) != want) err = -10;
+  }
+  if (lane == 0) {
+    J.out_len = opos; J.status = err;
+    if (pj) pj[blockIdx.x].status = err ? err : (opos != expect ? -20 : 0);
+  }
+#undef INF_REFILL
+#undef INF_BITS
+#undef INF_DROP
+#undef INF_FLUSH
+}
+__global__ void __launch_bounds__(64) k_png_statuses(const PngJob *jobs, int32_t *st, int n) {
+  const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (i < n) st[i] = jobs[i].status;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
-struct PngState { uvol_devbuf raw, jobs; uvol_devbuf rgba[2]; std::vector<PngJob> hjobs; hipStream_t stream = nullptr; hipEvent_t done[2] = { nullptr, nullptr }; bool pending[2] = { false, false }; };
+struct PngState { uvol_devbuf raw, jobs; uvol_devbuf rgba[2]; std::vector<PngJob> hjobs; hipStream_t stream = nullptr; hipEvent_t done[2] = { nullptr, nullptr }; bool pending[2] = { false, false };
+                  uvol_devbuf zin, ijobs, dstat; std::vector<InflJob> hij;                                      // device inflate: the compressed streams, their jobs, the statuses
+                  int32_t *hstat[2] = { nullptr, nullptr }; size_t hstat_cap[2] = { 0, 0 }; int nstat[2] = { 0, 0 }; };   // per slot: the last call's per-image statuses (pinned)
 int png_create(uvol_ctx *ctx) { ctx->png = new PngState(); return UVOL_OK; }
 // the layers of the last un-filter call are ready before anything queued on `stream` from here on (the texture entry points call this
 // before they read device inputs; uvol_sync too)
@@ -131,7 +376,8 @@ void png_destroy(uvol_ctx *ctx) {
   PngState *S = ctx->png; if (!S) return;
   if (S->stream) { (void)hipStreamSynchronize(S->stream); (void)hipStreamDestroy(S->stream); }
   for (hipEvent_t e : S->done) if (e) (void)hipEventDestroy(e);
-  for (uvol_devbuf *b : { &S->raw, &S->jobs, &S->rgba[0], &S->rgba[1] }) if (b->p) (void)hipFree(b->p);
+  for (uvol_devbuf *b : { &S->raw, &S->jobs, &S->rgba[0], &S->rgba[1], &S->zin, &S->ijobs, &S->dstat }) if (b->p) (void)hipFree(b->p);
+  for (int32_t *h : S->hstat) if (h) (void)hipHostFree(h);
   delete S; ctx->png = nullptr;
 }
 // n images of one size: raw[i] = the INFLATED IDAT stream of an 8-bit non-interlaced RGB (channels 3) or RGBA (4) PNG, i.e. height rows
@@ -140,6 +386,12 @@ void png_destroy(uvol_ctx *ctx) {
 // the kernel is queued (the staged upload is what takes host time): the context's texture entry points order themselves behind it, so
 // the un-filter of batch k + 1 runs beside the encode of batch k - one wave per image is 134 ms per batch whatever its size.
 int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out) {
+  return png_ingest_batch(ctx, raw, nullptr, n, w, h, channels, slot, rgba_dev_out);
+}
+// zlens != nullptr: raw[i] = the zlib stream itself (the concatenated IDAT chunks), zlens[i] bytes: inflated by k_inflate into the scanline
+// buffer the un-filter kernel reads - the host neither inflates nor stages 16.8 MB per image, it uploads the 3 MB file.  Per-image
+// statuses (corrupt stream, a size that is not height x (1 + width x channels)) come back through png_status().
+int png_ingest_batch(uvol_ctx *ctx, const uint8_t *const *raw, const size_t *zlens, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out) {
   PngState *S = ctx->png;
   if (n <= 0) return UVOL_OK;
   if (slot < 0 || slot > 1 || (channels != 3 && channels != 4) || !w || !h || w > 8192 || h > 16384) { ctx->set_error("uvol_unfilter_png_batch_dev: slot 0 / 1, 3 or 4 channels, at most 8192 x 16384 (wider images: un-filter on the host)"); return UVOL_E_INVALID; }
@@ -156,18 +408,63 @@ int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t
   for (int i = 0; i < n; i++) {
     if (!raw[i]) { ctx->set_error("PNG %d: no data", i); return UVOL_E_INVALID; }
     PngJob &J = S->hjobs[i]; J.raw = (const uint8_t *)S->raw.p + ra * (size_t)i; J.rgba = (uint8_t *)S->rgba[slot].p + obytes * (size_t)i; J.w = w; J.h = h; J.ch = (uint32_t)channels; J.status = 0;
-    ups.push_back(UvolUpItem{ ra * (size_t)i, raw[i], rbytes });
+    if (!zlens) ups.push_back(UvolUpItem{ ra * (size_t)i, raw[i], rbytes });
     rgba_dev_out[i] = J.rgba;
   }
-  { uvol_ctx::Scope sc(ctx, "ingest.png_upload", (uint64_t)rbytes * n);
-    if ((rc = uvol_upload_staged(ctx, (uint8_t *)S->raw.p, ups))) return rc; }
+  if (zlens) {
+    size_t ztot = 0; std::vector<size_t> zoff((size_t)n);
+    for (int i = 0; i < n; i++) { if (zlens[i] < 6 || zlens[i] > 0xfffffff0u) { ctx->set_error("PNG %d: not a zlib stream (%zu bytes)", i, zlens[i]); return UVOL_E_INVALID; } zoff[i] = ztot; ztot += (zlens[i] + 16 + 255) & ~(size_t)255; }
+    if ((rc = uvol_ensure(ctx, S->zin, ztot))) return rc;
+    if ((rc = uvol_ensure(ctx, S->ijobs, sizeof(InflJob) * (size_t)n))) return rc;
+    S->hij.assign((size_t)n, InflJob{});
+    for (int i = 0; i < n; i++) {
+      InflJob &Z = S->hij[i]; Z.z = (const uint8_t *)S->zin.p + zoff[i]; Z.zlen = (uint32_t)zlens[i]; Z.out = (uint8_t *)S->raw.p + ra * (size_t)i; Z.out_cap = (uint32_t)rbytes; Z.out_len = 0; Z.status = 0;
+      ups.push_back(UvolUpItem{ zoff[i], raw[i], zlens[i] });
+    }
+    { uvol_ctx::Scope sc(ctx, "ingest.png_upload", (uint64_t)ztot);
+      if ((rc = uvol_upload_staged(ctx, (uint8_t *)S->zin.p, ups))) return rc; }
+    UVOL_HIP_CHECK(ctx, hipMemcpyAsync(S->ijobs.p, S->hij.data(), sizeof(InflJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    uvol_ctx::Scope sc(ctx, "ingest.png_upload", (uint64_t)rbytes * n);
+    if ((rc = uvol_upload_staged(ctx, (uint8_t *)S->raw.p, ups))) return rc;
+  }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(S->jobs.p, S->hjobs.data(), sizeof(PngJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if (zlens) {
+    uvol_ctx::Scope sc(ctx, "ingest.png_inflate", (uint64_t)rbytes * n);
+    if (uvol_debug()) { fprintf(stderr, "[uvol] launch k_inflate\n"); fflush(stderr); }
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), (size_t)INF_LDS, ctx->stream, (InflJob *)S->ijobs.p, (PngJob *)S->jobs.p, (uint32_t)rbytes);
+  }
   { uvol_ctx::Scope sc(ctx, "ingest.png_unfilter", (uint64_t)(rbytes + obytes) * n);
     if (uvol_debug()) { fprintf(stderr, "[uvol] launch k_png_unfilter\n"); fflush(stderr); }
     hipLaunchKernelGGL(k_png_unfilter, dim3((unsigned)n), dim3(64), ((size_t)w + 16 * 32) * 4, ctx->stream, (PngJob *)S->jobs.p); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
+  // per-image statuses of this call, for png_status(): packed on the device, copied into the slot's pinned array
+  S->nstat[slot] = 0;
+  if ((rc = uvol_ensure(ctx, S->dstat, 4 * (size_t)n))) return rc;
+  if (S->hstat_cap[slot] < (size_t)n) {
+    if (S->hstat[slot]) { (void)hipEventSynchronize(S->done[slot]); (void)hipHostFree(S->hstat[slot]); S->hstat[slot] = nullptr; S->hstat_cap[slot] = 0; }
+    const size_t c = ((size_t)n + 255) & ~(size_t)255;
+    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&S->hstat[slot], 4 * c, hipHostMallocDefault)); S->hstat_cap[slot] = c;
+  }
+  hipLaunchKernelGGL(k_png_statuses, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const PngJob *)S->jobs.p, (int32_t *)S->dstat.p, n);
+  UVOL_HIP_CHECK(ctx, hipMemcpyAsync(S->hstat[slot], S->dstat.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  S->nstat[slot] = n;
   UVOL_HIP_CHECK(ctx, hipEventRecord(S->done[slot], ctx->stream));
   S->pending[slot] = true;
   if (uvol_debug()) UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return UVOL_OK;
+}
+// statuses of the slot's last ingest call (waits for its kernels): UVOL_OK, or UVOL_E_INVALID for an image whose zlib stream is corrupt or
+// does not hold height x (1 + width x channels) bytes; its layer is undefined, the other images of the call are not affected
+int png_status(uvol_ctx *ctx, int slot, int *status, int n) {
+  PngState *S = ctx->png;
+  if (!S || slot < 0 || slot > 1 || n < 0 || n > S->nstat[slot]) { ctx->set_error("uvol_png_status: slot 0 / 1, at most the %d images of the slot's last call", S && slot >= 0 && slot <= 1 ? S->nstat[slot] : 0); return UVOL_E_INVALID; }
+  if (S->done[slot]) { const hipError_t e = hipEventSynchronize(S->done[slot]); if (e != hipSuccess) { ctx->set_error("hipEventSynchronize (png slot %d): %s", slot, hipGetErrorString(e)); return UVOL_E_HIP; } }
+  int worst = UVOL_OK;
+  for (int i = 0; i < n; i++) {
+    const int32_t d = S->hstat[slot][i]; const int st = d == 0 ? UVOL_OK : UVOL_E_INVALID;
+    if (status) status[i] = st;
+    if (st != UVOL_OK && worst == UVOL_OK) { worst = st; ctx->set_error("PNG %d: corrupt or unexpected zlib stream (device status %d)", i, d); }
+  }
+  return status ? UVOL_OK : worst;
 }

@@ -463,6 +463,19 @@ int uvol_unfilter_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *inflated, i
   return png_unfilter_batch(ctx, inflated, n, width, height, channels, slot, rgba_dev_out);
 }
 
+int uvol_inflate_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *zlib_streams, const size_t *lens, int n, uint32_t width, uint32_t height, int channels, int slot, const uint8_t **rgba_dev_out) {
+  UVOL_AFTER_ASYNC(ctx);
+  if (!ctx || !zlib_streams || !lens || n < 0 || !rgba_dev_out) return UVOL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  return png_ingest_batch(ctx, zlib_streams, lens, n, width, height, channels, slot, rgba_dev_out);
+}
+int uvol_png_status(uvol_ctx *ctx, int slot, int *status, int n) {
+  if (!ctx) return UVOL_E_INVALID;
+  UVOL_AFTER_ASYNC(ctx);
+  (void)hipSetDevice(ctx->device);
+  return png_status(ctx, slot, status, n);
+}
+
 int uvol_encode_mesh_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, void *producer_stream,
                                    uint8_t *dev_out, size_t dev_cap, size_t *out_offs, size_t *out_lens, int *status) {
   UVOL_AFTER_ASYNC(ctx);

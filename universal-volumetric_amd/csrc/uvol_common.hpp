@@ -253,6 +253,8 @@ void png_destroy(uvol_ctx *ctx);
 int png_order_before(uvol_ctx *ctx, hipStream_t stream, const uint8_t *const *layers, size_t n_layers);
 int png_wait(uvol_ctx *ctx);
 int png_unfilter_batch(uvol_ctx *ctx, const uint8_t *const *raw, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out);
+int png_ingest_batch(uvol_ctx *ctx, const uint8_t *const *raw, const size_t *zlens, int n, uint32_t w, uint32_t h, int channels, int slot, const uint8_t **rgba_dev_out);
+int png_status(uvol_ctx *ctx, int slot, int *status, int n);
 int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);
 #define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */

@@ -40,7 +40,7 @@ EXPORTS = ["uvol_params_default", "uvol_abi_version", "uvol_device_count", "uvol
            "uvol_encode_texture_segment_dev", "uvol_encode_texture_segments", "uvol_encode_texture_segments_dev",
            "uvol_ktx2_info", "uvol_decode_texture_segments", "uvol_decode_texture_segments_dev", "uvol_transcode_texture_segments_etc1", "uvol_transcode_texture_segments_bc7", "uvol_transcode_texture_segments_etc2_rgba", "uvol_transcode_texture_segments_astc", "uvol_drc_info", "uvol_decode_mesh_batch", "uvol_profile_enable", "uvol_profile_reset", "uvol_profile_count",
            "uvol_profile_get", "uvol_encode_texture_segments_st", "uvol_transcode_texture_segments_st",
-           "uvol_host_alloc", "uvol_host_free"]
+           "uvol_host_alloc", "uvol_host_free", "uvol_inflate_png_batch_dev", "uvol_png_status"]
 
 
 def load(path=None):
@@ -83,6 +83,8 @@ def load(path=None):
     L.uvol_decode_mesh_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(DecodedMesh), C.POINTER(C.c_int)]
     L.uvol_decode_mesh_batch_dev.argtypes = L.uvol_decode_mesh_batch.argtypes
     L.uvol_unfilter_png_batch_dev.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.uvol_inflate_png_batch_dev.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.uvol_png_status.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.uvol_parse_obj_batch_dev.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(Mesh), C.POINTER(C.c_int)]
     L.uvol_encode_mesh_batch_dev_out.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.uvol_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -234,6 +236,21 @@ class Codec:
         if sync and self.L.uvol_sync(self.h) != UVOL_OK:
             raise UvolError(f"uvol_sync: {self.error()}")
         return [int(p) for p in out]
+
+    def inflate_png_batch_dev(self, zstreams, width, height, channels, slot=0, sync=True):
+        """zstreams: list of bytes (the zlib stream = concatenated IDAT data of 8-bit RGB / RGBA PNGs of one size) -> (list of DEVICE pointers
+        to RGBA8 layers, list of per-image statuses); inflate and un-filter both run on the device."""
+        zs = [bytes(z) for z in zstreams]; n = len(zs)
+        zp = (C.c_char_p * n)(*zs); ln = (C.c_size_t * n)(*[len(z) for z in zs]); out = (C.c_void_p * n)(); st = (C.c_int * n)()
+        rc = self.L.uvol_inflate_png_batch_dev(self.h, zp, ln, n, width, height, channels, slot, out)
+        if rc != UVOL_OK:
+            raise UvolError(f"inflate_png_batch_dev rc={rc}: {self.error()}")
+        rc = self.L.uvol_png_status(self.h, slot, st, n)
+        if rc != UVOL_OK:
+            raise UvolError(f"png_status rc={rc}: {self.error()}")
+        if sync and self.L.uvol_sync(self.h) != UVOL_OK:
+            raise UvolError(f"uvol_sync: {self.error()}")
+        return [int(p) for p in out], list(st)
 
     def drc_info(self, data):
         nf, mv = C.c_uint32(), C.c_uint32()
