@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
   UVOL_G(const uint32_t) zw = UVOL_TO_G(const uint32_t, reinterpret_cast<const uint32_t *>(J.z));          // 16-byte aligned, >= 16 readable bytes behind the stream
   UVOL_G(const uint8_t) zb = UVOL_TO_G(const uint8_t, J.z);
   const uint32_t zlen = (uint32_t)UVOL_READFIRST(J.zlen), nw = (zlen + 3u) / 4u, cap = (uint32_t)UVOL_READFIRST(J.out_cap);
-  UVOL_G(uint8_t) out = UVOL_TO_G(uint8_t, J.out);
+  UVOL_G(uint8_t) out = UVOL_TO_G(uint8_t, J.out); uint8_t *outg = J.out;
   const int dz = UVOL_LANE_ZERO();                      // (keeps the prefetched stream word in a vector register until it is consumed)
   unsigned long long bb = 0; uint32_t bc = 0, iw = 0;
   uint32_t wnext = zw[dz];
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
   // complete KiB of the ring -> HBM (lane = 16 bytes); the ring never holds more than 1 KiB + one token that has not left
 #define INF_FLUSH() do { while (opos - flushed >= 1024u) { UVOL_WAVE_SYNC(); \
       const uint4 v_ = *reinterpret_cast<const uint4 *>(ring + ((flushed + 16u * (uint32_t)lane) & (INF_WIN - 1u))); \
-      *reinterpret_cast<UVOL_G(uint4)>(out + flushed + 16u * (uint32_t)lane) = v_; inf_adler16(v_, flushed + 16u * (uint32_t)lane, ad_a, ad_p); flushed += 1024u; } } while (0)
+      *reinterpret_cast<uint4 *>(outg + flushed + 16u * (uint32_t)lane) = v_; inf_adler16(v_, flushed + 16u * (uint32_t)lane, ad_a, ad_p); flushed += 1024u; } } while (0)
   INF_REFILL();
   { const uint32_t cmf = INF_BITS(8), flg = (uint32_t)(bb >> 8) & 255u; INF_DROP(16);
     if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) err = -1; }

@@ -406,7 +406,7 @@ bool read_png(const std::string &path, Image &img, std::string &err, IngestScrat
   return true;
 }
 
-int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestScratch *scratch) {
+int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestScratch *scratch, bool keep_deflated) {
   IngestScratch local; IngestScratch &S = scratch ? *scratch : local;
   std::vector<uint8_t> &d = S.file; if (!read_file(path, d)) { err = "cannot read " + path; return -1; }
   static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
@@ -423,6 +423,7 @@ int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestS
   }
   if (!w || !h || interlace || depth != 8 || (ctype != 2 && ctype != 6) || w > 8192 || h > 16384) return 0;        // read_png decides (and words the errors)
   out.w = w; out.h = h; out.ch = ctype == 2 ? 3 : 4;
+  if (keep_deflated) { if (idat.size() < 6) { err = path + ": no image data"; return -1; } out.raw.assign(idat.begin(), idat.end()); return 1; }      // (uvol_inflate_png_batch_dev inflates it)
   out.raw.resize(((size_t)w * out.ch + 1) * h);
   if (!inflate_zlib_stream(idat.data(), idat.size(), out.raw.data(), out.raw.size())) { err = path + ": zlib inflate failed"; return -1; }
   return 1;

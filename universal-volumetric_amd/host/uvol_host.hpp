@@ -58,8 +58,8 @@ struct Image { uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; };
 bool read_png(const std::string &path, Image &img, std::string &err, IngestScratch *scratch = nullptr);
 // The device un-filters (uvol_unfilter_png_batch_dev): chunk parse + zlib inflate only.  raw = height rows of (filter-type byte + width * ch
 // bytes).  1: done; 0: a variant the device path does not take (16-bit, palette, grey, wider than 8192: use read_png); -1: error (err set)
-struct PngRaw { uint32_t w = 0, h = 0; int ch = 0; std::vector<uint8_t> raw; };
-int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestScratch *scratch = nullptr);
+struct PngRaw { uint32_t w = 0, h = 0; int ch = 0; std::vector<uint8_t> raw; };      // raw: the inflated scanlines, or (keep_deflated) the zlib stream itself
+int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestScratch *scratch = nullptr, bool keep_deflated = false);
 // CPUs this process may actually use: the cgroup v2 quota (cpu.max) when there is one, else the hardware thread count.  A container
 // that sees 256 hardware threads under a 16-CPU quota gets SLOWER with more than ~16 runnable threads (measured: DESIGN section 6).
 unsigned effective_cpus();

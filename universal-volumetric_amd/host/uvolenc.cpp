@@ -3,7 +3,7 @@
 // draco_encoder / basisu once per frame / per batch.  Output layout and manifest follow what the stock
 // player reads (src/Interfaces.ts:75-132, src/V2/player.ts:141-174).
 //
-//   uvolenc project-config.json [--gpus N] [--device D] [--batch-frames F] [--ingest-threads T] [--targets ktx2[,etc2]] [--uastc]
+//   uvolenc project-config.json [--gpus N] [--device D] [--batch-frames F] [--ingest-threads T] [--targets ktx2[,etc2]] [--uastc] [--device-inflate [--tex-batch-frames F]]
 //                               [--force] [--encoder-py-manifest]
 //   --targets   texture targets to write (src/Interfaces.ts:19 TextureFileFormat): `ktx2` always; `etc2` adds one raw ETC2 RGB
 //               (ETC1-subset) block image per frame, transcoded on the GPU from the ETC1S segments, and a second target in the manifest
@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
   }
   const auto t_start = std::chrono::steady_clock::now();
   { const char *e = std::getenv("UVOL_TIMING"); g_timing = e && *e == '1'; }
-  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false, host_png = false;
+  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false, host_png = false, dev_inflate = false; int tex_batch_frames = 0;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device0 = std::atoi(argv[++i]);
@@ -66,6 +66,8 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) ingest_threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--force")) force = true;
     else if (!std::strcmp(argv[i], "--host-png-unfilter")) host_png = true;       // PNG scanlines un-filtered by the ingest threads (as until round 3) instead of on the GPU
+    else if (!std::strcmp(argv[i], "--device-inflate")) dev_inflate = true;        // the PNGs' zlib streams inflated on the GPU too (k_inflate: one wave per image; pays with many images per call, see --tex-batch-frames)
+    else if (!std::strcmp(argv[i], "--tex-batch-frames") && i + 1 < argc) tex_batch_frames = std::atoi(argv[++i]);      // images per texture call (default: --batch-frames)
     else if (!std::strcmp(argv[i], "--host-obj-parser")) host_obj = true;          // OBJ text parsed by the ingest threads (as until round 3) instead of on the GPU
     else if (!std::strcmp(argv[i], "--uastc")) uastc = true;
     else if (!std::strcmp(argv[i], "--encoder-py-manifest")) encpy = true;
@@ -261,9 +263,9 @@ int main(int argc, char **argv) {
     // Segments of KTX2_BATCH_SIZE images are independent.  Full segments go to the GPU `segs_per_call` at a time
     // through the batched entry point (one launch per stage for all of them); PNGs of the next call are inflated by the
     // ingest threads meanwhile.  A short last segment (fewer layers) is encoded on its own.
-    const int segs_per_call = std::max(1, frames_per_batch / std::max(1, cfg.ktx2_batch_size));
+    const int segs_per_call = std::max(1, (tex_batch_frames > 0 ? tex_batch_frames : frames_per_batch) / std::max(1, cfg.ktx2_batch_size));
     struct TexBatch { size_t s0 = 0, ns = 0; std::vector<std::vector<Image>> imgs; std::vector<std::vector<Image>> spare; std::string err; int bad = -1;
-                      bool dev = false; std::vector<std::vector<PngRaw>> raws;        // dev: the images are INFLATED scanlines, un-filtered on the GPU
+                      bool dev = false; int slot = 0; std::vector<std::vector<PngRaw>> raws;        // dev: the images are INFLATED scanlines, un-filtered on the GPU
                       std::vector<std::vector<const uint8_t *>> dptr; bool issued = false; };   // ... their RGBA layers in HBM once the un-filter call is queued
     for (int g = 0; g < n_gpus; g++) tex_threads.emplace_back([&, g] {
       const size_t lo = starts.size() * (size_t)g / n_gpus, hi = starts.size() * (size_t)(g + 1) / n_gpus;       // = shard_plan's segment block
@@ -290,7 +292,7 @@ int main(int argc, char **argv) {
             const size_t s = j / (size_t)B; const int k = (int)(j % (size_t)B);
             char path[4096]; std::snprintf(path, sizeof path, cpat.c_str(), (unsigned)(starts[s0 + s] + k));
             std::string e;
-            const int r = read_png_raw(path, T->raws[s][(size_t)k], e, &scratch[wk]);
+            const int r = read_png_raw(path, T->raws[s][(size_t)k], e, &scratch[wk], dev_inflate);
             if (r == 1) present[s][(size_t)k] = 1;
             else if (r == 0) odd = 1;
             else if (k == 0 || starts[s0 + s] + k < cfg.ktx2_file_count) { std::lock_guard<std::mutex> l(mu); if (T->bad < 0 || (int)s < T->bad) { T->bad = (int)s; T->err = e; } }
@@ -300,7 +302,7 @@ int main(int argc, char **argv) {
           if (ok) {
             T->dev = true;
             for (size_t s = 0; s < T->ns; s++) { size_t n = 0; while (n < (size_t)B && present[s][n]) n++; T->imgs[s].resize(n); for (size_t k = 0; k < n; k++) { T->imgs[s][k].w = T->raws[s][k].w; T->imgs[s][k].h = T->raws[s][k].h; } }
-            if (g_timing && T->ns) std::fprintf(stderr, "[uvolenc-timing] tex load  s0=%zu n=%zu segments %.0f ms (inflate only)\n", s0, T->ns, now_ms() - tl0);
+            if (g_timing && T->ns) std::fprintf(stderr, "[uvolenc-timing] tex load  s0=%zu n=%zu segments %.0f ms (%s)\n", s0, T->ns, now_ms() - tl0, dev_inflate ? "files read, chunks parsed" : "inflate only");
             return T;
           }
           if (T->bad >= 0) return T;                         // a file is missing: reported as before
@@ -327,7 +329,12 @@ int main(int argc, char **argv) {
         if (!Tb.dev || Tb.bad >= 0) return true;
         std::vector<const uint8_t *> rp; for (size_t s = 0; s < Tb.ns; s++) for (size_t k = 0; k < Tb.imgs[s].size(); k++) rp.push_back(Tb.raws[s][k].raw.data());
         std::vector<const uint8_t *> dp(rp.size(), nullptr);
-        if (uvol_unfilter_png_batch_dev(tctxs[g], rp.data(), (int)rp.size(), Tb.raws[0][0].w, Tb.raws[0][0].h, Tb.raws[0][0].ch, (int)((n_issue++) & 1), dp.data()) != UVOL_OK) { fail(starts[Tb.s0], uvol_last_error(tctxs[g])); return false; }
+        Tb.slot = (int)((n_issue++) & 1);
+        int rcu;
+        if (dev_inflate) { std::vector<size_t> zl; for (size_t s = 0; s < Tb.ns; s++) for (size_t k = 0; k < Tb.imgs[s].size(); k++) zl.push_back(Tb.raws[s][k].raw.size());
+          rcu = uvol_inflate_png_batch_dev(tctxs[g], rp.data(), zl.data(), (int)rp.size(), Tb.raws[0][0].w, Tb.raws[0][0].h, Tb.raws[0][0].ch, Tb.slot, dp.data()); }
+        else rcu = uvol_unfilter_png_batch_dev(tctxs[g], rp.data(), (int)rp.size(), Tb.raws[0][0].w, Tb.raws[0][0].h, Tb.raws[0][0].ch, Tb.slot, dp.data());
+        if (rcu != UVOL_OK) { fail(starts[Tb.s0], uvol_last_error(tctxs[g])); return false; }
         size_t q = 0; for (size_t s = 0; s < Tb.ns; s++) for (size_t k = 0; k < Tb.imgs[s].size(); k++) Tb.dptr[s].push_back(dp[q++]);
         return true;
       };
@@ -350,6 +357,13 @@ int main(int argc, char **argv) {
         for (auto &seg : T->imgs) for (auto &im : seg) if (im.w != w || im.h != h) same = false;
         if (!same) { fail(starts[s0], "image sizes differ"); break; }
         tex_w = w; tex_h = h;
+        if (T->dev && dev_inflate) {                   // a PNG whose zlib stream the device found corrupt: its segment fails as `basisu` would on that file (scripts/Encoder.py:293-298)
+          size_t ni = 0; for (auto &seg : T->imgs) ni += seg.size();
+          std::vector<int> pst(ni, UVOL_OK); int bad_seg = -1;
+          if (uvol_png_status(tctxs[g], T->slot, pst.data(), (int)ni) != UVOL_OK) { fail(starts[s0], uvol_last_error(tctxs[g])); break; }
+          size_t q = 0; for (size_t s = 0; s < T->ns && bad_seg < 0; s++) for (size_t k = 0; k < T->imgs[s].size(); k++) if (pst[q++] != UVOL_OK) { bad_seg = (int)s; break; }
+          if (bad_seg >= 0) { fail(starts[s0 + (size_t)bad_seg], "zlib inflate failed"); break; }
+        }
         std::vector<std::unique_ptr<uint8_t[]>> outs(T->ns); std::vector<size_t> lens(T->ns, 0);
         // full segments: one batched call; segments with fewer layers: one call each
         std::vector<size_t> full; for (size_t s = 0; s < T->ns; s++) if ((int)T->imgs[s].size() == B) full.push_back(s);
