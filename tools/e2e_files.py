@@ -45,6 +45,7 @@ def quota_cpus():                          # what uvolenc's own default is based
 threads = "default"
 cmd = [os.path.join(ROOT, "universal-volumetric_amd", "bin", "uvolenc"), os.path.join(root, "project-config.json")] + (["--batch-frames", str(min(n, 120))] if "--batch-frames" not in extra else []) + extra
 t = time.perf_counter(); r = subprocess.run(cmd, cwd=root, capture_output=True, text=True); wall = time.perf_counter() - t
+if os.environ.get("UVOL_TIMING") == "1": sys.stderr.write("".join(l + "\n" for l in r.stderr.splitlines() if "uvolenc-timing" in l))
 m = re.search(r"encode phase ([0-9.]+) s, ([0-9.]+) frames/s", r.stdout)
 out_dir = os.path.join(root, "out")
 print(json.dumps({"what": "uvolenc end to end: %d OBJ (%.1f MB text each) + %d PNG (%.1f MB each) files -> .drc / .ktx2 / uvol.json on disk" % (n, obj_mb, n, png_mb),

@@ -7,5 +7,5 @@ mv $D/out $D/out_host
 run dev480 --device-inflate --tex-batch-frames 480
 diff -rq $D/out_host $D/out > $O/diff_dev480.txt 2>&1; echo "diff rc=$? ($(wc -l < $O/diff_dev480.txt) lines)" | tee -a $O/diff_dev480.txt
 run dev960 --device-inflate --tex-batch-frames 960
-run dev240 --device-inflate --tex-batch-frames 240
+
 rm -rf $D

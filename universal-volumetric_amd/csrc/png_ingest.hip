@@ -267,15 +267,23 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
     }
     if (inf_build(lens, hlit, cntl, sortl, lutl, INF_LBITS, lane) < 0) { err = -4; break; }
     if (inf_build(lens + hlit, hdist, cntd, sortd, lutd, INF_DBITS, lane) < 0) { err = -4; break; }
+    uint32_t fast_end = flushed + 1024u < cap ? flushed + 1024u : cap;      // below it a literal needs neither the flush nor the capacity test
     for (;;) {
       INF_REFILL();
       uint32_t e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]), L, sym;
+      // literals straight from the table, two per refill (2 x 11 bits of the >= 32 in the buffer; what is left covers any other symbol):
+      // every lane stores the same byte to the same place, so the store needs no lane mask
+      if (e - 1u < 0xfffu && opos + 2u <= fast_end) {
+        ring[opos & (INF_WIN - 1u)] = (uint8_t)(e >> 4); opos++; INF_DROP(e & 15u);
+        e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]);
+        if (e - 1u < 0xfffu) { ring[opos & (INF_WIN - 1u)] = (uint8_t)(e >> 4); opos++; INF_DROP(e & 15u); continue; }
+      }
       if (e) { L = e & 15u; sym = e >> 4; }
       else { const int s_ = inf_slow(bb, cntl, sortl, L); if (s_ < 0) { err = -5; break; } sym = (uint32_t)s_; }
       INF_DROP(L);
       if (sym < 256u) {
         if (opos >= cap) { err = -7; break; }
-        if (lane == 0) ring[opos & (INF_WIN - 1u)] = (uint8_t)sym;
+        ring[opos & (INF_WIN - 1u)] = (uint8_t)sym;
         opos++;
       } else if (sym == 256u) break;
       else {
@@ -308,6 +316,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
         opos += len;
       }
       INF_FLUSH();
+      fast_end = flushed + 1024u < cap ? flushed + 1024u : cap;
       if (iw > nw + 1u) { err = -8; break; }
     }
   }

@@ -272,7 +272,8 @@ int main(int argc, char **argv) {
       // three batch objects in turn: the one being encoded, the next one (loaded; its un-filter queued beside this encode), the one being loaded
       std::shared_ptr<TexBatch> pool[3] = { std::make_shared<TexBatch>(), std::make_shared<TexBatch>(), std::make_shared<TexBatch>() }; size_t n_loads = 0;
       std::vector<IngestScratch> scratch((size_t)std::max(1, tex_ingest));
-      auto slen = [&](size_t s0) -> size_t { return s0 == lo ? (size_t)std::max(1, std::min(segs_per_call, std::max(4, segs_per_call / 4))) : (size_t)segs_per_call; };      // (a short first call, as in the geometry stage)
+      // (a short first call, as in the geometry stage; not with the device inflate, whose kernel takes the same time for 1 or 1000 images)
+      auto slen = [&](size_t s0) -> size_t { return s0 == lo && !dev_inflate ? (size_t)std::max(1, std::min(segs_per_call, std::max(4, segs_per_call / 4))) : (size_t)segs_per_call; };
       auto load = [&](size_t s0, size_t slot) {
         std::shared_ptr<TexBatch> T = pool[slot]; T->s0 = s0; T->ns = s0 < hi ? std::min(hi - s0, slen(s0)) : 0; T->bad = -1; T->err.clear();
         // recycled Image objects keep their 16.8 MB pixel buffers (a short last segment shrinks imgs[s]; the layers come back from `spare`)
