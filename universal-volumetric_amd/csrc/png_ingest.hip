@@ -196,6 +196,8 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
   int err = 0;
   uint32_t opos = 0, flushed = 0;
   unsigned long long ad_a = 0, ad_p = 0;                // this lane's share of the Adler-32 sums
+  uint32_t pend = 0, npend = 0;                         // literals not in the ring yet: lane k holds the k-th, they end at opos
+#define INF_PEND_FLUSH() do { if (npend) { if ((uint32_t)lane < npend) ring[(opos - npend + (uint32_t)lane) & (INF_WIN - 1u)] = (uint8_t)pend; npend = 0; } } while (0)
 #define INF_REFILL() do { if (bc <= 32u) { bb |= (unsigned long long)(uint32_t)UVOL_READFIRST(wnext) << bc; bc += 32u; iw++; wnext = zw[(iw < nw ? iw : nw) + (uint32_t)dz]; } } while (0)
 #define INF_BITS(n) ((uint32_t)(bb & ((1ull << (n)) - 1ull)))
 #define INF_DROP(n) do { bb >>= (n); bc -= (n); } while (0)
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
     INF_REFILL();
     last = (bb & 1ull) != 0; const uint32_t type = (uint32_t)(bb >> 1) & 3u; INF_DROP(3);
     if (type == 0u) {
+      INF_PEND_FLUSH();
       INF_DROP(bc & 7u); INF_REFILL();
       uint32_t len = INF_BITS(16); const uint32_t nlen = (uint32_t)(bb >> 16) & 0xffffu; INF_DROP(32);
       if ((len ^ nlen) != 0xffffu) { err = -3; break; }
@@ -271,13 +274,15 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
     for (;;) {
       INF_REFILL();
       uint32_t e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]), L, sym;
-      // literals straight from the table, two per refill (2 x 11 bits of the >= 32 in the buffer; what is left covers any other symbol):
-      // every lane stores the same byte to the same place, so the store needs no lane mask
-      if (e - 1u < 0xfffu && opos + 2u <= fast_end) {
-        ring[opos & (INF_WIN - 1u)] = (uint8_t)(e >> 4); opos++; INF_DROP(e & 15u);
+      // literals straight from the table, two per refill (2 x 11 bits of the >= 32 in the buffer; what is left covers any other symbol);
+      // they collect in a register, lane k the k-th pending one, and reach the ring with one store per run (a store per literal
+      // queues in front of the next table read)
+      if (e - 1u < 0xfffu && opos + 2u <= fast_end && npend <= 62u) {
+        pend = lane == (int)npend ? (e >> 4) : pend; npend++; opos++; INF_DROP(e & 15u);
         e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]);
-        if (e - 1u < 0xfffu) { ring[opos & (INF_WIN - 1u)] = (uint8_t)(e >> 4); opos++; INF_DROP(e & 15u); continue; }
+        if (e - 1u < 0xfffu) { pend = lane == (int)npend ? (e >> 4) : pend; npend++; opos++; INF_DROP(e & 15u); continue; }
       }
+      INF_PEND_FLUSH();
       if (e) { L = e & 15u; sym = e >> 4; }
       else { const int s_ = inf_slow(bb, cntl, sortl, L); if (s_ < 0) { err = -5; break; } sym = (uint32_t)s_; }
       INF_DROP(L);
@@ -324,6 +329,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
   uint32_t want = 0;
   if (!err) { INF_DROP(bc & 7u); INF_REFILL(); const uint32_t t = INF_BITS(32); INF_DROP(32); want = (t >> 24) | ((t >> 8) & 0xff00u) | ((t << 8) & 0xff0000u) | (t << 24); }
   if (!err && 32ull * iw - bc > 8ull * zlen) err = -8;    // the stream ended inside a code or before its trailer
+  INF_PEND_FLUSH();
   UVOL_WAVE_SYNC();
   for (uint32_t i = flushed + (uint32_t)lane; i < opos; i += 64) { const uint32_t b = ring[i & (INF_WIN - 1u)]; out[i] = (uint8_t)b; ad_a += b; ad_p += (unsigned long long)i * b; }
   __syncthreads();
@@ -345,6 +351,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
 #undef INF_BITS
 #undef INF_DROP
 #undef INF_FLUSH
+#undef INF_PEND_FLUSH
 }
 __global__ void __launch_bounds__(64) k_png_statuses(const PngJob *jobs, int32_t *st, int n) {
   const int i = (int)(blockIdx.x * 64 + threadIdx.x);
