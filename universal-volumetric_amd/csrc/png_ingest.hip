@@ -311,12 +311,22 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
         if (opos + len > cap) { err = -7; break; }
         // the copy: 64 bytes per round, reads before writes; a match that overlaps itself repeats its first `dist` bytes
         const uint32_t from = opos - dist;
-        for (uint32_t b = 0; b < len; b += 64) {
-          const uint32_t i = b + (uint32_t)lane; uint8_t v = 0;
-          UVOL_WAVE_SYNC();
-          if (i < len) v = ring[(from + (dist >= len ? i : i % dist)) & (INF_WIN - 1u)];
-          UVOL_WAVE_SYNC();
-          if (i < len) ring[(opos + i) & (INF_WIN - 1u)] = v;
+        if (dist >= len) {                               // the usual case (PNG: the row above, the pixel to the left of a run): no modulo
+          for (uint32_t b = 0; b < len; b += 64) {
+            const uint32_t i = b + (uint32_t)lane; uint8_t v = 0;
+            UVOL_WAVE_SYNC();
+            if (i < len) v = ring[(from + i) & (INF_WIN - 1u)];
+            UVOL_WAVE_SYNC();
+            if (i < len) ring[(opos + i) & (INF_WIN - 1u)] = v;
+          }
+        } else {
+          for (uint32_t b = 0; b < len; b += 64) {
+            const uint32_t i = b + (uint32_t)lane; uint8_t v = 0;
+            UVOL_WAVE_SYNC();
+            if (i < len) v = ring[(from + i % dist) & (INF_WIN - 1u)];
+            UVOL_WAVE_SYNC();
+            if (i < len) ring[(opos + i) & (INF_WIN - 1u)] = v;
+          }
         }
         opos += len;
       }
