@@ -59,4 +59,24 @@ for kind, data, first in (("drc", files[0], 11), ("drc_std", files[1], 11), ("dr
         except (uvol.UvolError, ValueError):
             bad += 1
     outcomes[kind] = (ok, bad)
+# the device inflate: valid streams of every block type, then corrupted ones (bit flips, truncations, overwritten words, random bytes) - a
+# status per image, never an out-of-bounds access of the stream, the window ring or the scanline buffer
+import zlib
+from test_hipemu_tex import png_scanlines, zlib_variants
+h, w, c = 48, 40, 4
+img = (np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] + rng.integers(0, 6, (h, w, c))).astype(np.uint8)
+raw = png_scanlines(img, rng); zs = zlib_variants(raw, rng)
+ptrs, st = cd.inflate_png_batch_dev(zs, w, h, c); assert st == [0] * len(zs)
+ok = bad = 0
+for it in range(ncorrupt):
+    b = bytearray(zs[it % len(zs)]); mode = it % 4
+    if mode == 0:
+        for _ in range(int(rng.integers(1, 4))): b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+    elif mode == 1: b = b[:int(rng.integers(6, len(b)))]
+    elif mode == 2: p_ = int(rng.integers(2, len(b) - 4)); b[p_:p_ + 4] = rng.integers(0, 256, 4, dtype=np.uint8).tobytes()
+    else: b = bytearray(b[:2]) + bytearray(rng.integers(0, 256, int(rng.integers(8, 400)), dtype=np.uint8).tobytes())
+    _, st = cd.inflate_png_batch_dev([zs[0], bytes(b), zs[1]], w, h, c, slot=it & 1)
+    assert st[0] == 0 and st[2] == 0
+    ok += st[1] == 0; bad += st[1] != 0
+outcomes["inflate"] = (ok, bad)
 print("asan check passed:", outcomes)
