@@ -270,45 +270,47 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
     }
     if (inf_build(lens, hlit, cntl, sortl, lutl, INF_LBITS, lane) < 0) { err = -4; break; }
     if (inf_build(lens + hlit, hdist, cntd, sortd, lutd, INF_DBITS, lane) < 0) { err = -4; break; }
-    uint32_t fast_end = flushed + 1024u < cap ? flushed + 1024u : cap;      // below it a literal needs neither the flush nor the capacity test
+    // One token per trip of the outer loop, after a run of literals taken in a tight inner loop: literals straight from the table while there
+    // is `room` (neither the flush nor the capacity test can become due, the pending register has a free lane); they collect in a register,
+    // lane k the k-th pending one, and reach the ring with one store per run (a store per literal queues in front of the next table
+    // read).  The loops have few exits on purpose: every exit of a loop costs scalar bookkeeping in EVERY trip (the decode is bound by
+    // instruction issue - profiles/r05_device_inflate.json), so the checks of a match are one test with one exit.
     for (;;) {
-      INF_REFILL();
-      uint32_t e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]), L, sym;
-      // literals straight from the table, two per refill (2 x 11 bits of the >= 32 in the buffer; what is left covers any other symbol);
-      // they collect in a register, lane k the k-th pending one, and reach the ring with one store per run (a store per literal
-      // queues in front of the next table read)
-      if (e - 1u < 0xfffu && opos + 2u <= fast_end && npend <= 62u) {
-        pend = lane == (int)npend ? (e >> 4) : pend; npend++; opos++; INF_DROP(e & 15u);
-        e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]);
-        if (e - 1u < 0xfffu) { pend = lane == (int)npend ? (e >> 4) : pend; npend++; opos++; INF_DROP(e & 15u); continue; }
-      }
+      uint32_t e, L, sym;
+      { const uint32_t fast_end = flushed + 1024u < cap ? flushed + 1024u : cap, r1 = fast_end - opos, r2 = 64u - npend;
+        const uint32_t k0 = npend, kend = npend + (r1 < r2 ? r1 : r2);
+        for (;;) {
+          INF_REFILL();
+          e = (uint32_t)UVOL_READFIRST(lutl[bb & ((1ull << INF_LBITS) - 1ull)]);
+          if (e - 1u >= 0xfffu || npend == kend) break;
+          pend = lane == (int)npend ? (e >> 4) : pend; npend++; INF_DROP(e & 15u);
+        }
+        opos += npend - k0; }
       INF_PEND_FLUSH();
       if (e) { L = e & 15u; sym = e >> 4; }
       else { const int s_ = inf_slow(bb, cntl, sortl, L); if (s_ < 0) { err = -5; break; } sym = (uint32_t)s_; }
       INF_DROP(L);
-      if (sym < 256u) {
+      if (sym == 256u) break;
+      if (sym < 256u) {                                    // (a literal the inner loop had no room for)
         if (opos >= cap) { err = -7; break; }
         ring[opos & (INF_WIN - 1u)] = (uint8_t)sym;
         opos++;
-      } else if (sym == 256u) break;
-      else {
+      } else {
         sym -= 257u;
-        if (sym >= 29u) { err = -9; break; }
         uint32_t len;
         if (sym < 8u) len = 3u + sym;
-        else if (sym == 28u) len = 258u;
+        else if (sym >= 28u) len = 258u;
         else { const uint32_t x = (sym - 4u) >> 2; len = 3u + ((4u + (sym & 3u)) << x) + INF_BITS(x); INF_DROP(x); }
         INF_REFILL();
         e = (uint32_t)UVOL_READFIRST(lutd[bb & ((1ull << INF_DBITS) - 1ull)]); uint32_t ds;
         if (e) { L = e & 15u; ds = e >> 4; }
         else { const int s_ = inf_slow(bb, cntd, sortd, L); if (s_ < 0) { err = -5; break; } ds = (uint32_t)s_; }
         INF_DROP(L);
-        if (ds >= 30u) { err = -6; break; }
         uint32_t dist;
         if (ds < 4u) dist = 1u + ds;
-        else { const uint32_t x = (ds >> 1) - 1u; dist = 1u + ((2u + (ds & 1u)) << x) + INF_BITS(x); INF_DROP(x); }
-        if (dist > opos) { err = -6; break; }
-        if (opos + len > cap) { err = -7; break; }
+        else { const uint32_t x = ((ds >> 1) - 1u) & 15u; dist = 1u + ((2u + (ds & 1u)) << x) + INF_BITS(x); INF_DROP(x); }
+        // length symbols 286 / 287 and distance symbols 30 / 31 do not exist; a distance cannot reach before the output, a match not beyond it
+        if (sym > 28u || ds >= 30u || dist > opos || opos + len > cap) { err = -6; break; }
         // the copy: 64 bytes per round, reads before writes; a match that overlaps itself repeats its first `dist` bytes
         const uint32_t from = opos - dist;
         if (dist >= len) {                               // the usual case (PNG: the row above, the pixel to the left of a run): no modulo
@@ -331,7 +333,6 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
         opos += len;
       }
       INF_FLUSH();
-      fast_end = flushed + 1024u < cap ? flushed + 1024u : cap;
       if (iw > nw + 1u) { err = -8; break; }
     }
   }
