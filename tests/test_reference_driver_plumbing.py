@@ -192,7 +192,7 @@ def test_uvolenc_hipemu_device_inflate_writes_the_same_files(oracle, tmp_path):
     subprocess.check_call(["make", "-s", "-C", pkg, "hipemu-bins"])
     exe = os.path.join(ROOT, "tests", "hipemu", "bin", "uvolenc")
     outs = {}
-    for name, extra in (("host", []), ("dev", ["--device-inflate", "--tex-batch-frames", "6"])):
+    for name, extra in (("host", []), ("dev", ["--device-inflate", "--tex-batch-frames", "6", "--pinned-text"])):      # (--pinned-text: OBJ files read into a page-locked slab)
         root = str(tmp_path / name); os.makedirs(root)
         cfgp, cfg, meshes, texs = cli_helpers.make_sequence(root, n_frames=7, tex=32, batch=3)
         r = subprocess.run([exe, cfgp, "--batch-frames", "4"] + extra, cwd=root, capture_output=True, text=True, timeout=900)

@@ -204,6 +204,11 @@ bool read_file(const std::string &path, std::vector<uint8_t> &d) {
   std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
   d.resize(n > 0 ? (size_t)n : 0); bool ok = n >= 0 && std::fread(d.data(), 1, d.size(), f) == d.size(); std::fclose(f); return ok;
 }
+long file_size(const std::string &path) { struct stat st; return stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) ? (long)st.st_size : -1; }
+bool read_file_into(const std::string &path, uint8_t *dst, size_t n) {
+  FILE *f = std::fopen(path.c_str(), "rb"); if (!f) return false;
+  const bool ok = std::fread(dst, 1, n, f) == n && std::fgetc(f) == EOF; std::fclose(f); return ok;
+}
 std::vector<std::string> list_dir(const std::string &dir) {
   std::vector<std::string> v; DIR *d = opendir(dir.empty() ? "." : dir.c_str()); if (!d) return v;
   while (dirent *e = readdir(d)) { std::string n = e->d_name; if (n != "." && n != "..") v.push_back(n); }

@@ -65,6 +65,8 @@ int read_png_raw(const std::string &path, PngRaw &out, std::string &err, IngestS
 unsigned effective_cpus();
 bool write_file(const std::string &path, const void *data, size_t n);
 bool read_file(const std::string &path, std::vector<uint8_t> &data);
+long file_size(const std::string &path);                                      // -1: cannot stat
+bool read_file_into(const std::string &path, uint8_t *dst, size_t n);         // exactly n bytes (the size file_size gave), into caller memory (a page-locked slab)
 std::vector<std::string> list_dir(const std::string &dir);
 bool make_dirs(const std::string &dir);
 

@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
   }
   const auto t_start = std::chrono::steady_clock::now();
   { const char *e = std::getenv("UVOL_TIMING"); g_timing = e && *e == '1'; }
-  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false, host_png = false, dev_inflate = false; int tex_batch_frames = 0;
+  int n_gpus = 1, device0 = 0, frames_per_batch = 32, ingest_threads = 0; bool force = false, encpy = false, want_etc2 = false, uastc = false, host_obj = false, host_png = false, dev_inflate = false, pinned_text = false; int tex_batch_frames = 0;
   for (int i = 2; i < argc; i++) {
     if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device0 = std::atoi(argv[++i]);
@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) ingest_threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--force")) force = true;
     else if (!std::strcmp(argv[i], "--host-png-unfilter")) host_png = true;       // PNG scanlines un-filtered by the ingest threads (as until round 3) instead of on the GPU
+    else if (!std::strcmp(argv[i], "--pinned-text")) pinned_text = true;            // OBJ files read straight into page-locked memory (no staging copy before the upload)
     else if (!std::strcmp(argv[i], "--device-inflate")) dev_inflate = true;        // the PNGs' zlib streams inflated on the GPU too (k_inflate: one wave per image; pays with many images per call, see --tex-batch-frames)
     else if (!std::strcmp(argv[i], "--tex-batch-frames") && i + 1 < argc) tex_batch_frames = std::atoi(argv[++i]);      // images per texture call (default: --batch-frames)
     else if (!std::strcmp(argv[i], "--host-obj-parser")) host_obj = true;          // OBJ text parsed by the ingest threads (as until round 3) instead of on the GPU
@@ -138,6 +139,8 @@ int main(int argc, char **argv) {
     // buffers and the output buffers keep their capacity, so after the first two batches the stage allocates nothing.
     struct GeoBatch { size_t b0 = 0, nb = 0; std::vector<ObjMesh> ms; std::string err; int bad = -1; std::vector<std::unique_ptr<uint8_t[]>> outs; std::vector<size_t> ocap;
                       std::vector<std::vector<uint8_t>> text;              // device parser: the files as they are
+                      uint8_t *pin = nullptr; size_t pin_cap = 0; std::vector<size_t> toff, tlen;      // --pinned-text: ... read into ONE page-locked slab (uvol_host_alloc): the upload is DMA from where the text lies
+                      ~GeoBatch() { if (pin) uvol_host_free(pin); }
                       std::vector<uvol_mesh> um; std::vector<uint8_t *> op; std::vector<size_t> caps, lens; std::vector<int> st, pst; };
     for (int g = 0; g < n_gpus; g++) geo_threads.emplace_back([&, g] {
       const std::vector<std::string> &files = obj_files;
@@ -155,6 +158,14 @@ int main(int argc, char **argv) {
         std::mutex mu;
         const double tl0 = now_ms();
         if (!host_obj) {                                     // the GPU parses: the ingest threads only read the files
+          if (pinned_text) {
+            Bt->toff.assign(Bt->nb, 0); Bt->tlen.assign(Bt->nb, 0); size_t tot = 0;
+            for (size_t k = 0; k < Bt->nb; k++) { const long n = file_size(join(obj_dir, files[b0 + k])); if (n <= 0) { if (Bt->bad < 0) { Bt->bad = (int)k; Bt->err = "cannot read " + files[b0 + k]; } continue; } Bt->toff[k] = tot; Bt->tlen[k] = (size_t)n; tot += ((size_t)n + 4095) & ~(size_t)4095; }
+            if (tot > Bt->pin_cap) { if (Bt->pin) uvol_host_free(Bt->pin); Bt->pin_cap = tot + tot / 8; Bt->pin = (uint8_t *)uvol_host_alloc(Bt->pin_cap); if (!Bt->pin) { Bt->pin_cap = 0; Bt->bad = 0; Bt->err = "page-locked text buffer: allocation failed"; } }
+            if (Bt->pin) parallel_for_w(Bt->nb, geo_ingest, [&](size_t k, size_t) { if (Bt->tlen[k] && !read_file_into(join(obj_dir, files[b0 + k]), Bt->pin + Bt->toff[k], Bt->tlen[k])) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = "cannot read " + files[b0 + k]; } } });
+            if (g_timing && Bt->nb) std::fprintf(stderr, "[uvolenc-timing] geo load  b0=%zu n=%zu %.0f ms (page-locked slab of %.0f MB)\n", b0, Bt->nb, now_ms() - tl0, Bt->pin_cap / 1e6);
+            return Bt;
+          }
           if (Bt->text.size() < Bt->nb) Bt->text.resize(Bt->nb);
           parallel_for_w(Bt->nb, geo_ingest, [&](size_t k, size_t) { if (!read_file(join(obj_dir, files[b0 + k]), Bt->text[k]) || Bt->text[k].empty()) { std::lock_guard<std::mutex> l(mu); if (Bt->bad < 0 || (int)k < Bt->bad) { Bt->bad = (int)k; Bt->err = "cannot read " + files[b0 + k]; } } });
         } else
@@ -184,7 +195,7 @@ int main(int argc, char **argv) {
         if (Bt.outs.size() < nb) { Bt.outs.resize(nb); Bt.ocap.resize(nb, 0); }
         if (!host_obj) {
           std::vector<const uint8_t *> tp(nb); std::vector<size_t> tl(nb);
-          for (size_t k = 0; k < nb; k++) { tp[k] = Bt.text[k].data(); tl[k] = Bt.text[k].size(); }
+          for (size_t k = 0; k < nb; k++) { if (pinned_text) { tp[k] = Bt.pin + Bt.toff[k]; tl[k] = Bt.tlen[k]; } else { tp[k] = Bt.text[k].data(); tl[k] = Bt.text[k].size(); } }
           const int rc = uvol_parse_obj_batch_dev(pctxs[g], tp.data(), tl.data(), (int)nb, slot, Bt.um.data(), Bt.pst.data());
           if (rc != UVOL_OK) { std::printf("Failed to compress %s\n%s\n", files[b0].c_str(), uvol_last_error(pctxs[g])); geo_failed = (int)b0; return false; }
           if (Bt.ms.size() < nb) Bt.ms.resize(nb);
