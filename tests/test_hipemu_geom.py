@@ -181,6 +181,16 @@ def _obj_texts(tmp_path):
            ["%.9g" % (float(rng.standard_normal()) * 10.0 ** int(rng.integers(-9, 3))) for _ in range(3000)]      # (8- and 9-digit integers above 2^24 are exact float ties: the device parser hands those back, see below) + ["%e" % float(rng.standard_normal()) for _ in range(3000)]
     d = ["v %s %s %s" % tuple(nums[i:i + 3]) for i in range(0, len(nums), 3)] + ["f 1 2 3", "f 4 5 6 7 8 9 10"]
     (tmp_path / "d.obj").write_text("\n".join(d) + "\n"); out.append(tmp_path / "d.obj")
+    # lines longer than what a workgroup stages in LDS behind its 4 KiB tile (496 bytes): 300-corner polygons (fans), comment lines of
+    # 700 - 5000 bytes, blanks before a keyword - placed so that they straddle tile boundaries at many offsets
+    m = synth.torus_mesh(20, 16); n = len(m["pos"])
+    e = ["v %.7g %.7g %.7g" % tuple(float(x) for x in v) for v in m["pos"]]
+    for k in range(12):
+        e.append("#" + "x" * int(rng.integers(700, 5000)))
+        e.append("f " + " ".join(str(int(x) + 1) for x in rng.integers(0, n, 300)))
+        e.append(" " * int(rng.integers(1, 900)) + "f %d %d %d" % (1 + k, 2 + k, 3 + k))
+        e += ["v %d 0.5 -%d" % (k, k)] * int(rng.integers(1, 40))
+    (tmp_path / "e.obj").write_text("\n".join(e) + "\n"); out.append(tmp_path / "e.obj")
     return out
 
 
