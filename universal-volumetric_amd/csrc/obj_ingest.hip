@@ -92,8 +92,9 @@ __device__ inline int obj_num(const uint8_t *t, uint32_t &q, uint32_t le, float 
 
 // The workgroup's tile (+ the 16 bytes before it and OBJ_OVER bytes behind it) staged in LDS with 16-byte loads: the parsers walk their
 // lines byte by byte, and a byte load from global memory is a cache round trip per byte and lane (k_obj_parse read the text at 16 GB/s;
-// VERDICT r4 item 6c).  The returned pointer is indexed with FILE positions p in [tile0 - 1, min(len, tile0 + OBJ_TILE + OBJ_OVER)); a
-// line that runs past that window is read from global memory as before.
+// VERDICT r4 item 6c).  The returned pointer is the tile's first byte: it is indexed with positions RELATIVE to the tile, from -1 (the
+// byte before the tile) to min(len, tile0 + OBJ_TILE + OBJ_OVER) - tile0; a line that runs past that window is read from global memory
+// (absolute positions) as before.
 #define OBJ_OVER 496
 #define OBJ_STAGE (16 + OBJ_TILE + OBJ_OVER)
 __device__ __forceinline__ const uint8_t *obj_stage(const uint8_t *text, uint32_t len, uint32_t tile0, uint8_t *stage) {
@@ -102,13 +103,14 @@ __device__ __forceinline__ const uint8_t *obj_stage(const uint8_t *text, uint32_
     if (gp >= 0 && gp < (long long)len) *reinterpret_cast<uint4 *>(stage + 16 * j) = *reinterpret_cast<const uint4 *>(text + gp);
   }
   __syncthreads();
-  return stage + 16 - (ptrdiff_t)tile0;
+  return stage + 16;
 }
-// end of the line that starts at i: inside the staged window (t = the staged text), or - a long line - found in global memory (t = the file)
-__device__ __forceinline__ uint32_t obj_line_window(const uint8_t *tl, const uint8_t *tg, uint32_t i, uint32_t wend, uint32_t len, const uint8_t *&t) {
-  uint32_t le = obj_line_end(tl, i, wend); t = tl;
-  if (le == wend && wend < len) { t = tg; le = obj_line_end(tg, le, len); }
-  return le;
+// the line that starts at file position i: t / li = where to read it (the staged tile with a relative position, or - a long line - the
+// file with the absolute one); returns its end in the same coordinates
+__device__ __forceinline__ uint32_t obj_line_window(const uint8_t *ts, const uint8_t *tg, uint32_t i, uint32_t tile0, uint32_t wend, uint32_t len, const uint8_t *&t, uint32_t &li) {
+  const uint32_t le = obj_line_end(ts, i - tile0, wend - tile0);
+  if (le == wend - tile0 && wend < len) { t = tg; li = i; return obj_line_end(tg, wend, len); }
+  t = ts; li = i - tile0; return le;
 }
 
 // pass 1: per-workgroup counts
@@ -118,13 +120,13 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_obj_count(ObjJob *jobs) {
   const uint8_t *tg = J.text; const uint32_t len = J.len;
   __shared__ __attribute__((aligned(16))) uint8_t stage[OBJ_STAGE];
   const uint32_t tile0 = blockIdx.x * OBJ_TILE, wend = len - tile0 > OBJ_TILE + OBJ_OVER ? tile0 + OBJ_TILE + OBJ_OVER : len;
-  const uint8_t *tl = obj_stage(tg, len, tile0, stage);
+  const uint8_t *ts = obj_stage(tg, len, tile0, stage);
   const uint32_t b0 = tile0 + threadIdx.x * OBJ_BPT;
   uint32_t c[4] = { 0, 0, 0, 0 };
   for (uint32_t i = b0; i < b0 + OBJ_BPT && i < len; i++) {
-    if (i != 0 && tl[i - 1] != '\n') continue;
-    const uint8_t *t; const uint32_t le = obj_line_window(tl, tg, i, wend, len, t); uint32_t q;
-    const int k = obj_kind(t, i, le, q);
+    if (i != 0 && ts[(int)(i - tile0) - 1] != '\n') continue;
+    const uint8_t *t; uint32_t li; const uint32_t le = obj_line_window(ts, tg, i, tile0, wend, len, t, li); uint32_t q;
+    const int k = obj_kind(t, li, le, q);
     if (k == 3) { const uint32_t nc = obj_face_corners(t, q, le); c[OBJ_TRI] += nc > 2 ? nc - 2 : 0; }
     else if (k >= 0) c[k]++;
   }
@@ -164,15 +166,15 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_obj_parse(ObjJob *jobs) {
   const uint8_t *tg = J.text; const uint32_t len = J.len;
   __shared__ __attribute__((aligned(16))) uint8_t stage[OBJ_STAGE];
   const uint32_t tile0 = blockIdx.x * OBJ_TILE, wend = len - tile0 > OBJ_TILE + OBJ_OVER ? tile0 + OBJ_TILE + OBJ_OVER : len;
-  const uint8_t *tl = obj_stage(tg, len, tile0, stage);
+  const uint8_t *ts = obj_stage(tg, len, tile0, stage);
   const uint32_t b0 = tile0 + threadIdx.x * OBJ_BPT;
   const bool live = J.status == 0;
   // this thread's lines: counts first (as in pass 1), then an exclusive scan over the workgroup gives the rank of its first line of each kind
   uint32_t c[4] = { 0, 0, 0, 0 };
   if (live) for (uint32_t i = b0; i < b0 + OBJ_BPT && i < len; i++) {
-    if (i != 0 && tl[i - 1] != '\n') continue;
-    const uint8_t *t; const uint32_t le = obj_line_window(tl, tg, i, wend, len, t); uint32_t q;
-    const int k = obj_kind(t, i, le, q);
+    if (i != 0 && ts[(int)(i - tile0) - 1] != '\n') continue;
+    const uint8_t *t; uint32_t li; const uint32_t le = obj_line_window(ts, tg, i, tile0, wend, len, t, li); uint32_t q;
+    const int k = obj_kind(t, li, le, q);
     if (k == 3) { const uint32_t nc = obj_face_corners(t, q, le); c[OBJ_TRI] += nc > 2 ? nc - 2 : 0; }
     else if (k >= 0) c[k]++;
   }
@@ -186,9 +188,9 @@ __global__ void __launch_bounds__(UVOL_BLOCK) k_obj_parse(ObjJob *jobs) {
   if (!live) return;
   const uint32_t NP = J.tot[OBJ_V], NT = J.tot[OBJ_VT], NN = J.tot[OBJ_VN];
   for (uint32_t i = b0; i < b0 + OBJ_BPT && i < len; i++) {
-    if (i != 0 && tl[i - 1] != '\n') continue;
-    const uint8_t *t; const uint32_t le = obj_line_window(tl, tg, i, wend, len, t); uint32_t q;
-    const int k = obj_kind(t, i, le, q);
+    if (i != 0 && ts[(int)(i - tile0) - 1] != '\n') continue;
+    const uint8_t *t; uint32_t li; const uint32_t le = obj_line_window(ts, tg, i, tile0, wend, len, t, li); uint32_t q;
+    const int k = obj_kind(t, li, le, q);
     if (k == OBJ_V) {
       float v[3]; bool ok = true;
       for (int j = 0; j < 3; j++) { const int r = obj_num(t, q, le, v[j]); if (r != 1) { ok = false; break; } }
