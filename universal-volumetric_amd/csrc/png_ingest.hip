@@ -1,8 +1,8 @@
 // png_ingest.hip — PNG scanlines un-filtered on the device (the ingest stage).
 //
 // `basisu` reads the PNGs itself (scripts/Encoder.py:274-292).  On the host a 2048^2 RGBA PNG costs ~35 core-ms: the zlib inflate and
-// the un-filter pass (Sub / Up / Average / Paeth recurrences over 16.8 MB).  The inflate stays on the host (a serial bit stream per file,
-// and the files of a batch inflate in parallel on the ingest threads); the INFLATED scanlines - a filter-type byte + width * bpp filtered
+// the un-filter pass (Sub / Up / Average / Paeth recurrences over 16.8 MB).  By default the inflate stays on the host (a serial bit stream per file,
+// and the files of a batch inflate in parallel on the ingest threads; k_inflate below is the opt-in device form); the INFLATED scanlines - a filter-type byte + width * bpp filtered
 // bytes per row - are uploaded as they are (the same 16.8 MB the un-filtered image would be) and un-filtered here, straight into the
 // RGBA8 layers uvol_encode_texture_segments_dev reads.
 //
