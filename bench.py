@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=2560, help="frames in flight per step (per GPU); a frame holds ~56 MB of geometry workspace + 27 MB of inputs: 2560 frames leave ~17 GB of the 288 GB free (2760 no longer fit)")
     ap.add_argument("--total-frames", type=int, default=0, help="STRONG scaling: one job of this many frames split over the ranks (shard.plan, whole texture segments per rank); "
                                                                 "a step is the whole job.  BASELINE configs[3]: --total-frames 1200 --gpus 8")
+    ap.add_argument("--strong-frames", type=int, default=1200, help="N > 1, weak form: the line also carries `strong_configs3`, ONE job of this many frames split over the ranks (BASELINE configs[3]: 1200)")
     ap.add_argument("--tex-size", type=int, default=2048)
     ap.add_argument("--segs", type=int, default=400, help="sphere segments (400 x 251 rings = 100,002 vertices)")
     ap.add_argument("--rings", type=int, default=251)
@@ -74,24 +75,50 @@ def main():
     ap.add_argument("--host-enqueued", action="store_true", help="with --host-inputs: the passes go through the enqueue forms (uvol_*_async on host buffers, one uvol_sync)")
     args = ap.parse_args()
 
+    # `--gpus N` IS the rank count.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the two must agree; without one,
+    # `python bench.py --gpus N` launches its N ranks itself - the same command form as N = 1.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): the line would misreport n_gpus" % (args.gpus, world))
+    one_dev = os.environ.get("UVOL_BENCH_ONE_DEVICE") == "1"      # DIAGNOSTIC: every rank drives device 0, collectives over gloo (the N > 1 code path on a 1-GPU box)
+    launch_only = os.environ.get("UVOL_BENCH_LAUNCH_ONLY") == "1"  # TEST (no GPU needed): rendezvous + the manifest gather of an empty job, then one line
+
     import numpy as np
     import torch
     import uvol, synth, shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    one_dev = os.environ.get("UVOL_BENCH_ONE_DEVICE") == "1"      # DIAGNOSTIC: every rank drives device 0, collectives over gloo (the N > 1 code path on a 1-GPU box)
     if one_dev:
         local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if one_dev:
+        if launch_only:
+            dist.init_process_group(backend="gloo")
+        elif not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        elif one_dev:
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="gloo")
         else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit("bench.py: --gpus %d but this node shows %d device(s)" % (world, torch.cuda.device_count()))
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:                 # what the collective library saw, not what the environment says
+            raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, dist.get_world_size()))
+    if launch_only:
+        f_lo, nf, s_lo, ns = shard.plan(args.total_frames or 1200, args.batch, world, rank)
+        table = shard.gather_counts(nf, ns, args.batch, 0, device=None)
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": (dist.get_world_size() if world > 1 else 1), "ranks_gathered": int(table.shape[0]),
+                              "frames_gathered": int(shard.totals(table, args.batch)[0])}))
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -139,7 +166,8 @@ def main():
             mm.n_faces = len(m["idx_pos"]) // 3
             dev_meshes.append(mm)
         torch.cuda.synchronize()
-    build_inputs(meshes_h)
+    if not args.host_inputs:                                   # (--host-inputs: the frames stay in host memory, nothing is resident on the device)
+        build_inputs(meshes_h)
     ND = len(meshes_h)
     V = sum(len(meshes_h[i % ND]["pos"]) for i in range(F_alloc)) / F_alloc                  # per-frame averages over the frames of a step
     Fc = sum(len(meshes_h[i % ND]["idx_pos"]) // 3 for i in range(F_alloc)) / F_alloc
@@ -147,7 +175,7 @@ def main():
     tex_ptrs = [t.data_ptr() for t in tex_d]
     # texture segments: own buffers AND own content per segment (the base segment shifted by whole 4x4 blocks along x)
     tex_seg_ptrs = []
-    for s_ in range(max(nseg, 1)):
+    for s_ in range(max(nseg, 1) if not args.host_inputs else 1):
         if args.shared_inputs or s_ == 0:
             tex_seg_ptrs += tex_ptrs
         else:
@@ -329,7 +357,7 @@ def main():
     # gather inside the timed region - so that one driver line per N carries both curves
     strong_extra = None
     if world > 1 and not strong and not args.host_inputs and not args.only:
-        TF = 1200
+        TF = args.strong_frames
         _, Fs, _, nsegs = shard.plan(TF, B, world, rank)
         if 0 < Fs <= F:
             set_profiling(False)
@@ -346,6 +374,7 @@ def main():
                             "frames_per_s": 2.0 * TF / ds, "ms_per_job": 500.0 * ds, "scaling": "strong", "frames_gathered": int(shard.totals(tbl, B)[0])}
             set_profiling(True)
 
+    failed = 0
     if rank == 0:
         algo_per_frame = 32.0 * V + 12.0 * Fc + 4.0 * args.tex_size ** 2 + drc_len + ktx_len
         tg = {}
@@ -370,7 +399,7 @@ def main():
                "DIAGNOSTIC identical connectivity (the frames share one index array: lane-per-walker kernels run in lock step)"
         res = {
             "metric": "frames/s encode, 100k-vert mesh + 2048^2 texture",
-            "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total_frames / dt, "unit": "frames/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8/int32 (f32 only in the quantiser)", "data": "synthetic" + (" (host buffers, PCIe-inclusive)" if args.host_inputs else "") + (" DIAGNOSTIC %s only" % args.only if args.only else ""),
             "config": {"workload": "%s, %s: ~%d-vertex/~%d-face meshes + %dx%d RGBA8 ETC1S video segments of %d layers, qp11/qt10/qn8/cl7; %s%s"
@@ -414,11 +443,33 @@ def main():
                 res["variants"]["error"] = repr(e)                  # (the variants measured before the fault stay in the line)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+        if (res.get("parity") or {}).get("mismatches"):          # a fast line whose bytes differ from the reference algorithm's is not a result
+            failed = 3
     for c in geos + texs:
         c.close()
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit(failed)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as the driver's own N > 1 command does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>),
+    one process per GPU, and hand their exit code back.  Rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:                                # a free port on the loopback interface
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, ms_step, F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes):

@@ -67,3 +67,49 @@ def test_gpu_texture_calls_of_changing_size_and_kind_on_one_context(oracle):
                 assert np.array_equal(dec[l], d.images[l])
     finally:
         cd.close()
+
+
+def test_gpu_uplink_pinned_inputs_enqueued_calls(oracle):
+    """Round 6: inputs in uvol_host_alloc memory travel through the context's uplink - slots filled on a copy stream
+    when the call begins, lanes ordered behind them by events, slots re-used behind release events.  On the real streams: geometry calls of
+    700 frames (4 groups) enqueued three deep on a ring of six slots, frames laid out back to back in the arena (one DMA per run), then a
+    call with one pageable array (staged path) on the same context; texture calls of 130 segments (two parts) enqueued three deep with an
+    alpha segment in the deferred last part.  Every byte is the oracle's."""
+    import synth, uvol
+    from test_hipemu_tex import _alpha_sequence
+    shapes = [synth.sphere_mesh(40, 21, charts=(5, 4), frame=k) for k in range(3)] + [synth.torus_mesh(16, 8), synth.grid_mesh()]
+    want = [_want_mesh(oracle, f) for f in shapes]
+    ar = uvol.PinnedArena(256 << 20)
+    cd = uvol.Codec(device=0, max_batch=800)
+    ct = uvol.Codec(device=0)
+    try:
+        pm = [{k: ar.put(v) for k, v in f.items()} for f in shapes]
+        n = 700
+        frames = [pm[i % len(pm)] for i in range(n)]
+        for _ in range(3):
+            cd.start_mesh_batch(frames)
+        res = cd.finish()
+        assert len(res) == 3
+        for got in res:
+            bad = [i for i in range(n) if got[i] != want[i % len(pm)]]
+            assert not bad, bad[:5]
+        got = cd.encode_mesh_batch(frames[:330])                                     # blocking: two groups
+        assert all(got[i] == want[i % len(pm)] for i in range(330))
+        mixed = [dict(frames[0], pos=np.array(shapes[0]["pos"]))] + frames[1:200]      # one pageable array: the whole call is staged
+        got = cd.encode_mesh_batch(mixed)
+        assert all(got[i] == want[i % len(pm)] for i in range(200))
+        tex = [synth.texture_sequence(2, size=64, seed=k) for k in range(3)] + [_alpha_sequence(2, 64, 7)]
+        want_t = [oracle.ktx2_encode(t) for t in tex]
+        pt = [[ar.put(a) for a in t] for t in tex]
+        ns = 130
+        segs = [pt[s % 3] for s in range(ns - 1)] + [pt[3]]                           # the alpha segment closes the call's last part
+        for _ in range(3):
+            ct.start_texture_segments(segs)
+        res = ct.finish()
+        assert len(res) == 3
+        for got in res:
+            assert all(got[s] == want_t[s % 3] for s in range(ns - 1)) and got[ns - 1] == want_t[3]
+        got = ct.encode_texture_segments(segs[:5])
+        assert all(got[s] == want_t[s % 3] for s in range(5))
+    finally:
+        cd.close(); ct.close(); ar.close()

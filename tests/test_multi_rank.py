@@ -46,3 +46,32 @@ def test_plan_is_segment_aligned_and_contiguous():
             assert f0 == nxt and f0 % b == 0 or nf == 0
             nxt = f0 + nf if nf else nxt; segs += ns
         assert nxt == n and segs == (n + b - 1) // b
+
+
+def _run_bench(argv, env_extra, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if k not in env_extra:
+            env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_gpus_n_launches_n_ranks_by_itself(n):
+    """`python bench.py --gpus N` - the command form of the driver's N = 1 run - starts N ranks itself (re-exec under
+    torch.distributed.run on 127.0.0.1) and `n_gpus` is the size of the process group.  UVOL_BENCH_LAUNCH_ONLY=1 stops after the
+    rendezvous and the manifest gather of configs[3]'s 1200-frame plan (gloo; the encode itself needs a GPU: tests/test_gpu_cli.py)."""
+    p, line = _run_bench(["--gpus", str(n)], {"UVOL_BENCH_LAUNCH_ONLY": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line == {"launch_only": True, "n_gpus": n, "ranks_gathered": n, "frames_gathered": 1200}
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1          # rank 0 alone prints
+
+
+def test_bench_refuses_a_rank_count_other_than_gpus():
+    """A launcher that started a different number of ranks than --gpus says is an error, not a mislabelled line."""
+    p, line = _run_bench(["--gpus", "2"], {"UVOL_BENCH_LAUNCH_ONLY": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and line is None and "--gpus 2" in p.stderr

@@ -51,7 +51,11 @@ struct WsPlanCache { std::map<std::vector<uint64_t>, WsPlan> plans; };
 // buffers and the host-side record of the call it belongs to.  A call is cut into groups that run on different lanes, so that the
 // bandwidth-bound front end of one group runs beside the latency-bound walkers of another (geo_encode_batch); lane 0 runs on the
 // context's own stream.
+// a group's inputs already on their way through the context's uplink (uvol_common.hpp): the slot and the device offset of each of the
+// frame's six arrays in it (pos, uv, nrm, idx_pos, idx_uv, idx_nrm; unused ones are never read)
+struct GeoUp { UvolUpSlot *slot = nullptr; std::vector<size_t> off; };
 struct GeoLane {
+  GeoUp up;               // the group in flight reads its inputs from this uplink slot (slot == nullptr: caller's device arrays, or `inputs` below)
   hipStream_t stream = nullptr, aux = nullptr; bool own_stream = false;     // aux: valence replay runs beside renumber / seams / traversals
   hipEvent_t ev_walk = nullptr, ev_val = nullptr, ev_fe = nullptr;          // ev_fe: this group's front end (dedup + corner table) is done
   uvol_devbuf slab;       // all per-job workspaces
@@ -522,7 +526,7 @@ static int geo_encode_sequential(uvol_ctx *ctx, GeoJob *dj, int n, bool full, ui
   return UVOL_OK;
 }
 static int geo_submit(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, int n, int n_conc, bool on_device,
-                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full);
+                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full, GeoUp *pre = nullptr);
 static int geo_complete(uvol_ctx *ctx, GeoLane &L);
 
 // First half of a group of frames on lane L: lays out the workspaces, uploads host inputs, enqueues every kernel of the group and the
@@ -582,6 +586,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   bool compact = seq || (compact_env && face_alias && !full && can_probe && G->compact_ok);
   int rc;
   bool uploaded = false;
+  const bool pre_up = !on_device && L.up.slot != nullptr;
   auto lay = [&]() -> int {
   L.hjobs.assign((size_t)n, GeoJob{});
   ws_total = 0; in_total = 0; out_total = 0; max_ecap = 0; he_nb_max = 0; ms_nb_max = 1; he_part_all = true; algo_in = 0;
@@ -598,7 +603,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     ws_off[i] = ws_total; ws_total += wp.total; zero_sz[i] = wp.zero;
     const size_t in_sz = ((size_t)m.n_pos * 12 + 255) / 256 * 256 + ((size_t)J.n_uv * 8 + 255) / 256 * 256 + ((size_t)J.n_nrm * 12 + 255) / 256 * 256 +
                          (size_t)(1 + J.has_uv + J.has_nrm) * (((size_t)m.n_faces * 12 + 255) / 256 * 256);
-    in_off[i] = in_total; in_total += on_device ? 0 : in_sz;
+    in_off[i] = in_total; in_total += (on_device || pre_up) ? 0 : in_sz;
     // the frames' streams are packed back to back (k_out_offsets), so the batch's output area is sized for typical streams
     // (8 bytes per face; the defaults give 1.3), not for the sum of the callers' capacities; GEO_E_SLAB_FULL -> retried alone
     const size_t oc = full ? caps[i] : std::min<size_t>(caps[i], 32768 + 8 * (size_t)m.n_faces);
@@ -620,8 +625,8 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
   }
   if ((rc = uvol_ensure(ctx, L.jobs, sizeof(GeoJob) * (size_t)n))) return rc;
   if (!L.ext_out && (rc = uvol_ensure(ctx, L.outs, out_total))) return rc;
-  if (!on_device && (rc = uvol_ensure(ctx, L.inputs, in_total))) return rc;
-  std::vector<UvolUpItem> ups; if (!on_device) ups.reserve((size_t)n * 6);
+  if (!on_device && !pre_up && (rc = uvol_ensure(ctx, L.inputs, in_total))) return rc;
+  std::vector<UvolUpItem> ups; if (!on_device && !pre_up) ups.reserve((size_t)n * 6);
   for (int i = 0; i < n; i++) {
     const uvol_mesh &m = meshes[i]; GeoJob &J = L.hjobs[i];
     uint8_t *base = (uint8_t *)L.slab.p + ws_off[i];
@@ -630,6 +635,11 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     J.ws_base = base; J.ws_zero = zero_sz[i];          // cleared by ONE k_job_clear launch for the whole batch (was 2 memsets per frame)
     if (L.ext_out) { J.out_pack = L.ext_out; J.slab_cap = L.ext_cap; } else { J.out_pack = (uint8_t *)L.outs.p; J.slab_cap = out_total; }
     if (on_device) { J.pos = m.pos; J.uv = J.has_uv ? m.uv : nullptr; J.nrm = J.has_nrm ? m.nrm : nullptr; J.ipos = m.idx_pos; J.iuv = J.has_uv ? m.idx_uv : nullptr; J.inrm = J.has_nrm ? m.idx_nrm : nullptr; }
+    else if (pre_up) {                                       // already on their way: the group's uplink slot (geo_encode_batch_begin)
+      const uint8_t *sb = (const uint8_t *)L.up.slot->buf.p; const size_t *o6 = &L.up.off[(size_t)i * 6];
+      J.pos = (const float *)(sb + o6[0]); J.uv = J.has_uv ? (const float *)(sb + o6[1]) : nullptr; J.nrm = J.has_nrm ? (const float *)(sb + o6[2]) : nullptr;
+      J.ipos = (const uint32_t *)(sb + o6[3]); J.iuv = J.has_uv ? (const uint32_t *)(sb + o6[4]) : nullptr; J.inrm = J.has_nrm ? (const uint32_t *)(sb + o6[5]) : nullptr;
+    }
     else {
       uint8_t *ib = (uint8_t *)L.inputs.p + in_off[i]; size_t o = 0;
       auto up = [&](const void *src, size_t bytes) -> const void * {                 // queued: ONE staged upload for the whole batch below
@@ -649,7 +659,8 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     J.rb[0].bits = J.start_bits; J.rb[1].bits = J.seam_bits[0]; J.rb[2].bits = J.seam_bits[1]; J.rb[3].bits = J.ori_bits; J.rb[4].bits = J.flips;
     // rabs slot 1/2 follow the attribute-data slot; slot 3 = uv orientations, slot 4 = normal flips
   }
-  if (!on_device && !uploaded) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.inputs.p, ups); if (rcu != UVOL_OK) return rcu; uploaded = true; }
+  if (!on_device && !pre_up && !uploaded) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.inputs.p, ups); if (rcu != UVOL_OK) return rcu; uploaded = true; }
+  if (pre_up && !uploaded) { const int rcu = uvol_uplink_acquire(ctx, L.up.slot, ctx->stream); if (rcu != UVOL_OK) return rcu; uploaded = true; }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.jobs.p, L.hjobs.data(), sizeof(GeoJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   return UVOL_OK; };
   if ((rc = lay())) return rc;
@@ -908,6 +919,7 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     LAUNCH(k_gather, dim3(64, GEO_MAXPIECES, N), dim3(UVOL_BLOCK), dj);
   }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
+  if (pre_up) { const int rcr = uvol_uplink_release(ctx, L.up.slot, ctx->stream); if (rcr != UVOL_OK) return rcr; }      // (the auxiliary stream has been joined: nothing of this group reads the slot later)
   // (the job records are read back by geo_complete_impl: a device-to-host copy into pageable memory does not return before the stream
   // has reached it, i.e. before every kernel of this group is done - here it serialised the groups of a call)
   L.t_enq = ms_since(t_enter); L.t_enter = t_enter;
@@ -990,12 +1002,14 @@ static int geo_complete_impl(uvol_ctx *ctx, GeoLane &L) {
 
 // the lane's streams stand in for the context's while one of its groups is submitted / completed (LAUNCH, Scope, uvol_ensure use ctx->stream)
 static int geo_submit(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, int n, int n_conc, bool on_device,
-                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full) {
+                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool full, GeoUp *pre) {
+  if (pre) L.up = std::move(*pre); else { L.up.slot = nullptr; L.up.off.clear(); }
   L.meshes.assign(meshes, meshes + n); L.outp.assign(outs, outs + n); L.caps.assign(caps, caps + n);
   L.out_lens = out_lens; L.status = status; L.n = n; L.n_conc = n_conc; L.on_device = on_device; L.full = full;
   hipStream_t saved = ctx->stream; ctx->stream = L.stream;
   const int rc = geo_submit_impl(ctx, L, L.meshes.data(), n, n_conc, on_device, L.caps.data(), full);
   ctx->stream = saved;
+  if (rc != UVOL_OK && L.up.slot) { (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.aux); L.up.slot = nullptr; }      // (kernels already enqueued may read the slot: its release was never recorded)
   L.busy = rc == UVOL_OK;
   return rc;
 }
@@ -1053,6 +1067,44 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   static const int groups_env = [] { const char *e = getenv("UVOL_GEO_GROUPS"); const int k = e ? atoi(e) : 4; return k < 1 ? 1 : k; }();
   const int gmax = on_device ? std::min(want, groups_env) : want;
   const int groups = split ? std::max(1, std::min(gmax, n / geo_min_group())) : 1;
+  // Inputs in uvol_host_alloc memory (SURVEY 8(d)'s boundary): the uploads of ALL groups of the call are queued on the context's copy
+  // stream now, one uplink slot per group, before the first group's kernels are enqueued (uvol_common.hpp "Uplink").  The ring has as
+  // many slots as the lane ring (>= groups), so the slot a group takes was last used by a group of an EARLIER call, whose kernels - and
+  // with them the slot's release event - have been enqueued.  A frame's arrays are placed in the order of their host addresses, the
+  // frames in call order: a caller that lays consecutive frames back to back in its arena gets one DMA per run of frames.
+  std::vector<GeoUp> ups_pre;
+  if (!on_device && uvol_uplink_enabled() && n >= 1) {
+    bool all = true;
+    for (int i = 0; i < n && all; i++) {
+      const uvol_mesh &m = meshes[i];
+      if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0) { all = false; break; }                    // (geo_submit reports the invalid frame)
+      all = uvol_host_pinned(m.pos, (size_t)m.n_pos * 12) && uvol_host_pinned(m.idx_pos, (size_t)m.n_faces * 12);
+      if (all && m.uv && m.idx_uv && m.n_uv) all = uvol_host_pinned(m.uv, (size_t)m.n_uv * 8) && uvol_host_pinned(m.idx_uv, (size_t)m.n_faces * 12);
+      if (all && m.nrm && m.idx_nrm && m.n_nrm) all = uvol_host_pinned(m.nrm, (size_t)m.n_nrm * 12) && uvol_host_pinned(m.idx_nrm, (size_t)m.n_faces * 12);
+    }
+    UvolUplink *U = all ? uvol_uplink(ctx, (size_t)std::max(want, groups)) : nullptr;
+    if (all && !U) return UVOL_E_HIP;
+    if (U) {
+      ups_pre.resize((size_t)groups);
+      std::vector<UvolUpItem> items;
+      for (int g = 0; g < groups; g++) {
+        const int a = (int)((long long)n * g / groups), b = (int)((long long)n * (g + 1) / groups);
+        GeoUp &P = ups_pre[(size_t)g]; P.off.assign((size_t)(b - a) * 6, 0);
+        UvolUpPlacer pl; items.clear(); items.reserve((size_t)(b - a) * 6);
+        for (int i = a; i < b; i++) {
+          const uvol_mesh &m = meshes[i];
+          const bool hu = m.uv && m.idx_uv && m.n_uv, hn = m.nrm && m.idx_nrm && m.n_nrm;
+          struct Arr { const void *src; size_t bytes; int k; } arr[6] = {
+            { m.pos, (size_t)m.n_pos * 12, 0 }, { hu ? m.uv : nullptr, hu ? (size_t)m.n_uv * 8 : 0, 1 }, { hn ? m.nrm : nullptr, hn ? (size_t)m.n_nrm * 12 : 0, 2 },
+            { m.idx_pos, (size_t)m.n_faces * 12, 3 }, { hu ? m.idx_uv : nullptr, hu ? (size_t)m.n_faces * 12 : 0, 4 }, { hn ? m.idx_nrm : nullptr, hn ? (size_t)m.n_faces * 12 : 0, 5 } };
+          std::sort(arr, arr + 6, [](const Arr &x, const Arr &y) { return (uintptr_t)x.src < (uintptr_t)y.src; });
+          for (const Arr &A : arr) if (A.src && A.bytes) { const size_t d = pl.place(A.src, A.bytes); P.off[(size_t)(i - a) * 6 + A.k] = d; items.push_back(UvolUpItem{ d, A.src, A.bytes }); }
+        }
+        P.slot = uvol_uplink_fill(ctx, U, items, pl.total());
+        if (!P.slot) return UVOL_E_HIP;
+      }
+    }
+  }
   GeoLane *last = nullptr;
   for (int g = 0; g < groups; g++) {
     const int a = (int)((long long)n * g / groups), b = (int)((long long)n * (g + 1) / groups);
@@ -1061,8 +1113,12 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
     if (!L) { ctx->set_error("geometry lane: stream / event creation failed"); return UVOL_E_HIP; }
     if (split) G->next_lane = (G->next_lane + 1) % want;
     if (L->busy) { const int r = geo_complete(ctx, *L); if (r != UVOL_OK && G->deferred_rc == UVOL_OK) G->deferred_rc = r; }
-    const int rc = geo_submit(ctx, *L, meshes + a, b - a, n, on_device, outs + a, caps + a, out_lens + a, status ? status + a : nullptr, false);
-    if (rc != UVOL_OK) return rc;
+    const int rc = geo_submit(ctx, *L, meshes + a, b - a, n, on_device, outs + a, caps + a, out_lens + a, status ? status + a : nullptr, false, ups_pre.empty() ? nullptr : &ups_pre[(size_t)g]);
+    if (rc != UVOL_OK) {
+      // the slots this call filled and nobody will read: their copies must not outlive the caller's arrays (the call has failed)
+      if (!ups_pre.empty() && ctx->uplink) (void)hipStreamSynchronize(ctx->uplink->stream);
+      return rc;
+    }
     last = L;
   }
   // The lanes of the ring that have not held a group yet get their buffers NOW, sized like the group just submitted: a first allocation of tens of

@@ -1078,8 +1078,15 @@ struct TexLane {
   int n_seg = 0, n_layers = 0, alpha = 0; uint32_t W = 0, H = 0;
   uint8_t *const *outs = nullptr; const size_t *caps = nullptr; size_t *out_lens = nullptr;
   int *status = nullptr;               // optional per-segment result codes of the part (uvol_encode_texture_segments_st)
+  // the part stays in flight after tex_submit returns (busy) until tex_finish; the pointer ARRAYS of the call are copied - an enqueued call's
+  // arrays are gone by the time its last part is finished on behalf of the next call (tex_flush)
+  bool busy = false, on_device = false;
+  std::vector<uint8_t *> outv; std::vector<size_t> capv; std::vector<const uint8_t *> srcv;
+  // host layers that travel through the context's uplink (uvol_common.hpp): the slot, its generation when this part took it, and the
+  // device offset of every layer in it
+  UvolUpSlot *up = nullptr; uint64_t up_gen = 0; std::vector<size_t> up_off;
 };
-struct TexState { TexLane lane[2]; };
+struct TexState { TexLane lane[2]; int next = 0; int deferred_rc = UVOL_OK; char deferred_err[512] = {0}; };
 int tex_create(uvol_ctx *ctx) { ctx->tex = new TexState(); ctx->tex->lane[0].stream = ctx->stream; return UVOL_OK; }
 void tex_destroy(uvol_ctx *ctx) {
   if (!ctx->tex) return;
@@ -1234,7 +1241,8 @@ static int tex_submit_impl(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba
   int rc;
   if ((rc = uvol_ensure(ctx, L.slab, ws * (size_t)n_seg))) return rc;
   if ((rc = uvol_ensure(ctx, L.job, sizeof(TexJob) * (size_t)n_seg))) return rc;
-  if (!on_device && (rc = uvol_ensure(ctx, L.layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
+  const bool pre_up = !on_device && L.up != nullptr;     // the layers are already on their way (tex_encode_segments queued them on the uplink)
+  if (!on_device && !pre_up && (rc = uvol_ensure(ctx, L.layers, lbytes * (size_t)n_layers * (size_t)n_seg))) return rc;
   L.hjobs.assign((size_t)n_seg, J0);
   std::vector<UvolUpItem> ups;                                           // host layers: one staged upload for the whole batch
   for (int s = 0; s < n_seg; s++) {
@@ -1245,10 +1253,12 @@ static int tex_submit_impl(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba
     for (int l = 0; l < n_layers; l++) {
       const uint8_t *src = rgba[(size_t)s * n_layers + l];
       if (on_device) J.layer[l] = src;
+      else if (pre_up) J.layer[l] = (const uint8_t *)L.up->buf.p + L.up_off[(size_t)s * n_layers + l];
       else { uint8_t *d = (uint8_t *)L.layers.p + lbytes * ((size_t)s * n_layers + l); ups.push_back(UvolUpItem{ lbytes * ((size_t)s * n_layers + l), src, lbytes }); J.layer[l] = d; }
     }
   }
-  if (!on_device) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.layers.p, ups); if (rcu != UVOL_OK) return rcu; }
+  if (!on_device && !pre_up) { const int rcu = uvol_upload_staged(ctx, (uint8_t *)L.layers.p, ups); if (rcu != UVOL_OK) return rcu; }
+  if (pre_up) { const int rcu = uvol_uplink_acquire(ctx, L.up, ctx->stream); if (rcu != UVOL_OK) return rcu; }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(L.job.p, L.hjobs.data(), sizeof(TexJob) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
   TexJob *dj = (TexJob *)L.job.p;
   const TexJob &J = J0;
@@ -1329,6 +1339,7 @@ static int tex_submit_impl(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba
     hipLaunchKernelGGL(k_tex_pack_offsets, dim3(1), dim3(64), 0, ctx->stream, dj, n_seg);
     TLAUNCH(k_tex_pack, dim3(32), dim3(UVOL_BLOCK), 0, dj, (uint8_t *)L.packed.p, (unsigned long long)L.packed.cap); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
+  if (pre_up) { const int rcr = uvol_uplink_release(ctx, L.up, ctx->stream); if (rcr != UVOL_OK) return rcr; }
   return UVOL_OK;
 }
 // second half: waits for the lane's stream, reads the job records and the packed payloads back, writes the KTX2 containers
@@ -1406,35 +1417,58 @@ static int tex_finish_impl(uvol_ctx *ctx, TexLane &L) {
 // the lane's stream stands in for the context's while one of its halves runs (TLAUNCH, Scope, uvol_ensure, uvol_upload_staged use ctx->stream)
 static int tex_submit(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
                       bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int alpha, int *status = nullptr) {
-  hipStream_t saved = ctx->stream; ctx->stream = L.stream; L.status = status;
-  const int rc = tex_submit_impl(ctx, L, rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, alpha);
-  ctx->stream = saved; return rc;
+  hipStream_t saved = ctx->stream; ctx->stream = L.stream; L.status = status; L.on_device = on_device;
+  L.outv.assign(outs, outs + n_seg); L.capv.assign(caps, caps + n_seg); L.srcv.assign(rgba, rgba + (size_t)n_seg * n_layers);
+  const int rc = tex_submit_impl(ctx, L, L.srcv.data(), n_seg, n_layers, W, H, on_device, L.outv.data(), L.capv.data(), out_lens, alpha);
+  if (rc != UVOL_OK && L.up) { (void)hipStreamSynchronize(L.stream); L.up = nullptr; }      // (kernels already enqueued may read the slot: its release was never recorded)
+  ctx->stream = saved; L.busy = rc == UVOL_OK; return rc;
 }
 // finish + the second pass of the segments that turned out to have alpha (one more batch on the same lane; host layers were uploaded
-// by the first pass and are read where they lie)
-static int tex_finish(uvol_ctx *ctx, TexLane &L, const uint8_t *const *rgba, bool on_device) {
+// by the first pass and are read where they lie - unless they travelled through an uplink slot that has been filled again since)
+static int tex_finish(uvol_ctx *ctx, TexLane &L) {
+  if (!L.busy) return UVOL_OK;
+  L.busy = false;
   hipStream_t saved = ctx->stream; ctx->stream = L.stream;
+  const bool on_device = L.on_device; const uint8_t *const *rgba = L.srcv.data();
   const int n_seg = L.n_seg, n_layers = L.n_layers; uint8_t *const *outs = L.outs; const size_t *caps = L.caps; size_t *out_lens = L.out_lens; const uint32_t W = L.W, H = L.H;
   int *const status = L.status;
   int rc = tex_finish_impl(ctx, L);
   std::vector<int> again;
   for (int s = 0; s < n_seg; s++) if (out_lens[s] == TEX_RETRY_ALPHA) { again.push_back(s); out_lens[s] = 0; }
   if (!again.empty() && (rc == UVOL_OK || rc == UVOL_E_NOSPACE || rc == UVOL_E_ENCODE)) {
+    UvolUpSlot *const slot = L.up; const bool slot_live = slot && slot->gen == L.up_gen;      // (one thread drives the context: nothing fills the slot during this function)
+    const bool from_host = !on_device && slot && !slot_live;                                  // its bytes are gone: the layers cross the link once more, from the caller's arrays
     std::vector<const uint8_t *> src; std::vector<uint8_t *> o2; std::vector<size_t> c2, l2(again.size(), 0); std::vector<int> st2(again.size(), UVOL_OK);
-    for (int s : again) { for (int l = 0; l < n_layers; l++) src.push_back(on_device ? rgba[(size_t)s * n_layers + l] : L.hjobs[s].layer[l]); o2.push_back(outs[s]); c2.push_back(caps[s]); }
+    for (int s : again) { for (int l = 0; l < n_layers; l++) src.push_back((on_device || from_host) ? rgba[(size_t)s * n_layers + l] : L.hjobs[s].layer[l]); o2.push_back(outs[s]); c2.push_back(caps[s]); }
     L.status = status ? st2.data() : nullptr;
-    int rc2 = tex_submit_impl(ctx, L, src.data(), (int)again.size(), n_layers, W, H, true, o2.data(), c2.data(), l2.data(), 1);
-    if (rc2 == UVOL_OK) rc2 = tex_finish_impl(ctx, L);
+    L.up = nullptr;                                        // (the re-run reads device pointers, or uploads through the lane's own buffer)
+    int rc2 = tex_submit_impl(ctx, L, src.data(), (int)again.size(), n_layers, W, H, !from_host, o2.data(), c2.data(), l2.data(), 1);
+    if (rc2 == UVOL_OK && slot_live) rc2 = uvol_uplink_release(ctx, slot, ctx->stream);      // the slot is read until here
+    if (rc2 == UVOL_OK) rc2 = tex_finish_impl(ctx, L); else (void)hipStreamSynchronize(ctx->stream);
     L.status = status;
     for (size_t i = 0; i < again.size(); i++) { out_lens[again[i]] = l2[i]; if (status) status[again[i]] = rc2 != UVOL_OK ? rc2 : st2[i]; }
     if (rc == UVOL_OK) rc = rc2;
   }
+  L.up = nullptr;
   ctx->stream = saved; return rc;
+}
+// completes the parts still in flight on the lanes (an enqueued call leaves its last part for the next call, or for this), older part first;
+// returns the first error among them and among parts finished earlier on behalf of later calls
+int tex_flush(uvol_ctx *ctx) {
+  TexState *T = ctx->tex; if (!T) return UVOL_OK;
+  int rc = T->deferred_rc; T->deferred_rc = UVOL_OK;
+  if (rc != UVOL_OK) snprintf(ctx->err, sizeof ctx->err, "%s", T->deferred_err);
+  for (int k = 0; k < 2; k++) { const int r = tex_finish(ctx, T->lane[(T->next + k) & 1]); if (rc == UVOL_OK) rc = r; }
+  ctx->resolve_profile();
+  return rc;
 }
 // segments per part of a call on host inputs (UVOL_TEX_PART, tests: small values cut small calls too; 0 = never cut)
 static inline int tex_part_segments() { static const int v = [] { const char *e = getenv("UVOL_TEX_PART"); const int k = e ? atoi(e) : 64; return k < 0 ? 0 : k; }(); return v; }
+// defer = the enqueue form: the call's LAST part stays in flight when the call returns and is finished when the next call needs its lane
+// (or by tex_flush when the worker's queue runs empty), so that consecutive enqueued calls overlap on the device - the next call's first
+// part uploads and encodes beside this call's last
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t W, uint32_t H,
-                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+                        bool on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status, bool defer) {
   if (n_seg <= 0) return UVOL_OK;
   TexState *T = ctx->tex;
   T->lane[0].stream = ctx->stream;
@@ -1444,31 +1478,62 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   // flight are worth more than (profiles/r05_frames_in_flight.json)
   static const int part_dev = [] { const char *e = getenv("UVOL_TEX_PART_DEV"); const int k = e ? atoi(e) : 128; return k < 0 ? 0 : k; }();
   const int part = on_device ? part_dev : tex_part_segments();
-  int rc = UVOL_OK;
-  if (part <= 0 || n_seg < 2 * part) {                                    // one batch on the context's stream
-    rc = tex_submit(ctx, T->lane[0], rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0, status);
-    if (rc == UVOL_OK) rc = tex_finish(ctx, T->lane[0], rgba, on_device);
-    ctx->resolve_profile();
-    return rc;
-  }
-  // Host inputs, a large call: parts of >= `part` segments alternate between two lanes.  While the GPU encodes part k this thread stages
-  // part k + 1 through the pinned buffers and its DMAs run on the other lane's stream; then part k's containers are written while part
-  // k + 1 encodes.  16.8 MB per layer cross PCIe: without the overlap a call was upload, then encode, one after the other.
-  if (!T->lane[1].stream) { if (uvol_make_stream(ctx, &T->lane[1].stream) != hipSuccess) { ctx->set_error("texture lane: stream creation failed"); return UVOL_E_HIP; } T->lane[1].own_stream = true; }
-  if (on_device) { const int ro = png_order_before(ctx, T->lane[1].stream, rgba, (size_t)n_seg * n_layers); if (ro != UVOL_OK) return ro; }      // (the second lane reads the un-filtered layers too)
-  const int parts = on_device ? (n_seg + part - 1) / part : std::max(2, std::min(4, n_seg / part));           // few, large parts: every part pays the serial stages' latency (one wave per slice) once
+  const bool single = part <= 0 || n_seg < 2 * part;
+  const int parts = single ? 1 : (on_device ? (n_seg + part - 1) / part : std::max(2, std::min(4, n_seg / part)));           // few, large parts: every part pays the serial stages' latency (one wave per slice) once
   auto lo = [&](int k) { return (int)((long long)n_seg * k / parts); };
-  int worst = UVOL_OK;
-  for (int k = 0; k <= parts; k++) {
-    if (k < parts) {
-      const int a = lo(k), b = lo(k + 1);
-      const int r = tex_submit(ctx, T->lane[k & 1], rgba + (size_t)a * n_layers, b - a, n_layers, W, H, on_device, outs + a, caps + a, out_lens + a, 0, status ? status + a : nullptr);
-      if (r != UVOL_OK) { if (k > 0) (void)tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, on_device); return r; }
+  // Layers in uvol_host_alloc memory: the uploads of ALL parts are queued on the context's copy stream now, one uplink slot per part
+  // (uvol_common.hpp "Uplink"; at least four slots, so a part's slot was last read by a part whose kernels have been enqueued)
+  struct PartUp { UvolUpSlot *slot = nullptr; std::vector<size_t> off; };
+  std::vector<PartUp> pups;
+  if (!on_device && uvol_uplink_enabled()) {
+    const size_t lbytes = (size_t)W * H * 4; bool all = true;
+    for (size_t i = 0; i < (size_t)n_seg * n_layers && all; i++) all = rgba[i] && uvol_host_pinned(rgba[i], lbytes);
+    UvolUplink *U = all ? uvol_uplink(ctx, (size_t)std::max(4, parts)) : nullptr;
+    if (all && !U) return UVOL_E_HIP;
+    if (U) {
+      pups.resize((size_t)parts);
+      std::vector<UvolUpItem> items;
+      for (int k = 0; k < parts; k++) {
+        const int a = lo(k), b = lo(k + 1);
+        PartUp &P = pups[(size_t)k]; P.off.resize((size_t)(b - a) * n_layers);
+        UvolUpPlacer pl; items.clear(); items.reserve(P.off.size());
+        for (size_t i = 0; i < P.off.size(); i++) { const uint8_t *src = rgba[(size_t)a * n_layers + i]; const size_t d = pl.place(src, lbytes); P.off[i] = d; items.push_back(UvolUpItem{ d, src, lbytes }); }
+        P.slot = uvol_uplink_fill(ctx, U, items, pl.total());
+        if (!P.slot) { (void)hipStreamSynchronize(U->stream); return UVOL_E_HIP; }
+      }
     }
-    if (k > 0) { const int r = tex_finish(ctx, T->lane[(k - 1) & 1], rgba + (size_t)lo(k - 1) * n_layers, on_device); if (r != UVOL_OK && worst == UVOL_OK) worst = r; }
   }
-  ctx->resolve_profile();
-  return worst;
+  auto take_up = [&](TexLane &L, int k) { if (pups.empty()) { L.up = nullptr; return; } L.up = pups[(size_t)k].slot; L.up_gen = L.up->gen; L.up_off = std::move(pups[(size_t)k].off); };
+  auto fail_ups = [&]() { if (!pups.empty() && ctx->uplink) (void)hipStreamSynchronize(ctx->uplink->stream); };      // the copies nobody will read must not outlive the caller's arrays
+  auto keep_err = [&](int r) { if (r != UVOL_OK && T->deferred_rc == UVOL_OK) { T->deferred_rc = r; snprintf(T->deferred_err, sizeof T->deferred_err, "%s", ctx->err); } };
+  int rc = UVOL_OK;
+  if (single) {                                                           // one batch on the context's stream
+    keep_err(tex_flush(ctx));                                             // (nothing of an earlier enqueued call on the lanes)
+    take_up(T->lane[0], 0);
+    rc = tex_submit(ctx, T->lane[0], rgba, n_seg, n_layers, W, H, on_device, outs, caps, out_lens, 0, status);
+    if (rc != UVOL_OK) { fail_ups(); return rc; }
+    T->next = 1;                                                          // (lane 0 holds the older part)
+    if (defer) return UVOL_OK;
+    return tex_flush(ctx);
+  }
+  // A large call: parts of >= `part` segments alternate between two lanes.  While the GPU encodes part k the layers of part k + 1 cross
+  // the link (staged through the pinned buffers by this thread, or queued on the uplink above) and its kernels are enqueued on the other
+  // lane's stream; then part k's containers are written while part k + 1 encodes.  16.8 MB per layer cross PCIe: without the overlap a
+  // call was upload, then encode, one after the other.
+  if (!T->lane[1].stream) { if (uvol_make_stream(ctx, &T->lane[1].stream) != hipSuccess) { ctx->set_error("texture lane: stream creation failed"); fail_ups(); return UVOL_E_HIP; } T->lane[1].own_stream = true; }
+  if (on_device) { const int ro = png_order_before(ctx, T->lane[1].stream, rgba, (size_t)n_seg * n_layers); if (ro != UVOL_OK) return ro; }      // (the second lane reads the un-filtered layers too)
+  for (int k = 0; k < parts; k++) {
+    TexLane &L = T->lane[T->next & 1], &O = T->lane[(T->next & 1) ^ 1];
+    keep_err(tex_finish(ctx, L));                                         // (two parts in flight at most: normally a no-op, the loop below finished it)
+    const int a = lo(k), b = lo(k + 1);
+    take_up(L, k);
+    const int r = tex_submit(ctx, L, rgba + (size_t)a * n_layers, b - a, n_layers, W, H, on_device, outs + a, caps + a, out_lens + a, 0, status ? status + a : nullptr);
+    if (r != UVOL_OK) { fail_ups(); (void)tex_flush(ctx); return r; }
+    keep_err(tex_finish(ctx, O));                                         // the part before this one (of this call, or the last part of the call before)
+    T->next ^= 1;
+  }
+  if (defer) return UVOL_OK;
+  return tex_flush(ctx);
 }
 
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t W, uint32_t H,

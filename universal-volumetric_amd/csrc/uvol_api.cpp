@@ -89,7 +89,7 @@ static void async_worker(uvol_ctx *ctx) {
       l.unlock();
       (void)hipSetDevice(ctx->device);
       int rf = UVOL_OK;
-      try { rf = geo_flush(ctx); } catch (...) { rf = UVOL_E_HIP; ctx->set_error("enqueued call: out of memory on the host"); }
+      try { rf = geo_flush(ctx); const int rt = tex_flush(ctx); if (rf == UVOL_OK) rf = rt; } catch (...) { rf = UVOL_E_HIP; ctx->set_error("enqueued call: out of memory on the host"); }
       l.lock();
       if (rf != UVOL_OK && A->first_err == UVOL_OK) { A->first_err = rf; snprintf(A->err, sizeof A->err, "%s", ctx->err); }
     }
@@ -175,6 +175,7 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
+  uvol_uplink_destroy(ctx);
   geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx); png_destroy(ctx);
   for (int k = 0; k < 2; k++) { if (ctx->up_pin[k]) (void)hipHostFree(ctx->up_pin[k]); if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]); }
   for (int k = 0; k < 2; k++) if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
@@ -204,6 +205,7 @@ int uvol_trim(uvol_ctx *ctx) {
   if (!ctx) return rc;
   const int rf = geo_flush(ctx);
   const int rt = geo_trim(ctx);
+  uvol_uplink_trim(ctx);
   return rc != UVOL_OK ? rc : (rf != UVOL_OK ? rf : rt);
 }
 
@@ -301,7 +303,7 @@ static int tex_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_s
     return async_push(ctx, [ctx, r = std::move(r), o = std::move(o), c = std::move(c), n_segments, n_layers, width, height, dev, out_lens]() {
       (void)hipSetDevice(ctx->device);
       if (ctx->prm.uastc) return tex_uastc_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens);
-      return tex_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens); });
+      return tex_encode_segments(ctx, r.data(), n_segments, n_layers, width, height, dev, o.data(), c.data(), out_lens, nullptr, true); });
   } catch (...) { ctx->set_error("enqueue: out of memory on the host"); return UVOL_E_HIP; }
 }
 int uvol_encode_texture_segments_async(uvol_ctx *ctx, const uint8_t *const *rgba, int n_segments, int n_layers, uint32_t width, uint32_t height,

@@ -179,6 +179,7 @@ struct uvol_ctx {
   } *async = nullptr;
   uint8_t *dn_pin[2] = { nullptr, nullptr }; hipEvent_t dn_ev[2] = { nullptr, nullptr };      // staged downloads (uvol_download_staged)
   hipEvent_t pin_ev[2] = { nullptr, nullptr };          // uploads from uvol_host_alloc memory: one event per queued run of copies
+  struct UvolUplink *uplink = nullptr;                   // upload ring for inputs in uvol_host_alloc memory (uvol_uplink_*, below); freed by uvol_uplink_destroy
   uint8_t *up_pin[2] = { nullptr, nullptr }; size_t up_cap = 0; hipEvent_t up_ev[2] = { nullptr, nullptr }; bool up_rec[2] = { false, false };   // staged uploads (uvol_upload_staged); up_rec: a DMA out of that buffer may still be in flight
 
   void set_error(const char *fmt, ...) {
@@ -278,7 +279,8 @@ int tex_uastc_decode_segments(uvol_ctx *ctx, const uint8_t *const *files, const 
 int tex_create(uvol_ctx *ctx);
 void tex_destroy(uvol_ctx *ctx);
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
-                        bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status = nullptr);
+                        bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status = nullptr, bool defer = false);
+int tex_flush(uvol_ctx *ctx);      // completes the parts an enqueued texture call left in flight
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t w, uint32_t h,
                        bool inputs_on_device, uint8_t *out, size_t cap, size_t *out_len);
 
@@ -419,6 +421,116 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
   }
   return UVOL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Uplink (round 6): the upload ring of a context for calls whose inputs ALL lie in uvol_host_alloc (page-locked) memory - SURVEY 8(d)'s
+// boundary, "inputs resident in pinned host memory".  Such a call's uploads need no host thread: every group (geometry) / part (texture)
+// of the call gets a SLOT of the ring - a device buffer, a `ready` event and a `released` event - and the copies of ALL its groups are
+// queued on the context's own COPY STREAM when the call begins, before any kernel of the call is enqueued:
+//     copy stream :  wait(released of the slot's previous user) -> DMAs -> record(ready)
+//     lane stream :  wait(ready) -> the group's kernels -> record(released)
+// so the host link is busy from the first group's first byte to the last group's last byte whatever the host thread is waiting for in
+// between (a lane's previous group, the mid-batch read-back of geo_submit), and the next enqueued call's uploads queue up behind this
+// call's while its kernels still run.  Until round 5 the copies went on the lane's stream from inside the group's submission, 15 k
+// copies of 0.4 - 2.4 MB per 2560-frame pass in runs of 128 MB with two runs queued: the link idled whenever the host thread did
+// anything else (1458 - 1614 frames/s against 1520 - 1776 through the staging buffers, profiles/r05_final3_variant_host_inputs_2560.json).
+// The device layout MIRRORS the host layout (UvolUpPlacer): arrays that lie back to back in the caller's arena lie back to back in
+// the slot, and go over in ONE copy per contiguous run (a whole frame, or many frames) instead of one per array - the link delivers
+// 57 GB/s for copies of >= 16 MiB, 36 for 1 MiB (profiles/r05_h2d_rate.json).
+// One thread per context drives its uplink (the caller's, or the context's enqueue worker); the ring is not shared between contexts.
+// ------------------------------------------------------------------------------------------------
+struct UvolUpSlot {
+  uvol_devbuf buf;
+  hipEvent_t ready = nullptr, released = nullptr;
+  bool rel_rec = false;            // `released` has been recorded behind the kernels of the slot's current content
+  uint64_t gen = 0;                // bumped by every fill: a consumer that comes back later (the texture's alpha re-run) sees whether its bytes are still there
+};
+struct UvolUplink { hipStream_t stream = nullptr; std::vector<UvolUpSlot *> slots; size_t next = 0; };
+static inline bool uvol_uplink_enabled() { static const bool v = [] { const char *e = getenv("UVOL_UPLINK"); return !(e && *e == '0'); }(); return v; }      // UVOL_UPLINK=0 (diagnostic): round 5's in-submission copies
+// device offsets that mirror the host layout: an array that starts (almost) where its predecessor ended in host memory is placed
+// at the same distance behind it in the slot; anything else starts a new 256-byte-aligned run.  Every array keeps a 256-byte-aligned
+// device address (the kernels' vector loads), so runs are continued by 256-byte-aligned host arrays only.
+struct UvolUpPlacer {
+  size_t off = 0; uintptr_t prev_end = 0; size_t prev_dev_end = 0; bool run_ok = false;
+  size_t place(const void *src, size_t bytes) {
+    const uintptr_t s = (uintptr_t)src; size_t d;
+    if (run_ok && s >= prev_end && s - prev_end <= 4096 && (s & 255) == 0 && ((prev_dev_end + (s - prev_end)) & 255) == 0) d = prev_dev_end + (size_t)(s - prev_end);
+    else { d = (off + 255) & ~(size_t)255; run_ok = (s & 255) == 0; }
+    prev_end = s + bytes; prev_dev_end = d + bytes; off = prev_dev_end; return d;
+  }
+  size_t total() const { return (off + 255) & ~(size_t)255; }
+};
+static inline void uvol_uplink_destroy(uvol_ctx *ctx) {
+  UvolUplink *U = ctx->uplink; if (!U) return;
+  if (U->stream) { (void)hipStreamSynchronize(U->stream); }
+  for (UvolUpSlot *S : U->slots) {
+    if (S->rel_rec && S->released) (void)hipEventSynchronize(S->released);
+    if (S->buf.p) (void)hipFree(S->buf.p);
+    if (S->ready) (void)hipEventDestroy(S->ready);
+    if (S->released) (void)hipEventDestroy(S->released);
+    delete S;
+  }
+  if (U->stream) (void)hipStreamDestroy(U->stream);
+  delete U; ctx->uplink = nullptr;
+}
+// uvol_trim: the slots' device buffers go back to the device (nothing of the context is in flight)
+static inline void uvol_uplink_trim(uvol_ctx *ctx) {
+  UvolUplink *U = ctx->uplink; if (!U) return;
+  if (U->stream) (void)hipStreamSynchronize(U->stream);
+  for (UvolUpSlot *S : U->slots) { if (S->rel_rec && S->released) (void)hipEventSynchronize(S->released); S->rel_rec = false; if (S->buf.p) { (void)hipFree(S->buf.p); S->buf.p = nullptr; S->buf.cap = 0; } }
+}
+// the ring with at least `n` slots (it only grows); nullptr + error text when a stream / event cannot be created
+static inline UvolUplink *uvol_uplink(uvol_ctx *ctx, size_t n) {
+  if (!ctx->uplink) {
+    UvolUplink *U = new UvolUplink();
+    if (hipStreamCreateWithFlags(&U->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete U; ctx->set_error("uplink: copy stream creation failed"); return nullptr; }
+    ctx->uplink = U;
+  }
+  UvolUplink *U = ctx->uplink;
+  while (U->slots.size() < n) {
+    UvolUpSlot *S = new UvolUpSlot();
+    if (hipEventCreateWithFlags(&S->ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S->released, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError(); if (S->ready) (void)hipEventDestroy(S->ready); delete S; ctx->set_error("uplink: event creation failed"); return nullptr; }
+    U->slots.push_back(S);
+  }
+  return U;
+}
+// Fill the ring's next slot: `items` (sorted by dev_off, placed by UvolUpPlacer, every source in uvol_host_alloc memory) go to a buffer of
+// `total` bytes on the copy stream, behind the release of whatever the slot held; consecutive items that are contiguous on both sides
+// (gaps of the caller's alignment padding included: they lie inside the same page-locked allocation) travel as one copy of up to
+// 512 MiB.  Returns the slot (nullptr + error text on failure).  Nothing here waits for the device unless the slot's buffer has to grow.
+static inline UvolUpSlot *uvol_uplink_fill(uvol_ctx *ctx, UvolUplink *U, const std::vector<UvolUpItem> &items, size_t total) {
+  UvolUpSlot *S = U->slots[U->next % U->slots.size()]; U->next++;
+  if (total > S->buf.cap) {                                 // (re)allocation: the slot's last consumer first
+    if (S->rel_rec) { if (hipEventSynchronize(S->released) != hipSuccess) { ctx->set_error("uplink: waiting for a slot failed"); return nullptr; } S->rel_rec = false; }
+    if (hipStreamSynchronize(U->stream) != hipSuccess) { ctx->set_error("uplink: copy stream failed"); return nullptr; }
+    if (S->buf.p) { (void)hipFree(S->buf.p); S->buf.p = nullptr; S->buf.cap = 0; }
+    const size_t want = total + total / 16 + 4096;
+    if (hipMalloc(&S->buf.p, want) != hipSuccess) { (void)hipGetLastError(); S->buf.p = nullptr; ctx->set_error("uplink: %zu bytes of device memory for a slot", want); return nullptr; }
+    S->buf.cap = want;
+  }
+  if (S->rel_rec) { if (hipStreamWaitEvent(U->stream, S->released, 0) != hipSuccess) { ctx->set_error("uplink: hipStreamWaitEvent failed"); return nullptr; } S->rel_rec = false; }
+  S->gen++;
+  const size_t MAXC = (size_t)512 << 20;
+  for (size_t i = 0; i < items.size();) {
+    const UvolUpItem &a = items[i]; size_t len = a.bytes, j = i + 1;
+    for (; j < items.size(); j++) {
+      const UvolUpItem &b = items[j];
+      const uintptr_t ha = (uintptr_t)a.src + len, hb = (uintptr_t)b.src;
+      if (hb < ha || hb - ha > 4096 || b.dev_off != a.dev_off + len + (size_t)(hb - ha) || len + (hb - ha) + b.bytes > MAXC) break;
+      if (!uvol_host_pinned(a.src, len + (size_t)(hb - ha) + b.bytes)) break;      // one page-locked allocation holds both (and the padding between them)
+      len += (size_t)(hb - ha) + b.bytes;
+    }
+    if (len && hipMemcpyAsync((uint8_t *)S->buf.p + a.dev_off, a.src, len, hipMemcpyHostToDevice, U->stream) != hipSuccess) { ctx->set_error("uplink: hipMemcpyAsync failed"); return nullptr; }
+    i = j;
+  }
+  if (hipEventRecord(S->ready, U->stream) != hipSuccess) { ctx->set_error("uplink: hipEventRecord failed"); return nullptr; }
+  return S;
+}
+// consumer side: `stream` reads the slot from here on ...
+static inline int uvol_uplink_acquire(uvol_ctx *ctx, UvolUpSlot *S, hipStream_t stream) { UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, S->ready, 0)); return UVOL_OK; }
+// ... and everything queued on `stream` so far was the last of it
+static inline int uvol_uplink_release(uvol_ctx *ctx, UvolUpSlot *S, hipStream_t stream) { UVOL_HIP_CHECK(ctx, hipEventRecord(S->released, stream)); S->rel_rec = true; return UVOL_OK; }
 
 // Device -> host download of many arrays into caller-owned (pageable) memory: the mirror of uvol_upload_staged.  hipMemcpyAsync into
 // pageable memory is staged by the runtime on one thread (a decoded 1920-frame batch is 20 GB: several seconds); here consecutive arrays
