@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     ap.add_argument("--host-pinned", action="store_true", help="with --host-inputs: the input arrays lie in uvol_host_alloc (page-locked) memory")
     ap.add_argument("--host-enqueued", action="store_true", help="with --host-inputs: the passes go through the enqueue forms (uvol_*_async on host buffers, one uvol_sync)")
+    ap.add_argument("--background", choices=["off", "h2d_16m", "h2d_256m", "d2d"], default="off",
+                    help="DIAGNOSTIC (profiles/r06_uplink_forms.json): a host thread keeps copying during the timed steps - page-locked host memory to the device in copies of 16 MiB "
+                         "(the runtime's blit kernel) or 256 MiB (its SDMA engines), or device to device at about the link's rate - to see what an upload does to the encoders beside it")
     args = ap.parse_args()
 
     # `--gpus N` IS the rank count.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the two must agree; without one,
@@ -236,7 +239,7 @@ def main():
             a, b = self.gsl[gi]
             if self.host_enqueued and b > a:
                 for k in range(kk):
-                    geos[gi].start_mesh_batch(self.hf[a:b])
+                    geos[gi].start_mesh_batch(self.hf[a:b], slot=k & 1)
                 res = geos[gi].finish()
                 if any(r is None for r in res[-1]):
                     raise RuntimeError("bench: a geometry frame failed")
@@ -256,7 +259,7 @@ def main():
         def run_geo(self, gi):
             a, b = self.gsl[gi]
             if b > a:
-                out["drc_%d" % gi] = geos[gi].encode_mesh_batch(self.hf[a:b]) if self.host else geos[gi].encode_mesh_batch_dev(self.gb[gi], views=True)
+                out["drc_%d" % gi] = geos[gi].encode_mesh_batch(self.hf[a:b], views=True) if self.host else geos[gi].encode_mesh_batch_dev(self.gb[gi], views=True)
             else:
                 out["drc_%d" % gi] = []
 
@@ -265,9 +268,9 @@ def main():
             if not len(segs):
                 out["ktx2_%d" % ti] = []
             elif self.host:
-                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([self.tex_h] * len(segs))
+                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments([self.tex_h] * len(segs), views=True)
             else:
-                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev([p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]], B, args.tex_size, args.tex_size)
+                out["ktx2_%d" % ti] = texs[ti].encode_texture_segments_dev([p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]], B, args.tex_size, args.tex_size, views=True)
 
         def steps(self, k):
             """k passes.  Every stream (geometry sub-batch / texture share) runs its k passes back to back on its own host
@@ -284,8 +287,8 @@ def main():
                 if self.host_enqueued and fn == self.run_tex:            # texture share of a host-input job, enqueued like the geometry share
                     segs = range(arg, self.nseg, len(texs))
                     if len(segs):
-                        for _ in range(kk):
-                            texs[arg].start_texture_segments([self.tex_h] * len(segs))
+                        for k_ in range(kk):
+                            texs[arg].start_texture_segments([self.tex_h] * len(segs), slot=k_ & 1)
                         out["ktx2_%d" % arg] = texs[arg].finish()[-1]
                         return
                 for _ in range(kk):
@@ -331,6 +334,24 @@ def main():
     main_job = Job(F, host=args.host_inputs, host_enqueued=args.host_enqueued, pinned=args.host_pinned)
     if args.warmup:
         main_job.steps(args.warmup)
+    bg = {"stop": False, "bytes": 0, "t": 0.0}
+    if args.background != "off":
+        nb = (256 << 20) if args.background == "h2d_256m" else (16 << 20)
+        b_src = torch.empty(nb, dtype=torch.uint8).pin_memory() if args.background != "d2d" else torch.empty(nb, dtype=torch.uint8, device=dev)
+        b_dst = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
+        b_st = torch.cuda.Stream(device=dev)
+
+        def bg_loop():
+            t_ = time.perf_counter(); k_ = 0
+            while not bg["stop"]:
+                with torch.cuda.stream(b_st):
+                    for _ in range(4):
+                        b_dst[k_ & 3].copy_(b_src, non_blocking=True); k_ += 1
+                b_st.synchronize()
+                if args.background == "d2d":                    # paced to ~55 GB/s: 64 MiB every 1.2 ms
+                    time.sleep(max(0.0, k_ * nb / 55e9 - (time.perf_counter() - t_)))
+            bg["bytes"] = k_ * nb; bg["t"] = time.perf_counter() - t_
+        bg_th = threading.Thread(target=bg_loop); bg_th.start()
     set_profiling(True)
     barrier()
     t0 = time.perf_counter()
@@ -344,6 +365,8 @@ def main():
         assert total_frames == args.total_frames * args.steps, (total_frames, args.total_frames)
     barrier()
     dt = time.perf_counter() - t0
+    if args.background != "off":
+        bg["stop"] = True; bg_th.join()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -428,6 +451,8 @@ def main():
             res["roofline_mfma"] = {"bound": "mfma", "kernel": "tex.k10_sel_assign", "achieved": tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s",
                                     "frac": tops / I8_PEAK_TOPS, "avg_launch_ms": mfma_grp["total_ms"] / max(1, mfma_grp["launches"]),
                                     "ops_per_launch": mfma_grp["algo_bytes"] / max(1, mfma_grp["launches"]), "dtype": "i8 x i8 -> i32"}
+        if args.background != "off":
+            res["background"] = {"kind": args.background, "GBps": bg["bytes"] / max(bg["t"], 1e-9) / 1e9}
         res["quality"] = quality_gates(geos[0], texs[0], out, meshes_h[0], tex_h, B) if not args.only and F else None
         if args.parity_frames > 0 and F and not args.host_inputs:
             res["parity"] = parity_check(out, meshes_h, tex_h, args.parity_frames, args.only, args.mesh_order)
@@ -441,6 +466,14 @@ def main():
                 run_variants(res["variants"], args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geos, texs, keep, dev, res["ms_per_step"], F, B, V, Fc, local_rank, build_inputs, identical_meshes, dev_meshes)
             except Exception as e:                                   # the headline stands on its own
                 res["variants"]["error"] = repr(e)                  # (the variants measured before the fault stay in the line)
+            # beside `value` (inputs resident in HBM, as the bench contract prescribes): the same workload on SURVEY 8(d)'s boundary and BASELINE configs[2]'s own job
+            hi = res["variants"].get("host_inputs") or {}
+            if "pinned_enqueued" in hi:
+                res["survey_8d_boundary_frames_per_s"] = {"pinned_host_memory_enqueued": hi["pinned_enqueued"]["frames_per_s"], "pinned_host_memory_blocking": hi.get("pinned", {}).get("frames_per_s"),
+                                                          "pageable_host_memory_blocking": hi.get("frames_per_s"), "pageable_host_memory_enqueued": hi.get("enqueued_passes"),
+                                                          "link_bound": hi.get("link", {}).get("frames_per_s_the_link_allows")}
+            if "job_300" in res["variants"]:
+                res["configs2_job_300_frames_per_s"] = res["variants"]["job_300"]["frames_per_s"]
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(meshes_h[0], tex_h, B)
         print(json.dumps(res), flush=True)
@@ -488,8 +521,8 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
     note("events_off")
     set_profiling(False)
-    r = Job(F).timed(2, 0)
-    v["events_off"] = dict(r, note="headline workload without the per-group hipEvent brackets; ms_per_step with them: %.1f" % ms_step,
+    r = Job(F).timed(3, 1)
+    v["events_off"] = dict(r, note="headline workload without the per-group hipEvent brackets (3 passes after 1 warm-up); ms_per_step with them: %.1f" % ms_step,
                            events_cost_frac=ms_step / r["ms_per_pass"] - 1.0)
     # (1) small jobs (latency-bound: the serial walks of a frame do not shrink with the batch) and the 8-GPU projection of
     #     BASELINE configs[3] (1200 frames, 150 per GPU): 8 x rate(150-frame job) / rate(1200-frame job on one GPU)
@@ -539,13 +572,23 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers; "
                                                                    "one blocking call per pass and half; enqueued_passes: the same passes through uvol_*_async + uvol_sync (a pass uploads while its predecessor encodes)")
-    note("host_inputs pinned")
-    v["host_inputs"]["pinned"] = dict(Job(nh, host=True, pinned=True).timed(2, 1), note="the same with every input array in uvol_host_alloc memory: DMA from where the arrays lie, no staging copy")
     note("host_inputs enqueued")
     v["host_inputs"]["enqueued_passes"] = Job(nh, host=True, host_enqueued=True).timed(3, 1)["frames_per_s"]
+    note("host_inputs pinned")
+    v["host_inputs"]["pinned"] = dict(Job(nh, host=True, pinned=True).timed(2, 1), note="every input array in uvol_host_alloc memory, one blocking call per pass and half: the uploads of the call's groups / parts are queued "
+                                                                                         "on the context's copy stream when the call begins (uplink), nothing overlaps the last group's chain")
+    note("host_inputs pinned enqueued")
+    v["host_inputs"]["pinned_enqueued"] = dict(Job(nh, host=True, pinned=True, host_enqueued=True).timed(5, 1),
+                                               note="SURVEY 8(d)'s boundary as specified - inputs resident in PINNED host memory -> bytes in host memory - through the enqueue forms: "
+                                                    "the next pass's uploads run on the copy streams beside this pass's kernels")
+    bytes_per_frame = 12.0 * V * 2 + 8.0 * sum(len(m["uv"]) for m in meshes_h) / len(meshes_h) + 36.0 * Fc + 4.0 * args.tex_size ** 2
+    v["host_inputs"]["link"] = {"bytes_uploaded_per_frame": bytes_per_frame, "link_GBps_measured": 55.0,
+                                "frames_per_s_the_link_allows": 55.0e9 / bytes_per_frame,
+                                "note": "the C ABI takes OBJ-style separate index streams (36 bytes per face, SURVEY 8(d): 'would add 24 F'), so a frame is ~27.4 MB on the link, not the 22.4 MB of the "
+                                        "unified-index formula; 55 GB/s is what this box's link delivers for >= 16 MiB copies out of page-locked memory (profiles/r05_h2d_rate.json, r06_uplink_forms.json)"}
     # (4) decode path (BASELINE configs[4]) on this run's own output: fresh contexts (the encoders' workspaces are released first)
     note("decode")
-    drc = [bytes(x) for x in out["drc"][:480]]; ktx = list(out["ktx2"][:192])
+    drc = [bytes(x) for x in out["drc"][:480]]; ktx = [bytes(x) for x in out["ktx2"][:192]]
     drc = (drc * 4)[:1920]                                      # one call of 1920 frames (~90 MB of decode workspace each)
     for c in geos + texs:
         c.close()
@@ -637,7 +680,7 @@ def quality_gates(geo, tex, out, mesh0, tex0, B):
         pos = np.asarray(mesh0["pos"], np.float64)
         step = float((pos.max(0) - pos.min(0)).max()) / (2 ** 11 - 1)
         dist, _ = cKDTree(np.asarray(d["pos"], np.float64)).query(pos)
-        dec = tex.decode_texture_segments([out["ktx2"][0]])[0]
+        dec = tex.decode_texture_segments([bytes(out["ktx2"][0])])[0]
         src = np.stack([np.asarray(a)[::-1] for a in tex0]).astype(np.float64)
         mse = float(np.mean((src[..., :3] - dec[..., :3].astype(np.float64)) ** 2))
         return {"frame": 0, "max_pos_err": float(dist.max()), "pos_half_step_diagonal": step / 2 * 3 ** 0.5, "faces": int(d["n_faces"]),

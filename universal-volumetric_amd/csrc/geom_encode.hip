@@ -1065,7 +1065,19 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   // that consecutive enqueued calls hold want / groups calls' worth of frames on the chip (the walkers' chain is flat in the frame count:
   // throughput follows the frames in flight, profiles/r05_frames_in_flight.json) without the caller keeping more inputs resident
   static const int groups_env = [] { const char *e = getenv("UVOL_GEO_GROUPS"); const int k = e ? atoi(e) : 4; return k < 1 ? 1 : k; }();
-  const int gmax = on_device ? std::min(want, groups_env) : want;
+  // Host inputs that ALL lie in uvol_host_alloc memory travel through the uplink (below): their upload does not occupy a lane, so such a call is
+  // cut like a call on device inputs.  (Round 5 cut every host call into as many groups as the ring has lanes: consecutive enqueued calls then
+  // met lane by lane - group g of call c + 1 waited for group g of call c - and the six groups of a call ran their walkers, then their
+  // traversals, side by side, bunched: 2333 frames/s geometry alone against 5307 on device inputs, profiles/r06_uplink_forms.json.)
+  bool up_all = !on_device && uvol_uplink_enabled() && split && n >= 1;
+  for (int i = 0; i < n && up_all; i++) {
+    const uvol_mesh &m = meshes[i];
+    if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0) { up_all = false; break; }                    // (geo_submit reports the invalid frame)
+    up_all = uvol_host_pinned(m.pos, (size_t)m.n_pos * 12) && uvol_host_pinned(m.idx_pos, (size_t)m.n_faces * 12);
+    if (up_all && m.uv && m.idx_uv && m.n_uv) up_all = uvol_host_pinned(m.uv, (size_t)m.n_uv * 8) && uvol_host_pinned(m.idx_uv, (size_t)m.n_faces * 12);
+    if (up_all && m.nrm && m.idx_nrm && m.n_nrm) up_all = uvol_host_pinned(m.nrm, (size_t)m.n_nrm * 12) && uvol_host_pinned(m.idx_nrm, (size_t)m.n_faces * 12);
+  }
+  const int gmax = (on_device || up_all) ? std::min(want, groups_env) : want;
   const int groups = split ? std::max(1, std::min(gmax, n / geo_min_group())) : 1;
   // Inputs in uvol_host_alloc memory (SURVEY 8(d)'s boundary): the uploads of ALL groups of the call are queued on the context's copy
   // stream now, one uplink slot per group, before the first group's kernels are enqueued (uvol_common.hpp "Uplink").  The ring has as
@@ -1073,16 +1085,9 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   // with them the slot's release event - have been enqueued.  A frame's arrays are placed in the order of their host addresses, the
   // frames in call order: a caller that lays consecutive frames back to back in its arena gets one DMA per run of frames.
   std::vector<GeoUp> ups_pre;
-  if (!on_device && uvol_uplink_enabled() && n >= 1) {
-    bool all = true;
-    for (int i = 0; i < n && all; i++) {
-      const uvol_mesh &m = meshes[i];
-      if (!m.pos || !m.idx_pos || m.n_pos == 0 || m.n_faces == 0) { all = false; break; }                    // (geo_submit reports the invalid frame)
-      all = uvol_host_pinned(m.pos, (size_t)m.n_pos * 12) && uvol_host_pinned(m.idx_pos, (size_t)m.n_faces * 12);
-      if (all && m.uv && m.idx_uv && m.n_uv) all = uvol_host_pinned(m.uv, (size_t)m.n_uv * 8) && uvol_host_pinned(m.idx_uv, (size_t)m.n_faces * 12);
-      if (all && m.nrm && m.idx_nrm && m.n_nrm) all = uvol_host_pinned(m.nrm, (size_t)m.n_nrm * 12) && uvol_host_pinned(m.idx_nrm, (size_t)m.n_faces * 12);
-    }
-    UvolUplink *U = all ? uvol_uplink(ctx, (size_t)std::max(want, groups)) : nullptr;
+  if (up_all) {
+    const bool all = true;
+    UvolUplink *U = all ? uvol_uplink(ctx, (size_t)std::max(want + uvol_uplink_ahead(), groups)) : nullptr;
     if (all && !U) return UVOL_E_HIP;
     if (U) {
       ups_pre.resize((size_t)groups);
@@ -1126,7 +1131,7 @@ int geo_encode_batch_begin(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool o
   // this pool), and a ring longer than the groups of one call first reaches its last lane during the caller's SECOND call - here it happens
   // beside the kernels of the first.  A lane that cannot get them leaves the ring (lanes_cap).
   // (only the lanes the NEXT call of this shape will reach: a stream of small calls - one group each - allocates one lane ahead, not the whole ring at once)
-  if (split && on_device && last && groups < want) {
+  if (split && (on_device || up_all) && last && groups < want) {
     for (int j = 0; j < std::min(groups, want); j++) {
       const int k = (G->next_lane + j) % want;
       GeoLane *P = geo_lane(ctx, k);

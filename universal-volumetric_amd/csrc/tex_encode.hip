@@ -1488,7 +1488,7 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
   if (!on_device && uvol_uplink_enabled()) {
     const size_t lbytes = (size_t)W * H * 4; bool all = true;
     for (size_t i = 0; i < (size_t)n_seg * n_layers && all; i++) all = rgba[i] && uvol_host_pinned(rgba[i], lbytes);
-    UvolUplink *U = all ? uvol_uplink(ctx, (size_t)std::max(4, parts)) : nullptr;
+    UvolUplink *U = all ? uvol_uplink(ctx, (size_t)std::max(2 + uvol_uplink_ahead(), parts)) : nullptr;
     if (all && !U) return UVOL_E_HIP;
     if (U) {
       pups.resize((size_t)parts);
@@ -1529,7 +1529,9 @@ int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, in
     take_up(L, k);
     const int r = tex_submit(ctx, L, rgba + (size_t)a * n_layers, b - a, n_layers, W, H, on_device, outs + a, caps + a, out_lens + a, 0, status ? status + a : nullptr);
     if (r != UVOL_OK) { fail_ups(); (void)tex_flush(ctx); return r; }
-    keep_err(tex_finish(ctx, O));                                         // the part before this one (of this call, or the last part of the call before)
+    // the part before this one (of this call, or the last part of the call before) - but an enqueued call returns with its last TWO parts in flight:
+    // the next call's uploads are queued when it begins, and a worker that waited here for part parts - 2 reached that point after the link had run dry
+    if (!(defer && k == parts - 1)) keep_err(tex_finish(ctx, O));
     T->next ^= 1;
   }
   if (defer) return UVOL_OK;

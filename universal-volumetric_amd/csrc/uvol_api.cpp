@@ -28,6 +28,99 @@ extern "C" void uvol_host_free(void *p) {
   { std::lock_guard<std::mutex> l(g_pin_m); g_pin.erase((uintptr_t)p); }
   (void)hipHostFree(p);
 }
+// ------------------------------------------------------------------------------------------------
+// Uplink copy (uvol_common.hpp "Uplink").  Page-locked host memory is mapped into the device's address space, so the upload of a slot is
+// ONE kernel on the context's copy stream that reads the caller's arrays over the link and writes them where the encoders expect them:
+// a list of chunks of <= 256 KiB, one workgroup per chunk (grid-stride), 16-byte loads with eight in flight per lane.  A few dozen
+// workgroups keep the link full (its bandwidth-delay product is ~100 KB); they spend their time waiting, not issuing.
+// Measured (round 6, profiles/r06_uplink_forms.json) against the runtime's own copies on the same copy stream: hipMemcpyAsync of the
+// >= 84 MB runs of a mirrored layout goes to the SDMA engines, which delivered 22 GB/s per stream beside the encoders' kernels (36 GB/s for
+// both contexts together, 1295 frames/s); copies of <= 2.4 MB go through the runtime's blit kernel, one launch per array (1604).
+// UVOL_UPLINK_DMA=1 (diagnostic) keeps the runtime's copies.
+// ------------------------------------------------------------------------------------------------
+#define UPLINK_CHUNK ((size_t)256 << 10)
+__global__ void __launch_bounds__(256) k_uplink_copy(const UvolUpChunk *list, unsigned n_chunks) {
+  for (unsigned c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const UvolUpChunk ch = list[c];
+    const uint8_t *src = ch.src; uint8_t *dst = ch.dst; const size_t n = (size_t)ch.bytes;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+      const uint4 *s4 = (const uint4 *)src; uint4 *d4 = (uint4 *)dst; const size_t n4 = n >> 4;
+      size_t i = threadIdx.x;
+      for (; i + 7 * 256 < n4; i += 8 * 256) {              // eight independent 16-byte reads over the link per lane
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = s4[i + (size_t)k * 256];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d4[i + (size_t)k * 256] = v[k];
+      }
+      for (; i < n4; i += 256) d4[i] = s4[i];
+      for (size_t b = (n4 << 4) + threadIdx.x; b < n; b += 256) dst[b] = src[b];
+    } else if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) {
+      const uint32_t *s1 = (const uint32_t *)src; uint32_t *d1 = (uint32_t *)dst; const size_t n1 = n >> 2;
+      for (size_t i = threadIdx.x; i < n1; i += 256) d1[i] = s1[i];
+      for (size_t b = (n1 << 2) + threadIdx.x; b < n; b += 256) dst[b] = src[b];
+    } else {
+      for (size_t b = threadIdx.x; b < n; b += 256) dst[b] = src[b];
+    }
+  }
+}
+static inline bool uplink_dma() { static const bool v = [] { const char *e = getenv("UVOL_UPLINK_KERNEL"); return !(e && *e == '1'); }(); return v; }      // UVOL_UPLINK_KERNEL=1 (diagnostic): the gather kernel instead of the runtime's copies
+static inline unsigned uplink_wgs() { static const unsigned v = [] { const char *e = getenv("UVOL_UPLINK_WGS"); const int k = e ? atoi(e) : 0; return (unsigned)(k >= 1 && k <= 4096 ? k : 64); }(); return v; }
+UvolUpSlot *uvol_uplink_fill(uvol_ctx *ctx, UvolUplink *U, const std::vector<UvolUpItem> &items, size_t total) {
+  UvolUpSlot *S = U->slots[U->next % U->slots.size()]; U->next++;
+  if (total > S->buf.cap) {                                 // (re)allocation: the slot's last consumer first
+    if (S->rel_rec) { if (hipEventSynchronize(S->released) != hipSuccess) { ctx->set_error("uplink: waiting for a slot failed"); return nullptr; } S->rel_rec = false; }
+    if (hipStreamSynchronize(U->stream) != hipSuccess) { ctx->set_error("uplink: copy stream failed"); return nullptr; }
+    if (S->buf.p) { (void)hipFree(S->buf.p); S->buf.p = nullptr; S->buf.cap = 0; }
+    const size_t want = total + total / 16 + 4096;
+    if (hipMalloc(&S->buf.p, want) != hipSuccess) { (void)hipGetLastError(); S->buf.p = nullptr; ctx->set_error("uplink: %zu bytes of device memory for a slot", want); return nullptr; }
+    S->buf.cap = want;
+  }
+  // the slot's copy list lives in page-locked memory until its device copy has been made: the previous fill of this slot has long run
+  // (its consumers' kernels have been enqueued behind it), the wait is a formality
+  if (S->filled && hipEventSynchronize(S->ready) != hipSuccess) { ctx->set_error("uplink: waiting for a slot's previous fill failed"); return nullptr; }
+  if (S->rel_rec) { if (hipStreamWaitEvent(U->stream, S->released, 0) != hipSuccess) { ctx->set_error("uplink: hipStreamWaitEvent failed"); return nullptr; } S->rel_rec = false; }
+  S->gen++;
+  if (uplink_dma()) {
+    // consecutive items that are contiguous on both sides (gaps of the caller's alignment padding included) travel as one copy of up to 512 MiB
+    const size_t MAXC = (size_t)512 << 20;
+    for (size_t i = 0; i < items.size();) {
+      const UvolUpItem &a = items[i]; size_t len = a.bytes, j = i + 1;
+      for (; j < items.size(); j++) {
+        const UvolUpItem &b = items[j];
+        const uintptr_t ha = (uintptr_t)a.src + len, hb = (uintptr_t)b.src;
+        if (hb < ha || hb - ha > 4096 || b.dev_off != a.dev_off + len + (size_t)(hb - ha) || len + (hb - ha) + b.bytes > MAXC) break;
+        if (!uvol_host_pinned(a.src, len + (size_t)(hb - ha) + b.bytes)) break;      // one page-locked allocation holds both (and the padding between them)
+        len += (size_t)(hb - ha) + b.bytes;
+      }
+      if (len && hipMemcpyAsync((uint8_t *)S->buf.p + a.dev_off, a.src, len, hipMemcpyHostToDevice, U->stream) != hipSuccess) { ctx->set_error("uplink: hipMemcpyAsync failed"); return nullptr; }
+      i = j;
+    }
+  } else {
+    size_t nch = 0; for (const UvolUpItem &it : items) nch += (it.bytes + UPLINK_CHUNK - 1) / UPLINK_CHUNK;
+    if (nch > 0xffffffffull) { ctx->set_error("uplink: copy list too long"); return nullptr; }
+    if (nch > S->list_cap) {
+      if (S->list_host) { (void)hipHostFree(S->list_host); S->list_host = nullptr; } S->list_cap = 0;
+      if (S->list_dev.p) { (void)hipFree(S->list_dev.p); S->list_dev.p = nullptr; S->list_dev.cap = 0; }
+      const size_t cap = nch + nch / 4 + 64;
+      if (hipHostMalloc((void **)&S->list_host, cap * sizeof(UvolUpChunk), hipHostMallocDefault) != hipSuccess || hipMalloc(&S->list_dev.p, cap * sizeof(UvolUpChunk)) != hipSuccess) {
+        (void)hipGetLastError(); if (S->list_host) { (void)hipHostFree(S->list_host); S->list_host = nullptr; } ctx->set_error("uplink: copy list allocation failed"); return nullptr; }
+      S->list_cap = cap; S->list_dev.cap = cap * sizeof(UvolUpChunk);
+    }
+    size_t c = 0;
+    for (const UvolUpItem &it : items) for (size_t o = 0; o < it.bytes; o += UPLINK_CHUNK)
+      S->list_host[c++] = UvolUpChunk{ (const uint8_t *)it.src + o, (uint8_t *)S->buf.p + it.dev_off + o, (unsigned long long)std::min(UPLINK_CHUNK, it.bytes - o) };
+    if (nch) {
+      if (hipMemcpyAsync(S->list_dev.p, S->list_host, nch * sizeof(UvolUpChunk), hipMemcpyHostToDevice, U->stream) != hipSuccess) { ctx->set_error("uplink: copy list upload failed"); return nullptr; }
+      hipLaunchKernelGGL(k_uplink_copy, dim3((unsigned)std::min<size_t>(nch, uplink_wgs())), dim3(256), 0, U->stream, (const UvolUpChunk *)S->list_dev.p, (unsigned)nch);
+      if (hipGetLastError() != hipSuccess) { ctx->set_error("uplink: copy kernel launch failed"); return nullptr; }
+    }
+  }
+  if (hipEventRecord(S->ready, U->stream) != hipSuccess) { ctx->set_error("uplink: hipEventRecord failed"); return nullptr; }
+  S->filled = true;
+  return S;
+}
+
 hipError_t uvol_make_stream(uvol_ctx *ctx, hipStream_t *out) {
 #ifndef HIPEMU
   // cu_mod == -1: the CUs with per-XCD ordinal in [lo, hi), cu_residues = lo << 8 | hi.  Mask bit i is CU ordinal i / 8 of XCD i % 8

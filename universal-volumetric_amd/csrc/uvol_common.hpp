@@ -439,13 +439,19 @@ static inline int uvol_upload_staged(uvol_ctx *ctx, uint8_t *dev_base, const std
 // 57 GB/s for copies of >= 16 MiB, 36 for 1 MiB (profiles/r05_h2d_rate.json).
 // One thread per context drives its uplink (the caller's, or the context's enqueue worker); the ring is not shared between contexts.
 // ------------------------------------------------------------------------------------------------
+struct UvolUpChunk { const uint8_t *src; uint8_t *dst; unsigned long long bytes; };      // one workgroup-sized piece of a slot's copy list (k_uplink_copy)
 struct UvolUpSlot {
   uvol_devbuf buf;
+  uvol_devbuf list_dev; UvolUpChunk *list_host = nullptr; size_t list_cap = 0; bool filled = false;      // the copy list: written into page-locked memory, read by the kernel from its device copy
   hipEvent_t ready = nullptr, released = nullptr;
   bool rel_rec = false;            // `released` has been recorded behind the kernels of the slot's current content
   uint64_t gen = 0;                // bumped by every fill: a consumer that comes back later (the texture's alpha re-run) sees whether its bytes are still there
 };
 struct UvolUplink { hipStream_t stream = nullptr; std::vector<UvolUpSlot *> slots; size_t next = 0; };
+// slots beyond one per lane (UVOL_UPLINK_AHEAD, default 2): with exactly one slot per lane a group's upload could not start before the lane's
+// previous group had released its slot, and the lane idled while its inputs crossed the link; the extra slots let the link run that many
+// groups ahead of the lanes (a slot of 640 frames is 6.8 GB)
+static inline int uvol_uplink_ahead() { static const int v = [] { const char *e = getenv("UVOL_UPLINK_AHEAD"); const int k = e ? atoi(e) : 2; return k < 0 ? 0 : (k > 16 ? 16 : k); }(); return v; }
 static inline bool uvol_uplink_enabled() { static const bool v = [] { const char *e = getenv("UVOL_UPLINK"); return !(e && *e == '0'); }(); return v; }      // UVOL_UPLINK=0 (diagnostic): round 5's in-submission copies
 // device offsets that mirror the host layout: an array that starts (almost) where its predecessor ended in host memory is placed
 // at the same distance behind it in the slot; anything else starts a new 256-byte-aligned run.  Every array keeps a 256-byte-aligned
@@ -466,6 +472,8 @@ static inline void uvol_uplink_destroy(uvol_ctx *ctx) {
   for (UvolUpSlot *S : U->slots) {
     if (S->rel_rec && S->released) (void)hipEventSynchronize(S->released);
     if (S->buf.p) (void)hipFree(S->buf.p);
+    if (S->list_dev.p) (void)hipFree(S->list_dev.p);
+    if (S->list_host) (void)hipHostFree(S->list_host);
     if (S->ready) (void)hipEventDestroy(S->ready);
     if (S->released) (void)hipEventDestroy(S->released);
     delete S;
@@ -496,37 +504,9 @@ static inline UvolUplink *uvol_uplink(uvol_ctx *ctx, size_t n) {
   return U;
 }
 // Fill the ring's next slot: `items` (sorted by dev_off, placed by UvolUpPlacer, every source in uvol_host_alloc memory) go to a buffer of
-// `total` bytes on the copy stream, behind the release of whatever the slot held; consecutive items that are contiguous on both sides
-// (gaps of the caller's alignment padding included: they lie inside the same page-locked allocation) travel as one copy of up to
-// 512 MiB.  Returns the slot (nullptr + error text on failure).  Nothing here waits for the device unless the slot's buffer has to grow.
-static inline UvolUpSlot *uvol_uplink_fill(uvol_ctx *ctx, UvolUplink *U, const std::vector<UvolUpItem> &items, size_t total) {
-  UvolUpSlot *S = U->slots[U->next % U->slots.size()]; U->next++;
-  if (total > S->buf.cap) {                                 // (re)allocation: the slot's last consumer first
-    if (S->rel_rec) { if (hipEventSynchronize(S->released) != hipSuccess) { ctx->set_error("uplink: waiting for a slot failed"); return nullptr; } S->rel_rec = false; }
-    if (hipStreamSynchronize(U->stream) != hipSuccess) { ctx->set_error("uplink: copy stream failed"); return nullptr; }
-    if (S->buf.p) { (void)hipFree(S->buf.p); S->buf.p = nullptr; S->buf.cap = 0; }
-    const size_t want = total + total / 16 + 4096;
-    if (hipMalloc(&S->buf.p, want) != hipSuccess) { (void)hipGetLastError(); S->buf.p = nullptr; ctx->set_error("uplink: %zu bytes of device memory for a slot", want); return nullptr; }
-    S->buf.cap = want;
-  }
-  if (S->rel_rec) { if (hipStreamWaitEvent(U->stream, S->released, 0) != hipSuccess) { ctx->set_error("uplink: hipStreamWaitEvent failed"); return nullptr; } S->rel_rec = false; }
-  S->gen++;
-  const size_t MAXC = (size_t)512 << 20;
-  for (size_t i = 0; i < items.size();) {
-    const UvolUpItem &a = items[i]; size_t len = a.bytes, j = i + 1;
-    for (; j < items.size(); j++) {
-      const UvolUpItem &b = items[j];
-      const uintptr_t ha = (uintptr_t)a.src + len, hb = (uintptr_t)b.src;
-      if (hb < ha || hb - ha > 4096 || b.dev_off != a.dev_off + len + (size_t)(hb - ha) || len + (hb - ha) + b.bytes > MAXC) break;
-      if (!uvol_host_pinned(a.src, len + (size_t)(hb - ha) + b.bytes)) break;      // one page-locked allocation holds both (and the padding between them)
-      len += (size_t)(hb - ha) + b.bytes;
-    }
-    if (len && hipMemcpyAsync((uint8_t *)S->buf.p + a.dev_off, a.src, len, hipMemcpyHostToDevice, U->stream) != hipSuccess) { ctx->set_error("uplink: hipMemcpyAsync failed"); return nullptr; }
-    i = j;
-  }
-  if (hipEventRecord(S->ready, U->stream) != hipSuccess) { ctx->set_error("uplink: hipEventRecord failed"); return nullptr; }
-  return S;
-}
+// `total` bytes on the copy stream, behind the release of whatever the slot held.  Returns the slot (nullptr + error text on failure).
+// Nothing here waits for the device unless the slot's buffer has to grow.  (uvol_api.cpp: the copy is ONE gather kernel per slot.)
+UvolUpSlot *uvol_uplink_fill(uvol_ctx *ctx, UvolUplink *U, const std::vector<UvolUpItem> &items, size_t total);
 // consumer side: `stream` reads the slot from here on ...
 static inline int uvol_uplink_acquire(uvol_ctx *ctx, UvolUpSlot *S, hipStream_t stream) { UVOL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, S->ready, 0)); return UVOL_OK; }
 // ... and everything queued on `stream` so far was the last of it

@@ -183,13 +183,14 @@ class Codec:
     def encode_mesh(self, pos, idx_pos, uv=None, idx_uv=None, nrm=None, idx_nrm=None) -> bytes:
         return self.encode_mesh_batch([dict(pos=pos, idx_pos=idx_pos, uv=uv, idx_uv=idx_uv, nrm=nrm, idx_nrm=idx_nrm)])[0]
 
-    def encode_mesh_batch(self, frames, raise_on_error=True):
-        """frames: list of dicts(pos, idx_pos[, uv, idx_uv, nrm, idx_nrm]) of host arrays -> list of .drc bytes."""
+    def encode_mesh_batch(self, frames, raise_on_error=True, views=False):
+        """frames: list of dicts(pos, idx_pos[, uv, idx_uv, nrm, idx_nrm]) of host arrays -> list of .drc bytes (views=True: numpy views
+        of this codec's output buffers, valid until the next call)."""
         n = len(frames)
         meshes = (Mesh * n)(); keep = []
         for i, f in enumerate(frames):
             m, k = self._mesh_host(**f); meshes[i] = m; keep.append(k)
-        return self._run_batch(self.L.uvol_encode_mesh_batch, meshes, n, raise_on_error)
+        return self._run_batch(self.L.uvol_encode_mesh_batch, meshes, n, raise_on_error, views)
 
     def encode_mesh_batch_dev(self, meshes, raise_on_error=True, views=False):
         """meshes: ctypes array of Mesh holding DEVICE pointers (inputs resident in HBM).  views=True: numpy views of this
@@ -259,19 +260,27 @@ class Codec:
         return nf.value, mv.value
 
     # ---- enqueue form (uvol_*_async + uvol_sync): start_* record a call, finish() completes all of them in order ----
-    def start_mesh_batch(self, frames):
-        """Enqueues uvol_encode_mesh_batch_async for host frames; the result arrives with finish()."""
+    def start_mesh_batch(self, frames, slot=None):
+        """Enqueues uvol_encode_mesh_batch_async for host frames; the result arrives with finish().  slot=None: fresh output buffers, finish()
+        returns `bytes`; slot=k: the output buffers of slot k are re-used by every call with that slot and finish() returns numpy views into
+        them (two slots let consecutive enqueued calls overlap without a buffer set - and its page faults - per call)."""
         n = len(frames)
         meshes = (Mesh * n)(); keep = []
         for i, f in enumerate(frames):
             m, k = self._mesh_host(**f); meshes[i] = m; keep.append(k)
-        caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)(); bufs = []
+        caps = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); st = (C.c_int * n)(); outs = (C.c_void_p * n)()
+        bufs = [] if slot is None else self.__dict__.setdefault("_slot_bufs", {}).setdefault(("host", slot), [])
+        while len(bufs) < n:
+            bufs.append(np.empty(0, dtype=np.uint8))
         for i in range(n):
-            cap = self.L.uvol_mesh_bound(C.byref(meshes[i])); bufs.append(np.empty(cap, dtype=np.uint8)); caps[i] = cap; outs[i] = bufs[i].ctypes.data
+            cap = self.L.uvol_mesh_bound(C.byref(meshes[i]))
+            if bufs[i].size < cap:
+                bufs[i] = np.empty(cap, dtype=np.uint8)
+            caps[i] = cap; outs[i] = bufs[i].ctypes.data
         rc = self.L.uvol_encode_mesh_batch_async(self.h, meshes, n, outs, caps, lens, st)
         if rc != UVOL_OK:
             raise UvolError(f"encode_mesh_batch_async rc={rc}: {self.error()}")
-        self._pending = getattr(self, "_pending", []) + [("mesh", n, bufs, lens, st, keep, meshes)]
+        self._pending = getattr(self, "_pending", []) + [("mesh" if slot is None else "mesh_views", n, bufs, lens, st, keep, meshes)]
 
     def start_mesh_batch_dev(self, meshes, slot=0):
         """Enqueues uvol_encode_mesh_batch_dev_async for a ctypes array of Mesh holding DEVICE pointers.  The output buffers of `slot`
@@ -293,19 +302,29 @@ class Codec:
             raise UvolError(f"encode_mesh_batch_dev_async rc={rc}: {self.error()}")
         self._pending = getattr(self, "_pending", []) + [("mesh_views", n, bufs, lens, st, (caps, outs), meshes)]
 
-    def start_texture_segments(self, segments):
-        """Enqueues uvol_encode_texture_segments_async for host segments."""
+    def _tex_bufs(self, slot, nseg, cap):
+        """Output buffers of texture slot `slot` (kept between calls: no fresh pages to fault in per batch)."""
+        bufs = self.__dict__.setdefault("_slot_bufs", {}).setdefault(("tex", slot), [])
+        while len(bufs) < nseg:
+            bufs.append(np.empty(0, dtype=np.uint8))
+        for i in range(nseg):
+            if bufs[i].size < cap:
+                bufs[i] = np.empty(cap, dtype=np.uint8)
+        return bufs
+
+    def start_texture_segments(self, segments, slot=None):
+        """Enqueues uvol_encode_texture_segments_async for host segments (slot: as in start_mesh_batch)."""
         arrs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in seg] for seg in segments]
         h, w = arrs[0][0].shape[:2]; nl = len(arrs[0]); nseg = len(arrs)
         flat = [a for seg in arrs for a in seg]
         ptrs = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
         cap = self.L.uvol_texture_bound(w, h, nl)
-        bufs = [np.empty(cap, dtype=np.uint8) for _ in range(nseg)]
-        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
+        bufs = [np.empty(cap, dtype=np.uint8) for _ in range(nseg)] if slot is None else self._tex_bufs(slot, nseg, cap)
+        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs[:nseg]]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
         rc = self.L.uvol_encode_texture_segments_async(self.h, ptrs, nseg, nl, w, h, outs, caps, lens)
         if rc != UVOL_OK:
             raise UvolError(f"encode_texture_segments_async rc={rc}: {self.error()}")
-        self._pending = getattr(self, "_pending", []) + [("tex", nseg, bufs, lens, None, flat, ptrs)]
+        self._pending = getattr(self, "_pending", []) + [("tex" if slot is None else "tex_views", nseg, bufs, lens, None, flat, ptrs)]
 
     def trim(self):
         """uvol_trim: completes the context's work and gives its geometry workspaces back to the device (streams stay)."""
@@ -321,6 +340,8 @@ class Codec:
         for kind, n, bufs, lens, st, _, _ in pend:
             if kind == "mesh_views":
                 res.append([(bufs[i][:lens[i]] if st[i] == UVOL_OK else None) for i in range(n)])
+            elif kind == "tex_views":
+                res.append([(bufs[i][:lens[i]] if lens[i] else None) for i in range(n)])
             else:
                 res.append([(bufs[i][:lens[i]].tobytes() if ((st is None or st[i] == UVOL_OK) and lens[i]) else None) for i in range(n)])
         if rc != UVOL_OK:
@@ -370,20 +391,21 @@ class Codec:
         ptrs = (C.c_void_p * n)(*[int(p) for p in dev_ptrs])
         return self._run_tex(self.L.uvol_encode_texture_segment_dev, ptrs, n, width, height)
 
-    def encode_texture_segments(self, segments):
-        """segments: list of lists of HxWx4 uint8 arrays (same size, same layer count) -> list of .ktx2 bytes (one batched call)."""
+    def encode_texture_segments(self, segments, views=False):
+        """segments: list of lists of HxWx4 uint8 arrays (same size, same layer count) -> list of .ktx2 bytes (one batched call;
+        views=True: numpy views of this codec's output buffers, valid until the next call)."""
         arrs = [[np.ascontiguousarray(a, dtype=np.uint8) for a in seg] for seg in segments]
         h, w = arrs[0][0].shape[:2]; nl = len(arrs[0])
         flat = [a for seg in arrs for a in seg]
         if any(len(seg) != nl for seg in arrs) or any(a.shape != (h, w, 4) for a in flat):
             raise ValueError("all segments must have the same layer count and HxWx4 size")
         ptrs = (C.c_void_p * len(flat))(*[a.ctypes.data for a in flat])
-        return self._run_tex_batch(self.L.uvol_encode_texture_segments, ptrs, len(arrs), nl, w, h)
+        return self._run_tex_batch(self.L.uvol_encode_texture_segments, ptrs, len(arrs), nl, w, h, views)
 
-    def encode_texture_segments_dev(self, dev_ptrs, n_layers, width, height):
+    def encode_texture_segments_dev(self, dev_ptrs, n_layers, width, height, views=False):
         """dev_ptrs: flat list of n_segments*n_layers device pointers."""
         ptrs = (C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs])
-        return self._run_tex_batch(self.L.uvol_encode_texture_segments_dev, ptrs, len(dev_ptrs) // n_layers, n_layers, width, height)
+        return self._run_tex_batch(self.L.uvol_encode_texture_segments_dev, ptrs, len(dev_ptrs) // n_layers, n_layers, width, height, views)
 
     def encode_texture_segments_status(self, segments, caps=None):
         """Per-segment results (uvol_encode_texture_segments_st): -> (list of .ktx2 bytes or None, list of status codes).  caps: optional
@@ -423,14 +445,14 @@ class Codec:
             raise UvolError(f"transcode_texture_segments_st rc={rc}: {self.error()}")
         return [outs[i] if st[i] == UVOL_OK else None for i in range(n)], list(st)
 
-    def _run_tex_batch(self, fn, ptrs, nseg, nl, w, h):
+    def _run_tex_batch(self, fn, ptrs, nseg, nl, w, h, views=False):
         cap = self.L.uvol_texture_bound(w, h, nl)
-        bufs = [np.empty(cap, dtype=np.uint8) for _ in range(nseg)]
-        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
+        bufs = self._tex_bufs("blocking", nseg, cap)
+        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs[:nseg]]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
         rc = fn(self.h, ptrs, nseg, nl, w, h, outs, caps, lens)
         if rc != UVOL_OK:
             raise UvolError(f"encode_texture_segments rc={rc}: {self.error()}")
-        return [bufs[i][:lens[i]].tobytes() for i in range(nseg)]
+        return [(bufs[i][:lens[i]] if views else bufs[i][:lens[i]].tobytes()) for i in range(nseg)]
 
     def _run_tex(self, fn, ptrs, n, w, h):
         cap = self.L.uvol_texture_bound(w, h, n)
