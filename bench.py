@@ -407,13 +407,13 @@ def main():
                 a["launches"] += g["launches"]; a["total_ms"] += g["total_ms"]; a["algo_bytes"] += g["algo_bytes"]
         groups = sorted(tg.values(), key=lambda g: -g["total_ms"])
         mfma_grp = tg.get("tex.k10_sel_assign")                   # sub-scope of tex.k10_selector_codebook; its work field counts integer ops, not bytes
-        # dominant kernel: the longest group of the CRITICAL PATH, i.e. of the geometry stream (its groups sum to ~95 % of a step;
-        # the texture stream runs beside it and is idle a third of the time).  With --only tex the longest texture group stands in.
-        cand = [g for g in groups if g["name"].startswith("geo.")] or [g for g in groups if g["name"] != "tex.k10_sel_assign"]
+        # dominant kernel: the group with the largest total time over ALL groups of both contexts (only the sub-scope
+        # tex.k10_sel_assign, which is counted inside tex.k10_selector_codebook, is not a candidate)
+        cand = [g for g in groups if g["name"] != "tex.k10_sel_assign"]
         dom = cand[0]
         # frames one launch of that group processes: a geometry call is cut into groups on the context's lanes (each its own launch), a
         # texture call is one launch per stage
-        units = max(1.0, F * args.steps / max(1, dom["launches"]))
+        units = max(1.0, (F if dom["name"].startswith("geo.") else nseg * B) * args.steps / max(1, dom["launches"]))
         avg_ms = dom["total_ms"] / max(1, dom["launches"])
         achieved = algo_per_frame * units / (avg_ms * 1e-3) / 1e9
         workload = ("BASELINE configs[3] shape: ONE job of %d frames split over %d rank(s) by whole texture segments (rank 0: %d frames)" % (args.total_frames, world, F)) if strong else \

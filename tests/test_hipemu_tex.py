@@ -611,3 +611,41 @@ def test_hipemu_uplink_pinned_inputs_groups_parts_and_slot_reuse(oracle, hipemu_
     for extra in ({}, {"UVOL_UPLINK": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_TEX_PART="1", UVOL_GEO_MIN_GROUP="1", **extra), capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0 and "uplink ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_hipemu_advice_r5_status_forms_and_crafted_headers(oracle, hipemu_lib):
+    """ADVICE r5.  (1) uvol_transcode_texture_segments_st: an ETC1S file WITH alpha slices in an otherwise opaque batch (what this encoder's own
+    per-segment alpha re-run writes) no longer fails every ETC1S file of the call - files are batched by slice layout, the opaque targets
+    (ETC1, BC1) refuse the alpha file in its own slot.  (2) a crafted 150-byte Zstandard-supercompressed UASTC header that claims 64 layers of
+    16384^2 texels (17 GB) allocates nothing: uvol_ktx2_info reports the header's sizes without inflating, the decoders refuse the file in its
+    slot and the process lives."""
+    import synth, uvol
+    cd = uvol.Codec(lib_path=hipemu_lib); cu = uvol.Codec(lib_path=hipemu_lib, uastc=1)
+    op1 = synth.texture_sequence(2, size=36, seed=5); op2 = synth.texture_sequence(2, size=36, seed=6); al = _alpha_sequence(2, 36, 2)
+    f1, f2, fa = cd.encode_texture_segment(op1), cd.encode_texture_segment(op2), cd.encode_texture_segment(al)
+    assert oracle.ktx2_decode(fa).has_alpha == 1 and oracle.ktx2_decode(f1).has_alpha == 0
+    files = [f1, fa, f2]
+    outs, st = cd.transcode_texture_segments_status(files, "rgba32")
+    assert st == [uvol.UVOL_OK] * 3
+    for f, o in zip(files, outs):
+        want = oracle.ktx2_decode(f)
+        assert all(np.array_equal(o[l], want.images[l]) for l in range(2))
+    for target in ("etc1", "bc1"):
+        outs, st = cd.transcode_texture_segments_status(files, target)
+        assert st == [uvol.UVOL_OK, uvol.UVOL_E_UNSUPPORTED, uvol.UVOL_OK], target
+        assert outs[1] is None
+    assert np.array_equal(cd.transcode_texture_segments_status(files, "etc1")[0][0], cd.transcode_texture_segments_etc1([f1])[0])
+    for target in ("etc2_rgba", "bc7", "bc3"):                                 # the targets that carry alpha take all three
+        outs, st = cd.transcode_texture_segments_status(files, target)
+        assert st == [uvol.UVOL_OK] * 3, target
+    # (2) the crafted header: a real UASTC file's first 150 bytes with scheme 2 and huge sizes
+    plain = bytearray(cu.encode_texture_segment(synth.texture_sequence(2, size=64, seed=4))[:160])
+    W = H = 16384; L = 64; need = L * (W // 4) * (H // 4) * 16
+    plain[12 + 8:12 + 12] = W.to_bytes(4, "little"); plain[12 + 12:12 + 16] = H.to_bytes(4, "little"); plain[12 + 20:12 + 24] = L.to_bytes(4, "little")
+    plain[12 + 32:12 + 36] = (2).to_bytes(4, "little")                           # supercompressionScheme = Zstandard
+    plain[80:88] = (120).to_bytes(8, "little"); plain[88:96] = (30).to_bytes(8, "little"); plain[96:104] = need.to_bytes(8, "little")
+    crafted = bytes(plain[:150])
+    assert cu.ktx2_info(crafted) == (W, H, L)                                     # header fields only
+    outs, st = cu.transcode_texture_segments_status([crafted], "rgba32", shape=(2, 64, 64))
+    assert st[0] != uvol.UVOL_OK and outs[0] is None
+    cd.close(); cu.close()

@@ -192,25 +192,30 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
   UVOL_G(uint8_t) out = UVOL_TO_G(uint8_t, J.out); uint8_t *outg = J.out;
   const int dz = UVOL_LANE_ZERO();                      // (keeps the prefetched stream word in a vector register until it is consumed)
   unsigned long long bb = 0; uint32_t bc = 0, iw = 0;
-  uint32_t wnext = zw[dz];
   int err = 0;
   uint32_t opos = 0, flushed = 0;
   unsigned long long ad_a = 0, ad_p = 0;                // this lane's share of the Adler-32 sums
   uint32_t pend = 0, npend = 0;                         // literals not in the ring yet: lane k holds the k-th, they end at opos
 #define INF_PEND_FLUSH() do { if (npend) { if ((uint32_t)lane < npend) ring[(opos - npend + (uint32_t)lane) & (INF_WIN - 1u)] = (uint8_t)pend; npend = 0; } } while (0)
-#define INF_REFILL() do { if (bc <= 32u) { bb |= (unsigned long long)(uint32_t)UVOL_READFIRST(wnext) << bc; bc += 32u; iw++; wnext = zw[(iw < nw ? iw : nw) + (uint32_t)dz]; } } while (0)
+  // words of the stream; behind its last byte the decoder sees ZEROS, whatever the device buffer holds there (the padding behind a stream is
+  // never uploaded - a truncated stream decoded stale bytes of an earlier batch until a check caught it)
+  const uint32_t tail_mask = (zlen & 3u) ? ((1u << (8u * (zlen & 3u))) - 1u) : 0xffffffffu;
+#define INF_WORD(i_) ((i_) < nw ? (zw[(i_) + (uint32_t)dz] & ((i_) + 1u == nw ? tail_mask : 0xffffffffu)) : 0u)
+#define INF_REFILL() do { if (bc <= 32u) { bb |= (unsigned long long)(uint32_t)UVOL_READFIRST(wnext) << bc; bc += 32u; iw++; wnext = INF_WORD(iw); } } while (0)
 #define INF_BITS(n) ((uint32_t)(bb & ((1ull << (n)) - 1ull)))
 #define INF_DROP(n) do { bb >>= (n); bc -= (n); } while (0)
   // complete KiB of the ring -> HBM (lane = 16 bytes); the ring never holds more than 1 KiB + one token that has not left
 #define INF_FLUSH() do { while (opos - flushed >= 1024u) { UVOL_WAVE_SYNC(); \
       const uint4 v_ = *reinterpret_cast<const uint4 *>(ring + ((flushed + 16u * (uint32_t)lane) & (INF_WIN - 1u))); \
       *reinterpret_cast<uint4 *>(outg + flushed + 16u * (uint32_t)lane) = v_; inf_adler16(v_, flushed + 16u * (uint32_t)lane, ad_a, ad_p); flushed += 1024u; } } while (0)
+  uint32_t wnext = INF_WORD(0u);
   INF_REFILL();
   { const uint32_t cmf = INF_BITS(8), flg = (uint32_t)(bb >> 8) & 255u; INF_DROP(16);
     if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) err = -1; }
   bool last = false;
   while (!last && !err) {
     __syncthreads();                                     // (the tables of the block before are not read any more)
+    if (iw > nw + 1u) { err = -8; break; }               // the stream ended inside the block before (a run of empty non-final blocks terminates here)
     INF_REFILL();
     last = (bb & 1ull) != 0; const uint32_t type = (uint32_t)(bb >> 1) & 3u; INF_DROP(3);
     if (type == 0u) {
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(64) k_inflate(InflJob *jobs, PngJob *pj, uint3
         opos += n; p += n; len -= n;
         INF_FLUSH();
       }
-      iw = p / 4u; bb = 0; bc = 0; wnext = zw[(iw < nw ? iw : nw) + (uint32_t)dz]; INF_REFILL(); INF_DROP(8u * (p & 3u));
+      iw = p / 4u; bb = 0; bc = 0; wnext = INF_WORD(iw); INF_REFILL(); INF_DROP(8u * (p & 3u));
       continue;
     }
     if (type == 3u) { err = -2; break; }
@@ -372,7 +377,7 @@ __global__ void __launch_bounds__(64) k_png_statuses(const PngJob *jobs, int32_t
 // ================================================================================================
 // host side
 // ================================================================================================
-struct PngState { uvol_devbuf raw, jobs; uvol_devbuf rgba[2]; std::vector<PngJob> hjobs; hipStream_t stream = nullptr; hipEvent_t done[2] = { nullptr, nullptr }; bool pending[2] = { false, false };
+struct PngState { uvol_devbuf raw, jobs; uvol_devbuf rgba[2]; std::vector<PngJob> hjobs; hipStream_t stream = nullptr; hipEvent_t done[2] = { nullptr, nullptr }; hipEvent_t up_done = nullptr; bool pending[2] = { false, false };
                   uvol_devbuf zin, ijobs, dstat; std::vector<InflJob> hij;                                      // device inflate: the compressed streams, their jobs, the statuses
                   int32_t *hstat[2] = { nullptr, nullptr }; size_t hstat_cap[2] = { 0, 0 }; int nstat[2] = { 0, 0 }; };   // per slot: the last call's per-image statuses (pinned)
 int png_create(uvol_ctx *ctx) { ctx->png = new PngState(); return UVOL_OK; }
@@ -403,6 +408,7 @@ void png_destroy(uvol_ctx *ctx) {
   PngState *S = ctx->png; if (!S) return;
   if (S->stream) { (void)hipStreamSynchronize(S->stream); (void)hipStreamDestroy(S->stream); }
   for (hipEvent_t e : S->done) if (e) (void)hipEventDestroy(e);
+  if (S->up_done) (void)hipEventDestroy(S->up_done);
   for (uvol_devbuf *b : { &S->raw, &S->jobs, &S->rgba[0], &S->rgba[1], &S->zin, &S->ijobs, &S->dstat }) if (b->p) (void)hipFree(b->p);
   for (int32_t *h : S->hstat) if (h) (void)hipHostFree(h);
   delete S; ctx->png = nullptr;
@@ -430,6 +436,15 @@ int png_ingest_batch(uvol_ctx *ctx, const uint8_t *const *raw, const size_t *zle
   if ((rc = uvol_ensure(ctx, S->raw, ra * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, S->rgba[slot], obytes * (size_t)n))) return rc;
   if ((rc = uvol_ensure(ctx, S->jobs, sizeof(PngJob) * (size_t)n))) return rc;
+  // the per-image statuses' buffers first (a failing allocation after the kernels were queued returned without recording done[slot], and a
+  // later encode of the slot's layers was not ordered behind them)
+  S->nstat[slot] = 0;
+  if ((rc = uvol_ensure(ctx, S->dstat, 4 * (size_t)n))) return rc;
+  if (S->hstat_cap[slot] < (size_t)n) {
+    if (S->hstat[slot]) { (void)hipEventSynchronize(S->done[slot]); (void)hipHostFree(S->hstat[slot]); S->hstat[slot] = nullptr; S->hstat_cap[slot] = 0; }
+    const size_t c = ((size_t)n + 255) & ~(size_t)255;
+    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&S->hstat[slot], 4 * c, hipHostMallocDefault)); S->hstat_cap[slot] = c;
+  }
   S->hjobs.assign((size_t)n, PngJob{});
   std::vector<UvolUpItem> ups; ups.reserve((size_t)n);
   for (int i = 0; i < n; i++) {
@@ -456,6 +471,13 @@ int png_ingest_batch(uvol_ctx *ctx, const uint8_t *const *raw, const size_t *zle
     if ((rc = uvol_upload_staged(ctx, (uint8_t *)S->raw.p, ups))) return rc;
   }
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(S->jobs.p, S->hjobs.data(), sizeof(PngJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  // "the host buffers may be re-used at once" holds for staged uploads (they have been copied into the pinned buffers) - inputs that all lie
+  // in uvol_host_alloc memory go by DMA from where they lie, so the call waits for those copies (not for the kernels) before it returns
+  bool direct = true; for (const UvolUpItem &it : ups) if (it.bytes && !uvol_host_pinned(it.src, it.bytes)) { direct = false; break; }
+  if (direct) {
+    if (!S->up_done) UVOL_HIP_CHECK(ctx, hipEventCreateWithFlags(&S->up_done, hipEventDisableTiming));
+    UVOL_HIP_CHECK(ctx, hipEventRecord(S->up_done, ctx->stream));
+  }
   if (zlens) {
     uvol_ctx::Scope sc(ctx, "ingest.png_inflate", (uint64_t)rbytes * n);
     if (uvol_debug()) { fprintf(stderr, "[uvol] launch k_inflate\n"); fflush(stderr); }
@@ -466,18 +488,12 @@ int png_ingest_batch(uvol_ctx *ctx, const uint8_t *const *raw, const size_t *zle
     hipLaunchKernelGGL(k_png_unfilter, dim3((unsigned)n), dim3(64), ((size_t)w + 16 * 32) * 4, ctx->stream, (PngJob *)S->jobs.p); }
   UVOL_HIP_CHECK(ctx, hipGetLastError());
   // per-image statuses of this call, for png_status(): packed on the device, copied into the slot's pinned array
-  S->nstat[slot] = 0;
-  if ((rc = uvol_ensure(ctx, S->dstat, 4 * (size_t)n))) return rc;
-  if (S->hstat_cap[slot] < (size_t)n) {
-    if (S->hstat[slot]) { (void)hipEventSynchronize(S->done[slot]); (void)hipHostFree(S->hstat[slot]); S->hstat[slot] = nullptr; S->hstat_cap[slot] = 0; }
-    const size_t c = ((size_t)n + 255) & ~(size_t)255;
-    UVOL_HIP_CHECK(ctx, hipHostMalloc((void **)&S->hstat[slot], 4 * c, hipHostMallocDefault)); S->hstat_cap[slot] = c;
-  }
   hipLaunchKernelGGL(k_png_statuses, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const PngJob *)S->jobs.p, (int32_t *)S->dstat.p, n);
   UVOL_HIP_CHECK(ctx, hipMemcpyAsync(S->hstat[slot], S->dstat.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   S->nstat[slot] = n;
   UVOL_HIP_CHECK(ctx, hipEventRecord(S->done[slot], ctx->stream));
   S->pending[slot] = true;
+  if (direct) UVOL_HIP_CHECK(ctx, hipEventSynchronize(S->up_done));      // (the kernels queued behind the copies run on)
   if (uvol_debug()) UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return UVOL_OK;
 }

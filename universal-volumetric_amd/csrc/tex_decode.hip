@@ -640,14 +640,15 @@ extern "C" int uvol_ktx2_info(const uint8_t *ktx2, size_t len, uint32_t *width, 
   { uint32_t w, h, l; uint64_t lo;                    // UASTC files of this codec (tex_uastc.hip)
     const int pr = uastc_ktx2_probe(ktx2, len, &w, &h, &l, &lo);
     if (pr == 0) { if (width) *width = w; if (height) *height = h; if (layers) *layers = l; return UVOL_OK; }
-    if (pr == UASTC_PROBE_SUPERCOMPRESSED) {               // Zstandard-supercompressed UASTC: the size fields are in the header either way
-      std::vector<uint8_t> plain; const int rz = uastc_unzstd(ktx2, len, plain);
-      if (rz != 0 || uastc_ktx2_probe(plain.data(), plain.size(), &w, &h, &l, &lo) != 0) return UVOL_E_UNSUPPORTED;      // no libzstd here, another scheme, or a corrupt frame
+    if (pr == UASTC_PROBE_SUPERCOMPRESSED) {               // Zstandard-supercompressed UASTC: the size fields are in the header either way (nothing is inflated here)
+      if (uastc_zstd_info(ktx2, len, &w, &h, &l) != 0) return UVOL_E_UNSUPPORTED;      // another scheme, or sizes that contradict each other
       if (width) *width = w; if (height) *height = h; if (layers) *layers = l; return UVOL_OK; } }
   if (tdec_parse(ktx2, len, J)) return UVOL_E_INVALID;
   if (width) *width = J.width; if (height) *height = J.height; if (layers) *layers = J.layers;
   return UVOL_OK;
 }
+
+int tdec_file_alpha(const uint8_t *b, size_t n) { TexDecJob J; memset(&J, 0, sizeof J); if (tdec_parse(b, n, J)) return -1; return J.ashift ? 1 : 0; }
 
 int texdec_create(uvol_ctx *ctx) {
   ctx->texdec = new TexDecState();

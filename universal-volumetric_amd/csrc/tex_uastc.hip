@@ -759,22 +759,39 @@ int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint3
 // the host into an equivalent scheme-0 file (same header / DFD / key-values, level data at a 16-byte aligned offset) that the decoders then
 // take as any other.  0: `out` holds that file; 1: no libzstd on this machine (the caller refuses the file as before); < 0: not such a file /
 // corrupt frame / sizes that do not match the header.
-int uastc_unzstd(const uint8_t *b, size_t n, std::vector<uint8_t> &out) {
-  typedef size_t (*dec_fn)(void *, size_t, const void *, size_t); typedef unsigned (*err_fn)(size_t);
-  static dec_fn dec = nullptr; static err_fn is_err = nullptr;
-  static const bool have = [] {
-    void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL); if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL); if (!h) return false;
-    dec = (dec_fn)dlsym(h, "ZSTD_decompress"); is_err = (err_fn)dlsym(h, "ZSTD_isError"); return dec && is_err; }();
+// header of such a file: sizes and the level's place, checked against each other (no inflation)
+static int uastc_zstd_header(const uint8_t *b, size_t n, uint32_t &w, uint32_t &h, uint32_t &layers, uint64_t &lo, uint64_t &ll, uint64_t &need) {
   if (!b || n < 104 + 44) return -1;
   uint32_t u[9]; memcpy(u, b + 12, 36);
   if (u[0] != 0 || u[8] != 2 || u[7] != 1 || u[6] != 1 || !u[2] || !u[3] || u[2] > 16384 || u[3] > 16384) return -2;      // scheme 2 = Zstandard; 1 level, 1 face
-  uint64_t lo, ll, lu; memcpy(&lo, b + 80, 8); memcpy(&ll, b + 88, 8); memcpy(&lu, b + 96, 8);
-  const uint32_t layers = u[5] ? u[5] : 1;
-  const uint64_t need = (uint64_t)layers * ((u[2] + 3) / 4) * ((u[3] + 3) / 4) * 16;
-  if (layers > 64 || lo < 104 || lo > n || ll > n - lo || lu != need) return -4;
+  uint64_t lu; memcpy(&lo, b + 80, 8); memcpy(&ll, b + 88, 8); memcpy(&lu, b + 96, 8);
+  layers = u[5] ? u[5] : 1; w = u[2]; h = u[3];
+  if (layers > 64) return -4;
+  need = (uint64_t)layers * ((u[2] + 3) / 4) * ((u[3] + 3) / 4) * 16;
+  if (lo < 104 || lo > n || ll > n - lo || lu != need) return -4;
+  return 0;
+}
+// width / height / layers of a Zstandard-supercompressed UASTC file from its header alone (uvol_ktx2_info: nothing is inflated to report a size)
+int uastc_zstd_info(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L) {
+  uint32_t w, h, l; uint64_t lo, ll, need;
+  const int r = uastc_zstd_header(b, n, w, h, l, lo, ll, need); if (r) return r;
+  *W = w; *H = h; *L = l; return 0;
+}
+int uastc_unzstd(const uint8_t *b, size_t n, std::vector<uint8_t> &out) {
+  typedef size_t (*dec_fn)(void *, size_t, const void *, size_t); typedef unsigned (*err_fn)(size_t); typedef unsigned long long (*fcs_fn)(const void *, size_t);
+  static dec_fn dec = nullptr; static err_fn is_err = nullptr; static fcs_fn fcs = nullptr;
+  static const bool have = [] {
+    void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL); if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL); if (!h) return false;
+    dec = (dec_fn)dlsym(h, "ZSTD_decompress"); is_err = (err_fn)dlsym(h, "ZSTD_isError"); fcs = (fcs_fn)dlsym(h, "ZSTD_getFrameContentSize"); return dec && is_err && fcs; }();
+  uint32_t w, h, layers; uint64_t lo, ll, need;
+  const int rh = uastc_zstd_header(b, n, w, h, layers, lo, ll, need); if (rh) return rh;
   if (!have) return 1;
+  // `need` comes from header fields a crafted 150-byte file controls (up to 64 layers x 16384^2 texels = 17 GB): nothing is allocated before
+  // the FRAME says the same size (one-shot ZSTD_compress, which basisu uses, records it), and never more than a Zstandard frame of `ll` bytes can hold
+  const unsigned long long fsz = fcs(b + lo, (size_t)ll);
+  if (fsz != need || need > (uint64_t)ll * 65536ull + 65536ull) return -5;
   const size_t head = (size_t)lo, off = (head + 15) & ~(size_t)15;
-  out.assign(off + (size_t)need, 0);
+  try { out.assign(off + (size_t)need, 0); } catch (...) { out.clear(); return -6; }
   memcpy(out.data(), b, head);
   const size_t got = dec(out.data() + off, (size_t)need, b + lo, (size_t)ll);
   if (is_err(got) || got != need) return -5;

@@ -437,7 +437,7 @@ int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2
   const int n = n_segments;
   const UvolUnzstd Z(ktx2_in, lens_in, n);                  // (Zstandard-supercompressed UASTC files: inflated on the host, see decode_dispatch)
   const uint8_t *const *ktx2 = Z.p.data(); const size_t *lens = Z.l.data();
-  std::vector<int> kind((size_t)n, -1);                    // 0 ETC1S, 1 UASTC
+  std::vector<int> kind((size_t)n, -1);                    // 0 ETC1S opaque, 1 UASTC, 2 ETC1S with alpha slices
   uint32_t W0 = 0, H0 = 0, L0 = 0; bool have = false;
   for (int i = 0; i < n; i++) {
     status[i] = UVOL_E_INVALID;
@@ -451,9 +451,15 @@ int uvol_transcode_texture_segments_st(uvol_ctx *ctx, const uint8_t *const *ktx2
     if (!have) { W0 = w; H0 = h; L0 = l; have = true; }
     else if (w != W0 || h != H0 || l != L0) continue;                       // another shape than the batch's: UVOL_E_INVALID
     if (k == 0 && target == UVOL_TARGET_ASTC) { status[i] = UVOL_E_UNSUPPORTED; continue; }      // (ASTC is the target of UASTC sources only; UASTC sources take every target)
+    // an ETC1S batch is one launch per stage over files of ONE slice layout, so files with alpha slices (what this encoder's own
+    // per-segment alpha re-run writes into an otherwise opaque sequence) are a batch of their own; the opaque targets refuse them in their slot
+    if (k == 0 && tdec_file_alpha(ktx2[i], lens[i]) == 1) {
+      if (target == UVOL_TARGET_ETC1 || target == UVOL_TARGET_BC1) { status[i] = UVOL_E_UNSUPPORTED; continue; }
+      k = 2;
+    }
     kind[i] = k; status[i] = UVOL_OK;
   }
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < 3; k++) {
     std::vector<int> ix; for (int i = 0; i < n; i++) if (kind[i] == k) ix.push_back(i);
     if (ix.empty()) continue;
     std::vector<const uint8_t *> f(ix.size()); std::vector<size_t> ln(ix.size()); std::vector<uint8_t *> o(ix.size() * L0); std::vector<int> st(ix.size(), UVOL_OK);

@@ -260,6 +260,8 @@ int uastc_create(uvol_ctx *ctx);
 void uastc_destroy(uvol_ctx *ctx);
 #define UASTC_PROBE_SUPERCOMPRESSED (-10)      /* a UASTC .ktx2 (DFD colour model 166) whose level data are Zstandard-supercompressed */
 int uastc_ktx2_probe(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L, uint64_t *lvl_off);
+int uastc_zstd_info(const uint8_t *b, size_t n, uint32_t *W, uint32_t *H, uint32_t *L);      // sizes of a Zstandard-supercompressed UASTC file from its header (nothing inflated)
+int tdec_file_alpha(const uint8_t *b, size_t n);          // ETC1S .ktx2: 1 = has alpha slices, 0 = opaque, < 0 = not a file the ETC1S decoder reads (tex_decode.hip)
 int uastc_unzstd(const uint8_t *b, size_t n, std::vector<uint8_t> &out);      // Zstandard-supercompressed UASTC -> the equivalent scheme-0 file (needs the system's libzstd; tex_uastc.hip)
 // the files of a decode / transcode call with every Zstandard-supercompressed UASTC file replaced by its inflated equivalent (kept alive here)
 struct UvolUnzstd {
@@ -269,7 +271,8 @@ struct UvolUnzstd {
       uint32_t w, h, ly; uint64_t lo;
       if (!files[i] || uastc_ktx2_probe(files[i], lens[i], &w, &h, &ly, &lo) != UASTC_PROBE_SUPERCOMPRESSED) continue;
       std::vector<uint8_t> o;
-      if (uastc_unzstd(files[i], lens[i], o) == 0) { keep.push_back(std::move(o)); p[i] = keep.back().data(); l[i] = keep.back().size(); any = true; }
+      try { if (uastc_unzstd(files[i], lens[i], o) == 0) { keep.push_back(std::move(o)); p[i] = keep.back().data(); l[i] = keep.back().size(); any = true; } }
+      catch (...) { }                                    // out of host memory: the file stays supercompressed and is refused in its slot (no exception crosses the C ABI)
     }
   }
 };
