@@ -514,8 +514,8 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     def note(what):                                            # progress on stderr (a fault in a variant is then attributable)
         print("[bench] variant: " + what, file=sys.stderr, flush=True)
         v["in_progress"] = what                                # (stays in the line only if this variant raises)
-    def trim_geos():                                           # a lane's workspace only grows, and the variants below change its shape: back to the device
-        for c in geos:                                         # (uvol_trim; the contexts and their streams stay - fresh contexts measured 13 % slower,
+    def trim_geos(tex_too=False):                              # a lane's workspace only grows, and the variants below change its shape: back to the device
+        for c in geos + (texs if tex_too else []):             # (uvol_trim; the contexts and their streams stay - fresh contexts measured 13 % slower,
             c.trim()                                           #  profiles/r04_d_bench.json against r04_e)
         torch.cuda.empty_cache()
     # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
@@ -568,13 +568,14 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
     # (3) SURVEY 8(d) boundary: inputs in host memory -> bytes in host memory (PCIe inclusive); the device copies of the inputs go first
     note("host_inputs")
     frame_t.clear(); keep.clear(); del dev_meshes[:]
-    trim_geos()                                                # (the host path cuts a call into more groups than the device path)
+    trim_geos(tex_too=True)                                    # (the host path cuts a call into more groups than the device path)
     nh = F                                                     # (1080 until round 3; the host buffers are shared between frames, the device holds the staged copies)
     v["host_inputs"] = dict(Job(nh, host=True).timed(2, 1), note="SURVEY 8(d) boundary: pageable host buffers -> .drc / .ktx2 bytes in host memory, uploads through pinned double buffers; "
                                                                    "one blocking call per pass and half; enqueued_passes: the same passes through uvol_*_async + uvol_sync (a pass uploads while its predecessor encodes)")
     note("host_inputs enqueued")
     v["host_inputs"]["enqueued_passes"] = Job(nh, host=True, host_enqueued=True).timed(3, 1)["frames_per_s"]
     note("host_inputs pinned")
+    trim_geos(tex_too=True)                                    # (the staging path's input buffers on the lanes go back before the uplink's slots are allocated: both do not fit)
     v["host_inputs"]["pinned"] = dict(Job(nh, host=True, pinned=True).timed(2, 1), note="every input array in uvol_host_alloc memory, one blocking call per pass and half: the uploads of the call's groups / parts are queued "
                                                                                          "on the context's copy stream when the call begins (uplink), nothing overlaps the last group's chain")
     note("host_inputs pinned enqueued")

@@ -1097,6 +1097,16 @@ void tex_destroy(uvol_ctx *ctx) {
   }
   delete ctx->tex; ctx->tex = nullptr;
 }
+// uvol_trim: the lanes' device buffers go back to the device (nothing of the context is in flight: tex_flush has run)
+int tex_trim(uvol_ctx *ctx) {
+  TexState *T = ctx->tex; if (!T) return UVOL_OK;
+  for (TexLane &t : T->lane) {
+    if (t.busy) continue;
+    if (t.stream) UVOL_HIP_CHECK(ctx, hipStreamSynchronize(t.stream));
+    for (uvol_devbuf *b : { &t.slab, &t.packed, &t.layers }) if (b->p) { UVOL_HIP_CHECK(ctx, hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+  }
+  return UVOL_OK;
+}
 size_t uvol_texture_bound(uint32_t w, uint32_t h, int n) {
   const size_t nb = (size_t)((w + 3) / 4) * ((h + 3) / 4);
   return 65536 + 6 * (size_t)TEX_MAX_CODEBOOK * 4 + (nb * 16 + 64) * (size_t)(n > 0 ? n : 1);      // 16 bytes per block and layer: the UASTC mode

@@ -297,9 +297,11 @@ int uvol_trim(uvol_ctx *ctx) {
   const int rc = uvol_sync(ctx);
   if (!ctx) return rc;
   const int rf = geo_flush(ctx);
-  const int rt = geo_trim(ctx);
+  const int rx = tex_flush(ctx);
+  int rt = geo_trim(ctx);
+  const int ru = tex_trim(ctx); if (rt == UVOL_OK) rt = ru;
   uvol_uplink_trim(ctx);
-  return rc != UVOL_OK ? rc : (rf != UVOL_OK ? rf : rt);
+  return rc != UVOL_OK ? rc : (rf != UVOL_OK ? rf : (rx != UVOL_OK ? rx : rt));
 }
 
 // defer = the enqueue form: the call's groups are submitted and completed lazily (by the worker when its queue runs empty, or when a

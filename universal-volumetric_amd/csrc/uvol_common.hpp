@@ -283,6 +283,7 @@ int tex_create(uvol_ctx *ctx);
 void tex_destroy(uvol_ctx *ctx);
 int tex_encode_segments(uvol_ctx *ctx, const uint8_t *const *rgba, int n_seg, int n_layers, uint32_t w, uint32_t h,
                         bool inputs_on_device, uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status = nullptr, bool defer = false);
+int tex_trim(uvol_ctx *ctx);       // uvol_trim: the texture lanes' device buffers go back to the device
 int tex_flush(uvol_ctx *ctx);      // completes the parts an enqueued texture call left in flight
 int tex_encode_segment(uvol_ctx *ctx, const uint8_t *const *rgba, int n_layers, uint32_t w, uint32_t h,
                        bool inputs_on_device, uint8_t *out, size_t cap, size_t *out_len);
