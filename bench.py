@@ -35,7 +35,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 I8_PEAK_TOPS = 3944.0        # dense i8 MFMA (16x16x64), MI355X_MICROARCH.md
-PMC_FILE = "r05_pmc_traffic.json"
+PMC_FILE = "r06_final_pmc_traffic.json"
 
 
 def main():

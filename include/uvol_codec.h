@@ -78,16 +78,22 @@ const char *uvol_last_error(const uvol_ctx *ctx);
 /* completes everything enqueued on ctx (uvol_*_async calls and the stream); returns the first error among the enqueued calls */
 int  uvol_sync(uvol_ctx *ctx);
 
-/* Page-locked host memory (round 5; SURVEY 8(d) times the path from "inputs resident in pinned host memory").  The entry points that take
- * HOST arrays copy pageable memory through the library's own pinned double buffers (host threads fill them, ~42 GB/s); arrays that lie in
- * memory from uvol_host_alloc are read by the DMA engines where they are - no staging copy.  It takes effect when EVERY input array of
- * a call lies in such memory; otherwise the call is staged as before.  Process-wide, thread-safe; NULL when the runtime refuses (no
- * device, out of lockable memory).  What a caller of the reference holds at this boundary are files / host buffers
- * (scripts/Encoder.py:244-302): this is where it would read them into. */
+/* Page-locked host memory (SURVEY 8(d) times the path from "inputs resident in pinned host memory").  The entry points that take HOST arrays
+ * copy pageable memory through the library's own pinned double buffers (host threads fill them, ~42 GB/s).  A call whose input arrays ALL lie
+ * in memory from uvol_host_alloc takes the UPLINK instead (round 6): the uploads of all its groups (meshes) / parts (texture segments) are
+ * queued on a copy stream of the context when the call begins, ahead of its kernels, and the encoders' streams wait for them on the device -
+ * no host thread touches the data, and with the enqueue forms (`*_async`) the next call's uploads cross the link while this call encodes.
+ * The device layout mirrors the caller's: arrays that lie back to back in host memory (256-byte aligned, gaps of <= 4 KiB) go over in ONE
+ * copy per run - lay the arrays of a frame, and consecutive frames, next to each other in the arena.
+ * One pageable array and the whole call is staged as before.  Input arrays belong to the call until it completes (blocking forms: until they
+ * return; enqueue forms: until uvol_sync).  The ring of upload slots holds 8 mesh groups / 4 texture parts at most (a slot of 640
+ * 100 k-vertex frames is 6.8 GB; uvol_trim gives them back).  Process-wide registry, thread-safe; NULL when the runtime refuses (no device,
+ * out of lockable memory).  What a caller of the reference holds at this boundary are files / host buffers (scripts/Encoder.py:244-302):
+ * this is where it would read them into. */
 void *uvol_host_alloc(size_t bytes);
 void  uvol_host_free(void *p);
-/* uvol_sync, then the geometry workspaces of ctx go back to the device (they only grow: a context that once ran a 2560-frame call as one
- * group keeps ~130 GB until it is destroyed); its streams stay, the next call allocates what it needs.  No counterpart in the reference
+/* uvol_sync, then the workspaces of ctx - geometry lanes, texture lanes, upload slots - go back to the device (they only grow: a context that
+ * once ran a 2560-frame call as one group keeps ~130 GB until it is destroyed); its streams stay, the next call allocates what it needs.  No counterpart in the reference
  * (its encoders are processes that exit, scripts/Encoder.py:266-302); a long-lived host uses it between jobs of very different sizes. */
 int  uvol_trim(uvol_ctx *ctx);
 
@@ -141,7 +147,8 @@ int uvol_parse_obj_batch_dev(uvol_ctx *ctx, const uint8_t *const *obj_text, cons
  * is used again): rgba_dev_out[i] is what uvol_encode_texture_segments_dev takes.  The inflate stays with the caller (one serial bit
  * stream per file; the files of a batch inflate in parallel on host threads).  Other PNG variants (16-bit, palette, grey, interlaced,
  * wider than 8192): decode them on the host.  The call returns once the kernel is queued on an ingest stream of the context (the host
- * buffers may be re-used at once: they have been staged); the context's texture entry points order themselves behind it, a caller that
+ * buffers may be re-used at once: pageable buffers have been staged, buffers in uvol_host_alloc memory have been read - the call waits for
+ * those copies, not for the kernels); the context's texture entry points order themselves behind it, a caller that
  * reads the layers itself calls uvol_sync(ctx) first.  So the un-filter of batch k + 1 overlaps the encode of batch k. */
 int uvol_unfilter_png_batch_dev(uvol_ctx *ctx, const uint8_t *const *inflated, int n, uint32_t width, uint32_t height, int channels,
                                 int slot, const uint8_t **rgba_dev_out);

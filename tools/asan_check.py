@@ -79,4 +79,22 @@ for it in range(ncorrupt):
     assert st[0] == 0 and st[2] == 0
     ok += st[1] == 0; bad += st[1] != 0
 outcomes["inflate"] = (ok, bad)
+# round 6: inputs in uvol_host_alloc memory travel through the context's uplink (slots on a copy stream, device layout mirroring the caller's
+# arena, slots re-used behind release events, the texture call's deferred last part and its alpha re-run): enqueued calls in a row
+ar = uvol.PinnedArena(64 << 20, lib_path=lib)
+pm = [{k: ar.put(v) for k, v in m.items()} for m in ms[:6]]
+want = got[:6]
+assert cd.encode_mesh_batch(pm) == want
+for _ in range(3): cd.start_mesh_batch(pm)
+assert all(r == want for r in cd.finish())
+segs = [synth.texture_sequence(2, size=40, seed=s_) for s_ in (1, 2, 3)] + [_alpha_sequence(2, 40, 5)]
+wt = [o.ktx2_encode(s_) for s_ in segs]
+ps = [[ar.put(a) for a in s_] for s_ in segs]
+ct = uvol.Codec(lib_path=lib)
+assert ct.encode_texture_segments(ps) == wt
+for _ in range(3): ct.start_texture_segments(ps)
+assert all(r == wt for r in ct.finish())
+ct.trim(); assert ct.encode_texture_segments(ps[:2]) == wt[:2]
+ct.close(); ar.close()
+outcomes["uplink"] = "ok"
 print("asan check passed:", outcomes)
