@@ -518,12 +518,8 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
         for c in geos + (texs if tex_too else []):             # (uvol_trim; the contexts and their streams stay - fresh contexts measured 13 % slower,
             c.trim()                                           #  profiles/r04_d_bench.json against r04_e)
         torch.cuda.empty_cache()
-    # (0) cost of the hipEvent brackets inside the timed region: the same passes without them
-    note("events_off")
-    set_profiling(False)
-    r = Job(F).timed(3, 1)
-    v["events_off"] = dict(r, note="headline workload without the per-group hipEvent brackets (3 passes after 1 warm-up); ms_per_step with them: %.1f" % ms_step,
-                           events_cost_frac=ms_step / r["ms_per_pass"] - 1.0)
+    set_profiling(False)                                       # (the variants run without the per-group hipEvent brackets; an events-off copy of the headline said nothing - a 3-pass run amortises
+                                                               #  the last groups' tail over fewer passes than the headline's 6 and reads 5 % lower with or without events: removed)
     # (1) small jobs (latency-bound: the serial walks of a frame do not shrink with the batch) and the 8-GPU projection of
     #     BASELINE configs[3] (1200 frames, 150 per GPU): 8 x rate(150-frame job) / rate(1200-frame job on one GPU)
     for n in (150, 300, 1200):
