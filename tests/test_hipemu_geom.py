@@ -520,3 +520,49 @@ def test_hipemu_inputs_in_pinned_host_memory(oracle, hipemu_lib):
     tex = synth.texture_sequence(2, size=64, seed=1)
     assert cd.encode_texture_segments([[ar.put(t) for t in tex]]) == cd.encode_texture_segments([tex])
     cd.close(); ar.close()
+
+
+def test_hipemu_uplink_layouts_of_the_callers_arena(oracle, hipemu_lib):
+    """Round 6: the uplink mirrors the caller's arena - arrays back to back (256-byte aligned) travel as one run; arrays at odd offsets, in
+    reverse order, in two separate page-locked allocations or with large gaps between them each start a run of their own.  Whatever the
+    layout, the bytes are the ones the staged path (pageable copies of the same arrays) gives."""
+    import ctypes as C
+    import uvol
+    cd = uvol.Codec(lib_path=hipemu_lib)
+    ms = [m for _, m in _meshes()]
+    want = cd.encode_mesh_batch([{k: np.array(v) for k, v in m.items()} for m in ms])
+    assert want == [oracle.drc_encode(m["pos"], m["idx_pos"], m.get("uv"), m.get("idx_uv"), m.get("nrm"), m.get("idx_nrm")) for m in ms]
+    L = uvol.load(hipemu_lib)
+
+    def arena(nbytes):
+        p = L.uvol_host_alloc(nbytes); assert p
+        return p, (C.c_uint8 * nbytes).from_address(p)
+
+    def put(buf, off, a):
+        a = np.ascontiguousarray(a); v = np.frombuffer(buf, dtype=a.dtype, count=a.size, offset=off).reshape(a.shape); v[...] = a
+        return v, off + a.nbytes
+
+    pa, ba = arena(8 << 20); pb, bb = arena(8 << 20)
+    try:
+        # (1) odd offsets: every array 4 bytes past a 256-byte boundary (never merged, never mis-addressed)
+        off = 0; odd = []
+        for m in ms:
+            f = {}
+            for k, v in m.items():
+                f[k], off = put(ba, ((off + 255) & ~255) + 4, v)
+            odd.append(f)
+        assert cd.encode_mesh_batch(odd) == want
+        # (2) reverse order, the frames' arrays alternating between the two allocations, a 64 KiB gap after every array
+        offs = [0, 0]; rev = []
+        for i, m in enumerate(reversed(ms)):
+            f = {}
+            for j, (k, v) in enumerate(reversed(list(m.items()))):
+                w = (i + j) & 1
+                f[k], offs[w] = put(ba if w == 0 else bb, (offs[w] + 255) & ~255, v); offs[w] += 65536
+            rev.append(f)
+        assert cd.encode_mesh_batch(rev) == list(reversed(want))
+        for _ in range(2):
+            cd.start_mesh_batch(rev)
+        assert cd.finish() == [list(reversed(want))] * 2
+    finally:
+        cd.close(); L.uvol_host_free(pa); L.uvol_host_free(pb)
