@@ -608,9 +608,12 @@ def test_hipemu_uplink_pinned_inputs_groups_parts_and_slot_reuse(oracle, hipemu_
         "cd.trim(); assert cd.encode_mesh_batch(pm) == want_g\n"                                      # the slots' buffers were given back
         "cd.close(); ct.close(); ar.close(); print('uplink ok')\n"
     ) % (os.path.join(ROOT, "universal-volumetric_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), hipemu_lib)
-    for extra in ({}, {"UVOL_UPLINK": "0"}):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_TEX_PART="1", UVOL_GEO_MIN_GROUP="1", **extra), capture_output=True, text=True, timeout=1500)
-        assert r.returncode == 0 and "uplink ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-3000:])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UVOL_TEX_PART="1", UVOL_GEO_MIN_GROUP="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "uplink ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    # UVOL_UPLINK=0 (round 5's in-submission copies, kept as a diagnostic): one call of each kind
+    code0 = code.split("for _ in range(3): cd.start_mesh_batch(pm)")[0] + "tex = synth.texture_sequence(2, size=32, seed=1); assert ct.encode_texture_segments([[ar.put(a) for a in tex]]) == [O.ktx2_encode(tex)]\ncd.close(); ct.close(); ar.close(); print('uplink ok')\n"
+    r = subprocess.run([sys.executable, "-c", code0], env=dict(os.environ, UVOL_GEO_MIN_GROUP="1", UVOL_UPLINK="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "uplink ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
 def test_hipemu_advice_r5_status_forms_and_crafted_headers(oracle, hipemu_lib):

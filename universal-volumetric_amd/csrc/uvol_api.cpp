@@ -268,8 +268,8 @@ void uvol_ctx_destroy(uvol_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->resolve_profile();
-  uvol_uplink_destroy(ctx);
-  geo_destroy(ctx); tex_destroy(ctx); texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx); png_destroy(ctx);
+  geo_destroy(ctx); tex_destroy(ctx); uvol_uplink_destroy(ctx);      // (the lanes' streams are synchronised and gone before the slots they read are freed)
+  texdec_destroy(ctx); geodec_destroy(ctx); uastc_destroy(ctx); obj_destroy(ctx); png_destroy(ctx);
   for (int k = 0; k < 2; k++) { if (ctx->up_pin[k]) (void)hipHostFree(ctx->up_pin[k]); if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]); }
   for (int k = 0; k < 2; k++) if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
   for (int k = 0; k < 2; k++) { if (ctx->dn_pin[k]) (void)hipHostFree(ctx->dn_pin[k]); if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]); }
