@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: hand the C ABI host buffers (never the headline value)")
     ap.add_argument("--host-pinned", action="store_true", help="with --host-inputs: the input arrays lie in uvol_host_alloc (page-locked) memory")
     ap.add_argument("--host-enqueued", action="store_true", help="with --host-inputs: the passes go through the enqueue forms (uvol_*_async on host buffers, one uvol_sync)")
+    ap.add_argument("--tex-enqueued", type=int, default=0, help="1: the texture passes of a device-input job go through uvol_encode_texture_segments_dev_async + one uvol_sync (a pass's last two parts stay in flight beside the next pass's first); DIAGNOSTIC: measured 3534 - 3540 against 3463 - 3592 frames/s, inside the scatter - the texture context is not the critical path")
     ap.add_argument("--background", choices=["off", "h2d_16m", "h2d_256m", "d2d"], default="off",
                     help="DIAGNOSTIC (profiles/r06_uplink_forms.json): a host thread keeps copying during the timed steps - page-locked host memory to the device in copies of 16 MiB "
                          "(the runtime's blit kernel) or 256 MiB (its SDMA engines), or device to device at about the link's rate - to see what an upload does to the encoders beside it")
@@ -284,6 +285,14 @@ def main():
                     errors.append(e)
 
             def loop(fn, arg, kk):
+                if args.tex_enqueued and fn == self.run_tex and not self.host and not self.blocking:      # device inputs through the enqueue form
+                    segs = range(arg, self.nseg, len(texs))
+                    if len(segs):
+                        pl = [p_ for s_ in segs for p_ in tex_seg_ptrs[s_ * B:(s_ + 1) * B]]
+                        for k_ in range(kk):
+                            texs[arg].start_texture_segments_dev(pl, B, args.tex_size, args.tex_size, slot=k_ & 1)
+                        out["ktx2_%d" % arg] = texs[arg].finish()[-1]
+                        return
                 if self.host_enqueued and fn == self.run_tex:            # texture share of a host-input job, enqueued like the geometry share
                     segs = range(arg, self.nseg, len(texs))
                     if len(segs):

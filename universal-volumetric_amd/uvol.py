@@ -326,6 +326,18 @@ class Codec:
             raise UvolError(f"encode_texture_segments_async rc={rc}: {self.error()}")
         self._pending = getattr(self, "_pending", []) + [("tex" if slot is None else "tex_views", nseg, bufs, lens, None, flat, ptrs)]
 
+    def start_texture_segments_dev(self, dev_ptrs, n_layers, width, height, slot=0):
+        """Enqueues uvol_encode_texture_segments_dev_async for a flat list of n_segments * n_layers DEVICE pointers; output buffers of `slot`
+        are re-used, finish() returns numpy views."""
+        ptrs = (C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs]); nseg = len(dev_ptrs) // n_layers
+        cap = self.L.uvol_texture_bound(width, height, n_layers)
+        bufs = self._tex_bufs(("dev", slot), nseg, cap)
+        outs = (C.c_void_p * nseg)(*[b.ctypes.data for b in bufs[:nseg]]); caps = (C.c_size_t * nseg)(*([cap] * nseg)); lens = (C.c_size_t * nseg)()
+        rc = self.L.uvol_encode_texture_segments_dev_async(self.h, ptrs, nseg, n_layers, width, height, outs, caps, lens)
+        if rc != UVOL_OK:
+            raise UvolError(f"encode_texture_segments_dev_async rc={rc}: {self.error()}")
+        self._pending = getattr(self, "_pending", []) + [("tex_views", nseg, bufs, lens, None, None, ptrs)]
+
     def trim(self):
         """uvol_trim: completes the context's work and gives its geometry workspaces back to the device (streams stay)."""
         rc = self.L.uvol_trim(self.h)
