@@ -82,6 +82,7 @@ struct GeoState {
   WsPlanCache plan; std::vector<WsItem> items;     // workspace placements by frame shape
   size_t max_lds = 64 * 1024;
   int num_cu = 256;                    // CUs this context's streams may run on
+  bool blocking_call = false;          // the group being submitted belongs to a BLOCKING call (geo_encode_batch): nothing else of this context runs beside it
   bool compact_ok = true;              // the last group was all clean, coherently stored frames: the next one starts in the compact layout (geo_submit_impl)
 };
 static void geo_lane_free(GeoLane *L) {
@@ -868,7 +869,10 @@ static int geo_submit_impl(uvol_ctx *ctx, GeoLane &L, const uvol_mesh *meshes, i
     // CU instead of 3), the vertex bitmap lives in L2; each walker is ~30 % slower, twice as many are resident
     // unrelated meshes: FOUR traversers per wave in the wave form (3207 / 3774 / 4036 / 4060 / 3927 / 3780 frames/s geometry alone on two lanes with the lane
     // form at 1 and the wave form at 1 / 2 / 4 / 8 / 16 per wave, 2560 distinct frames: profiles/r05_walker_forms.json)
-    if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = fmtT == 2 ? 4 : 1;
+    // round 6: fewer per wave while the traversers of everything on the chip are few enough to have a SIMD (almost) to themselves - 1 / 2 / 4 per wave up to
+    // 2048 / 4096 / more traversers: a 600-frame job 135 / 141 / 149 ms (1514 / 1490 / 1442 frames/s), a 300-frame job 122 / 125 / 127 ms (profiles/r06_small_job_forms.json)
+    // (blocking calls only: enqueued calls run beside their predecessors' groups - a stream of 300-frame jobs lost 4 % with one per wave)
+    if (wp_trav.simt_w > 1 && !lockstep && geo_simt_env() == 0) wp_trav.simt_w = fmtT == 2 ? ((G->blocking_call && 3u * NC <= 2048u) ? 1 : ((G->blocking_call && 3u * NC <= 4096u) ? 2 : 4)) : 1;
     if (w_trav_env && wp_trav.simt_w) wp_trav.simt_w = w_trav_env;
     launch_traversals(ctx, dj, n, wp_trav, fmtT, base_shared ? 1 : 0);
   }
@@ -1161,7 +1165,9 @@ int geo_encode_batch_dev_out(uvol_ctx *ctx, const uvol_mesh *meshes, int n, hipS
 // blocking form: begin + flush
 int geo_encode_batch(uvol_ctx *ctx, const uvol_mesh *meshes, int n, bool on_device,
                      uint8_t *const *outs, const size_t *caps, size_t *out_lens, int *status) {
+  ctx->geo->blocking_call = true;
   const int rc = geo_encode_batch_begin(ctx, meshes, n, on_device, outs, caps, out_lens, status, !on_device);
+  ctx->geo->blocking_call = false;
   const int rf = geo_flush(ctx);
   return rc != UVOL_OK ? rc : rf;
 }
