@@ -320,7 +320,9 @@ typedef struct uvol_decoded_mesh {
 } uvol_decoded_mesh;
 /* host-only: face count of a .drc and the value count that always suffices (UVOL_E_INVALID for foreign data) */
 int uvol_drc_info(const uint8_t *drc, size_t len, uint32_t *n_faces, uint32_t *max_values);
-/* n frames, one kernel launch per stage; status[i] per frame (may be NULL) */
+/* n frames, one kernel launch per stage; status[i] per frame (may be NULL).  The arrays of `out` are caller-owned host memory: pageable arrays
+ * are filled through the library's pinned double buffers (host threads copy out of them); arrays that ALL lie in uvol_host_alloc memory are
+ * written by the DMA engines where they are (round 6: no staging, no host copy of the 10.5 MB a 100 k-vertex frame decodes to). */
 int uvol_decode_mesh_batch(uvol_ctx *ctx, const uint8_t *const *drc, const size_t *lens, int n, uvol_decoded_mesh *out, int *status);
 /* Same with the buffers of `out` in HBM (device pointers): the decoded arrays stay on the device - what a GPU-resident consumer
  * (a renderer's vertex buffers, or uvol_encode_mesh_batch_dev[_out] re-encoding them) reads without a host round trip.  The .drc

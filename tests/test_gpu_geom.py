@@ -157,6 +157,15 @@ def test_gpu_mesh_roundtrip_at_bench_size(oracle, gpu_codec):
     data = gpu_codec.encode_mesh(**m)
     d = gpu_codec.decode_mesh_batch([data])[0]
     _check_decoded(oracle, data, d)
+    # round 6: the same frame (x 40: a staged download would need its pinned buffers) with the output arrays in uvol_host_alloc memory -
+    # written by the DMA engines where they lie, equal to the staged results
+    import uvol
+    ar = uvol.PinnedArena(40 * (11 << 20))
+    try:
+        for dp in gpu_codec.decode_mesh_batch([data] * 40, views=True, arena=ar):
+            assert all(np.array_equal(dp[k], d[k]) for k in ("pos", "uv", "nrm", "idx_pos", "idx_uv", "idx_nrm"))
+    finally:
+        gpu_codec.__dict__.pop("_dec_bufs_pinned", None); ar.close()
     nf = len(m["idx_pos"]) // 3
     assert d["n_faces"] == nf
     step = float((m["pos"].max(0) - m["pos"].min(0)).max()) / (2 ** 11 - 1)

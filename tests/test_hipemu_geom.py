@@ -372,9 +372,15 @@ def test_hipemu_mesh_decode_matches_oracle(oracle, hipemu_lib):
     files += [open(os.path.join(GOLDEN, n), "rb").read() for n in ("00000.drc", "00075.drc")]
     for data, got in zip(files, cd.decode_mesh_batch(files)):
         _check_decoded(oracle, data, got)
+    # round 6: output arrays in uvol_host_alloc memory are written by the DMA engines where they lie (no staging buffers) - same arrays
+    ar = uvol.PinnedArena(96 << 20, lib_path=hipemu_lib)
+    for data, got in zip(files, cd.decode_mesh_batch(files, views=True, arena=ar)):
+        _check_decoded(oracle, data, got)
+    for data, got in zip(files[:3], cd.decode_mesh_batch(files[:3], views=True, arena=ar)):      # the kept arrays again
+        _check_decoded(oracle, data, got)
     with pytest.raises(uvol.UvolError):
         cd.decode_mesh_batch([files[0][:40]])
-    cd.close()
+    cd.close(); ar.close()
 
 
 def test_hipemu_decoder_corrects_a_header_that_lies_about_the_vertex_count(oracle, hipemu_lib):

@@ -525,6 +525,20 @@ static inline int uvol_download_staged(uvol_ctx *ctx, const std::vector<UvolDnIt
   size_t total = 0; for (const UvolDnItem &it : items) total += it.bytes;
   const size_t CH = (size_t)128 << 20;
   bool big = false; for (const UvolDnItem &it : items) big = big || it.bytes > CH;
+  // Outputs that ALL lie in uvol_host_alloc memory (round 6): the DMA engines write them where the caller wants them - no pinned staging buffer,
+  // no host thread copying 10.5 MB per decoded frame out of it (the staged form's limit: ~20 GB/s of memcpy into pageable memory).  Arrays that
+  // are contiguous on both sides go as one copy.
+  { bool all = !items.empty(); for (const UvolDnItem &it : items) if (it.bytes && !uvol_host_pinned(it.dst, it.bytes)) { all = false; break; }
+    if (all) {
+      for (size_t i = 0; i < items.size();) {
+        size_t len = items[i].bytes, j = i + 1;
+        for (; j < items.size(); j++) { if ((const uint8_t *)items[j].src != (const uint8_t *)items[i].src + len || (uint8_t *)items[j].dst != (uint8_t *)items[i].dst + len || len + items[j].bytes > ((size_t)512 << 20) || !uvol_host_pinned(items[i].dst, len + items[j].bytes)) break; len += items[j].bytes; }
+        if (len) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(items[i].dst, items[i].src, len, hipMemcpyDeviceToHost, ctx->stream));
+        i = j;
+      }
+      UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      return UVOL_OK;
+    } }
   if (total < ((size_t)4 << 20) || big) {                                  // small calls (or one huge array): the runtime's own path
     for (const UvolDnItem &it : items) if (it.bytes) UVOL_HIP_CHECK(ctx, hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, ctx->stream));
     UVOL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -118,6 +118,14 @@ class PinnedArena:
         v[...] = a; self.off = o + nb
         return v
 
+    def take(self, shape, dtype):
+        """An uninitialised array of this shape in the arena (256-byte aligned)."""
+        dt = np.dtype(dtype); cnt = int(np.prod(shape)); nb = cnt * dt.itemsize; o = (self.off + 255) & ~255
+        if o + nb > self.n:
+            raise UvolError("pinned arena full")
+        self.off = o + nb
+        return np.frombuffer(self.buf, dtype=dt, count=cnt, offset=o).reshape(shape)
+
     def close(self):
         if getattr(self, "p", None):
             self.buf = None; self.L.uvol_host_free(self.p); self.p = None
@@ -553,20 +561,23 @@ class Codec:
             raise UvolError(f"decode_texture_segments_dev rc={rc}: {self.error()}")
 
     # ---- decode path (geometry half) ----
-    def decode_mesh_batch(self, files, raise_on_error=True, fetch=True, views=False):
+    def decode_mesh_batch(self, files, raise_on_error=True, fetch=True, views=False, arena=None):
         """files: list of .drc bytes -> list of dicts {pos [n,3], uv [n,2], nrm [n,3] float32 in decoding order,
-        idx_pos / idx_uv / idx_nrm [3*faces] uint32 entry index per corner}; absent attributes are None."""
+        idx_pos / idx_uv / idx_nrm [3*faces] uint32 entry index per corner}; absent attributes are None.
+        arena (a PinnedArena, with views=True): the output arrays are carved from it - outputs that all lie in uvol_host_alloc memory are written
+        by the DMA engines where they are, without the library's staging buffers."""
         files = [bytes(f) for f in files]; n = len(files)
         metas = (DecodedMesh * n)(); keep = []
-        pool = self.__dict__.setdefault("_dec_bufs", []) if views else None      # views=True: the arrays are kept and re-used by the next call
+        pool = self.__dict__.setdefault("_dec_bufs_pinned" if arena is not None else "_dec_bufs", []) if views else None      # views=True: the arrays are kept and re-used by the next call
+        mk = (lambda shape, dt: arena.take(shape, dt)) if arena is not None else (lambda shape, dt: np.empty(shape, dt))
         for i, f in enumerate(files):
             nf, mv = C.c_uint32(), C.c_uint32()
             if self.L.uvol_drc_info(f, len(f), C.byref(nf), C.byref(mv)) != UVOL_OK:
                 raise UvolError(f"frame {i}: not a .drc this decoder handles")
             a = pool[i] if (pool is not None and i < len(pool) and pool[i]["idx_pos"].size >= 3 * nf.value and pool[i]["pos"].shape[0] >= mv.value) else None
             if a is None:
-                a = dict(pos=np.empty((mv.value, 3), np.float32), uv=np.empty((mv.value, 2), np.float32), nrm=np.empty((mv.value, 3), np.float32),
-                         idx_pos=np.empty(3 * nf.value, np.uint32), idx_uv=np.empty(3 * nf.value, np.uint32), idx_nrm=np.empty(3 * nf.value, np.uint32))
+                a = dict(pos=mk((mv.value, 3), np.float32), uv=mk((mv.value, 2), np.float32), nrm=mk((mv.value, 3), np.float32),
+                         idx_pos=mk((3 * nf.value,), np.uint32), idx_uv=mk((3 * nf.value,), np.uint32), idx_nrm=mk((3 * nf.value,), np.uint32))
                 if pool is not None:
                     if i < len(pool):
                         pool[i] = a
