@@ -613,7 +613,7 @@ def run_variants(v, args, Job, set_profiling, frame_t, meshes_h, tex_h, out, geo
         t = time.perf_counter(); d.decode_mesh_batch(drc[:nhd], views=True); dt = time.perf_counter() - t
         v["decode_mesh"]["to_host_memory"] = {"frames_per_s": nhd / dt, "frames": nhd}
         d.__dict__.pop("_dec_bufs", None)
-        ar_ = uvol.PinnedArena(nhd * (11 << 20))              # ... and with the caller's arrays in uvol_host_alloc memory: no staging buffers, no host copy
+        ar_ = uvol.PinnedArena(d.decode_arena_bytes(drc[:nhd]))              # ... and with the caller's arrays in uvol_host_alloc memory: no staging buffers, no host copy
         d.decode_mesh_batch(drc[:nhd], views=True, arena=ar_)
         t = time.perf_counter(); d.decode_mesh_batch(drc[:nhd], views=True, arena=ar_); dt = time.perf_counter() - t
         v["decode_mesh"]["to_pinned_host_memory"] = {"frames_per_s": nhd / dt, "frames": nhd}

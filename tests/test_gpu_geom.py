@@ -160,7 +160,7 @@ def test_gpu_mesh_roundtrip_at_bench_size(oracle, gpu_codec):
     # round 6: the same frame (x 40: a staged download would need its pinned buffers) with the output arrays in uvol_host_alloc memory -
     # written by the DMA engines where they lie, equal to the staged results
     import uvol
-    ar = uvol.PinnedArena(40 * (11 << 20))
+    ar = uvol.PinnedArena(gpu_codec.decode_arena_bytes([data] * 40))
     try:
         for dp in gpu_codec.decode_mesh_batch([data] * 40, views=True, arena=ar):
             assert all(np.array_equal(dp[k], d[k]) for k in ("pos", "uv", "nrm", "idx_pos", "idx_uv", "idx_nrm"))

@@ -16,7 +16,7 @@ t = time.time(); res = c.decode_mesh_batch(files, fetch=False); dt = time.time()
 c.profile(False)
 c.decode_mesh_batch(files, views=True)            # allocates (and touches) the host arrays of the whole batch
 t = time.time(); res2 = c.decode_mesh_batch(files, views=True); dt2 = time.time() - t      # arrays re-used: what a host that keeps its buffers sees
-ar = uvol.PinnedArena(n * (11 << 20))               # ... and what one sees whose arrays lie in uvol_host_alloc memory (DMA writes them where they are)
+ar = uvol.PinnedArena(c.decode_arena_bytes(files))               # ... and what one sees whose arrays lie in uvol_host_alloc memory (DMA writes them where they are)
 c.decode_mesh_batch(files, views=True, arena=ar)
 t = time.time(); res3 = c.decode_mesh_batch(files, views=True, arena=ar); dt3 = time.time() - t
 print(json.dumps(dict(frames=n, frames_per_s_with_fetch_to_pinned_host_arrays=n / dt3, drc_bytes=len(files[0]), wall_s=dt, frames_per_s=n / dt, frames_per_s_with_fetch_to_host=n / dt2, groups={g["name"]: round(g["total_ms"], 1) for g in c.profile_report()})))

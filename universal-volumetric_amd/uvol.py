@@ -561,6 +561,17 @@ class Codec:
             raise UvolError(f"decode_texture_segments_dev rc={rc}: {self.error()}")
 
     # ---- decode path (geometry half) ----
+    def decode_arena_bytes(self, files):
+        """Bytes of a PinnedArena that holds the output arrays of decode_mesh_batch(files, arena=...): capacities by uvol_drc_info (the counts
+        are not known before the decode: 3 x faces values per attribute at most)."""
+        tot = 0
+        for f in files:
+            nf, mv = C.c_uint32(), C.c_uint32()
+            if self.L.uvol_drc_info(bytes(f), len(f), C.byref(nf), C.byref(mv)) != UVOL_OK:
+                raise UvolError("not a .drc this decoder handles")
+            tot += mv.value * 32 + 3 * nf.value * 12 + 6 * 256
+        return tot + 4096
+
     def decode_mesh_batch(self, files, raise_on_error=True, fetch=True, views=False, arena=None):
         """files: list of .drc bytes -> list of dicts {pos [n,3], uv [n,2], nrm [n,3] float32 in decoding order,
         idx_pos / idx_uv / idx_nrm [3*faces] uint32 entry index per corner}; absent attributes are None.
