@@ -13,7 +13,14 @@ region ends when every .drc / .ktx2 byte is in host memory.
   python bench.py --gpus N --total-frames 1200 ...                    # STRONG scaling (BASELINE configs[3]): ONE job of that many
                                                                       # frames, split over the ranks by shard.plan; a step = the job
 
-The only collective is the final 32-byte-per-rank manifest gather, over RCCL.
+`value` is quoted with the inputs resident in HBM when the timed region starts - the bench contract's rule for this tier ("if the boundary hands over
+host buffers, note the PCIe-inclusive rate - it is never `value`").  The SAME line carries, as top-level keys, what the SURVEY §8(d) boundary gives
+(`survey_8d_boundary_frames_per_s`: pinned / pageable host memory through the blocking and the enqueue forms, and what the link allows for the bytes
+the ABI takes) and BASELINE configs[2]'s own 300-frame job (`configs2_job_300_frames_per_s`).
+
+`--gpus N` is the rank count: without a launcher `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run on 127.0.0.1); under one,
+WORLD_SIZE and the process group's size must equal it or the run exits non-zero.  The only collective is the final 32-byte-per-rank manifest gather
+(SURVEY §8e), over RCCL.
 On one GPU the line also carries `variants` (never `value`): the same path on the SURVEY §8(d) boundary (host buffers), as small
 jobs (150 / 300 / 1200 frames -> the 8-GPU projection of configs[3]), on a scan-like storage order, and the decode path
 (configs[4]); `--no-variants` skips them.
