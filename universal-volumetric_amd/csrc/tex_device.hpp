@@ -103,6 +103,18 @@ __device__ inline uint32_t t_eval_block(const uint32_t px[16], int c5r, int c5g,
     // form below, for 17 instead of 36 operations per texel.
     const int d0 = t_inten(t, 0), d1 = t_inten(t, 1), d2 = t_inten(t, 2), d3 = t_inten(t, 3);
     const int lo = br < bg ? (br < bb ? br : bb) : (bg < bb ? bg : bb), hi = br > bg ? (br > bb ? br : bb) : (bg > bb ? bg : bb);
+    if (!WANT_SEL && lo + d0 >= 0 && hi + d3 <= 255) {
+      // totals only (k_tex_fit; round 6): the tables are symmetric (d = -hi, -lo, lo, hi), so the best selector's error is
+      // A + min(3 hi^2 - hi |B2|, 3 lo^2 - lo |B2|) - the same integer as the four-way minimum below, without the selector bookkeeping
+      const int kh = 3 * d3 * d3, kl = 3 * d2 * d2;
+      for (int i = 0; i < 16; i++) {
+        const int er = br - (int)(px[i] & 255), eg = bg - (int)((px[i] >> 8) & 255), eb = bb - (int)((px[i] >> 16) & 255);
+        const int A = er * er + eg * eg + eb * eb, B2 = 2 * (er + eg + eb), ab = B2 < 0 ? -B2 : B2;
+        const int a = kh - d3 * ab, b = kl - d2 * ab;
+        tot += (uint32_t)(A + (a < b ? a : b));
+      }
+      return tot;
+    }
     if (lo + d0 >= 0 && hi + d3 <= 255) {
       const int k0 = 3 * d0 * d0, k1 = 3 * d1 * d1, k2 = 3 * d2 * d2, k3 = 3 * d3 * d3;
       for (int i = 0; i < 16; i++) {
